@@ -1,0 +1,100 @@
+"""ctypes binding of libe3dge_hip.so (the C-ABI declared in include/e3dge_hip.h).
+
+The library is built in-tree by `build.py` (hipcc --offload-arch=gfx950) and shipped next to this file; it is
+loaded lazily on first use.  Nothing here falls back to another implementation: a missing library or a
+failing call raises RuntimeError."""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libe3dge_hip.so")
+ABI_VERSION = 1
+
+_c_float_p = ctypes.c_void_p     # device pointers travel as integers
+_i32, _i64, _f32, _vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class RenderArgs(ctypes.Structure):
+    """Mirror of struct E3dgeRenderArgs (include/e3dge_hip.h)."""
+    _fields_ = [
+        ("packed", _vp), ("film", _vp), ("c2w", _vp), ("focal", _vp), ("near", _vp), ("far", _vp),
+        ("t_vals", _vp), ("tex_alpha", _vp), ("tex_beta", _vp),
+        ("sigmoid_beta", _f32), ("box_scale", _f32), ("mask_depth_thresh", _f32),
+        ("batch", _i32), ("height", _i32), ("width", _i32), ("n_samples", _i32),
+        ("res", _i32), ("force_background", _i32),
+        ("rgb", _vp), ("features", _vp), ("xyz", _vp), ("depth", _vp), ("mask", _vp), ("sdf", _vp),
+        ("weights", _vp), ("points", _vp), ("rays_d", _vp), ("viewdirs", _vp), ("dists", _vp),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/e3dge_hip.h declares.
+SIGNATURES = {
+    "e3dge_abi_version": (_i32, []),
+    "e3dge_last_error": (ctypes.c_char_p, []),
+    "e3dge_fused_bias_act": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _i64, _i64, _i64, _vp]),
+    "e3dge_noise_bias_act": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i64, _i64, _i64, _vp]),
+    "e3dge_upfirdn2d": (_i32, [_vp, _vp, _vp, _i64] + [_i32] * 12 + [_vp]),
+    "e3dge_upfirdn2d_out_size": (_i32, [_i32] * 6),
+    "e3dge_modconv_weights": (_i32, [_vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "e3dge_siren_packed_floats": (_i64, []),
+    "e3dge_siren_pack_weights": (_i32, [_vp] * 11 + [_vp]),
+    "e3dge_film_params": (_i32, [_vp] * 6 + [_i32, _vp]),
+    "e3dge_siren_render_fwd": (_i32, [ctypes.POINTER(RenderArgs), _vp]),
+    "e3dge_siren_points_fwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _i64, _vp, _vp, _vp]),
+    "e3dge_selftest_mfma": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "e3dge_selftest_sin": (_i32, [_vp, _vp, _i32, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library is absent or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no fallback implementation.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)     # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        got = lib.e3dge_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"libe3dge_hip.so ABI {got} != expected {ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().e3dge_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t):
+    """The current HIP stream of the tensor's device, as the void* the C-ABI wants."""
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def require_gpu(t, name):
+    import torch
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise RuntimeError(f"{name} must be a GPU (HIP) tensor; this build has no CPU path "
+                           f"(got {getattr(t, 'device', type(t))})")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 (got {t.dtype})")

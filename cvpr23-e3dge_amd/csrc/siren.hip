@@ -1,0 +1,894 @@
+// Fused FiLM-SIREN volume renderer for gfx950 (MI355X): ray generation -> sample placement -> 9 FiLM
+// sine layers -> sdf / rgb heads -> SDF->alpha -> transmittance scan -> composites, in ONE kernel.
+//
+// Reference path being replaced (all in project/utils/volume_renderer.py):
+//   get_rays :769-794, render :1666-1701, render_rays :1183-1287, run_network :1052-1128,
+//   FiLMSiren.forward :116-132, SirenGenerator.forward :168-264, volume_integration :809-943.
+//
+// Design (see DESIGN.md for the numbers)
+//   * The MLP is a dense fp32 contraction (526,848 MAC per point) -> it runs on v_mfma_f32_32x32x2_f32.
+//   * One workgroup = 4 waves = one wave per SIMD (the kernel wants ~400 of the 512 unified registers).
+//     A wave owns 32 points and keeps their 256-wide activation ENTIRELY IN REGISTERS across all layers:
+//     the MFMA C/D fragment of layer L (rows = features, cols = points) has exactly the lane structure of
+//     a B operand (k on lane>>5, column on lane&31), so layer L's accumulators feed layer L+1's MFMAs with
+//     no shuffle, no LDS round trip and no HBM traffic.  K is consumed in the fragment's own k order.
+//   * Weights are re-laid once (e3dge_siren_pack_weights) into the lane-linear A-fragment image and are
+//     streamed L2 -> LDS with global_load_lds (16 B/lane) in 32-KiB chunks (one 32-feature output tile x
+//     K=256), triple buffered; the 4 waves of a workgroup share each chunk (ds_read_b128, conflict-free
+//     by construction because the image is lane-linear).
+//   * The last (view) layer is evaluated TRANSPOSED (activations as the A operand, weights as B) so its
+//     output has features on lanes and points on registers: the feature composite sum_s w_s * f_s becomes
+//     16 FMAs per lane instead of a cross-lane reduction.
+//   * Transmittance is a sequential front-to-back scan per ray (same order as torch.cumprod), carried in
+//     LDS across the 128-point sub-tiles of a workgroup's ray block, so rays x samples can be tiled
+//     without aligning rays to tiles.
+#include "common.h"
+
+namespace e3dge {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWidth = E3DGE_SIREN_WIDTH;       // 256
+constexpr int kNT = kWidth / 32;                // 8 output tiles of 32 features
+constexpr int kChunkFloats = 32 * kWidth;       // one output tile x K=256 : 8192 floats = 32 KiB
+constexpr int kBigLayers = 8;                   // pts_linears.1..7 + views_linears[:, :256]
+constexpr int kChunksPerPass = kBigLayers * kNT;  // 64 chunks = 2 MiB per 128-point sub-tile
+constexpr int kNBuf = 3;                        // LDS weight buffers
+constexpr int kTilePts = 128;                   // points per sub-tile (4 waves x 32)
+constexpr int kThreads = 256;
+constexpr int kRMax = 16;                       // max rays per workgroup (LDS feature accumulators)
+constexpr int kFPitch = kWidth + 1;             // padded pitch of the feature accumulators
+constexpr int kMaxSlots = 3;                    // rays a 32-point slab can touch when S >= 16
+constexpr int kMinSamples = 16;
+
+// ---- packed weight image (floats) ----
+constexpr int64_t kOffBig = 0;                                       // [8 layers][8 t][8 c][4 q][64 lane][4]
+constexpr int64_t kOffFirst = kOffBig + (int64_t)kChunksPerPass * kChunkFloats;   // [8 t][2][64]
+constexpr int64_t kOffVTail = kOffFirst + kNT * 2 * 64;              // [8 t][2][64]
+constexpr int64_t kOffBias = kOffVTail + kNT * 2 * 64;               // [9][256]
+constexpr int64_t kOffWSigma = kOffBias + 9 * kWidth;                // [256]
+constexpr int64_t kOffWRgb = kOffWSigma + kWidth;                    // [3][256]
+constexpr int64_t kOffBHead = kOffWRgb + 3 * kWidth;                 // b_sigma, b_rgb[3]
+constexpr int64_t kPackedFloats = kOffBHead + 4;
+
+// ---- LDS carve (floats) ----
+constexpr int kLdsW = 0;
+constexpr int kLdsFilm = kLdsW + kNBuf * kChunkFloats;               // [9][2][256] gamma/beta of this image
+constexpr int kLdsHead = kLdsFilm + 9 * 2 * kWidth;                  // w_sigma[256], w_rgb[3][256], b_sigma, b_rgb[3]
+constexpr int kHeadFloats = 4 * kWidth + 4;
+constexpr int kLdsFeat = kLdsHead + kHeadFloats;                     // [kRMax][kFPitch]
+constexpr int kLdsPart = kLdsFeat + kRMax * kFPitch;                 // [4][kMaxSlots][256]
+constexpr int kLdsAlpha = ((kLdsPart + 4 * kMaxSlots * kWidth + 3) / 4) * 4;   // [128]
+constexpr int kLdsWgt = kLdsAlpha + kTilePts;                        // [128]
+constexpr int kLdsZ = kLdsWgt + kTilePts;                            // [128]
+constexpr int kLdsPts = kLdsZ + kTilePts;                            // [128][3]
+constexpr int kLdsRgb = kLdsPts + kTilePts * 3;                      // [128][3]
+constexpr int kLdsState = kLdsRgb + kTilePts * 3;                    // [kRMax][12]: T, wsum, depth, xyz3, rgb3
+constexpr int kStateStride = 12;
+constexpr int kLdsFloats = kLdsState + kRMax * kStateStride;
+constexpr int kLdsBytes = kLdsFloats * 4;
+static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+static_assert((kLdsFilm % 4) == 0 && (kLdsHead % 4) == 0 && (kLdsFeat % 4) == 0, "alignment");
+static_assert(kOffWRgb == kOffWSigma + kWidth && kOffBHead == kOffWSigma + 4 * kWidth, "head block is contiguous");
+
+struct SirenK {
+    const float* packed;
+    const float* film;         // (batch, 9, 2, 256)
+    // render mode
+    const float* c2w; const float* focal; const float* near; const float* far; const float* t_vals;
+    const float* tex_alpha; const float* tex_beta;
+    float sigmoid_beta, box_scale, mask_thresh;
+    int batch, H, Wd, S, res, force_bg;
+    int R, tiles_per_img;
+    float *rgb, *features, *xyz, *depth, *mask, *sdf, *weights, *points, *rays_d, *viewdirs, *dists;
+    // points mode
+    const float* pts; const float* vdirs; long long n_pts; int subtiles_per_wg, wgs_per_img;
+    float* raw;
+};
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// C/D fragment of v_mfma_f32_32x32x2_f32: lane l, register r holds D[row_of(r, l>>5)][l&31].
+__device__ __forceinline__ constexpr int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+}
+
+// sin(x), |x| < ~1e5: 3-term Cody-Waite reduction by pi/2 with FMAs + Cephes sinf/cosf minimax kernels on
+// [-pi/4, pi/4].  Branch-free; <= 2 ulp of the correctly rounded result (checked by the sin self-test).
+__device__ __forceinline__ float sin_f32(float x) {
+    const float kf = rintf(x * 0.636619772367581343f);
+    float r = fmaf(-kf, 1.5707963705062866e+00f, x);
+    r = fmaf(-kf, -4.3711388286737929e-08f, r);
+    r = fmaf(-kf, -1.7151245100058e-15f, r);
+    const int q = (int)kf;
+    const float r2 = r * r;
+    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = fmaf(sp, r2, -1.6666654611e-1f);
+    const float s = fmaf(sp * r2, r, r);
+    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = fmaf(cp, r2, 4.166664568298827e-2f);
+    const float c = fmaf(cp * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    float v = (q & 1) ? c : s;
+    return (q & 2) ? -v : v;
+}
+
+__device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, kWave); }
+
+// K=256 contraction of one 32-feature output tile against the wave's register-resident activations.
+//   TRANSPOSED=false: D[feature][point]  (weights = A operand, activations = B operand)
+//   TRANSPOSED=true : D[point][feature]  (activations = A operand, weights = B operand)
+// The weight fragments are double-buffered in registers: the 4 ds_read_b128 of k-block c+1 are issued
+// before the 16 MFMAs of k-block c (1024 cycles of cover for the LDS latency).
+template <bool TRANSPOSED>
+__device__ __forceinline__ f32x16 big_tile(const float* __restrict__ wchunk, int lane,
+                                           const f32x16 (&in)[kNT], f32x16 acc) {
+    const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wchunk) + lane;
+    f32x4 cur[4], nxt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = wp[q * 64];
+#pragma unroll
+    for (int c = 0; c < kNT; ++c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (c + 1 < kNT) {
+                nxt[q] = wp[((c + 1) * 4 + q) * 64];
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs it covers
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float act = in[c][4 * q + j];
+                acc = TRANSPOSED ? mfma32(act, cur[q][j], acc) : mfma32(cur[q][j], act, acc);
+            }
+        }
+        if (c + 1 < kNT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        }
+    }
+    return acc;
+}
+
+// accumulator initialised with the layer bias, standard layout (rows = features): 4 x 16 B from L2
+__device__ __forceinline__ f32x16 bias_std(const float* __restrict__ bias, int t, int half) {
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 32 * t + 8 * q + 4 * half);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4 * q + j] = b4[j];
+    }
+    return acc;
+}
+
+// sin(gamma * acc + beta), standard layout; gamma/beta of the layer come from the LDS copy of this image's
+// FiLM block ([2][256]).  gamma*out and +beta are separately rounded as in FiLMSiren.forward (:130).
+__device__ __forceinline__ f32x16 film_sin_std(f32x16 acc, const float* __restrict__ film_l, int t, int half) {
+    f32x16 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(film_l + 32 * t + 8 * q + 4 * half);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(film_l + kWidth + 32 * t + 8 * q + 4 * half);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[4 * q + j] = sin_f32(__fadd_rn(__fmul_rn(g4[j], acc[4 * q + j]), b4[j]));
+    }
+    return o;
+}
+
+__device__ __forceinline__ void set_tile(f32x16 (&dst)[kNT], int t, const f32x16& v) {
+    switch (t) {
+        case 0: dst[0] = v; break;
+        case 1: dst[1] = v; break;
+        case 2: dst[2] = v; break;
+        case 3: dst[3] = v; break;
+        case 4: dst[4] = v; break;
+        case 5: dst[5] = v; break;
+        case 6: dst[6] = v; break;
+        default: dst[7] = v; break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the kernel.  MODE 0 = render (rays x samples + compositing), MODE 1 = arbitrary point set (raw outputs)
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const wbuf = smem + kLdsW;
+    float* const film_s = smem + kLdsFilm;
+    float* const head_s = smem + kLdsHead;
+    float* const feat_acc = smem + kLdsFeat;
+    float* const part = smem + kLdsPart;
+    float* const alpha_s = smem + kLdsAlpha;
+    float* const wgt_s = smem + kLdsWgt;
+    float* const z_s = smem + kLdsZ;
+    float* const pts_s = smem + kLdsPts;
+    float* const rgb_s = smem + kLdsRgb;
+    float* const state = smem + kLdsState;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+
+    // ---- work assignment ----
+    int b, npts, n_sub;
+    int pix0 = 0, nrays = 0;            // render
+    long long pt0 = 0;                  // points mode: first point of this workgroup inside image b
+    const int S = (MODE == 0) ? a.S : 1;
+    if (MODE == 0) {
+        b = blockIdx.x / a.tiles_per_img;
+        const int tile = blockIdx.x - b * a.tiles_per_img;
+        const int HW = a.H * a.Wd;
+        pix0 = tile * a.R;
+        nrays = min(a.R, HW - pix0);
+        npts = nrays * S;
+    } else {
+        b = blockIdx.x / a.wgs_per_img;
+        const int wg = blockIdx.x - b * a.wgs_per_img;
+        pt0 = (long long)wg * a.subtiles_per_wg * kTilePts;
+        const long long rem = a.n_pts - pt0;
+        npts = (int)(rem < (long long)a.subtiles_per_wg * kTilePts ? rem : (long long)a.subtiles_per_wg * kTilePts);
+    }
+    n_sub = (npts + kTilePts - 1) / kTilePts;
+
+    const float* __restrict__ packed = a.packed;
+    const float* __restrict__ film_g = a.film + (int64_t)b * 9 * 2 * kWidth;
+    for (int i = tid; i < 9 * 2 * kWidth; i += kThreads) film_s[i] = film_g[i];   // published by the first barrier
+    const float* __restrict__ film = film_s;
+    for (int i = tid; i < kHeadFloats; i += kThreads) head_s[i] = packed[kOffWSigma + i];
+    const float* __restrict__ bias_all = packed + kOffBias;
+
+    // per-image camera (render mode)
+    float cw[12] = {0}, focal = 1.f, nearv = 0.f, farv = 0.f;
+    if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) cw[i] = a.c2w[b * 12 + i];
+        focal = a.focal[b]; nearv = a.near[b]; farv = a.far[b];
+        // zero the per-ray state and the feature accumulators
+        for (int i = tid; i < kRMax * kStateStride; i += kThreads) state[i] = 0.0f;
+        for (int i = tid; i < kRMax * kFPitch; i += kThreads) feat_acc[i] = 0.0f;
+    }
+
+    // ---- weight chunk pipeline ----
+    const int total_chunks = n_sub * kChunksPerPass;
+    int g_issue = 0;      // next chunk to issue
+    auto issue_chunk = [&]() {
+        if (g_issue < total_chunks) {
+            const float* src = packed + kOffBig + (int64_t)(g_issue % kChunksPerPass) * kChunkFloats;
+            float* dst = wbuf + (g_issue % kNBuf) * kChunkFloats;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int piece = wave * 8 + i;        // 32 pieces of 1 KiB, 8 per wave
+                glds16(src + piece * 256 + lane * 4, dst + piece * 256);
+            }
+        }
+        ++g_issue;
+    };
+    for (int i = 0; i < kNBuf - 1; ++i) issue_chunk();
+    int g_use = 0;        // chunk being consumed
+    // Every wave calls wait_chunk() before consuming chunk g_use: its own DMA pieces have landed (vmcnt),
+    // the barrier publishes everybody's and proves that all waves are done with chunk g_use-1, whose
+    // buffer the next issue_chunk() overwrites.
+    auto wait_chunk = [&]() -> const float* {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float* p = wbuf + (g_use % kNBuf) * kChunkFloats;
+        ++g_use;
+        return p;
+    };
+
+    f32x16 in[kNT], out[kNT];
+
+    for (int sub = 0; sub < n_sub; ++sub) {
+        // =====================================================================================
+        // 1. this lane's point
+        // =====================================================================================
+        const int p_sub = 32 * wave + col;                 // index inside the sub-tile
+        const int p = sub * kTilePts + p_sub;               // index inside the workgroup's block
+        const bool valid = p < npts;
+        const int pc = valid ? p : (npts - 1);
+        float px = 0.f, py = 0.f, pz = 0.f;                 // world-space point
+        float vx = 0.f, vy = 0.f, vz = 0.f;                 // view direction fed to the MLP
+        float zval = 0.f, dist = 0.f;
+        int ray_l = 0, s_idx = 0;
+        int64_t gpt;                                        // global point index (b, ray, s) / (b, n)
+        if (MODE == 0) {
+            ray_l = pc / S;
+            s_idx = pc - ray_l * S;
+            const int pix = pix0 + ray_l;
+            const int iy = pix / a.Wd, ix = pix - iy * a.Wd;
+            gpt = ((int64_t)b * a.H * a.Wd + pix) * S + s_idx;
+            // get_rays (:771-788): pixel centres at +0.5, camera looks down -z
+            const float hres = (float)a.res * 0.5f;
+            const float d0 = __fdiv_rn(((float)ix + 0.5f) - hres, focal);
+            const float d1 = -__fdiv_rn(((float)iy + 0.5f) - hres, focal);
+            const float d2 = -1.0f;
+            float rd[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                rd[m] = __fadd_rn(__fadd_rn(__fmul_rn(d0, cw[4 * m + 0]), __fmul_rn(d1, cw[4 * m + 1])),
+                                  __fmul_rn(d2, cw[4 * m + 2]));
+            // static_viewdirs: camera-space dirs, normalised in render (:1679)
+            const float dn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)));
+            vx = __fdiv_rn(d0, dn); vy = __fdiv_rn(d1, dn); vz = __fdiv_rn(d2, dn);
+            // z_vals (:1211) and pts (:1231)
+            const float tv = a.t_vals[s_idx];
+            zval = __fadd_rn(__fmul_rn(nearv, __fsub_rn(1.0f, tv)), __fmul_rn(farv, tv));
+            px = __fadd_rn(cw[3], __fmul_rn(rd[0], zval));
+            py = __fadd_rn(cw[7], __fmul_rn(rd[1], zval));
+            pz = __fadd_rn(cw[11], __fmul_rn(rd[2], zval));
+            // dists (:826-837)
+            const float rdn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rd[0], rd[0]), __fmul_rn(rd[1], rd[1])), __fmul_rn(rd[2], rd[2])));
+            if (s_idx + 1 < S) {
+                const float tn = a.t_vals[s_idx + 1];
+                const float zn = __fadd_rn(__fmul_rn(nearv, __fsub_rn(1.0f, tn)), __fmul_rn(farv, tn));
+                dist = __fmul_rn(__fsub_rn(zn, zval), rdn);
+            } else {
+                dist = __fmul_rn(1e10f, rdn);
+            }
+            if (valid && half == 0) {
+                if (a.points) { float* o = a.points + gpt * 3; o[0] = px; o[1] = py; o[2] = pz; }
+                if (a.dists) a.dists[gpt] = dist;
+                if (s_idx == 0) {
+                    const int64_t gr = (int64_t)b * a.H * a.Wd + pix;
+                    if (a.rays_d) { float* o = a.rays_d + gr * 3; o[0] = rd[0]; o[1] = rd[1]; o[2] = rd[2]; }
+                    if (a.viewdirs) { float* o = a.viewdirs + gr * 3; o[0] = vx; o[1] = vy; o[2] = vz; }
+                }
+            }
+        } else {
+            gpt = (int64_t)b * a.n_pts + pt0 + pc;
+            const float* pp = a.pts + gpt * 3;
+            px = pp[0]; py = pp[1]; pz = pp[2];
+            if (a.vdirs) { const float* vv = a.vdirs + gpt * 3; vx = vv[0]; vy = vv[1]; vz = vv[2]; }
+        }
+
+        // =====================================================================================
+        // 2. layer 0 (3 -> 256): two K=2 MFMAs per output tile, operands straight from L2
+        // =====================================================================================
+        {
+            const float xs = __fmul_rn(px, a.box_scale), ys = __fmul_rn(py, a.box_scale), zs = __fmul_rn(pz, a.box_scale);
+            const float b0 = half ? ys : xs;
+            const float b1 = half ? 0.0f : zs;
+            const float* __restrict__ wf = packed + kOffFirst;
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                f32x16 acc = bias_std(bias_all, t, half);
+                acc = mfma32(wf[(t * 2 + 0) * 64 + lane], b0, acc);
+                acc = mfma32(wf[(t * 2 + 1) * 64 + lane], b1, acc);
+                in[t] = film_sin_std(acc, film, t, half);
+            }
+        }
+
+        // =====================================================================================
+        // 3. layers 1..7 (256 -> 256), weights streamed through LDS
+        // =====================================================================================
+#pragma unroll 1
+        for (int L = 1; L < E3DGE_SIREN_DEPTH; ++L) {
+            const float* __restrict__ bias_l = bias_all + L * kWidth;
+            const float* __restrict__ film_l = film + L * 2 * kWidth;
+#pragma unroll 1
+            for (int t = 0; t < kNT; ++t) {
+                f32x16 acc = bias_std(bias_l, t, half);      // VMEM issued (and drained by wait_chunk) before the DMA
+                const float* wchunk = wait_chunk();
+                asm volatile("" : "+a"(acc));                // retire the bias load's wait here, not after the DMA issue
+                issue_chunk();
+                acc = big_tile<false>(wchunk, lane, in, acc);
+                set_tile(out, t, film_sin_std(acc, film_l, t, half));
+            }
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) in[t] = out[t];
+        }
+
+        // =====================================================================================
+        // 4. sdf head (:206-208) on the backbone output, standard layout: features live on registers
+        // =====================================================================================
+        float sdf;
+        {
+            const float* __restrict__ ws = head_s;
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < kNT; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(ws + 32 * c + 8 * q + 4 * half);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = fmaf(w4[j], in[c][4 * q + j], acc);
+                }
+            sdf = acc + xhalf(acc) + head_s[4 * kWidth];
+        }
+
+        if (MODE == 0) {
+            // SDF -> density -> alpha (:804-807, :852-861)
+            const float sg = __fdiv_rn(sigmoid_f32(__fdiv_rn(-sdf, a.sigmoid_beta)), a.sigmoid_beta);
+            const float alpha = __fsub_rn(1.0f, expf(-__fmul_rn(sg, dist)));
+            if (half == 0) {
+                alpha_s[p_sub] = valid ? alpha : 0.0f;
+                z_s[p_sub] = zval;
+                pts_s[p_sub * 3 + 0] = px; pts_s[p_sub * 3 + 1] = py; pts_s[p_sub * 3 + 2] = pz;
+                if (valid && a.sdf) a.sdf[gpt] = sdf;
+            }
+            __syncthreads();
+            // transmittance scan (:869-886): one thread per ray touching this sub-tile, front to back
+            const int sub_lo = sub * kTilePts;
+            const int sub_hi = min(sub_lo + kTilePts, npts);
+            const int r_first = sub_lo / S, r_last = (sub_hi - 1) / S;
+            for (int i = tid; i <= r_last - r_first; i += kThreads) {
+                const int rl = r_first + i;
+                const int s_lo = max(0, sub_lo - rl * S), s_hi = min(S, sub_hi - rl * S);
+                float* st = state + rl * kStateStride;
+                float T = (s_lo == 0) ? 1.0f : st[0];
+                float wsum = (s_lo == 0) ? 0.0f : st[1];
+                float dep = st[2], x0 = st[3], x1 = st[4], x2 = st[5];
+                for (int s = s_lo; s < s_hi; ++s) {
+                    const int ps = rl * S + s - sub_lo;
+                    const float al = alpha_s[ps];
+                    float w = __fmul_rn(al, T);
+                    if (a.force_bg && s == S - 1) w = __fsub_rn(1.0f, wsum);
+                    else wsum = __fadd_rn(wsum, w);
+                    T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.0f, al), 1e-10f));
+                    wgt_s[ps] = w;
+                    dep = __fadd_rn(dep, __fmul_rn(w, z_s[ps]));
+                    x0 = __fadd_rn(x0, __fmul_rn(w, pts_s[ps * 3 + 0]));
+                    x1 = __fadd_rn(x1, __fmul_rn(w, pts_s[ps * 3 + 1]));
+                    x2 = __fadd_rn(x2, __fmul_rn(w, pts_s[ps * 3 + 2]));
+                }
+                st[0] = T; st[1] = wsum; st[2] = dep; st[3] = x0; st[4] = x1; st[5] = x2;
+            }
+            __syncthreads();
+            if (valid && half == 0 && a.weights) a.weights[gpt] = wgt_s[p_sub];
+        }
+
+        // optional per-point texture FiLM (SirenGenerator.forward_tex :217-220), after the sdf head read h
+        if (MODE == 0 && a.tex_alpha) {
+            const float* __restrict__ ta = a.tex_alpha + gpt * kWidth;
+            const float* __restrict__ tb = a.tex_beta + gpt * kWidth;
+#pragma unroll
+            for (int c = 0; c < kNT; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(ta + 32 * c + 8 * q + 4 * half);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(tb + 32 * c + 8 * q + 4 * half);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        in[c][4 * q + j] = __fadd_rn(__fmul_rn(__fadd_rn(a4[j], 1.0f), in[c][4 * q + j]), b4[j]);
+                }
+        }
+
+        // =====================================================================================
+        // 5. view layer (259 -> 256), TRANSPOSED: rows (registers) = points, cols (lanes) = features
+        // =====================================================================================
+        // per-register (= per point row) compositing weight and ray slot of this wave's 32-point slab
+        float row_w[16];
+        int row_slot[16];
+        int slab_first_ray = 0, slab_nslots = 0;
+        if (MODE == 0) {
+            const int slab_lo = sub * kTilePts + 32 * wave;
+            const int slab_hi = min(slab_lo + 32, npts);           // exclusive; may be <= slab_lo
+            if (slab_hi > slab_lo) {
+                slab_first_ray = slab_lo / S;
+                slab_nslots = (slab_hi - 1) / S - slab_first_ray + 1;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pr = slab_lo + row_of(r, half);
+                const bool ok = pr < npts;
+                row_w[r] = ok ? wgt_s[32 * wave + row_of(r, half)] : 0.0f;
+                row_slot[r] = ok ? (pr / S - slab_first_ray) : -1;
+            }
+        }
+        float prgb[3][16];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) prgb[c][r] = 0.0f;
+        {
+            const float* __restrict__ bias_v = bias_all + 8 * kWidth;
+            const float* __restrict__ film_v = film + 8 * 2 * kWidth;
+            const float* __restrict__ wvt = packed + kOffVTail;
+            const float* __restrict__ wrgb = head_s + kWidth;
+            const float a0 = half ? vy : vx;
+            const float a1 = half ? 0.0f : vz;
+#pragma unroll 1
+            for (int t = 0; t < kNT; ++t) {
+                const int n = 32 * t + col;                       // this lane's output feature
+                float bv = bias_v[n];
+                float wt0 = wvt[(t * 2 + 0) * 64 + lane], wt1 = wvt[(t * 2 + 1) * 64 + lane];
+                const float* wchunk = wait_chunk();
+                asm volatile("" : "+v"(bv), "+v"(wt0), "+v"(wt1));
+                issue_chunk();
+                const float gm = film_v[n], bt = film_v[kWidth + n];
+                const float wr0 = wrgb[n], wr1 = wrgb[kWidth + n], wr2 = wrgb[2 * kWidth + n];
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = bv;
+                acc = big_tile<true>(wchunk, lane, in, acc);
+                acc = mfma32(a0, wt0, acc);
+                acc = mfma32(a1, wt1, acc);
+                float h[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    h[r] = sin_f32(__fadd_rn(__fmul_rn(gm, acc[r]), bt));
+                    prgb[0][r] = fmaf(wr0, h[r], prgb[0][r]);
+                    prgb[1][r] = fmaf(wr1, h[r], prgb[1][r]);
+                    prgb[2][r] = fmaf(wr2, h[r], prgb[2][r]);
+                }
+                if (MODE == 0) {
+                    // feature composite partials (:894): sum over this slab's points of each ray
+                    for (int sl = 0; sl < slab_nslots; ++sl) {
+                        float fa = 0.0f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) fa = fmaf((row_slot[r] == sl) ? row_w[r] : 0.0f, h[r], fa);
+                        fa += xhalf(fa);
+                        if (half == 0) part[(wave * kMaxSlots + sl) * kWidth + n] = fa;
+                    }
+                } else if (a.raw) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pr = sub * kTilePts + 32 * wave + row_of(r, half);
+                        if (pr < npts) a.raw[((int64_t)b * a.n_pts + pt0 + pr) * 260 + 4 + n] = h[r];
+                    }
+                }
+            }
+        }
+
+        // =====================================================================================
+        // 6. rgb head (:235): reduce the per-lane partials over the 32 feature lanes of each half
+        // =====================================================================================
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = prgb[c][r];
+                v += __shfl_xor(v, 1, kWave);
+                v += __shfl_xor(v, 2, kWave);
+                v += __shfl_xor(v, 4, kWave);
+                v += __shfl_xor(v, 8, kWave);
+                v += __shfl_xor(v, 16, kWave);
+                prgb[c][r] = v + head_s[4 * kWidth + 1 + c];
+            }
+        if (MODE == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (col == r) {
+                    const int ps = 32 * wave + row_of(r, half);
+                    rgb_s[ps * 3 + 0] = sigmoid_f32(prgb[0][r]);
+                    rgb_s[ps * 3 + 1] = sigmoid_f32(prgb[1][r]);
+                    rgb_s[ps * 3 + 2] = sigmoid_f32(prgb[2][r]);
+                }
+            __syncthreads();
+            // rgb composite (:888-890), sequential per ray, and ordered merge of the feature partials
+            const int sub_lo = sub * kTilePts;
+            const int sub_hi = min(sub_lo + kTilePts, npts);
+            const int r_first = sub_lo / S, r_last = (sub_hi - 1) / S;
+            for (int i = tid; i <= r_last - r_first; i += kThreads) {
+                const int rl = r_first + i;
+                const int s_lo = max(0, sub_lo - rl * S), s_hi = min(S, sub_hi - rl * S);
+                float* st = state + rl * kStateStride;
+                float c0 = st[6], c1 = st[7], c2 = st[8];
+                for (int s = s_lo; s < s_hi; ++s) {
+                    const int ps = rl * S + s - sub_lo;
+                    const float w = wgt_s[ps];
+                    c0 = __fadd_rn(c0, __fmul_rn(w, rgb_s[ps * 3 + 0]));
+                    c1 = __fadd_rn(c1, __fmul_rn(w, rgb_s[ps * 3 + 1]));
+                    c2 = __fadd_rn(c2, __fmul_rn(w, rgb_s[ps * 3 + 2]));
+                }
+                st[6] = c0; st[7] = c1; st[8] = c2;
+            }
+            {
+                const int n = tid;   // 256 threads <-> 256 features
+                for (int wv = 0; wv < 4; ++wv) {
+                    const int slab_lo = sub_lo + 32 * wv;
+                    const int slab_hi = min(slab_lo + 32, npts);
+                    if (slab_hi <= slab_lo) break;
+                    const int fr = slab_lo / S;
+                    const int ns = (slab_hi - 1) / S - fr + 1;
+                    for (int sl = 0; sl < ns; ++sl)
+                        feat_acc[(fr + sl) * kFPitch + n] += part[(wv * kMaxSlots + sl) * kWidth + n];
+                }
+            }
+            __syncthreads();
+        } else {
+            if (a.raw || a.sdf) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (col == r) {
+                        const int pr = sub * kTilePts + 32 * wave + row_of(r, half);
+                        if (pr < npts && a.raw) {
+                            float* o = a.raw + ((int64_t)b * a.n_pts + pt0 + pr) * 260;
+                            o[0] = prgb[0][r]; o[1] = prgb[1][r]; o[2] = prgb[2][r];
+                        }
+                    }
+                if (valid && half == 0) {
+                    if (a.sdf) a.sdf[gpt] = sdf;
+                    if (a.raw) a.raw[gpt * 260 + 3] = sdf;
+                }
+            }
+        }
+    }  // sub-tiles
+
+    // make sure no LDS-DMA is still in flight when the workgroup retires
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    if (MODE == 0) {
+        // =====================================================================================
+        // 7. per-ray outputs, channel-first like VolumeFeatureRenderer.forward returns them (:1957-1968)
+        // =====================================================================================
+        const int HW = a.H * a.Wd;
+        if (a.features) {
+            float* fo = a.features + (int64_t)b * kWidth * HW + pix0;
+            for (int e = tid; e < nrays * kWidth; e += kThreads) {
+                const int n = e / nrays, rl = e - n * nrays;        // consecutive lanes -> consecutive rays
+                fo[(int64_t)n * HW + rl] = feat_acc[rl * kFPitch + n];
+            }
+        }
+        for (int rl = tid; rl < nrays; rl += kThreads) {
+            const float* st = state + rl * kStateStride;
+            const int pix = pix0 + rl;
+            if (a.rgb) {
+                float* o = a.rgb + (int64_t)b * 3 * HW + pix;
+                o[0] = __fadd_rn(-1.0f, __fmul_rn(2.0f, st[6]));
+                o[HW] = __fadd_rn(-1.0f, __fmul_rn(2.0f, st[7]));
+                o[2 * HW] = __fadd_rn(-1.0f, __fmul_rn(2.0f, st[8]));
+            }
+            if (a.xyz) {
+                float* o = a.xyz + (int64_t)b * 3 * HW + pix;
+                o[0] = st[3]; o[HW] = st[4]; o[2 * HW] = st[5];
+            }
+            if (a.depth) a.depth[(int64_t)b * HW + pix] = st[2];
+            if (a.mask) a.mask[(int64_t)b * HW + pix] = (st[2] < a.mask_thresh) ? 1.0f : 0.0f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+siren_pack_kernel(float* __restrict__ packed, const float* __restrict__ w_first,
+                  const float* __restrict__ b_first, const float* __restrict__ w_hidden,
+                  const float* __restrict__ b_hidden, const float* __restrict__ w_view,
+                  const float* __restrict__ b_view, const float* __restrict__ w_rgb,
+                  const float* __restrict__ b_rgb, const float* __restrict__ w_sigma,
+                  const float* __restrict__ b_sigma) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < kPackedFloats; e += (int64_t)gridDim.x * 256) {
+        float v;
+        if (e < kOffFirst) {
+            // [Lb][t][c][q][lane][j] = W_Lb[32t + (lane&31)][32c + 8q + 4(lane>>5) + j]
+            int64_t r = e;
+            const int j = r & 3; r >>= 2;
+            const int lane = r & 63; r >>= 6;
+            const int q = r & 3; r >>= 2;
+            const int c = r & 7; r >>= 3;
+            const int t = r & 7; r >>= 3;
+            const int Lb = (int)r;
+            const int n = 32 * t + (lane & 31), k = 32 * c + 8 * q + 4 * (lane >> 5) + j;
+            v = (Lb < 7) ? w_hidden[((int64_t)Lb * kWidth + n) * kWidth + k] : w_view[(int64_t)n * 259 + k];
+        } else if (e < kOffBias) {
+            // [t][m][lane]: m=0 -> (half0: col 0, half1: col 1); m=1 -> (half0: col 2, half1: 0)
+            const bool vt = e >= kOffVTail;
+            int r = (int)(e - (vt ? kOffVTail : kOffFirst));
+            const int lane = r & 63; r >>= 6;
+            const int m = r & 1; r >>= 1;
+            const int t = r;
+            const int n = 32 * t + (lane & 31), hf = lane >> 5;
+            const int kcol = m * 2 + hf;
+            if (kcol >= 3) v = 0.0f;
+            else v = vt ? w_view[(int64_t)n * 259 + 256 + kcol] : w_first[n * 3 + kcol];
+        } else if (e < kOffWSigma) {
+            const int r = (int)(e - kOffBias);
+            const int L = r / kWidth, n = r - L * kWidth;
+            v = (L == 0) ? b_first[n] : (L < 8 ? b_hidden[(L - 1) * kWidth + n] : b_view[n]);
+        } else if (e < kOffWRgb) {
+            v = w_sigma[e - kOffWSigma];
+        } else if (e < kOffBHead) {
+            v = w_rgb[e - kOffWRgb];
+        } else {
+            const int r = (int)(e - kOffBHead);
+            v = (r == 0) ? b_sigma[0] : b_rgb[r - 1];
+        }
+        packed[e] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FiLM parameters: one wave per output row, lanes along K (16 B/lane coalesced), xor-reduce
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+film_params_kernel(float* __restrict__ film, const float* __restrict__ styles,
+                   const float* __restrict__ wg, const float* __restrict__ bg,
+                   const float* __restrict__ wb, const float* __restrict__ bb) {
+    // grid: (batch * 9 * 2); block: 4 waves x 64 rows each
+    int id = blockIdx.x;
+    const int which = id & 1; id >>= 1;
+    const int l = id % 9;
+    const int b = id / 9;
+    const float* __restrict__ Wm = (which ? wb : wg) + (int64_t)l * kWidth * kWidth;
+    const float* __restrict__ bv = (which ? bb : bg) + l * kWidth;
+    const float* __restrict__ s = styles + ((int64_t)b * 9 + l) * kWidth;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4 s4 = *reinterpret_cast<const f32x4*>(s + lane * 4);
+    const float std_init = which ? 0.25f : 15.0f, bias_init = which ? 0.0f : 30.0f;
+    float* __restrict__ o = film + (((int64_t)b * 9 + l) * 2 + which) * kWidth;
+    for (int i = 0; i < 64; ++i) {
+        const int n = wave * 64 + i;
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(Wm + (int64_t)n * kWidth + lane * 4);
+        float acc = w4[0] * s4[0];
+        acc = fmaf(w4[1], s4[1], acc);
+        acc = fmaf(w4[2], s4[2], acc);
+        acc = fmaf(w4[3], s4[3], acc);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+        if (lane == 0) o[n] = __fadd_rn(__fmul_rn(std_init, __fadd_rn(acc, bv[n])), bias_init);   // LinearLayer.forward :76-80
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// self tests
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+selftest_mfma_kernel(float* __restrict__ cmat, const float* __restrict__ amat,
+                     const float* __restrict__ bmat, int k) {
+    const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int kb = 0; kb < k; kb += 8) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(amat + col * k + kb + 4 * half);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bmat + col * k + kb + 4 * half);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = mfma32(a4[j], b4[j], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cmat[row_of(r, half) * 32 + col] = acc[r];
+}
+
+__global__ void selftest_sin_kernel(float* __restrict__ y, const float* __restrict__ x, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = sin_f32(x[i]);
+}
+
+static int ensure_lds_attr() {
+    static bool done = false;
+    if (!done) {
+        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&siren_kernel<0>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&siren_kernel<1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        if (e0 != hipSuccess || e1 != hipSuccess)
+            return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", kLdsBytes,
+                        hipGetErrorString(e0 != hipSuccess ? e0 : e1));
+        done = true;
+    }
+    return E3DGE_OK;
+}
+
+// rays per workgroup: the largest R <= kRMax whose R*S is a multiple of 128 if one exists (no padded
+// lanes), else the R <= kRMax minimising padding; small images get fewer rays per workgroup so that the
+// grid still covers the 256 CUs.
+static int pick_rays_per_wg(int S, int64_t total_rays) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int R = 1; R <= kRMax; ++R) {
+        const int pts = R * S;
+        const int nsub = (pts + kTilePts - 1) / kTilePts;
+        const double pad = (double)(nsub * kTilePts) / pts;                 // >= 1
+        const int64_t wgs = (total_rays + R - 1) / R;
+        const int64_t rounds = (wgs + 255) / 256;
+        const double fill = (double)(rounds * 256) / (double)wgs;           // >= 1, tail effect
+        const double cost = pad * fill * (1.0 + 0.02 / nsub);               // slight preference for longer blocks
+        if (cost < best_cost - 1e-12) { best_cost = cost; best = R; }
+    }
+    return best;
+}
+
+}  // namespace e3dge
+
+using namespace e3dge;
+
+extern "C" int64_t e3dge_siren_packed_floats(void) { return kPackedFloats; }
+
+extern "C" int e3dge_siren_pack_weights(float* packed, const float* w_first, const float* b_first,
+                                        const float* w_hidden, const float* b_hidden,
+                                        const float* w_view, const float* b_view, const float* w_rgb,
+                                        const float* b_rgb, const float* w_sigma, const float* b_sigma,
+                                        e3dge_stream_t stream) {
+    E3DGE_REQUIRE(packed && w_first && b_first && w_hidden && b_hidden && w_view && b_view && w_rgb && b_rgb &&
+                  w_sigma && b_sigma, "siren_pack_weights: null pointer");
+    E3DGE_REQUIRE((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "siren_pack_weights: packed must be 16-B aligned");
+    siren_pack_kernel<<<dim3(512), dim3(256), 0, as_stream(stream)>>>(packed, w_first, b_first, w_hidden, b_hidden,
+                                                                      w_view, b_view, w_rgb, b_rgb, w_sigma, b_sigma);
+    return check_launch("siren_pack_weights");
+}
+
+extern "C" int e3dge_film_params(float* film, const float* styles, const float* wg, const float* bg,
+                                 const float* wb, const float* bb, int batch, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(film && styles && wg && bg && wb && bb, "film_params: null pointer");
+    E3DGE_REQUIRE(batch >= 0, "film_params: batch=%d", batch);
+    if (batch == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(styles) | reinterpret_cast<uintptr_t>(wg) |
+                    reinterpret_cast<uintptr_t>(wb)) & 15) == 0, "film_params: inputs must be 16-B aligned");
+    film_params_kernel<<<dim3((unsigned)(batch * 9 * 2)), dim3(256), 0, as_stream(stream)>>>(film, styles, wg, bg, wb, bb);
+    return check_launch("film_params");
+}
+
+extern "C" int e3dge_siren_render_fwd(const E3dgeRenderArgs* r, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(r != nullptr, "siren_render_fwd: null args");
+    E3DGE_REQUIRE(r->packed && r->film && r->c2w && r->focal && r->near && r->far && r->t_vals,
+                  "siren_render_fwd: null input pointer");
+    E3DGE_REQUIRE(r->batch >= 0 && r->height > 0 && r->width > 0, "siren_render_fwd: bad image extent");
+    E3DGE_REQUIRE(r->n_samples >= kMinSamples && r->n_samples <= 4096,
+                  "siren_render_fwd: n_samples=%d outside [%d, 4096] (use e3dge_siren_points_fwd for raw queries)",
+                  r->n_samples, kMinSamples);
+    E3DGE_REQUIRE((r->tex_alpha == nullptr) == (r->tex_beta == nullptr), "siren_render_fwd: tex_alpha/tex_beta must come together");
+    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(r->packed) | reinterpret_cast<uintptr_t>(r->film) |
+                    reinterpret_cast<uintptr_t>(r->tex_alpha) | reinterpret_cast<uintptr_t>(r->tex_beta)) & 15) == 0,
+                  "siren_render_fwd: packed/film/tex pointers must be 16-B aligned");
+    E3DGE_REQUIRE(r->sigmoid_beta != 0.0f, "siren_render_fwd: sigmoid_beta must be non-zero");
+    if (r->batch == 0) return E3DGE_OK;
+    int rc = ensure_lds_attr();
+    if (rc) return rc;
+    const int64_t HW = (int64_t)r->height * r->width;
+    E3DGE_REQUIRE(HW * r->batch * (int64_t)r->n_samples < ((int64_t)1 << 40), "siren_render_fwd: too many points");
+    SirenK k{};
+    k.packed = r->packed; k.film = r->film; k.c2w = r->c2w; k.focal = r->focal; k.near = r->near; k.far = r->far;
+    k.t_vals = r->t_vals; k.tex_alpha = r->tex_alpha; k.tex_beta = r->tex_beta;
+    k.sigmoid_beta = r->sigmoid_beta; k.box_scale = r->box_scale; k.mask_thresh = r->mask_depth_thresh;
+    k.batch = r->batch; k.H = r->height; k.Wd = r->width; k.S = r->n_samples; k.res = r->res; k.force_bg = r->force_background;
+    k.R = pick_rays_per_wg(r->n_samples, HW * r->batch);
+    if (k.R > HW) k.R = (int)HW;
+    k.tiles_per_img = (int)((HW + k.R - 1) / k.R);
+    k.rgb = r->rgb; k.features = r->features; k.xyz = r->xyz; k.depth = r->depth; k.mask = r->mask; k.sdf = r->sdf;
+    k.weights = r->weights; k.points = r->points; k.rays_d = r->rays_d; k.viewdirs = r->viewdirs; k.dists = r->dists;
+    const int64_t grid = (int64_t)k.tiles_per_img * r->batch;
+    E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_render_fwd: grid too large");
+    siren_kernel<0><<<dim3((unsigned)grid), dim3(kThreads), kLdsBytes, as_stream(stream)>>>(k);
+    return check_launch("siren_render_fwd");
+}
+
+extern "C" int e3dge_siren_points_fwd(const float* packed, const float* film, const float* pts,
+                                      const float* viewdirs, float box_scale, int batch, int64_t n_pts,
+                                      float* sdf, float* raw, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(packed && film && pts, "siren_points_fwd: null input pointer");
+    E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "siren_points_fwd: bad sizes");
+    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(film)) & 15) == 0,
+                  "siren_points_fwd: packed/film must be 16-B aligned");
+    if (batch == 0 || n_pts == 0) return E3DGE_OK;
+    int rc = ensure_lds_attr();
+    if (rc) return rc;
+    SirenK k{};
+    k.packed = packed; k.film = film; k.pts = pts; k.vdirs = viewdirs; k.box_scale = box_scale;
+    k.batch = batch; k.n_pts = n_pts; k.sdf = sdf; k.raw = raw;
+    // sub-tiles per workgroup: enough workgroups to cover the chip, at most 8 sub-tiles each
+    const int64_t tiles = (n_pts + kTilePts - 1) / kTilePts;
+    int spw = (int)((tiles * batch + 255) / 256);
+    if (spw < 1) spw = 1;
+    if (spw > 8) spw = 8;
+    k.subtiles_per_wg = spw;
+    k.wgs_per_img = (int)((tiles + spw - 1) / spw);
+    const int64_t grid = (int64_t)k.wgs_per_img * batch;
+    E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_points_fwd: grid too large");
+    siren_kernel<1><<<dim3((unsigned)grid), dim3(kThreads), kLdsBytes, as_stream(stream)>>>(k);
+    return check_launch("siren_points_fwd");
+}
+
+extern "C" int e3dge_selftest_mfma(float* c, const float* a, const float* b, int k, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(c && a && b && k > 0 && k <= 256 && (k % 8) == 0, "selftest_mfma: bad arguments");
+    selftest_mfma_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(c, a, b, k);
+    return check_launch("selftest_mfma");
+}
+
+extern "C" int e3dge_selftest_sin(float* y, const float* x, int n, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(y && x && n >= 0, "selftest_sin: bad arguments");
+    if (n == 0) return E3DGE_OK;
+    selftest_sin_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(y, x, n);
+    return check_launch("selftest_sin");
+}

@@ -1,0 +1,289 @@
+// HBM-bound stream kernels of the StyleGAN2 up-sampler: fused bias+activation, fused noise+bias+
+// activation, and modulated-conv weight preparation.  gfx950 only; fp32.
+//
+// Roofline: all three are pure streams (8 B/element fwd for the activations), so the only goals are
+// 16 B/lane coalesced accesses, no per-element integer division, and >= 2k workgroups in flight.
+#include "common.h"
+
+namespace e3dge {
+
+static thread_local char g_err[512] = {0};
+char* err_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused_bias_act  (reference: project/models/op/fused_bias_act_kernel.cu:19-49)
+// ---------------------------------------------------------------------------------------------
+enum ActMode { kLinear = 0, kZero = 1, kLrelu = 2, kLreluGrad = 3 };
+
+template <int MODE>
+__device__ __forceinline__ float act_one(float x, float ref, float alpha, float scale) {
+    float y;
+    if (MODE == kLinear) y = x;
+    else if (MODE == kZero) y = 0.0f;
+    else if (MODE == kLrelu) y = (x > 0.0f) ? x : __fmul_rn(x, alpha);
+    else y = (ref > 0.0f) ? x : __fmul_rn(x, alpha);
+    return __fmul_rn(y, scale);
+}
+
+constexpr int kActThreads = 256;
+constexpr int kActVecPerThread = 4;                                  // float4s per thread
+constexpr int kActChunk = kActThreads * kActVecPerThread * 4;        // floats per workgroup
+
+// Row kernel: x viewed as (rows, step_b) with one bias value per row; step_b % 4 == 0.
+template <int MODE, bool HAS_BIAS, bool HAS_REF>
+__global__ void __launch_bounds__(kActThreads)
+bias_act_rows_kernel(float* __restrict__ y, const float* __restrict__ x,
+                     const float* __restrict__ bias, const float* __restrict__ ref, float alpha,
+                     float scale, int step_b, int size_b, int chunks_per_row) {
+    const int row = blockIdx.x / chunks_per_row;
+    const int chunk = blockIdx.x - row * chunks_per_row;
+    const float b = HAS_BIAS ? bias[row % size_b] : 0.0f;
+    const int64_t base = (int64_t)row * step_b;
+    const int nvec = step_b >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x + base);
+    const float4* r4 = HAS_REF ? reinterpret_cast<const float4*>(ref + base) : nullptr;
+    float4* y4 = reinterpret_cast<float4*>(y + base);
+    const int v0 = chunk * (kActThreads * kActVecPerThread) + threadIdx.x;
+    float4 xv[kActVecPerThread], rv[kActVecPerThread];
+#pragma unroll
+    for (int j = 0; j < kActVecPerThread; ++j) {
+        const int v = v0 + j * kActThreads;
+        if (v < nvec) {
+            xv[j] = x4[v];
+            if (HAS_REF) rv[j] = r4[v];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kActVecPerThread; ++j) {
+        const int v = v0 + j * kActThreads;
+        if (v < nvec) {
+            float4 o;
+            o.x = act_one<MODE>(HAS_BIAS ? xv[j].x + b : xv[j].x, HAS_REF ? rv[j].x : 0.0f, alpha, scale);
+            o.y = act_one<MODE>(HAS_BIAS ? xv[j].y + b : xv[j].y, HAS_REF ? rv[j].y : 0.0f, alpha, scale);
+            o.z = act_one<MODE>(HAS_BIAS ? xv[j].z + b : xv[j].z, HAS_REF ? rv[j].z : 0.0f, alpha, scale);
+            o.w = act_one<MODE>(HAS_BIAS ? xv[j].w + b : xv[j].w, HAS_REF ? rv[j].w : 0.0f, alpha, scale);
+            y4[v] = o;
+        }
+    }
+}
+
+// Generic element kernel (any step_b, e.g. the (B, C) outputs of MappingLinear / EqualLinear).
+template <int MODE, bool HAS_BIAS, bool HAS_REF>
+__global__ void __launch_bounds__(kActThreads)
+bias_act_elem_kernel(float* __restrict__ y, const float* __restrict__ x,
+                     const float* __restrict__ bias, const float* __restrict__ ref, float alpha,
+                     float scale, int n, int step_b, int size_b) {
+    for (int i = blockIdx.x * kActThreads + threadIdx.x; i < n; i += gridDim.x * kActThreads) {
+        float v = x[i];
+        if (HAS_BIAS) v += bias[(i / step_b) % size_b];
+        y[i] = act_one<MODE>(v, HAS_REF ? ref[i] : 0.0f, alpha, scale);
+    }
+}
+
+template <int MODE, bool HAS_BIAS, bool HAS_REF>
+static int launch_bias_act(float* y, const float* x, const float* bias, const float* ref,
+                           float alpha, float scale, int64_t n, int64_t step_b, int64_t size_b,
+                           hipStream_t st) {
+    const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                           (HAS_REF ? reinterpret_cast<uintptr_t>(ref) : 0)) & 15) == 0;
+    // Without a bias the whole tensor is one "row"; keep rows < 2^31 elements.
+    int64_t row_len = HAS_BIAS ? step_b : n;
+    if (aligned && row_len >= 4 && (row_len % 4) == 0 && (n % row_len) == 0) {
+        const int64_t rows = n / row_len;
+        const int64_t cpr = (row_len + kActChunk - 1) / kActChunk;
+        const int64_t blocks = rows * cpr;
+        if (blocks < (int64_t)1 << 31) {
+            bias_act_rows_kernel<MODE, HAS_BIAS, HAS_REF>
+                <<<dim3((unsigned)blocks), dim3(kActThreads), 0, st>>>(
+                    y, x, bias, ref, alpha, scale, (int)row_len, HAS_BIAS ? (int)size_b : 1, (int)cpr);
+            return check_launch("fused_bias_act(rows)");
+        }
+    }
+    int64_t blocks = (n + kActThreads - 1) / kActThreads;
+    if (blocks > 8192) blocks = 8192;
+    bias_act_elem_kernel<MODE, HAS_BIAS, HAS_REF><<<dim3((unsigned)blocks), dim3(kActThreads), 0, st>>>(
+        y, x, bias, ref, alpha, scale, (int)n, HAS_BIAS ? (int)step_b : 1, HAS_BIAS ? (int)size_b : 1);
+    return check_launch("fused_bias_act(elem)");
+}
+
+template <int MODE>
+static int dispatch_bias_act(float* y, const float* x, const float* bias, const float* ref,
+                             float alpha, float scale, int64_t n, int64_t step_b, int64_t size_b,
+                             hipStream_t st) {
+    const bool hb = bias != nullptr && size_b > 0;
+    const bool hr = (MODE == kLreluGrad) && ref != nullptr;
+    if (hb && hr) return launch_bias_act<MODE, true, true>(y, x, bias, ref, alpha, scale, n, step_b, size_b, st);
+    if (hb) return launch_bias_act<MODE, true, false>(y, x, bias, ref, alpha, scale, n, step_b, size_b, st);
+    if (hr) return launch_bias_act<MODE, false, true>(y, x, bias, ref, alpha, scale, n, step_b, size_b, st);
+    return launch_bias_act<MODE, false, false>(y, x, bias, ref, alpha, scale, n, step_b, size_b, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// noise + bias + lrelu  (reference chain: stylesdf_model.py:466 then fused_act.py:55-118)
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_NOISE, bool HAS_BIAS>
+__global__ void __launch_bounds__(kActThreads)
+noise_bias_act_kernel(float* __restrict__ y, const float* __restrict__ x,
+                      const float* __restrict__ noise, const float* __restrict__ noise_weight,
+                      const float* __restrict__ bias, float alpha, float scale, int channels, int hw,
+                      int noise_batch, int chunks_per_row) {
+    const int row = blockIdx.x / chunks_per_row;  // b * channels + c
+    const int chunk = blockIdx.x - row * chunks_per_row;
+    const int b = row / channels;
+    const int c = row - b * channels;
+    const float bc = HAS_BIAS ? bias[c] : 0.0f;
+    const float nw = HAS_NOISE ? noise_weight[0] : 0.0f;
+    const int nvec = hw >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x + (int64_t)row * hw);
+    const float4* n4 = HAS_NOISE
+        ? reinterpret_cast<const float4*>(noise + (int64_t)(noise_batch == 1 ? 0 : b) * hw) : nullptr;
+    float4* y4 = reinterpret_cast<float4*>(y + (int64_t)row * hw);
+    const int v0 = chunk * (kActThreads * kActVecPerThread) + threadIdx.x;
+    float4 xv[kActVecPerThread], nv[kActVecPerThread];
+#pragma unroll
+    for (int j = 0; j < kActVecPerThread; ++j) {
+        const int v = v0 + j * kActThreads;
+        if (v < nvec) {
+            xv[j] = x4[v];
+            if (HAS_NOISE) nv[j] = n4[v];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kActVecPerThread; ++j) {
+        const int v = v0 + j * kActThreads;
+        if (v < nvec) {
+            float4 t = xv[j];
+            if (HAS_NOISE) {  // image + weight * noise : a rounded product, then a rounded add
+                t.x = __fadd_rn(t.x, __fmul_rn(nw, nv[j].x));
+                t.y = __fadd_rn(t.y, __fmul_rn(nw, nv[j].y));
+                t.z = __fadd_rn(t.z, __fmul_rn(nw, nv[j].z));
+                t.w = __fadd_rn(t.w, __fmul_rn(nw, nv[j].w));
+            }
+            float4 o;
+            o.x = act_one<kLrelu>(HAS_BIAS ? t.x + bc : t.x, 0.0f, alpha, scale);
+            o.y = act_one<kLrelu>(HAS_BIAS ? t.y + bc : t.y, 0.0f, alpha, scale);
+            o.z = act_one<kLrelu>(HAS_BIAS ? t.z + bc : t.z, 0.0f, alpha, scale);
+            o.w = act_one<kLrelu>(HAS_BIAS ? t.w + bc : t.w, 0.0f, alpha, scale);
+            y4[v] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// modulated-conv weight preparation  (reference: stylesdf_model.py:317-338)
+// ---------------------------------------------------------------------------------------------
+constexpr int kModThreads = 256;
+
+__global__ void __launch_bounds__(kModThreads)
+modconv_weights_kernel(float* __restrict__ out, const float* __restrict__ weight,
+                       const float* __restrict__ style, float scale, int demodulate, int transpose,
+                       int co, int ci, int kk) {
+    __shared__ float red[kModThreads / kWave];
+    __shared__ float demod_s;
+    const int o = blockIdx.x % co;
+    const int b = blockIdx.x / co;
+    const int n = ci * kk;
+    const float* w = weight + (int64_t)o * n;
+    const float* s = style + (int64_t)b * ci;
+    float sq = 0.0f;
+    for (int e = threadIdx.x; e < n; e += kModThreads) {
+        const int i = e / kk;
+        const float v = __fmul_rn(__fmul_rn(scale, w[e]), s[i]);  // (scale * W) * style
+        sq = fmaf(v, v, sq);
+    }
+    float d = 1.0f;
+    if (demodulate) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.0f;
+            for (int k = 0; k < kModThreads / kWave; ++k) t += red[k];
+            demod_s = 1.0f / sqrtf(t + 1e-8f);
+        }
+        __syncthreads();
+        d = demod_s;
+    }
+    for (int e = threadIdx.x; e < n; e += kModThreads) {
+        const int i = e / kk;
+        const int k = e - i * kk;
+        float v = __fmul_rn(__fmul_rn(scale, w[e]), s[i]);
+        if (demodulate) v = __fmul_rn(v, d);
+        const int64_t dst = transpose ? (((int64_t)b * ci + i) * co + o) * kk + k
+                                      : (((int64_t)b * co + o) * ci + i) * kk + k;
+        out[dst] = v;
+    }
+}
+
+}  // namespace e3dge
+
+using namespace e3dge;
+
+extern "C" int e3dge_abi_version(void) { return 1; }
+extern "C" const char* e3dge_last_error(void) { return err_buf(); }
+
+extern "C" int e3dge_fused_bias_act(float* y, const float* x, const float* bias, const float* ref,
+                                    int act, int grad, float alpha, float scale, int64_t n,
+                                    int64_t step_b, int64_t size_b, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "fused_bias_act: n=%lld outside int32 range", (long long)n);
+    if (n == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(x && y, "fused_bias_act: null x/y");
+    const bool has_bias = bias != nullptr && size_b > 0;
+    E3DGE_REQUIRE(!has_bias || step_b >= 1, "fused_bias_act: step_b=%lld", (long long)step_b);
+    hipStream_t st = as_stream(stream);
+    // act*10+grad table of the reference (:35-45); anything unknown falls to 'linear' like its default.
+    const int code = act * 10 + grad;
+    switch (code) {
+        case 12: case 32:
+            return dispatch_bias_act<kZero>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
+        case 30:
+            return dispatch_bias_act<kLrelu>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
+        case 31:
+            return dispatch_bias_act<kLreluGrad>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
+        default:
+            return dispatch_bias_act<kLinear>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
+    }
+}
+
+extern "C" int e3dge_noise_bias_act(float* y, const float* x, const float* noise,
+                                    const float* noise_weight, const float* bias, float alpha,
+                                    float scale, int64_t batch, int64_t channels, int64_t hw,
+                                    int64_t noise_batch, e3dge_stream_t stream) {
+    const int64_t n = batch * channels * hw;
+    if (n == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(x && y, "noise_bias_act: null x/y");
+    E3DGE_REQUIRE(n < ((int64_t)1 << 31), "noise_bias_act: n=%lld outside int32 range", (long long)n);
+    E3DGE_REQUIRE(hw % 4 == 0, "noise_bias_act: hw=%lld must be a multiple of 4", (long long)hw);
+    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                    reinterpret_cast<uintptr_t>(noise)) & 15) == 0, "noise_bias_act: pointers must be 16-B aligned");
+    const bool hn = noise != nullptr;
+    E3DGE_REQUIRE(!hn || (noise_weight && (noise_batch == 1 || noise_batch == batch)),
+                  "noise_bias_act: noise_batch=%lld must be 1 or batch", (long long)noise_batch);
+    const int64_t cpr = (hw + kActChunk - 1) / kActChunk;
+    const int64_t blocks = batch * channels * cpr;
+    hipStream_t st = as_stream(stream);
+    dim3 g((unsigned)blocks), t(kActThreads);
+    if (hn && bias) noise_bias_act_kernel<true, true><<<g, t, 0, st>>>(y, x, noise, noise_weight, bias, alpha, scale, (int)channels, (int)hw, (int)noise_batch, (int)cpr);
+    else if (hn) noise_bias_act_kernel<true, false><<<g, t, 0, st>>>(y, x, noise, noise_weight, bias, alpha, scale, (int)channels, (int)hw, (int)noise_batch, (int)cpr);
+    else if (bias) noise_bias_act_kernel<false, true><<<g, t, 0, st>>>(y, x, noise, noise_weight, bias, alpha, scale, (int)channels, (int)hw, (int)noise_batch, (int)cpr);
+    else noise_bias_act_kernel<false, false><<<g, t, 0, st>>>(y, x, noise, noise_weight, bias, alpha, scale, (int)channels, (int)hw, (int)noise_batch, (int)cpr);
+    return check_launch("noise_bias_act");
+}
+
+extern "C" int e3dge_modconv_weights(float* out, const float* weight, const float* style, float scale,
+                                     int demodulate, int transpose, int batch, int co, int ci, int kk,
+                                     e3dge_stream_t stream) {
+    E3DGE_REQUIRE(out && weight && style, "modconv_weights: null pointer");
+    E3DGE_REQUIRE(batch > 0 && co > 0 && ci > 0 && kk > 0, "modconv_weights: bad sizes");
+    modconv_weights_kernel<<<dim3((unsigned)(batch * co)), dim3(kModThreads), 0, as_stream(stream)>>>(
+        out, weight, style, scale, demodulate, transpose, co, ci, kk);
+    return check_launch("modconv_weights");
+}

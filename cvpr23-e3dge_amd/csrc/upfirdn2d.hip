@@ -1,0 +1,194 @@
+// upfirdn2d for gfx950: zero-insert up-sample, pad/crop, correlate with the FLIPPED FIR, decimate.
+// Reference semantics: project/models/op/upfirdn2d_kernel.cu:49-207 (CUDA) and the PyTorch restatement
+// project/models/op/upfirdn2d.py:157-200.  minor_dim == 1 (how every Python caller invokes it).
+//
+//   U[uy][ux] = x[(uy-pad_y0)/up_y][(ux-pad_x0)/up_x]  when both quotients are exact and in range, else 0
+//   y[oy][ox] = sum_{ky,kx} U[oy*down_y+ky][ox*down_x+kx] * k[kh-1-ky][kw-1-kx]
+//
+// Roofline: pure HBM stream, 4*(in+out) bytes per plane.  The tiled kernel stages the up-sampled tile U
+// in LDS once (so every input element is fetched from HBM once, plus the (k-1)-wide halo), each lane
+// produces 1x4 adjacent outputs from two ds_read_b128 per tap row, and stores 16 B.
+#include "common.h"
+
+namespace e3dge {
+
+__host__ __device__ inline int floor_div_i(int a, int b) {
+    int q = a / b;
+    return (q * b > a) ? q - 1 : q;
+}
+
+struct UpfirdnGeom {
+    int in_h, in_w, out_h, out_w;
+    int up_x, up_y, down_x, down_y;
+    int pad_x0, pad_y0;
+    int kh, kw;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Tiled kernel: square up factor UP, square decimation DN, KHxKW taps; tile 32 x 64 outputs.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTileH = 32, kTileW = 64, kUpThreads = 256;
+
+template <int UP, int DN, int KH, int KW>
+__global__ void __launch_bounds__(kUpThreads)
+upfirdn2d_tiled_kernel(float* __restrict__ y, const float* __restrict__ x,
+                       const float* __restrict__ k, UpfirdnGeom g, int tiles_x, int tiles_y) {
+    constexpr int UH = (kTileH - 1) * DN + KH;           // rows of U needed by the tile
+    constexpr int UW = (kTileW - 1) * DN + KW;
+    constexpr int PITCH = (UW + 3) & ~3;                 // 16-B aligned rows for ds_read_b128
+    __shared__ __attribute__((aligned(16))) float u[UH * PITCH];
+
+    int bid = blockIdx.x;
+    const int tx_i = bid % tiles_x; bid /= tiles_x;
+    const int ty_i = bid % tiles_y; bid /= tiles_y;
+    const int64_t plane = bid;
+    const int oy0 = ty_i * kTileH, ox0 = tx_i * kTileW;
+    const float* xp = x + plane * (int64_t)g.in_h * g.in_w;
+
+    // ---- stage U (zero-inserted, padded) ----
+    const int gy0 = oy0 * DN - g.pad_y0, gx0 = ox0 * DN - g.pad_x0;   // U-tile origin in up-sampled coords
+    for (int e = threadIdx.x; e < UH * PITCH; e += kUpThreads) {
+        const int r = e / PITCH, c = e - r * PITCH;
+        float v = 0.0f;
+        if (c < UW) {
+            const int sy = gy0 + r, sx = gx0 + c;
+            if (sy >= 0 && sx >= 0) {
+                int iy = sy, ix = sx;
+                bool ok = true;
+                if (UP > 1) {
+                    iy = sy / UP; ix = sx / UP;
+                    ok = (iy * UP == sy) && (ix * UP == sx);
+                }
+                if (ok && iy < g.in_h && ix < g.in_w) v = xp[(int64_t)iy * g.in_w + ix];
+            }
+        }
+        u[e] = v;
+    }
+    // flipped taps, wave-uniform
+    float kf[KH][KW];
+#pragma unroll
+    for (int a = 0; a < KH; ++a)
+#pragma unroll
+        for (int b = 0; b < KW; ++b) kf[a][b] = k[(KH - 1 - a) * KW + (KW - 1 - b)];
+    __syncthreads();
+
+    // ---- compute: lane -> 4 adjacent outputs in x, rows ty and ty+16 ----
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float* yp = y + plane * (int64_t)g.out_h * g.out_w;
+    const bool vec_ok = (g.out_w & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int oyl = ty + rr * 16;
+        const int oy = oy0 + oyl;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        constexpr int NIN = 3 * DN + KW;                 // inputs spanned by 4 outputs
+        constexpr int NVEC = (NIN + 3) / 4;
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            const float* row = u + (oyl * DN + ky) * PITCH + tx * 4 * DN;
+            float in[NVEC * 4];
+#pragma unroll
+            for (int v = 0; v < NVEC; ++v) {
+                // the last vector of the last lane may run past UW but stays inside PITCH*UH + slack:
+                // PITCH >= UW and reads beyond are multiplied by nothing (indices < NIN only are used).
+                const float4 q = *reinterpret_cast<const float4*>(row + 4 * v);
+                in[4 * v + 0] = q.x; in[4 * v + 1] = q.y; in[4 * v + 2] = q.z; in[4 * v + 3] = q.w;
+            }
+#pragma unroll
+            for (int kx = 0; kx < KW; ++kx)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(in[j * DN + kx], kf[ky][kx], acc[j]);
+        }
+        if (oy < g.out_h) {
+            const int ox = ox0 + tx * 4;
+            float* dst = yp + (int64_t)oy * g.out_w + ox;
+            if (vec_ok && ox + 3 < g.out_w) {
+                *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ox + j < g.out_w) dst[j] = acc[j];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic kernel: one output per thread, direct gather (any up/down/pad/kernel <= 32x32).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kUpThreads)
+upfirdn2d_generic_kernel(float* __restrict__ y, const float* __restrict__ x,
+                         const float* __restrict__ k, UpfirdnGeom g, int64_t total) {
+    for (int64_t o = (int64_t)blockIdx.x * kUpThreads + threadIdx.x; o < total;
+         o += (int64_t)gridDim.x * kUpThreads) {
+        const int ox = (int)(o % g.out_w);
+        const int64_t t = o / g.out_w;
+        const int oy = (int)(t % g.out_h);
+        const int64_t plane = t / g.out_h;
+        const float* xp = x + plane * (int64_t)g.in_h * g.in_w;
+        const int by = oy * g.down_y - g.pad_y0, bx = ox * g.down_x - g.pad_x0;
+        float acc = 0.0f;
+        for (int ky = 0; ky < g.kh; ++ky) {
+            const int sy = by + ky;
+            if (sy < 0) continue;
+            const int iy = sy / g.up_y;
+            if (iy * g.up_y != sy || iy >= g.in_h) continue;
+            for (int kx = 0; kx < g.kw; ++kx) {
+                const int sx = bx + kx;
+                if (sx < 0) continue;
+                const int ix = sx / g.up_x;
+                if (ix * g.up_x != sx || ix >= g.in_w) continue;
+                acc = fmaf(xp[(int64_t)iy * g.in_w + ix], k[(g.kh - 1 - ky) * g.kw + (g.kw - 1 - kx)], acc);
+            }
+        }
+        y[o] = acc;
+    }
+}
+
+template <int UP, int DN, int KH, int KW>
+static int launch_tiled(float* y, const float* x, const float* k, const UpfirdnGeom& g,
+                        int64_t major, hipStream_t st) {
+    const int tiles_x = (g.out_w + kTileW - 1) / kTileW, tiles_y = (g.out_h + kTileH - 1) / kTileH;
+    const int64_t blocks = (int64_t)tiles_x * tiles_y * major;
+    if (blocks >= ((int64_t)1 << 31)) return fail(E3DGE_ERR_INVALID_ARG, "upfirdn2d: grid too large");
+    upfirdn2d_tiled_kernel<UP, DN, KH, KW><<<dim3((unsigned)blocks), dim3(kUpThreads), 0, st>>>(
+        y, x, k, g, tiles_x, tiles_y);
+    return check_launch("upfirdn2d(tiled)");
+}
+
+}  // namespace e3dge
+
+using namespace e3dge;
+
+extern "C" int e3dge_upfirdn2d_out_size(int in, int up, int down, int pad0, int pad1, int k) {
+    if (in <= 0 || up <= 0 || down <= 0 || k <= 0) return -1;
+    const int num = in * up + pad0 + pad1 - k + down;   // upfirdn2d_kernel.cu:237-240
+    if (num <= 0) return -1;
+    const int out = num / down;
+    return out > 0 ? out : -1;
+}
+
+extern "C" int e3dge_upfirdn2d(float* y, const float* x, const float* k, int64_t major, int in_h,
+                               int in_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                               int pad_x0, int pad_x1, int pad_y0, int pad_y1, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(up_x >= 1 && up_y >= 1 && down_x >= 1 && down_y >= 1, "upfirdn2d: up/down must be >= 1");
+    E3DGE_REQUIRE(kh >= 1 && kw >= 1 && kh <= 32 && kw <= 32, "upfirdn2d: kernel %dx%d outside 1..32", kh, kw);
+    E3DGE_REQUIRE(major >= 0 && in_h >= 1 && in_w >= 1, "upfirdn2d: bad input extent");
+    const int out_h = e3dge_upfirdn2d_out_size(in_h, up_y, down_y, pad_y0, pad_y1, kh);
+    const int out_w = e3dge_upfirdn2d_out_size(in_w, up_x, down_x, pad_x0, pad_x1, kw);
+    E3DGE_REQUIRE(out_h > 0 && out_w > 0, "upfirdn2d: empty output (%d x %d)", out_h, out_w);
+    if (major == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(x && y && k, "upfirdn2d: null pointer");
+    E3DGE_REQUIRE(major * (int64_t)out_h * out_w < ((int64_t)1 << 40), "upfirdn2d: output too large");
+    UpfirdnGeom g{in_h, in_w, out_h, out_w, up_x, up_y, down_x, down_y, pad_x0, pad_y0, kh, kw};
+    hipStream_t st = as_stream(stream);
+    const bool sq = (up_x == up_y) && (down_x == down_y) && kh == 4 && kw == 4;
+    if (sq && up_x == 1 && down_x == 1) return launch_tiled<1, 1, 4, 4>(y, x, k, g, major, st);   // Blur
+    if (sq && up_x == 2 && down_x == 1) return launch_tiled<2, 1, 4, 4>(y, x, k, g, major, st);   // Upsample
+    if (sq && up_x == 1 && down_x == 2) return launch_tiled<1, 2, 4, 4>(y, x, k, g, major, st);   // its gradient / Downsample
+    const int64_t total = major * (int64_t)out_h * out_w;
+    int64_t blocks = (total + kUpThreads - 1) / kUpThreads;
+    if (blocks > 16384) blocks = 16384;
+    upfirdn2d_generic_kernel<<<dim3((unsigned)blocks), dim3(kUpThreads), 0, st>>>(y, x, k, g, total);
+    return check_launch("upfirdn2d(generic)");
+}

@@ -1,0 +1,131 @@
+"""Deterministic synthetic weights, options and inputs (no checkpoints or datasets are reachable offline).
+
+Every tensor is drawn from a legacy numpy RandomState seeded by the CRC32 of its state-dict KEY, so the same
+key gets the same values whichever module (ours, the oracle, or the reference imported by the fixture
+generator) the state dict is loaded into, on any machine.  Ranges follow the reference initialisers
+(volume_renderer.py:53-71, 91-114; stylesdf_model.py:54-64, 179-187, 221-224, 305-308) except where the
+reference initialises to zero and a zero would leave a code path untested (noise weights, biases)."""
+import math
+import zlib
+
+import numpy as np
+import torch
+
+
+class AttrDict(dict):
+    """Minimal stand-in for the Munch objects the reference passes around (attribute + key access)."""
+    __getattr__ = dict.get
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def copy(self):
+        return AttrDict(dict.copy(self))
+
+
+def rendering_opt(N_samples=24, **over):
+    """The rendering options that reach the renderer after base_setup.py:53-56 / train_setup.py:53-56."""
+    o = AttrDict(perturb=0, no_offset_sampling=False, N_samples=N_samples, raw_noise_std=0., return_xyz=True,
+                 return_sdf=True, static_viewdirs=True, no_z_normalize=False, spatial_super_sampling_factor=1,
+                 force_background=True, no_sdf=False, add_fg_mask=False, width=256, depth=8,
+                 camera=AttrDict(dist_radius=0.12, fov=6, azim=0.3, elev=0.15, uniform=False),
+                 enable_local_model=False, return_feats=False, return_feats_layers=[1, 3, 5, 7],
+                 local_modulation_layer_in_backbone=False, local_modulation_layer=False,
+                 use_integrated_surface_normal=False, sample_near_surface=False, sample_uniform_grid=False)
+    o.update(over)
+    return o
+
+
+def model_opt(size=1024, channel_multiplier=2, renderer_spatial_output_dim=64, **over):
+    o = AttrDict(size=size, style_dim=256, channel_multiplier=channel_multiplier, lr_mapping=0.01,
+                 renderer_spatial_output_dim=renderer_spatial_output_dim, project_noise=False,
+                 freeze_renderer=True, is_test=True)
+    o.update(over)
+    return o
+
+
+def _rs(key, seed):
+    return np.random.RandomState((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+
+
+def _kaiming_std(fan_in, a=0.2):
+    return math.sqrt(2.0 / (1 + a * a)) / math.sqrt(fan_in)
+
+
+def synthetic_tensor(key, shape, seed=0):
+    """Value for one state-dict entry, chosen from its name."""
+    rs = _rs(key, seed)
+    shape = tuple(shape)
+    leaf = key.split('.')[-1]
+    u = lambda lim: rs.uniform(-lim, lim, size=shape)
+    if key.endswith('sigmoid_beta'):
+        return torch.full(shape, 0.1, dtype=torch.float32)
+    in_renderer = '.pts_linears.' in key or '.views_linears.' in key or '.rgb_linear.' in key or '.sigma_linear.' in key
+    if in_renderer:
+        if '.gamma.' in key or '.beta.' in key:                      # LinearLayer(style -> W): kaiming * 0.25
+            v = 0.25 * _kaiming_std(256) * rs.standard_normal(shape) if leaf == 'weight' else u(math.sqrt(1 / 256))
+        elif '.pts_linears.0.' in key:
+            v = u(1 / 3) if leaf == 'weight' else u(math.sqrt(1 / 3))
+        elif '.rgb_linear.' in key or '.sigma_linear.' in key:
+            v = u(math.sqrt(6 / 256) / 25) if leaf == 'weight' else u(math.sqrt(1 / 256))
+        else:                                                        # FiLMSiren 256(+3) -> 256
+            fan_in = shape[1] if leaf == 'weight' else (259 if '.views_linears.' in key else 256)
+            v = u(math.sqrt(6 / fan_in) / 25) if leaf == 'weight' else u(math.sqrt(1 / fan_in))
+        return torch.from_numpy(np.asarray(v, dtype=np.float32))
+    if key.startswith('style.') or ('.style.' not in key and key.split('.')[0] == 'style'):
+        v = _kaiming_std(shape[-1]) * rs.standard_normal(shape) if leaf == 'weight' else u(math.sqrt(1 / 256))
+        return torch.from_numpy(np.asarray(v, dtype=np.float32))
+    # ---- decoder ----
+    if '.noises.' in key:
+        v = rs.standard_normal(shape)
+    elif key.endswith('noise.weight'):
+        v = 0.1 + 0.05 * rs.standard_normal(shape)                   # reference init is 0 (:370): untestable
+    elif key.endswith('modulation.bias'):
+        v = 1.0 + 0.05 * rs.standard_normal(shape)                   # bias_init = 1
+    elif key.endswith('activate.bias') or (leaf == 'bias' and len(shape) == 4):
+        v = 0.1 * rs.standard_normal(shape)                          # reference init is 0
+    elif '.style.' in key and leaf == 'weight':
+        v = rs.standard_normal(shape) / 0.01                         # EqualLinear(lr_mul=0.01): randn / lr_mul
+    elif leaf == 'weight':
+        v = rs.standard_normal(shape)
+    elif leaf == 'kernel':
+        raise KeyError("blur kernels are deterministic buffers, not synthetic")
+    else:
+        v = 0.05 * rs.standard_normal(shape)
+    return torch.from_numpy(np.asarray(v, dtype=np.float32))
+
+
+def synthetic_state_dict(module, seed=0, prefix=''):
+    """Deterministic values for every parameter / persistent buffer of `module` (blur kernels untouched).
+    `prefix` is the module's path inside the full generator (e.g. 'renderer.' for a stand-alone
+    VolumeFeatureRenderer) so that it receives the same values it would get as a sub-module."""
+    out = {}
+    for k, v in module.state_dict().items():
+        if k.endswith('.kernel'):
+            continue
+        out[k] = synthetic_tensor(prefix + k, v.shape, seed)
+    return out
+
+
+def load_synthetic(module, seed=0, prefix=''):
+    sd = synthetic_state_dict(module, seed, prefix)
+    missing, unexpected = module.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(m.endswith('.kernel') for m in missing), missing
+    return module
+
+
+def synthetic_inputs(batch=1, seed=1, device="cpu"):
+    """W+ codes for the renderer (B,9,256) and the decoder (B,10,512): 0.1 * N(0,1)."""
+    w_r = 0.1 * np.random.RandomState(seed).standard_normal((batch, 9, 256))
+    w_d = 0.1 * np.random.RandomState(seed + 1).standard_normal((batch, 10, 512))
+    return (torch.from_numpy(w_r.astype(np.float32)).to(device), torch.from_numpy(w_d.astype(np.float32)).to(device))
+
+
+def synthetic_tex_conditions(batch, res, n_samples, seed=5, device="cpu"):
+    """Per-point texture FiLM (alpha, beta), each (B,H,W,S,256): what the local branch would hand over."""
+    rs = np.random.RandomState(seed)
+    shape = (batch, res, res, n_samples, 256)
+    a = 0.1 * rs.standard_normal(shape).astype(np.float32)
+    b = 0.05 * rs.standard_normal(shape).astype(np.float32)
+    return torch.from_numpy(a).to(device), torch.from_numpy(b).to(device)

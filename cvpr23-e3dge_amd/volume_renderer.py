@@ -1,0 +1,429 @@
+"""VolumeFeatureRenderer on the fused gfx950 kernel -- host-side mirror of project/utils/volume_renderer.py.
+
+What is kept identical to the reference (so that `train_setup.py:98-100` can swap the import):
+  * constructor signatures `VolumeFeatureRenderer(opt, style_dim=256, out_im_res=64, mode='train')`,
+    `SirenGenerator(opt, D, W, style_dim, ...)`, `FiLMSiren`, `LinearLayer` and their parameter names, hence
+    the checkpoint keys `renderer.sigmoid_beta`, `renderer.network[.netGlobal].pts_linears.{i}.{weight,bias,
+    gamma.weight,gamma.bias,beta.weight,beta.bias}`, `...views_linears.*`, `...rgb_linear.*`,
+    `...sigma_linear.*`;
+  * `forward(cam_poses, focal, near, far, styles, ...)` keyword list (:1865-1881) and the keys / shapes /
+    layouts of the returned dict (:1270-1287, :1695-1701, :1957-1968);
+  * `run_network(inputs, viewdirs, styles=...)` on arbitrary (B, ..., 3) point sets (:1052-1128).
+
+What differs: nothing is evaluated in PyTorch.  One `e3dge_film_params` launch turns the W+ codes into the 9
+(gamma, beta) pairs, one `e3dge_siren_render_fwd` launch does rays -> samples -> MLP -> composite.  Options
+the fused kernel does not cover (eikonal terms, stratified perturbation, density mode, mesh extraction,
+sample_mode) raise NotImplementedError instead of silently taking another path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _opt_get(opt, name, default=None):
+    if opt is None:
+        return default
+    if isinstance(opt, dict):
+        return opt.get(name, default)
+    return getattr(opt, name, default)
+
+
+class UniformBoxWarp(nn.Module):
+    """Reference :23-30."""
+
+    def __init__(self, sidelength):
+        super().__init__()
+        self.scale_factor = 2 / sidelength
+
+    def forward(self, coordinates):
+        return coordinates * self.scale_factor
+
+
+class LinearLayer(nn.Module):
+    """Parameter holder + initialiser of the reference's LinearLayer (:42-80).
+    out = std_init * (W x + b) + bias_init.  On the render path these are evaluated inside the HIP kernels
+    (gamma/beta in e3dge_film_params, the sdf/rgb heads in the fused renderer); `forward` exists for callers
+    that apply one directly and runs as a GPU torch op."""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, std_init=1, freq_init=False, is_first=False):
+        super().__init__()
+        if is_first:
+            w = torch.empty(out_dim, in_dim).uniform_(-1 / in_dim, 1 / in_dim)
+        elif freq_init:
+            lim = np.sqrt(6 / in_dim) / 25
+            w = torch.empty(out_dim, in_dim).uniform_(-lim, lim)
+        else:
+            w = 0.25 * nn.init.kaiming_normal_(torch.randn(out_dim, in_dim), a=0.2, mode='fan_in',
+                                               nonlinearity='leaky_relu')
+        self.weight = nn.Parameter(w)
+        lim = np.sqrt(1 / in_dim)
+        self.bias = nn.Parameter(torch.empty(out_dim).uniform_(-lim, lim))
+        self.bias_init = bias_init
+        self.std_init = std_init
+
+    def forward(self, input):
+        return self.std_init * torch.nn.functional.linear(input, self.weight, bias=self.bias) + self.bias_init
+
+
+class FiLMSiren(nn.Module):
+    """sin(gamma(style) * (W x + b) + beta(style)) -- parameter holder for reference :84-132."""
+
+    def __init__(self, in_channel, out_channel, style_dim, is_first=False):
+        super().__init__()
+        self.in_channel = in_channel
+        self.out_channel = out_channel
+        if is_first:
+            w = torch.empty(out_channel, in_channel).uniform_(-1 / 3, 1 / 3)
+        else:
+            lim = np.sqrt(6 / in_channel) / 25
+            w = torch.empty(out_channel, in_channel).uniform_(-lim, lim)
+        self.weight = nn.Parameter(w)
+        lim = np.sqrt(1 / in_channel)
+        self.bias = nn.Parameter(torch.empty(out_channel).uniform_(-lim, lim))
+        self.gamma = LinearLayer(style_dim, out_channel, bias_init=30, std_init=15)
+        self.beta = LinearLayer(style_dim, out_channel, bias_init=0, std_init=0.25)
+
+
+class SirenGenerator(nn.Module):
+    """The StyleSDF MLP (reference :136-264) as a parameter container plus the two device-side caches the
+    kernels consume: the MFMA fragment-major weight image and the stacked gamma/beta matrices."""
+
+    def __init__(self, opt=None, D=8, W=256, style_dim=256, input_ch=3, input_ch_views=3, output_ch=4,
+                 output_features=True, scene_scale=0.12, **kwargs):
+        super().__init__()
+        if D != 8 or W != 256 or style_dim != 256 or input_ch != 3 or input_ch_views != 3:
+            raise NotImplementedError(
+                f"the gfx950 kernels are specialised for D=8, W=256, style_dim=256, 3+3 inputs "
+                f"(got D={D}, W={W}, style_dim={style_dim}, input_ch={input_ch}, views={input_ch_views})")
+        self.opt = opt
+        self.D, self.W = D, W
+        self.input_ch, self.input_ch_views = input_ch, input_ch_views
+        self.style_dim = style_dim
+        self.output_features = output_features
+        self.pts_linears = nn.ModuleList(
+            [FiLMSiren(3, W, style_dim=style_dim, is_first=True)] +
+            [FiLMSiren(W, W, style_dim=style_dim) for _ in range(D - 1)])
+        self.views_linears = FiLMSiren(input_ch_views + W, W, style_dim=style_dim)
+        self.rgb_linear = LinearLayer(W, 3, freq_init=True)
+        self.sigma_linear = LinearLayer(W, 1, freq_init=True)
+        self._cache_key = None
+        self._cache = None
+
+    # -- device caches -------------------------------------------------------------------------------
+    def _film_layers(self):
+        return list(self.pts_linears) + [self.views_linears]
+
+    def _key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def device_image(self):
+        """(packed, wg, bg, wb, bb): rebuilt only when a parameter changed (or moved)."""
+        key = self._key()
+        if self._cache is not None and key == self._cache_key:
+            return self._cache
+        w0 = self.pts_linears[0].weight
+        _lib.require_gpu(w0, "SirenGenerator parameters")
+        lib = _lib.load()
+        with torch.no_grad():
+            dev = w0.device
+            f32 = dict(device=dev, dtype=torch.float32)
+            w_first = self.pts_linears[0].weight.detach().contiguous()
+            b_first = self.pts_linears[0].bias.detach().contiguous()
+            w_hidden = torch.stack([l.weight.detach() for l in self.pts_linears[1:]]).contiguous()
+            b_hidden = torch.stack([l.bias.detach() for l in self.pts_linears[1:]]).contiguous()
+            w_view = self.views_linears.weight.detach().contiguous()
+            b_view = self.views_linears.bias.detach().contiguous()
+            w_rgb = self.rgb_linear.weight.detach().contiguous()
+            b_rgb = self.rgb_linear.bias.detach().contiguous()
+            w_sig = self.sigma_linear.weight.detach().contiguous()
+            b_sig = self.sigma_linear.bias.detach().contiguous()
+            if self.rgb_linear.std_init != 1 or self.rgb_linear.bias_init != 0 or \
+                    self.sigma_linear.std_init != 1 or self.sigma_linear.bias_init != 0:
+                raise NotImplementedError("head LinearLayers with std_init != 1 / bias_init != 0")
+            packed = torch.empty(lib.e3dge_siren_packed_floats(), **f32)
+            with torch.cuda.device(dev):
+                rc = lib.e3dge_siren_pack_weights(
+                    _lib.ptr(packed), _lib.ptr(w_first), _lib.ptr(b_first), _lib.ptr(w_hidden), _lib.ptr(b_hidden),
+                    _lib.ptr(w_view), _lib.ptr(b_view), _lib.ptr(w_rgb), _lib.ptr(b_rgb), _lib.ptr(w_sig),
+                    _lib.ptr(b_sig), _lib.stream_of(packed))
+            _lib.check(rc, "e3dge_siren_pack_weights")
+            layers = self._film_layers()
+            wg = torch.stack([l.gamma.weight.detach() for l in layers]).contiguous()
+            bg = torch.stack([l.gamma.bias.detach() for l in layers]).contiguous()
+            wb = torch.stack([l.beta.weight.detach() for l in layers]).contiguous()
+            bb = torch.stack([l.beta.bias.detach() for l in layers]).contiguous()
+        self._cache, self._cache_key = (packed, wg, bg, wb, bb), key
+        return self._cache
+
+    def film_params(self, styles):
+        """styles (B,9,256) [W+] or (B,256) [W, shared by all layers, reference :189-191] -> (B,9,2,256)."""
+        _lib.require_gpu(styles, "styles")
+        if styles.ndim == 2:
+            styles = styles.unsqueeze(1).expand(-1, 9, -1)
+        if styles.ndim != 3 or styles.shape[1] != 9 or styles.shape[2] != self.style_dim:
+            raise RuntimeError(f"styles must be (B, 9, {self.style_dim}) or (B, {self.style_dim}); got {tuple(styles.shape)}")
+        styles = styles.contiguous()
+        _, wg, bg, wb, bb = self.device_image()
+        B = styles.shape[0]
+        film = torch.empty((B, 9, 2, self.W), device=styles.device, dtype=torch.float32)
+        with torch.cuda.device(styles.device):
+            rc = _lib.load().e3dge_film_params(_lib.ptr(film), _lib.ptr(styles), _lib.ptr(wg), _lib.ptr(bg),
+                                               _lib.ptr(wb), _lib.ptr(bb), B, _lib.stream_of(styles))
+        _lib.check(rc, "e3dge_film_params")
+        return film
+
+    def query_points(self, pts, viewdirs, styles, box_scale, want_raw=True):
+        """pts (B, N, 3) world-space, viewdirs (B, N, 3) or None -> (sdf (B,N), raw (B,N,260) or None)."""
+        _lib.require_gpu(pts, "pts")
+        packed = self.device_image()[0]
+        film = self.film_params(styles)
+        pts = pts.contiguous()
+        vd = None if viewdirs is None else viewdirs.contiguous()
+        B, N, _ = pts.shape
+        sdf = torch.empty((B, N), device=pts.device, dtype=torch.float32)
+        raw = torch.empty((B, N, 260), device=pts.device, dtype=torch.float32) if want_raw else None
+        with torch.cuda.device(pts.device):
+            rc = _lib.load().e3dge_siren_points_fwd(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(pts), _lib.ptr(vd),
+                                                    float(box_scale), B, N, _lib.ptr(sdf), _lib.ptr(raw),
+                                                    _lib.stream_of(pts))
+        _lib.check(rc, "e3dge_siren_points_fwd")
+        return sdf, raw
+
+    def forward(self, net_inputs, styles, residuals=None):
+        """(B, ..., 6) = [box-warped xyz, viewdir] -> (B, ..., 260) = [rgb3, sdf1, feat256] (reference :240-264).
+        The points are already warped here, so the kernel's box scale is 1."""
+        lead = net_inputs.shape[:-1]
+        B = net_inputs.shape[0]
+        flat = net_inputs.reshape(B, -1, 6)
+        _, raw = self.query_points(flat[..., :3], flat[..., 3:], styles, 1.0, want_raw=True)
+        return raw.reshape(*lead, 260)
+
+
+class SirenLocalGlobal(nn.Module):
+    """Holder that keeps the `network.netGlobal.*` checkpoint keys of the reference's local+global wrapper
+    (:267-558).  The PIFu local branch itself (netLocal) is outside this build; its OUTPUT --
+    per-point texture FiLM (alpha, beta), each (B,H,W,S,256) -- is accepted through
+    `local_data_batch['tex']` and applied inside the fused kernel (:217-220)."""
+
+    def __init__(self, D=8, W=256, style_dim=256, input_ch=3, input_ch_views=3, output_ch=4,
+                 output_features=True, scene_scale=0.12, local_options=None, opt=None):
+        super().__init__()
+        self.opt = opt
+        self.netGlobal = SirenGenerator(opt, D, W, style_dim, input_ch, input_ch_views, output_ch,
+                                        output_features, scene_scale)
+
+
+class VolumeFeatureRenderer(nn.Module):
+    """Drop-in for the reference class (:636-2043) on the inference configuration."""
+
+    def __init__(self, opt, style_dim=256, out_im_res=64, mode='train'):
+        super().__init__()
+        self.test = mode != 'train'
+        self.opt = opt
+        self.perturb = _opt_get(opt, 'perturb', 0)
+        self.offset_sampling = not _opt_get(opt, 'no_offset_sampling', False)
+        self.N_samples = int(_opt_get(opt, 'N_samples', 24))
+        self.raw_noise_std = _opt_get(opt, 'raw_noise_std', 0.)
+        self.return_xyz = _opt_get(opt, 'return_xyz', True)
+        self.return_sdf = True                                   # hard-wired in the reference (:648)
+        self.static_viewdirs = _opt_get(opt, 'static_viewdirs', True)
+        self.z_normalize = not _opt_get(opt, 'no_z_normalize', False)
+        self.out_im_res = out_im_res
+        self.spatial_ss = _opt_get(opt, 'spatial_super_sampling_factor', 1)
+        self.force_background = _opt_get(opt, 'force_background', True)
+        self.with_sdf = not _opt_get(opt, 'no_sdf', False)
+        self.add_fg_mask = _opt_get(opt, 'add_fg_mask', False)
+        keys = opt.keys() if hasattr(opt, 'keys') else ()
+        self.output_features = 'no_features_output' not in keys
+        if self.with_sdf:
+            self.sigmoid_beta = nn.Parameter(0.1 * torch.ones(1))
+        # pixel-centre grids (:666-674); kept as buffers for callers that read them, the kernel regenerates them
+        lin = torch.linspace(0.5, out_im_res - 0.5, out_im_res * self.spatial_ss)
+        i, j = torch.meshgrid(lin, lin, indexing='ij')
+        self.register_buffer('i', i.t().unsqueeze(0), persistent=False)
+        self.register_buffer('j', j.t().unsqueeze(0), persistent=False)
+        if self.offset_sampling:
+            t_vals = torch.linspace(0., 1. - 1 / self.N_samples, steps=self.N_samples).reshape(1, 1, 1, -1)
+        else:
+            t_vals = torch.linspace(0., 1., steps=self.N_samples).reshape(1, 1, 1, -1)
+        self.register_buffer('t_vals', t_vals, persistent=False)
+        self.register_buffer('inf', torch.Tensor([1e10]), persistent=False)
+        if self.test:
+            self.perturb = False
+            self.raw_noise_std = 0.
+        self.channel_dim = -1
+        self.samples_dim = 3
+        self.input_ch = 3
+        self.input_ch_views = 3
+        self.feature_out_size = _opt_get(opt, 'width', 256)
+        camera = _opt_get(opt, 'camera', None)
+        self.dist_radius = float(_opt_get(camera, 'dist_radius', 0.12))
+        self.grid_warper = UniformBoxWarp(self.dist_radius * 2)
+        self.grid_un_warper = UniformBoxWarp(1 / self.dist_radius * 2)
+        self.enable_local_model = bool(_opt_get(opt, 'enable_local_model', False))
+        net_kwargs = dict(opt=opt, D=_opt_get(opt, 'depth', 8), W=_opt_get(opt, 'width', 256), style_dim=style_dim,
+                          input_ch=self.input_ch, output_ch=4, input_ch_views=self.input_ch_views,
+                          output_features=self.output_features)
+        if self.enable_local_model:
+            self.network = SirenLocalGlobal(local_options=_opt_get(opt, 'pifu', None), **net_kwargs)
+        else:
+            self.network = SirenGenerator(**net_kwargs)
+        self.register_buffer('B_MAX', torch.Tensor([self.dist_radius] * 3), persistent=False)
+        self.register_buffer('B_MIN', -torch.Tensor([self.dist_radius] * 3), persistent=False)
+        self.local_batch = None
+        self.sample_mode = False
+        self.mask_depth_thresh = 1.08                            # :910
+        self._check_supported()
+
+    # -------------------------------------------------------------------------------------------------
+    def _check_supported(self):
+        bad = []
+        if not self.with_sdf: bad.append("no_sdf (density mode)")
+        if not self.offset_sampling: bad.append("no_offset_sampling")
+        if not self.static_viewdirs: bad.append("static_viewdirs=False")
+        if not self.z_normalize: bad.append("no_z_normalize")
+        if self.spatial_ss != 1: bad.append("spatial_super_sampling_factor != 1")
+        if not self.output_features: bad.append("no_features_output")
+        if not self.return_xyz: bad.append("return_xyz=False")
+        if _opt_get(self.opt, 'return_feats', False): bad.append("return_feats")
+        if bad:
+            raise NotImplementedError("VolumeFeatureRenderer (gfx950): unsupported options: " + ", ".join(bad))
+
+    @property
+    def siren(self):
+        return self.network.netGlobal if self.enable_local_model else self.network
+
+    @property
+    def box_scale(self):
+        return self.grid_warper.scale_factor
+
+    # -------------------------------------------------------------------------------------------------
+    def run_network(self, inputs, viewdirs, normalize=True, styles=None, global_only=False,
+                    return_sdf_only=False, **kwargs):
+        """Un-composited network query on arbitrary points (reference :1052-1128).
+        inputs (B, ..., 3) world-space; viewdirs broadcastable to it."""
+        if viewdirs.shape != inputs.shape:
+            if viewdirs.ndim != inputs.ndim:
+                viewdirs = viewdirs.unsqueeze(self.samples_dim)
+            viewdirs = viewdirs.expand(inputs.shape)
+        lead = inputs.shape[:-1]
+        B = inputs.shape[0]
+        sdf, raw = self.siren.query_points(inputs.reshape(B, -1, 3), viewdirs.reshape(B, -1, 3), styles,
+                                           self.box_scale, want_raw=not return_sdf_only)
+        if return_sdf_only:
+            return sdf.reshape(*lead, 1)
+        return raw.reshape(*lead, 260)
+
+    # -------------------------------------------------------------------------------------------------
+    def render(self, focal, c2w, near, far, styles, tex_conditions=None):
+        """Fused rays -> samples -> MLP -> composite.  Returns the dict of render_rays + render
+        (:1270-1287, :1695-1701), before forward()'s permutes (already applied here for free: the kernel
+        writes channel-first directly)."""
+        for name, t in (("cam_poses", c2w), ("focal", focal), ("near", near), ("far", far)):
+            _lib.require_gpu(t, name)
+        if not self.test and (self.perturb or self.raw_noise_std):
+            raise NotImplementedError("stratified perturbation / raw noise (train-mode sampling) is not covered by "
+                                      "the fused kernel; construct with mode='test' or perturb=0")
+        B = c2w.shape[0]
+        H = Wd = self.out_im_res
+        S = self.N_samples
+        dev = c2w.device
+        siren = self.siren
+        packed = siren.device_image()[0]
+        film = siren.film_params(styles)
+        c2w_c = c2w[:, :3, :4].contiguous()
+        focal_c = focal.reshape(B).contiguous()
+        near_c = near.reshape(B).contiguous()
+        far_c = far.reshape(B).contiguous()
+        ta = tb = None
+        if tex_conditions is not None:
+            ta, tb = tex_conditions
+            _lib.require_gpu(ta, "tex alpha"); _lib.require_gpu(tb, "tex beta")
+            if tuple(ta.shape) != (B, H, Wd, S, 256) or tuple(tb.shape) != (B, H, Wd, S, 256):
+                raise RuntimeError(f"tex conditions must be (B,H,W,S,256) = {(B, H, Wd, S, 256)}; got {tuple(ta.shape)}")
+            ta, tb = ta.contiguous(), tb.contiguous()
+        f32 = dict(device=dev, dtype=torch.float32)
+        out = dict(
+            rgb=torch.empty((B, 3, H, Wd), **f32), features=torch.empty((B, 256, H, Wd), **f32),
+            xyz=torch.empty((B, 3, H, Wd), **f32), depth=torch.empty((B, H, Wd, 1, 1), **f32),
+            mask=torch.empty((B, 1, H, Wd, 1), **f32), sdf=torch.empty((B, H, Wd, S, 1), **f32),
+            weights=torch.empty((B, H, Wd, S, 1), **f32), points=torch.empty((B, H, Wd, S, 3), **f32),
+            rays_d=torch.empty((B, H, Wd, 3), **f32), viewdirs=torch.empty((B, H, Wd, 3), **f32),
+            dists=torch.empty((B, H, Wd, S), **f32))
+        args = _lib.RenderArgs(
+            packed=_lib.ptr(packed), film=_lib.ptr(film), c2w=_lib.ptr(c2w_c), focal=_lib.ptr(focal_c),
+            near=_lib.ptr(near_c), far=_lib.ptr(far_c), t_vals=_lib.ptr(self.t_vals),
+            tex_alpha=_lib.ptr(ta), tex_beta=_lib.ptr(tb),
+            sigmoid_beta=self._sigmoid_beta_value(),
+            box_scale=float(self.box_scale), mask_depth_thresh=float(self.mask_depth_thresh),
+            batch=B, height=H, width=Wd, n_samples=S, res=int(self.out_im_res),
+            force_background=int(bool(self.force_background)),
+            rgb=_lib.ptr(out['rgb']), features=_lib.ptr(out['features']), xyz=_lib.ptr(out['xyz']),
+            depth=_lib.ptr(out['depth']), mask=_lib.ptr(out['mask']), sdf=_lib.ptr(out['sdf']),
+            weights=_lib.ptr(out['weights']), points=_lib.ptr(out['points']), rays_d=_lib.ptr(out['rays_d']),
+            viewdirs=_lib.ptr(out['viewdirs']), dists=_lib.ptr(out['dists']))
+        with torch.cuda.device(dev):
+            rc = _lib.load().e3dge_siren_render_fwd(ctypes.byref(args), _lib.stream_of(c2w))
+        _lib.check(rc, "e3dge_siren_render_fwd")
+        rays_o = c2w[:, None, None, :3, -1].expand(B, H, Wd, 3)
+        return {
+            'rays_o': rays_o, 'rays_d': out['rays_d'], 'dists': out['dists'],
+            'near': near.reshape(B, 1, 1, 1).expand(B, H, Wd, 1), 'far': far.reshape(B, 1, 1, 1).expand(B, H, Wd, 1),
+            'hit_prob': out['weights'], 'surface_eikonal_term': None, 'points': out['points'], 'sdf': out['sdf'],
+            'gen_thumb_imgs': out['rgb'], 'features': out['features'], 'mask': out['mask'], 'xyz': out['xyz'],
+            'eikonal_term': None, 'depth': out['depth'],
+            'mesh': None, 'shading_mesh': None, 'debug_mesh': None, 'viewdirs': out['viewdirs'],
+        }
+
+    def _sigmoid_beta_value(self):
+        """Host copy of the learned sigmoid_beta, refreshed only when the parameter changes (a `.item()` per
+        call would put a device synchronisation in front of every render)."""
+        p = self.sigmoid_beta
+        key = (p.data_ptr(), p._version)
+        if getattr(self, '_sb_key', None) != key:
+            self._sb_val, self._sb_key = float(p.detach().item()), key
+        return self._sb_val
+
+    # -------------------------------------------------------------------------------------------------
+    def forward(self, cam_poses, focal, near, far, styles=None, return_eikonal=False, geometry_sample=None,
+                return_surface_eikonal=False, local_data_batch=None, sample_mode=False, return_mesh=False,
+                mesh_with_shading=True, return_sdf_only=False, **kwargs):
+        if return_eikonal or return_surface_eikonal:
+            raise NotImplementedError("eikonal terms need the backward kernels (SURVEY.md 7 step 5); not in this build")
+        if sample_mode:
+            raise NotImplementedError("sample_mode (near-surface / uniform-grid sampling) is not in this build")
+        if return_mesh:
+            raise NotImplementedError("marching-cubes mesh extraction is out of scope (SURVEY.md 2 #13)")
+        if torch.is_grad_enabled() and isinstance(styles, torch.Tensor) and styles.requires_grad:
+            raise NotImplementedError("backward through the fused renderer is not in this build; wrap the call in "
+                                      "torch.no_grad() (the reference's test path runs under inference_mode)")
+        self.sample_mode = False
+        tex = None
+        if self.enable_local_model and local_data_batch is not None:
+            if 'tex' in local_data_batch:
+                tex = local_data_batch['tex']
+            else:
+                raise NotImplementedError(
+                    "local_data_batch must carry the texture FiLM conditions as local_data_batch['tex'] = (alpha, "
+                    "beta); computing them from 'feats' needs the PIFu head (SURVEY.md 8f-1)")
+            self.local_batch = local_data_batch
+        else:
+            self.local_batch = None
+
+        render_out = self.render(focal, cam_poses, near, far, styles, tex_conditions=tex)
+
+        if geometry_sample:   # 3-D supervision re-queries (:1916-1949)
+            corpus = ['uniform_pts'] + (['xyz'] if geometry_sample.get('xyz', None) is not None else [])
+            for k in corpus:
+                if k not in geometry_sample:
+                    continue
+                samples = geometry_sample[k]
+                if samples.ndim == 4:
+                    samples = samples.unsqueeze(self.samples_dim)
+                render_out[f'{k}_rec'] = self.run_network(samples, torch.zeros_like(samples), styles=styles,
+                                                          return_sdf_only=True)
+        return render_out

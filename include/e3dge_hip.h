@@ -1,0 +1,189 @@
+/*
+ * e3dge_hip.h -- C-ABI of libe3dge_hip.so: the MI355X (gfx950) volume-rendering hot path of E3DGE.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers + sizes + a HIP stream, allocates
+ * nothing, never synchronises, and returns 0 on success or a negative E3DGE_ERR_* code (the message is
+ * available from e3dge_last_error()).  All tensors are fp32, contiguous, resident in HBM.
+ *
+ * Each function names the reference interface it replaces (paths relative to the reference checkout).
+ * The Python host side (cvpr23-e3dge_amd/_lib.py) binds these with ctypes; INTEGRATION.md shows the
+ * stub a reference maintainer would add.
+ */
+#ifndef E3DGE_HIP_H
+#define E3DGE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* e3dge_stream_t; /* a hipStream_t (NULL = the legacy default stream) */
+
+enum {
+    E3DGE_OK = 0,
+    E3DGE_ERR_INVALID_ARG = -1, /* bad size / unsupported configuration / null pointer */
+    E3DGE_ERR_LAUNCH = -2,      /* hipLaunchKernel / hipFuncSetAttribute failed          */
+    E3DGE_ERR_UNSUPPORTED = -3  /* valid for the reference but outside this build's coverage */
+};
+
+/* ABI version; bumped whenever a signature below changes. */
+int e3dge_abi_version(void);
+/* Thread-local message of the most recent failing call on this thread ("" if none). */
+const char* e3dge_last_error(void);
+
+/* --------------------------------------------------------------------------------------------
+ * StyleGAN2 custom ops (reference: project/models/op/)
+ * ------------------------------------------------------------------------------------------ */
+
+/*
+ * Replaces fused_bias_act_op / fused_bias_act_kernel
+ * (project/models/op/fused_bias_act_kernel.cu:19-98, binding fused_bias_act.cpp:11-20).
+ *   y[i] = act(x[i] + bias[(i / step_b) % size_b]) * scale
+ *   act*10+grad: 10/11 linear, 12 -> 0, 30 lrelu(x>0 ? x : alpha x), 31 lrelu-grad gated by sign of
+ *   ref[i] (the saved forward OUTPUT), 32 -> 0.
+ * bias may be NULL (size_b == 0), ref may be NULL (treated as 0, as the reference does).
+ * n < 2^31 (the reference indexes with int32, :66).
+ */
+int e3dge_fused_bias_act(float* y, const float* x, const float* bias, const float* ref, int act,
+                         int grad, float alpha, float scale, int64_t n, int64_t step_b,
+                         int64_t size_b, e3dge_stream_t stream);
+
+/*
+ * StyledConv tail fused into one pass: NoiseInjection + FusedLeakyReLU
+ * (project/models/stylesdf_model.py:459-466 and :500-507 followed by fused_act.py:55-118):
+ *   y[b,c,h,w] = lrelu(x[b,c,h,w] + noise_weight[0] * noise[b % noise_batch, 0, h, w] + bias[c], alpha) * scale
+ * x,y: (batch, channels, hw) ; noise: (noise_batch, hw) with noise_batch in {1, batch};
+ * noise_weight: device pointer to the 1-element NoiseInjection.weight.
+ */
+int e3dge_noise_bias_act(float* y, const float* x, const float* noise, const float* noise_weight,
+                         const float* bias, float alpha, float scale, int64_t batch,
+                         int64_t channels, int64_t hw, int64_t noise_batch,
+                         e3dge_stream_t stream);
+
+/*
+ * Replaces upfirdn2d_op / upfirdn2d_kernel{,_large}
+ * (project/models/op/upfirdn2d_kernel.cu:49-369, binding upfirdn2d.cpp:12-23) for minor_dim == 1,
+ * which is the only way the Python wrappers call it (upfirdn2d.py:27,78,96).
+ * x: (major, in_h, in_w); k: (kh, kw) FIR, correlated FLIPPED (upfirdn2d_kernel.cu:137);
+ * y: (major, out_h, out_w) with out = (in*up + pad0 + pad1 - k + down) / down (:237-240).
+ * Negative pads crop.  kh, kw <= 32.
+ */
+int e3dge_upfirdn2d(float* y, const float* x, const float* k, int64_t major, int in_h, int in_w,
+                    int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                    int pad_x1, int pad_y0, int pad_y1, e3dge_stream_t stream);
+/* Output extent helper (same formula as above); returns <0 if the result would be empty. */
+int e3dge_upfirdn2d_out_size(int in, int up, int down, int pad0, int pad1, int k);
+
+/*
+ * ModulatedConv2d weight preparation (project/models/stylesdf_model.py:317-338) in one pass:
+ *   w'[b,o,i,:] = scale * weight[o,i,:] * style[b,i];  if demod: w' *= rsqrt(sum_{i,k} w'^2 + 1e-8)
+ * weight: (co, ci, kk) ; style: (batch, ci) (already through `modulation`) ;
+ * transpose == 0 -> out (batch*co, ci, kk)   [F.conv2d, groups=batch]
+ * transpose == 1 -> out (batch*ci, co, kk)   [F.conv_transpose2d, groups=batch]
+ */
+int e3dge_modconv_weights(float* out, const float* weight, const float* style, float scale,
+                          int demodulate, int transpose, int batch, int co, int ci, int kk,
+                          e3dge_stream_t stream);
+
+/* --------------------------------------------------------------------------------------------
+ * FiLM-SIREN volume renderer (reference: project/utils/volume_renderer.py)
+ * ------------------------------------------------------------------------------------------ */
+
+#define E3DGE_SIREN_WIDTH 256     /* W (options.py:841-844); the kernels are specialised for 256 */
+#define E3DGE_SIREN_DEPTH 8       /* D backbone layers (options.py:837-840)                       */
+#define E3DGE_SIREN_NLAYERS 9     /* D + views_linears                                           */
+
+/* Number of floats of the packed weight image produced by e3dge_siren_pack_weights. */
+int64_t e3dge_siren_packed_floats(void);
+
+/*
+ * Re-lays the SirenGenerator parameters (volume_renderer.py:158-166; FiLMSiren.weight/bias :91-104,
+ * rgb_linear / sigma_linear :165-166) into the MFMA fragment-major image the render kernels stream
+ * through LDS.  Call once per weight update.  All inputs row-major (out, in) as in the state dict:
+ *   w_first (256,3)  b_first (256)            pts_linears.0
+ *   w_hidden (7,256,256)  b_hidden (7,256)    pts_linears.1..7
+ *   w_view (256,259)  b_view (256)            views_linears  (input = [features(256), viewdir(3)])
+ *   w_rgb (3,256) b_rgb (3) ; w_sigma (1,256) b_sigma (1)
+ * packed: e3dge_siren_packed_floats() floats.
+ */
+int e3dge_siren_pack_weights(float* packed, const float* w_first, const float* b_first,
+                             const float* w_hidden, const float* b_hidden, const float* w_view,
+                             const float* b_view, const float* w_rgb, const float* b_rgb,
+                             const float* w_sigma, const float* b_sigma, e3dge_stream_t stream);
+
+/*
+ * FiLM parameters of all 9 layers for a batch of W+ codes
+ * (FiLMSiren.gamma / .beta = LinearLayer(std_init=15,bias_init=30) / (std_init=0.25),
+ *  volume_renderer.py:76-80,107-120):
+ *   film[b,l,0,:] = 15  * (Wg_l styles[b,l] + bg_l) + 30
+ *   film[b,l,1,:] = 0.25 * (Wb_l styles[b,l] + bb_l)
+ * styles (batch, 9, 256); wg, wb (9,256,256); bg, bb (9,256); film (batch, 9, 2, 256).
+ */
+int e3dge_film_params(float* film, const float* styles, const float* wg, const float* bg,
+                      const float* wb, const float* bb, int batch, e3dge_stream_t stream);
+
+/* Inputs/outputs of one fused render launch; unused outputs may be NULL. */
+typedef struct E3dgeRenderArgs {
+    /* ---- inputs ---- */
+    const float* packed;   /* from e3dge_siren_pack_weights                                      */
+    const float* film;     /* (batch, 9, 2, 256) from e3dge_film_params                           */
+    const float* c2w;      /* (batch, 3, 4) camera-to-world (cam_poses)                            */
+    const float* focal;    /* (batch)                                                              */
+    const float* near;     /* (batch)                                                              */
+    const float* far;      /* (batch)                                                              */
+    const float* t_vals;   /* (n_samples) -- VolumeFeatureRenderer.t_vals (:690-698)                */
+    const float* tex_alpha;/* optional (batch,H,W,S,256) per-point texture FiLM alpha (:217-220)     */
+    const float* tex_beta; /* optional, same shape                                                  */
+    float sigmoid_beta;    /* renderer.sigmoid_beta (:663)                                         */
+    float box_scale;       /* grid_warper scale = 2 / (2*dist_radius) (:720)                        */
+    float mask_depth_thresh; /* 1.08 (:910)                                                        */
+    int batch, height, width, n_samples;
+    int res;               /* out_im_res used for the pixel-centre offset (:773-774)                */
+    int force_background;  /* (:884-886)                                                           */
+    /* ---- outputs ---- */
+    float* rgb;            /* (batch, 3, H, W)    gen_thumb_imgs (:888-890, permuted :1964)          */
+    float* features;       /* (batch, 256, H, W)  (:894, :1967)                                     */
+    float* xyz;            /* (batch, 3, H, W)    (:905, :1958)                                     */
+    float* depth;          /* (batch, H, W)       (:907)                                            */
+    float* mask;           /* (batch, H, W)       (:910)                                            */
+    float* sdf;            /* (batch, H, W, S)    (:880)                                            */
+    float* weights;        /* (batch, H, W, S)    hit_prob (:877,:885)                              */
+    float* points;         /* (batch, H, W, S, 3) (:1231)                                           */
+    float* rays_d;         /* (batch, H, W, 3)    (:782)                                            */
+    float* viewdirs;       /* (batch, H, W, 3)    normalised (:1679)                                */
+    float* dists;          /* (batch, H, W, S)    (:826-837)                                        */
+} E3dgeRenderArgs;
+
+/*
+ * Replaces VolumeFeatureRenderer.render -> render_rays -> run_network -> SirenGenerator.forward ->
+ * volume_integration (volume_renderer.py:1666-1701, 1183-1287, 1052-1128, 168-264, 809-943) for the
+ * inference configuration (offset_sampling, static_viewdirs, perturb=0, with_sdf, return_xyz):
+ * ray generation, sample placement, the 9 FiLM-SIREN layers, both heads, SDF->alpha, transmittance
+ * scan and all composites in ONE kernel; the (B,H,W,S,260) raw tensor never exists.
+ * Requires n_samples >= 16 (or use e3dge_siren_points_fwd for un-composited queries).
+ */
+int e3dge_siren_render_fwd(const E3dgeRenderArgs* args, e3dge_stream_t stream);
+
+/*
+ * Replaces VolumeFeatureRenderer.run_network on an arbitrary point set
+ * (volume_renderer.py:1052-1128; callers :925-930, :1916-1949, sample_uniform_grid :945-).
+ * pts (batch, n_pts, 3) world-space (box warp applied inside); viewdirs (batch, n_pts, 3) or NULL (= 0).
+ * Outputs (any may be NULL): sdf (batch, n_pts); raw (batch, n_pts, 260) = [rgb3, sdf1, feat256]
+ * exactly as SirenGenerator.forward concatenates them (:259-261).
+ */
+int e3dge_siren_points_fwd(const float* packed, const float* film, const float* pts,
+                           const float* viewdirs, float box_scale, int batch, int64_t n_pts,
+                           float* sdf, float* raw, e3dge_stream_t stream);
+
+/* Layout self-test: runs a 32x32xK fp32-MFMA product with the fragment conventions the render kernel
+ * relies on and writes it to c (32*32 floats, row-major) for the caller to compare with a @ b^T.
+ * a: (32, k) row-major, b: (32, k) row-major, k multiple of 8, k <= 256. */
+int e3dge_selftest_mfma(float* c, const float* a, const float* b, int k, e3dge_stream_t stream);
+/* Accuracy self-test of the kernel's sine: y[i] = sin(x[i]) with the device routine the SIREN layers use. */
+int e3dge_selftest_sin(float* y, const float* x, int n, e3dge_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E3DGE_HIP_H */
