@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""bench.py -- the BASELINE.json metric on MI355X: rendered rays/s at 64x64 rays x 24 samples.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch of synthetic input on every rank: W+ codes -> FiLM parameters
+(e3dge_film_params) -> fused ray generation + SIREN + compositing (e3dge_siren_render_fwd) for ONE 64x64 image
+x 24 samples per GPU (BASELINE.json configs[1]; inputs already resident in HBM).  Images shard across ranks
+with no data-path collective (weak scaling); `value` = rays rendered by all ranks / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (siren_kernel<0>): algorithmic fp32 FLOPs per launch / its mean duration measured
+                with HIP events on the launch stream inside the timed region, against the dense fp32 MFMA peak.
+  cpu_baseline  the oracle restatement (oracle/renderer_ref.py, "port": it is bit-identical to the reference's
+                PyTorch path on the golden vectors) timed on this host's cores on a bounded sample.
+  inversion_fwd_ms   (informational) pass #1 + pass #2 with texture FiLM + decoder to 1024^2, one image.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+RES, N_SAMPLES = 64, 24
+MAC_PER_POINT = 3 * 256 + 7 * 256 * 256 + 259 * 256 + 256 * 3 + 256       # 526,848
+FLOP_PER_RAY = 2 * MAC_PER_POINT * N_SAMPLES                               # 25.29 MFLOP
+BYTES_PER_RAY = (264 + 5 * N_SAMPLES) * 4                                  # mandatory outputs, 1,536 B
+PEAK_F32_MFMA_TFLOPS = 157.3                                               # MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (metric config: 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inversion", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import e3dge_amd  # noqa: F401
+    from e3dge_amd import synthetic as syn
+    from e3dge_amd.camera_utils import generate_camera_params
+    from e3dge_amd.stylesdf_model import G_pred_latents
+
+    g = G_pred_latents(syn.model_opt(), syn.rendering_opt(N_samples=N_SAMPLES), full_pipeline=True)
+    syn.load_synthetic(g)
+    sd_cpu = {k: v.clone() for k, v in g.state_dict().items()} if rank == 0 else None
+    g = g.to(dev).eval()
+    renderer = g.renderer
+    B = args.batch
+    wr, wd = syn.synthetic_inputs(B, seed=1 + 17 * rank, device=dev)      # every rank renders its own image(s)
+    poses, focal, near, far, _ = generate_camera_params(RES, dev, locations=torch.zeros(B, 2, device=dev))
+    renderer.siren.device_image()                                          # weight image packed once, outside the loop
+
+    def step():
+        film = renderer.siren.film_params(wr)
+        return film
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            renderer.render_with_film(step(), focal, poses, near, far)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            film = step()
+            ev[i][0].record()                                              # same stream the kernel is launched on
+            out = renderer.render_with_film(film, focal, poses, near, far)
+            ev[i][1].record()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+    assert torch.isfinite(out['gen_thumb_imgs']).all()
+
+    rays_per_step = B * RES * RES * world
+    value = rays_per_step * args.steps / elapsed
+    result = {
+        "metric": "rendered_rays_per_sec_64x64x24", "value": value, "unit": "rays/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C2: single-image W+ -> volume render, 64x64 rays x 24 samples per ray, "
+                               f"{B} image(s) per GPU per step (film_params + fused render launch)",
+                   "rays_per_gpu_per_step": B * RES * RES, "samples_per_ray": N_SAMPLES, "parallelism": f"images sharded x{world}"},
+    }
+    if rank == 0:
+        flops = FLOP_PER_RAY * B * RES * RES
+        achieved = flops / (kern_ms * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "kernel": "siren_kernel<0> (e3dge_siren_render_fwd)", "achieved": achieved,
+                              "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                              "kernel_ms": kern_ms, "flop_per_launch": flops,
+                              "algorithmic_output_bytes_per_launch": BYTES_PER_RAY * B * RES * RES,
+                              "hbm_frac_of_8TBps": BYTES_PER_RAY * B * RES * RES / (kern_ms * 1e-3) / 8e12, "traffic": None}
+
+    # ---------------------------------------------------------------- informational: full inversion forward, one image
+    if rank == 0 and not args.no_inversion:
+        try:
+            with torch.no_grad():
+                gl = G_pred_latents(syn.model_opt(), syn.rendering_opt(N_samples=N_SAMPLES, enable_local_model=True),
+                                    full_pipeline=True)
+                gl.load_state_dict({k.replace('renderer.network.', 'renderer.network.netGlobal.'): v for k, v in sd_cpu.items()})
+                gl = gl.to(dev).eval()
+                w1, d1 = syn.synthetic_inputs(1, seed=1, device=dev)
+                p1, f1, n1, fa1, _ = generate_camera_params(RES, dev, locations=torch.zeros(1, 2, device=dev))
+                tex = syn.synthetic_tex_conditions(1, RES, N_SAMPLES, device=dev)
+
+                def inversion():
+                    gl([w1, d1], p1, f1, n1, fa1, input_is_latent=True, sample_with_renderer=True)       # pass #1
+                    return gl([w1, d1], p1, f1, n1, fa1, input_is_latent=True, randomize_noise=False,
+                              local_data_batch={'tex': tex})                                             # pass #2 + decoder
+                for _ in range(3):
+                    inversion()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n_inv = 10
+                for _ in range(n_inv):
+                    o = inversion()
+                torch.cuda.synchronize()
+                result["inversion_fwd_ms"] = 1e3 * (time.perf_counter() - t1) / n_inv
+                result["inversion_fwd_note"] = ("pass#1 render + pass#2 render with (alpha,beta) texture FiLM + decoder 64^2->1024^2; "
+                                                "encoder / local-branch networks excluded (out of scope)")
+                assert tuple(o['gen_imgs'].shape) == (1, 3, 1024, 1024)
+            del gl
+        except Exception as exc:  # the headline metric must still be printed
+            result["inversion_fwd_ms"] = None
+            result["inversion_fwd_note"] = f"failed: {type(exc).__name__}: {exc}"
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import renderer_ref
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        c = lambda t: t.detach().cpu()
+        a = (c(poses[:1]), c(focal[:1]), c(near[:1]), c(far[:1]), c(wr[:1]))
+        with torch.no_grad():
+            renderer_ref.render(sd_cpu, *a, res=RES, n_samples=N_SAMPLES)                      # warm-up
+            n, t1 = 0, time.perf_counter()
+            while True:
+                renderer_ref.render(sd_cpu, *a, res=RES, n_samples=N_SAMPLES)
+                n += 1
+                dt = time.perf_counter() - t1
+                if dt > 12.0 or n >= 40:
+                    break
+        result["cpu_baseline"] = {"value": n * RES * RES / dt, "unit": "rays/s", "cores": torch.get_num_threads(),
+                                  "kind": "port", "sample": f"{n} renders of one 64x64x24 image in {dt:.1f} s "
+                                  "(oracle/renderer_ref.py, PyTorch CPU fp32, bit-identical to the reference path on the golden vectors)"}
+        result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

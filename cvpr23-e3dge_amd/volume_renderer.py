@@ -328,13 +328,16 @@ class VolumeFeatureRenderer(nn.Module):
         if not self.test and (self.perturb or self.raw_noise_std):
             raise NotImplementedError("stratified perturbation / raw noise (train-mode sampling) is not covered by "
                                       "the fused kernel; construct with mode='test' or perturb=0")
+        film = self.siren.film_params(styles)
+        return self.render_with_film(film, focal, c2w, near, far, tex_conditions)
+
+    def render_with_film(self, film, focal, c2w, near, far, tex_conditions=None):
+        """The single fused launch (e3dge_siren_render_fwd) given precomputed FiLM parameters (B,9,2,256)."""
         B = c2w.shape[0]
         H = Wd = self.out_im_res
         S = self.N_samples
         dev = c2w.device
-        siren = self.siren
-        packed = siren.device_image()[0]
-        film = siren.film_params(styles)
+        packed = self.siren.device_image()[0]
         c2w_c = c2w[:, :3, :4].contiguous()
         focal_c = focal.reshape(B).contiguous()
         near_c = near.reshape(B).contiguous()

@@ -1,0 +1,138 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/e3dge_hip.h declares; the ctypes
+mirror of E3dgeRenderArgs matches the C layout; host-side logic (state-dict keys, adjoint geometry, camera
+mirror, loud failure without a GPU)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, REPO, load_golden
+
+import e3dge_amd  # noqa: F401
+from e3dge_amd import _lib, synthetic as syn
+
+HEADER = os.path.join(REPO, "include", "e3dge_hip.h")
+
+
+def test_library_exports_every_declared_symbol(lib):
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(e3dge_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 13
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in e3dge_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.e3dge_abi_version() == _lib.ABI_VERSION
+    assert lib.e3dge_siren_packed_floats() == 64 * 8192 + 2 * 1024 + 9 * 256 + 4 * 256 + 4
+
+
+def test_render_args_struct_layout_matches_c():
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "e3dge_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(E3dgeRenderArgs), offsetof(E3dgeRenderArgs, sigmoid_beta),
+         offsetof(E3dgeRenderArgs, batch), offsetof(E3dgeRenderArgs, force_background),
+         offsetof(E3dgeRenderArgs, rgb), offsetof(E3dgeRenderArgs, dists));
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), c, "-o", exe], check=True)
+        got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    R = _lib.RenderArgs
+    assert got == [ctypes.sizeof(R), R.sigmoid_beta.offset, R.batch.offset, R.force_background.offset,
+                   R.rgb.offset, R.dists.offset]
+
+
+def test_host_helpers_that_need_no_gpu(lib):
+    assert lib.e3dge_upfirdn2d_out_size(129, 1, 1, 1, 1, 4) == 128     # Blur after the 64->129 transposed conv
+    assert lib.e3dge_upfirdn2d_out_size(64, 2, 1, 2, 1, 4) == 128      # skip Upsample
+    assert lib.e3dge_upfirdn2d_out_size(3, 1, 1, 0, 0, 4) < 0          # empty output is an error, not a crash
+    # argument validation happens before any launch -> testable without a GPU
+    assert lib.e3dge_upfirdn2d(None, None, None, 1, 8, 8, 40, 4, 1, 1, 1, 1, 0, 0, 0, 0, None) == -1
+    assert b"kernel" in lib.e3dge_last_error()
+    assert lib.e3dge_fused_bias_act(None, None, None, None, 3, 0, 0.2, 1.0, 1 << 31, 1, 0, None) == -1
+    args = _lib.RenderArgs(n_samples=8, batch=1, height=4, width=4)
+    assert lib.e3dge_siren_render_fwd(ctypes.byref(args), None) == -1
+
+
+def test_state_dict_keys_equal_the_reference_generator():
+    from e3dge_amd.stylesdf_model import G_pred_latents
+    ref = json.load(open(os.path.join(GOLDEN, "state_dict_keys_1024.json")))
+    g = G_pred_latents(syn.model_opt(), syn.rendering_opt(), full_pipeline=True)
+    mine = {k: list(v.shape) for k, v in g.state_dict().items()}
+    assert mine == ref, (sorted(set(mine) ^ set(ref))[:10])
+
+
+def test_local_global_wrapper_keeps_netglobal_keys():
+    from e3dge_amd.volume_renderer import VolumeFeatureRenderer
+    r = VolumeFeatureRenderer(syn.rendering_opt(enable_local_model=True), mode='test')
+    keys = list(r.state_dict())
+    assert 'sigmoid_beta' in keys and 'network.netGlobal.pts_linears.0.gamma.weight' in keys
+    assert 'network.netGlobal.views_linears.weight' in keys and 'network.netGlobal.sigma_linear.bias' in keys
+
+
+def test_no_cpu_fallback_on_the_product_path():
+    from e3dge_amd import op
+    from e3dge_amd.volume_renderer import VolumeFeatureRenderer
+    x = torch.randn(1, 2, 8, 8)
+    with pytest.raises(RuntimeError, match="GPU"):
+        op.fused_leaky_relu(x, torch.zeros(2))
+    with pytest.raises(RuntimeError, match="GPU"):
+        op.upfirdn2d(x, torch.ones(4, 4))
+    r = VolumeFeatureRenderer(syn.rendering_opt(), mode='test')
+    cam = torch.zeros(1, 3, 4)
+    with pytest.raises(RuntimeError, match="GPU"):
+        r(cam, torch.ones(1, 1, 1), torch.ones(1, 1, 1), torch.ones(1, 1, 1), styles=torch.zeros(1, 9, 256))
+
+
+def test_unsupported_options_fail_loudly():
+    from e3dge_amd.volume_renderer import VolumeFeatureRenderer
+    with pytest.raises(NotImplementedError):
+        VolumeFeatureRenderer(syn.rendering_opt(no_sdf=True))
+    with pytest.raises(NotImplementedError):
+        VolumeFeatureRenderer(syn.rendering_opt(depth=6))
+    r = VolumeFeatureRenderer(syn.rendering_opt(), mode='test')
+    with pytest.raises(NotImplementedError):
+        r(None, None, None, None, styles=None, return_eikonal=True)
+
+
+def test_upfirdn_adjoint_geometry_is_an_involution():
+    from e3dge_amd.op.upfirdn2d import Geometry
+    for (h, w, k, up, down, pad) in [(33, 33, 4, 1, 1, (1, 1)), (16, 16, 4, 2, 1, (2, 1)), (32, 32, 4, 1, 2, (1, 1)),
+                                     (19, 23, 4, 2, 1, (-1, 2))]:
+        g = Geometry((up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
+        oh, ow = g.out_hw(h, w, k, k)
+        a = g.adjoint(h, w, k, k)
+        assert a.out_hw(oh, ow, k, k) == (h, w)                        # the adjoint maps back to the input extent
+        aa = a.adjoint(oh, ow, k, k)
+        assert aa.up == g.up and aa.down == g.down and aa.pad[0] == g.pad[0] and aa.pad[2] == g.pad[2]
+
+
+def test_camera_mirror_matches_reference_vectors():
+    from e3dge_amd.camera_utils import generate_camera_params
+    g = load_golden("camera")
+    cam = generate_camera_params(64, 'cpu', locations=torch.from_numpy(g['locations']), return_calibs=True)
+    np.testing.assert_allclose(cam['poses'].numpy(), g['ref_poses'], atol=1e-6)
+    np.testing.assert_allclose(cam['focal'].numpy(), g['ref_focal'], rtol=1e-6)
+    np.testing.assert_allclose(cam['calibs'].numpy(), g['ref_calibs'], atol=1e-5)
+    poses, focal, near, far, _ = generate_camera_params(128, 'cpu', locations=torch.from_numpy(g['traj_locations']))
+    np.testing.assert_allclose(poses.numpy(), g['ref_traj_poses'], atol=1e-6)
+    np.testing.assert_allclose(near.numpy().ravel(), 0.88, atol=1e-6)
+
+
+def test_synthetic_weights_are_key_deterministic():
+    a = syn.synthetic_tensor('renderer.network.pts_linears.3.weight', (256, 256))
+    b = syn.synthetic_tensor('renderer.network.pts_linears.3.weight', (256, 256))
+    c = syn.synthetic_tensor('renderer.network.pts_linears.4.weight', (256, 256))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert float(a.abs().max()) <= np.sqrt(6 / 256) / 25 + 1e-9

@@ -1,0 +1,81 @@
+"""GPU: the StyleGAN2 up-sampler glue (HIP ops + library convolutions) and the whole generator against the
+golden vectors recorded from the reference.
+
+Tolerance: the custom ops are elementwise / 16-tap and hold 1e-6 on their own (tests above); the 3x3 convolutions
+are MIOpen's (K = 9*Ci up to 4608 terms, algorithm chosen by the library), so the image bound is that of an fp32
+convolution stack: 2e-3 absolute on images of magnitude ~3 (|ref - f64| of the CPU stack is 2e-6)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import full_state_dict, load_golden, maxerr, record
+from oracle import decoder_ref
+
+import e3dge_amd  # noqa: F401
+from e3dge_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = lambda a: torch.from_numpy(np.asarray(a)).to(DEV)
+IMG_ATOL = 2e-3
+
+
+@pytest.fixture(scope="module")
+def gen():
+    g, sd = full_state_dict(size=256, cm=1)
+    return g.to(DEV).eval(), sd
+
+
+def test_mapping_networks(gen):
+    g, sd = gen
+    gold = load_golden("decoder_256")
+    with torch.no_grad():
+        w = g.style(T(gold['z']))
+        wdec = g.decoder.style(w)
+    e = dict(w=maxerr(w, gold['ref_w']), wdec=maxerr(wdec, gold['ref_wdec']), wdec_scale=float(np.abs(gold['ref_wdec']).max()))
+    record("mapping", **e)
+    assert e['w'] <= 2e-5
+    assert e['wdec'] <= 2e-4 * e['wdec_scale']
+
+
+def test_decoder_layers_and_image(gen):
+    g, sd = gen
+    gold = load_golden("decoder_256")
+    _, wd = syn.synthetic_inputs(1, seed=1, device=DEV)
+    wd = wd[:, :g.decoder.n_latent]
+    feats = T((0.5 * np.random.RandomState(int(gold['feats_seed'])).standard_normal((1, 256, 64, 64))).astype(np.float32))
+    with torch.no_grad():
+        c1 = g.decoder.conv1(feats, wd[:, 0], noise=g.decoder.noises.noise_0)
+        rgb1 = g.decoder.to_rgb1(c1, wd[:, 1])
+        up = g.decoder.convs[0](c1, wd[:, 1], noise=g.decoder.noises.noise_1)
+        img, _ = g.decoder(feats, [wd], input_is_latent=True, randomize_noise=False)
+    e = dict(conv1=maxerr(c1[:, ::16], gold['ref_conv1']), rgb1=maxerr(rgb1, gold['ref_rgb1']),
+             up=maxerr(up[:, ::16], gold['ref_up']), img=maxerr(img, gold['ref_img']),
+             img_vs_f64=maxerr(img[:, :, ::2, ::2], gold['f64_img_sub2']))
+    record("decoder_256", **e)
+    assert tuple(img.shape) == (1, 3, 256, 256)
+    for k, v in e.items():
+        assert v <= IMG_ATOL, (k, v)
+
+
+def test_generator_call_surface(gen):
+    """The runner-facing call (trainer.py:881-897): list of W+ codes, poses, focals, near, far -> dict."""
+    g, sd = gen
+    gold = load_golden("generator_256")
+    wr, wd = syn.synthetic_inputs(1, seed=int(gold['styles_seed']), device=DEV)
+    wd = wd[:, :g.decoder.n_latent]
+    with torch.no_grad():
+        out = g([wr, wd], T(gold['poses']), T(gold['focal']), T(gold['near']), T(gold['far']), input_is_latent=True,
+                randomize_noise=False)
+        thumb_only = g([wr, wd], T(gold['poses']), T(gold['focal']), T(gold['near']), T(gold['far']), input_is_latent=True,
+                       renderer_only=True)
+    assert 'gen_imgs' in out and 'decoder_latent' in out and 'styles' in out and 'gen_imgs' not in thumb_only
+    e = dict(gen_imgs=maxerr(out['gen_imgs'], gold['ref_gen_imgs']), thumb=maxerr(out['gen_thumb_imgs'], gold['ref_gen_thumb_imgs']),
+             depth=maxerr(out['depth'], gold['ref_depth']), feat=maxerr(out['features'][:, :, ::8, ::8], gold['ref_features_sub']))
+    record("generator_256", **e)
+    assert e['thumb'] <= 2e-5 and e['depth'] <= 1e-5 and e['feat'] <= 3e-4
+    assert e['gen_imgs'] <= IMG_ATOL
+    # random noise path runs and differs from the fixed-noise image
+    with torch.no_grad():
+        rnd = g([wr, wd], T(gold['poses']), T(gold['focal']), T(gold['near']), T(gold['far']), input_is_latent=True)
+    assert torch.isfinite(rnd['gen_imgs']).all() and not torch.equal(rnd['gen_imgs'], out['gen_imgs'])

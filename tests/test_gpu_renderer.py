@@ -1,0 +1,200 @@
+"""GPU: the fused FiLM-SIREN renderer through the C-ABI against (i) the golden vectors recorded from the
+reference, (ii) the float64 evaluation of the restatement ("truth") and (iii) the oracle on other inputs.
+
+Stated fp32 tolerance.  The reference's own fp32 result sits this far from the float64 truth on these fixtures
+(tests/golden/generation_report.json): rgb 1e-6, depth/xyz 3e-7, weights 7e-7, sdf 3e-6, 256-ch features 6e-5
+(eight sine layers at frequency ~30 amplify rounding by ~1.7x per layer).  A different but equally valid fp32
+summation order (MFMA k-order instead of MKL's) lands at the same distance, so the bound on |hip - reference| is
+a small multiple of that noise floor:
+    rgb 2e-5 | depth, xyz, weights 1e-5 | sdf 3e-5 | features 3e-4 | geometry (points, rays, dirs) 1e-6.
+The distance to the float64 truth is additionally required to stay within 4x the reference's own."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import full_state_dict, load_golden, maxerr, record
+from oracle import renderer_ref
+
+import e3dge_amd  # noqa: F401
+from e3dge_amd import synthetic as syn
+from e3dge_amd.camera_utils import generate_camera_params
+from e3dge_amd.volume_renderer import VolumeFeatureRenderer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = lambda a: torch.from_numpy(np.asarray(a)).to(DEV)
+
+ATOL = dict(gen_thumb_imgs=2e-5, depth=1e-5, xyz=1e-5, hit_prob=1e-5, sdf=3e-5, features=3e-4, points=1e-6,
+            rays_d=1e-6, viewdirs=1e-6)
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return full_state_dict()[1]
+
+
+def make_renderer(sd, res, S, **over):
+    r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S, **over), out_im_res=res, mode='test')
+    pre = 'network.netGlobal.' if over.get('enable_local_model') else 'network.'
+    own = {}
+    for k in r.state_dict():
+        src = 'renderer.' + (k.replace('network.netGlobal.', 'network.') if pre != 'network.' else k)
+        own[k] = sd[src]
+    r.load_state_dict(own)
+    return r.to(DEV)
+
+
+def check_against_golden(name, out, g, sub=None):
+    errs = {}
+    for k, atol in ATOL.items():
+        v = out[k]
+        if sub and k in ('sdf', 'hit_prob', 'points'):
+            v = v[:, ::sub, ::sub]
+        if sub and k == 'features':
+            v = v[:, :, ::sub, ::sub]
+        e_ref = maxerr(v, g['ref_' + k])
+        e_f64 = maxerr(v, g['f64_' + k])
+        ref_f64 = maxerr(g['ref_' + k], g['f64_' + k])
+        errs[k] = (e_ref, e_f64, ref_f64)
+    record(name, **{k + '_vs_ref': v[0] for k, v in errs.items()}, **{k + '_vs_f64': v[1] for k, v in errs.items()},
+           **{k + '_ref_vs_f64': v[2] for k, v in errs.items()})
+    for k, (e_ref, e_f64, ref_f64) in errs.items():
+        assert e_ref <= ATOL[k], f"{name}:{k} |hip-ref| = {e_ref:.3e} > {ATOL[k]:.1e}"
+        assert e_f64 <= max(4 * ref_f64, 0.25 * ATOL[k]), f"{name}:{k} |hip-f64| = {e_f64:.3e} vs reference's {ref_f64:.3e}"
+    # dists: last interval is 1e10 * |d| -> relative bound
+    d = out['dists'][:, ::sub, ::sub] if sub else out['dists']
+    rel = float(((d.double().cpu() - torch.from_numpy(g['ref_dists']).double()).abs() /
+                 torch.from_numpy(g['ref_dists']).double().abs().clamp_min(1e-12)).max())
+    assert rel <= 2e-5, rel     # differences of nearby z values: a few ulp of z relative to dz = 0.01
+    m = out['mask'].cpu().numpy()
+    near_thr = np.abs(g['ref_depth'].reshape(m.shape) - 1.08) < 1e-5
+    assert ((m == g['ref_mask']) | near_thr).all()
+
+
+@pytest.mark.parametrize("name,sub", [("renderer_16x24", None), ("renderer_8x48", None), ("renderer_8x18", None),
+                                      ("renderer_64x24", 8)])
+def test_render_matches_reference_golden(sd, name, sub):
+    g = load_golden(name)
+    B, res, S = int(g['batch']), int(g['res']), int(g['n_samples'])
+    r = make_renderer(sd, res, S)
+    wr, _ = syn.synthetic_inputs(B, seed=int(g['styles_seed']), device=DEV)
+    with torch.no_grad():
+        out = r(T(g['poses']), T(g['focal']), T(g['near']), T(g['far']), styles=wr)
+    # dict surface of VolumeFeatureRenderer.forward
+    assert set(out) >= {'rays_o', 'rays_d', 'dists', 'near', 'far', 'hit_prob', 'surface_eikonal_term', 'points', 'sdf',
+                        'gen_thumb_imgs', 'features', 'mask', 'xyz', 'eikonal_term', 'depth', 'mesh', 'viewdirs'}
+    assert tuple(out['gen_thumb_imgs'].shape) == (B, 3, res, res) and tuple(out['features'].shape) == (B, 256, res, res)
+    assert tuple(out['mask'].shape) == (B, 1, res, res, 1) and tuple(out['depth'].shape) == (B, res, res, 1, 1)
+    assert tuple(out['sdf'].shape) == (B, res, res, S, 1) and tuple(out['points'].shape) == (B, res, res, S, 3)
+    assert tuple(out['near'].shape) == (B, res, res, 1) and tuple(out['rays_o'].shape) == (B, res, res, 3)
+    check_against_golden(name, out, g, sub)
+
+
+def test_texture_film_pass(sd):
+    g = load_golden("renderer_tex_8x24")
+    r = make_renderer(sd, 8, 24, enable_local_model=True)
+    wr, _ = syn.synthetic_inputs(1, seed=1, device=DEV)
+    tex = syn.synthetic_tex_conditions(1, 8, 24, seed=int(g['tex_seed']), device=DEV)
+    with torch.no_grad():
+        out = r(T(g['poses']), T(g['focal']), T(g['near']), T(g['far']), styles=wr, local_data_batch={'tex': tex})
+    e = {k: maxerr(out[k], g['ref_' + k]) for k in ('gen_thumb_imgs', 'features', 'sdf', 'hit_prob')}
+    record("tex_film", **e)
+    for k, v in e.items():
+        assert v <= ATOL[k], (k, v)
+
+
+def test_film_params_and_point_queries(sd):
+    g = load_golden("points")
+    r = make_renderer(sd, 64, 24)
+    wr, _ = syn.synthetic_inputs(2, seed=1, device=DEV)
+    film = r.siren.film_params(wr)
+    e_film = maxerr(film, g['ref_film'])
+    record("film_params", vs_ref=e_film, vs_f64=maxerr(film, g['f64_film']), ref_vs_f64=maxerr(g['ref_film'], g['f64_film']))
+    assert e_film <= 3e-5          # gamma ~ 30 +- 15*dot(256): a few ulp of 30 (ulp = 2e-6)
+    pts, vd = T(g['pts']), T(g['viewdirs'])
+    with torch.no_grad():
+        raw0 = r.run_network(pts, torch.zeros_like(pts), styles=wr)
+        raw1 = r.run_network(pts, vd, styles=wr)
+        sdf_only = r.run_network(pts, torch.zeros_like(pts), styles=wr, return_sdf_only=True)
+    assert tuple(raw1.shape) == tuple(g['ref_raw_view'].shape)
+    for tag, raw, ref in (("zero_view", raw0, g['ref_raw_zero_view']), ("view", raw1, g['ref_raw_view'])):
+        e = dict(rgb=maxerr(raw[..., :3], ref[..., :3]), sdf=maxerr(raw[..., 3], ref[..., 3]), feat=maxerr(raw[..., 4:], ref[..., 4:]))
+        record("points_" + tag, **e)
+        assert e['rgb'] <= 3e-5 and e['sdf'] <= 3e-5 and e['feat'] <= 3e-4, e
+    assert maxerr(sdf_only[..., 0], raw0[..., 3]) == 0.0
+
+
+def test_full_size_properties_64x64x24(sd):
+    """BASELINE.json configs[1] size: invariants that need no oracle."""
+    res, S, B = 64, 24, 3
+    r = make_renderer(sd, res, S)
+    wr, _ = syn.synthetic_inputs(B, seed=11, device=DEV)
+    loc = torch.tensor([[0.0, 0.0], [0.25, -0.1], [-0.3, 0.12]])
+    poses, focal, near, far, _ = generate_camera_params(res, DEV, locations=loc.to(DEV))
+    with torch.no_grad():
+        out = r(poses, focal, near, far, styles=wr)
+        again = r(poses, focal, near, far, styles=wr)
+        single = r(poses[1:2], focal[1:2], near[1:2], far[1:2], styles=wr[1:2])
+    for k in ('gen_thumb_imgs', 'features', 'sdf', 'hit_prob', 'depth', 'xyz'):
+        assert torch.isfinite(out[k]).all(), k
+        assert torch.equal(out[k], again[k]), f"{k}: two identical launches differ (non-deterministic reduction?)"
+        assert torch.equal(out[k][1:2], single[k]), f"{k}: batch element 1 differs from its stand-alone render"
+    w = out['hit_prob'][..., 0]
+    assert float((w.sum(-1) - 1).abs().max()) <= 2e-6          # force_background: weights of a ray sum to one
+    z = near.reshape(B, 1, 1, 1) * (1 - r.t_vals) + far.reshape(B, 1, 1, 1) * r.t_vals
+    assert maxerr(out['points'], out['rays_o'].unsqueeze(3) + out['rays_d'].unsqueeze(3) * z.unsqueeze(-1)) <= 2e-7
+    assert maxerr(out['depth'][..., 0, 0], (w * z).sum(-1)) <= 1e-6
+    assert torch.equal(out['mask'][:, 0, :, :, 0], (out['depth'][..., 0, 0] < 1.08).float())
+    assert float(out['gen_thumb_imgs'].abs().max()) <= 1.0 + 1e-6
+    # against the oracle (fp32, CPU) on the second image
+    cpu = lambda t: t.detach().cpu()
+    with torch.no_grad():
+        ref = renderer_ref.render(sd, cpu(poses[1:2]), cpu(focal[1:2]), cpu(near[1:2]), cpu(far[1:2]), cpu(wr[1:2]), res=res, n_samples=S)
+    e = {k: maxerr(single[k], ref[k]) for k in ATOL}
+    record("full_64x64x24_vs_oracle", **e)
+    for k, v in e.items():
+        assert v <= ATOL[k], (k, v)
+
+
+def test_c4_size_128x128x48_against_oracle(sd):
+    """BASELINE.json configs[3]: 128x128 rays x 48 samples (786,432 points, the reference's W==128 sub-batch path)."""
+    res, S = 128, 48
+    r = make_renderer(sd, res, S)
+    wr, _ = syn.synthetic_inputs(1, seed=21, device=DEV)
+    poses, focal, near, far, _ = generate_camera_params(res, DEV, locations=torch.tensor([[0.45, 0.0]], device=DEV))
+    with torch.no_grad():
+        out = r(poses, focal, near, far, styles=wr)
+        cpu = lambda t: t.detach().cpu()
+        ref = renderer_ref.render(sd, cpu(poses), cpu(focal), cpu(near), cpu(far), cpu(wr), res=res, n_samples=S)
+    e = {k: maxerr(out[k], ref[k]) for k in ATOL}
+    record("c4_128x128x48_vs_oracle", **e)
+    for k, v in e.items():
+        assert v <= ATOL[k], (k, v)
+    assert float((out['hit_prob'][..., 0].sum(-1) - 1).abs().max()) <= 3e-6
+
+
+def test_geometry_sample_requery(sd):
+    r = make_renderer(sd, 16, 24)
+    wr, _ = syn.synthetic_inputs(1, seed=1, device=DEV)
+    poses, focal, near, far, _ = generate_camera_params(16, DEV, locations=torch.zeros(1, 2, device=DEV))
+    rs = np.random.RandomState(9)
+    uni = T((0.12 * rs.uniform(-1, 1, (1, 500, 1, 1, 3))).astype(np.float32))
+    with torch.no_grad():
+        out = r(poses, focal, near, far, styles=wr, geometry_sample={'uniform_pts': uni, 'xyz': None})
+        ref = renderer_ref.query_points(sd, uni.cpu(), None, wr.cpu())[..., 3:4]
+    assert tuple(out['uniform_pts_rec'].shape) == (1, 500, 1, 1, 1)
+    assert maxerr(out['uniform_pts_rec'], ref) <= 3e-5
+
+
+def test_ragged_and_tiny_extents(sd):
+    """Edge cases: one ray block smaller than a tile, a point count that is not a multiple of 128, a single point."""
+    r = make_renderer(sd, 8, 18)       # 64 rays x 18 = 1152 points
+    wr, _ = syn.synthetic_inputs(1, seed=3, device=DEV)
+    for n in (1, 127, 129, 1000):
+        pts = T((0.1 * np.random.RandomState(n).uniform(-1, 1, (1, n, 1, 1, 3))).astype(np.float32))
+        with torch.no_grad():
+            raw = r.run_network(pts, torch.zeros_like(pts), styles=wr)
+            ref = renderer_ref.query_points(sd, pts.cpu(), None, wr.cpu())
+        assert maxerr(raw[..., 3], ref[..., 3]) <= 3e-5 and maxerr(raw[..., 4:], ref[..., 4:]) <= 3e-4, n
+    empty = r.run_network(torch.empty(1, 0, 1, 1, 3, device=DEV), torch.empty(1, 0, 1, 1, 3, device=DEV), styles=wr)
+    assert empty.numel() == 0

@@ -1,0 +1,186 @@
+"""GPU: kernel self-tests and the StyleGAN2 custom ops through the C-ABI, against the golden vectors recorded
+from the reference and against the oracle on seeded inputs.  Tolerances are absolute fp32 bounds, written
+next to each check."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, maxerr, record
+from oracle import ops_ref
+
+import e3dge_amd  # noqa: F401
+from e3dge_amd import _lib, op
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = lambda a: torch.from_numpy(np.asarray(a)).to(DEV)
+
+
+def test_mfma_fragment_layout(lib):
+    # asymmetric operands: a transposed or row-permuted C/D mapping cannot pass
+    rs = np.random.RandomState(0)
+    for k in (8, 64, 256):
+        a = T(rs.standard_normal((32, k)).astype(np.float32))
+        b = T(rs.standard_normal((32, k)).astype(np.float32))
+        c = torch.full((32, 32), float('nan'), device=DEV)
+        _lib.check(lib.e3dge_selftest_mfma(c.data_ptr(), a.data_ptr(), b.data_ptr(), k, _lib.stream_of(c)), "selftest_mfma")
+        ref = a.double() @ b.double().t()
+        err = maxerr(c, ref)
+        record("mfma_layout", k=k, err=err)
+        assert err <= 2e-5 * np.sqrt(k), err
+
+
+def test_device_sine_accuracy(lib):
+    rs = np.random.RandomState(1)
+    x = np.concatenate([rs.uniform(-300, 300, 200000), rs.uniform(-4, 4, 50000), np.linspace(-50, 50, 20001),
+                        np.array([0.0, np.pi, -np.pi, np.pi / 2, 1e-8, -1e-8, 1e4, -1e4])]).astype(np.float32)
+    xt = T(x)
+    y = torch.empty_like(xt)
+    _lib.check(lib.e3dge_selftest_sin(y.data_ptr(), xt.data_ptr(), xt.numel(), _lib.stream_of(y)), "selftest_sin")
+    ref = np.sin(x.astype(np.float64))
+    err = float(np.abs(y.cpu().numpy().astype(np.float64) - ref).max())
+    record("device_sine", max_abs_err=err)
+    assert err <= 2.5e-7, err            # ~2 ulp at |sin| ~ 1
+
+
+@pytest.mark.parametrize("name", ['conv', 'mapping', 'nobias', 'ragged'])
+def test_fused_leaky_relu_golden(name):
+    g = load_golden("fused_act")
+    x = T(g[name + '_x']).requires_grad_(True)
+    b = T(g[name + '_b']).requires_grad_(True) if (name + '_b') in g else None
+    scale = float(g[name + '_scale'])
+    y = op.fused_leaky_relu(x, b, 0.2, scale)
+    gy = T(g[name + '_gy'])
+    grads = torch.autograd.grad(y, [x] + ([b] if b is not None else []), gy)
+    e = dict(y=maxerr(y, g[name + '_y']), gx=maxerr(grads[0], g[name + '_gx']))
+    if b is not None:
+        e['gb'] = maxerr(grads[1], g[name + '_gb'])
+    record("fused_leaky_relu_" + name, **e)
+    assert e['y'] <= 1e-6 and e['gx'] <= 1e-6           # elementwise: one rounding of difference at most
+    assert e.get('gb', 0) <= 1e-4                        # a sum over B*H*W terms
+
+
+def test_fused_bias_act_raw_table():
+    rs = np.random.RandomState(2)
+    x = rs.standard_normal((3, 6, 10, 12)).astype(np.float32)
+    b = rs.standard_normal(6).astype(np.float32)
+    r = rs.standard_normal((3, 6, 10, 12)).astype(np.float32)
+    for act, grad in [(1, 0), (1, 1), (1, 2), (3, 0), (3, 1), (3, 2)]:
+        for bias in (b, None):
+            for ref in (r, None):
+                want = ops_ref.fused_bias_act_ref(torch.from_numpy(x), None if bias is None else torch.from_numpy(bias),
+                                                  None if ref is None else torch.from_numpy(ref), act, grad, 0.2, 1.3)
+                got = op.fused_bias_act(T(x), None if bias is None else T(bias), None if ref is None else T(ref), act, grad, 0.2, 1.3)
+                assert maxerr(got, want) <= 1e-6, (act, grad, bias is None, ref is None)
+    # unaligned / odd sizes take the element kernel; empty input is a no-op
+    x1 = rs.standard_normal((5, 7)).astype(np.float32)
+    b1 = rs.standard_normal(7).astype(np.float32)
+    assert maxerr(op.fused_bias_act(T(x1), T(b1), None, 3, 0, 0.2, 1.0),
+                  ops_ref.fused_bias_act_ref(torch.from_numpy(x1), torch.from_numpy(b1), None, 3, 0, 0.2, 1.0)) <= 1e-6
+    assert op.fused_bias_act(torch.empty(0, 4, device=DEV), None, None, 3, 0, 0.2, 1.0).numel() == 0
+
+
+def test_fused_leaky_relu_second_order():
+    x = torch.randn(2, 3, 8, 8, device=DEV, dtype=torch.float32, requires_grad=True)
+    b = torch.randn(3, device=DEV, requires_grad=True)
+    y = op.fused_leaky_relu(x, b)
+    gy = torch.randn_like(y).requires_grad_(True)
+    gx, = torch.autograd.grad(y, x, gy, create_graph=True)
+    v = torch.randn_like(gx)
+    ggy, = torch.autograd.grad(gx, gy, v)
+    mask = torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.2)) * (2 ** 0.5)
+    assert maxerr(ggy, v * mask) <= 1e-6
+    assert maxerr(gx, gy * mask) <= 1e-6
+
+
+def test_noise_bias_act_matches_unfused_chain():
+    rs = np.random.RandomState(3)
+    for B, C, H, nb in [(2, 5, 16, 1), (2, 4, 8, 2), (1, 3, 64, 1)]:
+        x = rs.standard_normal((B, C, H, H)).astype(np.float32)
+        n = rs.standard_normal((nb, 1, H, H)).astype(np.float32)
+        w = np.float32([0.37])
+        b = rs.standard_normal(C).astype(np.float32)
+        want = ops_ref.fused_leaky_relu_ref(torch.from_numpy(x) + torch.from_numpy(w) * torch.from_numpy(n), torch.from_numpy(b))
+        got = op.noise_bias_act(T(x), T(n), T(w), T(b))
+        e = maxerr(got, want)
+        record("noise_bias_act", B=B, C=C, H=H, err=e)
+        assert e <= 1e-6
+    xg = T(x).requires_grad_(True)
+    y = op.noise_bias_act(xg, T(n), T(w), T(b))
+    gx, = torch.autograd.grad(y.sum(), xg)
+    xr = torch.from_numpy(x).requires_grad_(True)
+    yr = ops_ref.fused_leaky_relu_ref(xr + torch.from_numpy(w) * torch.from_numpy(n), torch.from_numpy(b))
+    gr, = torch.autograd.grad(yr.sum(), xr)
+    assert maxerr(gx, gr) <= 1e-6
+
+
+@pytest.mark.parametrize("name", ['blur_up', 'upsample', 'downsample', 'blur_down', 'k3', 'crop', 'big'])
+def test_upfirdn2d_golden(name):
+    g = load_golden("upfirdn2d")
+    up, down, p0, p1 = [int(v) for v in g[name + '_cfg']]
+    x = T(g[name + '_x']).requires_grad_(True)
+    k = T(g[name + '_k'])
+    y = op.upfirdn2d(x, k, up=up, down=down, pad=(p0, p1))
+    gy = T(g[name + '_gy']).requires_grad_(True)
+    gx, = torch.autograd.grad(y, x, gy, create_graph=True)
+    e = dict(y=maxerr(y, g[name + '_y']), gx=maxerr(gx, g[name + '_gx']))
+    record("upfirdn2d_" + name, **e)
+    assert e['y'] <= 2e-6 and e['gx'] <= 5e-6          # 16-tap fp32 sums of O(1) values
+    # second order: the adjoint of the adjoint is the forward operator
+    v = torch.randn_like(gx)
+    ggy, = torch.autograd.grad(gx, gy, v)
+    assert maxerr(ggy, op.upfirdn2d(v, k, up=up, down=down, pad=(p0, p1))) <= 2e-6
+
+
+def test_upfirdn2d_asymmetric_raw():
+    g = load_golden("upfirdn2d")
+    ux, uy, dx, dy, px0, px1, py0, py1 = [int(v) for v in g['asym_cfg']]
+    x = T(g['asym_x'])
+    y = op.upfirdn2d_raw(x.reshape(-1, x.shape[2], x.shape[3], 1), T(g['asym_k']), ux, uy, dx, dy, px0, px1, py0, py1)
+    assert maxerr(y.reshape(g['asym_y'].shape), g['asym_y']) <= 2e-6
+
+
+def test_upfirdn2d_full_decoder_sizes_and_properties():
+    """BASELINE-size planes: Blur of the last up-sampling stage (32 x 1025^2 -> 1024^2) against the oracle on a
+    channel subset, plus linearity and the adjoint identity <Ax, y> = <x, A^T y> on the whole tensor."""
+    from e3dge_amd.stylesdf_model import make_kernel
+    k = make_kernel([1, 3, 3, 1]) * 4
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 32, 1025, 1025, generator=g)
+    xd = x.to(DEV).requires_grad_(True)
+    y = op.upfirdn2d(xd, k.to(DEV), pad=(1, 1))
+    assert tuple(y.shape) == (1, 32, 1024, 1024)
+    want = ops_ref.upfirdn2d_ref_simple(x[:, :3], k, pad=(1, 1))
+    e = maxerr(y[:, :3], want)
+    record("upfirdn2d_1025_blur", err=e)
+    assert e <= 3e-6
+    w = torch.randn(y.shape, generator=g).to(DEV)
+    gx, = torch.autograd.grad(y, xd, w)
+    lhs = float((y.double() * w.double()).sum())
+    rhs = float((xd.double() * gx.double()).sum())
+    assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), 1.0) + 1e-2, (lhs, rhs)
+    y2 = op.upfirdn2d(2.5 * xd.detach(), k.to(DEV), pad=(1, 1))
+    assert maxerr(y2, 2.5 * y) <= 1e-5
+    # skip up-sampler at the last stage: (3, 512^2) -> 1024^2
+    s = torch.randn(1, 3, 512, 512, generator=g)
+    ys = op.upfirdn2d(s.to(DEV), k.to(DEV), up=2, pad=(2, 1))
+    assert maxerr(ys, ops_ref.upfirdn2d_ref_simple(s, k, up=2, pad=(2, 1))) <= 3e-6
+
+
+def test_modconv_weights_kernel():
+    rs = np.random.RandomState(5)
+    for (B, Co, Ci, k, demod, tr) in [(2, 8, 6, 3, 1, 0), (2, 8, 6, 3, 1, 1), (1, 3, 16, 1, 0, 0), (1, 32, 64, 3, 1, 1)]:
+        w = torch.from_numpy(rs.standard_normal((Co, Ci, k * k)).astype(np.float32))
+        s = torch.from_numpy((1 + 0.1 * rs.standard_normal((B, Ci))).astype(np.float32))
+        scale = 1 / np.sqrt(Ci * k * k)
+        ww = scale * w[None] * s[:, None, :, None]
+        if demod:
+            ww = ww * torch.rsqrt(ww.pow(2).sum([2, 3]) + 1e-8)[:, :, None, None]
+        want = ww.transpose(1, 2).reshape(B * Ci, Co, k * k) if tr else ww.reshape(B * Co, Ci, k * k)
+        out = torch.empty(want.shape, device=DEV)
+        lib = _lib.load()
+        _lib.check(lib.e3dge_modconv_weights(out.data_ptr(), T(w.numpy()).data_ptr(), T(s.numpy()).data_ptr(), float(scale),
+                                             demod, tr, B, Co, Ci, k * k, _lib.stream_of(out)), "modconv")
+        e = maxerr(out, want)
+        record("modconv_weights", Co=Co, Ci=Ci, err=e)
+        assert e <= 2e-6
