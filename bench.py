@@ -163,21 +163,30 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import renderer_ref
         cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
         c = lambda t: t.detach().cpu()
         a = (c(poses[:1]), c(focal[:1]), c(near[:1]), c(far[:1]), c(wr[:1]))
+        trials = {}
         with torch.no_grad():
-            renderer_ref.render(sd_cpu, *a, res=RES, n_samples=N_SAMPLES)                      # warm-up
-            n, t1 = 0, time.perf_counter()
-            while True:
-                renderer_ref.render(sd_cpu, *a, res=RES, n_samples=N_SAMPLES)
-                n += 1
-                dt = time.perf_counter() - t1
-                if dt > 12.0 or n >= 40:
-                    break
-        result["cpu_baseline"] = {"value": n * RES * RES / dt, "unit": "rays/s", "cores": torch.get_num_threads(),
-                                  "kind": "port", "sample": f"{n} renders of one 64x64x24 image in {dt:.1f} s "
-                                  "(oracle/renderer_ref.py, PyTorch CPU fp32, bit-identical to the reference path on the golden vectors)"}
+            # PyTorch's CPU GEMMs stop scaling (and on many-socket hosts collapse) long before all hardware threads
+            # are used, so the baseline is taken at 8 threads (the authoring container's count), at 32 and at
+            # min(64, cores); the best is reported with the thread count that produced it.
+            for nt in sorted({min(8, cores), min(32, cores), min(64, cores)}):
+                torch.set_num_threads(nt)
+                renderer_ref.render(sd_cpu, *a, res=RES, n_samples=N_SAMPLES)                  # warm-up
+                n, t1 = 0, time.perf_counter()
+                while True:
+                    renderer_ref.render(sd_cpu, *a, res=RES, n_samples=N_SAMPLES)
+                    n += 1
+                    dt = time.perf_counter() - t1
+                    if dt > 5.0 or n >= 12:
+                        break
+                trials[nt] = (n * RES * RES / dt, n, dt)
+        best = max(trials, key=lambda k: trials[k][0])
+        result["cpu_baseline"] = {"value": trials[best][0], "unit": "rays/s", "cores": best, "kind": "port",
+                                  "host_cores": cores,
+                                  "sample": "; ".join(f"{nt} threads: {v[1]} renders of one 64x64x24 image in {v[2]:.1f} s = {v[0]:.0f} rays/s"
+                                                      for nt, v in sorted(trials.items())) +
+                                  " (oracle/renderer_ref.py, PyTorch CPU fp32, bit-identical to the reference path on the golden vectors)"}
         result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
 
     if rank == 0:

@@ -50,6 +50,20 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _adopt_torch_hip_runtime():
+    """libe3dge_hip.so needs libamdhip64.so.7.  PyTorch-ROCm wheels ship their own copy; a process must not
+    hold two HIP runtimes (streams and device pointers would not be interchangeable and the second runtime
+    does not even find the device).  Importing torch first and pinning ITS libamdhip64 globally makes our
+    NEEDED entry resolve to the copy torch uses, whatever the import order of the caller."""
+    try:
+        import torch
+    except ImportError:          # plain C-ABI use without torch: the system ROCm runtime is the only one
+        return
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
 def load():
     """Load (once) and return the ctypes handle; raises if the library is absent or has the wrong ABI."""
     global _lib
@@ -62,6 +76,7 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no fallback implementation.")
+        _adopt_torch_hip_runtime()
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)     # AttributeError if a declared symbol is not exported

@@ -822,9 +822,10 @@ extern "C" int e3dge_film_params(float* film, const float* styles, const float* 
 
 extern "C" int e3dge_siren_render_fwd(const E3dgeRenderArgs* r, e3dge_stream_t stream) {
     E3DGE_REQUIRE(r != nullptr, "siren_render_fwd: null args");
+    E3DGE_REQUIRE(r->batch >= 0 && r->height > 0 && r->width > 0, "siren_render_fwd: bad image extent");
+    if (r->batch == 0) return E3DGE_OK;
     E3DGE_REQUIRE(r->packed && r->film && r->c2w && r->focal && r->near && r->far && r->t_vals,
                   "siren_render_fwd: null input pointer");
-    E3DGE_REQUIRE(r->batch >= 0 && r->height > 0 && r->width > 0, "siren_render_fwd: bad image extent");
     E3DGE_REQUIRE(r->n_samples >= kMinSamples && r->n_samples <= 4096,
                   "siren_render_fwd: n_samples=%d outside [%d, 4096] (use e3dge_siren_points_fwd for raw queries)",
                   r->n_samples, kMinSamples);
@@ -857,8 +858,9 @@ extern "C" int e3dge_siren_render_fwd(const E3dgeRenderArgs* r, e3dge_stream_t s
 extern "C" int e3dge_siren_points_fwd(const float* packed, const float* film, const float* pts,
                                       const float* viewdirs, float box_scale, int batch, int64_t n_pts,
                                       float* sdf, float* raw, e3dge_stream_t stream) {
-    E3DGE_REQUIRE(packed && film && pts, "siren_points_fwd: null input pointer");
     E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "siren_points_fwd: bad sizes");
+    if (batch == 0 || n_pts == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(packed && film && pts, "siren_points_fwd: null input pointer");
     E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(film)) & 15) == 0,
                   "siren_points_fwd: packed/film must be 16-B aligned");
     if (batch == 0 || n_pts == 0) return E3DGE_OK;

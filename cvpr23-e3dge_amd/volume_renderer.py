@@ -186,6 +186,8 @@ class SirenGenerator(nn.Module):
         B, N, _ = pts.shape
         sdf = torch.empty((B, N), device=pts.device, dtype=torch.float32)
         raw = torch.empty((B, N, 260), device=pts.device, dtype=torch.float32) if want_raw else None
+        if B == 0 or N == 0:
+            return sdf, raw
         with torch.cuda.device(pts.device):
             rc = _lib.load().e3dge_siren_points_fwd(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(pts), _lib.ptr(vd),
                                                     float(box_scale), B, N, _lib.ptr(sdf), _lib.ptr(raw),

@@ -2,8 +2,9 @@
 golden vectors recorded from the reference.
 
 Tolerance: the custom ops are elementwise / 16-tap and hold 1e-6 on their own (tests above); the 3x3 convolutions
-are MIOpen's (K = 9*Ci up to 4608 terms, algorithm chosen by the library), so the image bound is that of an fp32
-convolution stack: 2e-3 absolute on images of magnitude ~3 (|ref - f64| of the CPU stack is 2e-6)."""
+are MIOpen's (K = 9*Ci up to 4608 terms, algorithm chosen by the library).  Measured on MI355X (round 1): 2.5e-6 on the
+256^2 decoder image, 6.5e-6 through renderer + decoder, on images of magnitude ~3 (|ref - f64| of the CPU stack
+is 2e-6); the stated bound is 1e-4 absolute, which still fails any algorithmic slip (a wrong tap or pad shows at 1e-2)."""
 import numpy as np
 import pytest
 import torch
@@ -17,7 +18,7 @@ from e3dge_amd import synthetic as syn
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 T = lambda a: torch.from_numpy(np.asarray(a)).to(DEV)
-IMG_ATOL = 2e-3
+IMG_ATOL = 1e-4
 
 
 @pytest.fixture(scope="module")
@@ -73,7 +74,7 @@ def test_generator_call_surface(gen):
     e = dict(gen_imgs=maxerr(out['gen_imgs'], gold['ref_gen_imgs']), thumb=maxerr(out['gen_thumb_imgs'], gold['ref_gen_thumb_imgs']),
              depth=maxerr(out['depth'], gold['ref_depth']), feat=maxerr(out['features'][:, :, ::8, ::8], gold['ref_features_sub']))
     record("generator_256", **e)
-    assert e['thumb'] <= 2e-5 and e['depth'] <= 1e-5 and e['feat'] <= 3e-4
+    assert e['thumb'] <= 5e-6 and e['depth'] <= 4e-6 and e['feat'] <= 1e-4
     assert e['gen_imgs'] <= IMG_ATOL
     # random noise path runs and differs from the fixed-noise image
     with torch.no_grad():

@@ -5,9 +5,10 @@ Stated fp32 tolerance.  The reference's own fp32 result sits this far from the f
 (tests/golden/generation_report.json): rgb 1e-6, depth/xyz 3e-7, weights 7e-7, sdf 3e-6, 256-ch features 6e-5
 (eight sine layers at frequency ~30 amplify rounding by ~1.7x per layer).  A different but equally valid fp32
 summation order (MFMA k-order instead of MKL's) lands at the same distance, so the bound on |hip - reference| is
-a small multiple of that noise floor:
-    rgb 2e-5 | depth, xyz, weights 1e-5 | sdf 3e-5 | features 3e-4 | geometry (points, rays, dirs) 1e-6.
-The distance to the float64 truth is additionally required to stay within 4x the reference's own."""
+about that noise floor (measured on MI355X, round 1: rgb 5e-7, weights 4e-7, sdf 8e-7, features 1.1e-5, geometry
+bit-exact); the stated fp32 tolerance leaves ~5-10x margin over the measurement:
+    rgb 5e-6 | depth, xyz, weights 4e-6 | sdf 1e-5 | features 1e-4 | geometry (points, rays, dirs) 5e-7.
+The distance to the float64 truth is additionally required to stay within 3x the reference's own."""
 import numpy as np
 import pytest
 import torch
@@ -24,8 +25,8 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 T = lambda a: torch.from_numpy(np.asarray(a)).to(DEV)
 
-ATOL = dict(gen_thumb_imgs=2e-5, depth=1e-5, xyz=1e-5, hit_prob=1e-5, sdf=3e-5, features=3e-4, points=1e-6,
-            rays_d=1e-6, viewdirs=1e-6)
+ATOL = dict(gen_thumb_imgs=5e-6, depth=4e-6, xyz=4e-6, hit_prob=4e-6, sdf=1e-5, features=1e-4, points=5e-7,
+            rays_d=5e-7, viewdirs=5e-7)
 
 
 @pytest.fixture(scope="module")
@@ -60,7 +61,7 @@ def check_against_golden(name, out, g, sub=None):
            **{k + '_ref_vs_f64': v[2] for k, v in errs.items()})
     for k, (e_ref, e_f64, ref_f64) in errs.items():
         assert e_ref <= ATOL[k], f"{name}:{k} |hip-ref| = {e_ref:.3e} > {ATOL[k]:.1e}"
-        assert e_f64 <= max(4 * ref_f64, 0.25 * ATOL[k]), f"{name}:{k} |hip-f64| = {e_f64:.3e} vs reference's {ref_f64:.3e}"
+        assert e_f64 <= max(3 * ref_f64, 0.5 * ATOL[k]), f"{name}:{k} |hip-f64| = {e_f64:.3e} vs reference's {ref_f64:.3e}"
     # dists: last interval is 1e10 * |d| -> relative bound
     d = out['dists'][:, ::sub, ::sub] if sub else out['dists']
     rel = float(((d.double().cpu() - torch.from_numpy(g['ref_dists']).double()).abs() /
@@ -110,7 +111,7 @@ def test_film_params_and_point_queries(sd):
     film = r.siren.film_params(wr)
     e_film = maxerr(film, g['ref_film'])
     record("film_params", vs_ref=e_film, vs_f64=maxerr(film, g['f64_film']), ref_vs_f64=maxerr(g['ref_film'], g['f64_film']))
-    assert e_film <= 3e-5          # gamma ~ 30 +- 15*dot(256): a few ulp of 30 (ulp = 2e-6)
+    assert e_film <= 1e-5          # gamma ~ 30 +- 15*dot(256): a few ulp of 30 (ulp = 2e-6); measured 1.9e-6
     pts, vd = T(g['pts']), T(g['viewdirs'])
     with torch.no_grad():
         raw0 = r.run_network(pts, torch.zeros_like(pts), styles=wr)
@@ -120,7 +121,7 @@ def test_film_params_and_point_queries(sd):
     for tag, raw, ref in (("zero_view", raw0, g['ref_raw_zero_view']), ("view", raw1, g['ref_raw_view'])):
         e = dict(rgb=maxerr(raw[..., :3], ref[..., :3]), sdf=maxerr(raw[..., 3], ref[..., 3]), feat=maxerr(raw[..., 4:], ref[..., 4:]))
         record("points_" + tag, **e)
-        assert e['rgb'] <= 3e-5 and e['sdf'] <= 3e-5 and e['feat'] <= 3e-4, e
+        assert e['rgb'] <= 5e-6 and e['sdf'] <= 1e-5 and e['feat'] <= 1e-4, e
     assert maxerr(sdf_only[..., 0], raw0[..., 3]) == 0.0
 
 
@@ -183,7 +184,7 @@ def test_geometry_sample_requery(sd):
         out = r(poses, focal, near, far, styles=wr, geometry_sample={'uniform_pts': uni, 'xyz': None})
         ref = renderer_ref.query_points(sd, uni.cpu(), None, wr.cpu())[..., 3:4]
     assert tuple(out['uniform_pts_rec'].shape) == (1, 500, 1, 1, 1)
-    assert maxerr(out['uniform_pts_rec'], ref) <= 3e-5
+    assert maxerr(out['uniform_pts_rec'], ref) <= 1e-5
 
 
 def test_ragged_and_tiny_extents(sd):
@@ -195,6 +196,6 @@ def test_ragged_and_tiny_extents(sd):
         with torch.no_grad():
             raw = r.run_network(pts, torch.zeros_like(pts), styles=wr)
             ref = renderer_ref.query_points(sd, pts.cpu(), None, wr.cpu())
-        assert maxerr(raw[..., 3], ref[..., 3]) <= 3e-5 and maxerr(raw[..., 4:], ref[..., 4:]) <= 3e-4, n
+        assert maxerr(raw[..., 3], ref[..., 3]) <= 1e-5 and maxerr(raw[..., 4:], ref[..., 4:]) <= 1e-4, n
     empty = r.run_network(torch.empty(1, 0, 1, 1, 3, device=DEV), torch.empty(1, 0, 1, 1, 3, device=DEV), styles=wr)
     assert empty.numel() == 0

@@ -179,7 +179,8 @@ def test_modconv_weights_kernel():
         want = ww.transpose(1, 2).reshape(B * Ci, Co, k * k) if tr else ww.reshape(B * Co, Ci, k * k)
         out = torch.empty(want.shape, device=DEV)
         lib = _lib.load()
-        _lib.check(lib.e3dge_modconv_weights(out.data_ptr(), T(w.numpy()).data_ptr(), T(s.numpy()).data_ptr(), float(scale),
+        wd, sdv = T(w.numpy()), T(s.numpy())
+        _lib.check(lib.e3dge_modconv_weights(out.data_ptr(), wd.data_ptr(), sdv.data_ptr(), float(scale),
                                              demod, tr, B, Co, Ci, k * k, _lib.stream_of(out)), "modconv")
         e = maxerr(out, want)
         record("modconv_weights", Co=Co, Ci=Ci, err=e)
