@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 BENCH="python $PWD/bench.py --steps 30 --warmup 5 --no-cpu-baseline $*"
 cd /tmp
 echo "== kernel trace" 
-timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1
 echo "rc=$?"
 rocprofv3 -L > "$OUT/counters_list.txt" 2>&1
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
@@ -18,7 +18,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_I
            "FETCH_SIZE" "WRITE_SIZE"; do
   name=$(echo $grp | cut -d' ' -f1)
   echo "== pmc $grp"
-  timeout 600 rocprofv3 --kernel-trace --pmc $grp -d "$OUT/pmc_$name" -o pmc -- $BENCH --no-inversion > "$OUT/pmc_$name.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc_$name" -o pmc -- $BENCH --no-inversion > "$OUT/pmc_$name.log" 2>&1
   echo "rc=$?"
 done
 # compact summaries for profiles/
@@ -56,3 +56,7 @@ with open(os.path.join(out, "pmc_summary.txt"), "w") as f:
                     f.write(f"    {cn:<32} mean/dispatch = {tot / max(n,1):.6g}   (n={n})\n")
 print(open(os.path.join(out, "pmc_summary.txt")).read())
 PY
+( cd "$OUT" && find . -type f | head -60 > "$OUT/files.txt"; cat "$OUT/files.txt" )
+# keep the merge-back small: drop anything above 2 MB (raw traces, databases)
+find "$OUT" -type f -size +2M -delete
+du -sh "$OUT"
