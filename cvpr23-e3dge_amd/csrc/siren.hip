@@ -57,7 +57,8 @@ constexpr int kLdsW = 0;
 constexpr int kLdsFilm = kLdsW + kNBuf * kChunkFloats;               // [9][2][256] gamma/beta of this image
 constexpr int kLdsHead = kLdsFilm + 9 * 2 * kWidth;                  // w_sigma[256], w_rgb[3][256], b_sigma, b_rgb[3]
 constexpr int kHeadFloats = 4 * kWidth + 4;
-constexpr int kLdsFeat = kLdsHead + kHeadFloats;                     // [kRMax][kFPitch]
+constexpr int kLdsVTail = kLdsHead + kHeadFloats;                    // [8 t][2][64] view-layer tail fragments
+constexpr int kLdsFeat = kLdsVTail + kNT * 2 * 64;                   // [kRMax][kFPitch]
 constexpr int kLdsPart = kLdsFeat + kRMax * kFPitch;                 // [4][kMaxSlots][256]
 constexpr int kLdsAlpha = ((kLdsPart + 4 * kMaxSlots * kWidth + 3) / 4) * 4;   // [128]
 constexpr int kLdsWgt = kLdsAlpha + kTilePts;                        // [128]
@@ -101,23 +102,20 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
                                      (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
 
-// sin(x), |x| < ~1e5: 3-term Cody-Waite reduction by pi/2 with FMAs + Cephes sinf/cosf minimax kernels on
-// [-pi/4, pi/4].  Branch-free; <= 2 ulp of the correctly rounded result (checked by the sin self-test).
+// sin(x) for |x| < ~1e5 in 13 VALU ops: k = rint(x/pi), r = x - k*pi by a 2-term Cody-Waite reduction with FMAs
+// (|r| <= pi/2), sin(x) = (-1)^k * (r + r^3 * P(r^2)) with a degree-9 minimax P (4.7e-9 in exact arithmetic), sign
+// applied by xor-ing k's parity into the sign bit.  Branch-free; measured max abs error 1.2e-7 (self-test).
 __device__ __forceinline__ float sin_f32(float x) {
-    const float kf = rintf(x * 0.636619772367581343f);
-    float r = fmaf(-kf, 1.5707963705062866e+00f, x);
-    r = fmaf(-kf, -4.3711388286737929e-08f, r);
-    r = fmaf(-kf, -1.7151245100058e-15f, r);
-    const int q = (int)kf;
+    const float kf = rintf(x * 0.318309886183790672f);
+    float r = fmaf(-kf, 3.1415927410125732f, x);
+    r = fmaf(-kf, -8.742277657347586e-08f, r);
     const float r2 = r * r;
-    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    sp = fmaf(sp, r2, -1.6666654611e-1f);
-    const float s = fmaf(sp * r2, r, r);
-    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    cp = fmaf(cp, r2, 4.166664568298827e-2f);
-    const float c = fmaf(cp * r2, r2, fmaf(-0.5f, r2, 1.0f));
-    float v = (q & 1) ? c : s;
-    return (q & 2) ? -v : v;
+    float p = fmaf(r2, 2.6003292532550404e-06f, -1.9806761702056974e-04f);
+    p = fmaf(p, r2, 8.33301991224289e-03f);
+    p = fmaf(p, r2, -1.6666656732559204e-01f);
+    const float sv = fmaf(r * r2, p, r);
+    const unsigned sign = ((unsigned)(int)kf) << 31;
+    return __uint_as_float(__float_as_uint(sv) ^ sign);
 }
 
 __device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
@@ -127,51 +125,46 @@ __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, kWave
 // K=256 contraction of one 32-feature output tile against the wave's register-resident activations.
 //   TRANSPOSED=false: D[feature][point]  (weights = A operand, activations = B operand)
 //   TRANSPOSED=true : D[point][feature]  (activations = A operand, weights = B operand)
-// The weight fragments are double-buffered in registers: the 4 ds_read_b128 of k-block c+1 are issued
-// before the 16 MFMAs of k-block c (1024 cycles of cover for the LDS latency).
-template <bool TRANSPOSED>
+// * The weight fragments are double-buffered in registers: each ds_read_b128 of k-block c+1 is issued ahead of
+//   4 MFMAs of k-block c (one k-block = 1024 cycles of cover for the LDS latency).
+// * `epi(r)`, r = 0..15, is the epilogue of the PREVIOUS output tile (FiLM + sine of one accumulator register, ~20
+//   VALU ops); it is called once every second 4-MFMA group so that its VALU work issues in the shadow of this
+//   tile's MFMAs (the matrix pipe is busy 64 cycles per MFMA, a VALU op takes 4) instead of after them.
+struct NoEpilogue { __device__ __forceinline__ void operator()(int) const {} };
+
+template <bool TRANSPOSED, class Epi>
 __device__ __forceinline__ f32x16 big_tile(const float* __restrict__ wchunk, int lane,
-                                           const f32x16 (&in)[kNT], f32x16 acc) {
+                                           const f32x16 (&in)[kNT], f32x16 acc, Epi&& epi) {
     const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wchunk) + lane;
-    f32x4 cur[4], nxt[4];
+    constexpr int kGroups = kNT * 4;     // 32 groups of 4 MFMAs (one ds_read_b128 each)
+    constexpr int kAhead = 2;            // fragments in flight ahead of the one being consumed
+    f32x4 ring[kAhead + 1];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cur[q] = wp[q * 64];
+    for (int g = 0; g < kAhead; ++g) ring[g] = wp[g * 64];
 #pragma unroll
-    for (int c = 0; c < kNT; ++c) {
+    for (int g = 0; g < kGroups; ++g) {
+        if (g + kAhead < kGroups) ring[(g + kAhead) % (kAhead + 1)] = wp[(g + kAhead) * 64];
+        __builtin_amdgcn_sched_barrier(0);              // keep the prefetch ahead of the MFMAs it covers
+        const f32x4 w4 = ring[g % (kAhead + 1)];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (c + 1 < kNT) {
-                nxt[q] = wp[((c + 1) * 4 + q) * 64];
-                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs it covers
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float act = in[c][4 * q + j];
-                acc = TRANSPOSED ? mfma32(act, cur[q][j], acc) : mfma32(cur[q][j], act, acc);
-            }
+        for (int j = 0; j < 4; ++j) {
+            const float act = in[g >> 2][4 * (g & 3) + j];
+            acc = TRANSPOSED ? mfma32(act, w4[j], acc) : mfma32(w4[j], act, acc);
         }
-        if (c + 1 < kNT) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
-        }
+        if ((g & 1) == 0) epi(g >> 1);
     }
     return acc;
 }
 
-// accumulator initialised with the layer bias, standard layout (rows = features): 4 x 16 B from L2
-__device__ __forceinline__ f32x16 bias_std(const float* __restrict__ bias, int t, int half) {
-    f32x16 acc;
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 32 * t + 8 * q + 4 * half);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[4 * q + j] = b4[j];
-    }
-    return acc;
+    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+    return z;
 }
 
 // sin(gamma * acc + beta), standard layout; gamma/beta of the layer come from the LDS copy of this image's
-// FiLM block ([2][256]).  gamma*out and +beta are separately rounded as in FiLMSiren.forward (:130).
+// FiLM block ([2][256], bias already folded into beta).  gamma*out and +beta are separately rounded (:130).
 __device__ __forceinline__ f32x16 film_sin_std(f32x16 acc, const float* __restrict__ film_l, int t, int half) {
     f32x16 o;
 #pragma unroll
@@ -207,6 +200,7 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
     float* const wbuf = smem + kLdsW;
     float* const film_s = smem + kLdsFilm;
     float* const head_s = smem + kLdsHead;
+    float* const vtail_s = smem + kLdsVTail;
     float* const feat_acc = smem + kLdsFeat;
     float* const part = smem + kLdsPart;
     float* const alpha_s = smem + kLdsAlpha;
@@ -242,9 +236,20 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
 
     const float* __restrict__ packed = a.packed;
     const float* __restrict__ film_g = a.film + (int64_t)b * 9 * 2 * kWidth;
-    for (int i = tid; i < 9 * 2 * kWidth; i += kThreads) film_s[i] = film_g[i];   // published by the first barrier
+    // Per-image FiLM block in LDS with the layer bias folded into the offset:
+    //   sin(gamma * (W h + b) + beta) = sin(gamma * (W h) + beta'),  beta' = gamma * b + beta
+    // so the accumulators start at literal zero and the pipelined tiles issue no VMEM besides the weight DMA.
+    // (Differs from the reference's rounding order by ~1 ulp of the sine argument, the same size as the
+    // difference between the MFMA's and MKL's summation orders.)  Published by the first chunk barrier.
+    for (int i = tid; i < 9 * kWidth; i += kThreads) {
+        const int l = i >> 8, n = i & 255;
+        const float gm = film_g[(l * 2 + 0) * kWidth + n], bt = film_g[(l * 2 + 1) * kWidth + n];
+        film_s[(l * 2 + 0) * kWidth + n] = gm;
+        film_s[(l * 2 + 1) * kWidth + n] = __fadd_rn(__fmul_rn(gm, packed[kOffBias + l * kWidth + n]), bt);
+    }
     const float* __restrict__ film = film_s;
     for (int i = tid; i < kHeadFloats; i += kThreads) head_s[i] = packed[kOffWSigma + i];
+    for (int i = tid; i < kNT * 2 * 64; i += kThreads) vtail_s[i] = packed[kOffVTail + i];
     const float* __restrict__ bias_all = packed + kOffBias;
 
     // per-image camera (render mode)
@@ -361,7 +366,7 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
             const float* __restrict__ wf = packed + kOffFirst;
 #pragma unroll
             for (int t = 0; t < kNT; ++t) {
-                f32x16 acc = bias_std(bias_all, t, half);
+                f32x16 acc = zero16();
                 acc = mfma32(wf[(t * 2 + 0) * 64 + lane], b0, acc);
                 acc = mfma32(wf[(t * 2 + 1) * 64 + lane], b1, acc);
                 in[t] = film_sin_std(acc, film, t, half);
@@ -369,23 +374,44 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
         }
 
         // =====================================================================================
-        // 3. layers 1..7 (256 -> 256), weights streamed through LDS
+        // 3. layers 1..7 (256 -> 256): 56 output tiles, weights streamed through LDS.  Software pipeline: the
+        //    FiLM + sine epilogue of tile i-1 issues inside the MFMA stream of tile i (big_tile's epi hook), the
+        //    bias of tile i+1 is fetched while tile i computes.  Only the last tile of a layer (whose result the
+        //    next layer's first MFMAs need) runs its epilogue on its own.
         // =====================================================================================
+        {
 #pragma unroll 1
-        for (int L = 1; L < E3DGE_SIREN_DEPTH; ++L) {
-            const float* __restrict__ bias_l = bias_all + L * kWidth;
-            const float* __restrict__ film_l = film + L * 2 * kWidth;
-#pragma unroll 1
-            for (int t = 0; t < kNT; ++t) {
-                f32x16 acc = bias_std(bias_l, t, half);      // VMEM issued (and drained by wait_chunk) before the DMA
-                const float* wchunk = wait_chunk();
-                asm volatile("" : "+a"(acc));                // retire the bias load's wait here, not after the DMA issue
-                issue_chunk();
-                acc = big_tile<false>(wchunk, lane, in, acc);
-                set_tile(out, t, film_sin_std(acc, film_l, t, half));
-            }
+            for (int L = 1; L < E3DGE_SIREN_DEPTH; ++L) {
+                const float* __restrict__ film_l = film + L * 2 * kWidth;
+                f32x16 prev;
 #pragma unroll
-            for (int t = 0; t < kNT; ++t) in[t] = out[t];
+                for (int t = 0; t < kNT; ++t) {
+                    const float* wchunk = wait_chunk();
+                    issue_chunk();
+                    f32x16 acc = zero16();
+                    if (t == 0) {
+                        acc = big_tile<false>(wchunk, lane, in, acc, NoEpilogue());
+                    } else {
+                        f32x4 g4, b4;
+                        const float* __restrict__ fl = film_l + 32 * (t - 1) + 4 * half;
+                        acc = big_tile<false>(wchunk, lane, in, acc, [&](int r) {
+                            if ((r & 3) == 0) {
+                                g4 = *reinterpret_cast<const f32x4*>(fl + 8 * (r >> 2));
+                                b4 = *reinterpret_cast<const f32x4*>(fl + kWidth + 8 * (r >> 2));
+                            }
+                            out[t - 1][r] = sin_f32(__fadd_rn(__fmul_rn(g4[r & 3], prev[r]), b4[r & 3]));
+                        });
+                        asm volatile("" : "+a"(out[t - 1]));   // park finished activations in the accumulator half
+                    }
+                    prev = acc;
+                }
+                out[kNT - 1] = film_sin_std(prev, film_l, kNT - 1, half);
+#pragma unroll
+                for (int tt = 0; tt < kNT; ++tt) {
+                    in[tt] = out[tt];
+                    asm volatile("" : "+a"(in[tt]));         // MFMA B/A operands are read straight from AGPRs
+                }
+            }
         }
 
         // =====================================================================================
@@ -491,53 +517,69 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) prgb[c][r] = 0.0f;
         {
-            const float* __restrict__ bias_v = bias_all + 8 * kWidth;
             const float* __restrict__ film_v = film + 8 * 2 * kWidth;
-            const float* __restrict__ wvt = packed + kOffVTail;
+            const float* __restrict__ wvt = vtail_s;
             const float* __restrict__ wrgb = head_s + kWidth;
             const float a0 = half ? vy : vx;
             const float a1 = half ? 0.0f : vz;
+            const int slab_p0 = sub * kTilePts + 32 * wave;
+            // epilogue of one finished view tile `tp` held in `pv`: FiLM + sine, rgb-head partials, and either the
+            // per-ray feature composite partials (render) or the raw feature rows (points mode)
+            f32x16 pv;
+            float fa0 = 0.f, fa1 = 0.f, fa2 = 0.f;
+            float e_gm = 0.f, e_bt = 0.f, e_w0 = 0.f, e_w1 = 0.f, e_w2 = 0.f;
+            int e_n = 0;
+            auto epi_begin = [&](int tp) {
+                e_n = 32 * tp + col;
+                e_gm = film_v[e_n]; e_bt = film_v[kWidth + e_n];
+                e_w0 = wrgb[e_n]; e_w1 = wrgb[kWidth + e_n]; e_w2 = wrgb[2 * kWidth + e_n];
+                fa0 = fa1 = fa2 = 0.f;
+            };
+            auto epi_r = [&](int r) {
+                const float h = sin_f32(__fadd_rn(__fmul_rn(e_gm, pv[r]), e_bt));
+                prgb[0][r] = fmaf(e_w0, h, prgb[0][r]);
+                prgb[1][r] = fmaf(e_w1, h, prgb[1][r]);
+                prgb[2][r] = fmaf(e_w2, h, prgb[2][r]);
+                if (MODE == 0) {
+                    fa0 = fmaf((row_slot[r] == 0) ? row_w[r] : 0.0f, h, fa0);
+                    fa1 = fmaf((row_slot[r] == 1) ? row_w[r] : 0.0f, h, fa1);
+                    fa2 = fmaf((row_slot[r] == 2) ? row_w[r] : 0.0f, h, fa2);
+                } else if (a.raw) {
+                    const int pr = slab_p0 + row_of(r, half);
+                    if (pr < npts) a.raw[((int64_t)b * a.n_pts + pt0 + pr) * 260 + 4 + e_n] = h;
+                }
+            };
+            auto epi_end = [&]() {
+                if (MODE == 0) {
+                    fa0 += xhalf(fa0); fa1 += xhalf(fa1); fa2 += xhalf(fa2);
+                    if (half == 0) {
+                        float* pp = part + (wave * kMaxSlots) * kWidth + e_n;
+                        if (slab_nslots > 0) pp[0] = fa0;
+                        if (slab_nslots > 1) pp[kWidth] = fa1;
+                        if (slab_nslots > 2) pp[2 * kWidth] = fa2;
+                    }
+                }
+            };
 #pragma unroll 1
             for (int t = 0; t < kNT; ++t) {
-                const int n = 32 * t + col;                       // this lane's output feature
-                float bv = bias_v[n];
-                float wt0 = wvt[(t * 2 + 0) * 64 + lane], wt1 = wvt[(t * 2 + 1) * 64 + lane];
                 const float* wchunk = wait_chunk();
-                asm volatile("" : "+v"(bv), "+v"(wt0), "+v"(wt1));
                 issue_chunk();
-                const float gm = film_v[n], bt = film_v[kWidth + n];
-                const float wr0 = wrgb[n], wr1 = wrgb[kWidth + n], wr2 = wrgb[2 * kWidth + n];
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = bv;
-                acc = big_tile<true>(wchunk, lane, in, acc);
-                acc = mfma32(a0, wt0, acc);
-                acc = mfma32(a1, wt1, acc);
-                float h[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    h[r] = sin_f32(__fadd_rn(__fmul_rn(gm, acc[r]), bt));
-                    prgb[0][r] = fmaf(wr0, h[r], prgb[0][r]);
-                    prgb[1][r] = fmaf(wr1, h[r], prgb[1][r]);
-                    prgb[2][r] = fmaf(wr2, h[r], prgb[2][r]);
+                f32x16 acc = zero16();
+                if (t == 0) {
+                    acc = big_tile<true>(wchunk, lane, in, acc, NoEpilogue());
+                } else {
+                    epi_begin(t - 1);
+                    acc = big_tile<true>(wchunk, lane, in, acc, epi_r);
+                    epi_end();
                 }
-                if (MODE == 0) {
-                    // feature composite partials (:894): sum over this slab's points of each ray
-                    for (int sl = 0; sl < slab_nslots; ++sl) {
-                        float fa = 0.0f;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) fa = fmaf((row_slot[r] == sl) ? row_w[r] : 0.0f, h[r], fa);
-                        fa += xhalf(fa);
-                        if (half == 0) part[(wave * kMaxSlots + sl) * kWidth + n] = fa;
-                    }
-                } else if (a.raw) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int pr = sub * kTilePts + 32 * wave + row_of(r, half);
-                        if (pr < npts) a.raw[((int64_t)b * a.n_pts + pt0 + pr) * 260 + 4 + n] = h[r];
-                    }
-                }
+                acc = mfma32(a0, wvt[(t * 2 + 0) * 64 + lane], acc);
+                acc = mfma32(a1, wvt[(t * 2 + 1) * 64 + lane], acc);
+                pv = acc;
             }
+            epi_begin(kNT - 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) epi_r(r);
+            epi_end();
         }
 
         // =====================================================================================
