@@ -8,7 +8,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libe3dge_hip.so")
+LIB_PATH = os.environ.get("E3DGE_LIB_PATH") or os.path.join(_HERE, "lib", "libe3dge_hip.so")   # override: kernel A/B variants
 ABI_VERSION = 1
 
 _c_float_p = ctypes.c_void_p     # device pointers travel as integers
@@ -44,6 +44,7 @@ SIGNATURES = {
     "e3dge_siren_points_fwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _i64, _vp, _vp, _vp]),
     "e3dge_selftest_mfma": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "e3dge_selftest_sin": (_i32, [_vp, _vp, _i32, _vp]),
+    "e3dge_selftest_sin_poly": (_i32, [_vp, _vp, _i32, _vp]),
 }
 
 _lib = None

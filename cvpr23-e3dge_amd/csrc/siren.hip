@@ -42,6 +42,18 @@ constexpr int kFPitch = kWidth + 1;             // padded pitch of the feature a
 constexpr int kMaxSlots = 3;                    // rays a 32-point slab can touch when S >= 16
 constexpr int kMinSamples = 16;
 
+// VALU instructions of the pipelined epilogue forced behind each MFMA with sched_group_barrier (0 = leave the
+// placement to the compiler).  Measured on MI355X (round 1, tools/build_variant.sh A/B): 0 -> 0.949 ms, 2..4 ->
+// 1.00-1.02 ms, with one or two accumulators alike: on gfx950 the fp32 MFMA and the fp32 VALU do not execute
+// concurrently for one wave (PMC: MFMA-busy + VALU-active + waits = wave cycles in every variant), so spreading
+// only adds issue bubbles.  The lever that works is FEWER VALU instructions, not better placement.
+#ifndef E3DGE_SPREAD_STD
+#define E3DGE_SPREAD_STD 0
+#endif
+#ifndef E3DGE_SPREAD_VIEW
+#define E3DGE_SPREAD_VIEW 0
+#endif
+
 // ---- packed weight image (floats) ----
 constexpr int64_t kOffBig = 0;                                       // [8 layers][8 t][8 c][4 q][64 lane][4]
 constexpr int64_t kOffFirst = kOffBig + (int64_t)kChunksPerPass * kChunkFloats;   // [8 t][2][64]
@@ -102,10 +114,20 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
                                      (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
 
-// sin(x) for |x| < ~1e5 in 13 VALU ops: k = rint(x/pi), r = x - k*pi by a 2-term Cody-Waite reduction with FMAs
-// (|r| <= pi/2), sin(x) = (-1)^k * (r + r^3 * P(r^2)) with a degree-9 minimax P (4.7e-9 in exact arithmetic), sign
-// applied by xor-ing k's parity into the sign bit.  Branch-free; measured max abs error 1.2e-7 (self-test).
-__device__ __forceinline__ float sin_f32(float x) {
+// Two sines, both with an exact FMA Cody-Waite range reduction (|x| < ~1e5):
+//  * sin_hw_f32 (default, 6 VALU ops): reduce to |r| <= pi, hardware v_sin_f32 on r / 2pi.  Max abs error 3.8e-7.
+//  * sin_poly_f32 (13 VALU ops): reduce to |r| <= pi/2, degree-9 minimax odd polynomial (4.7e-9 in exact
+//    arithmetic), sign from k's parity.  Max abs error 1.2e-7.
+// fp32 MFMA and fp32 VALU do not overlap on gfx950, so every VALU op of the epilogue is paid in full; the
+// renderer's parity against the reference is the same with either (features ~1e-5, the summation-order noise).
+// -DE3DGE_POLY_SINE selects the polynomial for the kernels.
+__device__ __forceinline__ float sin_hw_f32(float x) {
+    const float kf = rintf(x * 0.159154943091895336f);
+    float r = fmaf(-kf, 6.2831854820251465f, x);
+    r = fmaf(-kf, -1.7484555314695172e-07f, r);
+    return __builtin_amdgcn_sinf(r * 0.159154943091895336f);
+}
+__device__ __forceinline__ float sin_poly_f32(float x) {
     const float kf = rintf(x * 0.318309886183790672f);
     float r = fmaf(-kf, 3.1415927410125732f, x);
     r = fmaf(-kf, -8.742277657347586e-08f, r);
@@ -116,6 +138,13 @@ __device__ __forceinline__ float sin_f32(float x) {
     const float sv = fmaf(r * r2, p, r);
     const unsigned sign = ((unsigned)(int)kf) << 31;
     return __uint_as_float(__float_as_uint(sv) ^ sign);
+}
+__device__ __forceinline__ float sin_f32(float x) {
+#ifdef E3DGE_POLY_SINE
+    return sin_poly_f32(x);
+#else
+    return sin_hw_f32(x);
+#endif
 }
 
 __device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
@@ -132,26 +161,41 @@ __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, kWave
 //   tile's MFMAs (the matrix pipe is busy 64 cycles per MFMA, a VALU op takes 4) instead of after them.
 struct NoEpilogue { __device__ __forceinline__ void operator()(int) const {} };
 
-template <bool TRANSPOSED, class Epi>
+template <bool TRANSPOSED, int VALU_PER_MFMA, class Epi, class Issue>
 __device__ __forceinline__ f32x16 big_tile(const float* __restrict__ wchunk, int lane,
-                                           const f32x16 (&in)[kNT], f32x16 acc, Epi&& epi) {
+                                           const f32x16 (&in)[kNT], f32x16 acc, Epi&& epi, Issue&& issue_next) {
     const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wchunk) + lane;
     constexpr int kGroups = kNT * 4;     // 32 groups of 4 MFMAs (one ds_read_b128 each)
-    constexpr int kAhead = 2;            // fragments in flight ahead of the one being consumed
-    f32x4 ring[kAhead + 1];
+    constexpr int kAhead = 2;            // fragments in flight ahead of the pair being consumed
+    f32x4 ring[kAhead + 2];
 #pragma unroll
     for (int g = 0; g < kAhead; ++g) ring[g] = wp[g * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    issue_next();                        // the next chunk's DMA is issued in the shadow of the first LDS reads
 #pragma unroll
-    for (int g = 0; g < kGroups; ++g) {
-        if (g + kAhead < kGroups) ring[(g + kAhead) % (kAhead + 1)] = wp[(g + kAhead) * 64];
+    for (int gp = 0; gp < kGroups; gp += 2) {
+        // one scheduling region = 2 fragment prefetches + 8 MFMAs + one epilogue register of the previous tile
+#pragma unroll
+        for (int g = gp; g < gp + 2; ++g)
+            if (g + kAhead < kGroups) ring[(g + kAhead) % (kAhead + 2)] = wp[(g + kAhead) * 64];
         __builtin_amdgcn_sched_barrier(0);              // keep the prefetch ahead of the MFMAs it covers
-        const f32x4 w4 = ring[g % (kAhead + 1)];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float act = in[g >> 2][4 * (g & 3) + j];
-            acc = TRANSPOSED ? mfma32(act, w4[j], acc) : mfma32(w4[j], act, acc);
+        for (int g = gp; g < gp + 2; ++g) {
+            const f32x4 w4 = ring[g % (kAhead + 2)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float act = in[g >> 2][4 * (g & 3) + j];
+                acc = TRANSPOSED ? mfma32(act, w4[j], acc) : mfma32(w4[j], act, acc);
+            }
         }
-        if ((g & 1) == 0) epi(g >> 1);
+        epi(gp >> 1);
+        if (VALU_PER_MFMA > 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);   // n VALU
+            }
+        }
     }
     return acc;
 }
@@ -164,7 +208,7 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 
 // sin(gamma * acc + beta), standard layout; gamma/beta of the layer come from the LDS copy of this image's
-// FiLM block ([2][256], bias already folded into beta).  gamma*out and +beta are separately rounded (:130).
+// FiLM block ([2][256], bias already folded into beta); one fused multiply-add feeds the sine.
 __device__ __forceinline__ f32x16 film_sin_std(f32x16 acc, const float* __restrict__ film_l, int t, int half) {
     f32x16 o;
 #pragma unroll
@@ -173,7 +217,7 @@ __device__ __forceinline__ f32x16 film_sin_std(f32x16 acc, const float* __restri
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(film_l + kWidth + 32 * t + 8 * q + 4 * half);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            o[4 * q + j] = sin_f32(__fadd_rn(__fmul_rn(g4[j], acc[4 * q + j]), b4[j]));
+            o[4 * q + j] = sin_f32(fmaf(g4[j], acc[4 * q + j], b4[j]));
     }
     return o;
 }
@@ -194,6 +238,15 @@ __device__ __forceinline__ void set_tile(f32x16 (&dst)[kNT], int t, const f32x16
 // ---------------------------------------------------------------------------------------------
 // the kernel.  MODE 0 = render (rays x samples + compositing), MODE 1 = arbitrary point set (raw outputs)
 // ---------------------------------------------------------------------------------------------
+// Phase timing (variant builds only, -DE3DGE_PHASE_TIMING): wave 0 of workgroup 0 records s_memtime at the phase
+// boundaries of each sub-tile and, at the very end, overwrites the first floats of the `dists` output with the
+// per-phase cycle counts (tools/phase_timing.py reads them back).
+#ifdef E3DGE_PHASE_TIMING
+#define PHASE_MARK(i) do { if (MODE == 0 && blockIdx.x == 0 && tid == 0 && sub < 4) tstamp[sub * 6 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PHASE_MARK(i) do { } while (0)
+#endif
+
 template <int MODE>
 __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -264,36 +317,44 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
     }
 
     // ---- weight chunk pipeline ----
+    // 32 pieces of 1 KiB per chunk, 8 per wave.  The LDS side is wave-uniform (SGPR -> M0), the global side is one
+    // per-lane base plus immediates; chunk / buffer indices are running scalar counters (no division per tile).
     const int total_chunks = n_sub * kChunksPerPass;
-    int g_issue = 0;      // next chunk to issue
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const float* const src_lane = packed + kOffBig + wave_u * 2048 + lane * 4;
+    int g_issue = 0, issue_chunk_idx = 0, issue_buf = 0;
     auto issue_chunk = [&]() {
         if (g_issue < total_chunks) {
-            const float* src = packed + kOffBig + (int64_t)(g_issue % kChunksPerPass) * kChunkFloats;
-            float* dst = wbuf + (g_issue % kNBuf) * kChunkFloats;
+            const float* src = src_lane + (int64_t)issue_chunk_idx * kChunkFloats;
+            float* dst = wbuf + issue_buf * kChunkFloats + wave_u * 2048;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int piece = wave * 8 + i;        // 32 pieces of 1 KiB, 8 per wave
-                glds16(src + piece * 256 + lane * 4, dst + piece * 256);
-            }
+            for (int i = 0; i < 8; ++i) glds16(src + i * 256, dst + i * 256);
         }
         ++g_issue;
+        issue_chunk_idx = (issue_chunk_idx + 1 == kChunksPerPass) ? 0 : issue_chunk_idx + 1;
+        issue_buf = (issue_buf + 1 == kNBuf) ? 0 : issue_buf + 1;
     };
     for (int i = 0; i < kNBuf - 1; ++i) issue_chunk();
-    int g_use = 0;        // chunk being consumed
-    // Every wave calls wait_chunk() before consuming chunk g_use: its own DMA pieces have landed (vmcnt),
-    // the barrier publishes everybody's and proves that all waves are done with chunk g_use-1, whose
-    // buffer the next issue_chunk() overwrites.
+    int use_buf = 0;      // buffer of the chunk being consumed
+    // Every wave calls wait_chunk() before consuming a chunk: its own DMA pieces have landed (vmcnt), the barrier
+    // publishes everybody's and proves that all waves are done with the previous chunk, whose buffer the next
+    // issue_chunk() overwrites.
     auto wait_chunk = [&]() -> const float* {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const float* p = wbuf + (g_use % kNBuf) * kChunkFloats;
-        ++g_use;
+        const float* p = wbuf + use_buf * kChunkFloats;
+        use_buf = (use_buf + 1 == kNBuf) ? 0 : use_buf + 1;
         return p;
     };
 
     f32x16 in[kNT], out[kNT];
+#ifdef E3DGE_PHASE_TIMING
+    unsigned long long tstamp[24];
+    for (int i = 0; i < 24; ++i) tstamp[i] = 0;
+#endif
 
     for (int sub = 0; sub < n_sub; ++sub) {
+        PHASE_MARK(0);
         // =====================================================================================
         // 1. this lane's point
         // =====================================================================================
@@ -373,6 +434,7 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
             }
         }
 
+        PHASE_MARK(1);
         // =====================================================================================
         // 3. layers 1..7 (256 -> 256): 56 output tiles, weights streamed through LDS.  Software pipeline: the
         //    FiLM + sine epilogue of tile i-1 issues inside the MFMA stream of tile i (big_tile's epi hook), the
@@ -387,23 +449,23 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
 #pragma unroll
                 for (int t = 0; t < kNT; ++t) {
                     const float* wchunk = wait_chunk();
-                    issue_chunk();
                     f32x16 acc = zero16();
                     if (t == 0) {
-                        acc = big_tile<false>(wchunk, lane, in, acc, NoEpilogue());
+                        acc = big_tile<false, 0>(wchunk, lane, in, acc, NoEpilogue(), issue_chunk);
                     } else {
                         f32x4 g4, b4;
                         const float* __restrict__ fl = film_l + 32 * (t - 1) + 4 * half;
-                        acc = big_tile<false>(wchunk, lane, in, acc, [&](int r) {
+                        acc = big_tile<false, E3DGE_SPREAD_STD>(wchunk, lane, in, acc, [&](int r) {
                             if ((r & 3) == 0) {
                                 g4 = *reinterpret_cast<const f32x4*>(fl + 8 * (r >> 2));
                                 b4 = *reinterpret_cast<const f32x4*>(fl + kWidth + 8 * (r >> 2));
                             }
-                            out[t - 1][r] = sin_f32(__fadd_rn(__fmul_rn(g4[r & 3], prev[r]), b4[r & 3]));
-                        });
+                            out[t - 1][r] = sin_f32(fmaf(g4[r & 3], prev[r], b4[r & 3]));
+                        }, issue_chunk);
                         asm volatile("" : "+a"(out[t - 1]));   // park finished activations in the accumulator half
                     }
                     prev = acc;
+                    asm volatile("" : "+v"(prev));           // the epilogue's VALU reads it: keep it out of the AGPRs
                 }
                 out[kNT - 1] = film_sin_std(prev, film_l, kNT - 1, half);
 #pragma unroll
@@ -414,6 +476,7 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
             }
         }
 
+        PHASE_MARK(2);
         // =====================================================================================
         // 4. sdf head (:206-208) on the backbone output, standard layout: features live on registers
         // =====================================================================================
@@ -454,18 +517,31 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 float T = (s_lo == 0) ? 1.0f : st[0];
                 float wsum = (s_lo == 0) ? 0.0f : st[1];
                 float dep = st[2], x0 = st[3], x1 = st[4], x2 = st[5];
-                for (int s = s_lo; s < s_hi; ++s) {
-                    const int ps = rl * S + s - sub_lo;
-                    const float al = alpha_s[ps];
-                    float w = __fmul_rn(al, T);
-                    if (a.force_bg && s == S - 1) w = __fsub_rn(1.0f, wsum);
-                    else wsum = __fadd_rn(wsum, w);
-                    T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.0f, al), 1e-10f));
-                    wgt_s[ps] = w;
-                    dep = __fadd_rn(dep, __fmul_rn(w, z_s[ps]));
-                    x0 = __fadd_rn(x0, __fmul_rn(w, pts_s[ps * 3 + 0]));
-                    x1 = __fadd_rn(x1, __fmul_rn(w, pts_s[ps * 3 + 1]));
-                    x2 = __fadd_rn(x2, __fmul_rn(w, pts_s[ps * 3 + 2]));
+                // 4 samples per trip: the 20 LDS reads of a trip are independent of the carried (T, wsum) chain and
+                // issue together; only the two multiplies per sample are serial.
+                for (int s0 = s_lo; s0 < s_hi; s0 += 4) {
+                    float al[4], zz[4], p0[4], p1[4], p2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ps = min(rl * S + s0 + u, sub_hi - 1) - sub_lo;
+                        al[u] = alpha_s[ps]; zz[u] = z_s[ps];
+                        p0[u] = pts_s[ps * 3 + 0]; p1[u] = pts_s[ps * 3 + 1]; p2[u] = pts_s[ps * 3 + 2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int s = s0 + u;
+                        if (s < s_hi) {
+                            float w = __fmul_rn(al[u], T);
+                            if (a.force_bg && s == S - 1) w = __fsub_rn(1.0f, wsum);
+                            else wsum = __fadd_rn(wsum, w);
+                            T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.0f, al[u]), 1e-10f));
+                            wgt_s[rl * S + s - sub_lo] = w;
+                            dep = __fadd_rn(dep, __fmul_rn(w, zz[u]));
+                            x0 = __fadd_rn(x0, __fmul_rn(w, p0[u]));
+                            x1 = __fadd_rn(x1, __fmul_rn(w, p1[u]));
+                            x2 = __fadd_rn(x2, __fmul_rn(w, p2[u]));
+                        }
+                    }
                 }
                 st[0] = T; st[1] = wsum; st[2] = dep; st[3] = x0; st[4] = x1; st[5] = x2;
             }
@@ -489,12 +565,14 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 }
         }
 
+        PHASE_MARK(3);
         // =====================================================================================
         // 5. view layer (259 -> 256), TRANSPOSED: rows (registers) = points, cols (lanes) = features
         // =====================================================================================
         // per-register (= per point row) compositing weight and ray slot of this wave's 32-point slab
-        float row_w[16];
-        int row_slot[16];
+        // Composite weights of this wave's 32-point slab, split by the ray they belong to.  With S >= 16 a slab
+        // touches at most 3 rays; their boundaries inside the slab are at rows b1 and b1 + S.
+        float wq0[16], wq1[16], wq2[16];
         int slab_first_ray = 0, slab_nslots = 0;
         if (MODE == 0) {
             const int slab_lo = sub * kTilePts + 32 * wave;
@@ -503,12 +581,14 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 slab_first_ray = slab_lo / S;
                 slab_nslots = (slab_hi - 1) / S - slab_first_ray + 1;
             }
+            const int b1 = (slab_first_ray + 1) * S - slab_lo, b2 = b1 + S;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int pr = slab_lo + row_of(r, half);
-                const bool ok = pr < npts;
-                row_w[r] = ok ? wgt_s[32 * wave + row_of(r, half)] : 0.0f;
-                row_slot[r] = ok ? (pr / S - slab_first_ray) : -1;
+                const int row = row_of(r, half);
+                const float w = (slab_lo + row < npts) ? wgt_s[32 * wave + row] : 0.0f;
+                wq0[r] = (row < b1) ? w : 0.0f;
+                wq1[r] = (row >= b1 && row < b2) ? w : 0.0f;
+                wq2[r] = (row >= b2) ? w : 0.0f;
             }
         }
         float prgb[3][16];
@@ -536,14 +616,14 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 fa0 = fa1 = fa2 = 0.f;
             };
             auto epi_r = [&](int r) {
-                const float h = sin_f32(__fadd_rn(__fmul_rn(e_gm, pv[r]), e_bt));
+                const float h = sin_f32(fmaf(e_gm, pv[r], e_bt));
                 prgb[0][r] = fmaf(e_w0, h, prgb[0][r]);
                 prgb[1][r] = fmaf(e_w1, h, prgb[1][r]);
                 prgb[2][r] = fmaf(e_w2, h, prgb[2][r]);
                 if (MODE == 0) {
-                    fa0 = fmaf((row_slot[r] == 0) ? row_w[r] : 0.0f, h, fa0);
-                    fa1 = fmaf((row_slot[r] == 1) ? row_w[r] : 0.0f, h, fa1);
-                    fa2 = fmaf((row_slot[r] == 2) ? row_w[r] : 0.0f, h, fa2);
+                    fa0 = fmaf(wq0[r], h, fa0);
+                    fa1 = fmaf(wq1[r], h, fa1);
+                    fa2 = fmaf(wq2[r], h, fa2);
                 } else if (a.raw) {
                     const int pr = slab_p0 + row_of(r, half);
                     if (pr < npts) a.raw[((int64_t)b * a.n_pts + pt0 + pr) * 260 + 4 + e_n] = h;
@@ -563,18 +643,18 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
 #pragma unroll 1
             for (int t = 0; t < kNT; ++t) {
                 const float* wchunk = wait_chunk();
-                issue_chunk();
                 f32x16 acc = zero16();
                 if (t == 0) {
-                    acc = big_tile<true>(wchunk, lane, in, acc, NoEpilogue());
+                    acc = big_tile<true, 0>(wchunk, lane, in, acc, NoEpilogue(), issue_chunk);
                 } else {
                     epi_begin(t - 1);
-                    acc = big_tile<true>(wchunk, lane, in, acc, epi_r);
+                    acc = big_tile<true, E3DGE_SPREAD_VIEW>(wchunk, lane, in, acc, epi_r, issue_chunk);
                     epi_end();
                 }
                 acc = mfma32(a0, wvt[(t * 2 + 0) * 64 + lane], acc);
                 acc = mfma32(a1, wvt[(t * 2 + 1) * 64 + lane], acc);
                 pv = acc;
+                asm volatile("" : "+v"(pv));
             }
             epi_begin(kNT - 1);
 #pragma unroll
@@ -582,30 +662,48 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
             epi_end();
         }
 
+        PHASE_MARK(4);
         // =====================================================================================
         // 6. rgb head (:235): reduce the per-lane partials over the 32 feature lanes of each half
         // =====================================================================================
+        // Transpose-reduce over the 32 feature lanes of each half: at every step a lane keeps half of its rows and
+        // hands the other half to its xor-partner, so the row count halves while the lane span doubles (8+4+2+1+1
+        // shuffles per channel instead of 5 x 16).  Afterwards lane `col` (and col^1) holds the total of row col >> 1.
+        float rgbv[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c) {
+            float q8[8], q4[4], q2[2], q1;
+            const bool b4 = col & 16, b3 = col & 8, b2 = col & 4, b1 = col & 2;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = prgb[c][r];
-                v += __shfl_xor(v, 1, kWave);
-                v += __shfl_xor(v, 2, kWave);
-                v += __shfl_xor(v, 4, kWave);
-                v += __shfl_xor(v, 8, kWave);
-                v += __shfl_xor(v, 16, kWave);
-                prgb[c][r] = v + head_s[4 * kWidth + 1 + c];
+            for (int i = 0; i < 8; ++i) {
+                const float keep = b4 ? prgb[c][8 + i] : prgb[c][i], send = b4 ? prgb[c][i] : prgb[c][8 + i];
+                q8[i] = keep + __shfl_xor(send, 16, kWave);
             }
-        if (MODE == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (col == r) {
-                    const int ps = 32 * wave + row_of(r, half);
-                    rgb_s[ps * 3 + 0] = sigmoid_f32(prgb[0][r]);
-                    rgb_s[ps * 3 + 1] = sigmoid_f32(prgb[1][r]);
-                    rgb_s[ps * 3 + 2] = sigmoid_f32(prgb[2][r]);
-                }
+            for (int i = 0; i < 4; ++i) {
+                const float keep = b3 ? q8[4 + i] : q8[i], send = b3 ? q8[i] : q8[4 + i];
+                q4[i] = keep + __shfl_xor(send, 8, kWave);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float keep = b2 ? q4[2 + i] : q4[i], send = b2 ? q4[i] : q4[2 + i];
+                q2[i] = keep + __shfl_xor(send, 4, kWave);
+            }
+            {
+                const float keep = b1 ? q2[1] : q2[0], send = b1 ? q2[0] : q2[1];
+                q1 = keep + __shfl_xor(send, 2, kWave);
+            }
+            q1 += __shfl_xor(q1, 1, kWave);
+            rgbv[c] = q1 + head_s[4 * kWidth + 1 + c];
+        }
+        const int my_row = row_of(col >> 1, half);                 // the slab row whose rgb this lane now holds
+        if (MODE == 0) {
+            if ((col & 1) == 0) {
+                const int ps = 32 * wave + my_row;
+                rgb_s[ps * 3 + 0] = sigmoid_f32(rgbv[0]);
+                rgb_s[ps * 3 + 1] = sigmoid_f32(rgbv[1]);
+                rgb_s[ps * 3 + 2] = sigmoid_f32(rgbv[2]);
+            }
             __syncthreads();
             // rgb composite (:888-890), sequential per ray, and ordered merge of the feature partials
             const int sub_lo = sub * kTilePts;
@@ -616,12 +714,21 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 const int s_lo = max(0, sub_lo - rl * S), s_hi = min(S, sub_hi - rl * S);
                 float* st = state + rl * kStateStride;
                 float c0 = st[6], c1 = st[7], c2 = st[8];
-                for (int s = s_lo; s < s_hi; ++s) {
-                    const int ps = rl * S + s - sub_lo;
-                    const float w = wgt_s[ps];
-                    c0 = __fadd_rn(c0, __fmul_rn(w, rgb_s[ps * 3 + 0]));
-                    c1 = __fadd_rn(c1, __fmul_rn(w, rgb_s[ps * 3 + 1]));
-                    c2 = __fadd_rn(c2, __fmul_rn(w, rgb_s[ps * 3 + 2]));
+                for (int s0 = s_lo; s0 < s_hi; s0 += 4) {
+                    float ww[4], q0[4], q1[4], q2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ps = min(rl * S + s0 + u, sub_hi - 1) - sub_lo;
+                        ww[u] = (s0 + u < s_hi) ? wgt_s[ps] : 0.0f;
+                        q0[u] = rgb_s[ps * 3 + 0]; q1[u] = rgb_s[ps * 3 + 1]; q2[u] = rgb_s[ps * 3 + 2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (s0 + u < s_hi) {
+                            c0 = __fadd_rn(c0, __fmul_rn(ww[u], q0[u]));
+                            c1 = __fadd_rn(c1, __fmul_rn(ww[u], q1[u]));
+                            c2 = __fadd_rn(c2, __fmul_rn(ww[u], q2[u]));
+                        }
                 }
                 st[6] = c0; st[7] = c1; st[8] = c2;
             }
@@ -640,21 +747,20 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
             __syncthreads();
         } else {
             if (a.raw || a.sdf) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (col == r) {
-                        const int pr = sub * kTilePts + 32 * wave + row_of(r, half);
-                        if (pr < npts && a.raw) {
-                            float* o = a.raw + ((int64_t)b * a.n_pts + pt0 + pr) * 260;
-                            o[0] = prgb[0][r]; o[1] = prgb[1][r]; o[2] = prgb[2][r];
-                        }
+                if (a.raw && (col & 1) == 0) {
+                    const int pr = sub * kTilePts + 32 * wave + my_row;
+                    if (pr < npts) {
+                        float* o = a.raw + ((int64_t)b * a.n_pts + pt0 + pr) * 260;
+                        o[0] = rgbv[0]; o[1] = rgbv[1]; o[2] = rgbv[2];
                     }
+                }
                 if (valid && half == 0) {
                     if (a.sdf) a.sdf[gpt] = sdf;
                     if (a.raw) a.raw[gpt * 260 + 3] = sdf;
                 }
             }
         }
+        PHASE_MARK(5);
     }  // sub-tiles
 
     // make sure no LDS-DMA is still in flight when the workgroup retires
@@ -688,6 +794,12 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
             if (a.depth) a.depth[(int64_t)b * HW + pix] = st[2];
             if (a.mask) a.mask[(int64_t)b * HW + pix] = (st[2] < a.mask_thresh) ? 1.0f : 0.0f;
         }
+#ifdef E3DGE_PHASE_TIMING
+        __syncthreads();
+        if (blockIdx.x == 0 && tid == 0 && a.dists)
+            for (int i = 0; i < 18; ++i)
+                a.dists[i] = (i % 6 == 0) ? (float)(i / 6 ? tstamp[i] - tstamp[i - 1] : 0) : (float)(tstamp[i] - tstamp[i - 1]);
+#endif
     }
 }
 
@@ -793,9 +905,9 @@ selftest_mfma_kernel(float* __restrict__ cmat, const float* __restrict__ amat,
     for (int r = 0; r < 16; ++r) cmat[row_of(r, half) * 32 + col] = acc[r];
 }
 
-__global__ void selftest_sin_kernel(float* __restrict__ y, const float* __restrict__ x, int n) {
+__global__ void selftest_sin_kernel(float* __restrict__ y, const float* __restrict__ x, int n, int mode) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] = sin_f32(x[i]);
+    if (i < n) y[i] = mode ? sin_poly_f32(x[i]) : sin_f32(x[i]);
 }
 
 static int ensure_lds_attr() {
@@ -933,6 +1045,13 @@ extern "C" int e3dge_selftest_mfma(float* c, const float* a, const float* b, int
 extern "C" int e3dge_selftest_sin(float* y, const float* x, int n, e3dge_stream_t stream) {
     E3DGE_REQUIRE(y && x && n >= 0, "selftest_sin: bad arguments");
     if (n == 0) return E3DGE_OK;
-    selftest_sin_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(y, x, n);
+    selftest_sin_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(y, x, n, 0);
     return check_launch("selftest_sin");
+}
+
+extern "C" int e3dge_selftest_sin_poly(float* y, const float* x, int n, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(y && x && n >= 0, "selftest_sin_poly: bad arguments");
+    if (n == 0) return E3DGE_OK;
+    selftest_sin_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(y, x, n, 1);
+    return check_launch("selftest_sin_poly");
 }

@@ -182,6 +182,8 @@ int e3dge_siren_points_fwd(const float* packed, const float* film, const float* 
 int e3dge_selftest_mfma(float* c, const float* a, const float* b, int k, e3dge_stream_t stream);
 /* Accuracy self-test of the kernel's sine: y[i] = sin(x[i]) with the device routine the SIREN layers use. */
 int e3dge_selftest_sin(float* y, const float* x, int n, e3dge_stream_t stream);
+/* The alternative 13-op polynomial sine (kernels built with -DE3DGE_POLY_SINE use it). */
+int e3dge_selftest_sin_poly(float* y, const float* x, int n, e3dge_stream_t stream);
 
 #ifdef __cplusplus
 }
