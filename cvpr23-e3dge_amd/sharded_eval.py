@@ -1,0 +1,59 @@
+"""Image-sharded evaluation across GPUs (BASELINE.json configs[2] and [3]).
+
+The reference evaluates on ONE GPU (`scripts/test/eval_2dmetrics_ffhq.sh:24-26`, `trainer.py:290-556`); its only
+collective anywhere near this path is the loss-vector reduce of `dist_utils.py:108-130`.  Every image (or camera
+pose of a sweep) is an independent unit, so the MI355X design is: one process per GPU, unit i -> rank i mod W,
+weights replicated, NO collective inside the path, and exactly one RCCL `all_gather` of the per-unit metric
+rows at the end (ragged tails padded).  The 8 columns are the scalars `losses/builder.py:174-184` reports:
+loss_l2, loss_id, loss_lpips, loss, mae, PSNR, SSIM, ID_SIM -- whatever `unit_fn` returns is gathered verbatim.
+
+`backend` is "nccl" (= RCCL on ROCm) on GPUs and "gloo" in the CPU tests; the logic is identical."""
+import torch
+import torch.distributed as dist
+
+N_METRICS = 8
+
+
+def shard_indices(n_units, rank, world_size):
+    """Units owned by `rank`: i = rank, rank + W, rank + 2W, ...  (interleaved, so ranks stay balanced when the
+    cost of a unit drifts along the list, e.g. along a camera sweep)."""
+    if not (0 <= rank < world_size):
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    return list(range(rank, n_units, world_size))
+
+
+def gather_metric_rows(local_rows, n_units, rank, world_size, group=None):
+    """local_rows (n_local, M) on this rank's device, rows in shard_indices order -> (n_units, M) in global unit
+    order on EVERY rank.  One all_gather of a (ceil(n/W), M) block per rank; ragged tails are padded with NaN and
+    dropped after the gather."""
+    n_local = len(shard_indices(n_units, rank, world_size))
+    if local_rows.ndim != 2 or local_rows.shape[0] != n_local:
+        raise ValueError(f"expected ({n_local}, M) rows on rank {rank}, got {tuple(local_rows.shape)}")
+    per_rank = (n_units + world_size - 1) // world_size
+    M = local_rows.shape[1]
+    block = torch.full((per_rank, M), float('nan'), dtype=local_rows.dtype, device=local_rows.device)
+    block[:n_local] = local_rows
+    if world_size == 1:
+        gathered = [block]
+    else:
+        gathered = [torch.empty_like(block) for _ in range(world_size)]
+        dist.all_gather(gathered, block, group=group)
+    out = torch.empty((n_units, M), dtype=local_rows.dtype, device=local_rows.device)
+    for r in range(world_size):
+        idx = shard_indices(n_units, r, world_size)
+        if idx:
+            out[torch.tensor(idx, device=out.device)] = gathered[r][:len(idx)]
+    return out
+
+
+def evaluate_sharded(unit_fn, n_units, rank=0, world_size=1, device="cpu", group=None):
+    """Runs `unit_fn(i) -> (M,) tensor of metric scalars` for the units this rank owns and returns the (n_units, M)
+    table (identical on all ranks).  `unit_fn` is where the hot path is called (renderer / generator forward on
+    this rank's GPU); nothing is exchanged between ranks until the final gather."""
+    rows = [unit_fn(i).reshape(-1).to(device) for i in shard_indices(n_units, rank, world_size)]
+    if rows:
+        local = torch.stack(rows)
+    else:
+        probe = unit_fn.__dict__.get('n_metrics', N_METRICS)
+        local = torch.empty((0, probe), device=device)
+    return gather_metric_rows(local, n_units, rank, world_size, group)
