@@ -161,33 +161,34 @@ __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, kWave
 //   tile's MFMAs (the matrix pipe is busy 64 cycles per MFMA, a VALU op takes 4) instead of after them.
 struct NoEpilogue { __device__ __forceinline__ void operator()(int) const {} };
 
-template <bool TRANSPOSED, int VALU_PER_MFMA, class Epi, class Issue>
-__device__ __forceinline__ f32x16 big_tile(const float* __restrict__ wchunk, int lane,
-                                           const f32x16 (&in)[kNT], f32x16 acc, Epi&& epi, Issue&& issue_next) {
+constexpr int kRing = 4;          // weight fragments held in registers (2 being consumed + 2 in flight)
+constexpr int kSyncPair = 4;      // MFMA-group pair after which the chunk barrier + next DMA issue happen
+
+template <bool TRANSPOSED, int VALU_PER_MFMA, class Epi, class Sync>
+__device__ __forceinline__ f32x16 big_tile(const float* __restrict__ wchunk, const float* __restrict__ wnext,
+                                           int lane, const f32x16 (&in)[kNT], f32x16 acc, f32x4 (&ring)[kRing],
+                                           Epi&& epi, Sync&& sync) {
     const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wchunk) + lane;
+    const f32x4* __restrict__ wn = reinterpret_cast<const f32x4*>(wnext) + lane;
     constexpr int kGroups = kNT * 4;     // 32 groups of 4 MFMAs (one ds_read_b128 each)
-    constexpr int kAhead = 2;            // fragments in flight ahead of the pair being consumed
-    f32x4 ring[kAhead + 2];
-#pragma unroll
-    for (int g = 0; g < kAhead; ++g) ring[g] = wp[g * 64];
-    __builtin_amdgcn_sched_barrier(0);
-    issue_next();                        // the next chunk's DMA is issued in the shadow of the first LDS reads
+    // On entry ring[0], ring[1] hold groups 0 and 1 of this chunk (fetched by the previous tile's tail or the
+    // prologue); on exit they hold groups 0 and 1 of the NEXT chunk, so consecutive tiles run back to back.
 #pragma unroll
     for (int gp = 0; gp < kGroups; gp += 2) {
-        // one scheduling region = 2 fragment prefetches + 8 MFMAs + one epilogue register of the previous tile
 #pragma unroll
-        for (int g = gp; g < gp + 2; ++g)
-            if (g + kAhead < kGroups) ring[(g + kAhead) % (kAhead + 2)] = wp[(g + kAhead) * 64];
+        for (int g = gp + 2; g < gp + 4; ++g)
+            ring[g % kRing] = (g < kGroups) ? wp[g * 64] : wn[(g - kGroups) * 64];
         __builtin_amdgcn_sched_barrier(0);              // keep the prefetch ahead of the MFMAs it covers
 #pragma unroll
         for (int g = gp; g < gp + 2; ++g) {
-            const f32x4 w4 = ring[g % (kAhead + 2)];
+            const f32x4 w4 = ring[g % kRing];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float act = in[g >> 2][4 * (g & 3) + j];
                 acc = TRANSPOSED ? mfma32(act, w4[j], acc) : mfma32(w4[j], act, acc);
             }
         }
+        if (gp == kSyncPair) sync();
         epi(gp >> 1);
         if (VALU_PER_MFMA > 0) {
 #pragma unroll
@@ -335,17 +336,29 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
         issue_buf = (issue_buf + 1 == kNBuf) ? 0 : issue_buf + 1;
     };
     for (int i = 0; i < kNBuf - 1; ++i) issue_chunk();
-    int use_buf = 0;      // buffer of the chunk being consumed
-    // Every wave calls wait_chunk() before consuming a chunk: its own DMA pieces have landed (vmcnt), the barrier
-    // publishes everybody's and proves that all waves are done with the previous chunk, whose buffer the next
-    // issue_chunk() overwrites.
-    auto wait_chunk = [&]() -> const float* {
+    // Chunk protocol (3 buffers).  chunk_sync() runs in the MIDDLE of every tile g: each wave drains its own DMA
+    // (that is chunk g+1, issued one whole tile earlier), the barrier publishes it to the other waves and proves
+    // that everybody has left tile g-1, whose buffer the DMA of chunk g+2 may now overwrite.  Hence chunk g+1 is
+    // complete and visible before tile g+1 starts: tiles need no barrier, wait or LDS-latency bubble between them.
+    auto chunk_sync = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const float* p = wbuf + use_buf * kChunkFloats;
-        use_buf = (use_buf + 1 == kNBuf) ? 0 : use_buf + 1;
-        return p;
+        issue_chunk();
     };
+    int use_buf = 0;      // buffer of the chunk being consumed
+    const float* wcur = wbuf;
+    const float* wnxt = wbuf + kChunkFloats;
+    auto advance_chunk = [&]() {
+        use_buf = (use_buf + 1 == kNBuf) ? 0 : use_buf + 1;
+        wcur = wnxt;
+        wnxt = wbuf + ((use_buf + 1 == kNBuf) ? 0 : use_buf + 1) * kChunkFloats;
+    };
+    // first chunk (and the LDS parameter blocks staged above) visible to everyone; prime the fragment ring
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4 ring[kRing];
+    ring[0] = reinterpret_cast<const f32x4*>(wcur)[lane];
+    ring[1] = reinterpret_cast<const f32x4*>(wcur)[64 + lane];
 
     f32x16 in[kNT], out[kNT];
 #ifdef E3DGE_PHASE_TIMING
@@ -448,22 +461,22 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 f32x16 prev;
 #pragma unroll
                 for (int t = 0; t < kNT; ++t) {
-                    const float* wchunk = wait_chunk();
                     f32x16 acc = zero16();
                     if (t == 0) {
-                        acc = big_tile<false, 0>(wchunk, lane, in, acc, NoEpilogue(), issue_chunk);
+                        acc = big_tile<false, 0>(wcur, wnxt, lane, in, acc, ring, NoEpilogue(), chunk_sync);
                     } else {
                         f32x4 g4, b4;
                         const float* __restrict__ fl = film_l + 32 * (t - 1) + 4 * half;
-                        acc = big_tile<false, E3DGE_SPREAD_STD>(wchunk, lane, in, acc, [&](int r) {
+                        acc = big_tile<false, E3DGE_SPREAD_STD>(wcur, wnxt, lane, in, acc, ring, [&](int r) {
                             if ((r & 3) == 0) {
                                 g4 = *reinterpret_cast<const f32x4*>(fl + 8 * (r >> 2));
                                 b4 = *reinterpret_cast<const f32x4*>(fl + kWidth + 8 * (r >> 2));
                             }
                             out[t - 1][r] = sin_f32(fmaf(g4[r & 3], prev[r], b4[r & 3]));
-                        }, issue_chunk);
+                        }, chunk_sync);
                         asm volatile("" : "+a"(out[t - 1]));   // park finished activations in the accumulator half
                     }
+                    advance_chunk();
                     prev = acc;
                     asm volatile("" : "+v"(prev));           // the epilogue's VALU reads it: keep it out of the AGPRs
                 }
@@ -642,15 +655,15 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
             };
 #pragma unroll 1
             for (int t = 0; t < kNT; ++t) {
-                const float* wchunk = wait_chunk();
                 f32x16 acc = zero16();
                 if (t == 0) {
-                    acc = big_tile<true, 0>(wchunk, lane, in, acc, NoEpilogue(), issue_chunk);
+                    acc = big_tile<true, 0>(wcur, wnxt, lane, in, acc, ring, NoEpilogue(), chunk_sync);
                 } else {
                     epi_begin(t - 1);
-                    acc = big_tile<true, E3DGE_SPREAD_VIEW>(wchunk, lane, in, acc, epi_r, issue_chunk);
+                    acc = big_tile<true, E3DGE_SPREAD_VIEW>(wcur, wnxt, lane, in, acc, ring, epi_r, chunk_sync);
                     epi_end();
                 }
+                advance_chunk();
                 acc = mfma32(a0, wvt[(t * 2 + 0) * 64 + lane], acc);
                 acc = mfma32(a1, wvt[(t * 2 + 1) * 64 + lane], acc);
                 pv = acc;
