@@ -28,6 +28,9 @@ namespace e3dge {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));       // 8 packed f16 = one f16-MFMA operand
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWidth = E3DGE_SIREN_WIDTH;       // 256
 constexpr int kNT = kWidth / 32;                // 8 output tiles of 32 features
@@ -62,7 +65,14 @@ constexpr int64_t kOffBias = kOffVTail + kNT * 2 * 64;               // [9][256]
 constexpr int64_t kOffWSigma = kOffBias + 9 * kWidth;                // [256]
 constexpr int64_t kOffWRgb = kOffWSigma + kWidth;                    // [3][256]
 constexpr int64_t kOffBHead = kOffWRgb + 3 * kWidth;                 // b_sigma, b_rgb[3]
-constexpr int64_t kPackedFloats = kOffBHead + 4;
+constexpr int64_t kOffBig16 = kOffBHead + 4;                         // f16x3 image of the 8 big layers, see below
+constexpr int64_t kPackedFloats = kOffBig16 + (int64_t)kChunksPerPass * kChunkFloats;
+// f16x3 image: the same 64 chunks of 32 KiB, each [16 k-steps g = 2c+s][hi, lo][64 lanes][8 f16]: lane l holds
+//   128 * W[32t + (l&31)][32c + 16s + (j&3) + 8(j>>2) + 4(l>>5)],  j = 0..7
+// split as hi = f16(v), lo = f16(v - hi).  The k order is the one in which a lane's C/D registers of the previous
+// layer (r = 8s + j) become the 8 k-slots of a v_mfma_f32_32x32x16_f16 operand; 128 keeps `lo` out of the f16
+// subnormals and is undone exactly by storing gamma / 128.
+constexpr float kW16Scale = 128.0f;
 
 // ---- LDS carve (floats) ----
 constexpr int kLdsW = 0;
@@ -108,6 +118,30 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 // C/D fragment of v_mfma_f32_32x32x2_f32: lane l, register r holds D[row_of(r, l>>5)][l&31].
 __device__ __forceinline__ constexpr int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float f16lo(unsigned p) { return (float)__builtin_bit_cast(fp16x2, p).x; }
+__device__ __forceinline__ float f16hi(unsigned p) { return (float)__builtin_bit_cast(fp16x2, p).y; }
+// fp32 pair -> packed f16 (hi word, lo word) with x = hi + lo up to 2^-21 |x| (v_cvt_pkrtz rounds toward zero, so the
+// remainder is exact in fp32 and has the sign of x).  Simulated against float64 this split with three products
+// (hi*hi + hi*lo + lo*hi, fp32 accumulate) is as accurate as plain fp32 in this network.
+struct HiLo { unsigned h, l; };
+__device__ __forceinline__ HiLo split2(float x0, float x1) {
+    HiLo p;
+    p.h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    p.l = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0 - f16lo(p.h), x1 - f16hi(p.h)));
+    return p;
+}
+// (vector elements cannot be bound to references, hence the macro)
+#define SPLIT2_TO(x0, x1, H, L) do { const HiLo p_ = split2((x0), (x1)); (H) = p_.h; (L) = p_.l; } while (0)
+
+// value r (0..15) of feature tile c from the packed (hi, lo) representation
+__device__ __forceinline__ float acts16_get(const u32x4 (&aH)[2 * kNT], const u32x4 (&aL)[2 * kNT], int c, int r) {
+    const int g = 2 * c + (r >> 3), k = (r & 7) >> 1;
+    return (r & 1) ? f16hi(aH[g][k]) + f16hi(aL[g][k]) : f16lo(aH[g][k]) + f16lo(aL[g][k]);
+}
 
 __device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -201,6 +235,42 @@ __device__ __forceinline__ f32x16 big_tile(const float* __restrict__ wchunk, con
     return acc;
 }
 
+// The same contraction on the f16 matrix pipe: fp32 operands split into f16 hi + lo, three products per k-step
+// (hi*hi, lo_w*hi_a, hi_w*lo_a) into one fp32 accumulator.  16 k-steps of K=16 per tile = 48 MFMAs of 32
+// cycles (1536 vs 8192 for fp32), and this pipe runs concurrently with the VALU, so the epilogue hides under it.
+constexpr int kRing16 = 4;        // k-steps whose (hi, lo) weight fragments are held: 1 consumed + 3 in flight
+constexpr int kSyncStep16 = 2;    // k-step after which the chunk barrier + next DMA issue happen
+
+template <bool TRANSPOSED, class Epi, class Sync>
+__device__ __forceinline__ void big_tile_f16(const float* __restrict__ wchunk, const float* __restrict__ wnext,
+                                             int lane, const u32x4 (&aH)[2 * kNT], const u32x4 (&aL)[2 * kNT],
+                                             f32x16& acc, u32x4 (&ringH)[kRing16],
+                                             u32x4 (&ringL)[kRing16], Epi&& epi, Sync&& sync) {
+    const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(wchunk) + lane;
+    const u32x4* __restrict__ wn = reinterpret_cast<const u32x4*>(wnext) + lane;
+    constexpr int kSteps = 2 * kNT;
+    // entry: ring slots 0..2 hold k-steps 0..2 of this chunk; exit: k-steps 0..2 of the next chunk
+#pragma unroll
+    for (int g = 0; g < kSteps; ++g) {
+        const int ga = g + kRing16 - 1;
+        ringH[ga % kRing16] = (ga < kSteps) ? wp[(ga * 2 + 0) * 64] : wn[((ga - kSteps) * 2 + 0) * 64];
+        ringL[ga % kRing16] = (ga < kSteps) ? wp[(ga * 2 + 1) * 64] : wn[((ga - kSteps) * 2 + 1) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x4 wh = ringH[g % kRing16], wl = ringL[g % kRing16];
+        if (!TRANSPOSED) {
+            acc = mfma16(wh, aH[g], acc);
+            acc = mfma16(wl, aH[g], acc);
+            acc = mfma16(wh, aL[g], acc);
+        } else {
+            acc = mfma16(aH[g], wh, acc);
+            acc = mfma16(aH[g], wl, acc);
+            acc = mfma16(aL[g], wh, acc);
+        }
+        if (g == kSyncStep16) sync();
+        epi(g);
+    }
+}
+
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -248,8 +318,10 @@ __device__ __forceinline__ void set_tile(f32x16 (&dst)[kNT], int t, const f32x16
 #define PHASE_MARK(i) do { } while (0)
 #endif
 
-template <int MODE>
+// PREC 0: fp32 MFMA (v_mfma_f32_32x32x2_f32).  PREC 1: "f16x3" -- split-f16 contraction on v_mfma_f32_32x32x16_f16.
+template <int MODE, int PREC>
 __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
+    constexpr bool F16 = PREC == 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wbuf = smem + kLdsW;
     float* const film_s = smem + kLdsFilm;
@@ -298,7 +370,8 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
     for (int i = tid; i < 9 * kWidth; i += kThreads) {
         const int l = i >> 8, n = i & 255;
         const float gm = film_g[(l * 2 + 0) * kWidth + n], bt = film_g[(l * 2 + 1) * kWidth + n];
-        film_s[(l * 2 + 0) * kWidth + n] = gm;
+        // f16x3: the streamed weights carry a factor 128 (kW16Scale); gamma / 128 is exact and undoes it
+        film_s[(l * 2 + 0) * kWidth + n] = (F16 && l >= 1) ? gm * (1.0f / kW16Scale) : gm;
         film_s[(l * 2 + 1) * kWidth + n] = __fadd_rn(__fmul_rn(gm, packed[kOffBias + l * kWidth + n]), bt);
     }
     const float* __restrict__ film = film_s;
@@ -322,7 +395,7 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
     // per-lane base plus immediates; chunk / buffer indices are running scalar counters (no division per tile).
     const int total_chunks = n_sub * kChunksPerPass;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const float* const src_lane = packed + kOffBig + wave_u * 2048 + lane * 4;
+    const float* const src_lane = packed + (F16 ? kOffBig16 : kOffBig) + wave_u * 2048 + lane * 4;
     int g_issue = 0, issue_chunk_idx = 0, issue_buf = 0;
     auto issue_chunk = [&]() {
         if (g_issue < total_chunks) {
@@ -357,10 +430,23 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x4 ring[kRing];
-    ring[0] = reinterpret_cast<const f32x4*>(wcur)[lane];
-    ring[1] = reinterpret_cast<const f32x4*>(wcur)[64 + lane];
+    u32x4 ringH[kRing16], ringL[kRing16];
+    if (!F16) {
+        ring[0] = reinterpret_cast<const f32x4*>(wcur)[lane];
+        ring[1] = reinterpret_cast<const f32x4*>(wcur)[64 + lane];
+    } else {
+#pragma unroll
+        for (int g = 0; g < kRing16 - 1; ++g) {
+            ringH[g] = reinterpret_cast<const u32x4*>(wcur)[(g * 2 + 0) * 64 + lane];
+            ringL[g] = reinterpret_cast<const u32x4*>(wcur)[(g * 2 + 1) * 64 + lane];
+        }
+    }
 
+    // Register-resident activations of this wave's 32 points.
+    //   fp32 : in[t][r]                      = feature 32t + row_of(r, half)
+    //   f16x3: inH/inL[2t + (r>>3)] word (r&7)>>1, half-word r&1  (packed f16 hi / lo of the same value)
     f32x16 in[kNT], out[kNT];
+    u32x4 inH[2 * kNT], inL[2 * kNT], outH[2 * kNT], outL[2 * kNT];
 #ifdef E3DGE_PHASE_TIMING
     unsigned long long tstamp[24];
     for (int i = 0; i < 24; ++i) tstamp[i] = 0;
@@ -443,7 +529,14 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 f32x16 acc = zero16();
                 acc = mfma32(wf[(t * 2 + 0) * 64 + lane], b0, acc);
                 acc = mfma32(wf[(t * 2 + 1) * 64 + lane], b1, acc);
-                in[t] = film_sin_std(acc, film, t, half);
+                const f32x16 v0 = film_sin_std(acc, film, t, half);
+                if (!F16) {
+                    in[t] = v0;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2)
+                        SPLIT2_TO(v0[r], v0[r + 1], inH[2 * t + (r >> 3)][(r & 7) >> 1], inL[2 * t + (r >> 3)][(r & 7) >> 1]);
+                }
             }
         }
 
@@ -454,7 +547,7 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
         //    bias of tile i+1 is fetched while tile i computes.  Only the last tile of a layer (whose result the
         //    next layer's first MFMAs need) runs its epilogue on its own.
         // =====================================================================================
-        {
+        if (!F16) {
 #pragma unroll 1
             for (int L = 1; L < E3DGE_SIREN_DEPTH; ++L) {
                 const float* __restrict__ film_l = film + L * 2 * kWidth;
@@ -487,6 +580,47 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                     asm volatile("" : "+a"(in[tt]));         // MFMA B/A operands are read straight from AGPRs
                 }
             }
+        } else {
+#pragma unroll 1
+            for (int L = 1; L < E3DGE_SIREN_DEPTH; ++L) {
+                const float* __restrict__ film_l = film + L * 2 * kWidth;
+                f32x16 prev;
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) {
+                    f32x16 acc = zero16();
+                    if (t == 0) {
+                        big_tile_f16<false>(wcur, wnxt, lane, inH, inL, acc, ringH, ringL, NoEpilogue(), chunk_sync);
+                    } else {
+                        f32x4 g4, b4;
+                        float xe = 0.f;
+                        const float* __restrict__ fl = film_l + 32 * (t - 1) + 4 * half;
+                        big_tile_f16<false>(wcur, wnxt, lane, inH, inL, acc, ringH, ringL, [&](int r) {
+                            if ((r & 3) == 0) {
+                                g4 = *reinterpret_cast<const f32x4*>(fl + 8 * (r >> 2));
+                                b4 = *reinterpret_cast<const f32x4*>(fl + kWidth + 8 * (r >> 2));
+                            }
+                            const float x = sin_f32(fmaf(g4[r & 3], prev[r], b4[r & 3]));
+                            if (r & 1) SPLIT2_TO(xe, x, outH[2 * (t - 1) + (r >> 3)][(r & 7) >> 1], outL[2 * (t - 1) + (r >> 3)][(r & 7) >> 1]);
+                            else xe = x;
+                        }, chunk_sync);
+                        asm volatile("" : "+a"(outH[2 * (t - 1)]), "+a"(outH[2 * (t - 1) + 1]), "+a"(outL[2 * (t - 1)]), "+a"(outL[2 * (t - 1) + 1]));
+                    }
+                    advance_chunk();
+                    prev = acc;
+                    asm volatile("" : "+v"(prev));
+                }
+                {
+                    const f32x16 v7 = film_sin_std(prev, film_l, kNT - 1, half);
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2)
+                        SPLIT2_TO(v7[r], v7[r + 1], outH[2 * (kNT - 1) + (r >> 3)][(r & 7) >> 1], outL[2 * (kNT - 1) + (r >> 3)][(r & 7) >> 1]);
+                }
+#pragma unroll
+                for (int g = 0; g < 2 * kNT; ++g) {
+                    inH[g] = outH[g]; inL[g] = outL[g];
+                    asm volatile("" : "+a"(inH[g]), "+a"(inL[g]));
+                }
+            }
         }
 
         PHASE_MARK(2);
@@ -503,7 +637,8 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 w4 = *reinterpret_cast<const f32x4*>(ws + 32 * c + 8 * q + 4 * half);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc = fmaf(w4[j], in[c][4 * q + j], acc);
+                    for (int j = 0; j < 4; ++j)
+                        acc = fmaf(w4[j], F16 ? acts16_get(inH, inL, c, 4 * q + j) : in[c][4 * q + j], acc);
                 }
             sdf = acc + xhalf(acc) + head_s[4 * kWidth];
         }
@@ -572,9 +707,19 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 a4 = *reinterpret_cast<const f32x4*>(ta + 32 * c + 8 * q + 4 * half);
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(tb + 32 * c + 8 * q + 4 * half);
+                    if (!F16) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        in[c][4 * q + j] = __fadd_rn(__fmul_rn(__fadd_rn(a4[j], 1.0f), in[c][4 * q + j]), b4[j]);
+                        for (int j = 0; j < 4; ++j)
+                            in[c][4 * q + j] = __fadd_rn(__fmul_rn(__fadd_rn(a4[j], 1.0f), in[c][4 * q + j]), b4[j]);
+                    } else {
+                        float y[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            y[j] = __fadd_rn(__fmul_rn(__fadd_rn(a4[j], 1.0f), acts16_get(inH, inL, c, 4 * q + j)), b4[j]);
+                        const int g = 2 * c + (q >> 1), k0 = 2 * (q & 1);
+                        SPLIT2_TO(y[0], y[1], inH[g][k0], inL[g][k0]);
+                        SPLIT2_TO(y[2], y[3], inH[g][k0 + 1], inL[g][k0 + 1]);
+                    }
                 }
         }
 
@@ -656,16 +801,29 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
 #pragma unroll 1
             for (int t = 0; t < kNT; ++t) {
                 f32x16 acc = zero16();
-                if (t == 0) {
-                    acc = big_tile<true, 0>(wcur, wnxt, lane, in, acc, ring, NoEpilogue(), chunk_sync);
+                if (!F16) {
+                    if (t == 0) {
+                        acc = big_tile<true, 0>(wcur, wnxt, lane, in, acc, ring, NoEpilogue(), chunk_sync);
+                    } else {
+                        epi_begin(t - 1);
+                        acc = big_tile<true, E3DGE_SPREAD_VIEW>(wcur, wnxt, lane, in, acc, ring, epi_r, chunk_sync);
+                        epi_end();
+                    }
+                    acc = mfma32(a0, wvt[(t * 2 + 0) * 64 + lane], acc);
+                    acc = mfma32(a1, wvt[(t * 2 + 1) * 64 + lane], acc);
                 } else {
-                    epi_begin(t - 1);
-                    acc = big_tile<true, E3DGE_SPREAD_VIEW>(wcur, wnxt, lane, in, acc, ring, epi_r, chunk_sync);
-                    epi_end();
+                    if (t == 0) {
+                        big_tile_f16<true>(wcur, wnxt, lane, inH, inL, acc, ringH, ringL, NoEpilogue(), chunk_sync);
+                    } else {
+                        epi_begin(t - 1);
+                        big_tile_f16<true>(wcur, wnxt, lane, inH, inL, acc, ringH, ringL, epi_r, chunk_sync);
+                        epi_end();
+                    }
+                    // view-direction tail in fp32, carrying the same 128 scale as the streamed weights
+                    acc = mfma32(a0 * kW16Scale, wvt[(t * 2 + 0) * 64 + lane], acc);
+                    acc = mfma32(a1 * kW16Scale, wvt[(t * 2 + 1) * 64 + lane], acc);
                 }
                 advance_chunk();
-                acc = mfma32(a0, wvt[(t * 2 + 0) * 64 + lane], acc);
-                acc = mfma32(a1, wvt[(t * 2 + 1) * 64 + lane], acc);
                 pv = acc;
                 asm volatile("" : "+v"(pv));
             }
@@ -858,9 +1016,29 @@ siren_pack_kernel(float* __restrict__ packed, const float* __restrict__ w_first,
             v = w_sigma[e - kOffWSigma];
         } else if (e < kOffBHead) {
             v = w_rgb[e - kOffWRgb];
-        } else {
+        } else if (e < kOffBig16) {
             const int r = (int)(e - kOffBHead);
             v = (r == 0) ? b_sigma[0] : b_rgb[r - 1];
+        } else {
+            // one 32-bit word = two f16: [Lb][t][g = 2c+s][hl][lane][word k]  ->  j = 2k, 2k+1
+            int64_t r = e - kOffBig16;
+            const int k = r & 3; r >>= 2;
+            const int lane = r & 63; r >>= 6;
+            const int hl = r & 1; r >>= 1;
+            const int g = r & 15; r >>= 4;
+            const int t = r & 7; r >>= 3;
+            const int Lb = (int)r;
+            const int n = 32 * t + (lane & 31);
+            unsigned word = 0;
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const int j = 2 * k + e2;
+                const int kk = 32 * (g >> 1) + 16 * (g & 1) + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+                const float w = kW16Scale * ((Lb < 7) ? w_hidden[((int64_t)Lb * kWidth + n) * kWidth + kk] : w_view[(int64_t)n * 259 + kk]);
+                const _Float16 hi = (_Float16)w;
+                const _Float16 val = hl ? (_Float16)(w - (float)hi) : hi;
+                word |= (unsigned)__builtin_bit_cast(unsigned short, val) << (16 * e2);
+            }
+            v = __uint_as_float(word);
         }
         packed[e] = v;
     }
@@ -918,6 +1096,26 @@ selftest_mfma_kernel(float* __restrict__ cmat, const float* __restrict__ amat,
     for (int r = 0; r < 16; ++r) cmat[row_of(r, half) * 32 + col] = acc[r];
 }
 
+// Same for v_mfma_f32_32x32x16_f16 with the k-slot convention of the f16x3 path: lane l supplies, for k-step g,
+// the 8 values k = 16g + 8(l>>5) + j of row (A) / column (B) l&31.
+__global__ void __launch_bounds__(64)
+selftest_mfma16_kernel(float* __restrict__ cmat, const float* __restrict__ amat,
+                       const float* __restrict__ bmat, int k) {
+    const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
+    f32x16 acc = zero16();
+    for (int kb = 0; kb < k; kb += 16) {
+        u32x4 a4, b4, dummy;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            SPLIT2_TO(amat[col * k + kb + 8 * half + 2 * w], amat[col * k + kb + 8 * half + 2 * w + 1], a4[w], dummy[w]);
+            SPLIT2_TO(bmat[col * k + kb + 8 * half + 2 * w], bmat[col * k + kb + 8 * half + 2 * w + 1], b4[w], dummy[w]);
+        }
+        acc = mfma16(a4, b4, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cmat[row_of(r, half) * 32 + col] = acc[r];
+}
+
 __global__ void selftest_sin_kernel(float* __restrict__ y, const float* __restrict__ x, int n, int mode) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = mode ? sin_poly_f32(x[i]) : sin_f32(x[i]);
@@ -926,13 +1124,13 @@ __global__ void selftest_sin_kernel(float* __restrict__ y, const float* __restri
 static int ensure_lds_attr() {
     static bool done = false;
     if (!done) {
-        hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&siren_kernel<0>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&siren_kernel<1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        if (e0 != hipSuccess || e1 != hipSuccess)
-            return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", kLdsBytes,
-                        hipGetErrorString(e0 != hipSuccess ? e0 : e1));
+        const void* fns[4] = {reinterpret_cast<const void*>(&siren_kernel<0, 0>), reinterpret_cast<const void*>(&siren_kernel<1, 0>),
+                              reinterpret_cast<const void*>(&siren_kernel<0, 1>), reinterpret_cast<const void*>(&siren_kernel<1, 1>)};
+        for (const void* f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+            if (e != hipSuccess)
+                return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", kLdsBytes, hipGetErrorString(e));
+        }
         done = true;
     }
     return E3DGE_OK;
@@ -1001,6 +1199,7 @@ extern "C" int e3dge_siren_render_fwd(const E3dgeRenderArgs* r, e3dge_stream_t s
                     reinterpret_cast<uintptr_t>(r->tex_alpha) | reinterpret_cast<uintptr_t>(r->tex_beta)) & 15) == 0,
                   "siren_render_fwd: packed/film/tex pointers must be 16-B aligned");
     E3DGE_REQUIRE(r->sigmoid_beta != 0.0f, "siren_render_fwd: sigmoid_beta must be non-zero");
+    E3DGE_REQUIRE(r->precision == E3DGE_PREC_F32 || r->precision == E3DGE_PREC_F16X3, "siren_render_fwd: precision=%d", r->precision);
     if (r->batch == 0) return E3DGE_OK;
     int rc = ensure_lds_attr();
     if (rc) return rc;
@@ -1018,13 +1217,17 @@ extern "C" int e3dge_siren_render_fwd(const E3dgeRenderArgs* r, e3dge_stream_t s
     k.weights = r->weights; k.points = r->points; k.rays_d = r->rays_d; k.viewdirs = r->viewdirs; k.dists = r->dists;
     const int64_t grid = (int64_t)k.tiles_per_img * r->batch;
     E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_render_fwd: grid too large");
-    siren_kernel<0><<<dim3((unsigned)grid), dim3(kThreads), kLdsBytes, as_stream(stream)>>>(k);
+    if (r->precision == E3DGE_PREC_F16X3)
+        siren_kernel<0, 1><<<dim3((unsigned)grid), dim3(kThreads), kLdsBytes, as_stream(stream)>>>(k);
+    else
+        siren_kernel<0, 0><<<dim3((unsigned)grid), dim3(kThreads), kLdsBytes, as_stream(stream)>>>(k);
     return check_launch("siren_render_fwd");
 }
 
 extern "C" int e3dge_siren_points_fwd(const float* packed, const float* film, const float* pts,
                                       const float* viewdirs, float box_scale, int batch, int64_t n_pts,
-                                      float* sdf, float* raw, e3dge_stream_t stream) {
+                                      float* sdf, float* raw, int precision, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(precision == E3DGE_PREC_F32 || precision == E3DGE_PREC_F16X3, "siren_points_fwd: precision=%d", precision);
     E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "siren_points_fwd: bad sizes");
     if (batch == 0 || n_pts == 0) return E3DGE_OK;
     E3DGE_REQUIRE(packed && film && pts, "siren_points_fwd: null input pointer");
@@ -1045,7 +1248,10 @@ extern "C" int e3dge_siren_points_fwd(const float* packed, const float* film, co
     k.wgs_per_img = (int)((tiles + spw - 1) / spw);
     const int64_t grid = (int64_t)k.wgs_per_img * batch;
     E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_points_fwd: grid too large");
-    siren_kernel<1><<<dim3((unsigned)grid), dim3(kThreads), kLdsBytes, as_stream(stream)>>>(k);
+    if (precision == E3DGE_PREC_F16X3)
+        siren_kernel<1, 1><<<dim3((unsigned)grid), dim3(kThreads), kLdsBytes, as_stream(stream)>>>(k);
+    else
+        siren_kernel<1, 0><<<dim3((unsigned)grid), dim3(kThreads), kLdsBytes, as_stream(stream)>>>(k);
     return check_launch("siren_points_fwd");
 }
 
@@ -1053,6 +1259,12 @@ extern "C" int e3dge_selftest_mfma(float* c, const float* a, const float* b, int
     E3DGE_REQUIRE(c && a && b && k > 0 && k <= 256 && (k % 8) == 0, "selftest_mfma: bad arguments");
     selftest_mfma_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(c, a, b, k);
     return check_launch("selftest_mfma");
+}
+
+extern "C" int e3dge_selftest_mfma16(float* c, const float* a, const float* b, int k, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(c && a && b && k > 0 && k <= 256 && (k % 16) == 0, "selftest_mfma16: bad arguments");
+    selftest_mfma16_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(c, a, b, k);
+    return check_launch("selftest_mfma16");
 }
 
 extern "C" int e3dge_selftest_sin(float* y, const float* x, int n, e3dge_stream_t stream) {

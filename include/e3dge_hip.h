@@ -94,6 +94,10 @@ int e3dge_modconv_weights(float* out, const float* weight, const float* style, f
 #define E3DGE_SIREN_DEPTH 8       /* D backbone layers (options.py:837-840)                       */
 #define E3DGE_SIREN_NLAYERS 9     /* D + views_linears                                           */
 
+/* How the 256-wide contractions are evaluated.  Both accumulate in fp32 and meet the same parity bounds. */
+#define E3DGE_PREC_F32 0          /* v_mfma_f32_32x32x2_f32 on fp32 operands                                     */
+#define E3DGE_PREC_F16X3 1        /* operands split as f16 hi+lo, 3 products on v_mfma_f32_32x32x16_f16 (~4x faster) */
+
 /* Number of floats of the packed weight image produced by e3dge_siren_pack_weights. */
 int64_t e3dge_siren_packed_floats(void);
 
@@ -141,6 +145,7 @@ typedef struct E3dgeRenderArgs {
     int batch, height, width, n_samples;
     int res;               /* out_im_res used for the pixel-centre offset (:773-774)                */
     int force_background;  /* (:884-886)                                                           */
+    int precision;         /* E3DGE_PREC_F32 or E3DGE_PREC_F16X3                                      */
     /* ---- outputs ---- */
     float* rgb;            /* (batch, 3, H, W)    gen_thumb_imgs (:888-890, permuted :1964)          */
     float* features;       /* (batch, 256, H, W)  (:894, :1967)                                     */
@@ -174,12 +179,14 @@ int e3dge_siren_render_fwd(const E3dgeRenderArgs* args, e3dge_stream_t stream);
  */
 int e3dge_siren_points_fwd(const float* packed, const float* film, const float* pts,
                            const float* viewdirs, float box_scale, int batch, int64_t n_pts,
-                           float* sdf, float* raw, e3dge_stream_t stream);
+                           float* sdf, float* raw, int precision, e3dge_stream_t stream);
 
 /* Layout self-test: runs a 32x32xK fp32-MFMA product with the fragment conventions the render kernel
  * relies on and writes it to c (32*32 floats, row-major) for the caller to compare with a @ b^T.
  * a: (32, k) row-major, b: (32, k) row-major, k multiple of 8, k <= 256. */
 int e3dge_selftest_mfma(float* c, const float* a, const float* b, int k, e3dge_stream_t stream);
+/* The same with one f16 MFMA (v_mfma_f32_32x32x16_f16) per 16 k on the hi halves of a, b; k multiple of 16. */
+int e3dge_selftest_mfma16(float* c, const float* a, const float* b, int k, e3dge_stream_t stream);
 /* Accuracy self-test of the kernel's sine: y[i] = sin(x[i]) with the device routine the SIREN layers use. */
 int e3dge_selftest_sin(float* y, const float* x, int n, e3dge_stream_t stream);
 /* The alternative 13-op polynomial sine (kernels built with -DE3DGE_POLY_SINE use it). */

@@ -34,8 +34,13 @@ def sd():
     return full_state_dict()[1]
 
 
-def make_renderer(sd, res, S, **over):
+MODES = ["f16x3", "f32"]     # both contraction kernels must meet the same bounds
+
+
+def make_renderer(sd, res, S, mfma_mode=None, **over):
     r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S, **over), out_im_res=res, mode='test')
+    if mfma_mode is not None:
+        r.siren.mfma_mode = mfma_mode
     pre = 'network.netGlobal.' if over.get('enable_local_model') else 'network.'
     own = {}
     for k in r.state_dict():
@@ -72,12 +77,13 @@ def check_against_golden(name, out, g, sub=None):
     assert ((m == g['ref_mask']) | near_thr).all()
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name,sub", [("renderer_16x24", None), ("renderer_8x48", None), ("renderer_8x18", None),
                                       ("renderer_64x24", 8)])
-def test_render_matches_reference_golden(sd, name, sub):
+def test_render_matches_reference_golden(sd, name, sub, mode):
     g = load_golden(name)
     B, res, S = int(g['batch']), int(g['res']), int(g['n_samples'])
-    r = make_renderer(sd, res, S)
+    r = make_renderer(sd, res, S, mfma_mode=mode)
     wr, _ = syn.synthetic_inputs(B, seed=int(g['styles_seed']), device=DEV)
     with torch.no_grad():
         out = r(T(g['poses']), T(g['focal']), T(g['near']), T(g['far']), styles=wr)
@@ -88,25 +94,27 @@ def test_render_matches_reference_golden(sd, name, sub):
     assert tuple(out['mask'].shape) == (B, 1, res, res, 1) and tuple(out['depth'].shape) == (B, res, res, 1, 1)
     assert tuple(out['sdf'].shape) == (B, res, res, S, 1) and tuple(out['points'].shape) == (B, res, res, S, 3)
     assert tuple(out['near'].shape) == (B, res, res, 1) and tuple(out['rays_o'].shape) == (B, res, res, 3)
-    check_against_golden(name, out, g, sub)
+    check_against_golden(name + ':' + mode, out, g, sub)
 
 
-def test_texture_film_pass(sd):
+@pytest.mark.parametrize("mode", MODES)
+def test_texture_film_pass(sd, mode):
     g = load_golden("renderer_tex_8x24")
-    r = make_renderer(sd, 8, 24, enable_local_model=True)
+    r = make_renderer(sd, 8, 24, mfma_mode=mode, enable_local_model=True)
     wr, _ = syn.synthetic_inputs(1, seed=1, device=DEV)
     tex = syn.synthetic_tex_conditions(1, 8, 24, seed=int(g['tex_seed']), device=DEV)
     with torch.no_grad():
         out = r(T(g['poses']), T(g['focal']), T(g['near']), T(g['far']), styles=wr, local_data_batch={'tex': tex})
     e = {k: maxerr(out[k], g['ref_' + k]) for k in ('gen_thumb_imgs', 'features', 'sdf', 'hit_prob')}
-    record("tex_film", **e)
+    record("tex_film:" + mode, **e)
     for k, v in e.items():
         assert v <= ATOL[k], (k, v)
 
 
-def test_film_params_and_point_queries(sd):
+@pytest.mark.parametrize("mode", MODES)
+def test_film_params_and_point_queries(sd, mode):
     g = load_golden("points")
-    r = make_renderer(sd, 64, 24)
+    r = make_renderer(sd, 64, 24, mfma_mode=mode)
     wr, _ = syn.synthetic_inputs(2, seed=1, device=DEV)
     film = r.siren.film_params(wr)
     e_film = maxerr(film, g['ref_film'])
@@ -120,15 +128,16 @@ def test_film_params_and_point_queries(sd):
     assert tuple(raw1.shape) == tuple(g['ref_raw_view'].shape)
     for tag, raw, ref in (("zero_view", raw0, g['ref_raw_zero_view']), ("view", raw1, g['ref_raw_view'])):
         e = dict(rgb=maxerr(raw[..., :3], ref[..., :3]), sdf=maxerr(raw[..., 3], ref[..., 3]), feat=maxerr(raw[..., 4:], ref[..., 4:]))
-        record("points_" + tag, **e)
+        record("points_" + tag + ":" + mode, **e)
         assert e['rgb'] <= 5e-6 and e['sdf'] <= 1e-5 and e['feat'] <= 1e-4, e
     assert maxerr(sdf_only[..., 0], raw0[..., 3]) == 0.0
 
 
-def test_full_size_properties_64x64x24(sd):
+@pytest.mark.parametrize("mode", MODES)
+def test_full_size_properties_64x64x24(sd, mode):
     """BASELINE.json configs[1] size: invariants that need no oracle."""
     res, S, B = 64, 24, 3
-    r = make_renderer(sd, res, S)
+    r = make_renderer(sd, res, S, mfma_mode=mode)
     wr, _ = syn.synthetic_inputs(B, seed=11, device=DEV)
     loc = torch.tensor([[0.0, 0.0], [0.25, -0.1], [-0.3, 0.12]])
     poses, focal, near, far, _ = generate_camera_params(res, DEV, locations=loc.to(DEV))
@@ -152,7 +161,7 @@ def test_full_size_properties_64x64x24(sd):
     with torch.no_grad():
         ref = renderer_ref.render(sd, cpu(poses[1:2]), cpu(focal[1:2]), cpu(near[1:2]), cpu(far[1:2]), cpu(wr[1:2]), res=res, n_samples=S)
     e = {k: maxerr(single[k], ref[k]) for k in ATOL}
-    record("full_64x64x24_vs_oracle", **e)
+    record("full_64x64x24_vs_oracle:" + mode, **e)
     for k, v in e.items():
         assert v <= ATOL[k], (k, v)
 

@@ -30,6 +30,19 @@ def test_mfma_fragment_layout(lib):
         assert err <= 2e-5 * np.sqrt(k), err
 
 
+def test_f16_mfma_fragment_layout(lib):
+    """v_mfma_f32_32x32x16_f16 with the k-slot convention of the f16x3 path (values exactly representable in f16)."""
+    rs = np.random.RandomState(4)
+    for k in (16, 64, 256):
+        a = T((rs.randint(-8, 9, size=(32, k)) / 8.0).astype(np.float32))
+        b = T((rs.randint(-8, 9, size=(32, k)) / 4.0).astype(np.float32))
+        c = torch.full((32, 32), float('nan'), device=DEV)
+        _lib.check(lib.e3dge_selftest_mfma16(c.data_ptr(), a.data_ptr(), b.data_ptr(), k, _lib.stream_of(c)), "selftest_mfma16")
+        err = maxerr(c, a.double() @ b.double().t())
+        record("mfma16_layout", k=k, err=err)
+        assert err == 0.0, err          # small dyadic rationals: every product and sum is exact
+
+
 def test_device_sine_accuracy(lib):
     rs = np.random.RandomState(1)
     x = np.concatenate([rs.uniform(-300, 300, 200000), rs.uniform(-4, 4, 50000), np.linspace(-50, 50, 20001),
