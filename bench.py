@@ -30,10 +30,13 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 RES, N_SAMPLES = 64, 24
+# HBM traffic of one 64x64x24 render launch measured with PMC counters (profiles/*_pmc.txt): KB -> bytes
+TRAFFIC_BYTES_PER_LAUNCH = {"f32": int((2 * 10432.5 + 11552) * 1024), "f16x3": int((2 * 18299.1 + 23027) * 1024)}
 MAC_PER_POINT = 3 * 256 + 7 * 256 * 256 + 259 * 256 + 256 * 3 + 256       # 526,848
 FLOP_PER_RAY = 2 * MAC_PER_POINT * N_SAMPLES                               # 25.29 MFLOP
 BYTES_PER_RAY = (264 + 5 * N_SAMPLES) * 4                                  # mandatory outputs, 1,536 B
-PEAK_F32_MFMA_TFLOPS = 157.3                                               # MI355X_MICROARCH.md
+PEAK_F32_MFMA_TFLOPS = 157.3                                               # MI355X_MICROARCH.md (dense fp32 MFMA)
+PEAK_F16_MFMA_TFLOPS = 2500.0                                              # dense f16 / bf16 MFMA (NOT the 2:1-sparse figure)
 
 
 def main():
@@ -117,14 +120,24 @@ def main():
                                f"{B} image(s) per GPU per step (film_params + fused render launch)",
                    "rays_per_gpu_per_step": B * RES * RES, "samples_per_ray": N_SAMPLES, "parallelism": f"images sharded x{world}"},
     }
+    mode = renderer.siren.mfma_mode
+    result["dtype"] = "f32" if mode == "f32" else "f32 (operands split f16 hi+lo, 3 f16 MFMA products, fp32 accumulate)"
+    result["config"]["mfma_mode"] = mode
     if rank == 0:
-        flops = FLOP_PER_RAY * B * RES * RES
+        flops = FLOP_PER_RAY * B * RES * RES                    # ALGORITHMIC flops (one fp32 multiply-add per weight per point)
         achieved = flops / (kern_ms * 1e-3) / 1e12
-        result["roofline"] = {"bound": "mfma", "kernel": "siren_kernel<0> (e3dge_siren_render_fwd)", "achieved": achieved,
-                              "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+        if mode == "f32":
+            peak, note = PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA peak"
+        else:   # every algorithmic product costs three f16 MFMA products
+            peak, note = PEAK_F16_MFMA_TFLOPS / 3.0, "dense f16 MFMA peak / 3 (the split needs 3 f16 products per fp32-accurate product)"
+        result["roofline"] = {"bound": "mfma", "kernel": f"siren_kernel<0,{int(mode != 'f32')}> (e3dge_siren_render_fwd, {mode})",
+                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": note,
+                              "achieved_over_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                               "kernel_ms": kern_ms, "flop_per_launch": flops,
                               "algorithmic_output_bytes_per_launch": BYTES_PER_RAY * B * RES * RES,
-                              "hbm_frac_of_8TBps": BYTES_PER_RAY * B * RES * RES / (kern_ms * 1e-3) / 8e12, "traffic": None}
+                              "hbm_frac_of_8TBps": BYTES_PER_RAY * B * RES * RES / (kern_ms * 1e-3) / 8e12,
+                              "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(mode) if B == 1 else None,
+                              "traffic_note": "PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch, separate rocprofv3 --pmc passes, see profiles/"}
 
     # ---------------------------------------------------------------- informational: full inversion forward, one image
     if rank == 0 and not args.no_inversion:

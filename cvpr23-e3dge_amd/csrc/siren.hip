@@ -56,6 +56,10 @@ constexpr int kMinSamples = 16;
 #ifndef E3DGE_SPREAD_VIEW
 #define E3DGE_SPREAD_VIEW 0
 #endif
+// f16x3 path: VALU instructions scheduled behind each f16 MFMA (there the pipes DO overlap; 0 = compiler's placement)
+#ifndef E3DGE_SPREAD16
+#define E3DGE_SPREAD16 5
+#endif
 
 // ---- packed weight image (floats) ----
 constexpr int64_t kOffBig = 0;                                       // [8 layers][8 t][8 c][4 q][64 lane][4]
@@ -147,6 +151,13 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
 }
+// Same with the instruction's immediate offset, which the hardware adds to BOTH the global and the LDS address
+// (the chunk image has the same layout on both sides), so the 8 pieces of a chunk share two address setups.
+template <int OFF_BYTES>
+__device__ __forceinline__ void glds16_off(const float* gsrc, float* ldst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)ldst, 16, OFF_BYTES, 0);
+}
 
 // Two sines, both with an exact FMA Cody-Waite range reduction (|x| < ~1e5):
 //  * sin_hw_f32 (default, 6 VALU ops): reduce to |r| <= pi, hardware v_sin_f32 on r / 2pi.  Max abs error 3.8e-7.
@@ -196,12 +207,12 @@ __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, kWave
 struct NoEpilogue { __device__ __forceinline__ void operator()(int) const {} };
 
 constexpr int kRing = 4;          // weight fragments held in registers (2 being consumed + 2 in flight)
-constexpr int kSyncPair = 4;      // MFMA-group pair after which the chunk barrier + next DMA issue happen
+constexpr int kSyncPair = 2;      // MFMA-group pair (even index) after which the chunk barrier happens; DMA pieces follow
 
-template <bool TRANSPOSED, int VALU_PER_MFMA, class Epi, class Sync>
+template <bool TRANSPOSED, int VALU_PER_MFMA, class Epi, class Sync, class Dma>
 __device__ __forceinline__ f32x16 big_tile(const float* __restrict__ wchunk, const float* __restrict__ wnext,
                                            int lane, const f32x16 (&in)[kNT], f32x16 acc, f32x4 (&ring)[kRing],
-                                           Epi&& epi, Sync&& sync) {
+                                           Epi&& epi, Sync&& sync, Dma&& dma) {
     const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wchunk) + lane;
     const f32x4* __restrict__ wn = reinterpret_cast<const f32x4*>(wnext) + lane;
     constexpr int kGroups = kNT * 4;     // 32 groups of 4 MFMAs (one ds_read_b128 each)
@@ -223,6 +234,7 @@ __device__ __forceinline__ f32x16 big_tile(const float* __restrict__ wchunk, con
             }
         }
         if (gp == kSyncPair) sync();
+        if (gp > kSyncPair && gp <= kSyncPair + 16) dma((gp - kSyncPair) / 2 - 1);   // one DMA piece per group pair
         epi(gp >> 1);
         if (VALU_PER_MFMA > 0) {
 #pragma unroll
@@ -241,11 +253,14 @@ __device__ __forceinline__ f32x16 big_tile(const float* __restrict__ wchunk, con
 constexpr int kRing16 = 4;        // k-steps whose (hi, lo) weight fragments are held: 1 consumed + 3 in flight
 constexpr int kSyncStep16 = 2;    // k-step after which the chunk barrier + next DMA issue happen
 
-template <bool TRANSPOSED, class Epi, class Sync>
+// Ablation switches for tools/ablate.sh (timing experiments only -- results are wrong when any is defined):
+//   E3DGE_ABL_NOEPI  drop the pipelined epilogue VALU     E3DGE_ABL_NODMA  drop the weight DMA
+//   E3DGE_ABL_NOLDS  drop the weight-fragment LDS reads   E3DGE_ABL_NOSYNC drop the chunk barrier
+template <bool TRANSPOSED, class Epi, class Sync, class Dma>
 __device__ __forceinline__ void big_tile_f16(const float* __restrict__ wchunk, const float* __restrict__ wnext,
                                              int lane, const u32x4 (&aH)[2 * kNT], const u32x4 (&aL)[2 * kNT],
-                                             f32x16& acc, u32x4 (&ringH)[kRing16],
-                                             u32x4 (&ringL)[kRing16], Epi&& epi, Sync&& sync) {
+                                             f32x16& acc, f32x16& accb, u32x4 (&ringH)[kRing16],
+                                             u32x4 (&ringL)[kRing16], Epi&& epi, Sync&& sync, Dma&& dma) {
     const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(wchunk) + lane;
     const u32x4* __restrict__ wn = reinterpret_cast<const u32x4*>(wnext) + lane;
     constexpr int kSteps = 2 * kNT;
@@ -253,21 +268,45 @@ __device__ __forceinline__ void big_tile_f16(const float* __restrict__ wchunk, c
 #pragma unroll
     for (int g = 0; g < kSteps; ++g) {
         const int ga = g + kRing16 - 1;
+#ifndef E3DGE_ABL_NOLDS
         ringH[ga % kRing16] = (ga < kSteps) ? wp[(ga * 2 + 0) * 64] : wn[((ga - kSteps) * 2 + 0) * 64];
         ringL[ga % kRing16] = (ga < kSteps) ? wp[(ga * 2 + 1) * 64] : wn[((ga - kSteps) * 2 + 1) * 64];
+#endif
         __builtin_amdgcn_sched_barrier(0);
         const u32x4 wh = ringH[g % kRing16], wl = ringL[g % kRing16];
+        // Two accumulators used alternately (a b a | b a b | ...): an instruction issued between two MFMAs that chain
+        // on the SAME accumulator costs ~43 cycles (the accumulate-forwarding path is lost); with the interleaved
+        // epilogue every MFMA would pay it.  The caller adds the two once per tile.
+        f32x16& x0 = (g & 1) ? accb : acc;
+        f32x16& x1 = (g & 1) ? acc : accb;
         if (!TRANSPOSED) {
-            acc = mfma16(wh, aH[g], acc);
-            acc = mfma16(wl, aH[g], acc);
-            acc = mfma16(wh, aL[g], acc);
+            x0 = mfma16(wh, aH[g], x0);
+            x1 = mfma16(wl, aH[g], x1);
+            x0 = mfma16(wh, aL[g], x0);
         } else {
-            acc = mfma16(aH[g], wh, acc);
-            acc = mfma16(aH[g], wl, acc);
-            acc = mfma16(aL[g], wh, acc);
+            x0 = mfma16(aH[g], wh, x0);
+            x1 = mfma16(aH[g], wl, x1);
+            x0 = mfma16(aL[g], wh, x0);
         }
+#ifndef E3DGE_ABL_NOSYNC
         if (g == kSyncStep16) sync();
+#endif
+#ifndef E3DGE_ABL_NODMA
+        if (g > kSyncStep16 && g <= kSyncStep16 + 8) dma(g - kSyncStep16 - 1);            // one DMA piece per k-step
+#endif
+#ifndef E3DGE_ABL_NOEPI
         epi(g);
+#endif
+        if (E3DGE_SPREAD16 > 0) {
+            // f16 MFMAs co-execute with the VALU when the fillers sit BETWEEN consecutive MFMAs (about five single-issue
+            // instructions hide per 32-cycle MFMA): lay the epilogue out as {MFMA, n VALU, LDS read} x 3 per k-step
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, E3DGE_SPREAD16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
     }
 }
 
@@ -397,26 +436,51 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const float* const src_lane = packed + (F16 ? kOffBig16 : kOffBig) + wave_u * 2048 + lane * 4;
     int g_issue = 0, issue_chunk_idx = 0, issue_buf = 0;
-    auto issue_chunk = [&]() {
+    // One of the 8 DMA pieces of the chunk being issued.  Issuing an LDS-DMA costs ~60-185 cycles of issue time
+    // (measured: ~600-1000 cycles per tile when the 8 are issued in a burst), so the pieces are handed out one per
+    // MFMA group after the chunk barrier, where they issue in the shadow of the MFMAs.
+    auto issue_piece = [&](int i) {
         if (g_issue < total_chunks) {
-            const float* src = src_lane + (int64_t)issue_chunk_idx * kChunkFloats;
-            float* dst = wbuf + issue_buf * kChunkFloats + wave_u * 2048;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) glds16(src + i * 256, dst + i * 256);
+            const float* src = src_lane + (int64_t)issue_chunk_idx * kChunkFloats + (i >> 2) * 1024;
+            float* dst = wbuf + issue_buf * kChunkFloats + wave_u * 2048 + (i >> 2) * 1024;
+            switch (i & 3) {                    // i is a compile-time constant at every call site
+                case 0: glds16_off<0>(src, dst); break;
+                case 1: glds16_off<1024>(src, dst); break;
+                case 2: glds16_off<2048>(src, dst); break;
+                default: glds16_off<3072>(src, dst); break;
+            }
         }
-        ++g_issue;
-        issue_chunk_idx = (issue_chunk_idx + 1 == kChunksPerPass) ? 0 : issue_chunk_idx + 1;
-        issue_buf = (issue_buf + 1 == kNBuf) ? 0 : issue_buf + 1;
+        if (i == 7) {
+            ++g_issue;
+            issue_chunk_idx = (issue_chunk_idx + 1 == kChunksPerPass) ? 0 : issue_chunk_idx + 1;
+            issue_buf = (issue_buf + 1 == kNBuf) ? 0 : issue_buf + 1;
+        }
+    };
+    auto issue_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) issue_piece(i);
     };
     for (int i = 0; i < kNBuf - 1; ++i) issue_chunk();
-    // Chunk protocol (3 buffers).  chunk_sync() runs in the MIDDLE of every tile g: each wave drains its own DMA
-    // (that is chunk g+1, issued one whole tile earlier), the barrier publishes it to the other waves and proves
-    // that everybody has left tile g-1, whose buffer the DMA of chunk g+2 may now overwrite.  Hence chunk g+1 is
-    // complete and visible before tile g+1 starts: tiles need no barrier, wait or LDS-latency bubble between them.
+    // Chunk protocol (3 buffers).  chunk_sync() runs early in every tile g: each wave drains its own DMA (that is
+    // chunk g+1, issued one whole tile earlier), the barrier publishes it to the other waves and proves that
+    // everybody has left tile g-1, whose buffer the DMA of chunk g+2 (pieces issued over the following MFMA groups)
+    // may now overwrite.  Hence chunk g+1 is complete and visible before tile g+1 starts: tiles need no barrier,
+    // wait or LDS-latency bubble between them.
+#ifdef E3DGE_PHASE_TIMING
+    unsigned long long t_vm = 0, t_bar = 0, t_iss = 0;
+#endif
     auto chunk_sync = [&]() {
+#ifdef E3DGE_PHASE_TIMING
+        const unsigned long long c0 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long c1 = __builtin_readcyclecounter();
+        __syncthreads();
+        const unsigned long long c2 = __builtin_readcyclecounter();
+        t_vm += c1 - c0; t_bar += c2 - c1;
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        issue_chunk();
+#endif
     };
     int use_buf = 0;      // buffer of the chunk being consumed
     const float* wcur = wbuf;
@@ -556,17 +620,21 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 for (int t = 0; t < kNT; ++t) {
                     f32x16 acc = zero16();
                     if (t == 0) {
-                        acc = big_tile<false, 0>(wcur, wnxt, lane, in, acc, ring, NoEpilogue(), chunk_sync);
+                        acc = big_tile<false, 0>(wcur, wnxt, lane, in, acc, ring, NoEpilogue(), chunk_sync, issue_piece);
                     } else {
-                        f32x4 g4, b4;
+                        // FiLM (gamma, beta') of the 4 registers being processed, and of the NEXT 4 (fetched from LDS one quad
+                        // ahead: a read issued right before its use exposes the LDS latency four times per tile)
                         const float* __restrict__ fl = film_l + 32 * (t - 1) + 4 * half;
+                        f32x4 g4 = *reinterpret_cast<const f32x4*>(fl), b4 = *reinterpret_cast<const f32x4*>(fl + kWidth);
+                        f32x4 g4n = g4, b4n = b4;
                         acc = big_tile<false, E3DGE_SPREAD_STD>(wcur, wnxt, lane, in, acc, ring, [&](int r) {
-                            if ((r & 3) == 0) {
-                                g4 = *reinterpret_cast<const f32x4*>(fl + 8 * (r >> 2));
-                                b4 = *reinterpret_cast<const f32x4*>(fl + kWidth + 8 * (r >> 2));
+                            if ((r & 3) == 0 && r < 12) {
+                                g4n = *reinterpret_cast<const f32x4*>(fl + 8 * ((r >> 2) + 1));
+                                b4n = *reinterpret_cast<const f32x4*>(fl + kWidth + 8 * ((r >> 2) + 1));
                             }
                             out[t - 1][r] = sin_f32(fmaf(g4[r & 3], prev[r], b4[r & 3]));
-                        }, chunk_sync);
+                            if ((r & 3) == 3) { g4 = g4n; b4 = b4n; }
+                        }, chunk_sync, issue_piece);
                         asm volatile("" : "+a"(out[t - 1]));   // park finished activations in the accumulator half
                     }
                     advance_chunk();
@@ -587,26 +655,28 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 f32x16 prev;
 #pragma unroll
                 for (int t = 0; t < kNT; ++t) {
-                    f32x16 acc = zero16();
+                    f32x16 acc = zero16(), accb = zero16();
                     if (t == 0) {
-                        big_tile_f16<false>(wcur, wnxt, lane, inH, inL, acc, ringH, ringL, NoEpilogue(), chunk_sync);
+                        big_tile_f16<false>(wcur, wnxt, lane, inH, inL, acc, accb, ringH, ringL, NoEpilogue(), chunk_sync, issue_piece);
                     } else {
-                        f32x4 g4, b4;
                         float xe = 0.f;
                         const float* __restrict__ fl = film_l + 32 * (t - 1) + 4 * half;
-                        big_tile_f16<false>(wcur, wnxt, lane, inH, inL, acc, ringH, ringL, [&](int r) {
-                            if ((r & 3) == 0) {
-                                g4 = *reinterpret_cast<const f32x4*>(fl + 8 * (r >> 2));
-                                b4 = *reinterpret_cast<const f32x4*>(fl + kWidth + 8 * (r >> 2));
+                        f32x4 g4 = *reinterpret_cast<const f32x4*>(fl), b4 = *reinterpret_cast<const f32x4*>(fl + kWidth);
+                        f32x4 g4n = g4, b4n = b4;
+                        big_tile_f16<false>(wcur, wnxt, lane, inH, inL, acc, accb, ringH, ringL, [&](int r) {
+                            if ((r & 3) == 0 && r < 12) {       // FiLM of the next quad, one quad ahead of its use
+                                g4n = *reinterpret_cast<const f32x4*>(fl + 8 * ((r >> 2) + 1));
+                                b4n = *reinterpret_cast<const f32x4*>(fl + kWidth + 8 * ((r >> 2) + 1));
                             }
                             const float x = sin_f32(fmaf(g4[r & 3], prev[r], b4[r & 3]));
                             if (r & 1) SPLIT2_TO(xe, x, outH[2 * (t - 1) + (r >> 3)][(r & 7) >> 1], outL[2 * (t - 1) + (r >> 3)][(r & 7) >> 1]);
                             else xe = x;
-                        }, chunk_sync);
+                            if ((r & 3) == 3) { g4 = g4n; b4 = b4n; }
+                        }, chunk_sync, issue_piece);
                         asm volatile("" : "+a"(outH[2 * (t - 1)]), "+a"(outH[2 * (t - 1) + 1]), "+a"(outL[2 * (t - 1)]), "+a"(outL[2 * (t - 1) + 1]));
                     }
                     advance_chunk();
-                    prev = acc;
+                    prev = acc + accb;
                     asm volatile("" : "+v"(prev));
                 }
                 {
@@ -803,25 +873,27 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 f32x16 acc = zero16();
                 if (!F16) {
                     if (t == 0) {
-                        acc = big_tile<true, 0>(wcur, wnxt, lane, in, acc, ring, NoEpilogue(), chunk_sync);
+                        acc = big_tile<true, 0>(wcur, wnxt, lane, in, acc, ring, NoEpilogue(), chunk_sync, issue_piece);
                     } else {
                         epi_begin(t - 1);
-                        acc = big_tile<true, E3DGE_SPREAD_VIEW>(wcur, wnxt, lane, in, acc, ring, epi_r, chunk_sync);
+                        acc = big_tile<true, E3DGE_SPREAD_VIEW>(wcur, wnxt, lane, in, acc, ring, epi_r, chunk_sync, issue_piece);
                         epi_end();
                     }
                     acc = mfma32(a0, wvt[(t * 2 + 0) * 64 + lane], acc);
                     acc = mfma32(a1, wvt[(t * 2 + 1) * 64 + lane], acc);
                 } else {
+                    f32x16 accb = zero16();
                     if (t == 0) {
-                        big_tile_f16<true>(wcur, wnxt, lane, inH, inL, acc, ringH, ringL, NoEpilogue(), chunk_sync);
+                        big_tile_f16<true>(wcur, wnxt, lane, inH, inL, acc, accb, ringH, ringL, NoEpilogue(), chunk_sync, issue_piece);
                     } else {
                         epi_begin(t - 1);
-                        big_tile_f16<true>(wcur, wnxt, lane, inH, inL, acc, ringH, ringL, epi_r, chunk_sync);
+                        big_tile_f16<true>(wcur, wnxt, lane, inH, inL, acc, accb, ringH, ringL, epi_r, chunk_sync, issue_piece);
                         epi_end();
                     }
                     // view-direction tail in fp32, carrying the same 128 scale as the streamed weights
                     acc = mfma32(a0 * kW16Scale, wvt[(t * 2 + 0) * 64 + lane], acc);
-                    acc = mfma32(a1 * kW16Scale, wvt[(t * 2 + 1) * 64 + lane], acc);
+                    accb = mfma32(a1 * kW16Scale, wvt[(t * 2 + 1) * 64 + lane], accb);
+                    acc = acc + accb;
                 }
                 advance_chunk();
                 pv = acc;
@@ -970,6 +1042,9 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
         if (blockIdx.x == 0 && tid == 0 && a.dists)
             for (int i = 0; i < 18; ++i)
                 a.dists[i] = (i % 6 == 0) ? (float)(i / 6 ? tstamp[i] - tstamp[i - 1] : 0) : (float)(tstamp[i] - tstamp[i - 1]);
+        if (blockIdx.x == 0 && (tid & 63) == 0 && a.dists) {
+            a.dists[18 + wave * 3 + 0] = (float)t_vm; a.dists[18 + wave * 3 + 1] = (float)t_bar; a.dists[18 + wave * 3 + 2] = (float)t_iss;
+        }
 #endif
     }
 }

@@ -1,0 +1,50 @@
+"""HBM roofline of the stream ops at the decoder's real sizes (B=1, 1024^2 generator): GB/s = algorithmic bytes /
+mean kernel time (HIP events on the launch stream), against 8 TB/s peak (6.3 TB/s achievable, MI355X_MICROARCH.md).
+Prints one JSON line per case."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import e3dge_amd  # noqa
+from e3dge_amd import op
+from e3dge_amd.stylesdf_model import make_kernel
+
+dev = "cuda:0"
+k4 = (make_kernel([1, 3, 3, 1]) * 4).to(dev)
+
+
+def timeit(fn, n=30, warm=5):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e-3
+
+
+cases = []
+with torch.no_grad():
+    for C, L in [(256, 128), (128, 256), (64, 512), (32, 1024)]:
+        x = torch.randn(1, C, L + 1, L + 1, device=dev)
+        t = timeit(lambda: op.upfirdn2d(x, k4, pad=(1, 1)))
+        by = 4 * (x.numel() + C * L * L)
+        cases.append(dict(op="upfirdn2d blur (up1,down1,4x4)", shape=[C, L + 1, L + 1], bytes=by, us=t * 1e6, GBps=by / t / 1e9))
+        a = torch.randn(1, C, L, L, device=dev); b = torch.randn(C, device=dev)
+        nz = torch.randn(1, 1, L, L, device=dev); nw = torch.full((1,), 0.1, device=dev)
+        t = timeit(lambda: op.fused_leaky_relu(a, b))
+        by = 8 * a.numel()
+        cases.append(dict(op="fused_bias_act (lrelu fwd)", shape=[C, L, L], bytes=by, us=t * 1e6, GBps=by / t / 1e9))
+        t = timeit(lambda: op.noise_bias_act(a, nz, nw, b))
+        by = 8 * a.numel() + 4 * nz.numel()
+        cases.append(dict(op="noise_bias_act (noise+bias+lrelu)", shape=[C, L, L], bytes=by, us=t * 1e6, GBps=by / t / 1e9))
+    for L in (64, 128, 256, 512):
+        s = torch.randn(1, 3, L, L, device=dev)
+        t = timeit(lambda: op.upfirdn2d(s, k4, up=2, pad=(2, 1)))
+        by = 4 * (s.numel() + 3 * 4 * L * L)
+        cases.append(dict(op="upfirdn2d skip upsample (up2,4x4)", shape=[3, L, L], bytes=by, us=t * 1e6, GBps=by / t / 1e9))
+for c in cases:
+    c["frac_of_8TBps"] = c["GBps"] / 8000.0
+    print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()}))

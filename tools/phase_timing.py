@@ -20,7 +20,9 @@ with torch.no_grad():
         out = r(poses, focal, near, far, styles=wr)
     torch.cuda.synchronize()
     d = out['dists'].reshape(-1)[:18].cpu().tolist()
+    sync = out['dists'].reshape(-1)[18:30].cpu().tolist()
 for sub in range(3):
     print(f"sub-tile {sub}: " + ", ".join(f"{names[i]}={d[sub * 6 + i]:.0f}" for i in range(6)))
 tot = sum(d)
+print("chunk_sync totals per wave (cycles over 192 tiles): " + "; ".join(f"w{w}: dma-wait={sync[3*w]:.0f} barrier={sync[3*w+1]:.0f} issue={sync[3*w+2]:.0f}" for w in range(4)))
 print("sum", tot, " mfma-only per sub-tile would be", 8224 * 64)
