@@ -1122,12 +1122,15 @@ siren_pack_kernel(float* __restrict__ packed, const float* __restrict__ w_first,
 // ---------------------------------------------------------------------------------------------
 // FiLM parameters: one wave per output row, lanes along K (16 B/lane coalesced), xor-reduce
 // ---------------------------------------------------------------------------------------------
+constexpr int kFilmRowsPerBlock = 16;      // 4 waves x 4 rows: 16 x 18 = 288 workgroups per image (was 18 -> latency-bound)
+
 __global__ void __launch_bounds__(256)
 film_params_kernel(float* __restrict__ film, const float* __restrict__ styles,
                    const float* __restrict__ wg, const float* __restrict__ bg,
                    const float* __restrict__ wb, const float* __restrict__ bb) {
-    // grid: (batch * 9 * 2); block: 4 waves x 64 rows each
+    // grid: batch * 9 * 2 * (256 / kFilmRowsPerBlock)
     int id = blockIdx.x;
+    const int rg = id % (kWidth / kFilmRowsPerBlock); id /= (kWidth / kFilmRowsPerBlock);
     const int which = id & 1; id >>= 1;
     const int l = id % 9;
     const int b = id / 9;
@@ -1138,13 +1141,17 @@ film_params_kernel(float* __restrict__ film, const float* __restrict__ styles,
     const f32x4 s4 = *reinterpret_cast<const f32x4*>(s + lane * 4);
     const float std_init = which ? 0.25f : 15.0f, bias_init = which ? 0.0f : 30.0f;
     float* __restrict__ o = film + (((int64_t)b * 9 + l) * 2 + which) * kWidth;
-    for (int i = 0; i < 64; ++i) {
-        const int n = wave * 64 + i;
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(Wm + (int64_t)n * kWidth + lane * 4);
-        float acc = w4[0] * s4[0];
-        acc = fmaf(w4[1], s4[1], acc);
-        acc = fmaf(w4[2], s4[2], acc);
-        acc = fmaf(w4[3], s4[3], acc);
+    f32x4 w4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        w4[i] = *reinterpret_cast<const f32x4*>(Wm + (int64_t)(rg * kFilmRowsPerBlock + wave * 4 + i) * kWidth + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = rg * kFilmRowsPerBlock + wave * 4 + i;
+        float acc = w4[i][0] * s4[0];
+        acc = fmaf(w4[i][1], s4[1], acc);
+        acc = fmaf(w4[i][2], s4[2], acc);
+        acc = fmaf(w4[i][3], s4[3], acc);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
         if (lane == 0) o[n] = __fadd_rn(__fmul_rn(std_init, __fadd_rn(acc, bv[n])), bias_init);   // LinearLayer.forward :76-80
@@ -1256,7 +1263,7 @@ extern "C" int e3dge_film_params(float* film, const float* styles, const float* 
     if (batch == 0) return E3DGE_OK;
     E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(styles) | reinterpret_cast<uintptr_t>(wg) |
                     reinterpret_cast<uintptr_t>(wb)) & 15) == 0, "film_params: inputs must be 16-B aligned");
-    film_params_kernel<<<dim3((unsigned)(batch * 9 * 2)), dim3(256), 0, as_stream(stream)>>>(film, styles, wg, bg, wb, bb);
+    film_params_kernel<<<dim3((unsigned)(batch * 9 * 2 * (kWidth / kFilmRowsPerBlock))), dim3(256), 0, as_stream(stream)>>>(film, styles, wg, bg, wb, bb);
     return check_launch("film_params");
 }
 
