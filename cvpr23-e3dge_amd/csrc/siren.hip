@@ -22,328 +22,9 @@
 //   * Transmittance is a sequential front-to-back scan per ray (same order as torch.cumprod), carried in
 //     LDS across the 128-point sub-tiles of a workgroup's ray block, so rays x samples can be tiled
 //     without aligning rays to tiles.
-#include "common.h"
+#include "siren_common.h"
 
 namespace e3dge {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));       // 8 packed f16 = one f16-MFMA operand
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-
-constexpr int kWidth = E3DGE_SIREN_WIDTH;       // 256
-constexpr int kNT = kWidth / 32;                // 8 output tiles of 32 features
-constexpr int kChunkFloats = 32 * kWidth;       // one output tile x K=256 : 8192 floats = 32 KiB
-constexpr int kBigLayers = 8;                   // pts_linears.1..7 + views_linears[:, :256]
-constexpr int kChunksPerPass = kBigLayers * kNT;  // 64 chunks = 2 MiB per 128-point sub-tile
-constexpr int kNBuf = 3;                        // LDS weight buffers
-constexpr int kTilePts = 128;                   // points per sub-tile (4 waves x 32)
-constexpr int kThreads = 256;
-constexpr int kRMax = 16;                       // max rays per workgroup (LDS feature accumulators)
-constexpr int kFPitch = kWidth + 1;             // padded pitch of the feature accumulators
-constexpr int kMaxSlots = 3;                    // rays a 32-point slab can touch when S >= 16
-constexpr int kMinSamples = 16;
-
-// VALU instructions of the pipelined epilogue forced behind each MFMA with sched_group_barrier (0 = leave the
-// placement to the compiler).  Measured on MI355X (round 1, tools/build_variant.sh A/B): 0 -> 0.949 ms, 2..4 ->
-// 1.00-1.02 ms, with one or two accumulators alike: on gfx950 the fp32 MFMA and the fp32 VALU do not execute
-// concurrently for one wave (PMC: MFMA-busy + VALU-active + waits = wave cycles in every variant), so spreading
-// only adds issue bubbles.  The lever that works is FEWER VALU instructions, not better placement.
-#ifndef E3DGE_SPREAD_STD
-#define E3DGE_SPREAD_STD 0
-#endif
-#ifndef E3DGE_SPREAD_VIEW
-#define E3DGE_SPREAD_VIEW 0
-#endif
-// f16x3 path: VALU instructions scheduled behind each f16 MFMA (there the pipes DO overlap; 0 = compiler's placement)
-#ifndef E3DGE_SPREAD16
-#define E3DGE_SPREAD16 5
-#endif
-
-// ---- packed weight image (floats) ----
-constexpr int64_t kOffBig = 0;                                       // [8 layers][8 t][8 c][4 q][64 lane][4]
-constexpr int64_t kOffFirst = kOffBig + (int64_t)kChunksPerPass * kChunkFloats;   // [8 t][2][64]
-constexpr int64_t kOffVTail = kOffFirst + kNT * 2 * 64;              // [8 t][2][64]
-constexpr int64_t kOffBias = kOffVTail + kNT * 2 * 64;               // [9][256]
-constexpr int64_t kOffWSigma = kOffBias + 9 * kWidth;                // [256]
-constexpr int64_t kOffWRgb = kOffWSigma + kWidth;                    // [3][256]
-constexpr int64_t kOffBHead = kOffWRgb + 3 * kWidth;                 // b_sigma, b_rgb[3]
-constexpr int64_t kOffBig16 = kOffBHead + 4;                         // f16x3 image of the 8 big layers, see below
-constexpr int64_t kPackedFloats = kOffBig16 + (int64_t)kChunksPerPass * kChunkFloats;
-// f16x3 image: the same 64 chunks of 32 KiB, each [16 k-steps g = 2c+s][hi, lo][64 lanes][8 f16]: lane l holds
-//   128 * W[32t + (l&31)][32c + 16s + (j&3) + 8(j>>2) + 4(l>>5)],  j = 0..7
-// split as hi = f16(v), lo = f16(v - hi).  The k order is the one in which a lane's C/D registers of the previous
-// layer (r = 8s + j) become the 8 k-slots of a v_mfma_f32_32x32x16_f16 operand; 128 keeps `lo` out of the f16
-// subnormals and is undone exactly by storing gamma / 128.
-constexpr float kW16Scale = 128.0f;
-
-// ---- LDS carve (floats) ----
-constexpr int kLdsW = 0;
-constexpr int kLdsFilm = kLdsW + kNBuf * kChunkFloats;               // [9][2][256] gamma/beta of this image
-constexpr int kLdsHead = kLdsFilm + 9 * 2 * kWidth;                  // w_sigma[256], w_rgb[3][256], b_sigma, b_rgb[3]
-constexpr int kHeadFloats = 4 * kWidth + 4;
-constexpr int kLdsVTail = kLdsHead + kHeadFloats;                    // [8 t][2][64] view-layer tail fragments
-constexpr int kLdsFeat = kLdsVTail + kNT * 2 * 64;                   // [kRMax][kFPitch]
-constexpr int kLdsPart = kLdsFeat + kRMax * kFPitch;                 // [4][kMaxSlots][256]
-constexpr int kLdsAlpha = ((kLdsPart + 4 * kMaxSlots * kWidth + 3) / 4) * 4;   // [128]
-constexpr int kLdsWgt = kLdsAlpha + kTilePts;                        // [128]
-constexpr int kLdsZ = kLdsWgt + kTilePts;                            // [128]
-constexpr int kLdsPts = kLdsZ + kTilePts;                            // [128][3]
-constexpr int kLdsRgb = kLdsPts + kTilePts * 3;                      // [128][3]
-constexpr int kLdsState = kLdsRgb + kTilePts * 3;                    // [kRMax][12]: T, wsum, depth, xyz3, rgb3
-constexpr int kStateStride = 12;
-constexpr int kLdsFloats = kLdsState + kRMax * kStateStride;
-constexpr int kLdsBytes = kLdsFloats * 4;
-static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
-static_assert((kLdsFilm % 4) == 0 && (kLdsHead % 4) == 0 && (kLdsFeat % 4) == 0, "alignment");
-static_assert(kOffWRgb == kOffWSigma + kWidth && kOffBHead == kOffWSigma + 4 * kWidth, "head block is contiguous");
-
-struct SirenK {
-    const float* packed;
-    const float* film;         // (batch, 9, 2, 256)
-    // render mode
-    const float* c2w; const float* focal; const float* near; const float* far; const float* t_vals;
-    const float* tex_alpha; const float* tex_beta;
-    float sigmoid_beta, box_scale, mask_thresh;
-    int batch, H, Wd, S, res, force_bg;
-    int R, tiles_per_img;
-    float *rgb, *features, *xyz, *depth, *mask, *sdf, *weights, *points, *rays_d, *viewdirs, *dists;
-    // points mode
-    const float* pts; const float* vdirs; long long n_pts; int subtiles_per_wg, wgs_per_img;
-    float* raw;
-};
-
-// ---------------------------------------------------------------------------------------------
-// small device helpers
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-// C/D fragment of v_mfma_f32_32x32x2_f32: lane l, register r holds D[row_of(r, l>>5)][l&31].
-__device__ __forceinline__ constexpr int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
-
-__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ float f16lo(unsigned p) { return (float)__builtin_bit_cast(fp16x2, p).x; }
-__device__ __forceinline__ float f16hi(unsigned p) { return (float)__builtin_bit_cast(fp16x2, p).y; }
-// fp32 pair -> packed f16 (hi word, lo word) with x = hi + lo up to 2^-21 |x| (v_cvt_pkrtz rounds toward zero, so the
-// remainder is exact in fp32 and has the sign of x).  Simulated against float64 this split with three products
-// (hi*hi + hi*lo + lo*hi, fp32 accumulate) is as accurate as plain fp32 in this network.
-struct HiLo { unsigned h, l; };
-__device__ __forceinline__ HiLo split2(float x0, float x1) {
-    HiLo p;
-    p.h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-    p.l = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0 - f16lo(p.h), x1 - f16hi(p.h)));
-    return p;
-}
-// (vector elements cannot be bound to references, hence the macro)
-#define SPLIT2_TO(x0, x1, H, L) do { const HiLo p_ = split2((x0), (x1)); (H) = p_.h; (L) = p_.l; } while (0)
-
-// value r (0..15) of feature tile c from the packed (hi, lo) representation
-__device__ __forceinline__ float acts16_get(const u32x4 (&aH)[2 * kNT], const u32x4 (&aL)[2 * kNT], int c, int r) {
-    const int g = 2 * c + (r >> 3), k = (r & 7) >> 1;
-    return (r & 1) ? f16hi(aH[g][k]) + f16hi(aL[g][k]) : f16lo(aH[g][k]) + f16lo(aL[g][k]);
-}
-
-__device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
-}
-// Same with the instruction's immediate offset, which the hardware adds to BOTH the global and the LDS address
-// (the chunk image has the same layout on both sides), so the 8 pieces of a chunk share two address setups.
-template <int OFF_BYTES>
-__device__ __forceinline__ void glds16_off(const float* gsrc, float* ldst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)ldst, 16, OFF_BYTES, 0);
-}
-
-// Two sines, both with an exact FMA Cody-Waite range reduction (|x| < ~1e5):
-//  * sin_hw_f32 (default, 6 VALU ops): reduce to |r| <= pi, hardware v_sin_f32 on r / 2pi.  Max abs error 3.8e-7.
-//  * sin_poly_f32 (13 VALU ops): reduce to |r| <= pi/2, degree-9 minimax odd polynomial (4.7e-9 in exact
-//    arithmetic), sign from k's parity.  Max abs error 1.2e-7.
-// fp32 MFMA and fp32 VALU do not overlap on gfx950, so every VALU op of the epilogue is paid in full; the
-// renderer's parity against the reference is the same with either (features ~1e-5, the summation-order noise).
-// -DE3DGE_POLY_SINE selects the polynomial for the kernels.
-__device__ __forceinline__ float sin_hw_f32(float x) {
-    const float kf = rintf(x * 0.159154943091895336f);
-    float r = fmaf(-kf, 6.2831854820251465f, x);
-    r = fmaf(-kf, -1.7484555314695172e-07f, r);
-    return __builtin_amdgcn_sinf(r * 0.159154943091895336f);
-}
-__device__ __forceinline__ float sin_poly_f32(float x) {
-    const float kf = rintf(x * 0.318309886183790672f);
-    float r = fmaf(-kf, 3.1415927410125732f, x);
-    r = fmaf(-kf, -8.742277657347586e-08f, r);
-    const float r2 = r * r;
-    float p = fmaf(r2, 2.6003292532550404e-06f, -1.9806761702056974e-04f);
-    p = fmaf(p, r2, 8.33301991224289e-03f);
-    p = fmaf(p, r2, -1.6666656732559204e-01f);
-    const float sv = fmaf(r * r2, p, r);
-    const unsigned sign = ((unsigned)(int)kf) << 31;
-    return __uint_as_float(__float_as_uint(sv) ^ sign);
-}
-__device__ __forceinline__ float sin_f32(float x) {
-#ifdef E3DGE_POLY_SINE
-    return sin_poly_f32(x);
-#else
-    return sin_hw_f32(x);
-#endif
-}
-
-__device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
-
-__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, kWave); }
-
-// K=256 contraction of one 32-feature output tile against the wave's register-resident activations.
-//   TRANSPOSED=false: D[feature][point]  (weights = A operand, activations = B operand)
-//   TRANSPOSED=true : D[point][feature]  (activations = A operand, weights = B operand)
-// * The weight fragments are double-buffered in registers: each ds_read_b128 of k-block c+1 is issued ahead of
-//   4 MFMAs of k-block c (one k-block = 1024 cycles of cover for the LDS latency).
-// * `epi(r)`, r = 0..15, is the epilogue of the PREVIOUS output tile (FiLM + sine of one accumulator register, ~20
-//   VALU ops); it is called once every second 4-MFMA group so that its VALU work issues in the shadow of this
-//   tile's MFMAs (the matrix pipe is busy 64 cycles per MFMA, a VALU op takes 4) instead of after them.
-struct NoEpilogue { __device__ __forceinline__ void operator()(int) const {} };
-
-constexpr int kRing = 4;          // weight fragments held in registers (2 being consumed + 2 in flight)
-constexpr int kSyncPair = 2;      // MFMA-group pair (even index) after which the chunk barrier happens; DMA pieces follow
-
-template <bool TRANSPOSED, int VALU_PER_MFMA, class Epi, class Sync, class Dma>
-__device__ __forceinline__ f32x16 big_tile(const float* __restrict__ wchunk, const float* __restrict__ wnext,
-                                           int lane, const f32x16 (&in)[kNT], f32x16 acc, f32x4 (&ring)[kRing],
-                                           Epi&& epi, Sync&& sync, Dma&& dma) {
-    const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wchunk) + lane;
-    const f32x4* __restrict__ wn = reinterpret_cast<const f32x4*>(wnext) + lane;
-    constexpr int kGroups = kNT * 4;     // 32 groups of 4 MFMAs (one ds_read_b128 each)
-    // On entry ring[0], ring[1] hold groups 0 and 1 of this chunk (fetched by the previous tile's tail or the
-    // prologue); on exit they hold groups 0 and 1 of the NEXT chunk, so consecutive tiles run back to back.
-#pragma unroll
-    for (int gp = 0; gp < kGroups; gp += 2) {
-#pragma unroll
-        for (int g = gp + 2; g < gp + 4; ++g)
-            ring[g % kRing] = (g < kGroups) ? wp[g * 64] : wn[(g - kGroups) * 64];
-        __builtin_amdgcn_sched_barrier(0);              // keep the prefetch ahead of the MFMAs it covers
-#pragma unroll
-        for (int g = gp; g < gp + 2; ++g) {
-            const f32x4 w4 = ring[g % kRing];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float act = in[g >> 2][4 * (g & 3) + j];
-                acc = TRANSPOSED ? mfma32(act, w4[j], acc) : mfma32(w4[j], act, acc);
-            }
-        }
-        if (gp == kSyncPair) sync();
-        if (gp > kSyncPair && gp <= kSyncPair + 16) dma((gp - kSyncPair) / 2 - 1);   // one DMA piece per group pair
-        epi(gp >> 1);
-        if (VALU_PER_MFMA > 0) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);   // n VALU
-            }
-        }
-    }
-    return acc;
-}
-
-// The same contraction on the f16 matrix pipe: fp32 operands split into f16 hi + lo, three products per k-step
-// (hi*hi, lo_w*hi_a, hi_w*lo_a) into one fp32 accumulator.  16 k-steps of K=16 per tile = 48 MFMAs of 32
-// cycles (1536 vs 8192 for fp32), and this pipe runs concurrently with the VALU, so the epilogue hides under it.
-constexpr int kRing16 = 4;        // k-steps whose (hi, lo) weight fragments are held: 1 consumed + 3 in flight
-constexpr int kSyncStep16 = 2;    // k-step after which the chunk barrier + next DMA issue happen
-
-// Ablation switches for tools/ablate.sh (timing experiments only -- results are wrong when any is defined):
-//   E3DGE_ABL_NOEPI  drop the pipelined epilogue VALU     E3DGE_ABL_NODMA  drop the weight DMA
-//   E3DGE_ABL_NOLDS  drop the weight-fragment LDS reads   E3DGE_ABL_NOSYNC drop the chunk barrier
-template <bool TRANSPOSED, class Epi, class Sync, class Dma>
-__device__ __forceinline__ void big_tile_f16(const float* __restrict__ wchunk, const float* __restrict__ wnext,
-                                             int lane, const u32x4 (&aH)[2 * kNT], const u32x4 (&aL)[2 * kNT],
-                                             f32x16& acc, f32x16& accb, u32x4 (&ringH)[kRing16],
-                                             u32x4 (&ringL)[kRing16], Epi&& epi, Sync&& sync, Dma&& dma) {
-    const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(wchunk) + lane;
-    const u32x4* __restrict__ wn = reinterpret_cast<const u32x4*>(wnext) + lane;
-    constexpr int kSteps = 2 * kNT;
-    // entry: ring slots 0..2 hold k-steps 0..2 of this chunk; exit: k-steps 0..2 of the next chunk
-#pragma unroll
-    for (int g = 0; g < kSteps; ++g) {
-        const int ga = g + kRing16 - 1;
-#ifndef E3DGE_ABL_NOLDS
-        ringH[ga % kRing16] = (ga < kSteps) ? wp[(ga * 2 + 0) * 64] : wn[((ga - kSteps) * 2 + 0) * 64];
-        ringL[ga % kRing16] = (ga < kSteps) ? wp[(ga * 2 + 1) * 64] : wn[((ga - kSteps) * 2 + 1) * 64];
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        const u32x4 wh = ringH[g % kRing16], wl = ringL[g % kRing16];
-        // Two accumulators used alternately (a b a | b a b | ...): an instruction issued between two MFMAs that chain
-        // on the SAME accumulator costs ~43 cycles (the accumulate-forwarding path is lost); with the interleaved
-        // epilogue every MFMA would pay it.  The caller adds the two once per tile.
-        f32x16& x0 = (g & 1) ? accb : acc;
-        f32x16& x1 = (g & 1) ? acc : accb;
-        if (!TRANSPOSED) {
-            x0 = mfma16(wh, aH[g], x0);
-            x1 = mfma16(wl, aH[g], x1);
-            x0 = mfma16(wh, aL[g], x0);
-        } else {
-            x0 = mfma16(aH[g], wh, x0);
-            x1 = mfma16(aH[g], wl, x1);
-            x0 = mfma16(aL[g], wh, x0);
-        }
-#ifndef E3DGE_ABL_NOSYNC
-        if (g == kSyncStep16) sync();
-#endif
-#ifndef E3DGE_ABL_NODMA
-        if (g > kSyncStep16 && g <= kSyncStep16 + 8) dma(g - kSyncStep16 - 1);            // one DMA piece per k-step
-#endif
-#ifndef E3DGE_ABL_NOEPI
-        epi(g);
-#endif
-        if (E3DGE_SPREAD16 > 0) {
-            // f16 MFMAs co-execute with the VALU when the fillers sit BETWEEN consecutive MFMAs (about five single-issue
-            // instructions hide per 32-cycle MFMA): lay the epilogue out as {MFMA, n VALU, LDS read} x 3 per k-step
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, E3DGE_SPREAD16, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ f32x16 zero16() {
-    f32x16 z;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-    return z;
-}
-
-// sin(gamma * acc + beta), standard layout; gamma/beta of the layer come from the LDS copy of this image's
-// FiLM block ([2][256], bias already folded into beta); one fused multiply-add feeds the sine.
-__device__ __forceinline__ f32x16 film_sin_std(f32x16 acc, const float* __restrict__ film_l, int t, int half) {
-    f32x16 o;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(film_l + 32 * t + 8 * q + 4 * half);
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(film_l + kWidth + 32 * t + 8 * q + 4 * half);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            o[4 * q + j] = sin_f32(fmaf(g4[j], acc[4 * q + j], b4[j]));
-    }
-    return o;
-}
-
-__device__ __forceinline__ void set_tile(f32x16 (&dst)[kNT], int t, const f32x16& v) {
-    switch (t) {
-        case 0: dst[0] = v; break;
-        case 1: dst[1] = v; break;
-        case 2: dst[2] = v; break;
-        case 3: dst[3] = v; break;
-        case 4: dst[4] = v; break;
-        case 5: dst[5] = v; break;
-        case 6: dst[6] = v; break;
-        default: dst[7] = v; break;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // the kernel.  MODE 0 = render (rays x samples + compositing), MODE 1 = arbitrary point set (raw outputs)
@@ -358,7 +39,8 @@ __device__ __forceinline__ void set_tile(f32x16 (&dst)[kNT], int t, const f32x16
 #endif
 
 // PREC 0: fp32 MFMA (v_mfma_f32_32x32x2_f32).  PREC 1: "f16x3" -- split-f16 contraction on v_mfma_f32_32x32x16_f16.
-template <int MODE, int PREC>
+// SAVE: additionally store the pre-sine argument of every FiLM layer (what the backward kernels consume).
+template <int MODE, int PREC, bool SAVE>
 __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
     constexpr bool F16 = PREC == 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -580,6 +262,11 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
             if (a.vdirs) { const float* vv = a.vdirs + gpt * 3; vx = vv[0]; vy = vv[1]; vz = vv[2]; }
         }
 
+        // training: where this lane's point keeps its [9][256] pre-sine arguments (null: nothing is saved)
+        float* const sv = (SAVE && valid && half >= 0) ? a.save_args + gpt * (9 * kWidth) : nullptr;
+        // first point of this workgroup's block in the same numbering (block points are contiguous)
+        const int64_t gpt_block = (MODE == 0) ? ((int64_t)b * a.H * a.Wd + pix0) * S : (int64_t)b * a.n_pts + pt0;
+
         // =====================================================================================
         // 2. layer 0 (3 -> 256): two K=2 MFMAs per output tile, operands straight from L2
         // =====================================================================================
@@ -593,7 +280,7 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 f32x16 acc = zero16();
                 acc = mfma32(wf[(t * 2 + 0) * 64 + lane], b0, acc);
                 acc = mfma32(wf[(t * 2 + 1) * 64 + lane], b1, acc);
-                const f32x16 v0 = film_sin_std(acc, film, t, half);
+                const f32x16 v0 = film_sin_std(acc, film, t, half, SAVE ? sv : nullptr);
                 if (!F16) {
                     in[t] = v0;
                 } else {
@@ -626,13 +313,18 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                         // ahead: a read issued right before its use exposes the LDS latency four times per tile)
                         const float* __restrict__ fl = film_l + 32 * (t - 1) + 4 * half;
                         f32x4 g4 = *reinterpret_cast<const f32x4*>(fl), b4 = *reinterpret_cast<const f32x4*>(fl + kWidth);
-                        f32x4 g4n = g4, b4n = b4;
+                        f32x4 g4n = g4, b4n = b4, sarg;
                         acc = big_tile<false, E3DGE_SPREAD_STD>(wcur, wnxt, lane, in, acc, ring, [&](int r) {
                             if ((r & 3) == 0 && r < 12) {
                                 g4n = *reinterpret_cast<const f32x4*>(fl + 8 * ((r >> 2) + 1));
                                 b4n = *reinterpret_cast<const f32x4*>(fl + kWidth + 8 * ((r >> 2) + 1));
                             }
-                            out[t - 1][r] = sin_f32(fmaf(g4[r & 3], prev[r], b4[r & 3]));
+                            const float arg = fmaf(g4[r & 3], prev[r], b4[r & 3]);
+                            out[t - 1][r] = sin_f32(arg);
+                            if (SAVE) {
+                                sarg[r & 3] = arg;
+                                if ((r & 3) == 3 && sv) *reinterpret_cast<f32x4*>(sv + L * kWidth + 32 * (t - 1) + 8 * (r >> 2) + 4 * half) = sarg;
+                            }
                             if ((r & 3) == 3) { g4 = g4n; b4 = b4n; }
                         }, chunk_sync, issue_piece);
                         asm volatile("" : "+a"(out[t - 1]));   // park finished activations in the accumulator half
@@ -641,7 +333,7 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                     prev = acc;
                     asm volatile("" : "+v"(prev));           // the epilogue's VALU reads it: keep it out of the AGPRs
                 }
-                out[kNT - 1] = film_sin_std(prev, film_l, kNT - 1, half);
+                out[kNT - 1] = film_sin_std(prev, film_l, kNT - 1, half, (SAVE && sv) ? sv + L * kWidth : nullptr);
 #pragma unroll
                 for (int tt = 0; tt < kNT; ++tt) {
                     in[tt] = out[tt];
@@ -662,13 +354,18 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                         float xe = 0.f;
                         const float* __restrict__ fl = film_l + 32 * (t - 1) + 4 * half;
                         f32x4 g4 = *reinterpret_cast<const f32x4*>(fl), b4 = *reinterpret_cast<const f32x4*>(fl + kWidth);
-                        f32x4 g4n = g4, b4n = b4;
+                        f32x4 g4n = g4, b4n = b4, sarg;
                         big_tile_f16<false>(wcur, wnxt, lane, inH, inL, acc, accb, ringH, ringL, [&](int r) {
                             if ((r & 3) == 0 && r < 12) {       // FiLM of the next quad, one quad ahead of its use
                                 g4n = *reinterpret_cast<const f32x4*>(fl + 8 * ((r >> 2) + 1));
                                 b4n = *reinterpret_cast<const f32x4*>(fl + kWidth + 8 * ((r >> 2) + 1));
                             }
-                            const float x = sin_f32(fmaf(g4[r & 3], prev[r], b4[r & 3]));
+                            const float arg = fmaf(g4[r & 3], prev[r], b4[r & 3]);
+                            const float x = sin_f32(arg);
+                            if (SAVE) {
+                                sarg[r & 3] = arg;
+                                if ((r & 3) == 3 && sv) *reinterpret_cast<f32x4*>(sv + L * kWidth + 32 * (t - 1) + 8 * (r >> 2) + 4 * half) = sarg;
+                            }
                             if (r & 1) SPLIT2_TO(xe, x, outH[2 * (t - 1) + (r >> 3)][(r & 7) >> 1], outL[2 * (t - 1) + (r >> 3)][(r & 7) >> 1]);
                             else xe = x;
                             if ((r & 3) == 3) { g4 = g4n; b4 = b4n; }
@@ -680,7 +377,7 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                     asm volatile("" : "+v"(prev));
                 }
                 {
-                    const f32x16 v7 = film_sin_std(prev, film_l, kNT - 1, half);
+                    const f32x16 v7 = film_sin_std(prev, film_l, kNT - 1, half, (SAVE && sv) ? sv + L * kWidth : nullptr);
 #pragma unroll
                     for (int r = 0; r < 16; r += 2)
                         SPLIT2_TO(v7[r], v7[r + 1], outH[2 * (kNT - 1) + (r >> 3)][(r & 7) >> 1], outL[2 * (kNT - 1) + (r >> 3)][(r & 7) >> 1]);
@@ -844,7 +541,12 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 fa0 = fa1 = fa2 = 0.f;
             };
             auto epi_r = [&](int r) {
-                const float h = sin_f32(fmaf(e_gm, pv[r], e_bt));
+                const float varg = fmaf(e_gm, pv[r], e_bt);
+                const float h = sin_f32(varg);
+                if (SAVE) {
+                    const int pr = slab_p0 + row_of(r, half);
+                    if (pr < npts) a.save_args[((gpt_block + pr) * 9 + 8) * kWidth + e_n] = varg;
+                }
                 prgb[0][r] = fmaf(e_w0, h, prgb[0][r]);
                 prgb[1][r] = fmaf(e_w1, h, prgb[1][r]);
                 prgb[2][r] = fmaf(e_w2, h, prgb[2][r]);
@@ -1094,6 +796,17 @@ siren_pack_kernel(float* __restrict__ packed, const float* __restrict__ w_first,
         } else if (e < kOffBig16) {
             const int r = (int)(e - kOffBHead);
             v = (r == 0) ? b_sigma[0] : b_rgb[r - 1];
+        } else if (e >= kOffBigT) {
+            // transposed fp32 image for the backward chain (siren_common.h)
+            int64_t r = e - kOffBigT;
+            const int j = r & 3; r >>= 2;
+            const int lane = r & 63; r >>= 6;
+            const int q = r & 3; r >>= 2;
+            const int c = r & 7; r >>= 3;
+            const int t = r & 7; r >>= 3;
+            const int L = 8 - (int)r;
+            const int kin = 32 * t + (lane & 31), n = 32 * c + 8 * q + 4 * (lane >> 5) + j;
+            v = (L == 8) ? w_view[(int64_t)n * 259 + kin] : w_hidden[((int64_t)(L - 1) * kWidth + n) * kWidth + kin];
         } else {
             // one 32-bit word = two f16: [Lb][t][g = 2c+s][hl][lane][word k]  ->  j = 2k, 2k+1
             int64_t r = e - kOffBig16;
@@ -1206,8 +919,11 @@ __global__ void selftest_sin_kernel(float* __restrict__ y, const float* __restri
 static int ensure_lds_attr() {
     static bool done = false;
     if (!done) {
-        const void* fns[4] = {reinterpret_cast<const void*>(&siren_kernel<0, 0>), reinterpret_cast<const void*>(&siren_kernel<1, 0>),
-                              reinterpret_cast<const void*>(&siren_kernel<0, 1>), reinterpret_cast<const void*>(&siren_kernel<1, 1>)};
+        const void* fns[8] = {
+            reinterpret_cast<const void*>(&siren_kernel<0, 0, false>), reinterpret_cast<const void*>(&siren_kernel<1, 0, false>),
+            reinterpret_cast<const void*>(&siren_kernel<0, 1, false>), reinterpret_cast<const void*>(&siren_kernel<1, 1, false>),
+            reinterpret_cast<const void*>(&siren_kernel<0, 0, true>), reinterpret_cast<const void*>(&siren_kernel<1, 0, true>),
+            reinterpret_cast<const void*>(&siren_kernel<0, 1, true>), reinterpret_cast<const void*>(&siren_kernel<1, 1, true>)};
         for (const void* f : fns) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
             if (e != hipSuccess)
@@ -1216,6 +932,19 @@ static int ensure_lds_attr() {
         done = true;
     }
     return E3DGE_OK;
+}
+
+template <int MODE>
+static void launch_siren(const SirenK& k, int precision, int64_t grid, hipStream_t st) {
+    const dim3 g((unsigned)grid), t(kThreads);
+    const bool save = k.save_args != nullptr;
+    if (precision == E3DGE_PREC_F16X3) {
+        if (save) siren_kernel<MODE, 1, true><<<g, t, kLdsBytes, st>>>(k);
+        else siren_kernel<MODE, 1, false><<<g, t, kLdsBytes, st>>>(k);
+    } else {
+        if (save) siren_kernel<MODE, 0, true><<<g, t, kLdsBytes, st>>>(k);
+        else siren_kernel<MODE, 0, false><<<g, t, kLdsBytes, st>>>(k);
+    }
 }
 
 // rays per workgroup: the largest R <= kRMax whose R*S is a multiple of 128 if one exists (no padded
@@ -1299,16 +1028,14 @@ extern "C" int e3dge_siren_render_fwd(const E3dgeRenderArgs* r, e3dge_stream_t s
     k.weights = r->weights; k.points = r->points; k.rays_d = r->rays_d; k.viewdirs = r->viewdirs; k.dists = r->dists;
     const int64_t grid = (int64_t)k.tiles_per_img * r->batch;
     E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_render_fwd: grid too large");
-    if (r->precision == E3DGE_PREC_F16X3)
-        siren_kernel<0, 1><<<dim3((unsigned)grid), dim3(kThreads), kLdsBytes, as_stream(stream)>>>(k);
-    else
-        siren_kernel<0, 0><<<dim3((unsigned)grid), dim3(kThreads), kLdsBytes, as_stream(stream)>>>(k);
+    k.save_args = r->save_args;
+    launch_siren<0>(k, r->precision, grid, as_stream(stream));
     return check_launch("siren_render_fwd");
 }
 
 extern "C" int e3dge_siren_points_fwd(const float* packed, const float* film, const float* pts,
                                       const float* viewdirs, float box_scale, int batch, int64_t n_pts,
-                                      float* sdf, float* raw, int precision, e3dge_stream_t stream) {
+                                      float* sdf, float* raw, float* save_args, int precision, e3dge_stream_t stream) {
     E3DGE_REQUIRE(precision == E3DGE_PREC_F32 || precision == E3DGE_PREC_F16X3, "siren_points_fwd: precision=%d", precision);
     E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "siren_points_fwd: bad sizes");
     if (batch == 0 || n_pts == 0) return E3DGE_OK;
@@ -1330,10 +1057,8 @@ extern "C" int e3dge_siren_points_fwd(const float* packed, const float* film, co
     k.wgs_per_img = (int)((tiles + spw - 1) / spw);
     const int64_t grid = (int64_t)k.wgs_per_img * batch;
     E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_points_fwd: grid too large");
-    if (precision == E3DGE_PREC_F16X3)
-        siren_kernel<1, 1><<<dim3((unsigned)grid), dim3(kThreads), kLdsBytes, as_stream(stream)>>>(k);
-    else
-        siren_kernel<1, 0><<<dim3((unsigned)grid), dim3(kThreads), kLdsBytes, as_stream(stream)>>>(k);
+    k.save_args = save_args;
+    launch_siren<1>(k, precision, grid, as_stream(stream));
     return check_launch("siren_points_fwd");
 }
 

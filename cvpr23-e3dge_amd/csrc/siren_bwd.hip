@@ -1,0 +1,336 @@
+// Backward of the FiLM-SIREN MLP with respect to the FiLM parameters (gamma, beta of all 9 layers), i.e. the path
+// the encoder's gradient takes: styles -> (gamma, beta) -> every layer (generator weights are frozen, trainer.py:1568).
+//
+// Reference being replaced: autograd through SirenGenerator.forward (project/utils/volume_renderer.py:168-264) as
+// train_ae.py drives it (loss.backward(), trainer.py:728).  Inputs are the pre-sine arguments the forward kernel saved
+// (E3dgeRenderArgs.save_args) and the gradient w.r.t. the per-point network outputs [rgb3, sdf1, feat256].
+//
+// Same machine as the forward kernel: one wave keeps its 32 points' 256-wide gradient in registers and chains
+//     dh_{L-1} = W_L^T (gamma_L * dh_L * cos(arg_L))
+// through fp32 MFMAs (gradients do not fit f16's range) against the TRANSPOSED weight image streamed through LDS;
+// the C/D fragment of one GEMM is again the B operand of the next.  d(gamma), d(beta) are sums over points: each wave
+// reduces its 32 lanes with a transpose-reduce and accumulates into its own slice of a partial buffer (no two waves
+// share an address -> deterministic), which a small kernel then folds; a last kernel maps d(film) to d(styles).
+#include "siren_common.h"
+
+namespace e3dge {
+
+struct SirenBwdK {
+    const float* packed;
+    const float* film;       // (batch, 9, 2, 256) gamma, beta as e3dge_film_params produced them
+    const float* args;       // (batch, n_pts, 9, 256) saved pre-sine arguments
+    const float* d_feat;     // (batch, n_pts, 256) or null
+    const float* d_rgb;      // (batch, n_pts, 3) or null
+    const float* d_sdf;      // (batch, n_pts) or null
+    float* partials;         // (grid, 4, 9, 2, 256), zero-initialised by the caller
+    long long n_pts;
+    int batch, subtiles_per_wg, wgs_per_img;
+};
+
+constexpr int kBwdLdsW = 0;
+constexpr int kBwdLdsFilm = kBwdLdsW + kNBuf * kChunkFloats;     // [9][3][256] gamma, beta, 1/gamma
+constexpr int kBwdLdsHead = kBwdLdsFilm + 9 * 3 * kWidth;        // w_sigma[256], w_rgb[3][256]
+constexpr int kBwdLdsFloats = kBwdLdsHead + 4 * kWidth;
+constexpr int kBwdLdsBytes = kBwdLdsFloats * 4;
+
+// sum of v over the 32 lanes of a half for 8 per-lane values: afterwards lanes with (col & 3) == 0 hold the total of
+// value index 4*b4 + 2*b3 + b2 (b_i = bit i of col).  4+2+1+1+1 shuffles.
+__device__ __forceinline__ float reduce8_over_lanes(const float (&v)[8], int col) {
+    const bool b4 = col & 16, b3 = col & 8, b2 = col & 4;
+    float q4[4], q2[2], q1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b4 ? v[4 + i] : v[i], send = b4 ? v[i] : v[4 + i];
+        q4[i] = keep + __shfl_xor(send, 16, kWave);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b3 ? q4[2 + i] : q4[i], send = b3 ? q4[i] : q4[2 + i];
+        q2[i] = keep + __shfl_xor(send, 8, kWave);
+    }
+    {
+        const float keep = b2 ? q2[1] : q2[0], send = b2 ? q2[0] : q2[1];
+        q1 = keep + __shfl_xor(send, 4, kWave);
+    }
+    q1 += __shfl_xor(q1, 2, kWave);
+    q1 += __shfl_xor(q1, 1, kWave);
+    return q1;
+}
+
+__global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const wbuf = smem + kBwdLdsW;
+    float* const film_s = smem + kBwdLdsFilm;
+    float* const head_s = smem + kBwdLdsHead;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int b = blockIdx.x / a.wgs_per_img;
+    const int wg = blockIdx.x - b * a.wgs_per_img;
+    const long long pt0 = (long long)wg * a.subtiles_per_wg * kTilePts;
+    const long long rem = a.n_pts - pt0;
+    const int npts = (int)(rem < (long long)a.subtiles_per_wg * kTilePts ? rem : (long long)a.subtiles_per_wg * kTilePts);
+    const int n_sub = (npts + kTilePts - 1) / kTilePts;
+
+    const float* __restrict__ packed = a.packed;
+    const float* __restrict__ film_g = a.film + (int64_t)b * 9 * 2 * kWidth;
+    for (int i = tid; i < 9 * kWidth; i += kThreads) {
+        const int l = i >> 8, n = i & 255;
+        const float g = film_g[(l * 2) * kWidth + n];
+        film_s[(l * 3) * kWidth + n] = g;
+        film_s[(l * 3 + 1) * kWidth + n] = film_g[(l * 2 + 1) * kWidth + n];
+        film_s[(l * 3 + 2) * kWidth + n] = 1.0f / g;
+    }
+    for (int i = tid; i < 4 * kWidth; i += kThreads) head_s[i] = packed[kOffWSigma + i];
+    float* const my_partial = a.partials + ((int64_t)blockIdx.x * 4 + wave) * (9 * 2 * kWidth);
+
+    // ---- weight chunk pipeline: identical protocol to the forward kernel, transposed image ----
+    const int total_chunks = n_sub * kChunksPerPass;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const float* const src_lane = packed + kOffBigT + wave_u * 2048 + lane * 4;
+    int g_issue = 0, issue_chunk_idx = 0, issue_buf = 0;
+    auto issue_piece = [&](int i) {
+        if (g_issue < total_chunks) {
+            const float* src = src_lane + (int64_t)issue_chunk_idx * kChunkFloats + (i >> 2) * 1024;
+            float* dst = wbuf + issue_buf * kChunkFloats + wave_u * 2048 + (i >> 2) * 1024;
+            switch (i & 3) {
+                case 0: glds16_off<0>(src, dst); break;
+                case 1: glds16_off<1024>(src, dst); break;
+                case 2: glds16_off<2048>(src, dst); break;
+                default: glds16_off<3072>(src, dst); break;
+            }
+        }
+        if (i == 7) {
+            ++g_issue;
+            issue_chunk_idx = (issue_chunk_idx + 1 == kChunksPerPass) ? 0 : issue_chunk_idx + 1;
+            issue_buf = (issue_buf + 1 == kNBuf) ? 0 : issue_buf + 1;
+        }
+    };
+    for (int c = 0; c < kNBuf - 1; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) issue_piece(i);
+    auto chunk_sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    int use_buf = 0;
+    const float* wcur = wbuf;
+    const float* wnxt = wbuf + kChunkFloats;
+    auto advance_chunk = [&]() {
+        use_buf = (use_buf + 1 == kNBuf) ? 0 : use_buf + 1;
+        wcur = wnxt;
+        wnxt = wbuf + ((use_buf + 1 == kNBuf) ? 0 : use_buf + 1) * kChunkFloats;
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4 ring[kRing];
+    ring[0] = reinterpret_cast<const f32x4*>(wcur)[lane];
+    ring[1] = reinterpret_cast<const f32x4*>(wcur)[64 + lane];
+
+    f32x16 in[kNT], out[kNT];
+
+    for (int sub = 0; sub < n_sub; ++sub) {
+        const int p = sub * kTilePts + 32 * wave + col;
+        const bool valid = p < npts;
+        const int pc = valid ? p : (npts - 1);
+        const int64_t gpt = (int64_t)b * a.n_pts + pt0 + pc;
+        const float* __restrict__ ap = a.args + gpt * (9 * kWidth);
+        const float vmask = valid ? 1.0f : 0.0f;                      // padded lanes contribute nothing
+        const float dsdf = (a.d_sdf && valid) ? a.d_sdf[gpt] : 0.0f;
+        float drgb[3] = {0.f, 0.f, 0.f};
+        if (a.d_rgb && valid) { drgb[0] = a.d_rgb[gpt * 3]; drgb[1] = a.d_rgb[gpt * 3 + 1]; drgb[2] = a.d_rgb[gpt * 3 + 2]; }
+
+        // per-tile reduction of d(beta) += da, d(gamma) += da * u over this wave's 32 points, layer `layer`, tile `t`
+        auto reduce_tile = [&](int layer, int t, const float (&rb)[16], const float (&rg)[16]) {
+#pragma unroll
+            for (int h8 = 0; h8 < 2; ++h8) {
+                float vb[8], vg[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { vb[i] = rb[8 * h8 + i]; vg[i] = rg[8 * h8 + i]; }
+                const float sb = reduce8_over_lanes(vb, col), sg = reduce8_over_lanes(vg, col);
+                if ((col & 3) == 0) {
+                    const int r = 8 * h8 + (col >> 2);                 // 4*b4 + 2*b3 + b2
+                    const int n = 32 * t + row_of(r, half);
+                    atomicAdd(my_partial + (layer * 2 + 0) * kWidth + n, sg);
+                    atomicAdd(my_partial + (layer * 2 + 1) * kWidth + n, sb);
+                }
+            }
+        };
+
+        // =====================================================================================
+        // 1. view layer: dh_view = d_feat + Wrgb^T d_rgb ; g8 = gamma8 * dh_view * cos(arg8)
+        // =====================================================================================
+        {
+            const float* __restrict__ fg = film_s + 8 * 3 * kWidth;
+            const float* __restrict__ wr = head_s + kWidth;
+            const float* __restrict__ df = a.d_feat ? a.d_feat + gpt * kWidth : nullptr;
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                float rb[16], rg[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = 32 * t + 8 * q + 4 * half;
+                    const f32x4 ar = *reinterpret_cast<const f32x4*>(ap + 8 * kWidth + o);
+                    f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+                    if (df) d4 = *reinterpret_cast<const f32x4*>(df + o);
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(fg + o), b4 = *reinterpret_cast<const f32x4*>(fg + kWidth + o),
+                                i4 = *reinterpret_cast<const f32x4*>(fg + 2 * kWidth + o);
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + o), w1 = *reinterpret_cast<const f32x4*>(wr + kWidth + o),
+                                w2 = *reinterpret_cast<const f32x4*>(wr + 2 * kWidth + o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float dh = vmask * (d4[j] + w0[j] * drgb[0] + w1[j] * drgb[1] + w2[j] * drgb[2]);
+                        const float da = dh * cos_hw_f32(ar[j]);
+                        rb[4 * q + j] = da;
+                        rg[4 * q + j] = da * ((ar[j] - b4[j]) * i4[j]);
+                        in[t][4 * q + j] = g4[j] * da;
+                    }
+                }
+                reduce_tile(8, t, rb, rg);
+            }
+        }
+
+        // =====================================================================================
+        // 2. the chain: GEMM Gb (layer L = 8 - Gb) turns g_L into dh_{L-1}; its epilogue makes g_{L-1}
+        // =====================================================================================
+#pragma unroll 1
+        for (int Gb = 0; Gb < kBigLayers; ++Gb) {
+            const int Lm1 = 7 - Gb;                                      // layer whose argument / FiLM the epilogue uses
+            const float* __restrict__ fg = film_s + Lm1 * 3 * kWidth;
+            const float* __restrict__ apl = ap + Lm1 * kWidth;
+            const float sdf_term = (Gb == 0) ? dsdf : 0.0f;              // sdf head reads the backbone output h8
+            f32x16 prev;
+            f32x4 argb[2][4];                                            // saved arguments, fetched one tile ahead
+            auto epilogue = [&](int tp, const f32x16& dhv, const f32x4 (&ar)[4], f32x16& dst) {
+                float rb[16], rg[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = 32 * tp + 8 * q + 4 * half;
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(fg + o), b4 = *reinterpret_cast<const f32x4*>(fg + kWidth + o),
+                                i4 = *reinterpret_cast<const f32x4*>(fg + 2 * kWidth + o);
+                    const f32x4 ws = *reinterpret_cast<const f32x4*>(head_s + o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float dh = vmask * fmaf(ws[j], sdf_term, dhv[4 * q + j]);
+                        const float da = dh * cos_hw_f32(ar[q][j]);
+                        rb[4 * q + j] = da;
+                        rg[4 * q + j] = da * ((ar[q][j] - b4[j]) * i4[j]);
+                        dst[4 * q + j] = g4[j] * da;
+                    }
+                }
+                reduce_tile(Lm1, tp, rb, rg);
+            };
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                // arguments of tile t (consumed one tile later): issued before this tile's DMA pieces
+#pragma unroll
+                for (int q = 0; q < 4; ++q) argb[t & 1][q] = *reinterpret_cast<const f32x4*>(apl + 32 * t + 8 * q + 4 * half);
+                if (t > 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(argb[(t - 1) & 1][q]));   // retire its wait before any new DMA
+                }
+                f32x16 acc = zero16();
+                acc = big_tile<false, 0>(wcur, wnxt, lane, in, acc, ring, NoEpilogue(), chunk_sync, issue_piece);
+                advance_chunk();
+                if (t > 0) {
+                    epilogue(t - 1, prev, argb[(t - 1) & 1], out[t - 1]);
+                    asm volatile("" : "+a"(out[t - 1]));
+                }
+                prev = acc;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(argb[(kNT - 1) & 1][q]));
+            epilogue(kNT - 1, prev, argb[(kNT - 1) & 1], out[kNT - 1]);
+#pragma unroll
+            for (int tt = 0; tt < kNT; ++tt) {
+                in[tt] = out[tt];
+                asm volatile("" : "+a"(in[tt]));
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// fold the per-(workgroup, wave) partial sums: dfilm[b][l][gb][n] = sum over the image's slices, fixed order
+__global__ void __launch_bounds__(256)
+bwd_reduce_kernel(float* __restrict__ dfilm, const float* __restrict__ partials, int wgs_per_img) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;                    // < 9*2*256
+    float acc = 0.0f;
+    const float* p = partials + (int64_t)b * wgs_per_img * 4 * (9 * 2 * kWidth) + e;
+    for (int s = 0; s < wgs_per_img * 4; ++s) acc += p[(int64_t)s * (9 * 2 * kWidth)];
+    dfilm[(int64_t)b * 9 * 2 * kWidth + e] = acc;
+}
+
+// d(styles)[b][l][k] = 15 * sum_n Wg_l[n][k] dgamma[b][l][n] + 0.25 * sum_n Wb_l[n][k] dbeta[b][l][n]
+// (backward of LinearLayer.forward :76-80; film_params_kernel is the forward)
+__global__ void __launch_bounds__(256)
+film_bwd_kernel(float* __restrict__ dstyles, const float* __restrict__ dfilm, const float* __restrict__ wg,
+                const float* __restrict__ wb) {
+    const int l = blockIdx.x % 9, b = blockIdx.x / 9;
+    const int k = threadIdx.x;
+    const float* __restrict__ dg = dfilm + ((int64_t)b * 9 + l) * 2 * kWidth;
+    const float* __restrict__ db = dg + kWidth;
+    const float* __restrict__ Wg = wg + (int64_t)l * kWidth * kWidth;
+    const float* __restrict__ Wb = wb + (int64_t)l * kWidth * kWidth;
+    float acc = 0.0f;
+    for (int n = 0; n < kWidth; ++n)                                   // lanes along k: coalesced rows
+        acc += 15.0f * Wg[(int64_t)n * kWidth + k] * dg[n] + 0.25f * Wb[(int64_t)n * kWidth + k] * db[n];
+    dstyles[((int64_t)b * 9 + l) * kWidth + k] = acc;
+}
+
+}  // namespace e3dge
+
+using namespace e3dge;
+
+static int bwd_geometry(int batch, int64_t n_pts, int* subtiles_per_wg, int* wgs_per_img) {
+    const int64_t tiles = (n_pts + kTilePts - 1) / kTilePts;
+    int spw = (int)((tiles * batch + 255) / 256);
+    if (spw < 1) spw = 1;
+    if (spw > 8) spw = 8;
+    *subtiles_per_wg = spw;
+    *wgs_per_img = (int)((tiles + spw - 1) / spw);
+    return 0;
+}
+
+extern "C" int64_t e3dge_siren_bwd_partial_floats(int batch, int64_t n_pts) {
+    if (batch <= 0 || n_pts <= 0) return 0;
+    int spw, wpi;
+    bwd_geometry(batch, n_pts, &spw, &wpi);
+    return (int64_t)batch * wpi * 4 * (9 * 2 * kWidth);
+}
+
+extern "C" int e3dge_siren_bwd(const float* packed, const float* film, const float* args, const float* d_feat,
+                               const float* d_rgb, const float* d_sdf, const float* wg, const float* wb,
+                               int batch, int64_t n_pts, float* partials, float* dfilm, float* dstyles,
+                               e3dge_stream_t stream) {
+    E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "siren_bwd: bad sizes");
+    if (batch == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(packed && film && args && wg && wb && partials && dfilm && dstyles, "siren_bwd: null pointer");
+    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(args) | reinterpret_cast<uintptr_t>(d_feat)) & 15) == 0,
+                  "siren_bwd: packed/args/d_feat must be 16-B aligned");
+    hipStream_t st = as_stream(stream);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&siren_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsBytes);
+        if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(siren_bwd): %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    SirenBwdK k{};
+    k.packed = packed; k.film = film; k.args = args; k.d_feat = d_feat; k.d_rgb = d_rgb; k.d_sdf = d_sdf;
+    k.partials = partials; k.n_pts = n_pts; k.batch = batch;
+    bwd_geometry(batch, n_pts, &k.subtiles_per_wg, &k.wgs_per_img);
+    if (n_pts > 0) {
+        const int64_t grid = (int64_t)k.wgs_per_img * batch;
+        E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_bwd: grid too large");
+        siren_bwd_kernel<<<dim3((unsigned)grid), dim3(kThreads), kBwdLdsBytes, st>>>(k);
+        int rc = check_launch("siren_bwd");
+        if (rc) return rc;
+    }
+    bwd_reduce_kernel<<<dim3(9 * 2 * kWidth / 256, (unsigned)batch), dim3(256), 0, st>>>(dfilm, partials, n_pts > 0 ? k.wgs_per_img : 0);
+    int rc = check_launch("siren_bwd(reduce)");
+    if (rc) return rc;
+    film_bwd_kernel<<<dim3((unsigned)(batch * 9)), dim3(256), 0, st>>>(dstyles, dfilm, wg, wb);
+    return check_launch("siren_bwd(film)");
+}

@@ -1,0 +1,345 @@
+// Shared device-side definitions of the SIREN kernels (forward: siren.hip, backward: siren_bwd.hip): vector types,
+// the packed weight image layout, LDS carve of the forward kernel, MFMA / LDS-DMA / sine helpers and the tile routines.
+#pragma once
+#include "common.h"
+
+namespace e3dge {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));       // 8 packed f16 = one f16-MFMA operand
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWidth = E3DGE_SIREN_WIDTH;       // 256
+constexpr int kNT = kWidth / 32;                // 8 output tiles of 32 features
+constexpr int kChunkFloats = 32 * kWidth;       // one output tile x K=256 : 8192 floats = 32 KiB
+constexpr int kBigLayers = 8;                   // pts_linears.1..7 + views_linears[:, :256]
+constexpr int kChunksPerPass = kBigLayers * kNT;  // 64 chunks = 2 MiB per 128-point sub-tile
+constexpr int kNBuf = 3;                        // LDS weight buffers
+constexpr int kTilePts = 128;                   // points per sub-tile (4 waves x 32)
+constexpr int kThreads = 256;
+constexpr int kRMax = 16;                       // max rays per workgroup (LDS feature accumulators)
+constexpr int kFPitch = kWidth + 1;             // padded pitch of the feature accumulators
+constexpr int kMaxSlots = 3;                    // rays a 32-point slab can touch when S >= 16
+constexpr int kMinSamples = 16;
+
+// VALU instructions of the pipelined epilogue forced behind each MFMA with sched_group_barrier (0 = leave the
+// placement to the compiler).  Measured on MI355X (round 1, tools/build_variant.sh A/B): 0 -> 0.949 ms, 2..4 ->
+// 1.00-1.02 ms, with one or two accumulators alike: on gfx950 the fp32 MFMA and the fp32 VALU do not execute
+// concurrently for one wave (PMC: MFMA-busy + VALU-active + waits = wave cycles in every variant), so spreading
+// only adds issue bubbles.  The lever that works is FEWER VALU instructions, not better placement.
+#ifndef E3DGE_SPREAD_STD
+#define E3DGE_SPREAD_STD 0
+#endif
+#ifndef E3DGE_SPREAD_VIEW
+#define E3DGE_SPREAD_VIEW 0
+#endif
+// f16x3 path: VALU instructions scheduled behind each f16 MFMA (there the pipes DO overlap; 0 = compiler's placement)
+#ifndef E3DGE_SPREAD16
+#define E3DGE_SPREAD16 5
+#endif
+
+// ---- packed weight image (floats) ----
+constexpr int64_t kOffBig = 0;                                       // [8 layers][8 t][8 c][4 q][64 lane][4]
+constexpr int64_t kOffFirst = kOffBig + (int64_t)kChunksPerPass * kChunkFloats;   // [8 t][2][64]
+constexpr int64_t kOffVTail = kOffFirst + kNT * 2 * 64;              // [8 t][2][64]
+constexpr int64_t kOffBias = kOffVTail + kNT * 2 * 64;               // [9][256]
+constexpr int64_t kOffWSigma = kOffBias + 9 * kWidth;                // [256]
+constexpr int64_t kOffWRgb = kOffWSigma + kWidth;                    // [3][256]
+constexpr int64_t kOffBHead = kOffWRgb + 3 * kWidth;                 // b_sigma, b_rgb[3]
+constexpr int64_t kOffBig16 = kOffBHead + 4;                         // f16x3 image of the 8 big layers, see below
+// fp32 image of the TRANSPOSED big layers for the backward chain dh_{L-1} = W_L^T g_L, in the order it is consumed:
+// [Gb = 0..7 <-> layer L = 8 - Gb][8 out-tiles of k_in][8 c][4 q][64 lanes][4] = W_L[32c + 8q + 4(l>>5) + j][32t + (l&31)]
+constexpr int64_t kOffBigT = kOffBig16 + (int64_t)kChunksPerPass * kChunkFloats;
+constexpr int64_t kPackedFloats = kOffBigT + (int64_t)kChunksPerPass * kChunkFloats;
+// f16x3 image: the same 64 chunks of 32 KiB, each [16 k-steps g = 2c+s][hi, lo][64 lanes][8 f16]: lane l holds
+//   128 * W[32t + (l&31)][32c + 16s + (j&3) + 8(j>>2) + 4(l>>5)],  j = 0..7
+// split as hi = f16(v), lo = f16(v - hi).  The k order is the one in which a lane's C/D registers of the previous
+// layer (r = 8s + j) become the 8 k-slots of a v_mfma_f32_32x32x16_f16 operand; 128 keeps `lo` out of the f16
+// subnormals and is undone exactly by storing gamma / 128.
+constexpr float kW16Scale = 128.0f;
+
+// ---- LDS carve (floats) ----
+constexpr int kLdsW = 0;
+constexpr int kLdsFilm = kLdsW + kNBuf * kChunkFloats;               // [9][2][256] gamma/beta of this image
+constexpr int kLdsHead = kLdsFilm + 9 * 2 * kWidth;                  // w_sigma[256], w_rgb[3][256], b_sigma, b_rgb[3]
+constexpr int kHeadFloats = 4 * kWidth + 4;
+constexpr int kLdsVTail = kLdsHead + kHeadFloats;                    // [8 t][2][64] view-layer tail fragments
+constexpr int kLdsFeat = kLdsVTail + kNT * 2 * 64;                   // [kRMax][kFPitch]
+constexpr int kLdsPart = kLdsFeat + kRMax * kFPitch;                 // [4][kMaxSlots][256]
+constexpr int kLdsAlpha = ((kLdsPart + 4 * kMaxSlots * kWidth + 3) / 4) * 4;   // [128]
+constexpr int kLdsWgt = kLdsAlpha + kTilePts;                        // [128]
+constexpr int kLdsZ = kLdsWgt + kTilePts;                            // [128]
+constexpr int kLdsPts = kLdsZ + kTilePts;                            // [128][3]
+constexpr int kLdsRgb = kLdsPts + kTilePts * 3;                      // [128][3]
+constexpr int kLdsState = kLdsRgb + kTilePts * 3;                    // [kRMax][12]: T, wsum, depth, xyz3, rgb3
+constexpr int kStateStride = 12;
+constexpr int kLdsFloats = kLdsState + kRMax * kStateStride;
+constexpr int kLdsBytes = kLdsFloats * 4;
+static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+static_assert((kLdsFilm % 4) == 0 && (kLdsHead % 4) == 0 && (kLdsFeat % 4) == 0, "alignment");
+static_assert(kOffWRgb == kOffWSigma + kWidth && kOffBHead == kOffWSigma + 4 * kWidth, "head block is contiguous");
+
+struct SirenK {
+    const float* packed;
+    const float* film;         // (batch, 9, 2, 256)
+    // render mode
+    const float* c2w; const float* focal; const float* near; const float* far; const float* t_vals;
+    const float* tex_alpha; const float* tex_beta;
+    float sigmoid_beta, box_scale, mask_thresh;
+    int batch, H, Wd, S, res, force_bg;
+    int R, tiles_per_img;
+    float *rgb, *features, *xyz, *depth, *mask, *sdf, *weights, *points, *rays_d, *viewdirs, *dists;
+    // points mode
+    const float* pts; const float* vdirs; long long n_pts; int subtiles_per_wg, wgs_per_img;
+    float* raw;
+    float* save_args;          // training: (points, 9, 256) pre-sine arguments of every layer, or null
+};
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// C/D fragment of v_mfma_f32_32x32x2_f32: lane l, register r holds D[row_of(r, l>>5)][l&31].
+__device__ __forceinline__ constexpr int row_of(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ float f16lo(unsigned p) { return (float)__builtin_bit_cast(fp16x2, p).x; }
+__device__ __forceinline__ float f16hi(unsigned p) { return (float)__builtin_bit_cast(fp16x2, p).y; }
+// fp32 pair -> packed f16 (hi word, lo word) with x = hi + lo up to 2^-21 |x| (v_cvt_pkrtz rounds toward zero, so the
+// remainder is exact in fp32 and has the sign of x).  Simulated against float64 this split with three products
+// (hi*hi + hi*lo + lo*hi, fp32 accumulate) is as accurate as plain fp32 in this network.
+struct HiLo { unsigned h, l; };
+__device__ __forceinline__ HiLo split2(float x0, float x1) {
+    HiLo p;
+    p.h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    p.l = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0 - f16lo(p.h), x1 - f16hi(p.h)));
+    return p;
+}
+// (vector elements cannot be bound to references, hence the macro)
+#define SPLIT2_TO(x0, x1, H, L) do { const HiLo p_ = split2((x0), (x1)); (H) = p_.h; (L) = p_.l; } while (0)
+
+// value r (0..15) of feature tile c from the packed (hi, lo) representation
+__device__ __forceinline__ float acts16_get(const u32x4 (&aH)[2 * kNT], const u32x4 (&aL)[2 * kNT], int c, int r) {
+    const int g = 2 * c + (r >> 3), k = (r & 7) >> 1;
+    return (r & 1) ? f16hi(aH[g][k]) + f16hi(aL[g][k]) : f16lo(aH[g][k]) + f16lo(aL[g][k]);
+}
+
+__device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+}
+// Same with the instruction's immediate offset, which the hardware adds to BOTH the global and the LDS address
+// (the chunk image has the same layout on both sides), so the 8 pieces of a chunk share two address setups.
+template <int OFF_BYTES>
+__device__ __forceinline__ void glds16_off(const float* gsrc, float* ldst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)ldst, 16, OFF_BYTES, 0);
+}
+
+// Two sines, both with an exact FMA Cody-Waite range reduction (|x| < ~1e5):
+//  * sin_hw_f32 (default, 6 VALU ops): reduce to |r| <= pi, hardware v_sin_f32 on r / 2pi.  Max abs error 3.8e-7.
+//  * sin_poly_f32 (13 VALU ops): reduce to |r| <= pi/2, degree-9 minimax odd polynomial (4.7e-9 in exact
+//    arithmetic), sign from k's parity.  Max abs error 1.2e-7.
+// fp32 MFMA and fp32 VALU do not overlap on gfx950, so every VALU op of the epilogue is paid in full; the
+// renderer's parity against the reference is the same with either (features ~1e-5, the summation-order noise).
+// -DE3DGE_POLY_SINE selects the polynomial for the kernels.
+__device__ __forceinline__ float sin_hw_f32(float x) {
+    const float kf = rintf(x * 0.159154943091895336f);
+    float r = fmaf(-kf, 6.2831854820251465f, x);
+    r = fmaf(-kf, -1.7484555314695172e-07f, r);
+    return __builtin_amdgcn_sinf(r * 0.159154943091895336f);
+}
+// cos with the same exact reduction (backward kernels: d/dx sin = cos of the SAVED argument)
+__device__ __forceinline__ float cos_hw_f32(float x) {
+    const float kf = rintf(x * 0.159154943091895336f);
+    float r = fmaf(-kf, 6.2831854820251465f, x);
+    r = fmaf(-kf, -1.7484555314695172e-07f, r);
+    return __builtin_amdgcn_cosf(r * 0.159154943091895336f);
+}
+__device__ __forceinline__ float sin_poly_f32(float x) {
+    const float kf = rintf(x * 0.318309886183790672f);
+    float r = fmaf(-kf, 3.1415927410125732f, x);
+    r = fmaf(-kf, -8.742277657347586e-08f, r);
+    const float r2 = r * r;
+    float p = fmaf(r2, 2.6003292532550404e-06f, -1.9806761702056974e-04f);
+    p = fmaf(p, r2, 8.33301991224289e-03f);
+    p = fmaf(p, r2, -1.6666656732559204e-01f);
+    const float sv = fmaf(r * r2, p, r);
+    const unsigned sign = ((unsigned)(int)kf) << 31;
+    return __uint_as_float(__float_as_uint(sv) ^ sign);
+}
+__device__ __forceinline__ float sin_f32(float x) {
+#ifdef E3DGE_POLY_SINE
+    return sin_poly_f32(x);
+#else
+    return sin_hw_f32(x);
+#endif
+}
+
+__device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, kWave); }
+
+// K=256 contraction of one 32-feature output tile against the wave's register-resident activations.
+//   TRANSPOSED=false: D[feature][point]  (weights = A operand, activations = B operand)
+//   TRANSPOSED=true : D[point][feature]  (activations = A operand, weights = B operand)
+// * The weight fragments are double-buffered in registers: each ds_read_b128 of k-block c+1 is issued ahead of
+//   4 MFMAs of k-block c (one k-block = 1024 cycles of cover for the LDS latency).
+// * `epi(r)`, r = 0..15, is the epilogue of the PREVIOUS output tile (FiLM + sine of one accumulator register, ~20
+//   VALU ops); it is called once every second 4-MFMA group so that its VALU work issues in the shadow of this
+//   tile's MFMAs (the matrix pipe is busy 64 cycles per MFMA, a VALU op takes 4) instead of after them.
+struct NoEpilogue { __device__ __forceinline__ void operator()(int) const {} };
+
+constexpr int kRing = 4;          // weight fragments held in registers (2 being consumed + 2 in flight)
+constexpr int kSyncPair = 2;      // MFMA-group pair (even index) after which the chunk barrier happens; DMA pieces follow
+
+template <bool TRANSPOSED, int VALU_PER_MFMA, class Epi, class Sync, class Dma>
+__device__ __forceinline__ f32x16 big_tile(const float* __restrict__ wchunk, const float* __restrict__ wnext,
+                                           int lane, const f32x16 (&in)[kNT], f32x16 acc, f32x4 (&ring)[kRing],
+                                           Epi&& epi, Sync&& sync, Dma&& dma) {
+    const f32x4* __restrict__ wp = reinterpret_cast<const f32x4*>(wchunk) + lane;
+    const f32x4* __restrict__ wn = reinterpret_cast<const f32x4*>(wnext) + lane;
+    constexpr int kGroups = kNT * 4;     // 32 groups of 4 MFMAs (one ds_read_b128 each)
+    // On entry ring[0], ring[1] hold groups 0 and 1 of this chunk (fetched by the previous tile's tail or the
+    // prologue); on exit they hold groups 0 and 1 of the NEXT chunk, so consecutive tiles run back to back.
+#pragma unroll
+    for (int gp = 0; gp < kGroups; gp += 2) {
+#pragma unroll
+        for (int g = gp + 2; g < gp + 4; ++g)
+            ring[g % kRing] = (g < kGroups) ? wp[g * 64] : wn[(g - kGroups) * 64];
+        __builtin_amdgcn_sched_barrier(0);              // keep the prefetch ahead of the MFMAs it covers
+#pragma unroll
+        for (int g = gp; g < gp + 2; ++g) {
+            const f32x4 w4 = ring[g % kRing];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float act = in[g >> 2][4 * (g & 3) + j];
+                acc = TRANSPOSED ? mfma32(act, w4[j], acc) : mfma32(w4[j], act, acc);
+            }
+        }
+        if (gp == kSyncPair) sync();
+        if (gp > kSyncPair && gp <= kSyncPair + 16) dma((gp - kSyncPair) / 2 - 1);   // one DMA piece per group pair
+        epi(gp >> 1);
+        if (VALU_PER_MFMA > 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER_MFMA, 0);   // n VALU
+            }
+        }
+    }
+    return acc;
+}
+
+// The same contraction on the f16 matrix pipe: fp32 operands split into f16 hi + lo, three products per k-step
+// (hi*hi, lo_w*hi_a, hi_w*lo_a) into one fp32 accumulator.  16 k-steps of K=16 per tile = 48 MFMAs of 32
+// cycles (1536 vs 8192 for fp32), and this pipe runs concurrently with the VALU, so the epilogue hides under it.
+constexpr int kRing16 = 4;        // k-steps whose (hi, lo) weight fragments are held: 1 consumed + 3 in flight
+constexpr int kSyncStep16 = 2;    // k-step after which the chunk barrier + next DMA issue happen
+
+// Ablation switches for tools/ablate.sh (timing experiments only -- results are wrong when any is defined):
+//   E3DGE_ABL_NOEPI  drop the pipelined epilogue VALU     E3DGE_ABL_NODMA  drop the weight DMA
+//   E3DGE_ABL_NOLDS  drop the weight-fragment LDS reads   E3DGE_ABL_NOSYNC drop the chunk barrier
+template <bool TRANSPOSED, class Epi, class Sync, class Dma>
+__device__ __forceinline__ void big_tile_f16(const float* __restrict__ wchunk, const float* __restrict__ wnext,
+                                             int lane, const u32x4 (&aH)[2 * kNT], const u32x4 (&aL)[2 * kNT],
+                                             f32x16& acc, f32x16& accb, u32x4 (&ringH)[kRing16],
+                                             u32x4 (&ringL)[kRing16], Epi&& epi, Sync&& sync, Dma&& dma) {
+    const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(wchunk) + lane;
+    const u32x4* __restrict__ wn = reinterpret_cast<const u32x4*>(wnext) + lane;
+    constexpr int kSteps = 2 * kNT;
+    // entry: ring slots 0..2 hold k-steps 0..2 of this chunk; exit: k-steps 0..2 of the next chunk
+#pragma unroll
+    for (int g = 0; g < kSteps; ++g) {
+        const int ga = g + kRing16 - 1;
+#ifndef E3DGE_ABL_NOLDS
+        ringH[ga % kRing16] = (ga < kSteps) ? wp[(ga * 2 + 0) * 64] : wn[((ga - kSteps) * 2 + 0) * 64];
+        ringL[ga % kRing16] = (ga < kSteps) ? wp[(ga * 2 + 1) * 64] : wn[((ga - kSteps) * 2 + 1) * 64];
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x4 wh = ringH[g % kRing16], wl = ringL[g % kRing16];
+        // Two accumulators used alternately (a b a | b a b | ...): an instruction issued between two MFMAs that chain
+        // on the SAME accumulator costs ~43 cycles (the accumulate-forwarding path is lost); with the interleaved
+        // epilogue every MFMA would pay it.  The caller adds the two once per tile.
+        f32x16& x0 = (g & 1) ? accb : acc;
+        f32x16& x1 = (g & 1) ? acc : accb;
+        if (!TRANSPOSED) {
+            x0 = mfma16(wh, aH[g], x0);
+            x1 = mfma16(wl, aH[g], x1);
+            x0 = mfma16(wh, aL[g], x0);
+        } else {
+            x0 = mfma16(aH[g], wh, x0);
+            x1 = mfma16(aH[g], wl, x1);
+            x0 = mfma16(aL[g], wh, x0);
+        }
+#ifndef E3DGE_ABL_NOSYNC
+        if (g == kSyncStep16) sync();
+#endif
+#ifndef E3DGE_ABL_NODMA
+        if (g > kSyncStep16 && g <= kSyncStep16 + 8) dma(g - kSyncStep16 - 1);            // one DMA piece per k-step
+#endif
+#ifndef E3DGE_ABL_NOEPI
+        epi(g);
+#endif
+        if (E3DGE_SPREAD16 > 0) {
+            // f16 MFMAs co-execute with the VALU when the fillers sit BETWEEN consecutive MFMAs (about five single-issue
+            // instructions hide per 32-cycle MFMA): lay the epilogue out as {MFMA, n VALU, LDS read} x 3 per k-step
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, E3DGE_SPREAD16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+    return z;
+}
+
+// sin(gamma * acc + beta), standard layout; gamma/beta of the layer come from the LDS copy of this image's
+// FiLM block ([2][256], bias already folded into beta); one fused multiply-add feeds the sine.
+// `save` (may be null): where this lane's point keeps the 256 arguments of the layer ([256] floats).
+__device__ __forceinline__ f32x16 film_sin_std(f32x16 acc, const float* __restrict__ film_l, int t, int half,
+                                               float* __restrict__ save = nullptr) {
+    f32x16 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(film_l + 32 * t + 8 * q + 4 * half);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(film_l + kWidth + 32 * t + 8 * q + 4 * half);
+        f32x4 arg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            arg[j] = fmaf(g4[j], acc[4 * q + j], b4[j]);
+            o[4 * q + j] = sin_f32(arg[j]);
+        }
+        if (save) *reinterpret_cast<f32x4*>(save + 32 * t + 8 * q + 4 * half) = arg;
+    }
+    return o;
+}
+
+__device__ __forceinline__ void set_tile(f32x16 (&dst)[kNT], int t, const f32x16& v) {
+    switch (t) {
+        case 0: dst[0] = v; break;
+        case 1: dst[1] = v; break;
+        case 2: dst[2] = v; break;
+        case 3: dst[3] = v; break;
+        case 4: dst[4] = v; break;
+        case 5: dst[5] = v; break;
+        case 6: dst[6] = v; break;
+        default: dst[7] = v; break;
+    }
+}
+
+
+}  // namespace e3dge

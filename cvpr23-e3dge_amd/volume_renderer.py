@@ -190,11 +190,21 @@ class SirenGenerator(nn.Module):
         _lib.check(rc, "e3dge_film_params")
         return film
 
-    def query_points(self, pts, viewdirs, styles, box_scale, want_raw=True, mfma_mode=None):
-        """pts (B, N, 3) world-space, viewdirs (B, N, 3) or None -> (sdf (B,N), raw (B,N,260) or None)."""
+    def query_points(self, pts, viewdirs, styles, box_scale, want_raw=True, mfma_mode=None, save_args=None):
+        """pts (B, N, 3) world-space, viewdirs (B, N, 3) or None -> (sdf (B,N), raw (B,N,260) or None).
+        When `styles` requires grad the call is differentiable w.r.t. it (HIP backward, e3dge_siren_bwd)."""
         _lib.require_gpu(pts, "pts")
-        packed = self.device_image()[0]
+        if torch.is_grad_enabled() and styles.requires_grad and pts.shape[0] and pts.shape[1]:
+            if pts.requires_grad or (viewdirs is not None and viewdirs.requires_grad):
+                raise NotImplementedError("gradients w.r.t. sample positions / view directions (eikonal term) are "
+                                          "not covered by the HIP backward")
+            sdf, raw = _PointsQuery.apply(styles, self, pts, viewdirs, box_scale, mfma_mode)
+            return sdf, (raw if want_raw else None)
         film = self.film_params(styles)
+        return self._points_launch(film, pts, viewdirs, box_scale, want_raw, mfma_mode, save_args)
+
+    def _points_launch(self, film, pts, viewdirs, box_scale, want_raw, mfma_mode, save_args):
+        packed = self.device_image()[0]
         pts = pts.contiguous()
         vd = None if viewdirs is None else viewdirs.contiguous()
         B, N, _ = pts.shape
@@ -204,7 +214,7 @@ class SirenGenerator(nn.Module):
             return sdf, raw
         with torch.cuda.device(pts.device):
             rc = _lib.load().e3dge_siren_points_fwd(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(pts), _lib.ptr(vd),
-                                                    float(box_scale), B, N, _lib.ptr(sdf), _lib.ptr(raw),
+                                                    float(box_scale), B, N, _lib.ptr(sdf), _lib.ptr(raw), _lib.ptr(save_args),
                                                     MFMA_MODES[mfma_mode or self.mfma_mode], _lib.stream_of(pts))
         _lib.check(rc, "e3dge_siren_points_fwd")
         return sdf, raw
@@ -217,6 +227,55 @@ class SirenGenerator(nn.Module):
         flat = net_inputs.reshape(B, -1, 6)
         _, raw = self.query_points(flat[..., :3], flat[..., 3:], styles, 1.0, want_raw=True)
         return raw.reshape(*lead, 260)
+
+
+def siren_backward(siren, film, args, d_feat, d_rgb, d_sdf):
+    """dL/d(styles) (B,9,256) and dL/d(film) (B,9,2,256) from the per-point output gradients (e3dge_siren_bwd).
+    args (B,N,9,256) are the forward launch's saved pre-sine arguments; any of d_feat (B,N,256), d_rgb (B,N,3),
+    d_sdf (B,N) may be None."""
+    packed, wg, _, wb, _ = siren.device_image()
+    B, N = args.shape[0], args.shape[1]
+    dev = args.device
+    lib = _lib.load()
+    d_feat, d_rgb, d_sdf = [None if t is None else t.contiguous().float() for t in (d_feat, d_rgb, d_sdf)]
+    n_part = lib.e3dge_siren_bwd_partial_floats(B, N)
+    partials = torch.zeros(max(n_part, 1), device=dev, dtype=torch.float32)
+    dfilm = torch.empty((B, 9, 2, siren.W), device=dev, dtype=torch.float32)
+    dstyles = torch.empty((B, 9, siren.W), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        rc = lib.e3dge_siren_bwd(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), _lib.ptr(d_feat), _lib.ptr(d_rgb),
+                                 _lib.ptr(d_sdf), _lib.ptr(wg), _lib.ptr(wb), B, N, _lib.ptr(partials),
+                                 _lib.ptr(dfilm), _lib.ptr(dstyles), _lib.stream_of(args))
+    _lib.check(rc, "e3dge_siren_bwd")
+    return dstyles, dfilm
+
+
+class _PointsQuery(torch.autograd.Function):
+    """run_network with a gradient path to the styles (the encoder's output): forward saves the pre-sine arguments,
+    backward is the fused HIP chain.  Points / view directions get no gradient (they are fixed samples)."""
+
+    @staticmethod
+    def forward(ctx, styles, siren, pts, viewdirs, box_scale, mfma_mode):
+        B, N = pts.shape[0], pts.shape[1]
+        args = torch.empty((B, N, 9, siren.W), device=pts.device, dtype=torch.float32)
+        film = siren.film_params(styles)
+        sdf, raw = siren._points_launch(film, pts, viewdirs, box_scale, True, mfma_mode, args)
+        ctx.siren, ctx.styles_ndim = siren, styles.ndim
+        ctx.save_for_backward(film, args)
+        return sdf, raw
+
+    @staticmethod
+    def backward(ctx, d_sdf, d_raw):
+        film, args = ctx.saved_tensors
+        d_rgb = d_feat = None
+        ds = d_sdf
+        if d_raw is not None:
+            d_rgb, d_feat = d_raw[..., :3], d_raw[..., 4:]
+            ds = d_raw[..., 3] if ds is None else ds + d_raw[..., 3]
+        dstyles, _ = siren_backward(ctx.siren, film, args, d_feat, d_rgb, ds)
+        if ctx.styles_ndim == 2:                   # one W shared by the nine layers (reference :189-191)
+            dstyles = dstyles.sum(1)
+        return dstyles, None, None, None, None, None
 
 
 class SirenLocalGlobal(nn.Module):

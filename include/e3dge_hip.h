@@ -158,6 +158,8 @@ typedef struct E3dgeRenderArgs {
     float* rays_d;         /* (batch, H, W, 3)    (:782)                                            */
     float* viewdirs;       /* (batch, H, W, 3)    normalised (:1679)                                */
     float* dists;          /* (batch, H, W, S)    (:826-837)                                        */
+    float* save_args;      /* training only, else NULL: (batch, H, W, S, 9, 256) pre-sine arguments of the 9 FiLM
+                              layers, consumed by e3dge_siren_bwd                                        */
 } E3dgeRenderArgs;
 
 /*
@@ -175,11 +177,33 @@ int e3dge_siren_render_fwd(const E3dgeRenderArgs* args, e3dge_stream_t stream);
  * (volume_renderer.py:1052-1128; callers :925-930, :1916-1949, sample_uniform_grid :945-).
  * pts (batch, n_pts, 3) world-space (box warp applied inside); viewdirs (batch, n_pts, 3) or NULL (= 0).
  * Outputs (any may be NULL): sdf (batch, n_pts); raw (batch, n_pts, 260) = [rgb3, sdf1, feat256]
- * exactly as SirenGenerator.forward concatenates them (:259-261).
+ * exactly as SirenGenerator.forward concatenates them (:259-261); save_args (batch, n_pts, 9, 256) as in
+ * E3dgeRenderArgs (training only).
  */
 int e3dge_siren_points_fwd(const float* packed, const float* film, const float* pts,
                            const float* viewdirs, float box_scale, int batch, int64_t n_pts,
-                           float* sdf, float* raw, int precision, e3dge_stream_t stream);
+                           float* sdf, float* raw, float* save_args, int precision, e3dge_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Training direction: gradient of a loss w.r.t. the renderer's styles (W+ latents), generator weights frozen.
+ * Replaces autograd through SirenGenerator.forward (project/utils/volume_renderer.py:168-264) as the encoder
+ * trainer drives it (project/trainer.py:728 loss.backward(); the generator is frozen at :1568).
+ *
+ *   args     (batch, n_pts, 9, 256)  pre-sine arguments saved by the forward launch (save_args)
+ *   d_feat   (batch, n_pts, 256)     dL/d(view-layer features) per point, or NULL (= 0)
+ *   d_rgb    (batch, n_pts, 3)       dL/d(rgb head output, pre-sigmoid), or NULL
+ *   d_sdf    (batch, n_pts)          dL/d(sdf head output), or NULL
+ *   wg, wb   (9, 256, 256)           the gamma / beta style-linear weights as given to e3dge_film_params
+ *   partials  e3dge_siren_bwd_partial_floats(batch, n_pts) floats of scratch, ZEROED by the caller
+ *   dfilm    (batch, 9, 2, 256) out  dL/d(gamma, beta)
+ *   dstyles  (batch, 9, 256)    out  dL/d(styles)
+ * No tex-FiLM (second pass) support: that pass runs under no_grad in the reference's stage-1 training.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int64_t e3dge_siren_bwd_partial_floats(int batch, int64_t n_pts);
+int e3dge_siren_bwd(const float* packed, const float* film, const float* args, const float* d_feat,
+                    const float* d_rgb, const float* d_sdf, const float* wg, const float* wb,
+                    int batch, int64_t n_pts, float* partials, float* dfilm, float* dstyles, e3dge_stream_t stream);
+
 
 /* Layout self-test: runs a 32x32xK fp32-MFMA product with the fragment conventions the render kernel
  * relies on and writes it to c (32*32 floats, row-major) for the caller to compare with a @ b^T.
