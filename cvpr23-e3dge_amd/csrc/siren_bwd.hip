@@ -22,6 +22,10 @@ struct SirenBwdK {
     const float* d_feat;     // (batch, n_pts, 256) or null
     const float* d_rgb;      // (batch, n_pts, 3) or null
     const float* d_sdf;      // (batch, n_pts) or null
+    // render mode: d_feat of a point is weights[p] * d_featmap[ray(p)] (never materialised per point)
+    const float* d_featmap;  // (batch * rays, 256) or null
+    const float* weights;    // (batch, n_pts) compositing weights of the forward launch
+    int samples;             // points per ray
     float* partials;         // (grid, 4, 9, 2, 256), zero-initialised by the caller
     long long n_pts;
     int batch, subtiles_per_wg, wgs_per_img;
@@ -164,6 +168,11 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
             const float* __restrict__ fg = film_s + 8 * 3 * kWidth;
             const float* __restrict__ wr = head_s + kWidth;
             const float* __restrict__ df = a.d_feat ? a.d_feat + gpt * kWidth : nullptr;
+            float wfeat = 1.0f;
+            if (a.d_featmap) {
+                df = a.d_featmap + (gpt / a.samples) * kWidth;
+                wfeat = a.weights[gpt];
+            }
 #pragma unroll
             for (int t = 0; t < kNT; ++t) {
                 float rb[16], rg[16];
@@ -179,7 +188,7 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                                 w2 = *reinterpret_cast<const f32x4*>(wr + 2 * kWidth + o);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float dh = vmask * (d4[j] + w0[j] * drgb[0] + w1[j] * drgb[1] + w2[j] * drgb[2]);
+                        const float dh = vmask * (wfeat * d4[j] + w0[j] * drgb[0] + w1[j] * drgb[1] + w2[j] * drgb[2]);
                         const float da = dh * cos_hw_f32(ar[j]);
                         rb[4 * q + j] = da;
                         rg[4 * q + j] = da * ((ar[j] - b4[j]) * i4[j]);
@@ -251,6 +260,139 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of volume_integration (project/utils/volume_renderer.py:809-943, the sdf / force_background configuration)
+// down to the per-point network outputs: one wave per ray.
+//   dL/dw_s   = 2 sum_c dRGB_c sigmoid(rgb_s,c) + <dFEAT, feat_s> + <dXYZ, pts_s> + dDEPTH z_s
+//   w_s       = alpha_s T_s,  T_s = prod_{j<s} (1 - alpha_j + 1e-10);  force_background: w_{S-1} = 1 - sum_{j<S-1} w_j
+//   dL/dalpha_s = dw_s T_s - (sum_{j>s} dw_j alpha_j T_j) / (1 - alpha_s + 1e-10)
+//   alpha = 1 - exp(-sigma delta), sigma = sigmoid(-sdf/beta)/beta
+// feat_s = sin(arg8_s) and rgb_s = Wrgb feat_s + b are recomputed from the saved view-layer arguments.
+// ---------------------------------------------------------------------------------------------------------------
+struct CompositeBwdK {
+    const float* packed; const float* args; const float* sdf; const float* dists; const float* points;
+    const float* weights; const float* t_vals; const float* near; const float* far;
+    const float* d_rgbmap;   // (rays, 3)
+    const float* d_featmap;  // (rays, 256)
+    const float* d_xyzmap;   // (rays, 3) or null
+    const float* d_depthmap; // (rays) or null
+    const float* d_sdf_in;   // (rays, S) or null: gradient arriving at the per-point sdf output
+    float* d_rgb_pts;        // (rays, S, 3) out
+    float* d_sdf_pts;        // (rays, S) out
+    float sigmoid_beta;
+    int S, force_bg;
+    long long n_rays, rays_per_img;
+};
+
+constexpr int kCbStride = 8;     // floats of LDS per sample: dw, alpha, T, dalpha/dsdf, rgb[3], d_sdf
+
+__global__ void __launch_bounds__(kThreads) composite_bwd_kernel(const CompositeBwdK a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = a.S;
+    float* const ws = smem + (size_t)wave * S * kCbStride;
+    const float* __restrict__ wrgb = a.packed + kOffWRgb;
+    const float* __restrict__ bhead = a.packed + kOffBHead;
+    f32x4 wr4[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) wr4[c] = *reinterpret_cast<const f32x4*>(wrgb + c * kWidth + 4 * lane);
+    const float inv_beta = 1.0f / a.sigmoid_beta;
+    const long long stride = (long long)gridDim.x * 4;
+    const long long trips = (a.n_rays + stride - 1) / stride;
+    for (long long it = 0; it < trips; ++it) {
+        const long long ray = it * stride + (long long)blockIdx.x * 4 + wave;
+        const bool active = ray < a.n_rays;
+        if (active) {
+            const int b = (int)(ray / a.rays_per_img);
+            const float nearv = a.near[b], farv = a.far[b];
+            f32x4 df4 = {0.f, 0.f, 0.f, 0.f};
+            if (a.d_featmap) df4 = *reinterpret_cast<const f32x4*>(a.d_featmap + ray * kWidth + 4 * lane);
+            float drgb[3] = {0.f, 0.f, 0.f}, dxyz[3] = {0.f, 0.f, 0.f};
+            if (a.d_rgbmap) { drgb[0] = a.d_rgbmap[ray * 3]; drgb[1] = a.d_rgbmap[ray * 3 + 1]; drgb[2] = a.d_rgbmap[ray * 3 + 2]; }
+            if (a.d_xyzmap) { dxyz[0] = a.d_xyzmap[ray * 3]; dxyz[1] = a.d_xyzmap[ray * 3 + 1]; dxyz[2] = a.d_xyzmap[ray * 3 + 2]; }
+            const float ddepth = a.d_depthmap ? a.d_depthmap[ray] : 0.0f;
+            // phase 1: recompute feat / rgb of every sample, four wave-wide dot products each
+            for (int s = 0; s < S; ++s) {
+                const long long gpt = ray * S + s;
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(a.args + gpt * (9 * kWidth) + 8 * kWidth + 4 * lane);
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float f = sin_f32(a4[j]);
+                    v[0] = fmaf(df4[j], f, v[0]);
+                    v[1] = fmaf(wr4[0][j], f, v[1]);
+                    v[2] = fmaf(wr4[1][j], f, v[2]);
+                    v[3] = fmaf(wr4[2][j], f, v[3]);
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] += __shfl_xor(v[i], off, kWave);
+                }
+                if (lane == 0) {
+                    const float tv = a.t_vals[s];
+                    const float z = nearv * (1.0f - tv) + farv * tv;
+                    const float* pp = a.points + gpt * 3;
+                    float dw = v[0] + dxyz[0] * pp[0] + dxyz[1] * pp[1] + dxyz[2] * pp[2] + ddepth * z;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float rc = v[1 + c] + bhead[1 + c];
+                        ws[s * kCbStride + 4 + c] = rc;
+                        dw = fmaf(2.0f * drgb[c], sigmoid_f32(rc), dw);
+                    }
+                    ws[s * kCbStride + 0] = dw;
+                }
+            }
+            // phase 2: alpha and d(alpha)/d(sdf), lanes over samples
+            for (int s = lane; s < S; s += kWave) {
+                const long long gpt = ray * S + s;
+                const float sg = sigmoid_f32(-a.sdf[gpt] * inv_beta);
+                const float sigma = sg * inv_beta;
+                const float delta = a.dists[gpt];
+                const float e = __expf(-sigma * delta);
+                ws[s * kCbStride + 1] = 1.0f - e;
+                // d alpha / d sdf = delta e * (-sg (1 - sg) / beta^2); delta = 1e10 |d| on the last sample: e == 0 there
+                ws[s * kCbStride + 3] = (e == 0.0f) ? 0.0f : delta * e * (-sg * (1.0f - sg) * inv_beta * inv_beta);
+            }
+        }
+        __syncthreads();
+        if (active && lane == 0) {
+            // phase 3: the two sequential scans of one ray (S is a few dozen)
+            float T = 1.0f, dw_last = 0.0f;
+            for (int s = 0; s < S; ++s) {
+                ws[s * kCbStride + 2] = T;
+                T *= (1.0f - ws[s * kCbStride + 1] + 1e-10f);
+            }
+            if (a.force_bg) dw_last = ws[(S - 1) * kCbStride + 0];
+            float suffix = 0.0f;
+            for (int s = S - 1; s >= 0; --s) {
+                const float al = ws[s * kCbStride + 1], Ts = ws[s * kCbStride + 2];
+                const float dwe = (a.force_bg && s == S - 1) ? 0.0f : ws[s * kCbStride + 0] - dw_last;
+                const float dal = dwe * Ts - suffix / (1.0f - al + 1e-10f);
+                suffix = fmaf(dwe, al * Ts, suffix);
+                ws[s * kCbStride + 7] = dal * ws[s * kCbStride + 3];
+            }
+        }
+        __syncthreads();
+        if (active) {
+            float drgb[3] = {0.f, 0.f, 0.f};
+            if (a.d_rgbmap) { drgb[0] = a.d_rgbmap[ray * 3]; drgb[1] = a.d_rgbmap[ray * 3 + 1]; drgb[2] = a.d_rgbmap[ray * 3 + 2]; }
+            for (int s = lane; s < S; s += kWave) {
+                const long long gpt = ray * S + s;
+                const float w = a.weights[gpt];
+                a.d_sdf_pts[gpt] = ws[s * kCbStride + 7] + (a.d_sdf_in ? a.d_sdf_in[gpt] : 0.0f);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float sc = sigmoid_f32(ws[s * kCbStride + 4 + c]);
+                    a.d_rgb_pts[gpt * 3 + c] = 2.0f * drgb[c] * w * sc * (1.0f - sc);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // fold the per-(workgroup, wave) partial sums: dfilm[b][l][gb][n] = sum over the image's slices, fixed order
 __global__ void __launch_bounds__(256)
 bwd_reduce_kernel(float* __restrict__ dfilm, const float* __restrict__ partials, int wgs_per_img) {
@@ -300,16 +442,14 @@ extern "C" int64_t e3dge_siren_bwd_partial_floats(int batch, int64_t n_pts) {
     return (int64_t)batch * wpi * 4 * (9 * 2 * kWidth);
 }
 
-extern "C" int e3dge_siren_bwd(const float* packed, const float* film, const float* args, const float* d_feat,
-                               const float* d_rgb, const float* d_sdf, const float* wg, const float* wb,
-                               int batch, int64_t n_pts, float* partials, float* dfilm, float* dstyles,
-                               e3dge_stream_t stream) {
-    E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "siren_bwd: bad sizes");
-    if (batch == 0) return E3DGE_OK;
-    E3DGE_REQUIRE(packed && film && args && wg && wb && partials && dfilm && dstyles, "siren_bwd: null pointer");
-    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(args) | reinterpret_cast<uintptr_t>(d_feat)) & 15) == 0,
+static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfilm, float* dstyles, hipStream_t st) {
+    const int batch = k.batch;
+    const int64_t n_pts = k.n_pts;
+    E3DGE_REQUIRE(k.packed && k.film && k.args && wg && wb && k.partials && dfilm && dstyles, "siren_bwd: null pointer");
+    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(k.packed) | reinterpret_cast<uintptr_t>(k.args) | reinterpret_cast<uintptr_t>(k.d_feat) |
+                    reinterpret_cast<uintptr_t>(k.d_featmap)) & 15) == 0,
                   "siren_bwd: packed/args/d_feat must be 16-B aligned");
-    hipStream_t st = as_stream(stream);
+    float* const partials = k.partials;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&siren_bwd_kernel),
@@ -317,9 +457,6 @@ extern "C" int e3dge_siren_bwd(const float* packed, const float* film, const flo
         if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(siren_bwd): %s", hipGetErrorString(e));
         attr_done = true;
     }
-    SirenBwdK k{};
-    k.packed = packed; k.film = film; k.args = args; k.d_feat = d_feat; k.d_rgb = d_rgb; k.d_sdf = d_sdf;
-    k.partials = partials; k.n_pts = n_pts; k.batch = batch;
     bwd_geometry(batch, n_pts, &k.subtiles_per_wg, &k.wgs_per_img);
     if (n_pts > 0) {
         const int64_t grid = (int64_t)k.wgs_per_img * batch;
@@ -333,4 +470,55 @@ extern "C" int e3dge_siren_bwd(const float* packed, const float* film, const flo
     if (rc) return rc;
     film_bwd_kernel<<<dim3((unsigned)(batch * 9)), dim3(256), 0, st>>>(dstyles, dfilm, wg, wb);
     return check_launch("siren_bwd(film)");
+}
+
+extern "C" int e3dge_siren_bwd(const float* packed, const float* film, const float* args, const float* d_feat,
+                               const float* d_rgb, const float* d_sdf, const float* wg, const float* wb,
+                               int batch, int64_t n_pts, float* partials, float* dfilm, float* dstyles,
+                               e3dge_stream_t stream) {
+    E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "siren_bwd: bad sizes");
+    if (batch == 0) return E3DGE_OK;
+    SirenBwdK k{};
+    k.packed = packed; k.film = film; k.args = args; k.d_feat = d_feat; k.d_rgb = d_rgb; k.d_sdf = d_sdf;
+    k.partials = partials; k.n_pts = n_pts; k.batch = batch; k.samples = 1;
+    return launch_bwd(k, wg, wb, dfilm, dstyles, as_stream(stream));
+}
+
+extern "C" int e3dge_siren_render_bwd(const E3dgeRenderBwdArgs* r, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(r != nullptr, "siren_render_bwd: null args");
+    E3DGE_REQUIRE(r->batch >= 0 && r->height > 0 && r->width > 0, "siren_render_bwd: bad image extent");
+    if (r->batch == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(r->n_samples >= 1 && r->n_samples <= 1024, "siren_render_bwd: n_samples=%d outside [1, 1024]", r->n_samples);
+    E3DGE_REQUIRE(r->packed && r->film && r->args && r->sdf && r->dists && r->points && r->weights && r->t_vals &&
+                  r->near && r->far && r->d_rgb_pts && r->d_sdf_pts, "siren_render_bwd: null pointer");
+    E3DGE_REQUIRE(r->sigmoid_beta != 0.0f, "siren_render_bwd: sigmoid_beta must be non-zero");
+    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(r->d_feat_map) | reinterpret_cast<uintptr_t>(r->args)) & 15) == 0,
+                  "siren_render_bwd: args/d_feat_map must be 16-B aligned");
+    hipStream_t st = as_stream(stream);
+    const int64_t HW = (int64_t)r->height * r->width;
+    CompositeBwdK c{};
+    c.packed = r->packed; c.args = r->args; c.sdf = r->sdf; c.dists = r->dists; c.points = r->points; c.weights = r->weights;
+    c.t_vals = r->t_vals; c.near = r->near; c.far = r->far;
+    c.d_rgbmap = r->d_rgb_map; c.d_featmap = r->d_feat_map; c.d_xyzmap = r->d_xyz_map; c.d_depthmap = r->d_depth_map;
+    c.d_sdf_in = r->d_sdf; c.d_rgb_pts = r->d_rgb_pts; c.d_sdf_pts = r->d_sdf_pts;
+    c.sigmoid_beta = r->sigmoid_beta; c.S = r->n_samples; c.force_bg = r->force_background;
+    c.n_rays = HW * r->batch; c.rays_per_img = HW;
+    const size_t lds = (size_t)4 * r->n_samples * kCbStride * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 1024 * kCbStride * 4);
+        if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(composite_bwd): %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    int64_t grid = (c.n_rays + 3) / 4;
+    if (grid > 256 * 16) grid = 256 * 16;
+    composite_bwd_kernel<<<dim3((unsigned)grid), dim3(kThreads), lds, st>>>(c);
+    int rc = check_launch("siren_render_bwd(composite)");
+    if (rc) return rc;
+    SirenBwdK k{};
+    k.packed = r->packed; k.film = r->film; k.args = r->args; k.d_feat = nullptr; k.d_rgb = r->d_rgb_pts; k.d_sdf = r->d_sdf_pts;
+    k.d_featmap = r->d_feat_map; k.weights = r->weights; k.samples = r->n_samples;
+    k.partials = r->partials; k.n_pts = HW * r->n_samples; k.batch = r->batch;
+    return launch_bwd(k, r->wg, r->wb, r->dfilm, r->dstyles, st);
 }

@@ -278,6 +278,73 @@ class _PointsQuery(torch.autograd.Function):
         return dstyles, None, None, None, None, None
 
 
+_DIFF_KEYS = ('gen_thumb_imgs', 'features', 'xyz', 'depth', 'sdf')
+_AUX_KEYS = ('mask', 'hit_prob', 'points', 'rays_d', 'viewdirs', 'dists')
+
+
+class _RenderQuery(torch.autograd.Function):
+    """VolumeFeatureRenderer.render with a gradient path from (rgb, features, xyz, depth, sdf) to the styles:
+    e3dge_siren_render_fwd with saved pre-sine arguments, e3dge_siren_render_bwd for the way back."""
+
+    @staticmethod
+    def differentiable(renderer, styles, focal, c2w, near, far):
+        vals = _RenderQuery.apply(styles, renderer, focal, c2w, near, far)
+        out = dict(renderer._last_render)          # non-tensor / view entries of the forward's dict
+        renderer._last_render = None
+        for k, v in zip(_DIFF_KEYS + _AUX_KEYS, vals):
+            out[k] = v
+        return out
+
+    @staticmethod
+    def forward(ctx, styles, renderer, focal, c2w, near, far):
+        B, H, S = c2w.shape[0], renderer.out_im_res, renderer.N_samples
+        film = renderer.siren.film_params(styles)
+        args = torch.empty((B, H * H * S, 9, renderer.siren.W), device=c2w.device, dtype=torch.float32)
+        out = renderer.render_with_film(film, focal, c2w, near, far, None, save_args=args)
+        renderer._last_render = out
+        ctx.renderer, ctx.styles_ndim = renderer, styles.ndim
+        ctx.sigmoid_beta = renderer._sigmoid_beta_value()
+        ctx.save_for_backward(film, args, out['sdf'], out['dists'], out['points'], out['hit_prob'],
+                              near.reshape(B).contiguous().float(), far.reshape(B).contiguous().float())
+        aux = tuple(out[k] for k in _AUX_KEYS)
+        ctx.mark_non_differentiable(*aux)
+        return tuple(out[k] for k in _DIFF_KEYS) + aux
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_feat, d_xyz, d_depth, d_sdf, *unused):
+        film, args, sdf, dists, points, weights, near, far = ctx.saved_tensors
+        r = ctx.renderer
+        siren = r.siren
+        B, H, S = film.shape[0], r.out_im_res, r.N_samples
+        dev = film.device
+        rows = lambda t, c: None if t is None else t.reshape(B, c, H * H).transpose(1, 2).contiguous().float()
+        d_rgb_map, d_feat_map, d_xyz_map = rows(d_rgb, 3), rows(d_feat, siren.W), rows(d_xyz, 3)
+        d_depth_map = None if d_depth is None else d_depth.reshape(B, H * H).contiguous().float()
+        d_sdf_in = None if d_sdf is None else d_sdf.reshape(B, H * H * S).contiguous().float()
+        packed, wg, _, wb, _ = siren.device_image()
+        lib = _lib.load()
+        n_pts = H * H * S
+        partials = torch.zeros(max(lib.e3dge_siren_bwd_partial_floats(B, n_pts), 1), device=dev, dtype=torch.float32)
+        d_rgb_pts = torch.empty((B, n_pts, 3), device=dev, dtype=torch.float32)
+        d_sdf_pts = torch.empty((B, n_pts), device=dev, dtype=torch.float32)
+        dfilm = torch.empty((B, 9, 2, siren.W), device=dev, dtype=torch.float32)
+        dstyles = torch.empty((B, 9, siren.W), device=dev, dtype=torch.float32)
+        a = _lib.RenderBwdArgs(
+            packed=_lib.ptr(packed), film=_lib.ptr(film), args=_lib.ptr(args), sdf=_lib.ptr(sdf), dists=_lib.ptr(dists),
+            points=_lib.ptr(points), weights=_lib.ptr(weights), t_vals=_lib.ptr(r.t_vals), near=_lib.ptr(near),
+            far=_lib.ptr(far), wg=_lib.ptr(wg), wb=_lib.ptr(wb), d_rgb_map=_lib.ptr(d_rgb_map),
+            d_feat_map=_lib.ptr(d_feat_map), d_xyz_map=_lib.ptr(d_xyz_map), d_depth_map=_lib.ptr(d_depth_map),
+            d_sdf=_lib.ptr(d_sdf_in), sigmoid_beta=ctx.sigmoid_beta, batch=B, height=H, width=H, n_samples=S,
+            force_background=int(bool(r.force_background)), d_rgb_pts=_lib.ptr(d_rgb_pts), d_sdf_pts=_lib.ptr(d_sdf_pts),
+            partials=_lib.ptr(partials), dfilm=_lib.ptr(dfilm), dstyles=_lib.ptr(dstyles))
+        with torch.cuda.device(dev):
+            rc = lib.e3dge_siren_render_bwd(ctypes.byref(a), _lib.stream_of(film))
+        _lib.check(rc, "e3dge_siren_render_bwd")
+        if ctx.styles_ndim == 2:
+            dstyles = dstyles.sum(1)
+        return dstyles, None, None, None, None, None
+
+
 class SirenLocalGlobal(nn.Module):
     """Holder that keeps the `network.netGlobal.*` checkpoint keys of the reference's local+global wrapper
     (:267-558).  The PIFu local branch itself (netLocal) is outside this build; its OUTPUT --
@@ -403,10 +470,15 @@ class VolumeFeatureRenderer(nn.Module):
         if not self.test and (self.perturb or self.raw_noise_std):
             raise NotImplementedError("stratified perturbation / raw noise (train-mode sampling) is not covered by "
                                       "the fused kernel; construct with mode='test' or perturb=0")
+        if torch.is_grad_enabled() and styles.requires_grad and c2w.shape[0]:
+            if tex_conditions is not None:
+                raise NotImplementedError("the HIP backward covers the global (first) renderer pass; the tex-FiLM pass "
+                                          "runs under no_grad in stage-1 training")
+            return _RenderQuery.differentiable(self, styles, focal, c2w, near, far)
         film = self.siren.film_params(styles)
         return self.render_with_film(film, focal, c2w, near, far, tex_conditions)
 
-    def render_with_film(self, film, focal, c2w, near, far, tex_conditions=None):
+    def render_with_film(self, film, focal, c2w, near, far, tex_conditions=None, save_args=None):
         """The single fused launch (e3dge_siren_render_fwd) given precomputed FiLM parameters (B,9,2,256)."""
         B = c2w.shape[0]
         H = Wd = self.out_im_res
@@ -443,7 +515,7 @@ class VolumeFeatureRenderer(nn.Module):
             rgb=_lib.ptr(out['rgb']), features=_lib.ptr(out['features']), xyz=_lib.ptr(out['xyz']),
             depth=_lib.ptr(out['depth']), mask=_lib.ptr(out['mask']), sdf=_lib.ptr(out['sdf']),
             weights=_lib.ptr(out['weights']), points=_lib.ptr(out['points']), rays_d=_lib.ptr(out['rays_d']),
-            viewdirs=_lib.ptr(out['viewdirs']), dists=_lib.ptr(out['dists']))
+            viewdirs=_lib.ptr(out['viewdirs']), dists=_lib.ptr(out['dists']), save_args=_lib.ptr(save_args))
         with torch.cuda.device(dev):
             rc = _lib.load().e3dge_siren_render_fwd(ctypes.byref(args), _lib.stream_of(c2w))
         _lib.check(rc, "e3dge_siren_render_fwd")
@@ -471,14 +543,12 @@ class VolumeFeatureRenderer(nn.Module):
                 return_surface_eikonal=False, local_data_batch=None, sample_mode=False, return_mesh=False,
                 mesh_with_shading=True, return_sdf_only=False, **kwargs):
         if return_eikonal or return_surface_eikonal:
-            raise NotImplementedError("eikonal terms need the backward kernels (SURVEY.md 7 step 5); not in this build")
+            raise NotImplementedError("eikonal terms (d sdf / d x, double backward) are not covered by the HIP backward; "
+                                      "the gradient path to the styles is")
         if sample_mode:
             raise NotImplementedError("sample_mode (near-surface / uniform-grid sampling) is not in this build")
         if return_mesh:
             raise NotImplementedError("marching-cubes mesh extraction is out of scope (SURVEY.md 2 #13)")
-        if torch.is_grad_enabled() and isinstance(styles, torch.Tensor) and styles.requires_grad:
-            raise NotImplementedError("backward through the fused renderer is not in this build; wrap the call in "
-                                      "torch.no_grad() (the reference's test path runs under inference_mode)")
         self.sample_mode = False
         tex = None
         if self.enable_local_model and local_data_batch is not None:

@@ -204,6 +204,25 @@ int e3dge_siren_bwd(const float* packed, const float* film, const float* args, c
                     const float* d_rgb, const float* d_sdf, const float* wg, const float* wb,
                     int batch, int64_t n_pts, float* partials, float* dfilm, float* dstyles, e3dge_stream_t stream);
 
+/* Backward of e3dge_siren_render_fwd: volume_integration (volume_renderer.py:809-943) back to the per-point outputs
+ * (one wave per ray), then the MLP chain above.  Gradient maps are ROW-MAJOR PER RAY (ray = (b*H + y)*W + x):
+ *   d_rgb_map (rays,3)  d_feat_map (rays,256)  d_xyz_map (rays,3)  d_depth_map (rays)  d_sdf (rays,S); any may be NULL.
+ * args/sdf/dists/points/weights are the forward launch's outputs (save_args, sdf, dists, points, weights).
+ * d_rgb_pts (rays,S,3) and d_sdf_pts (rays,S) are scratch the caller provides; partials as for e3dge_siren_bwd with
+ * n_pts = H*W*S, zeroed.  sigmoid_beta and the generator weights get no gradient (frozen in encoder training). */
+typedef struct E3dgeRenderBwdArgs {
+    const float* packed; const float* film; const float* args; const float* sdf; const float* dists;
+    const float* points; const float* weights; const float* t_vals; const float* near; const float* far;
+    const float* wg; const float* wb;
+    const float* d_rgb_map; const float* d_feat_map; const float* d_xyz_map; const float* d_depth_map; const float* d_sdf;
+    float sigmoid_beta;
+    int batch, height, width, n_samples, force_background;
+    float* d_rgb_pts; float* d_sdf_pts; float* partials;
+    float* dfilm; float* dstyles;
+} E3dgeRenderBwdArgs;
+int e3dge_siren_render_bwd(const E3dgeRenderBwdArgs* args, e3dge_stream_t stream);
+
+
 
 /* Layout self-test: runs a 32x32xK fp32-MFMA product with the fragment conventions the render kernel
  * relies on and writes it to c (32*32 floats, row-major) for the caller to compare with a @ b^T.

@@ -3,7 +3,8 @@ generator frozen :1568) through e3dge_siren_bwd, against torch autograd of the o
 
 The comparison value is autograd of the restatement in float64 ("truth"); autograd of the same restatement in fp32 is
 what the reference itself computes.  Stated fp32 tolerance: max|d - truth| <= 5e-5 * max|truth| (measured 5-6e-6, the fp32 oracle itself 5-7e-6) per tensor, and no
-worse than 4x the fp32 oracle's own distance to the truth (+ a floor of 2e-5 * max|truth|)."""
+worse than 4x the fp32 oracle's own distance to the truth (+ a floor of 2e-5 * max|truth|).  Render-level gradients
+whose fp32 autograd is itself further than 5e-5 from the truth are bounded by 2x that distance instead."""
 import numpy as np
 import pytest
 import torch
@@ -114,3 +115,61 @@ def test_dfilm_and_determinism(sd):
     x = pts[0, 0].double().cpu() / 0.12
     want = f[0, 0, 0] * (w0 @ x + b0) + f[0, 0, 1]
     assert float((a0 - want).abs().max()) <= 2e-5
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# render level: volume_integration backward + the MLP chain (e3dge_siren_render_bwd)
+# ----------------------------------------------------------------------------------------------------------------
+RENDER_KEYS = ('gen_thumb_imgs', 'features', 'xyz', 'depth', 'sdf')
+
+
+def render_loss(out, G):
+    return sum((out[k] * G[k]).sum() for k in G)
+
+
+def oracle_render_grads(sd, cams, styles, G, res, S, dtype):
+    cpu = lambda t: t.detach().cpu()
+    s = cpu(styles).to(dtype).requires_grad_(True)
+    out = renderer_ref.render(sd, *[cpu(c) for c in cams], s, res=res, n_samples=S, dtype=dtype)
+    render_loss(out, {k: cpu(v).to(dtype) for k, v in G.items()}).backward()
+    return s.grad
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f32"])
+@pytest.mark.parametrize("res,S,batch,keys", [
+    (8, 18, 2, RENDER_KEYS), (16, 24, 1, RENDER_KEYS), (16, 24, 1, ('gen_thumb_imgs',)), (16, 24, 1, ('features',)),
+    (16, 24, 1, ('xyz', 'depth')), (16, 24, 1, ('sdf',)), (32, 24, 1, RENDER_KEYS)])
+def test_render_backward_vs_oracle_autograd(sd, mode, res, S, batch, keys):
+    from e3dge_amd.camera_utils import generate_camera_params
+    r = make_renderer(sd, res, S, mfma_mode=mode)
+    wr, _ = syn.synthetic_inputs(batch, seed=res + S, device=DEV)
+    loc = torch.tensor([[0.3, -0.1], [-0.2, 0.15]], device=DEV)[:batch]
+    poses, focal, near, far, _ = generate_camera_params(res, DEV, batch=batch, locations=loc)
+    styles = wr.clone().requires_grad_(True)
+    out = r(poses, focal, near, far, styles=styles)
+    gen = torch.Generator().manual_seed(res * 100 + S)
+    G = {k: torch.randn(out[k].shape, generator=gen).to(DEV) for k in keys}
+    render_loss(out, G).backward()
+    cams = (poses, focal, near, far)
+    truth = oracle_render_grads(sd, cams, wr, G, res, S, torch.float64)
+    ref32 = oracle_render_grads(sd, cams, wr, G, res, S, torch.float32)
+    e, e32 = rel_err(styles.grad, truth), rel_err(ref32, truth)
+    record(f"render_bwd_{mode}_{res}x{res}x{S}_b{batch}_{'+'.join(keys)}", rel_err_vs_f64=e, oracle_fp32_rel_err_vs_f64=e32)
+    # compositing makes some of these gradients ill-conditioned (rgb alone: the fp32 oracle is itself 6e-5 from the
+    # truth); the bound follows the reference's own fp32 distance there
+    assert e <= max(REL_TOL, 2 * e32), (e, e32)
+    assert e <= 4 * e32 + 2e-5, (e, e32)
+
+
+def test_render_forward_values_unchanged_by_training_mode(sd):
+    """The saving launch returns bit-identical outputs to the inference launch."""
+    from e3dge_amd.camera_utils import generate_camera_params
+    r = make_renderer(sd, 16, 24)
+    wr, _ = syn.synthetic_inputs(1, seed=2, device=DEV)
+    poses, focal, near, far, _ = generate_camera_params(16, DEV, locations=torch.zeros(1, 2, device=DEV))
+    with torch.no_grad():
+        a = r(poses, focal, near, far, styles=wr)
+    b = r(poses, focal, near, far, styles=wr.clone().requires_grad_(True))
+    for k in RENDER_KEYS + ('hit_prob', 'mask', 'points'):
+        assert torch.equal(a[k], b[k].detach()), k
+    assert b['features'].requires_grad and not b['mask'].requires_grad
