@@ -26,7 +26,7 @@ struct SirenBwdK {
     const float* d_featmap;  // (batch * rays, 256) or null
     const float* weights;    // (batch, n_pts) compositing weights of the forward launch
     int samples;             // points per ray
-    float* partials;         // (grid, 4, 9, 2, 256), zero-initialised by the caller
+    float* partials;         // (grid, 9, 2, 256): every workgroup writes its whole slice
     long long n_pts;
     int batch, subtiles_per_wg, wgs_per_img;
 };
@@ -34,31 +34,31 @@ struct SirenBwdK {
 constexpr int kBwdLdsW = 0;
 constexpr int kBwdLdsFilm = kBwdLdsW + kNBuf * kChunkFloats;     // [9][3][256] gamma, beta, 1/gamma
 constexpr int kBwdLdsHead = kBwdLdsFilm + 9 * 3 * kWidth;        // w_sigma[256], w_rgb[3][256]
-constexpr int kBwdLdsFloats = kBwdLdsHead + 4 * kWidth;
+constexpr int kBwdLdsAcc = kBwdLdsHead + 4 * kWidth;              // [9][2][256] this workgroup's d(gamma), d(beta)
+constexpr int kBwdLdsSlot = kBwdLdsAcc + 9 * 2 * kWidth;          // [2 parity][4 waves][2][32] per-tile wave sums
+constexpr int kBwdLdsFloats = kBwdLdsSlot + 2 * 4 * 2 * 32;
 constexpr int kBwdLdsBytes = kBwdLdsFloats * 4;
 
-// sum of v over the 32 lanes of a half for 8 per-lane values: afterwards lanes with (col & 3) == 0 hold the total of
-// value index 4*b4 + 2*b3 + b2 (b_i = bit i of col).  4+2+1+1+1 shuffles.
-__device__ __forceinline__ float reduce8_over_lanes(const float (&v)[8], int col) {
-    const bool b4 = col & 16, b3 = col & 8, b2 = col & 4;
-    float q4[4], q2[2], q1;
+// Sum over the 32 lanes of a half for 8 per-lane values, entirely in the VALU (no LDS round trips: one wave per SIMD,
+// so any lgkmcnt stall would idle the MFMA pipe).  v_permlane16_swap exchanges the odd 16-lane rows of one register
+// with the even rows of another, so x[i] + x[4+i] after the swap is the two-row sum of value i in even rows and of
+// value 4+i in odd rows; four DPP row rotations finish the 16 lanes.  Result: q[i] (i < 4) on every lane = total of
+// value i (lanes 0-15 of the half) or value 4+i (lanes 16-31).
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void reduce8_over_lanes(const float (&v)[8], float (&q)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float keep = b4 ? v[4 + i] : v[i], send = b4 ? v[i] : v[4 + i];
-        q4[i] = keep + __shfl_xor(send, 16, kWave);
+        float lo = v[i], hi = v[4 + i];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+        float x = lo + hi;
+        x += dpp_f32<0x128>(x);    // row_ror:8
+        x += dpp_f32<0x124>(x);    // row_ror:4
+        x += dpp_f32<0x122>(x);    // row_ror:2
+        x += dpp_f32<0x121>(x);    // row_ror:1
+        q[i] = x;
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float keep = b3 ? q4[2 + i] : q4[i], send = b3 ? q4[i] : q4[2 + i];
-        q2[i] = keep + __shfl_xor(send, 8, kWave);
-    }
-    {
-        const float keep = b2 ? q2[1] : q2[0], send = b2 ? q2[0] : q2[1];
-        q1 = keep + __shfl_xor(send, 4, kWave);
-    }
-    q1 += __shfl_xor(q1, 2, kWave);
-    q1 += __shfl_xor(q1, 1, kWave);
-    return q1;
 }
 
 __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) {
@@ -86,7 +86,22 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
         film_s[(l * 3 + 2) * kWidth + n] = 1.0f / g;
     }
     for (int i = tid; i < 4 * kWidth; i += kThreads) head_s[i] = packed[kOffWSigma + i];
-    float* const my_partial = a.partials + ((int64_t)blockIdx.x * 4 + wave) * (9 * 2 * kWidth);
+    float* const acc_s = smem + kBwdLdsAcc;
+    float* const slot_s = smem + kBwdLdsSlot;
+    for (int i = tid; i < 9 * 2 * kWidth; i += kThreads) acc_s[i] = 0.0f;
+    // d(gamma), d(beta) are sums over points.  Global atomics would sit in vmcnt and stall every weight-chunk wait, so:
+    // each wave leaves its 32-lane sums of a tile in its LDS slot; after the next workgroup barrier (every weight chunk
+    // has one) the four slots are added in fixed order into the workgroup accumulator -- deterministic, LDS only.
+    int pend_layer = -1, pend_t = 0, pend_par = 0, par = 0;
+    auto fold_pending = [&]() {
+        if (pend_layer >= 0 && lane < 16) {
+            const int v = wave * 16 + lane, gb = v >> 5, nl = v & 31;
+            const float* sp = slot_s + pend_par * 256 + gb * 32 + nl;
+            const float sum = ((sp[0] + sp[64]) + sp[128]) + sp[192];
+            acc_s[(pend_layer * 2 + gb) * kWidth + 32 * pend_t + nl] += sum;
+        }
+        pend_layer = -1;
+    };
 
     // ---- weight chunk pipeline: identical protocol to the forward kernel, transposed image ----
     const int total_chunks = n_sub * kChunksPerPass;
@@ -146,19 +161,26 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
 
         // per-tile reduction of d(beta) += da, d(gamma) += da * u over this wave's 32 points, layer `layer`, tile `t`
         auto reduce_tile = [&](int layer, int t, const float (&rb)[16], const float (&rg)[16]) {
+            fold_pending();                                            // previous tile: a barrier has passed since
+            float* const my_slot = slot_s + par * 256 + wave * 64;
 #pragma unroll
             for (int h8 = 0; h8 < 2; ++h8) {
-                float vb[8], vg[8];
+                float vb[8], vg[8], qb[4], qg[4];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { vb[i] = rb[8 * h8 + i]; vg[i] = rg[8 * h8 + i]; }
-                const float sb = reduce8_over_lanes(vb, col), sg = reduce8_over_lanes(vg, col);
-                if ((col & 3) == 0) {
-                    const int r = 8 * h8 + (col >> 2);                 // 4*b4 + 2*b3 + b2
-                    const int n = 32 * t + row_of(r, half);
-                    atomicAdd(my_partial + (layer * 2 + 0) * kWidth + n, sg);
-                    atomicAdd(my_partial + (layer * 2 + 1) * kWidth + n, sb);
+                reduce8_over_lanes(vb, qb);
+                reduce8_over_lanes(vg, qg);
+                // lanes 0-3 of each 16-lane row publish value (col & 3) [+4 in the odd row]
+                const int i = col & 3;
+                const float sb = i == 0 ? qb[0] : i == 1 ? qb[1] : i == 2 ? qb[2] : qb[3];
+                const float sg = i == 0 ? qg[0] : i == 1 ? qg[1] : i == 2 ? qg[2] : qg[3];
+                if ((col & 15) < 4) {
+                    const int nl = row_of(8 * h8 + 4 * (col >> 4) + i, half);
+                    my_slot[nl] = sg;
+                    my_slot[32 + nl] = sb;
                 }
             }
+            pend_layer = layer; pend_t = t; pend_par = par; par ^= 1;
         };
 
         // =====================================================================================
@@ -195,6 +217,7 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                         in[t][4 * q + j] = g4[j] * da;
                     }
                 }
+                __syncthreads();                                       // no weight-chunk barrier between these tiles
                 reduce_tile(8, t, rb, rg);
             }
         }
@@ -231,15 +254,20 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
             };
 #pragma unroll
             for (int t = 0; t < kNT; ++t) {
-                // arguments of tile t (consumed one tile later): issued before this tile's DMA pieces
+                // Saved arguments of tile t are consumed one tile later.  They come from HBM (cold stream), so they are
+                // issued right AFTER this tile's weight-chunk wait -- the vmcnt(0) of the next tile's wait, a whole
+                // tile of MFMAs later, is what retires them; issued before it they would stall the wait itself.
+                auto sync_and_fetch = [&]() {
+                    chunk_sync();
+                    if (t > 0) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) argb[t & 1][q] = *reinterpret_cast<const f32x4*>(apl + 32 * t + 8 * q + 4 * half);
-                if (t > 0) {
+                        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(argb[(t - 1) & 1][q]));
+                    }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(argb[(t - 1) & 1][q]));   // retire its wait before any new DMA
-                }
+                    for (int q = 0; q < 4; ++q) argb[t & 1][q] = *reinterpret_cast<const f32x4*>(apl + 32 * t + 8 * q + 4 * half);
+                };
                 f32x16 acc = zero16();
-                acc = big_tile<false, 0>(wcur, wnxt, lane, in, acc, ring, NoEpilogue(), chunk_sync, issue_piece);
+                acc = big_tile<false, 0>(wcur, wnxt, lane, in, acc, ring, NoEpilogue(), sync_and_fetch, issue_piece);
                 advance_chunk();
                 if (t > 0) {
                     epilogue(t - 1, prev, argb[(t - 1) & 1], out[t - 1]);
@@ -249,6 +277,7 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(argb[(kNT - 1) & 1][q]));
+            __syncthreads();       // the last two epilogues of a layer have no weight-chunk barrier between them
             epilogue(kNT - 1, prev, argb[(kNT - 1) & 1], out[kNT - 1]);
 #pragma unroll
             for (int tt = 0; tt < kNT; ++tt) {
@@ -258,6 +287,11 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    fold_pending();
+    __syncthreads();
+    float* const my_partial = a.partials + (int64_t)blockIdx.x * (9 * 2 * kWidth);
+    for (int i = tid; i < 9 * 2 * kWidth; i += kThreads) my_partial[i] = acc_s[i];
 }
 
 
@@ -393,15 +427,27 @@ __global__ void __launch_bounds__(kThreads) composite_bwd_kernel(const Composite
     }
 }
 
-// fold the per-(workgroup, wave) partial sums: dfilm[b][l][gb][n] = sum over the image's slices, fixed order
-__global__ void __launch_bounds__(256)
+// fold the per-workgroup partial sums: dfilm[b][l][gb][n] = sum over the image's slices.  64 elements x 16
+// slice groups per block; fixed association order -> bit-reproducible.
+constexpr int kRedGroups = 16;
+__global__ void __launch_bounds__(64 * kRedGroups)
 bwd_reduce_kernel(float* __restrict__ dfilm, const float* __restrict__ partials, int wgs_per_img) {
+    __shared__ float part[kRedGroups][64];
     const int b = blockIdx.y;
-    const int e = blockIdx.x * 256 + threadIdx.x;                    // < 9*2*256
+    const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;                               // < 9*2*256
+    const int n_slices = wgs_per_img;
+    const float* p = partials + (int64_t)b * n_slices * (9 * 2 * kWidth) + e;
     float acc = 0.0f;
-    const float* p = partials + (int64_t)b * wgs_per_img * 4 * (9 * 2 * kWidth) + e;
-    for (int s = 0; s < wgs_per_img * 4; ++s) acc += p[(int64_t)s * (9 * 2 * kWidth)];
-    dfilm[(int64_t)b * 9 * 2 * kWidth + e] = acc;
+    for (int s = g; s < n_slices; s += kRedGroups) acc += p[(int64_t)s * (9 * 2 * kWidth)];
+    part[g][el] = acc;
+    __syncthreads();
+    if (g == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kRedGroups; ++i) t += part[i][el];
+        dfilm[(int64_t)b * 9 * 2 * kWidth + e] = t;
+    }
 }
 
 // d(styles)[b][l][k] = 15 * sum_n Wg_l[n][k] dgamma[b][l][n] + 0.25 * sum_n Wb_l[n][k] dbeta[b][l][n]
@@ -439,7 +485,7 @@ extern "C" int64_t e3dge_siren_bwd_partial_floats(int batch, int64_t n_pts) {
     if (batch <= 0 || n_pts <= 0) return 0;
     int spw, wpi;
     bwd_geometry(batch, n_pts, &spw, &wpi);
-    return (int64_t)batch * wpi * 4 * (9 * 2 * kWidth);
+    return (int64_t)batch * wpi * (9 * 2 * kWidth);
 }
 
 static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfilm, float* dstyles, hipStream_t st) {
@@ -465,7 +511,7 @@ static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfil
         int rc = check_launch("siren_bwd");
         if (rc) return rc;
     }
-    bwd_reduce_kernel<<<dim3(9 * 2 * kWidth / 256, (unsigned)batch), dim3(256), 0, st>>>(dfilm, partials, n_pts > 0 ? k.wgs_per_img : 0);
+    bwd_reduce_kernel<<<dim3(9 * 2 * kWidth / 64, (unsigned)batch), dim3(64 * kRedGroups), 0, st>>>(dfilm, partials, n_pts > 0 ? k.wgs_per_img : 0);
     int rc = check_launch("siren_bwd(reduce)");
     if (rc) return rc;
     film_bwd_kernel<<<dim3((unsigned)(batch * 9)), dim3(256), 0, st>>>(dstyles, dfilm, wg, wb);

@@ -239,7 +239,7 @@ def siren_backward(siren, film, args, d_feat, d_rgb, d_sdf):
     lib = _lib.load()
     d_feat, d_rgb, d_sdf = [None if t is None else t.contiguous().float() for t in (d_feat, d_rgb, d_sdf)]
     n_part = lib.e3dge_siren_bwd_partial_floats(B, N)
-    partials = torch.zeros(max(n_part, 1), device=dev, dtype=torch.float32)
+    partials = torch.empty(max(n_part, 1), device=dev, dtype=torch.float32)
     dfilm = torch.empty((B, 9, 2, siren.W), device=dev, dtype=torch.float32)
     dstyles = torch.empty((B, 9, siren.W), device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):
@@ -324,7 +324,7 @@ class _RenderQuery(torch.autograd.Function):
         packed, wg, _, wb, _ = siren.device_image()
         lib = _lib.load()
         n_pts = H * H * S
-        partials = torch.zeros(max(lib.e3dge_siren_bwd_partial_floats(B, n_pts), 1), device=dev, dtype=torch.float32)
+        partials = torch.empty(max(lib.e3dge_siren_bwd_partial_floats(B, n_pts), 1), device=dev, dtype=torch.float32)
         d_rgb_pts = torch.empty((B, n_pts, 3), device=dev, dtype=torch.float32)
         d_sdf_pts = torch.empty((B, n_pts), device=dev, dtype=torch.float32)
         dfilm = torch.empty((B, 9, 2, siren.W), device=dev, dtype=torch.float32)

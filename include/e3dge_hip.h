@@ -194,7 +194,7 @@ int e3dge_siren_points_fwd(const float* packed, const float* film, const float* 
  *   d_rgb    (batch, n_pts, 3)       dL/d(rgb head output, pre-sigmoid), or NULL
  *   d_sdf    (batch, n_pts)          dL/d(sdf head output), or NULL
  *   wg, wb   (9, 256, 256)           the gamma / beta style-linear weights as given to e3dge_film_params
- *   partials  e3dge_siren_bwd_partial_floats(batch, n_pts) floats of scratch, ZEROED by the caller
+ *   partials  e3dge_siren_bwd_partial_floats(batch, n_pts) floats of scratch (need not be initialised)
  *   dfilm    (batch, 9, 2, 256) out  dL/d(gamma, beta)
  *   dstyles  (batch, 9, 256)    out  dL/d(styles)
  * No tex-FiLM (second pass) support: that pass runs under no_grad in the reference's stage-1 training.
@@ -209,7 +209,7 @@ int e3dge_siren_bwd(const float* packed, const float* film, const float* args, c
  *   d_rgb_map (rays,3)  d_feat_map (rays,256)  d_xyz_map (rays,3)  d_depth_map (rays)  d_sdf (rays,S); any may be NULL.
  * args/sdf/dists/points/weights are the forward launch's outputs (save_args, sdf, dists, points, weights).
  * d_rgb_pts (rays,S,3) and d_sdf_pts (rays,S) are scratch the caller provides; partials as for e3dge_siren_bwd with
- * n_pts = H*W*S, zeroed.  sigmoid_beta and the generator weights get no gradient (frozen in encoder training). */
+ * n_pts = H*W*S.  sigmoid_beta and the generator weights get no gradient (frozen in encoder training). */
 typedef struct E3dgeRenderBwdArgs {
     const float* packed; const float* film; const float* args; const float* sdf; const float* dists;
     const float* points; const float* weights; const float* t_vals; const float* near; const float* far;

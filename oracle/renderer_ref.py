@@ -67,7 +67,7 @@ def siren_forward(sd, net_prefix, net_inputs, styles, tex=None):
 def get_rays(res, focal, c2w):
     """get_rays :769-794 with static_viewdirs.  focal (B,1,1), c2w (B,3,4) -> rays_o, rays_d, dirs (B,res,res,3)."""
     dt = c2w.dtype
-    lin = torch.linspace(0.5, res - 0.5, res, dtype=torch.float32).to(dt)   # :666-670 (built in fp32 there)
+    lin = torch.linspace(0.5, res - 0.5, res, dtype=torch.float32, device=c2w.device).to(dt)   # :666-670 (built in fp32 there)
     gi, gj = torch.meshgrid(lin, lin, indexing='ij')
     i = gi.t().unsqueeze(0)                                        # :672-674: i[r,c] = x of column c
     j = gj.t().unsqueeze(0)
@@ -110,7 +110,7 @@ def render(sd, c2w, focal, near, far, styles, res=64, n_samples=24, dist_radius=
     B = c2w.shape[0]
     rays_o, rays_d, dirs = get_rays(res, focal.reshape(B, 1, 1), c2w)
     viewdirs = dirs / torch.norm(dirs, dim=-1, keepdim=True)       # :1679
-    t_vals = torch.linspace(0., 1. - 1 / n_samples, steps=n_samples, dtype=torch.float32).to(dtype).reshape(1, 1, 1, -1)  # :690-693
+    t_vals = torch.linspace(0., 1. - 1 / n_samples, steps=n_samples, dtype=torch.float32, device=c2w.device).to(dtype).reshape(1, 1, 1, -1)  # :690-693
     nearb = near.reshape(B, 1, 1, 1) * torch.ones_like(rays_d[..., :1])
     farb = far.reshape(B, 1, 1, 1) * torch.ones_like(rays_d[..., :1])
     z_vals = nearb * (1. - t_vals) + farb * t_vals                 # :1211

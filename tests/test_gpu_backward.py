@@ -173,3 +173,47 @@ def test_render_forward_values_unchanged_by_training_mode(sd):
     for k in RENDER_KEYS + ('hit_prob', 'mask', 'points'):
         assert torch.equal(a[k], b[k].detach()), k
     assert b['features'].requires_grad and not b['mask'].requires_grad
+
+
+def test_generator_backward_end_to_end(sd):
+    """The encoder-training step's generator part (C5, trainer.py:666-742): W+ codes -> renderer -> decoder -> image,
+    plus the 3-D supervision re-query, loss.backward() down to both latents.  Renderer backward = HIP kernels,
+    decoder backward = autograd over the HIP ops' own backward functions + library convolutions."""
+    from e3dge_amd.camera_utils import generate_camera_params
+    from oracle import decoder_ref
+    g, gsd = full_state_dict(size=64, cm=1, res=16, n_samples=24)
+    g = g.to(DEV).eval()
+    for p in g.parameters():
+        p.requires_grad_(False)                                        # frozen generator (:1568)
+    wr0, wd0 = syn.synthetic_inputs(1, seed=4, device=DEV)
+    wd0 = wd0[:, :g.decoder.n_latent]
+    poses, focal, near, far, _ = generate_camera_params(16, DEV, locations=torch.tensor([[0.2, 0.1]], device=DEV))
+    rs = np.random.RandomState(1)
+    uni = torch.from_numpy((0.12 * rs.uniform(-1, 1, (1, 300, 1, 1, 3))).astype(np.float32)).to(DEV)
+    wr, wd = wr0.clone().requires_grad_(True), wd0.clone().requires_grad_(True)
+    out = g([wr, wd], poses, focal, near, far, input_is_latent=True, randomize_noise=False,
+            geometry_sample={'uniform_pts': uni})
+    gen = torch.Generator().manual_seed(0)
+    G_img = torch.randn(out['gen_imgs'].shape, generator=gen).to(DEV)
+    G_th = torch.randn(out['gen_thumb_imgs'].shape, generator=gen).to(DEV)
+    G_u = torch.randn(out['uniform_pts_rec'].shape, generator=gen).to(DEV)
+    ((out['gen_imgs'] * G_img).sum() + (out['gen_thumb_imgs'] * G_th).sum() + (out['uniform_pts_rec'] * G_u).sum()).backward()
+
+    def oracle(dtype):
+        cpu = lambda t: t.detach().cpu()
+        a, b = cpu(wr0).to(dtype).requires_grad_(True), cpu(wd0).to(dtype).requires_grad_(True)
+        ro = renderer_ref.render(gsd, cpu(poses), cpu(focal), cpu(near), cpu(far), a, res=16, n_samples=24, dtype=dtype)
+        img = decoder_ref.decoder_forward(gsd, ro['features'], b, dtype=dtype)
+        rec = renderer_ref.query_points(gsd, cpu(uni), None, a, dtype=dtype)[..., 3:4]
+        ((img * cpu(G_img).to(dtype)).sum() + (ro['gen_thumb_imgs'] * cpu(G_th).to(dtype)).sum()
+         + (rec * cpu(G_u).to(dtype)).sum()).backward()
+        return a.grad, b.grad, img
+    tr, td, img64 = oracle(torch.float64)
+    fr, fd, _ = oracle(torch.float32)
+    e = dict(d_renderer_latent=rel_err(wr.grad, tr), d_decoder_latent=rel_err(wd.grad, td),
+             oracle32_d_renderer_latent=rel_err(fr, tr), oracle32_d_decoder_latent=rel_err(fd, td),
+             img=float((out["gen_imgs"].detach().double().cpu() - img64.detach()).abs().max()))
+    record("generator_bwd_64", **e)
+    assert e['img'] <= 1e-4
+    assert e['d_renderer_latent'] <= max(REL_TOL, 3 * e['oracle32_d_renderer_latent']), e
+    assert e['d_decoder_latent'] <= max(REL_TOL, 3 * e['oracle32_d_decoder_latent']), e
