@@ -26,6 +26,9 @@ struct SirenBwdK {
     const float* d_featmap;  // (batch * rays, 256) or null
     const float* weights;    // (batch, n_pts) compositing weights of the forward launch
     int samples;             // points per ray
+    // second-order (eikonal) streams, both (batch, n_pts, 8, 256), or null
+    const float* tang;       // tangent arguments ta_l of the tangent kernel
+    const float* rsave;      // r_l = d sdf / d h_l of the sdf-chain kernel
     float* partials;         // (grid, 9, 2, 256): every workgroup writes its whole slice
     long long n_pts;
     int batch, subtiles_per_wg, wgs_per_img;
@@ -61,6 +64,75 @@ __device__ __forceinline__ void reduce8_over_lanes(const float (&v)[8], float (&
     }
 }
 
+// sin and cos of a saved argument with one shared range reduction
+__device__ __forceinline__ void sincos_hw_f32(float x, float& sn, float& cs) {
+    const float kf = rintf(x * 0.159154943091895336f);
+    float r = fmaf(-kf, 6.2831854820251465f, x);
+    r = fmaf(-kf, -1.7484555314695172e-07f, r);
+    r *= 0.159154943091895336f;
+    sn = __builtin_amdgcn_sinf(r);
+    cs = __builtin_amdgcn_cosf(r);
+}
+
+// The weight-chunk pipeline shared by the kernels of this file: 32 KiB chunks (one 32-row output tile x K=256) of a
+// fragment image stream L2 -> LDS through three buffers, eight 16-B LDS-DMA pieces per lane and chunk, issued from
+// inside the MFMA stream of the tile two chunks earlier.  Same protocol as the forward kernel (siren.hip).
+struct ChunkPipe {
+    float* wbuf;
+    const float* src_lane;
+    int wave_u, total, g_issue, idx, first, count, buf, use_buf;
+    const float* wcur;
+    const float* wnxt;
+    __device__ __forceinline__ void init(float* wbuf_, const float* image, int wave, int lane, int first_, int count_, int total_) {
+        wbuf = wbuf_;
+        wave_u = __builtin_amdgcn_readfirstlane(wave);
+        src_lane = image + wave_u * 2048 + lane * 4;
+        first = first_; count = count_; total = total_;
+        g_issue = 0; idx = first_; buf = 0; use_buf = 0;
+        wcur = wbuf_; wnxt = wbuf_ + kChunkFloats;
+    }
+    __device__ __forceinline__ void issue_piece(int i) {
+        if (g_issue < total) {
+            const float* src = src_lane + (int64_t)idx * kChunkFloats + (i >> 2) * 1024;
+            float* dst = wbuf + buf * kChunkFloats + wave_u * 2048 + (i >> 2) * 1024;
+            switch (i & 3) {
+                case 0: glds16_off<0>(src, dst); break;
+                case 1: glds16_off<1024>(src, dst); break;
+                case 2: glds16_off<2048>(src, dst); break;
+                default: glds16_off<3072>(src, dst); break;
+            }
+        }
+        if (i == 7) {
+            ++g_issue;
+            idx = (idx + 1 == first + count) ? first : idx + 1;
+            buf = (buf + 1 == kNBuf) ? 0 : buf + 1;
+        }
+    }
+    __device__ __forceinline__ void prime() {
+        for (int c = 0; c < kNBuf - 1; ++c)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) issue_piece(i);
+    }
+    __device__ __forceinline__ void sync() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    __device__ __forceinline__ void advance() {
+        use_buf = (use_buf + 1 == kNBuf) ? 0 : use_buf + 1;
+        wcur = wnxt;
+        wnxt = wbuf + ((use_buf + 1 == kNBuf) ? 0 : use_buf + 1) * kChunkFloats;
+    }
+};
+
+// EIK = false: gradient of a loss that reaches the network through (feat, rgb, sdf).
+// EIK = true : additionally the loss depends on the eikonal term e = d sdf / d x (get_eikonal_term :796-802, i.e. the
+//   reference's create_graph=True double backward).  With v = dL/de held fixed, dL = d(v.e) and v.e is the tangent of
+//   sdf along v, so the extra terms come from differentiating the tangent pass: with r_l = d sdf / d h_l (saved by the
+//   sdf-chain kernel) and ta_l = gamma_l * (W_l th_{l-1}) the tangent argument (saved by the tangent kernel),
+//       adj(a_l)     = cos(a_l) adj(h_l) - sin(a_l) ta_l r_l
+//       adj(gamma_l) = adj(a_l) z_l + (ta_l / gamma_l) cos(a_l) r_l ,   adj(beta_l) = adj(a_l)
+//   and the same transposed chain carries adj(h) downwards.
+template <bool EIK>
 __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wbuf = smem + kBwdLdsW;
@@ -103,48 +175,15 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
         pend_layer = -1;
     };
 
-    // ---- weight chunk pipeline: identical protocol to the forward kernel, transposed image ----
-    const int total_chunks = n_sub * kChunksPerPass;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const float* const src_lane = packed + kOffBigT + wave_u * 2048 + lane * 4;
-    int g_issue = 0, issue_chunk_idx = 0, issue_buf = 0;
-    auto issue_piece = [&](int i) {
-        if (g_issue < total_chunks) {
-            const float* src = src_lane + (int64_t)issue_chunk_idx * kChunkFloats + (i >> 2) * 1024;
-            float* dst = wbuf + issue_buf * kChunkFloats + wave_u * 2048 + (i >> 2) * 1024;
-            switch (i & 3) {
-                case 0: glds16_off<0>(src, dst); break;
-                case 1: glds16_off<1024>(src, dst); break;
-                case 2: glds16_off<2048>(src, dst); break;
-                default: glds16_off<3072>(src, dst); break;
-            }
-        }
-        if (i == 7) {
-            ++g_issue;
-            issue_chunk_idx = (issue_chunk_idx + 1 == kChunksPerPass) ? 0 : issue_chunk_idx + 1;
-            issue_buf = (issue_buf + 1 == kNBuf) ? 0 : issue_buf + 1;
-        }
-    };
-    for (int c = 0; c < kNBuf - 1; ++c)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) issue_piece(i);
-    auto chunk_sync = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    };
-    int use_buf = 0;
-    const float* wcur = wbuf;
-    const float* wnxt = wbuf + kChunkFloats;
-    auto advance_chunk = [&]() {
-        use_buf = (use_buf + 1 == kNBuf) ? 0 : use_buf + 1;
-        wcur = wnxt;
-        wnxt = wbuf + ((use_buf + 1 == kNBuf) ? 0 : use_buf + 1) * kChunkFloats;
-    };
+    ChunkPipe pipe;
+    pipe.init(wbuf, packed + kOffBigT, wave, lane, 0, kChunksPerPass, n_sub * kChunksPerPass);
+    pipe.prime();
+    auto issue_piece = [&](int i) { pipe.issue_piece(i); };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x4 ring[kRing];
-    ring[0] = reinterpret_cast<const f32x4*>(wcur)[lane];
-    ring[1] = reinterpret_cast<const f32x4*>(wcur)[64 + lane];
+    ring[0] = reinterpret_cast<const f32x4*>(pipe.wcur)[lane];
+    ring[1] = reinterpret_cast<const f32x4*>(pipe.wcur)[64 + lane];
 
     f32x16 in[kNT], out[kNT];
 
@@ -154,6 +193,8 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
         const int pc = valid ? p : (npts - 1);
         const int64_t gpt = (int64_t)b * a.n_pts + pt0 + pc;
         const float* __restrict__ ap = a.args + gpt * (9 * kWidth);
+        const float* __restrict__ tp_ = EIK ? a.tang + gpt * (8 * kWidth) : nullptr;
+        const float* __restrict__ rp_ = EIK ? a.rsave + gpt * (8 * kWidth) : nullptr;
         const float vmask = valid ? 1.0f : 0.0f;                      // padded lanes contribute nothing
         const float dsdf = (a.d_sdf && valid) ? a.d_sdf[gpt] : 0.0f;
         float drgb[3] = {0.f, 0.f, 0.f};
@@ -230,9 +271,12 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
             const int Lm1 = 7 - Gb;                                      // layer whose argument / FiLM the epilogue uses
             const float* __restrict__ fg = film_s + Lm1 * 3 * kWidth;
             const float* __restrict__ apl = ap + Lm1 * kWidth;
+            const float* __restrict__ tpl = EIK ? tp_ + Lm1 * kWidth : nullptr;
+            const float* __restrict__ rpl = EIK ? rp_ + Lm1 * kWidth : nullptr;
             const float sdf_term = (Gb == 0) ? dsdf : 0.0f;              // sdf head reads the backbone output h8
             f32x16 prev;
             f32x4 argb[2][4];                                            // saved arguments, fetched one tile ahead
+            f32x4 tgb[4], rsb[4];                                        // EIK: tangent arguments and r of the tile being finished
             auto epilogue = [&](int tp, const f32x16& dhv, const f32x4 (&ar)[4], f32x16& dst) {
                 float rb[16], rg[16];
 #pragma unroll
@@ -244,13 +288,33 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float dh = vmask * fmaf(ws[j], sdf_term, dhv[4 * q + j]);
-                        const float da = dh * cos_hw_f32(ar[q][j]);
+                        float da, dg_extra = 0.0f;
+                        if (EIK) {
+                            float sn, cs;
+                            sincos_hw_f32(ar[q][j], sn, cs);
+                            const float tr = vmask * tgb[q][j] * rsb[q][j];
+                            da = fmaf(dh, cs, -sn * tr);
+                            dg_extra = tr * i4[j] * cs;
+                        } else {
+#ifndef E3DGE_BWD_ABL_NO_COS
+                            da = dh * cos_hw_f32(ar[q][j]);
+#else
+                            da = dh * ar[q][j];
+#endif
+                        }
                         rb[4 * q + j] = da;
-                        rg[4 * q + j] = da * ((ar[q][j] - b4[j]) * i4[j]);
+                        rg[4 * q + j] = fmaf(da, (ar[q][j] - b4[j]) * i4[j], dg_extra);
                         dst[4 * q + j] = g4[j] * da;
                     }
                 }
+#ifndef E3DGE_BWD_ABL_NO_REDUCE
                 reduce_tile(Lm1, tp, rb, rg);
+#else
+                float keep = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) keep += rb[i] + rg[i];
+                dst[0] += keep * 1e-30f;
+#endif
             };
 #pragma unroll
             for (int t = 0; t < kNT; ++t) {
@@ -258,17 +322,28 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                 // issued right AFTER this tile's weight-chunk wait -- the vmcnt(0) of the next tile's wait, a whole
                 // tile of MFMAs later, is what retires them; issued before it they would stall the wait itself.
                 auto sync_and_fetch = [&]() {
-                    chunk_sync();
+                    pipe.sync();
                     if (t > 0) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(argb[(t - 1) & 1][q]));
                     }
+#ifndef E3DGE_BWD_ABL_NO_ARGLOAD
 #pragma unroll
                     for (int q = 0; q < 4; ++q) argb[t & 1][q] = *reinterpret_cast<const f32x4*>(apl + 32 * t + 8 * q + 4 * half);
+#else
+                    for (int q = 0; q < 4; ++q) argb[t & 1][q] = f32x4{0.1f * t, 0.2f, 0.3f + q, 0.4f};
+#endif
+                    if (EIK && t > 0) {     // the second-order streams of the tile whose epilogue follows this GEMM tile
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            tgb[q] = *reinterpret_cast<const f32x4*>(tpl + 32 * (t - 1) + 8 * q + 4 * half);
+                            rsb[q] = *reinterpret_cast<const f32x4*>(rpl + 32 * (t - 1) + 8 * q + 4 * half);
+                        }
+                    }
                 };
                 f32x16 acc = zero16();
-                acc = big_tile<false, 0>(wcur, wnxt, lane, in, acc, ring, NoEpilogue(), sync_and_fetch, issue_piece);
-                advance_chunk();
+                acc = big_tile<false, 0>(pipe.wcur, pipe.wnxt, lane, in, acc, ring, NoEpilogue(), sync_and_fetch, issue_piece);
+                pipe.advance();
                 if (t > 0) {
                     epilogue(t - 1, prev, argb[(t - 1) & 1], out[t - 1]);
                     asm volatile("" : "+a"(out[t - 1]));
@@ -277,6 +352,13 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(argb[(kNT - 1) & 1][q]));
+            if (EIK) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    tgb[q] = *reinterpret_cast<const f32x4*>(tpl + 32 * (kNT - 1) + 8 * q + 4 * half);
+                    rsb[q] = *reinterpret_cast<const f32x4*>(rpl + 32 * (kNT - 1) + 8 * q + 4 * half);
+                }
+            }
             __syncthreads();       // the last two epilogues of a layer have no weight-chunk barrier between them
             epilogue(kNT - 1, prev, argb[(kNT - 1) & 1], out[kNT - 1]);
 #pragma unroll
@@ -294,6 +376,211 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
     for (int i = tid; i < 9 * 2 * kWidth; i += kThreads) my_partial[i] = acc_s[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The two first-order chains the eikonal term needs, one kernel template (seven 256x256 GEMMs per point each):
+//   TANGENT = false  "sdf chain":  r_7 = w_sigma * seed ;  r_{l-1} = W_l^T (gamma_l cos(a_l) r_l) ;
+//                    saves r_l = d sdf / d h_l (l = 0..7) and writes e = d sdf / d x = s W_0^T (gamma_0 cos(a_0) r_0)
+//                    -- get_eikonal_term (volume_renderer.py:796-802) without an autograd graph.
+//   TANGENT = true   "tangent":    ta_0 = gamma_0 W_0 (s v) ;  ta_l = gamma_l W_l (cos(a_{l-1}) ta_{l-1}) ;
+//                    saves ta_l (l = 0..7): the forward-mode derivative of the arguments along v = dL/de.
+// Both feed the next GEMM with gamma cos(a) acc; they differ in direction (transposed image, descending layers / forward
+// image, ascending layers), in what is stored (acc / gamma acc) and at the two ends.  Stores of a tile are issued after
+// the NEXT tile's weight-chunk wait so that they never sit in front of a vmcnt(0).
+// ---------------------------------------------------------------------------------------------------------------
+struct SirenChainK {
+    const float* packed;
+    const float* film;
+    const float* args;       // (batch, n_pts, 9, 256)
+    const float* seed;       // TANGENT: v (batch, n_pts, 3);  else: per-point scale of r_7 (batch, n_pts) or null (= 1)
+    float* save;             // (batch, n_pts, 8, 256): ta_l or r_l
+    float* eik;              // (batch, n_pts, 3), sdf chain only
+    float box_scale;
+    long long n_pts;
+    int batch, subtiles_per_wg, wgs_per_img;
+};
+
+constexpr int kChLdsW = 0;
+constexpr int kChLdsFilm = kChLdsW + kNBuf * kChunkFloats;      // [8][256] gamma of the backbone layers
+constexpr int kChLdsW0 = kChLdsFilm + 8 * kWidth;               // [3][256] first-layer weights, column-major
+constexpr int kChLdsHead = kChLdsW0 + 3 * kWidth;               // w_sigma[256]
+constexpr int kChLdsFloats = kChLdsHead + kWidth;
+constexpr int kChLdsBytes = kChLdsFloats * 4;
+
+template <bool TANGENT>
+__global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const wbuf = smem + kChLdsW;
+    float* const gam_s = smem + kChLdsFilm;
+    float* const w0_s = smem + kChLdsW0;
+    float* const ws_s = smem + kChLdsHead;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
+    const int b = blockIdx.x / a.wgs_per_img;
+    const int wg = blockIdx.x - b * a.wgs_per_img;
+    const long long pt0 = (long long)wg * a.subtiles_per_wg * kTilePts;
+    const long long rem = a.n_pts - pt0;
+    const int npts = (int)(rem < (long long)a.subtiles_per_wg * kTilePts ? rem : (long long)a.subtiles_per_wg * kTilePts);
+    const int n_sub = (npts + kTilePts - 1) / kTilePts;
+
+    const float* __restrict__ packed = a.packed;
+    const float* __restrict__ film_g = a.film + (int64_t)b * 9 * 2 * kWidth;
+    for (int i = tid; i < 8 * kWidth; i += kThreads) gam_s[i] = film_g[((i >> 8) * 2) * kWidth + (i & 255)];
+    for (int i = tid; i < 3 * kWidth; i += kThreads) {
+        const int c = i >> 8, n = i & 255;           // fragment image of layer 0 (siren_pack_kernel): [t][m][lane], k = 2m + half
+        w0_s[i] = packed[kOffFirst + ((n >> 5) * 2 + (c >> 1)) * 64 + (c & 1) * 32 + (n & 31)];
+    }
+    for (int i = tid; i < kWidth; i += kThreads) ws_s[i] = packed[kOffWSigma + i];
+
+    constexpr int kChainChunks = 7 * kNT;             // layers 1..7
+    ChunkPipe pipe;
+    pipe.init(wbuf, packed + (TANGENT ? kOffBig : kOffBigT), wave, lane, TANGENT ? 0 : kNT, kChainChunks, n_sub * kChainChunks);
+    pipe.prime();
+    auto issue_piece = [&](int i) { pipe.issue_piece(i); };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4 ring[kRing];
+    ring[0] = reinterpret_cast<const f32x4*>(pipe.wcur)[lane];
+    ring[1] = reinterpret_cast<const f32x4*>(pipe.wcur)[64 + lane];
+
+    f32x16 in[kNT], out[kNT];
+
+    for (int sub = 0; sub < n_sub; ++sub) {
+        const int p = sub * kTilePts + 32 * wave + col;
+        const bool valid = p < npts;
+        const int pc = valid ? p : (npts - 1);
+        const int64_t gpt = (int64_t)b * a.n_pts + pt0 + pc;
+        const float* __restrict__ ap = a.args + gpt * (9 * kWidth);
+        float* __restrict__ sp = a.save + gpt * (8 * kWidth);
+
+        // ---- first layer of the chain (no GEMM) ----
+        {
+            const int l0 = TANGENT ? 0 : 7;
+            const float* __restrict__ gl = gam_s + l0 * kWidth;
+            float sx = 0.f, sy = 0.f, sz = 0.f, seed = 1.0f;
+            if (TANGENT) {
+                const float* vv = a.seed + gpt * 3;
+                sx = vv[0] * a.box_scale; sy = vv[1] * a.box_scale; sz = vv[2] * a.box_scale;
+            } else if (a.seed) {
+                seed = a.seed[gpt];
+            }
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = 32 * t + 8 * q + 4 * half;
+                    const f32x4 ar = *reinterpret_cast<const f32x4*>(ap + l0 * kWidth + o);
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gl + o);
+                    f32x4 x4;
+                    if (TANGENT) {
+                        const f32x4 wx = *reinterpret_cast<const f32x4*>(w0_s + o), wy = *reinterpret_cast<const f32x4*>(w0_s + kWidth + o),
+                                    wz = *reinterpret_cast<const f32x4*>(w0_s + 2 * kWidth + o);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) x4[j] = g4[j] * fmaf(wz[j], sz, fmaf(wy[j], sy, wx[j] * sx));   // ta_0
+                    } else {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(ws_s + o);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) x4[j] = w4[j] * seed;                                          // r_7
+                    }
+                    if (valid) *reinterpret_cast<f32x4*>(sp + l0 * kWidth + o) = x4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        in[t][4 * q + j] = cos_hw_f32(ar[j]) * (TANGENT ? x4[j] : g4[j] * x4[j]);
+                }
+            }
+        }
+
+        // ---- seven GEMMs ----
+#pragma unroll 1
+        for (int step = 0; step < 7; ++step) {
+            const int l = TANGENT ? step + 1 : 6 - step;                 // layer whose argument / gamma the epilogue uses
+            const float* __restrict__ gl = gam_s + l * kWidth;
+            const float* __restrict__ apl = ap + l * kWidth;
+            float* __restrict__ spl = sp + l * kWidth;
+            f32x16 prev;
+            f32x4 argb[2][4];
+            f32x4 st4[4];                                                // the finished tile's values, stored one wait later
+            auto epilogue = [&](int tp, const f32x16& accv, const f32x4 (&ar)[4], f32x16& dst) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gl + 32 * tp + 8 * q + 4 * half);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float ga = g4[j] * accv[4 * q + j];
+                        st4[q][j] = TANGENT ? ga : accv[4 * q + j];
+                        dst[4 * q + j] = cos_hw_f32(ar[q][j]) * ga;
+                    }
+                }
+            };
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+                auto sync_and_fetch = [&]() {
+                    pipe.sync();
+                    if (t > 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(argb[(t - 1) & 1][q]));
+                    }
+                    if (t > 1 && valid) {                                // tile t-2 finished during the previous GEMM tile
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(spl + 32 * (t - 2) + 8 * q + 4 * half) = st4[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) argb[t & 1][q] = *reinterpret_cast<const f32x4*>(apl + 32 * t + 8 * q + 4 * half);
+                };
+                f32x16 acc = zero16();
+                acc = big_tile<false, 0>(pipe.wcur, pipe.wnxt, lane, in, acc, ring, NoEpilogue(), sync_and_fetch, issue_piece);
+                pipe.advance();
+                if (t > 0) {
+                    epilogue(t - 1, prev, argb[(t - 1) & 1], out[t - 1]);
+                    asm volatile("" : "+a"(out[t - 1]));
+                }
+                prev = acc;
+            }
+            // tail of the layer: tile 6 is still pending in st4, tile 7 has no GEMM tile after it
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(spl + 32 * (kNT - 2) + 8 * q + 4 * half) = st4[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(argb[(kNT - 1) & 1][q]));
+            epilogue(kNT - 1, prev, argb[(kNT - 1) & 1], out[kNT - 1]);
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(spl + 32 * (kNT - 1) + 8 * q + 4 * half) = st4[q];
+            }
+#pragma unroll
+            for (int tt = 0; tt < kNT; ++tt) {
+                in[tt] = out[tt];
+                asm volatile("" : "+a"(in[tt]));
+            }
+        }
+
+        // ---- sdf chain: e = s W_0^T g_0 ----
+        if (!TANGENT) {
+            float ex = 0.f, ey = 0.f, ez = 0.f;
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = 32 * t + 8 * q + 4 * half;
+                    const f32x4 wx = *reinterpret_cast<const f32x4*>(w0_s + o), wy = *reinterpret_cast<const f32x4*>(w0_s + kWidth + o),
+                                wz = *reinterpret_cast<const f32x4*>(w0_s + 2 * kWidth + o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float g = in[t][4 * q + j];
+                        ex = fmaf(wx[j], g, ex); ey = fmaf(wy[j], g, ey); ez = fmaf(wz[j], g, ez);
+                    }
+                }
+            }
+            ex += xhalf(ex); ey += xhalf(ey); ez += xhalf(ez);
+            if (valid && half == 0) {
+                float* o = a.eik + gpt * 3;
+                o[0] = ex * a.box_scale; o[1] = ey * a.box_scale; o[2] = ez * a.box_scale;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Backward of volume_integration (project/utils/volume_renderer.py:809-943, the sdf / force_background configuration)
@@ -496,18 +783,23 @@ static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfil
                     reinterpret_cast<uintptr_t>(k.d_featmap)) & 15) == 0,
                   "siren_bwd: packed/args/d_feat must be 16-B aligned");
     float* const partials = k.partials;
+    E3DGE_REQUIRE((k.tang == nullptr) == (k.rsave == nullptr), "siren_bwd: tang and rsave must come together");
+    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(k.tang) | reinterpret_cast<uintptr_t>(k.rsave)) & 15) == 0, "siren_bwd: tang/rsave must be 16-B aligned");
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&siren_bwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsBytes);
-        if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(siren_bwd): %s", hipGetErrorString(e));
+        const void* fns[2] = {reinterpret_cast<const void*>(&siren_bwd_kernel<false>), reinterpret_cast<const void*>(&siren_bwd_kernel<true>)};
+        for (const void* fn : fns) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsBytes);
+            if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(siren_bwd): %s", hipGetErrorString(e));
+        }
         attr_done = true;
     }
     bwd_geometry(batch, n_pts, &k.subtiles_per_wg, &k.wgs_per_img);
     if (n_pts > 0) {
         const int64_t grid = (int64_t)k.wgs_per_img * batch;
         E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_bwd: grid too large");
-        siren_bwd_kernel<<<dim3((unsigned)grid), dim3(kThreads), kBwdLdsBytes, st>>>(k);
+        if (k.tang) siren_bwd_kernel<true><<<dim3((unsigned)grid), dim3(kThreads), kBwdLdsBytes, st>>>(k);
+        else siren_bwd_kernel<false><<<dim3((unsigned)grid), dim3(kThreads), kBwdLdsBytes, st>>>(k);
         int rc = check_launch("siren_bwd");
         if (rc) return rc;
     }
@@ -519,14 +811,15 @@ static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfil
 }
 
 extern "C" int e3dge_siren_bwd(const float* packed, const float* film, const float* args, const float* d_feat,
-                               const float* d_rgb, const float* d_sdf, const float* wg, const float* wb,
+                               const float* d_rgb, const float* d_sdf, const float* tang, const float* rsave,
+                               const float* wg, const float* wb,
                                int batch, int64_t n_pts, float* partials, float* dfilm, float* dstyles,
                                e3dge_stream_t stream) {
     E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "siren_bwd: bad sizes");
     if (batch == 0) return E3DGE_OK;
     SirenBwdK k{};
     k.packed = packed; k.film = film; k.args = args; k.d_feat = d_feat; k.d_rgb = d_rgb; k.d_sdf = d_sdf;
-    k.partials = partials; k.n_pts = n_pts; k.batch = batch; k.samples = 1;
+    k.partials = partials; k.n_pts = n_pts; k.batch = batch; k.samples = 1; k.tang = tang; k.rsave = rsave;
     return launch_bwd(k, wg, wb, dfilm, dstyles, as_stream(stream));
 }
 
@@ -565,6 +858,42 @@ extern "C" int e3dge_siren_render_bwd(const E3dgeRenderBwdArgs* r, e3dge_stream_
     SirenBwdK k{};
     k.packed = r->packed; k.film = r->film; k.args = r->args; k.d_feat = nullptr; k.d_rgb = r->d_rgb_pts; k.d_sdf = r->d_sdf_pts;
     k.d_featmap = r->d_feat_map; k.weights = r->weights; k.samples = r->n_samples;
-    k.partials = r->partials; k.n_pts = HW * r->n_samples; k.batch = r->batch;
+    k.partials = r->partials; k.n_pts = HW * r->n_samples; k.batch = r->batch; k.tang = r->tang; k.rsave = r->rsave;
     return launch_bwd(k, r->wg, r->wb, r->dfilm, r->dstyles, st);
+}
+
+template <bool TANGENT>
+static int launch_chain(const float* packed, const float* film, const float* args, const float* seed, float box_scale,
+                        int batch, int64_t n_pts, float* save, float* eik, hipStream_t st, const char* what) {
+    E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "%s: bad sizes", what);
+    if (batch == 0 || n_pts == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(packed && film && args && save && (TANGENT ? seed != nullptr : eik != nullptr), "%s: null pointer", what);
+    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(args) | reinterpret_cast<uintptr_t>(save)) & 15) == 0,
+                  "%s: packed/args/save must be 16-B aligned", what);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kChLdsBytes);
+        if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+        attr_done = true;
+    }
+    SirenChainK k{};
+    k.packed = packed; k.film = film; k.args = args; k.seed = seed; k.save = save; k.eik = eik; k.box_scale = box_scale;
+    k.n_pts = n_pts; k.batch = batch;
+    bwd_geometry(batch, n_pts, &k.subtiles_per_wg, &k.wgs_per_img);
+    const int64_t grid = (int64_t)k.wgs_per_img * batch;
+    E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "%s: grid too large", what);
+    siren_chain_kernel<TANGENT><<<dim3((unsigned)grid), dim3(kThreads), kChLdsBytes, st>>>(k);
+    return check_launch(what);
+}
+
+extern "C" int e3dge_siren_sdf_grad(const float* packed, const float* film, const float* args, const float* seed,
+                                    float box_scale, int batch, int64_t n_pts, float* rsave, float* eik,
+                                    e3dge_stream_t stream) {
+    return launch_chain<false>(packed, film, args, seed, box_scale, batch, n_pts, rsave, eik, as_stream(stream), "siren_sdf_grad");
+}
+
+extern "C" int e3dge_siren_tangent(const float* packed, const float* film, const float* args, const float* v,
+                                   float box_scale, int batch, int64_t n_pts, float* tang, e3dge_stream_t stream) {
+    return launch_chain<true>(packed, film, args, v, box_scale, batch, n_pts, tang, nullptr, as_stream(stream), "siren_tangent");
 }

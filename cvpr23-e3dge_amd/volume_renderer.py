@@ -190,18 +190,27 @@ class SirenGenerator(nn.Module):
         _lib.check(rc, "e3dge_film_params")
         return film
 
-    def query_points(self, pts, viewdirs, styles, box_scale, want_raw=True, mfma_mode=None, save_args=None):
-        """pts (B, N, 3) world-space, viewdirs (B, N, 3) or None -> (sdf (B,N), raw (B,N,260) or None).
-        When `styles` requires grad the call is differentiable w.r.t. it (HIP backward, e3dge_siren_bwd)."""
+    def query_points(self, pts, viewdirs, styles, box_scale, want_raw=True, mfma_mode=None, save_args=None,
+                     want_eikonal=False):
+        """pts (B, N, 3) world-space, viewdirs (B, N, 3) or None -> (sdf (B,N), raw (B,N,260) or None)
+        [, eikonal term d sdf / d pts (B,N,3) with want_eikonal].
+        When `styles` requires grad the call is differentiable w.r.t. it (HIP backward, e3dge_siren_bwd), the eikonal
+        term included.  d(outputs)/d(pts) beyond the eikonal term itself is not provided."""
         _lib.require_gpu(pts, "pts")
-        if torch.is_grad_enabled() and styles.requires_grad and pts.shape[0] and pts.shape[1]:
-            if pts.requires_grad or (viewdirs is not None and viewdirs.requires_grad):
-                raise NotImplementedError("gradients w.r.t. sample positions / view directions (eikonal term) are "
-                                          "not covered by the HIP backward")
-            sdf, raw = _PointsQuery.apply(styles, self, pts, viewdirs, box_scale, mfma_mode)
-            return sdf, (raw if want_raw else None)
+        live = pts.shape[0] and pts.shape[1]
+        if torch.is_grad_enabled() and styles.requires_grad and live:
+            sdf, raw, eik = _PointsQuery.apply(styles, self, pts.detach(), None if viewdirs is None else viewdirs.detach(),
+                                               box_scale, mfma_mode, bool(want_eikonal))
+            raw = raw if want_raw else None
+            return (sdf, raw, eik) if want_eikonal else (sdf, raw)
         film = self.film_params(styles)
-        return self._points_launch(film, pts, viewdirs, box_scale, want_raw, mfma_mode, save_args)
+        if not want_eikonal:
+            return self._points_launch(film, pts, viewdirs, box_scale, want_raw, mfma_mode, save_args)
+        B, N = pts.shape[0], pts.shape[1]
+        args = save_args if save_args is not None else torch.empty((B, N, 9, self.W), device=pts.device, dtype=torch.float32)
+        sdf, raw = self._points_launch(film, pts, viewdirs, box_scale, want_raw, mfma_mode, args)
+        eik = sdf_gradient(self, film, args, box_scale)[0] if live else torch.empty((B, N, 3), device=pts.device)
+        return sdf, raw, eik
 
     def _points_launch(self, film, pts, viewdirs, box_scale, want_raw, mfma_mode, save_args):
         packed = self.device_image()[0]
@@ -229,10 +238,37 @@ class SirenGenerator(nn.Module):
         return raw.reshape(*lead, 260)
 
 
-def siren_backward(siren, film, args, d_feat, d_rgb, d_sdf):
+def sdf_gradient(siren, film, args, box_scale):
+    """Eikonal term e = d sdf / d x (B,N,3) from the saved arguments (e3dge_siren_sdf_grad, reference :796-802), plus
+    the per-layer r_l = d sdf / d h_l (B,N,8,256) a loss on e needs for its backward."""
+    packed = siren.device_image()[0]
+    B, N = args.shape[0], args.shape[1]
+    rsave = torch.empty((B, N, 8, siren.W), device=args.device, dtype=torch.float32)
+    eik = torch.empty((B, N, 3), device=args.device, dtype=torch.float32)
+    with torch.cuda.device(args.device):
+        rc = _lib.load().e3dge_siren_sdf_grad(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), None, float(box_scale),
+                                              B, N, _lib.ptr(rsave), _lib.ptr(eik), _lib.stream_of(args))
+    _lib.check(rc, "e3dge_siren_sdf_grad")
+    return eik, rsave
+
+
+def tangent_arguments(siren, film, args, v, box_scale):
+    """Tangent arguments (B,N,8,256) along v = dL/de (B,N,3) (e3dge_siren_tangent)."""
+    packed = siren.device_image()[0]
+    B, N = args.shape[0], args.shape[1]
+    v = v.reshape(B, N, 3).contiguous().float()
+    tang = torch.empty((B, N, 8, siren.W), device=args.device, dtype=torch.float32)
+    with torch.cuda.device(args.device):
+        rc = _lib.load().e3dge_siren_tangent(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), _lib.ptr(v), float(box_scale),
+                                             B, N, _lib.ptr(tang), _lib.stream_of(args))
+    _lib.check(rc, "e3dge_siren_tangent")
+    return tang
+
+
+def siren_backward(siren, film, args, d_feat, d_rgb, d_sdf, tang=None, rsave=None):
     """dL/d(styles) (B,9,256) and dL/d(film) (B,9,2,256) from the per-point output gradients (e3dge_siren_bwd).
     args (B,N,9,256) are the forward launch's saved pre-sine arguments; any of d_feat (B,N,256), d_rgb (B,N,3),
-    d_sdf (B,N) may be None."""
+    d_sdf (B,N) may be None.  tang + rsave add the gradient of a loss on the eikonal term."""
     packed, wg, _, wb, _ = siren.device_image()
     B, N = args.shape[0], args.shape[1]
     dev = args.device
@@ -244,7 +280,7 @@ def siren_backward(siren, film, args, d_feat, d_rgb, d_sdf):
     dstyles = torch.empty((B, 9, siren.W), device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):
         rc = lib.e3dge_siren_bwd(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), _lib.ptr(d_feat), _lib.ptr(d_rgb),
-                                 _lib.ptr(d_sdf), _lib.ptr(wg), _lib.ptr(wb), B, N, _lib.ptr(partials),
+                                 _lib.ptr(d_sdf), _lib.ptr(tang), _lib.ptr(rsave), _lib.ptr(wg), _lib.ptr(wb), B, N, _lib.ptr(partials),
                                  _lib.ptr(dfilm), _lib.ptr(dstyles), _lib.stream_of(args))
     _lib.check(rc, "e3dge_siren_bwd")
     return dstyles, dfilm
@@ -252,33 +288,43 @@ def siren_backward(siren, film, args, d_feat, d_rgb, d_sdf):
 
 class _PointsQuery(torch.autograd.Function):
     """run_network with a gradient path to the styles (the encoder's output): forward saves the pre-sine arguments,
-    backward is the fused HIP chain.  Points / view directions get no gradient (they are fixed samples)."""
+    backward is the fused HIP chain.  With want_eik the eikonal term d sdf / d x is a third, differentiable output
+    (the reference builds it with autograd.grad(create_graph=True), :796-802).  The points / view directions themselves
+    get no gradient (they are fixed samples)."""
 
     @staticmethod
-    def forward(ctx, styles, siren, pts, viewdirs, box_scale, mfma_mode):
+    def forward(ctx, styles, siren, pts, viewdirs, box_scale, mfma_mode, want_eik):
         B, N = pts.shape[0], pts.shape[1]
         args = torch.empty((B, N, 9, siren.W), device=pts.device, dtype=torch.float32)
         film = siren.film_params(styles)
         sdf, raw = siren._points_launch(film, pts, viewdirs, box_scale, True, mfma_mode, args)
-        ctx.siren, ctx.styles_ndim = siren, styles.ndim
-        ctx.save_for_backward(film, args)
-        return sdf, raw
+        ctx.siren, ctx.styles_ndim, ctx.box_scale = siren, styles.ndim, float(box_scale)
+        if want_eik:
+            eik, rsave = sdf_gradient(siren, film, args, box_scale)
+        else:
+            eik, rsave = torch.empty(0, device=pts.device), torch.empty(0, device=pts.device)
+        ctx.want_eik = want_eik
+        ctx.save_for_backward(film, args, rsave)
+        return sdf, raw, eik
 
     @staticmethod
-    def backward(ctx, d_sdf, d_raw):
-        film, args = ctx.saved_tensors
+    def backward(ctx, d_sdf, d_raw, d_eik):
+        film, args, rsave = ctx.saved_tensors
         d_rgb = d_feat = None
         ds = d_sdf
         if d_raw is not None:
             d_rgb, d_feat = d_raw[..., :3], d_raw[..., 4:]
             ds = d_raw[..., 3] if ds is None else ds + d_raw[..., 3]
-        dstyles, _ = siren_backward(ctx.siren, film, args, d_feat, d_rgb, ds)
+        tang = rs = None
+        if ctx.want_eik and d_eik is not None:
+            tang, rs = tangent_arguments(ctx.siren, film, args, d_eik, ctx.box_scale), rsave
+        dstyles, _ = siren_backward(ctx.siren, film, args, d_feat, d_rgb, ds, tang, rs)
         if ctx.styles_ndim == 2:                   # one W shared by the nine layers (reference :189-191)
             dstyles = dstyles.sum(1)
-        return dstyles, None, None, None, None, None
+        return dstyles, None, None, None, None, None, None
 
 
-_DIFF_KEYS = ('gen_thumb_imgs', 'features', 'xyz', 'depth', 'sdf')
+_DIFF_KEYS = ('gen_thumb_imgs', 'features', 'xyz', 'depth', 'sdf', 'eikonal_term')
 _AUX_KEYS = ('mask', 'hit_prob', 'points', 'rays_d', 'viewdirs', 'dists')
 
 
@@ -287,32 +333,39 @@ class _RenderQuery(torch.autograd.Function):
     e3dge_siren_render_fwd with saved pre-sine arguments, e3dge_siren_render_bwd for the way back."""
 
     @staticmethod
-    def differentiable(renderer, styles, focal, c2w, near, far):
-        vals = _RenderQuery.apply(styles, renderer, focal, c2w, near, far)
+    def differentiable(renderer, styles, focal, c2w, near, far, want_eik=False):
+        vals = _RenderQuery.apply(styles, renderer, focal, c2w, near, far, bool(want_eik))
         out = dict(renderer._last_render)          # non-tensor / view entries of the forward's dict
         renderer._last_render = None
         for k, v in zip(_DIFF_KEYS + _AUX_KEYS, vals):
             out[k] = v
+        if not want_eik:
+            out['eikonal_term'] = None
         return out
 
     @staticmethod
-    def forward(ctx, styles, renderer, focal, c2w, near, far):
+    def forward(ctx, styles, renderer, focal, c2w, near, far, want_eik):
         B, H, S = c2w.shape[0], renderer.out_im_res, renderer.N_samples
         film = renderer.siren.film_params(styles)
         args = torch.empty((B, H * H * S, 9, renderer.siren.W), device=c2w.device, dtype=torch.float32)
         out = renderer.render_with_film(film, focal, c2w, near, far, None, save_args=args)
+        if want_eik:
+            eik, rsave = sdf_gradient(renderer.siren, film, args, renderer.box_scale)
+            out['eikonal_term'] = eik.reshape(B, H, H, S, 3)
+        else:
+            out['eikonal_term'], rsave = torch.empty(0, device=c2w.device), torch.empty(0, device=c2w.device)
         renderer._last_render = out
-        ctx.renderer, ctx.styles_ndim = renderer, styles.ndim
+        ctx.renderer, ctx.styles_ndim, ctx.want_eik = renderer, styles.ndim, want_eik
         ctx.sigmoid_beta = renderer._sigmoid_beta_value()
         ctx.save_for_backward(film, args, out['sdf'], out['dists'], out['points'], out['hit_prob'],
-                              near.reshape(B).contiguous().float(), far.reshape(B).contiguous().float())
+                              near.reshape(B).contiguous().float(), far.reshape(B).contiguous().float(), rsave)
         aux = tuple(out[k] for k in _AUX_KEYS)
         ctx.mark_non_differentiable(*aux)
         return tuple(out[k] for k in _DIFF_KEYS) + aux
 
     @staticmethod
-    def backward(ctx, d_rgb, d_feat, d_xyz, d_depth, d_sdf, *unused):
-        film, args, sdf, dists, points, weights, near, far = ctx.saved_tensors
+    def backward(ctx, d_rgb, d_feat, d_xyz, d_depth, d_sdf, d_eik, *unused):
+        film, args, sdf, dists, points, weights, near, far, rsave = ctx.saved_tensors
         r = ctx.renderer
         siren = r.siren
         B, H, S = film.shape[0], r.out_im_res, r.N_samples
@@ -329,12 +382,15 @@ class _RenderQuery(torch.autograd.Function):
         d_sdf_pts = torch.empty((B, n_pts), device=dev, dtype=torch.float32)
         dfilm = torch.empty((B, 9, 2, siren.W), device=dev, dtype=torch.float32)
         dstyles = torch.empty((B, 9, siren.W), device=dev, dtype=torch.float32)
+        tang = rs = None
+        if ctx.want_eik and d_eik is not None:
+            tang, rs = tangent_arguments(siren, film, args, d_eik, r.box_scale), rsave
         a = _lib.RenderBwdArgs(
             packed=_lib.ptr(packed), film=_lib.ptr(film), args=_lib.ptr(args), sdf=_lib.ptr(sdf), dists=_lib.ptr(dists),
             points=_lib.ptr(points), weights=_lib.ptr(weights), t_vals=_lib.ptr(r.t_vals), near=_lib.ptr(near),
             far=_lib.ptr(far), wg=_lib.ptr(wg), wb=_lib.ptr(wb), d_rgb_map=_lib.ptr(d_rgb_map),
             d_feat_map=_lib.ptr(d_feat_map), d_xyz_map=_lib.ptr(d_xyz_map), d_depth_map=_lib.ptr(d_depth_map),
-            d_sdf=_lib.ptr(d_sdf_in), sigmoid_beta=ctx.sigmoid_beta, batch=B, height=H, width=H, n_samples=S,
+            d_sdf=_lib.ptr(d_sdf_in), tang=_lib.ptr(tang), rsave=_lib.ptr(rs), sigmoid_beta=ctx.sigmoid_beta, batch=B, height=H, width=H, n_samples=S,
             force_background=int(bool(r.force_background)), d_rgb_pts=_lib.ptr(d_rgb_pts), d_sdf_pts=_lib.ptr(d_sdf_pts),
             partials=_lib.ptr(partials), dfilm=_lib.ptr(dfilm), dstyles=_lib.ptr(dstyles))
         with torch.cuda.device(dev):
@@ -342,7 +398,7 @@ class _RenderQuery(torch.autograd.Function):
         _lib.check(rc, "e3dge_siren_render_bwd")
         if ctx.styles_ndim == 2:
             dstyles = dstyles.sum(1)
-        return dstyles, None, None, None, None, None
+        return dstyles, None, None, None, None, None, None
 
 
 class SirenLocalGlobal(nn.Module):
@@ -461,7 +517,7 @@ class VolumeFeatureRenderer(nn.Module):
         return raw.reshape(*lead, 260)
 
     # -------------------------------------------------------------------------------------------------
-    def render(self, focal, c2w, near, far, styles, tex_conditions=None):
+    def render(self, focal, c2w, near, far, styles, tex_conditions=None, return_eikonal=False):
         """Fused rays -> samples -> MLP -> composite.  Returns the dict of render_rays + render
         (:1270-1287, :1695-1701), before forward()'s permutes (already applied here for free: the kernel
         writes channel-first directly)."""
@@ -474,9 +530,18 @@ class VolumeFeatureRenderer(nn.Module):
             if tex_conditions is not None:
                 raise NotImplementedError("the HIP backward covers the global (first) renderer pass; the tex-FiLM pass "
                                           "runs under no_grad in stage-1 training")
-            return _RenderQuery.differentiable(self, styles, focal, c2w, near, far)
+            return _RenderQuery.differentiable(self, styles, focal, c2w, near, far, return_eikonal)
         film = self.siren.film_params(styles)
-        return self.render_with_film(film, focal, c2w, near, far, tex_conditions)
+        if not return_eikonal:
+            return self.render_with_film(film, focal, c2w, near, far, tex_conditions)
+        if tex_conditions is not None:
+            raise NotImplementedError("eikonal term together with the tex-FiLM pass")
+        B, H, S = c2w.shape[0], self.out_im_res, self.N_samples
+        args = torch.empty((B, H * H * S, 9, self.siren.W), device=c2w.device, dtype=torch.float32)
+        out = self.render_with_film(film, focal, c2w, near, far, None, save_args=args)
+        if B:
+            out['eikonal_term'] = sdf_gradient(self.siren, film, args, self.box_scale)[0].reshape(B, H, H, S, 3)
+        return out
 
     def render_with_film(self, film, focal, c2w, near, far, tex_conditions=None, save_args=None):
         """The single fused launch (e3dge_siren_render_fwd) given precomputed FiLM parameters (B,9,2,256)."""
@@ -542,9 +607,6 @@ class VolumeFeatureRenderer(nn.Module):
     def forward(self, cam_poses, focal, near, far, styles=None, return_eikonal=False, geometry_sample=None,
                 return_surface_eikonal=False, local_data_batch=None, sample_mode=False, return_mesh=False,
                 mesh_with_shading=True, return_sdf_only=False, **kwargs):
-        if return_eikonal or return_surface_eikonal:
-            raise NotImplementedError("eikonal terms (d sdf / d x, double backward) are not covered by the HIP backward; "
-                                      "the gradient path to the styles is")
         if sample_mode:
             raise NotImplementedError("sample_mode (near-surface / uniform-grid sampling) is not in this build")
         if return_mesh:
@@ -562,7 +624,15 @@ class VolumeFeatureRenderer(nn.Module):
         else:
             self.local_batch = None
 
-        render_out = self.render(focal, cam_poses, near, far, styles, tex_conditions=tex)
+        render_out = self.render(focal, cam_poses, near, far, styles, tex_conditions=tex, return_eikonal=return_eikonal)
+        if return_surface_eikonal:
+            # normal at the integrated surface point (:921-930).  The point itself is treated as a fixed sample: the
+            # term's gradient reaches the styles through the network, not through d xyz / d styles (a second
+            # derivative in x that the stage-1 losses never use -- they take xyz_rec_eikonal_term below).
+            B = cam_poses.shape[0]
+            surf = render_out['xyz'].detach().permute(0, 2, 3, 1).reshape(B, -1, 3)
+            _, _, se = self.siren.query_points(surf, None, styles, self.box_scale, want_raw=False, want_eikonal=True)
+            render_out['surface_eikonal_term'] = se.reshape(B, self.out_im_res, self.out_im_res, 1, 3)
 
         if geometry_sample:   # 3-D supervision re-queries (:1916-1949)
             corpus = ['uniform_pts'] + (['xyz'] if geometry_sample.get('xyz', None) is not None else [])
@@ -572,6 +642,13 @@ class VolumeFeatureRenderer(nn.Module):
                 samples = geometry_sample[k]
                 if samples.ndim == 4:
                     samples = samples.unsqueeze(self.samples_dim)
+                if return_surface_eikonal and k == 'xyz':      # normals of the surface samples (:1944-1949)
+                    Bq = samples.shape[0]
+                    sdf_q, _, eik_q = self.siren.query_points(samples.reshape(Bq, -1, 3), None, styles, self.box_scale,
+                                                              want_raw=False, want_eikonal=True)
+                    render_out[f'{k}_rec'] = sdf_q.reshape(*samples.shape[:-1], 1)
+                    render_out[f'{k}_rec_eikonal_term'] = eik_q.reshape(samples.shape)
+                    continue
                 render_out[f'{k}_rec'] = self.run_network(samples, torch.zeros_like(samples), styles=styles,
                                                           return_sdf_only=True)
         return render_out

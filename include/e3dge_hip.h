@@ -201,8 +201,21 @@ int e3dge_siren_points_fwd(const float* packed, const float* film, const float* 
  * ---------------------------------------------------------------------------------------------------------------- */
 int64_t e3dge_siren_bwd_partial_floats(int batch, int64_t n_pts);
 int e3dge_siren_bwd(const float* packed, const float* film, const float* args, const float* d_feat,
-                    const float* d_rgb, const float* d_sdf, const float* wg, const float* wb,
+                    const float* d_rgb, const float* d_sdf, const float* tang, const float* rsave,
+                    const float* wg, const float* wb,
                     int batch, int64_t n_pts, float* partials, float* dfilm, float* dstyles, e3dge_stream_t stream);
+
+/* Eikonal term e = d sdf / d x (get_eikonal_term, volume_renderer.py:796-802) and its double backward.
+ *   e3dge_siren_sdf_grad : from the saved arguments, e (batch, n_pts, 3) [world-space x: includes box_scale] and
+ *                          rsave (batch, n_pts, 8, 256) = d sdf / d h_l, needed again if a loss on e is differentiated.
+ *                          seed (batch, n_pts) scales r_7 per point, NULL = 1 (grad_outputs = ones, :799).
+ *   e3dge_siren_tangent  : given v = dL/de (batch, n_pts, 3), the tangent arguments tang (batch, n_pts, 8, 256).
+ * Passing tang + rsave to e3dge_siren_bwd / E3dgeRenderBwdArgs adds dL/d(styles) of the loss on e (the reference's
+ * create_graph=True path) to the first-order gradient; NULL, NULL = no such loss. */
+int e3dge_siren_sdf_grad(const float* packed, const float* film, const float* args, const float* seed,
+                         float box_scale, int batch, int64_t n_pts, float* rsave, float* eik, e3dge_stream_t stream);
+int e3dge_siren_tangent(const float* packed, const float* film, const float* args, const float* v,
+                        float box_scale, int batch, int64_t n_pts, float* tang, e3dge_stream_t stream);
 
 /* Backward of e3dge_siren_render_fwd: volume_integration (volume_renderer.py:809-943) back to the per-point outputs
  * (one wave per ray), then the MLP chain above.  Gradient maps are ROW-MAJOR PER RAY (ray = (b*H + y)*W + x):
@@ -215,6 +228,7 @@ typedef struct E3dgeRenderBwdArgs {
     const float* points; const float* weights; const float* t_vals; const float* near; const float* far;
     const float* wg; const float* wb;
     const float* d_rgb_map; const float* d_feat_map; const float* d_xyz_map; const float* d_depth_map; const float* d_sdf;
+    const float* tang; const float* rsave;
     float sigmoid_beta;
     int batch, height, width, n_samples, force_background;
     float* d_rgb_pts; float* d_sdf_pts; float* partials;

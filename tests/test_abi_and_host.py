@@ -104,7 +104,9 @@ def test_unsupported_options_fail_loudly():
         VolumeFeatureRenderer(syn.rendering_opt(depth=6))
     r = VolumeFeatureRenderer(syn.rendering_opt(), mode='test')
     with pytest.raises(NotImplementedError):
-        r(None, None, None, None, styles=None, return_eikonal=True)
+        r(None, None, None, None, styles=None, sample_mode=True)
+    with pytest.raises(NotImplementedError):
+        r(None, None, None, None, styles=None, return_mesh=True)
 
 
 def test_upfirdn_adjoint_geometry_is_an_involution():

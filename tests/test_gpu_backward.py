@@ -217,3 +217,100 @@ def test_generator_backward_end_to_end(sd):
     assert e['img'] <= 1e-4
     assert e['d_renderer_latent'] <= max(REL_TOL, 3 * e['oracle32_d_renderer_latent']), e
     assert e['d_decoder_latent'] <= max(REL_TOL, 3 * e['oracle32_d_decoder_latent']), e
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# eikonal term (a10): value, and the gradient of a loss on it (the reference's create_graph=True double backward)
+# ----------------------------------------------------------------------------------------------------------------
+def oracle_points_with_eikonal(sd, pts, styles, dtype):
+    """sdf and d sdf / d pts exactly as the reference builds them: autograd.grad(create_graph=True) (:796-802)."""
+    x = pts.detach().cpu().to(dtype).requires_grad_(True)
+    raw = renderer_ref.query_points(sd, x, None, styles, dtype=dtype)
+    sdf = raw[..., 3:4]
+    eik = torch.autograd.grad(sdf, x, grad_outputs=torch.ones_like(sdf), create_graph=True)[0]
+    return raw, eik
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f32"])
+@pytest.mark.parametrize("n_pts,batch", [(1, 1), (200, 2), (1500, 1)])
+def test_eikonal_term_value_and_double_backward(sd, mode, n_pts, batch):
+    r = make_renderer(sd, 8, 18, mfma_mode=mode)
+    wr, _ = syn.synthetic_inputs(batch, seed=3 + n_pts, device=DEV)
+    rs = np.random.RandomState(n_pts + 1)
+    pts = torch.from_numpy((0.11 * rs.uniform(-1, 1, (batch, n_pts, 3))).astype(np.float32)).to(DEV)
+    G_e = torch.from_numpy(rs.normal(size=(batch, n_pts, 3)).astype(np.float32)).to(DEV)
+    G_s = torch.from_numpy(rs.normal(size=(batch, n_pts)).astype(np.float32)).to(DEV)
+
+    # value only, no autograd
+    with torch.no_grad():
+        sdf0, _, eik0 = r.siren.query_points(pts, None, wr, r.box_scale, want_raw=False, want_eikonal=True)
+    styles = wr.clone().requires_grad_(True)
+    sdf, raw, eik = r.siren.query_points(pts, None, styles, r.box_scale, want_eikonal=True)
+    assert torch.equal(eik.detach(), eik0) and torch.equal(sdf.detach(), sdf0)
+    # eikonal loss of the reference (losses/gan_loss.py:18) + a linear functional + an ordinary sdf term
+    loss = ((eik.norm(dim=-1) - 1) ** 2).mean() + (eik * G_e).sum() * 1e-3 + (sdf * G_s).sum() * 1e-2
+    loss.backward()
+
+    res = {}
+    for name, dtype in (("f64", torch.float64), ("f32", torch.float32)):
+        s = wr.detach().cpu().to(dtype).requires_grad_(True)
+        raw_o, eik_o = oracle_points_with_eikonal(sd, pts, s, dtype)
+        l = ((eik_o.norm(dim=-1) - 1) ** 2).mean() + (eik_o * G_e.cpu().to(dtype)).sum() * 1e-3 \
+            + (raw_o[..., 3] * G_s.cpu().to(dtype)).sum() * 1e-2
+        l.backward()
+        res[name] = (eik_o.detach(), s.grad)
+    e_val = float((eik.detach().double().cpu() - res["f64"][0]).abs().max() / res["f64"][0].abs().max())
+    e_val32 = float((res["f32"][0].double() - res["f64"][0]).abs().max() / res["f64"][0].abs().max())
+    e_g, e_g32 = rel_err(styles.grad, res["f64"][1]), rel_err(res["f32"][1], res["f64"][1])
+    record(f"eikonal_{mode}_n{n_pts}_b{batch}", eik_rel_err=e_val, oracle32_eik_rel_err=e_val32,
+           grad_rel_err=e_g, oracle32_grad_rel_err=e_g32)
+    assert e_val <= max(2e-5, 3 * e_val32), (e_val, e_val32)
+    assert e_g <= max(REL_TOL, 3 * e_g32), (e_g, e_g32)
+
+
+def test_render_eikonal_and_surface_normals(sd):
+    """return_eikonal / return_surface_eikonal through VolumeFeatureRenderer.forward, with the 3-D supervision
+    re-queries of stage 1 (uniform points sdf, surface points sdf + normals), gradient to the styles."""
+    from e3dge_amd.camera_utils import generate_camera_params
+    res, S = 8, 18
+    r = make_renderer(sd, res, S)
+    wr, _ = syn.synthetic_inputs(1, seed=8, device=DEV)
+    poses, focal, near, far, _ = generate_camera_params(res, DEV, locations=torch.tensor([[0.1, 0.05]], device=DEV))
+    rs = np.random.RandomState(5)
+    uni = torch.from_numpy((0.12 * rs.uniform(-1, 1, (1, 64, 1, 1, 3))).astype(np.float32)).to(DEV)
+    surf = torch.from_numpy((0.08 * rs.uniform(-1, 1, (1, res, res, 3))).astype(np.float32)).to(DEV)
+    n_gt = torch.from_numpy(rs.normal(size=(1, res, res, 1, 3)).astype(np.float32)).to(DEV)
+    styles = wr.clone().requires_grad_(True)
+    out = r(poses, focal, near, far, styles=styles, return_eikonal=True, return_surface_eikonal=True,
+            geometry_sample={'uniform_pts': uni, 'xyz': surf})
+    assert tuple(out['eikonal_term'].shape) == (1, res, res, S, 3)
+    assert tuple(out['surface_eikonal_term'].shape) == (1, res, res, 1, 3)
+    assert tuple(out['xyz_rec_eikonal_term'].shape) == (1, res, res, 1, 3) and tuple(out['xyz_rec'].shape) == (1, res, res, 1, 1)
+
+    def loss_of(o, n_ref):
+        return (((o['eikonal_term'].norm(dim=-1) - 1) ** 2).mean() * 0.1 + (o['gen_thumb_imgs'] ** 2).mean()
+                + ((o['xyz_rec_eikonal_term'] - n_ref) ** 2).mean() + (o['xyz_rec'] ** 2).mean()
+                + (o['uniform_pts_rec'] ** 2).mean() * 0.2)
+    loss_of(out, n_gt).backward()
+
+    def oracle(dtype):
+        cpu = lambda t: t.detach().cpu()
+        s = cpu(wr).to(dtype).requires_grad_(True)
+        ro = renderer_ref.render(sd, cpu(poses), cpu(focal), cpu(near), cpu(far), s, res=res, n_samples=S, dtype=dtype)
+        # eikonal of the ray samples: d sdf / d pts with create_graph (render_rays -> volume_integration :853-858)
+        x = ro['points'].detach().clone().requires_grad_(True)
+        raw = renderer_ref.query_points(sd, x, None, s, dtype=dtype)
+        eik = torch.autograd.grad(raw[..., 3:4], x, torch.ones_like(raw[..., 3:4]), create_graph=True)[0]
+        raw_s, eik_s = oracle_points_with_eikonal(sd, cpu(surf).unsqueeze(3), s, dtype)
+        o = dict(eikonal_term=eik, gen_thumb_imgs=ro['gen_thumb_imgs'], xyz_rec_eikonal_term=eik_s, xyz_rec=raw_s[..., 3:4],
+                 uniform_pts_rec=renderer_ref.query_points(sd, cpu(uni), None, s, dtype=dtype)[..., 3:4])
+        loss_of(o, cpu(n_gt).to(dtype)).backward()
+        return s.grad, eik.detach(), eik_s.detach()
+    g64, eik64, eiks64 = oracle(torch.float64)
+    g32, eik32, _ = oracle(torch.float32)
+    e = dict(oracle32_eik=float((eik32.double() - eik64).abs().max() / eik64.abs().max()), eik=float((out['eikonal_term'].detach().double().cpu() - eik64).abs().max() / eik64.abs().max()),
+             surf_eik=float((out['xyz_rec_eikonal_term'].detach().double().cpu() - eiks64).abs().max() / eiks64.abs().max()),
+             grad=rel_err(styles.grad, g64), oracle32_grad=rel_err(g32, g64))
+    record("render_eikonal_8x8x18", **e)
+    assert e['eik'] <= max(2e-5, 3 * e['oracle32_eik']) and e['surf_eik'] <= 2e-5, e    # ray samples: fp32 sample positions
+    assert e['grad'] <= max(REL_TOL, 3 * e['oracle32_grad']), e
