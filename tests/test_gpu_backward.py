@@ -314,3 +314,36 @@ def test_render_eikonal_and_surface_normals(sd):
     record("render_eikonal_8x8x18", **e)
     assert e['eik'] <= max(2e-5, 3 * e['oracle32_eik']) and e['surf_eik'] <= 2e-5, e    # ray samples: fp32 sample positions
     assert e['grad'] <= max(REL_TOL, 3 * e['oracle32_grad']), e
+
+
+def test_stage1_step_against_reference_golden_gradients():
+    """The recorded reference step (tests/golden/grads_8x18.npz, oracle/gen_golden_grads.py): the reference's own
+    eikonal terms, re-query outputs, loss and dL/dstyles, reproduced by the HIP forward + backward kernels."""
+    from conftest import load_golden
+    from oracle.training_ref import stage1_loss
+    g = load_golden("grads_8x18")
+    res, S = int(g['res']), int(g['n_samples'])
+    sd_ = full_state_dict(res=res, n_samples=S)[1]
+    r = make_renderer(sd_, res, S)
+    wr, _ = syn.synthetic_inputs(1, seed=int(g['styles_seed']), device=DEV)
+    T = lambda k: torch.from_numpy(g[k]).to(DEV)
+    styles = wr.clone().requires_grad_(True)
+    out = r(T('poses'), T('focal'), T('near'), T('far'), styles=styles, return_eikonal=True, return_surface_eikonal=True,
+            geometry_sample={'uniform_pts': T('uniform_pts'), 'xyz': T('surface_pts')})
+    loss = stage1_loss(out, T('normals_gt'), T('g_feat'))
+    loss.backward()
+    rel = lambda a, b: float(np.abs(a.detach().cpu().double().numpy() - b).max() / np.abs(b).max())
+    e = dict(eik_vs_ref=rel(out['eikonal_term'], g['ref_eikonal_term']),
+             ref_eik_vs_f64=float(np.abs(g['ref_eikonal_term'] - g['f64_eikonal_term']).max() / np.abs(g['f64_eikonal_term']).max()),
+             surf_normal_vs_ref=rel(out['xyz_rec_eikonal_term'], g['ref_xyz_rec_eikonal_term']),
+             uniform_sdf_vs_ref=float(np.abs(out['uniform_pts_rec'].detach().cpu().numpy() - g['ref_uniform_pts_rec']).max()),
+             loss_rel=abs(float(loss.detach()) - float(g["ref_loss"])) / abs(float(g['ref_loss'])),
+             dstyles_vs_ref=rel(styles.grad, g['ref_dstyles']), dstyles_vs_f64=rel(styles.grad, g['f64_dstyles']),
+             ref_dstyles_vs_f64=float(np.abs(g['ref_dstyles'] - g['f64_dstyles']).max() / np.abs(g['f64_dstyles']).max()))
+    record("stage1_golden_8x18", **e)
+    assert e['eik_vs_ref'] <= max(2e-5, 3 * e['ref_eik_vs_f64']), e
+    assert e['surf_normal_vs_ref'] <= 2e-5 and e['uniform_sdf_vs_ref'] <= 1e-5, e
+    assert e['loss_rel'] <= 2e-5, e
+    assert e['dstyles_vs_ref'] <= REL_TOL and e['dstyles_vs_f64'] <= max(REL_TOL, 3 * e['ref_dstyles_vs_f64']), e
+    # the reference also returns the normal at the integrated surface point
+    assert rel(out['surface_eikonal_term'], g['ref_surface_eikonal_term']) <= 1e-4

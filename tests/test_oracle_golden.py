@@ -142,3 +142,24 @@ def test_camera_restatement():
     poses_t, focal_t, _, _ = camera_ref.camera_from_locations(128, T(g['traj_locations']))
     _close(poses_t.numpy(), g['ref_traj_poses'], atol=1e-6)
     _close(focal_t.numpy(), g['ref_traj_focal'], atol=2e-4)
+
+
+def test_training_direction_restatement_matches_reference_gradients():
+    """The restatement's autograd (eikonal terms with create_graph, loss.backward to the styles) against the vectors
+    recorded from the reference's own VolumeFeatureRenderer.forward + backward (oracle/gen_golden_grads.py)."""
+    from oracle.training_ref import restated, stage1_loss
+    g = load_golden("grads_8x18")
+    sd = full_state_dict(res=int(g['res']), n_samples=int(g['n_samples']))[1]
+    wr, _ = syn.synthetic_inputs(1, seed=int(g['styles_seed']))
+    T = torch.from_numpy
+    s = wr.clone().requires_grad_(True)
+    o = restated(sd, T(g['poses']), T(g['focal']), T(g['near']), T(g['far']), s, T(g['uniform_pts']), T(g['surface_pts']),
+                 int(g['res']), int(g['n_samples']), torch.float32)
+    loss = stage1_loss(o, T(g['normals_gt']), T(g['g_feat']))
+    loss.backward()
+    assert np.abs(o['eikonal_term'].detach().numpy() - g['ref_eikonal_term']).max() <= 1e-6
+    assert np.abs(o['xyz_rec_eikonal_term'].detach().numpy() - g['ref_xyz_rec_eikonal_term']).max() <= 1e-6
+    assert np.abs(o['uniform_pts_rec'].detach().numpy() - g['ref_uniform_pts_rec']).max() <= 1e-7
+    assert abs(float(loss) - float(g['ref_loss'])) <= 1e-6 * abs(float(g['ref_loss']))
+    rel = np.abs(s.grad.numpy() - g['ref_dstyles']).max() / np.abs(g['ref_dstyles']).max()
+    assert rel <= 1e-6, rel
