@@ -15,6 +15,7 @@ Extra objects on the JSON line:
                 with HIP events on the launch stream inside the timed region, against the dense fp32 MFMA peak.
   cpu_baseline  the oracle restatement (oracle/renderer_ref.py, "port": it is bit-identical to the reference's
                 PyTorch path on the golden vectors) timed on this host's cores on a bounded sample.
+  train_step_ms      (informational) stage-1 training step of the renderer at 64x64x18 with eikonal terms, fwd + bwd.
   inversion_fwd_ms   (informational) pass #1 + pass #2 with texture FiLM + decoder to 1024^2, one image.
 """
 import argparse
@@ -47,6 +48,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (metric config: 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inversion", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -171,6 +173,48 @@ def main():
         except Exception as exc:  # the headline metric must still be printed
             result["inversion_fwd_ms"] = None
             result["inversion_fwd_note"] = f"failed: {type(exc).__name__}: {exc}"
+
+    # ---------------------------------------------------------------- informational: stage-1 training step of the renderer (C5)
+    if rank == 0 and not args.no_train_step:
+        try:
+            from e3dge_amd.volume_renderer import VolumeFeatureRenderer
+            S5 = 18                                                    # scripts/train/ffhq/stage1.sh
+            r5 = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S5), out_im_res=RES, mode='test')
+            r5.load_state_dict(renderer.state_dict())
+            r5 = r5.to(dev)
+            for p_ in r5.parameters():
+                p_.requires_grad_(False)                               # frozen generator, gradient to the styles only
+            w5, _ = syn.synthetic_inputs(1, seed=1, device=dev)
+            p5, f5, n5, fa5, _ = generate_camera_params(RES, dev, locations=torch.zeros(1, 2, device=dev))
+
+            def train_step():
+                s_ = w5.clone().requires_grad_(True)
+                o = r5(p5, f5, n5, fa5, styles=s_, return_eikonal=True, return_surface_eikonal=True)
+                loss = ((o['gen_thumb_imgs'] ** 2).mean() + ((o['eikonal_term'].norm(dim=-1) - 1) ** 2).mean()
+                        + (o['surface_eikonal_term'] ** 2).mean())
+                loss.backward()
+                return s_.grad
+            for _ in range(3):
+                train_step()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            n_tr = 10
+            for _ in range(n_tr):
+                gr = train_step()
+            e1.record()
+            torch.cuda.synchronize()
+            assert torch.isfinite(gr).all()
+            ms = e0.elapsed_time(e1) / n_tr
+            result["train_step_ms"] = ms
+            result["train_step_rays_per_sec"] = RES * RES / ms * 1e3
+            result["train_step_note"] = ("C5 renderer part, 1 image 64x64x18: forward saving arguments + eikonal term (sdf chain) + "
+                                         "surface normals, loss = mean(rgb^2) + mean((|eik|-1)^2) + mean(surf_eik^2), backward to the "
+                                         "styles incl. the double backward (tangent + second-order chain); fp32 MFMA backward")
+            del r5
+        except Exception as exc:
+            result["train_step_ms"] = None
+            result["train_step_note"] = f"failed: {type(exc).__name__}: {exc}"
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N=1 only)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -39,7 +39,8 @@ constexpr int kBwdLdsFilm = kBwdLdsW + kNBuf * kChunkFloats;     // [9][3][256] 
 constexpr int kBwdLdsHead = kBwdLdsFilm + 9 * 3 * kWidth;        // w_sigma[256], w_rgb[3][256]
 constexpr int kBwdLdsAcc = kBwdLdsHead + 4 * kWidth;              // [9][2][256] this workgroup's d(gamma), d(beta)
 constexpr int kBwdLdsSlot = kBwdLdsAcc + 9 * 2 * kWidth;          // [2 parity][4 waves][2][32] per-tile wave sums
-constexpr int kBwdLdsFloats = kBwdLdsSlot + 2 * 4 * 2 * 32;
+constexpr int kBwdLdsSlot8 = kBwdLdsSlot + 2 * 4 * 2 * 32;        // [8 tiles][4 waves][2][32] view-layer wave sums
+constexpr int kBwdLdsFloats = kBwdLdsSlot8 + kNT * 4 * 2 * 32;
 constexpr int kBwdLdsBytes = kBwdLdsFloats * 4;
 
 // Sum over the 32 lanes of a half for 8 per-lane values, entirely in the VALU (no LDS round trips: one wave per SIMD,
@@ -113,10 +114,21 @@ struct ChunkPipe {
 #pragma unroll
             for (int i = 0; i < 8; ++i) issue_piece(i);
     }
+#ifdef E3DGE_BWD_TIMING
+    unsigned long long t_vm = 0, t_bar = 0;
+    __device__ __forceinline__ void sync() {
+        const unsigned long long c0 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long c1 = __builtin_readcyclecounter();
+        __syncthreads();
+        t_vm += c1 - c0; t_bar += __builtin_readcyclecounter() - c1;
+    }
+#else
     __device__ __forceinline__ void sync() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+#endif
     __device__ __forceinline__ void advance() {
         use_buf = (use_buf + 1 == kNBuf) ? 0 : use_buf + 1;
         wcur = wnxt;
@@ -186,8 +198,16 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
     ring[1] = reinterpret_cast<const f32x4*>(pipe.wcur)[64 + lane];
 
     f32x16 in[kNT], out[kNT];
+#ifdef E3DGE_BWD_TIMING
+    unsigned long long t_tile = 0, t_epi = 0, t_pro = 0, t_tail = 0;
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+#define BT_NOW() __builtin_readcyclecounter()
+#else
+#define BT_NOW() 0ull
+#endif
 
     for (int sub = 0; sub < n_sub; ++sub) {
+        [[maybe_unused]] const unsigned long long tp0 = BT_NOW();
         const int p = sub * kTilePts + 32 * wave + col;
         const bool valid = p < npts;
         const int pc = valid ? p : (npts - 1);
@@ -201,9 +221,9 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
         if (a.d_rgb && valid) { drgb[0] = a.d_rgb[gpt * 3]; drgb[1] = a.d_rgb[gpt * 3 + 1]; drgb[2] = a.d_rgb[gpt * 3 + 2]; }
 
         // per-tile reduction of d(beta) += da, d(gamma) += da * u over this wave's 32 points, layer `layer`, tile `t`
-        auto reduce_tile = [&](int layer, int t, const float (&rb)[16], const float (&rg)[16]) {
-            fold_pending();                                            // previous tile: a barrier has passed since
-            float* const my_slot = slot_s + par * 256 + wave * 64;
+        auto reduce_tile = [&](int layer, int t, const float (&rb)[16], const float (&rg)[16], float* view_slot = nullptr) {
+            if (!view_slot) fold_pending();                            // previous tile: a barrier has passed since
+            float* const my_slot = view_slot ? view_slot : slot_s + par * 256 + wave * 64;
 #pragma unroll
             for (int h8 = 0; h8 < 2; ++h8) {
                 float vb[8], vg[8], qb[4], qg[4];
@@ -221,7 +241,7 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                     my_slot[32 + nl] = sb;
                 }
             }
-            pend_layer = layer; pend_t = t; pend_par = par; par ^= 1;
+            if (!view_slot) { pend_layer = layer; pend_t = t; pend_par = par; par ^= 1; }
         };
 
         // =====================================================================================
@@ -236,15 +256,35 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                 df = a.d_featmap + (gpt / a.samples) * kWidth;
                 wfeat = a.weights[gpt];
             }
+            // Opaque copy of the lane's half index: every address below then has to be recomputed per sub-tile.
+            // Otherwise the compiler hoists ~150 loop-invariant address registers out of the sub-tile loop, cannot
+            // keep them through the chain (in[] alone is 128 VGPRs), spills them, and their reloads -- in-order in
+            // vmcnt with the HBM prefetches -- serialise this whole block on memory latency.
+            int half_p = half;
+            asm volatile("" : "+v"(half_p));
+            // the (cold, HBM) argument / gradient rows of this layer are fetched two tiles ahead of their use
+            constexpr int kAhead = 2;
+            f32x4 arb[kAhead + 1][4], dfb[kAhead + 1][4];
+            auto fetch = [&](int t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = 32 * t + 8 * q + 4 * half_p;
+                    arb[t % (kAhead + 1)][q] = *reinterpret_cast<const f32x4*>(ap + 8 * kWidth + o);
+                    dfb[t % (kAhead + 1)][q] = df ? *reinterpret_cast<const f32x4*>(df + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            };
+#pragma unroll
+            for (int t = 0; t < kAhead; ++t) fetch(t);
+            float* const slot8 = smem + kBwdLdsSlot8;
 #pragma unroll
             for (int t = 0; t < kNT; ++t) {
+                if (t + kAhead < kNT) fetch(t + kAhead);
                 float rb[16], rg[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int o = 32 * t + 8 * q + 4 * half;
-                    const f32x4 ar = *reinterpret_cast<const f32x4*>(ap + 8 * kWidth + o);
-                    f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
-                    if (df) d4 = *reinterpret_cast<const f32x4*>(df + o);
+                    const int o = 32 * t + 8 * q + 4 * half_p;
+                    const f32x4 ar = arb[t % (kAhead + 1)][q];
+                    const f32x4 d4 = dfb[t % (kAhead + 1)][q];
                     const f32x4 g4 = *reinterpret_cast<const f32x4*>(fg + o), b4 = *reinterpret_cast<const f32x4*>(fg + kWidth + o),
                                 i4 = *reinterpret_cast<const f32x4*>(fg + 2 * kWidth + o);
                     const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + o), w1 = *reinterpret_cast<const f32x4*>(wr + kWidth + o),
@@ -255,14 +295,30 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                         const float da = dh * cos_hw_f32(ar[j]);
                         rb[4 * q + j] = da;
                         rg[4 * q + j] = da * ((ar[j] - b4[j]) * i4[j]);
-                        in[t][4 * q + j] = g4[j] * da;
+                        out[t][4 * q + j] = g4[j] * da;
                     }
                 }
-                __syncthreads();                                       // no weight-chunk barrier between these tiles
-                reduce_tile(8, t, rb, rg);
+                asm volatile("" : "+a"(out[t]));                       // results wait in AGPRs: the VGPRs stay free for the loads
+                reduce_tile(8, t, rb, rg, slot8 + (t * 4 + wave) * 64);   // own slot per (tile, wave): no barrier needed here
+            }
+#pragma unroll
+            for (int tt = 0; tt < kNT; ++tt) in[tt] = out[tt];
+            // one barrier, then every wave folds its quarter of the eight tiles in fixed order
+            __syncthreads();
+            fold_pending();                                            // the previous sub-tile's last tile
+            if (lane < 16) {
+#pragma unroll
+                for (int t = 0; t < kNT; ++t) {
+                    const int v = wave * 16 + lane, gb = v >> 5, nl = v & 31;
+                    const float* sp8 = slot8 + t * 256 + gb * 32 + nl;
+                    acc_s[(8 * 2 + gb) * kWidth + 32 * t + nl] += ((sp8[0] + sp8[64]) + sp8[128]) + sp8[192];
+                }
             }
         }
 
+#ifdef E3DGE_BWD_TIMING
+        t_pro += BT_NOW() - tp0;
+#endif
         // =====================================================================================
         // 2. the chain: GEMM Gb (layer L = 8 - Gb) turns g_L into dh_{L-1}; its epilogue makes g_{L-1}
         // =====================================================================================
@@ -275,7 +331,8 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
             const float* __restrict__ rpl = EIK ? rp_ + Lm1 * kWidth : nullptr;
             const float sdf_term = (Gb == 0) ? dsdf : 0.0f;              // sdf head reads the backbone output h8
             f32x16 prev;
-            f32x4 argb[2][4];                                            // saved arguments, fetched one tile ahead
+            f32x4 argb[4];                                               // saved arguments of the tile being finished
+            f32x4 argt[4];                                               // ... and of the layer's last tile (no GEMM tile follows it)
             f32x4 tgb[4], rsb[4];                                        // EIK: tangent arguments and r of the tile being finished
             auto epilogue = [&](int tp, const f32x16& dhv, const f32x4 (&ar)[4], f32x16& dst) {
                 float rb[16], rg[16];
@@ -287,7 +344,7 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                     const f32x4 ws = *reinterpret_cast<const f32x4*>(head_s + o);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float dh = vmask * fmaf(ws[j], sdf_term, dhv[4 * q + j]);
+                        const float dh = fmaf(ws[j], sdf_term, dhv[4 * q + j]);   // padded lanes: in[] = 0 and dsdf = 0, so dh = 0
                         float da, dg_extra = 0.0f;
                         if (EIK) {
                             float sn, cs;
@@ -318,22 +375,24 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
             };
 #pragma unroll
             for (int t = 0; t < kNT; ++t) {
-                // Saved arguments of tile t are consumed one tile later.  They come from HBM (cold stream), so they are
-                // issued right AFTER this tile's weight-chunk wait -- the vmcnt(0) of the next tile's wait, a whole
-                // tile of MFMAs later, is what retires them; issued before it they would stall the wait itself.
+                // The saved arguments of tile t-1 (HBM, cold stream) are needed by the epilogue that follows GEMM tile t.
+                // They are issued right AFTER this tile's weight-chunk wait (issued before it they would stall the
+                // vmcnt(0) of the wait itself) and have the rest of the tile, ~7.5k cycles of MFMAs, to arrive.
                 auto sync_and_fetch = [&]() {
                     pipe.sync();
                     if (t > 0) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(argb[(t - 1) & 1][q]));
-                    }
 #ifndef E3DGE_BWD_ABL_NO_ARGLOAD
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) argb[t & 1][q] = *reinterpret_cast<const f32x4*>(apl + 32 * t + 8 * q + 4 * half);
+                        for (int q = 0; q < 4; ++q) argb[q] = *reinterpret_cast<const f32x4*>(apl + 32 * (t - 1) + 8 * q + 4 * half);
 #else
-                    for (int q = 0; q < 4; ++q) argb[t & 1][q] = f32x4{0.1f * t, 0.2f, 0.3f + q, 0.4f};
+                        for (int q = 0; q < 4; ++q) argb[q] = f32x4{0.1f * t, 0.2f, 0.3f + q, 0.4f};
 #endif
-                    if (EIK && t > 0) {     // the second-order streams of the tile whose epilogue follows this GEMM tile
+                    }
+                    if (t == kNT - 1) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) argt[q] = *reinterpret_cast<const f32x4*>(apl + 32 * (kNT - 1) + 8 * q + 4 * half);
+                    }
+                    if (EIK && t > 0) {     // the second-order streams of the same tile
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             tgb[q] = *reinterpret_cast<const f32x4*>(tpl + 32 * (t - 1) + 8 * q + 4 * half);
@@ -342,16 +401,20 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                     }
                 };
                 f32x16 acc = zero16();
+                [[maybe_unused]] const unsigned long long c0 = BT_NOW();
                 acc = big_tile<false, 0>(pipe.wcur, pipe.wnxt, lane, in, acc, ring, NoEpilogue(), sync_and_fetch, issue_piece);
+                [[maybe_unused]] const unsigned long long c1 = BT_NOW();
                 pipe.advance();
                 if (t > 0) {
-                    epilogue(t - 1, prev, argb[(t - 1) & 1], out[t - 1]);
+                    epilogue(t - 1, prev, argb, out[t - 1]);
                     asm volatile("" : "+a"(out[t - 1]));
                 }
                 prev = acc;
+#ifdef E3DGE_BWD_TIMING
+                t_tile += c1 - c0; t_epi += BT_NOW() - c1;
+#endif
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(argb[(kNT - 1) & 1][q]));
+            [[maybe_unused]] const unsigned long long ct0 = BT_NOW();
             if (EIK) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -360,12 +423,15 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                 }
             }
             __syncthreads();       // the last two epilogues of a layer have no weight-chunk barrier between them
-            epilogue(kNT - 1, prev, argb[(kNT - 1) & 1], out[kNT - 1]);
+            epilogue(kNT - 1, prev, argt, out[kNT - 1]);
 #pragma unroll
             for (int tt = 0; tt < kNT; ++tt) {
                 in[tt] = out[tt];
                 asm volatile("" : "+a"(in[tt]));
             }
+#ifdef E3DGE_BWD_TIMING
+            t_tail += BT_NOW() - ct0;
+#endif
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -374,6 +440,14 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
     __syncthreads();
     float* const my_partial = a.partials + (int64_t)blockIdx.x * (9 * 2 * kWidth);
     for (int i = tid; i < 9 * 2 * kWidth; i += kThreads) my_partial[i] = acc_s[i];
+#ifdef E3DGE_BWD_TIMING
+    // profiling build: the first floats of this workgroup's slice carry wave 0's cycle counts (tools/bwd_timing.py)
+    __syncthreads();
+    if (tid == 0) {
+        my_partial[0] = (float)(BT_NOW() - t_begin); my_partial[1] = (float)t_pro; my_partial[2] = (float)t_tile;
+        my_partial[3] = (float)t_epi; my_partial[4] = (float)t_tail; my_partial[5] = (float)pipe.t_vm; my_partial[6] = (float)pipe.t_bar;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -455,6 +529,8 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
 
         // ---- first layer of the chain (no GEMM) ----
         {
+            int half_p = half;                       // opaque: keeps the address math of this block inside the loop
+            asm volatile("" : "+v"(half_p));         // (see siren_bwd_kernel)
             const int l0 = TANGENT ? 0 : 7;
             const float* __restrict__ gl = gam_s + l0 * kWidth;
             float sx = 0.f, sy = 0.f, sz = 0.f, seed = 1.0f;
@@ -468,7 +544,7 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
             for (int t = 0; t < kNT; ++t) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int o = 32 * t + 8 * q + 4 * half;
+                    const int o = 32 * t + 8 * q + 4 * half_p;
                     const f32x4 ar = *reinterpret_cast<const f32x4*>(ap + l0 * kWidth + o);
                     const f32x4 g4 = *reinterpret_cast<const f32x4*>(gl + o);
                     f32x4 x4;
@@ -557,12 +633,14 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
 
         // ---- sdf chain: e = s W_0^T g_0 ----
         if (!TANGENT) {
+            int half_e = half;
+            asm volatile("" : "+v"(half_e));
             float ex = 0.f, ey = 0.f, ez = 0.f;
 #pragma unroll
             for (int t = 0; t < kNT; ++t) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int o = 32 * t + 8 * q + 4 * half;
+                    const int o = 32 * t + 8 * q + 4 * half_e;
                     const f32x4 wx = *reinterpret_cast<const f32x4*>(w0_s + o), wy = *reinterpret_cast<const f32x4*>(w0_s + kWidth + o),
                                 wz = *reinterpret_cast<const f32x4*>(w0_s + 2 * kWidth + o);
 #pragma unroll

@@ -72,3 +72,39 @@ def test_fused_vs_eager_same_gpu(batch):
            hip_train_rays_per_s=rays / t['hip_train_ms'] * 1e3, eager_train_rays_per_s=rays / t['eager_train_ms'] * 1e3)
     assert rel <= 2e-3      # two fp32 evaluations of an ill-conditioned sum; each is checked against float64 elsewhere
     assert t['hip_fwd_ms'] < t['eager_fwd_ms'] and t['hip_train_ms'] < t['eager_train_ms'], t
+
+
+def test_stage1_step_fused_vs_eager_same_gpu():
+    """C5 (renderer part): 64x64x18, eikonal term over all ray samples + loss on it (double backward), eager = the
+    restatement with autograd.grad(create_graph=True) exactly as the reference does it, on the same GPU."""
+    res, S = 64, 18
+    sd = full_state_dict(res=res, n_samples=S)[1]
+    sd_dev = {k: v.to(DEV) for k, v in sd.items()}
+    r = make_renderer(sd, res, S)
+    wr, _ = syn.synthetic_inputs(1, seed=7, device=DEV)
+    poses, focal, near, far, _ = generate_camera_params(res, DEV, locations=torch.zeros(1, 2, device=DEV))
+
+    def loss_of(rgb, eik):
+        return (rgb ** 2).mean() + ((eik.norm(dim=-1) - 1) ** 2).mean()
+
+    def hip_step():
+        s = wr.clone().requires_grad_(True)
+        o = r(poses, focal, near, far, styles=s, return_eikonal=True)
+        loss_of(o['gen_thumb_imgs'], o['eikonal_term']).backward()
+        return s.grad
+
+    def eager_step():
+        s = wr.clone().requires_grad_(True)
+        ro = renderer_ref.render(sd_dev, poses, focal, near, far, s, res=res, n_samples=S)
+        x = ro['points'].detach().clone().requires_grad_(True)
+        raw = renderer_ref.query_points(sd_dev, x, None, s)
+        eik = torch.autograd.grad(raw[..., 3:4], x, torch.ones_like(raw[..., 3:4]), create_graph=True)[0]
+        loss_of(ro['gen_thumb_imgs'], eik).backward()
+        return s.grad
+
+    ga, gb = hip_step(), eager_step()
+    rel = float((ga - gb).abs().max() / gb.abs().max())
+    t = dict(hip_ms=timed(hip_step, n=5, warm=2), eager_ms=timed(eager_step, n=5, warm=2))
+    record("stage1_fused_vs_eager_same_gpu", grad_rel_diff=rel, **t, speedup=t['eager_ms'] / t['hip_ms'])
+    assert rel <= 2e-3
+    assert t['hip_ms'] < t['eager_ms'], t
