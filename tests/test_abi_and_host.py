@@ -54,6 +54,36 @@ int main(void) {
                    R.rgb.offset, R.dists.offset]
 
 
+def test_render_bwd_args_struct_layout_matches_c():
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "e3dge_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(E3dgeRenderBwdArgs), offsetof(E3dgeRenderBwdArgs, d_rgb_map),
+         offsetof(E3dgeRenderBwdArgs, tang), offsetof(E3dgeRenderBwdArgs, sigmoid_beta),
+         offsetof(E3dgeRenderBwdArgs, force_background), offsetof(E3dgeRenderBwdArgs, dstyles));
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), c, "-o", exe], check=True)
+        got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    R = _lib.RenderBwdArgs
+    assert got == [ctypes.sizeof(R), R.d_rgb_map.offset, R.tang.offset, R.sigmoid_beta.offset,
+                   R.force_background.offset, R.dstyles.offset]
+    # argument validation of the training entry points happens before any launch
+    lib = _lib.load()
+    assert lib.e3dge_siren_render_bwd(None, None) == -1
+    bad = _lib.RenderBwdArgs(batch=1, height=4, width=4, n_samples=0)
+    assert lib.e3dge_siren_render_bwd(ctypes.byref(bad), None) == -1 and b"n_samples" in lib.e3dge_last_error()
+    assert lib.e3dge_siren_bwd(None, None, None, None, None, None, None, None, None, None, 1, 10, None, None, None, None) == -1
+    assert lib.e3dge_siren_sdf_grad(None, None, None, None, 1.0, 1, 10, None, None, None) == -1
+    assert lib.e3dge_siren_tangent(None, None, None, None, 1.0, 1, 10, None, None) == -1
+    assert lib.e3dge_siren_bwd_partial_floats(2, 1000) == 2 * 8 * 9 * 2 * 256     # 8 sub-tiles -> 8 workgroups per image
+
+
 def test_host_helpers_that_need_no_gpu(lib):
     assert lib.e3dge_upfirdn2d_out_size(129, 1, 1, 1, 1, 4) == 128     # Blur after the 64->129 transposed conv
     assert lib.e3dge_upfirdn2d_out_size(64, 2, 1, 2, 1, 4) == 128      # skip Upsample
