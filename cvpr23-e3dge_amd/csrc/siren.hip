@@ -111,80 +111,26 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
         for (int i = tid; i < kRMax * kFPitch; i += kThreads) feat_acc[i] = 0.0f;
     }
 
-    // ---- weight chunk pipeline ----
-    // 32 pieces of 1 KiB per chunk, 8 per wave.  The LDS side is wave-uniform (SGPR -> M0), the global side is one
-    // per-lane base plus immediates; chunk / buffer indices are running scalar counters (no division per tile).
-    const int total_chunks = n_sub * kChunksPerPass;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const float* const src_lane = packed + (F16 ? kOffBig16 : kOffBig) + wave_u * 2048 + lane * 4;
-    int g_issue = 0, issue_chunk_idx = 0, issue_buf = 0;
-    // One of the 8 DMA pieces of the chunk being issued.  Issuing an LDS-DMA costs ~60-185 cycles of issue time
-    // (measured: ~600-1000 cycles per tile when the 8 are issued in a burst), so the pieces are handed out one per
-    // MFMA group after the chunk barrier, where they issue in the shadow of the MFMAs.
-    auto issue_piece = [&](int i) {
-        if (g_issue < total_chunks) {
-            const float* src = src_lane + (int64_t)issue_chunk_idx * kChunkFloats + (i >> 2) * 1024;
-            float* dst = wbuf + issue_buf * kChunkFloats + wave_u * 2048 + (i >> 2) * 1024;
-            switch (i & 3) {                    // i is a compile-time constant at every call site
-                case 0: glds16_off<0>(src, dst); break;
-                case 1: glds16_off<1024>(src, dst); break;
-                case 2: glds16_off<2048>(src, dst); break;
-                default: glds16_off<3072>(src, dst); break;
-            }
-        }
-        if (i == 7) {
-            ++g_issue;
-            issue_chunk_idx = (issue_chunk_idx + 1 == kChunksPerPass) ? 0 : issue_chunk_idx + 1;
-            issue_buf = (issue_buf + 1 == kNBuf) ? 0 : issue_buf + 1;
-        }
-    };
-    auto issue_chunk = [&]() {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) issue_piece(i);
-    };
-    for (int i = 0; i < kNBuf - 1; ++i) issue_chunk();
-    // Chunk protocol (3 buffers).  chunk_sync() runs early in every tile g: each wave drains its own DMA (that is
-    // chunk g+1, issued one whole tile earlier), the barrier publishes it to the other waves and proves that
-    // everybody has left tile g-1, whose buffer the DMA of chunk g+2 (pieces issued over the following MFMA groups)
-    // may now overwrite.  Hence chunk g+1 is complete and visible before tile g+1 starts: tiles need no barrier,
-    // wait or LDS-latency bubble between them.
-#ifdef E3DGE_PHASE_TIMING
-    unsigned long long t_vm = 0, t_bar = 0, t_iss = 0;
-#endif
-    auto chunk_sync = [&]() {
-#ifdef E3DGE_PHASE_TIMING
-        const unsigned long long c0 = __builtin_readcyclecounter();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long c1 = __builtin_readcyclecounter();
-        __syncthreads();
-        const unsigned long long c2 = __builtin_readcyclecounter();
-        t_vm += c1 - c0; t_bar += c2 - c1;
-#else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#endif
-    };
-    int use_buf = 0;      // buffer of the chunk being consumed
-    const float* wcur = wbuf;
-    const float* wnxt = wbuf + kChunkFloats;
-    auto advance_chunk = [&]() {
-        use_buf = (use_buf + 1 == kNBuf) ? 0 : use_buf + 1;
-        wcur = wnxt;
-        wnxt = wbuf + ((use_buf + 1 == kNBuf) ? 0 : use_buf + 1) * kChunkFloats;
-    };
+    // ---- weight chunk pipeline (ChunkPipe, siren_common.h) ----
+    ChunkPipe pipe;
+    pipe.init(wbuf, packed + (F16 ? kOffBig16 : kOffBig), wave, lane, 0, kChunksPerPass);
+    pipe.prime();
+    auto issue_piece = [&](int i) { pipe.issue_piece(i); };
+    auto chunk_sync = [&]() { pipe.sync(); };
+    auto advance_chunk = [&]() { pipe.advance(); };
     // first chunk (and the LDS parameter blocks staged above) visible to everyone; prime the fragment ring
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x4 ring[kRing];
     u32x4 ringH[kRing16], ringL[kRing16];
     if (!F16) {
-        ring[0] = reinterpret_cast<const f32x4*>(wcur)[lane];
-        ring[1] = reinterpret_cast<const f32x4*>(wcur)[64 + lane];
+        ring[0] = reinterpret_cast<const f32x4*>(pipe.wcur)[lane];
+        ring[1] = reinterpret_cast<const f32x4*>(pipe.wcur)[64 + lane];
     } else {
 #pragma unroll
         for (int g = 0; g < kRing16 - 1; ++g) {
-            ringH[g] = reinterpret_cast<const u32x4*>(wcur)[(g * 2 + 0) * 64 + lane];
-            ringL[g] = reinterpret_cast<const u32x4*>(wcur)[(g * 2 + 1) * 64 + lane];
+            ringH[g] = reinterpret_cast<const u32x4*>(pipe.wcur)[(g * 2 + 0) * 64 + lane];
+            ringL[g] = reinterpret_cast<const u32x4*>(pipe.wcur)[(g * 2 + 1) * 64 + lane];
         }
     }
 
@@ -307,14 +253,14 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 for (int t = 0; t < kNT; ++t) {
                     f32x16 acc = zero16();
                     if (t == 0) {
-                        acc = big_tile<false, 0>(wcur, wnxt, lane, in, acc, ring, NoEpilogue(), chunk_sync, issue_piece);
+                        acc = big_tile<false, 0>(pipe.wcur, pipe.wnxt, lane, in, acc, ring, NoEpilogue(), chunk_sync, issue_piece);
                     } else {
                         // FiLM (gamma, beta') of the 4 registers being processed, and of the NEXT 4 (fetched from LDS one quad
                         // ahead: a read issued right before its use exposes the LDS latency four times per tile)
                         const float* __restrict__ fl = film_l + 32 * (t - 1) + 4 * half;
                         f32x4 g4 = *reinterpret_cast<const f32x4*>(fl), b4 = *reinterpret_cast<const f32x4*>(fl + kWidth);
                         f32x4 g4n = g4, b4n = b4, sarg;
-                        acc = big_tile<false, E3DGE_SPREAD_STD>(wcur, wnxt, lane, in, acc, ring, [&](int r) {
+                        acc = big_tile<false, E3DGE_SPREAD_STD>(pipe.wcur, pipe.wnxt, lane, in, acc, ring, [&](int r) {
                             if ((r & 3) == 0 && r < 12) {
                                 g4n = *reinterpret_cast<const f32x4*>(fl + 8 * ((r >> 2) + 1));
                                 b4n = *reinterpret_cast<const f32x4*>(fl + kWidth + 8 * ((r >> 2) + 1));
@@ -349,13 +295,13 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 for (int t = 0; t < kNT; ++t) {
                     f32x16 acc = zero16(), accb = zero16();
                     if (t == 0) {
-                        big_tile_f16<false>(wcur, wnxt, lane, inH, inL, acc, accb, ringH, ringL, NoEpilogue(), chunk_sync, issue_piece);
+                        big_tile_f16<false>(pipe.wcur, pipe.wnxt, lane, inH, inL, acc, accb, ringH, ringL, NoEpilogue(), chunk_sync, issue_piece);
                     } else {
                         float xe = 0.f;
                         const float* __restrict__ fl = film_l + 32 * (t - 1) + 4 * half;
                         f32x4 g4 = *reinterpret_cast<const f32x4*>(fl), b4 = *reinterpret_cast<const f32x4*>(fl + kWidth);
                         f32x4 g4n = g4, b4n = b4, sarg;
-                        big_tile_f16<false>(wcur, wnxt, lane, inH, inL, acc, accb, ringH, ringL, [&](int r) {
+                        big_tile_f16<false>(pipe.wcur, pipe.wnxt, lane, inH, inL, acc, accb, ringH, ringL, [&](int r) {
                             if ((r & 3) == 0 && r < 12) {       // FiLM of the next quad, one quad ahead of its use
                                 g4n = *reinterpret_cast<const f32x4*>(fl + 8 * ((r >> 2) + 1));
                                 b4n = *reinterpret_cast<const f32x4*>(fl + kWidth + 8 * ((r >> 2) + 1));
@@ -575,10 +521,10 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 f32x16 acc = zero16();
                 if (!F16) {
                     if (t == 0) {
-                        acc = big_tile<true, 0>(wcur, wnxt, lane, in, acc, ring, NoEpilogue(), chunk_sync, issue_piece);
+                        acc = big_tile<true, 0>(pipe.wcur, pipe.wnxt, lane, in, acc, ring, NoEpilogue(), chunk_sync, issue_piece);
                     } else {
                         epi_begin(t - 1);
-                        acc = big_tile<true, E3DGE_SPREAD_VIEW>(wcur, wnxt, lane, in, acc, ring, epi_r, chunk_sync, issue_piece);
+                        acc = big_tile<true, E3DGE_SPREAD_VIEW>(pipe.wcur, pipe.wnxt, lane, in, acc, ring, epi_r, chunk_sync, issue_piece);
                         epi_end();
                     }
                     acc = mfma32(a0, wvt[(t * 2 + 0) * 64 + lane], acc);
@@ -586,10 +532,10 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 } else {
                     f32x16 accb = zero16();
                     if (t == 0) {
-                        big_tile_f16<true>(wcur, wnxt, lane, inH, inL, acc, accb, ringH, ringL, NoEpilogue(), chunk_sync, issue_piece);
+                        big_tile_f16<true>(pipe.wcur, pipe.wnxt, lane, inH, inL, acc, accb, ringH, ringL, NoEpilogue(), chunk_sync, issue_piece);
                     } else {
                         epi_begin(t - 1);
-                        big_tile_f16<true>(wcur, wnxt, lane, inH, inL, acc, accb, ringH, ringL, epi_r, chunk_sync, issue_piece);
+                        big_tile_f16<true>(pipe.wcur, pipe.wnxt, lane, inH, inL, acc, accb, ringH, ringL, epi_r, chunk_sync, issue_piece);
                         epi_end();
                     }
                     // view-direction tail in fp32, carrying the same 128 scale as the streamed weights
@@ -745,10 +691,11 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
             for (int i = 0; i < 18; ++i)
                 a.dists[i] = (i % 6 == 0) ? (float)(i / 6 ? tstamp[i] - tstamp[i - 1] : 0) : (float)(tstamp[i] - tstamp[i - 1]);
         if (blockIdx.x == 0 && (tid & 63) == 0 && a.dists) {
-            a.dists[18 + wave * 3 + 0] = (float)t_vm; a.dists[18 + wave * 3 + 1] = (float)t_bar; a.dists[18 + wave * 3 + 2] = (float)t_iss;
+            a.dists[18 + wave * 3 + 0] = (float)pipe.t_vm; a.dists[18 + wave * 3 + 1] = (float)pipe.t_bar; a.dists[18 + wave * 3 + 2] = 0.0f;
         }
 #endif
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the pipeline fetches two chunks past the end of the work
 }
 
 // ---------------------------------------------------------------------------------------------

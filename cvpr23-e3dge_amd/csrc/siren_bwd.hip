@@ -75,67 +75,6 @@ __device__ __forceinline__ void sincos_hw_f32(float x, float& sn, float& cs) {
     cs = __builtin_amdgcn_cosf(r);
 }
 
-// The weight-chunk pipeline shared by the kernels of this file: 32 KiB chunks (one 32-row output tile x K=256) of a
-// fragment image stream L2 -> LDS through three buffers, eight 16-B LDS-DMA pieces per lane and chunk, issued from
-// inside the MFMA stream of the tile two chunks earlier.  Same protocol as the forward kernel (siren.hip).
-struct ChunkPipe {
-    float* wbuf;
-    const float* src_lane;
-    int wave_u, total, g_issue, idx, first, count, buf, use_buf;
-    const float* wcur;
-    const float* wnxt;
-    __device__ __forceinline__ void init(float* wbuf_, const float* image, int wave, int lane, int first_, int count_, int total_) {
-        wbuf = wbuf_;
-        wave_u = __builtin_amdgcn_readfirstlane(wave);
-        src_lane = image + wave_u * 2048 + lane * 4;
-        first = first_; count = count_; total = total_;
-        g_issue = 0; idx = first_; buf = 0; use_buf = 0;
-        wcur = wbuf_; wnxt = wbuf_ + kChunkFloats;
-    }
-    __device__ __forceinline__ void issue_piece(int i) {
-        if (g_issue < total) {
-            const float* src = src_lane + (int64_t)idx * kChunkFloats + (i >> 2) * 1024;
-            float* dst = wbuf + buf * kChunkFloats + wave_u * 2048 + (i >> 2) * 1024;
-            switch (i & 3) {
-                case 0: glds16_off<0>(src, dst); break;
-                case 1: glds16_off<1024>(src, dst); break;
-                case 2: glds16_off<2048>(src, dst); break;
-                default: glds16_off<3072>(src, dst); break;
-            }
-        }
-        if (i == 7) {
-            ++g_issue;
-            idx = (idx + 1 == first + count) ? first : idx + 1;
-            buf = (buf + 1 == kNBuf) ? 0 : buf + 1;
-        }
-    }
-    __device__ __forceinline__ void prime() {
-        for (int c = 0; c < kNBuf - 1; ++c)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) issue_piece(i);
-    }
-#ifdef E3DGE_BWD_TIMING
-    unsigned long long t_vm = 0, t_bar = 0;
-    __device__ __forceinline__ void sync() {
-        const unsigned long long c0 = __builtin_readcyclecounter();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long c1 = __builtin_readcyclecounter();
-        __syncthreads();
-        t_vm += c1 - c0; t_bar += __builtin_readcyclecounter() - c1;
-    }
-#else
-    __device__ __forceinline__ void sync() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-#endif
-    __device__ __forceinline__ void advance() {
-        use_buf = (use_buf + 1 == kNBuf) ? 0 : use_buf + 1;
-        wcur = wnxt;
-        wnxt = wbuf + ((use_buf + 1 == kNBuf) ? 0 : use_buf + 1) * kChunkFloats;
-    }
-};
-
 // EIK = false: gradient of a loss that reaches the network through (feat, rgb, sdf).
 // EIK = true : additionally the loss depends on the eikonal term e = d sdf / d x (get_eikonal_term :796-802, i.e. the
 //   reference's create_graph=True double backward).  With v = dL/de held fixed, dL = d(v.e) and v.e is the tangent of
@@ -188,7 +127,7 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
     };
 
     ChunkPipe pipe;
-    pipe.init(wbuf, packed + kOffBigT, wave, lane, 0, kChunksPerPass, n_sub * kChunksPerPass);
+    pipe.init(wbuf, packed + kOffBigT, wave, lane, 0, kChunksPerPass);
     pipe.prime();
     auto issue_piece = [&](int i) { pipe.issue_piece(i); };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -508,7 +447,7 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
 
     constexpr int kChainChunks = 7 * kNT;             // layers 1..7
     ChunkPipe pipe;
-    pipe.init(wbuf, packed + (TANGENT ? kOffBig : kOffBigT), wave, lane, TANGENT ? 0 : kNT, kChainChunks, n_sub * kChainChunks);
+    pipe.init(wbuf, packed + (TANGENT ? kOffBig : kOffBigT), wave, lane, TANGENT ? 0 : kNT, kChainChunks);
     pipe.prime();
     auto issue_piece = [&](int i) { pipe.issue_piece(i); };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

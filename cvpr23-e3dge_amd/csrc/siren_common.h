@@ -142,6 +142,92 @@ __device__ __forceinline__ void glds16_off(const float* gsrc, float* ldst) {
                                      (__attribute__((address_space(3))) void*)ldst, 16, OFF_BYTES, 0);
 }
 
+// The form the kernels use: scalar 64-bit base + per-lane 32-bit byte offset + immediate, LDS destination through M0.
+// hipcc never selects this addressing mode for the builtin (it builds a 64-bit VGPR address per piece: ~10 instructions
+// and two VGPRs each time); written out, a piece is s_mov m0 / s_nop / global_load_lds.  No other code in these kernels
+// uses M0.  The compiler does not count these in vmcnt; every consumer waits with an explicit vmcnt(0).
+template <int OFF_BYTES>
+__device__ __forceinline__ void glds16_saddr(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                 :: "v"(voff), "s"(sbase), "s"(lds_addr), "n"(OFF_BYTES) : "memory");
+}
+
+// The weight-chunk pipeline shared by every kernel: 32 KiB chunks (one 32-row output tile x K=256) of a fragment image
+// stream L2 -> LDS through kNBuf buffers, eight 16-B LDS-DMA pieces per lane and chunk, handed out one per MFMA group
+// pair inside the tile two chunks earlier.  sync() runs early in every tile g: each wave drains its own DMA (chunk g+1,
+// issued one whole tile earlier), the barrier publishes it and proves that everybody has left tile g-1, whose buffer
+// the DMA of chunk g+2 may now overwrite.  Chunk indices wrap inside [first, first+count): the two chunks fetched past
+// the end of the work land in buffers nobody reads (kernels end with vmcnt(0)).
+struct ChunkPipe {
+    const char* img;          // image + this wave's 8 KiB slice (wave-uniform)
+    const char* src;          // chunk being issued
+    uint32_t voff;            // lane * 16
+    uint32_t lds_base;        // LDS byte address of wbuf + this wave's slice
+    uint32_t lds_dst;         // ... of the buffer being filled
+    int idx, first, count, buf, use_buf;
+    float* wbuf;
+    const float* wcur;
+    const float* wnxt;
+#if defined(E3DGE_PHASE_TIMING) || defined(E3DGE_BWD_TIMING)
+    unsigned long long t_vm, t_bar;
+#endif
+    __device__ __forceinline__ void init(float* wbuf_, const float* image, int wave, int lane, int first_, int count_) {
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        wbuf = wbuf_;
+        img = reinterpret_cast<const char*>(image) + wave_u * 8192;
+        voff = (uint32_t)lane * 16u;
+        lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) float*)wbuf_ + (uint32_t)wave_u * 8192u;
+        first = first_; count = count_;
+        idx = first_; buf = 0; use_buf = 0;
+        src = img + (size_t)idx * (kChunkFloats * 4);
+        lds_dst = lds_base;
+        wcur = wbuf_; wnxt = wbuf_ + kChunkFloats;
+#if defined(E3DGE_PHASE_TIMING) || defined(E3DGE_BWD_TIMING)
+        t_vm = 0; t_bar = 0;
+#endif
+    }
+    __device__ __forceinline__ void issue_piece(int i) {     // i is a compile-time constant at every call site
+#ifndef E3DGE_ABL_NODMA
+        const char* s = src + (i >> 2) * 4096;
+        const uint32_t d = lds_dst + (uint32_t)(i >> 2) * 4096u;
+        switch (i & 3) {
+            case 0: glds16_saddr<0>(s, voff, d); break;
+            case 1: glds16_saddr<1024>(s, voff, d); break;
+            case 2: glds16_saddr<2048>(s, voff, d); break;
+            default: glds16_saddr<3072>(s, voff, d); break;
+        }
+#endif
+        if (i == 7) {
+            idx = (idx + 1 == first + count) ? first : idx + 1;
+            src = img + (size_t)idx * (kChunkFloats * 4);
+            buf = (buf + 1 == kNBuf) ? 0 : buf + 1;
+            lds_dst = lds_base + (uint32_t)buf * (kChunkFloats * 4);
+        }
+    }
+    __device__ __forceinline__ void prime() {
+        for (int c = 0; c < kNBuf - 1; ++c)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) issue_piece(i);
+    }
+    __device__ __forceinline__ void sync() {
+#if defined(E3DGE_PHASE_TIMING) || defined(E3DGE_BWD_TIMING)
+        const unsigned long long c0 = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long c1 = __builtin_readcyclecounter();
+        __syncthreads();
+        t_vm += c1 - c0; t_bar += __builtin_readcyclecounter() - c1;
+#else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#endif
+    }
+    __device__ __forceinline__ void advance() {
+        use_buf = (use_buf + 1 == kNBuf) ? 0 : use_buf + 1;
+        wcur = wnxt;
+        wnxt = wbuf + ((use_buf + 1 == kNBuf) ? 0 : use_buf + 1) * kChunkFloats;
+    }
+};
+
 // Two sines, both with an exact FMA Cody-Waite range reduction (|x| < ~1e5):
 //  * sin_hw_f32 (default, 6 VALU ops): reduce to |r| <= pi, hardware v_sin_f32 on r / 2pi.  Max abs error 3.8e-7.
 //  * sin_poly_f32 (13 VALU ops): reduce to |r| <= pi/2, degree-9 minimax odd polynomial (4.7e-9 in exact
