@@ -67,10 +67,7 @@ __device__ __forceinline__ void reduce8_over_lanes(const float (&v)[8], float (&
 
 // sin and cos of a saved argument with one shared range reduction
 __device__ __forceinline__ void sincos_hw_f32(float x, float& sn, float& cs) {
-    const float kf = rintf(x * 0.159154943091895336f);
-    float r = fmaf(-kf, 6.2831854820251465f, x);
-    r = fmaf(-kf, -1.7484555314695172e-07f, r);
-    r *= 0.159154943091895336f;
+    const float r = revolutions_f32(x);
     sn = __builtin_amdgcn_sinf(r);
     cs = __builtin_amdgcn_cosf(r);
 }

@@ -118,7 +118,12 @@ struct HiLo { unsigned h, l; };
 __device__ __forceinline__ HiLo split2(float x0, float x1) {
     HiLo p;
     p.h = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-    p.l = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0 - f16lo(p.h), x1 - f16hi(p.h)));
+    // residual x - (float)hi in ONE instruction per value: v_fma_mix_f32 reads the f16 half directly (the compiler emits
+    // v_cvt_f32_f16 + v_sub_f32 for the C expression; the product with -1 is exact, so the result is the same bits)
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(p.h), "v"(x0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(p.h), "v"(x1));
+    p.l = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
     return p;
 }
 // (vector elements cannot be bound to references, hence the macro)
@@ -229,25 +234,23 @@ struct ChunkPipe {
 };
 
 // Two sines, both with an exact FMA Cody-Waite range reduction (|x| < ~1e5):
-//  * sin_hw_f32 (default, 6 VALU ops): reduce to |r| <= pi, hardware v_sin_f32 on r / 2pi.  Max abs error 3.8e-7.
+//  * sin_hw_f32 (default, 5 VALU ops): x/2pi reduced to [-0.5, 0.5] revolutions, hardware v_sin_f32.  Max abs error 3e-7.
 //  * sin_poly_f32 (13 VALU ops): reduce to |r| <= pi/2, degree-9 minimax odd polynomial (4.7e-9 in exact
 //    arithmetic), sign from k's parity.  Max abs error 1.2e-7.
 // fp32 MFMA and fp32 VALU do not overlap on gfx950, so every VALU op of the epilogue is paid in full; the
 // renderer's parity against the reference is the same with either (features ~1e-5, the summation-order noise).
 // -DE3DGE_POLY_SINE selects the polynomial for the kernels.
-__device__ __forceinline__ float sin_hw_f32(float x) {
-    const float kf = rintf(x * 0.159154943091895336f);
-    float r = fmaf(-kf, 6.2831854820251465f, x);
-    r = fmaf(-kf, -1.7484555314695172e-07f, r);
-    return __builtin_amdgcn_sinf(r * 0.159154943091895336f);
+// x / 2pi - rint(x / 2pi) in [-0.5, 0.5] to one rounding: the first product only picks the period, the fused
+// multiply-add re-forms it exactly, the second adds the low part of 1/2pi.  4 ops; 3.0e-8 revolutions (1.9e-7 rad) max
+// error over |x| < 80 -- the subtract-2pi-multiples form needed 5 ops for 3.3e-7 rad.
+__device__ __forceinline__ float revolutions_f32(float x) {
+    const float kf = rintf(x * 0.15915494f);
+    float r = fmaf(x, 0.15915494f, -kf);
+    return fmaf(x, 6.4206382e-09f, r);
 }
-// cos with the same exact reduction (backward kernels: d/dx sin = cos of the SAVED argument)
-__device__ __forceinline__ float cos_hw_f32(float x) {
-    const float kf = rintf(x * 0.159154943091895336f);
-    float r = fmaf(-kf, 6.2831854820251465f, x);
-    r = fmaf(-kf, -1.7484555314695172e-07f, r);
-    return __builtin_amdgcn_cosf(r * 0.159154943091895336f);
-}
+__device__ __forceinline__ float sin_hw_f32(float x) { return __builtin_amdgcn_sinf(revolutions_f32(x)); }
+// cos of the SAVED argument (backward kernels: d/dx sin)
+__device__ __forceinline__ float cos_hw_f32(float x) { return __builtin_amdgcn_cosf(revolutions_f32(x)); }
 __device__ __forceinline__ float sin_poly_f32(float x) {
     const float kf = rintf(x * 0.318309886183790672f);
     float r = fmaf(-kf, 3.1415927410125732f, x);
