@@ -329,7 +329,10 @@ __device__ __forceinline__ f32x16 big_tile(const float* __restrict__ wchunk, con
 // The same contraction on the f16 matrix pipe: fp32 operands split into f16 hi + lo, three products per k-step
 // (hi*hi, lo_w*hi_a, hi_w*lo_a) into one fp32 accumulator.  16 k-steps of K=16 per tile = 48 MFMAs of 32
 // cycles (1536 vs 8192 for fp32), and this pipe runs concurrently with the VALU, so the epilogue hides under it.
-constexpr int kRing16 = 4;        // k-steps whose (hi, lo) weight fragments are held: 1 consumed + 3 in flight
+#ifndef E3DGE_RING16
+#define E3DGE_RING16 4
+#endif
+constexpr int kRing16 = E3DGE_RING16;   // k-steps whose (hi, lo) weight fragments are held: 1 consumed + the rest in flight
 constexpr int kSyncStep16 = 2;    // k-step after which the chunk barrier + next DMA issue happen
 
 // Ablation switches for tools/ablate.sh (timing experiments only -- results are wrong when any is defined):
