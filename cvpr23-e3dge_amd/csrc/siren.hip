@@ -144,7 +144,14 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
     for (int i = 0; i < 24; ++i) tstamp[i] = 0;
 #endif
 
+    const int tid_k = tid;
     for (int sub = 0; sub < n_sub; ++sub) {
+        // Opaque per-iteration copies of the lane indices: every address derived from them is then recomputed inside
+        // the sub-tile instead of being hoisted out of this loop, held across the MFMA chain (where no register is free)
+        // and spilled -- the reloads are vmcnt-ordered behind the LDS-DMA pieces and stall on them.
+        int tid_o = tid_k;
+        asm volatile("" : "+v"(tid_o));
+        const int tid = tid_o, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
         PHASE_MARK(0);
         // =====================================================================================
         // 1. this lane's point
@@ -443,7 +450,10 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
         // per-register (= per point row) compositing weight and ray slot of this wave's 32-point slab
         // Composite weights of this wave's 32-point slab, split by the ray they belong to.  With S >= 16 a slab
         // touches at most 3 rays; their boundaries inside the slab are at rows b1 and b1 + S.
-        float wq0[16], wq1[16], wq2[16];
+        // They are the same for all 32 lanes of a half, and 48 registers of them next to the 48 rgb partials and the
+        // 128 activation registers made the view layer spill -- with every reload ordered behind the LDS-DMA pieces
+        // in vmcnt.  They live in LDS instead ([slot][half][16 rows] per wave) and are read back a quad at a time.
+        float* const wq_s = smem + kLdsWq + wave * (kMaxSlots * 2 * 16);
         int slab_first_ray = 0, slab_nslots = 0;
         if (MODE == 0) {
             const int slab_lo = sub * kTilePts + 32 * wave;
@@ -453,13 +463,12 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 slab_nslots = (slab_hi - 1) / S - slab_first_ray + 1;
             }
             const int b1 = (slab_first_ray + 1) * S - slab_lo, b2 = b1 + S;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row_of(r, half);
+            if (col < 16) {                                       // lane (col = r, half) owns row row_of(r, half)
+                const int row = row_of(col, half);
                 const float w = (slab_lo + row < npts) ? wgt_s[32 * wave + row] : 0.0f;
-                wq0[r] = (row < b1) ? w : 0.0f;
-                wq1[r] = (row >= b1 && row < b2) ? w : 0.0f;
-                wq2[r] = (row >= b2) ? w : 0.0f;
+                wq_s[(0 * 2 + half) * 16 + col] = (row < b1) ? w : 0.0f;
+                wq_s[(1 * 2 + half) * 16 + col] = (row >= b1 && row < b2) ? w : 0.0f;
+                wq_s[(2 * 2 + half) * 16 + col] = (row >= b2) ? w : 0.0f;
             }
         }
         float prgb[3][16];
@@ -480,13 +489,23 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
             float fa0 = 0.f, fa1 = 0.f, fa2 = 0.f;
             float e_gm = 0.f, e_bt = 0.f, e_w0 = 0.f, e_w1 = 0.f, e_w2 = 0.f;
             int e_n = 0;
+            const float* __restrict__ wqh = wq_s + half * 16;
+            f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0, q2 = q0, q0n = q0, q1n = q0, q2n = q0;   // composite weights of a row quad
             auto epi_begin = [&](int tp) {
                 e_n = 32 * tp + col;
                 e_gm = film_v[e_n]; e_bt = film_v[kWidth + e_n];
                 e_w0 = wrgb[e_n]; e_w1 = wrgb[kWidth + e_n]; e_w2 = wrgb[2 * kWidth + e_n];
                 fa0 = fa1 = fa2 = 0.f;
+                if (MODE == 0) {
+                    q0 = *reinterpret_cast<const f32x4*>(wqh); q1 = *reinterpret_cast<const f32x4*>(wqh + 32);
+                    q2 = *reinterpret_cast<const f32x4*>(wqh + 64);
+                }
             };
             auto epi_r = [&](int r) {
+                if (MODE == 0 && (r & 3) == 0 && r < 12) {      // next quad, one quad ahead of its use
+                    q0n = *reinterpret_cast<const f32x4*>(wqh + r + 4); q1n = *reinterpret_cast<const f32x4*>(wqh + 32 + r + 4);
+                    q2n = *reinterpret_cast<const f32x4*>(wqh + 64 + r + 4);
+                }
                 const float varg = fmaf(e_gm, pv[r], e_bt);
                 const float h = sin_f32(varg);
                 if (SAVE) {
@@ -497,9 +516,10 @@ __global__ void __launch_bounds__(kThreads) siren_kernel(const SirenK a) {
                 prgb[1][r] = fmaf(e_w1, h, prgb[1][r]);
                 prgb[2][r] = fmaf(e_w2, h, prgb[2][r]);
                 if (MODE == 0) {
-                    fa0 = fmaf(wq0[r], h, fa0);
-                    fa1 = fmaf(wq1[r], h, fa1);
-                    fa2 = fmaf(wq2[r], h, fa2);
+                    fa0 = fmaf(q0[r & 3], h, fa0);
+                    fa1 = fmaf(q1[r & 3], h, fa1);
+                    fa2 = fmaf(q2[r & 3], h, fa2);
+                    if ((r & 3) == 3) { q0 = q0n; q1 = q1n; q2 = q2n; }
                 } else if (a.raw) {
                     const int pr = slab_p0 + row_of(r, half);
                     if (pr < npts) a.raw[((int64_t)b * a.n_pts + pt0 + pr) * 260 + 4 + e_n] = h;

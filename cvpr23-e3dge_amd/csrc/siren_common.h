@@ -75,7 +75,8 @@ constexpr int kLdsPts = kLdsZ + kTilePts;                            // [128][3]
 constexpr int kLdsRgb = kLdsPts + kTilePts * 3;                      // [128][3]
 constexpr int kLdsState = kLdsRgb + kTilePts * 3;                    // [kRMax][12]: T, wsum, depth, xyz3, rgb3
 constexpr int kStateStride = 12;
-constexpr int kLdsFloats = kLdsState + kRMax * kStateStride;
+constexpr int kLdsWq = kLdsState + kRMax * kStateStride;             // [4 waves][3 slots][2 halves][16]: composite weights per row
+constexpr int kLdsFloats = kLdsWq + 4 * kMaxSlots * 2 * 16;
 constexpr int kLdsBytes = kLdsFloats * 4;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 static_assert((kLdsFilm % 4) == 0 && (kLdsHead % 4) == 0 && (kLdsFeat % 4) == 0, "alignment");
