@@ -763,6 +763,26 @@ siren_pack_kernel(float* __restrict__ packed, const float* __restrict__ w_first,
         } else if (e < kOffBig16) {
             const int r = (int)(e - kOffBHead);
             v = (r == 0) ? b_sigma[0] : b_rgb[r - 1];
+        } else if (e >= kOffBigT16) {
+            // transposed f16x3 image: out row kin = 32t + (lane & 31), contraction index nn in the k-slot order of kOffBig16
+            int64_t r = e - kOffBigT16;
+            const int k = r & 3; r >>= 2;
+            const int lane = r & 63; r >>= 6;
+            const int hl = r & 1; r >>= 1;
+            const int g = r & 15; r >>= 4;
+            const int t = r & 7; r >>= 3;
+            const int L = 8 - (int)r;
+            const int kin = 32 * t + (lane & 31);
+            unsigned word = 0;
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const int j = 2 * k + e2;
+                const int nn = 32 * (g >> 1) + 16 * (g & 1) + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+                const float w = kW16Scale * ((L == 8) ? w_view[(int64_t)nn * 259 + kin] : w_hidden[((int64_t)(L - 1) * kWidth + nn) * kWidth + kin]);
+                const _Float16 hi = (_Float16)w;
+                const _Float16 val = hl ? (_Float16)(w - (float)hi) : hi;
+                word |= (unsigned)__builtin_bit_cast(unsigned short, val) << (16 * e2);
+            }
+            v = __uint_as_float(word);
         } else if (e >= kOffBigT) {
             // transposed fp32 image for the backward chain (siren_common.h)
             int64_t r = e - kOffBigT;

@@ -29,6 +29,7 @@ struct SirenBwdK {
     // second-order (eikonal) streams, both (batch, n_pts, 8, 256), or null
     const float* tang;       // tangent arguments ta_l of the tangent kernel
     const float* rsave;      // r_l = d sdf / d h_l of the sdf-chain kernel
+    int precision;           // E3DGE_PREC_F32 / E3DGE_PREC_F16X3
     float* partials;         // (grid, 9, 2, 256): every workgroup writes its whole slice
     long long n_pts;
     int batch, subtiles_per_wg, wgs_per_img;
@@ -72,6 +73,30 @@ __device__ __forceinline__ void sincos_hw_f32(float x, float& sn, float& cs) {
     cs = __builtin_amdgcn_cosf(r);
 }
 
+// Split-f16 operand of a backward-type GEMM.  The B operand here is a gradient: no bounded range, so each point (a
+// column of B, one lane pair) gets its own power-of-two scale that brings the largest of its 256 values into [1, 2)
+// before the (hi, lo) split; the GEMM is linear per column, so D / (128 * scale) is the unscaled result exactly.
+// Relative to the column's largest element the representation is good to ~2^-24, the same as the forward kernel's
+// activations, and the accumulation is fp32 in both.  `src` = the 256 values of the point held by this lane (standard
+// layout); returns 1 / (kW16Scale * scale) for the epilogue.
+__device__ __forceinline__ float scale_split(const f32x16 (&src)[kNT], u32x4 (&dH)[2 * kNT], u32x4 (&dL)[2 * kNT]) {
+    float m = 0.0f;
+#pragma unroll
+    for (int t = 0; t < kNT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(src[t][r]));
+    m = fmaxf(m, xhalf(m));
+    const unsigned e = (__float_as_uint(m) >> 23) & 255u;               // m in [2^(e-127), 2^(e-126))
+    const float sc = __uint_as_float((254u - e) << 23);                 // m * sc in [1, 2)   (m == 0: sc = 2^127, harmless)
+    const float inv = __uint_as_float((e > 8u ? e - 7u : 1u) << 23);    // 1 / (128 * sc) = 2^(e-134)
+#pragma unroll
+    for (int t = 0; t < kNT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2)
+            SPLIT2_TO(src[t][r] * sc, src[t][r + 1] * sc, dH[2 * t + (r >> 3)][(r & 7) >> 1], dL[2 * t + (r >> 3)][(r & 7) >> 1]);
+    return inv;
+}
+
 // EIK = false: gradient of a loss that reaches the network through (feat, rgb, sdf).
 // EIK = true : additionally the loss depends on the eikonal term e = d sdf / d x (get_eikonal_term :796-802, i.e. the
 //   reference's create_graph=True double backward).  With v = dL/de held fixed, dL = d(v.e) and v.e is the tangent of
@@ -80,7 +105,8 @@ __device__ __forceinline__ void sincos_hw_f32(float x, float& sn, float& cs) {
 //       adj(a_l)     = cos(a_l) adj(h_l) - sin(a_l) ta_l r_l
 //       adj(gamma_l) = adj(a_l) z_l + (ta_l / gamma_l) cos(a_l) r_l ,   adj(beta_l) = adj(a_l)
 //   and the same transposed chain carries adj(h) downwards.
-template <bool EIK>
+// F16 = true: the eight GEMMs run as block-scaled split-f16 contractions (scale_split above) on the f16 matrix pipe.
+template <bool EIK, bool F16>
 __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wbuf = smem + kBwdLdsW;
@@ -124,16 +150,39 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
     };
 
     ChunkPipe pipe;
-    pipe.init(wbuf, packed + kOffBigT, wave, lane, 0, kChunksPerPass);
+    pipe.init(wbuf, packed + (F16 ? kOffBigT16 : kOffBigT), wave, lane, 0, kChunksPerPass);
     pipe.prime();
     auto issue_piece = [&](int i) { pipe.issue_piece(i); };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x4 ring[kRing];
-    ring[0] = reinterpret_cast<const f32x4*>(pipe.wcur)[lane];
-    ring[1] = reinterpret_cast<const f32x4*>(pipe.wcur)[64 + lane];
+    u32x4 ringH[kRing16], ringL[kRing16];
+    if (!F16) {
+        ring[0] = reinterpret_cast<const f32x4*>(pipe.wcur)[lane];
+        ring[1] = reinterpret_cast<const f32x4*>(pipe.wcur)[64 + lane];
+    } else {
+#pragma unroll
+        for (int g = 0; g < kRing16 - 1; ++g) {
+            ringH[g] = reinterpret_cast<const u32x4*>(pipe.wcur)[(g * 2 + 0) * 64 + lane];
+            ringL[g] = reinterpret_cast<const u32x4*>(pipe.wcur)[(g * 2 + 1) * 64 + lane];
+        }
+    }
 
     f32x16 in[kNT], out[kNT];
+    u32x4 inH[2 * kNT], inL[2 * kNT];
+    float inv_scale = 1.0f;                       // F16: undoes the operand scaling of the GEMM being consumed
+    // g_L of a finished layer (out[], fp32) becomes the B operand of the next GEMM
+    auto next_operand = [&]() {
+        if (F16) {
+            inv_scale = scale_split(out, inH, inL);
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < kNT; ++tt) {
+                in[tt] = out[tt];
+                asm volatile("" : "+a"(in[tt]));
+            }
+        }
+    };
 #ifdef E3DGE_BWD_TIMING
     unsigned long long t_tile = 0, t_epi = 0, t_pro = 0, t_tail = 0;
     const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -237,8 +286,7 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                 asm volatile("" : "+a"(out[t]));                       // results wait in AGPRs: the VGPRs stay free for the loads
                 reduce_tile(8, t, rb, rg, slot8 + (t * 4 + wave) * 64);   // own slot per (tile, wave): no barrier needed here
             }
-#pragma unroll
-            for (int tt = 0; tt < kNT; ++tt) in[tt] = out[tt];
+            next_operand();
             // one barrier, then every wave folds its quarter of the eight tiles in fixed order
             __syncthreads();
             fold_pending();                                            // the previous sub-tile's last tile
@@ -338,7 +386,13 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                 };
                 f32x16 acc = zero16();
                 [[maybe_unused]] const unsigned long long c0 = BT_NOW();
-                acc = big_tile<false, 0>(pipe.wcur, pipe.wnxt, lane, in, acc, ring, NoEpilogue(), sync_and_fetch, issue_piece);
+                if (!F16) {
+                    acc = big_tile<false, 0>(pipe.wcur, pipe.wnxt, lane, in, acc, ring, NoEpilogue(), sync_and_fetch, issue_piece);
+                } else {
+                    f32x16 accb = zero16();
+                    big_tile_f16<false>(pipe.wcur, pipe.wnxt, lane, inH, inL, acc, accb, ringH, ringL, NoEpilogue(), sync_and_fetch, issue_piece);
+                    acc = (acc + accb) * inv_scale;
+                }
                 [[maybe_unused]] const unsigned long long c1 = BT_NOW();
                 pipe.advance();
                 if (t > 0) {
@@ -360,11 +414,7 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
             }
             __syncthreads();       // the last two epilogues of a layer have no weight-chunk barrier between them
             epilogue(kNT - 1, prev, argt, out[kNT - 1]);
-#pragma unroll
-            for (int tt = 0; tt < kNT; ++tt) {
-                in[tt] = out[tt];
-                asm volatile("" : "+a"(in[tt]));
-            }
+            next_operand();
 #ifdef E3DGE_BWD_TIMING
             t_tail += BT_NOW() - ct0;
 #endif
@@ -416,7 +466,7 @@ constexpr int kChLdsHead = kChLdsW0 + 3 * kWidth;               // w_sigma[256]
 constexpr int kChLdsFloats = kChLdsHead + kWidth;
 constexpr int kChLdsBytes = kChLdsFloats * 4;
 
-template <bool TANGENT>
+template <bool TANGENT, bool F16>
 __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wbuf = smem + kChLdsW;
@@ -444,16 +494,39 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
 
     constexpr int kChainChunks = 7 * kNT;             // layers 1..7
     ChunkPipe pipe;
-    pipe.init(wbuf, packed + (TANGENT ? kOffBig : kOffBigT), wave, lane, TANGENT ? 0 : kNT, kChainChunks);
+    pipe.init(wbuf, packed + (TANGENT ? (F16 ? kOffBig16 : kOffBig) : (F16 ? kOffBigT16 : kOffBigT)), wave, lane,
+              TANGENT ? 0 : kNT, kChainChunks);
     pipe.prime();
     auto issue_piece = [&](int i) { pipe.issue_piece(i); };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x4 ring[kRing];
-    ring[0] = reinterpret_cast<const f32x4*>(pipe.wcur)[lane];
-    ring[1] = reinterpret_cast<const f32x4*>(pipe.wcur)[64 + lane];
+    u32x4 ringH[kRing16], ringL[kRing16];
+    if (!F16) {
+        ring[0] = reinterpret_cast<const f32x4*>(pipe.wcur)[lane];
+        ring[1] = reinterpret_cast<const f32x4*>(pipe.wcur)[64 + lane];
+    } else {
+#pragma unroll
+        for (int g = 0; g < kRing16 - 1; ++g) {
+            ringH[g] = reinterpret_cast<const u32x4*>(pipe.wcur)[(g * 2 + 0) * 64 + lane];
+            ringL[g] = reinterpret_cast<const u32x4*>(pipe.wcur)[(g * 2 + 1) * 64 + lane];
+        }
+    }
 
     f32x16 in[kNT], out[kNT];
+    u32x4 inH[2 * kNT], inL[2 * kNT];
+    float inv_scale = 1.0f;
+    auto next_operand = [&]() {
+        if (F16) {
+            inv_scale = scale_split(out, inH, inL);
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < kNT; ++tt) {
+                in[tt] = out[tt];
+                asm volatile("" : "+a"(in[tt]));
+            }
+        }
+    };
 
     for (int sub = 0; sub < n_sub; ++sub) {
         const int p = sub * kTilePts + 32 * wave + col;
@@ -497,9 +570,11 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
                     if (valid) *reinterpret_cast<f32x4*>(sp + l0 * kWidth + o) = x4;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        in[t][4 * q + j] = cos_hw_f32(ar[j]) * (TANGENT ? x4[j] : g4[j] * x4[j]);
+                        out[t][4 * q + j] = cos_hw_f32(ar[j]) * (TANGENT ? x4[j] : g4[j] * x4[j]);
                 }
+                asm volatile("" : "+a"(out[t]));
             }
+            next_operand();
         }
 
         // ---- seven GEMMs ----
@@ -540,7 +615,13 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
                     for (int q = 0; q < 4; ++q) argb[t & 1][q] = *reinterpret_cast<const f32x4*>(apl + 32 * t + 8 * q + 4 * half);
                 };
                 f32x16 acc = zero16();
-                acc = big_tile<false, 0>(pipe.wcur, pipe.wnxt, lane, in, acc, ring, NoEpilogue(), sync_and_fetch, issue_piece);
+                if (!F16) {
+                    acc = big_tile<false, 0>(pipe.wcur, pipe.wnxt, lane, in, acc, ring, NoEpilogue(), sync_and_fetch, issue_piece);
+                } else {
+                    f32x16 accb = zero16();
+                    big_tile_f16<false>(pipe.wcur, pipe.wnxt, lane, inH, inL, acc, accb, ringH, ringL, NoEpilogue(), sync_and_fetch, issue_piece);
+                    acc = (acc + accb) * inv_scale;
+                }
                 pipe.advance();
                 if (t > 0) {
                     epilogue(t - 1, prev, argb[(t - 1) & 1], out[t - 1]);
@@ -560,14 +641,10 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
 #pragma unroll
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(spl + 32 * (kNT - 1) + 8 * q + 4 * half) = st4[q];
             }
-#pragma unroll
-            for (int tt = 0; tt < kNT; ++tt) {
-                in[tt] = out[tt];
-                asm volatile("" : "+a"(in[tt]));
-            }
+            if (step < 6) next_operand();
         }
 
-        // ---- sdf chain: e = s W_0^T g_0 ----
+        // ---- sdf chain: e = s W_0^T g_0 (g_0 is in out[]) ----
         if (!TANGENT) {
             int half_e = half;
             asm volatile("" : "+v"(half_e));
@@ -581,7 +658,7 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
                                 wz = *reinterpret_cast<const f32x4*>(w0_s + 2 * kWidth + o);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float g = in[t][4 * q + j];
+                        const float g = out[t][4 * q + j];
                         ex = fmaf(wx[j], g, ex); ey = fmaf(wy[j], g, ey); ez = fmaf(wz[j], g, ez);
                     }
                 }
@@ -798,10 +875,12 @@ static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfil
                   "siren_bwd: packed/args/d_feat must be 16-B aligned");
     float* const partials = k.partials;
     E3DGE_REQUIRE((k.tang == nullptr) == (k.rsave == nullptr), "siren_bwd: tang and rsave must come together");
+    E3DGE_REQUIRE(k.precision == E3DGE_PREC_F32 || k.precision == E3DGE_PREC_F16X3, "siren_bwd: precision=%d", k.precision);
     E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(k.tang) | reinterpret_cast<uintptr_t>(k.rsave)) & 15) == 0, "siren_bwd: tang/rsave must be 16-B aligned");
     static bool attr_done = false;
     if (!attr_done) {
-        const void* fns[2] = {reinterpret_cast<const void*>(&siren_bwd_kernel<false>), reinterpret_cast<const void*>(&siren_bwd_kernel<true>)};
+        const void* fns[4] = {reinterpret_cast<const void*>(&siren_bwd_kernel<false, false>), reinterpret_cast<const void*>(&siren_bwd_kernel<true, false>),
+                              reinterpret_cast<const void*>(&siren_bwd_kernel<false, true>), reinterpret_cast<const void*>(&siren_bwd_kernel<true, true>)};
         for (const void* fn : fns) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsBytes);
             if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(siren_bwd): %s", hipGetErrorString(e));
@@ -812,8 +891,14 @@ static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfil
     if (n_pts > 0) {
         const int64_t grid = (int64_t)k.wgs_per_img * batch;
         E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_bwd: grid too large");
-        if (k.tang) siren_bwd_kernel<true><<<dim3((unsigned)grid), dim3(kThreads), kBwdLdsBytes, st>>>(k);
-        else siren_bwd_kernel<false><<<dim3((unsigned)grid), dim3(kThreads), kBwdLdsBytes, st>>>(k);
+        const dim3 g3((unsigned)grid), b3(kThreads);
+        if (k.precision == E3DGE_PREC_F16X3) {
+            if (k.tang) siren_bwd_kernel<true, true><<<g3, b3, kBwdLdsBytes, st>>>(k);
+            else siren_bwd_kernel<false, true><<<g3, b3, kBwdLdsBytes, st>>>(k);
+        } else {
+            if (k.tang) siren_bwd_kernel<true, false><<<g3, b3, kBwdLdsBytes, st>>>(k);
+            else siren_bwd_kernel<false, false><<<g3, b3, kBwdLdsBytes, st>>>(k);
+        }
         int rc = check_launch("siren_bwd");
         if (rc) return rc;
     }
@@ -828,12 +913,12 @@ extern "C" int e3dge_siren_bwd(const float* packed, const float* film, const flo
                                const float* d_rgb, const float* d_sdf, const float* tang, const float* rsave,
                                const float* wg, const float* wb,
                                int batch, int64_t n_pts, float* partials, float* dfilm, float* dstyles,
-                               e3dge_stream_t stream) {
+                               int precision, e3dge_stream_t stream) {
     E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "siren_bwd: bad sizes");
     if (batch == 0) return E3DGE_OK;
     SirenBwdK k{};
     k.packed = packed; k.film = film; k.args = args; k.d_feat = d_feat; k.d_rgb = d_rgb; k.d_sdf = d_sdf;
-    k.partials = partials; k.n_pts = n_pts; k.batch = batch; k.samples = 1; k.tang = tang; k.rsave = rsave;
+    k.partials = partials; k.n_pts = n_pts; k.batch = batch; k.samples = 1; k.tang = tang; k.rsave = rsave; k.precision = precision;
     return launch_bwd(k, wg, wb, dfilm, dstyles, as_stream(stream));
 }
 
@@ -872,13 +957,14 @@ extern "C" int e3dge_siren_render_bwd(const E3dgeRenderBwdArgs* r, e3dge_stream_
     SirenBwdK k{};
     k.packed = r->packed; k.film = r->film; k.args = r->args; k.d_feat = nullptr; k.d_rgb = r->d_rgb_pts; k.d_sdf = r->d_sdf_pts;
     k.d_featmap = r->d_feat_map; k.weights = r->weights; k.samples = r->n_samples;
-    k.partials = r->partials; k.n_pts = HW * r->n_samples; k.batch = r->batch; k.tang = r->tang; k.rsave = r->rsave;
+    k.partials = r->partials; k.n_pts = HW * r->n_samples; k.batch = r->batch; k.tang = r->tang; k.rsave = r->rsave; k.precision = r->precision;
     return launch_bwd(k, r->wg, r->wb, r->dfilm, r->dstyles, st);
 }
 
 template <bool TANGENT>
 static int launch_chain(const float* packed, const float* film, const float* args, const float* seed, float box_scale,
-                        int batch, int64_t n_pts, float* save, float* eik, hipStream_t st, const char* what) {
+                        int batch, int64_t n_pts, float* save, float* eik, int precision, hipStream_t st, const char* what) {
+    E3DGE_REQUIRE(precision == E3DGE_PREC_F32 || precision == E3DGE_PREC_F16X3, "%s: precision=%d", what, precision);
     E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "%s: bad sizes", what);
     if (batch == 0 || n_pts == 0) return E3DGE_OK;
     E3DGE_REQUIRE(packed && film && args && save && (TANGENT ? seed != nullptr : eik != nullptr), "%s: null pointer", what);
@@ -886,9 +972,12 @@ static int launch_chain(const float* packed, const float* film, const float* arg
                   "%s: packed/args/save must be 16-B aligned", what);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kChLdsBytes);
-        if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+        const void* fns[2] = {reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, false>),
+                              reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, true>)};
+        for (const void* fn : fns) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kChLdsBytes);
+            if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+        }
         attr_done = true;
     }
     SirenChainK k{};
@@ -897,17 +986,19 @@ static int launch_chain(const float* packed, const float* film, const float* arg
     bwd_geometry(batch, n_pts, &k.subtiles_per_wg, &k.wgs_per_img);
     const int64_t grid = (int64_t)k.wgs_per_img * batch;
     E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "%s: grid too large", what);
-    siren_chain_kernel<TANGENT><<<dim3((unsigned)grid), dim3(kThreads), kChLdsBytes, st>>>(k);
+    if (precision == E3DGE_PREC_F16X3) siren_chain_kernel<TANGENT, true><<<dim3((unsigned)grid), dim3(kThreads), kChLdsBytes, st>>>(k);
+    else siren_chain_kernel<TANGENT, false><<<dim3((unsigned)grid), dim3(kThreads), kChLdsBytes, st>>>(k);
     return check_launch(what);
 }
 
 extern "C" int e3dge_siren_sdf_grad(const float* packed, const float* film, const float* args, const float* seed,
                                     float box_scale, int batch, int64_t n_pts, float* rsave, float* eik,
-                                    e3dge_stream_t stream) {
-    return launch_chain<false>(packed, film, args, seed, box_scale, batch, n_pts, rsave, eik, as_stream(stream), "siren_sdf_grad");
+                                    int precision, e3dge_stream_t stream) {
+    return launch_chain<false>(packed, film, args, seed, box_scale, batch, n_pts, rsave, eik, precision, as_stream(stream), "siren_sdf_grad");
 }
 
 extern "C" int e3dge_siren_tangent(const float* packed, const float* film, const float* args, const float* v,
-                                   float box_scale, int batch, int64_t n_pts, float* tang, e3dge_stream_t stream) {
-    return launch_chain<true>(packed, film, args, v, box_scale, batch, n_pts, tang, nullptr, as_stream(stream), "siren_tangent");
+                                   float box_scale, int batch, int64_t n_pts, float* tang, int precision,
+                                   e3dge_stream_t stream) {
+    return launch_chain<true>(packed, film, args, v, box_scale, batch, n_pts, tang, nullptr, precision, as_stream(stream), "siren_tangent");
 }

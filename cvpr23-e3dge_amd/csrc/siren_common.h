@@ -52,7 +52,10 @@ constexpr int64_t kOffBig16 = kOffBHead + 4;                         // f16x3 im
 // fp32 image of the TRANSPOSED big layers for the backward chain dh_{L-1} = W_L^T g_L, in the order it is consumed:
 // [Gb = 0..7 <-> layer L = 8 - Gb][8 out-tiles of k_in][8 c][4 q][64 lanes][4] = W_L[32c + 8q + 4(l>>5) + j][32t + (l&31)]
 constexpr int64_t kOffBigT = kOffBig16 + (int64_t)kChunksPerPass * kChunkFloats;
-constexpr int64_t kPackedFloats = kOffBigT + (int64_t)kChunksPerPass * kChunkFloats;
+// f16x3 (hi, lo) image of the same transposed GEMMs, same chunk order and word layout as kOffBig16:
+// [Gb][8 out-tiles][16 k-steps][hi|lo][64 lanes][4 words of two f16], carrying the factor kW16Scale
+constexpr int64_t kOffBigT16 = kOffBigT + (int64_t)kChunksPerPass * kChunkFloats;
+constexpr int64_t kPackedFloats = kOffBigT16 + (int64_t)kChunksPerPass * kChunkFloats;
 // f16x3 image: the same 64 chunks of 32 KiB, each [16 k-steps g = 2c+s][hi, lo][64 lanes][8 f16]: lane l holds
 //   128 * W[32t + (l&31)][32c + 16s + (j&3) + 8(j>>2) + 4(l>>5)],  j = 0..7
 // split as hi = f16(v), lo = f16(v - hi).  The k order is the one in which a lane's C/D registers of the previous

@@ -37,6 +37,16 @@ def default_mfma_mode():
     return mode
 
 
+def default_bwd_mode():
+    """The same choice for the backward-type kernels (E3DGE_BWD_MODE; default = the forward mode): 'f16x3' scales every
+    gradient operand per point by a power of two before the (hi, lo) split."""
+    import os
+    mode = os.environ.get("E3DGE_BWD_MODE", default_mfma_mode())
+    if mode not in MFMA_MODES:
+        raise RuntimeError(f"E3DGE_BWD_MODE must be one of {sorted(MFMA_MODES)}, got {mode!r}")
+    return mode
+
+
 def _opt_get(opt, name, default=None):
     if opt is None:
         return default
@@ -126,6 +136,7 @@ class SirenGenerator(nn.Module):
         self._cache_key = None
         self._cache = None
         self.mfma_mode = default_mfma_mode()
+        self.bwd_mode = default_bwd_mode()
 
     # -- device caches -------------------------------------------------------------------------------
     def _film_layers(self):
@@ -247,7 +258,8 @@ def sdf_gradient(siren, film, args, box_scale):
     eik = torch.empty((B, N, 3), device=args.device, dtype=torch.float32)
     with torch.cuda.device(args.device):
         rc = _lib.load().e3dge_siren_sdf_grad(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), None, float(box_scale),
-                                              B, N, _lib.ptr(rsave), _lib.ptr(eik), _lib.stream_of(args))
+                                              B, N, _lib.ptr(rsave), _lib.ptr(eik), MFMA_MODES[siren.bwd_mode],
+                                              _lib.stream_of(args))
     _lib.check(rc, "e3dge_siren_sdf_grad")
     return eik, rsave
 
@@ -260,7 +272,7 @@ def tangent_arguments(siren, film, args, v, box_scale):
     tang = torch.empty((B, N, 8, siren.W), device=args.device, dtype=torch.float32)
     with torch.cuda.device(args.device):
         rc = _lib.load().e3dge_siren_tangent(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), _lib.ptr(v), float(box_scale),
-                                             B, N, _lib.ptr(tang), _lib.stream_of(args))
+                                             B, N, _lib.ptr(tang), MFMA_MODES[siren.bwd_mode], _lib.stream_of(args))
     _lib.check(rc, "e3dge_siren_tangent")
     return tang
 
@@ -281,7 +293,7 @@ def siren_backward(siren, film, args, d_feat, d_rgb, d_sdf, tang=None, rsave=Non
     with torch.cuda.device(dev):
         rc = lib.e3dge_siren_bwd(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), _lib.ptr(d_feat), _lib.ptr(d_rgb),
                                  _lib.ptr(d_sdf), _lib.ptr(tang), _lib.ptr(rsave), _lib.ptr(wg), _lib.ptr(wb), B, N, _lib.ptr(partials),
-                                 _lib.ptr(dfilm), _lib.ptr(dstyles), _lib.stream_of(args))
+                                 _lib.ptr(dfilm), _lib.ptr(dstyles), MFMA_MODES[siren.bwd_mode], _lib.stream_of(args))
     _lib.check(rc, "e3dge_siren_bwd")
     return dstyles, dfilm
 
@@ -391,7 +403,7 @@ class _RenderQuery(torch.autograd.Function):
             far=_lib.ptr(far), wg=_lib.ptr(wg), wb=_lib.ptr(wb), d_rgb_map=_lib.ptr(d_rgb_map),
             d_feat_map=_lib.ptr(d_feat_map), d_xyz_map=_lib.ptr(d_xyz_map), d_depth_map=_lib.ptr(d_depth_map),
             d_sdf=_lib.ptr(d_sdf_in), tang=_lib.ptr(tang), rsave=_lib.ptr(rs), sigmoid_beta=ctx.sigmoid_beta, batch=B, height=H, width=H, n_samples=S,
-            force_background=int(bool(r.force_background)), d_rgb_pts=_lib.ptr(d_rgb_pts), d_sdf_pts=_lib.ptr(d_sdf_pts),
+            force_background=int(bool(r.force_background)), precision=MFMA_MODES[siren.bwd_mode], d_rgb_pts=_lib.ptr(d_rgb_pts), d_sdf_pts=_lib.ptr(d_sdf_pts),
             partials=_lib.ptr(partials), dfilm=_lib.ptr(dfilm), dstyles=_lib.ptr(dstyles))
         with torch.cuda.device(dev):
             rc = lib.e3dge_siren_render_bwd(ctypes.byref(a), _lib.stream_of(film))

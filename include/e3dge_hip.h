@@ -197,13 +197,16 @@ int e3dge_siren_points_fwd(const float* packed, const float* film, const float* 
  *   partials  e3dge_siren_bwd_partial_floats(batch, n_pts) floats of scratch (need not be initialised)
  *   dfilm    (batch, 9, 2, 256) out  dL/d(gamma, beta)
  *   dstyles  (batch, 9, 256)    out  dL/d(styles)
+ * precision: E3DGE_PREC_F32 (fp32 MFMA) or E3DGE_PREC_F16X3: every gradient operand is scaled per point by a power of
+ * two into [1, 2), split into f16 hi + lo, three f16 MFMA products accumulated in fp32 -- same error as fp32.
  * No tex-FiLM (second pass) support: that pass runs under no_grad in the reference's stage-1 training.
  * ---------------------------------------------------------------------------------------------------------------- */
 int64_t e3dge_siren_bwd_partial_floats(int batch, int64_t n_pts);
 int e3dge_siren_bwd(const float* packed, const float* film, const float* args, const float* d_feat,
                     const float* d_rgb, const float* d_sdf, const float* tang, const float* rsave,
                     const float* wg, const float* wb,
-                    int batch, int64_t n_pts, float* partials, float* dfilm, float* dstyles, e3dge_stream_t stream);
+                    int batch, int64_t n_pts, float* partials, float* dfilm, float* dstyles, int precision,
+                    e3dge_stream_t stream);
 
 /* Eikonal term e = d sdf / d x (get_eikonal_term, volume_renderer.py:796-802) and its double backward.
  *   e3dge_siren_sdf_grad : from the saved arguments, e (batch, n_pts, 3) [world-space x: includes box_scale] and
@@ -213,9 +216,10 @@ int e3dge_siren_bwd(const float* packed, const float* film, const float* args, c
  * Passing tang + rsave to e3dge_siren_bwd / E3dgeRenderBwdArgs adds dL/d(styles) of the loss on e (the reference's
  * create_graph=True path) to the first-order gradient; NULL, NULL = no such loss. */
 int e3dge_siren_sdf_grad(const float* packed, const float* film, const float* args, const float* seed,
-                         float box_scale, int batch, int64_t n_pts, float* rsave, float* eik, e3dge_stream_t stream);
+                         float box_scale, int batch, int64_t n_pts, float* rsave, float* eik, int precision,
+                         e3dge_stream_t stream);
 int e3dge_siren_tangent(const float* packed, const float* film, const float* args, const float* v,
-                        float box_scale, int batch, int64_t n_pts, float* tang, e3dge_stream_t stream);
+                        float box_scale, int batch, int64_t n_pts, float* tang, int precision, e3dge_stream_t stream);
 
 /* Backward of e3dge_siren_render_fwd: volume_integration (volume_renderer.py:809-943) back to the per-point outputs
  * (one wave per ray), then the MLP chain above.  Gradient maps are ROW-MAJOR PER RAY (ray = (b*H + y)*W + x):
@@ -231,6 +235,7 @@ typedef struct E3dgeRenderBwdArgs {
     const float* tang; const float* rsave;
     float sigmoid_beta;
     int batch, height, width, n_samples, force_background;
+    int precision;           /* E3DGE_PREC_F32 or E3DGE_PREC_F16X3 (block-scaled split-f16 GEMMs, fp32 accumulate) */
     float* d_rgb_pts; float* d_sdf_pts; float* partials;
     float* dfilm; float* dstyles;
 } E3dgeRenderBwdArgs;

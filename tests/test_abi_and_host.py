@@ -29,8 +29,8 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), f"{name} declared in e3dge_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert lib.e3dge_abi_version() == _lib.ABI_VERSION
-    # fp32 fragment image + small blocks, the f16x3 (hi, lo) image of the same 64 chunks, the transposed fp32 image
-    assert lib.e3dge_siren_packed_floats() == (64 * 8192 + 2 * 1024 + 9 * 256 + 4 * 256 + 4) + 2 * 64 * 8192
+    # fp32 fragment image + small blocks, the f16x3 (hi, lo) image of the same 64 chunks, the transposed fp32 and f16x3 images
+    assert lib.e3dge_siren_packed_floats() == (64 * 8192 + 2 * 1024 + 9 * 256 + 4 * 256 + 4) + 3 * 64 * 8192
 
 
 def test_render_args_struct_layout_matches_c():
@@ -78,9 +78,9 @@ int main(void) {
     assert lib.e3dge_siren_render_bwd(None, None) == -1
     bad = _lib.RenderBwdArgs(batch=1, height=4, width=4, n_samples=0)
     assert lib.e3dge_siren_render_bwd(ctypes.byref(bad), None) == -1 and b"n_samples" in lib.e3dge_last_error()
-    assert lib.e3dge_siren_bwd(None, None, None, None, None, None, None, None, None, None, 1, 10, None, None, None, None) == -1
-    assert lib.e3dge_siren_sdf_grad(None, None, None, None, 1.0, 1, 10, None, None, None) == -1
-    assert lib.e3dge_siren_tangent(None, None, None, None, 1.0, 1, 10, None, None) == -1
+    assert lib.e3dge_siren_bwd(None, None, None, None, None, None, None, None, None, None, 1, 10, None, None, None, 0, None) == -1
+    assert lib.e3dge_siren_sdf_grad(None, None, None, None, 1.0, 1, 10, None, None, 0, None) == -1
+    assert lib.e3dge_siren_tangent(None, None, None, None, 1.0, 1, 10, None, 0, None) == -1
     assert lib.e3dge_siren_bwd_partial_floats(2, 1000) == 2 * 8 * 9 * 2 * 256     # 8 sub-tiles -> 8 workgroups per image
 
 

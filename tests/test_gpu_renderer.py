@@ -41,6 +41,7 @@ def make_renderer(sd, res, S, mfma_mode=None, **over):
     r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S, **over), out_im_res=res, mode='test')
     if mfma_mode is not None:
         r.siren.mfma_mode = mfma_mode
+        r.siren.bwd_mode = mfma_mode          # the backward-type kernels run in the same mode
     pre = 'network.netGlobal.' if over.get('enable_local_model') else 'network.'
     own = {}
     for k in r.state_dict():
