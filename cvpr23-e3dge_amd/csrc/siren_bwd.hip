@@ -206,25 +206,30 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
         if (a.d_rgb && valid) { drgb[0] = a.d_rgb[gpt * 3]; drgb[1] = a.d_rgb[gpt * 3 + 1]; drgb[2] = a.d_rgb[gpt * 3 + 2]; }
 
         // per-tile reduction of d(beta) += da, d(gamma) += da * u over this wave's 32 points, layer `layer`, tile `t`
+        // registers 8*h8 .. 8*h8+7 of a tile: lane sums into this wave's slot
+        auto reduce_half = [&](int h8, const float (&vb)[8], const float (&vg)[8], float* my_slot) {
+            float qb[4], qg[4];
+            reduce8_over_lanes(vb, qb);
+            reduce8_over_lanes(vg, qg);
+            // lanes 0-3 of each 16-lane row publish value (col & 3) [+4 in the odd row]
+            const int i = col & 3;
+            const float sb = i == 0 ? qb[0] : i == 1 ? qb[1] : i == 2 ? qb[2] : qb[3];
+            const float sg = i == 0 ? qg[0] : i == 1 ? qg[1] : i == 2 ? qg[2] : qg[3];
+            if ((col & 15) < 4) {
+                const int nl = row_of(8 * h8 + 4 * (col >> 4) + i, half);
+                my_slot[nl] = sg;
+                my_slot[32 + nl] = sb;
+            }
+        };
         auto reduce_tile = [&](int layer, int t, const float (&rb)[16], const float (&rg)[16], float* view_slot = nullptr) {
             if (!view_slot) fold_pending();                            // previous tile: a barrier has passed since
             float* const my_slot = view_slot ? view_slot : slot_s + par * 256 + wave * 64;
 #pragma unroll
             for (int h8 = 0; h8 < 2; ++h8) {
-                float vb[8], vg[8], qb[4], qg[4];
+                float vb[8], vg[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { vb[i] = rb[8 * h8 + i]; vg[i] = rg[8 * h8 + i]; }
-                reduce8_over_lanes(vb, qb);
-                reduce8_over_lanes(vg, qg);
-                // lanes 0-3 of each 16-lane row publish value (col & 3) [+4 in the odd row]
-                const int i = col & 3;
-                const float sb = i == 0 ? qb[0] : i == 1 ? qb[1] : i == 2 ? qb[2] : qb[3];
-                const float sg = i == 0 ? qg[0] : i == 1 ? qg[1] : i == 2 ? qg[2] : qg[3];
-                if ((col & 15) < 4) {
-                    const int nl = row_of(8 * h8 + 4 * (col >> 4) + i, half);
-                    my_slot[nl] = sg;
-                    my_slot[32 + nl] = sb;
-                }
+                reduce_half(h8, vb, vg, my_slot);
             }
             if (!view_slot) { pend_layer = layer; pend_t = t; pend_par = par; par ^= 1; }
         };
@@ -318,6 +323,11 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
             f32x4 argb[4];                                               // saved arguments of the tile being finished
             f32x4 argt[4];                                               // ... and of the layer's last tile (no GEMM tile follows it)
             f32x4 tgb[4], rsb[4];                                        // EIK: tangent arguments and r of the tile being finished
+            // F16: the epilogue of tile t-1 is issued from inside GEMM tile t (one accumulator register per k-step, in the
+            // shadow of the f16 MFMAs -- standing alone it cost more than the GEMM), so its streams are fetched a tile ahead
+            f32x4 arg2[2][4], tg2[2][4], rs2[2][4];
+            f32x4 e_g = {0.f, 0.f, 0.f, 0.f}, e_b = e_g, e_i = e_g, e_w = e_g;
+            float rbh[8], rgh[8];
             auto epilogue = [&](int tp, const f32x16& dhv, const f32x4 (&ar)[4], f32x16& dst) {
                 float rb[16], rg[16];
 #pragma unroll
@@ -357,6 +367,34 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                 dst[0] += keep * 1e-30f;
 #endif
             };
+            auto epi_step = [&](int tp, int r, f32x16& dst) {           // tp, r: compile-time constants at every call site
+                const int q = r >> 2, j = r & 3;
+                if (j == 0) {
+                    const int o = 32 * tp + 8 * q + 4 * half;
+                    e_g = *reinterpret_cast<const f32x4*>(fg + o); e_b = *reinterpret_cast<const f32x4*>(fg + kWidth + o);
+                    e_i = *reinterpret_cast<const f32x4*>(fg + 2 * kWidth + o); e_w = *reinterpret_cast<const f32x4*>(head_s + o);
+                }
+                const float ar = arg2[tp & 1][q][j];
+                const float dh = fmaf(e_w[j], sdf_term, prev[r]);
+                float da, dg_extra = 0.0f;
+                if (EIK) {
+                    float sn, cs;
+                    sincos_hw_f32(ar, sn, cs);
+                    const float tr = vmask * tg2[tp & 1][q][j] * rs2[tp & 1][q][j];
+                    da = fmaf(dh, cs, -sn * tr);
+                    dg_extra = tr * e_i[j] * cs;
+                } else {
+                    da = dh * cos_hw_f32(ar);
+                }
+                rbh[r & 7] = da;
+                rgh[r & 7] = fmaf(da, (ar - e_b[j]) * e_i[j], dg_extra);
+                dst[r] = e_g[j] * da;
+                if (r == 3) fold_pending();                              // this tile's chunk barrier (k-step 2) has passed
+                if ((r & 7) == 7) {
+                    reduce_half(r >> 3, rbh, rgh, slot_s + par * 256 + wave * 64);
+                    if (r == 15) { pend_layer = Lm1; pend_t = tp; pend_par = par; par ^= 1; }
+                }
+            };
 #pragma unroll
             for (int t = 0; t < kNT; ++t) {
                 // The saved arguments of tile t-1 (HBM, cold stream) are needed by the epilogue that follows GEMM tile t.
@@ -364,6 +402,17 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                 // vmcnt(0) of the wait itself) and have the rest of the tile, ~7.5k cycles of MFMAs, to arrive.
                 auto sync_and_fetch = [&]() {
                     pipe.sync();
+                    if (F16) {                                           // streams of tile t itself: used one GEMM tile later
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            arg2[t & 1][q] = *reinterpret_cast<const f32x4*>(apl + 32 * t + 8 * q + 4 * half);
+                            if (EIK) {
+                                tg2[t & 1][q] = *reinterpret_cast<const f32x4*>(tpl + 32 * t + 8 * q + 4 * half);
+                                rs2[t & 1][q] = *reinterpret_cast<const f32x4*>(rpl + 32 * t + 8 * q + 4 * half);
+                            }
+                        }
+                        return;
+                    }
                     if (t > 0) {
 #ifndef E3DGE_BWD_ABL_NO_ARGLOAD
 #pragma unroll
@@ -390,22 +439,35 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                     acc = big_tile<false, 0>(pipe.wcur, pipe.wnxt, lane, in, acc, ring, NoEpilogue(), sync_and_fetch, issue_piece);
                 } else {
                     f32x16 accb = zero16();
-                    big_tile_f16<false>(pipe.wcur, pipe.wnxt, lane, inH, inL, acc, accb, ringH, ringL, NoEpilogue(), sync_and_fetch, issue_piece);
+                    if (t == 0) {
+                        big_tile_f16<false>(pipe.wcur, pipe.wnxt, lane, inH, inL, acc, accb, ringH, ringL, NoEpilogue(), sync_and_fetch, issue_piece);
+                    } else {
+                        big_tile_f16<false>(pipe.wcur, pipe.wnxt, lane, inH, inL, acc, accb, ringH, ringL,
+                                            [&](int r) { epi_step(t - 1, r, out[t - 1]); }, sync_and_fetch, issue_piece);
+                        asm volatile("" : "+a"(out[t - 1]));
+                    }
                     acc = (acc + accb) * inv_scale;
                 }
                 [[maybe_unused]] const unsigned long long c1 = BT_NOW();
                 pipe.advance();
-                if (t > 0) {
+                if (!F16 && t > 0) {
                     epilogue(t - 1, prev, argb, out[t - 1]);
                     asm volatile("" : "+a"(out[t - 1]));
                 }
                 prev = acc;
+                if (F16) asm volatile("" : "+v"(prev));
 #ifdef E3DGE_BWD_TIMING
                 t_tile += c1 - c0; t_epi += BT_NOW() - c1;
 #endif
             }
             [[maybe_unused]] const unsigned long long ct0 = BT_NOW();
-            if (EIK) {
+            if (F16) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    argt[q] = arg2[(kNT - 1) & 1][q];
+                    if (EIK) { tgb[q] = tg2[(kNT - 1) & 1][q]; rsb[q] = rs2[(kNT - 1) & 1][q]; }
+                }
+            } else if (EIK) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     tgb[q] = *reinterpret_cast<const f32x4*>(tpl + 32 * (kNT - 1) + 8 * q + 4 * half);

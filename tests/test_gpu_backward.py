@@ -347,3 +347,25 @@ def test_stage1_step_against_reference_golden_gradients():
     assert e['dstyles_vs_ref'] <= REL_TOL and e['dstyles_vs_f64'] <= max(REL_TOL, 3 * e['ref_dstyles_vs_f64']), e
     # the reference also returns the normal at the integrated surface point
     assert rel(out['surface_eikonal_term'], g['ref_surface_eikonal_term']) <= 1e-4
+
+
+@pytest.mark.parametrize("scale", [1e-18, 1.0, 1e+12])
+def test_backward_block_scaling_is_scale_invariant(sd, scale):
+    """The split-f16 backward scales every gradient column by a power of two: the relative error must not depend on
+    the magnitude of the incoming gradient (1e-18 ... 1e+12 here; the eikonal second-order stream included)."""
+    r = make_renderer(sd, 8, 18, mfma_mode="f16x3")
+    wr, _ = syn.synthetic_inputs(1, seed=21, device=DEV)
+    rs = np.random.RandomState(4)
+    n = 900
+    pts = torch.from_numpy((0.11 * rs.uniform(-1, 1, (1, n, 3))).astype(np.float32)).to(DEV)
+    G = torch.from_numpy(rs.normal(size=(1, n, 260)).astype(np.float32)).to(DEV)
+    Ge = torch.from_numpy(rs.normal(size=(1, n, 3)).astype(np.float32)).to(DEV)
+    styles = wr.clone().requires_grad_(True)
+    sdf, raw, eik = r.siren.query_points(pts, None, styles, r.box_scale, want_eikonal=True)
+    (((raw * G).sum() + (eik * Ge).sum() * 1e-2) * scale).backward()
+    s = wr.detach().cpu().double().requires_grad_(True)
+    raw_o, eik_o = oracle_points_with_eikonal(sd, pts, s, torch.float64)
+    (((raw_o * G.cpu().double()).sum() + (eik_o * Ge.cpu().double()).sum() * 1e-2) * scale).backward()
+    e = rel_err(styles.grad, s.grad)
+    record(f"bwd_scale_invariance_{scale:g}", rel_err_vs_f64=e)
+    assert torch.isfinite(styles.grad).all() and e <= REL_TOL, e
