@@ -79,12 +79,8 @@ __device__ __forceinline__ void sincos_hw_f32(float x, float& sn, float& cs) {
 // Relative to the column's largest element the representation is good to ~2^-24, the same as the forward kernel's
 // activations, and the accumulation is fp32 in both.  `src` = the 256 values of the point held by this lane (standard
 // layout); returns 1 / (kW16Scale * scale) for the epilogue.
-__device__ __forceinline__ float scale_split(const f32x16 (&src)[kNT], u32x4 (&dH)[2 * kNT], u32x4 (&dL)[2 * kNT]) {
-    float m = 0.0f;
-#pragma unroll
-    for (int t = 0; t < kNT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(src[t][r]));
+// `m` = max |value| over this lane's 128 values (the producers keep it as a running max).
+__device__ __forceinline__ float scale_split(const f32x16 (&src)[kNT], u32x4 (&dH)[2 * kNT], u32x4 (&dL)[2 * kNT], float m) {
     m = fmaxf(m, xhalf(m));
     const unsigned e = (__float_as_uint(m) >> 23) & 255u;               // m in [2^(e-127), 2^(e-126))
     const float sc = __uint_as_float((254u - e) << 23);                 // m * sc in [1, 2)   (m == 0: sc = 2^127, harmless)
@@ -95,6 +91,15 @@ __device__ __forceinline__ float scale_split(const f32x16 (&src)[kNT], u32x4 (&d
         for (int r = 0; r < 16; r += 2)
             SPLIT2_TO(src[t][r] * sc, src[t][r + 1] * sc, dH[2 * t + (r >> 3)][(r & 7) >> 1], dL[2 * t + (r >> 3)][(r & 7) >> 1]);
     return inv;
+}
+
+__device__ __forceinline__ float scale_split(const f32x16 (&src)[kNT], u32x4 (&dH)[2 * kNT], u32x4 (&dL)[2 * kNT]) {
+    float m = 0.0f;
+#pragma unroll
+    for (int t = 0; t < kNT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(src[t][r]));
+    return scale_split(src, dH, dL, m);
 }
 
 // EIK = false: gradient of a loss that reaches the network through (feat, rgb, sdf).
@@ -171,10 +176,16 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
     f32x16 in[kNT], out[kNT];
     u32x4 inH[2 * kNT], inL[2 * kNT];
     float inv_scale = 1.0f;                       // F16: undoes the operand scaling of the GEMM being consumed
+    // F16: running max |g| of the layer being produced (this lane's 128 values).  With the two extra streams of the EIK
+    // variant one more live register tips the allocator into spilling inside the MFMA stream, so that variant takes
+    // the max in a separate pass over out[] instead.
+    constexpr bool kRunMax = F16 && !EIK;
+    float gmax = 0.0f;
     // g_L of a finished layer (out[], fp32) becomes the B operand of the next GEMM
     auto next_operand = [&]() {
         if (F16) {
-            inv_scale = scale_split(out, inH, inL);
+            inv_scale = kRunMax ? scale_split(out, inH, inL, gmax) : scale_split(out, inH, inL);
+            gmax = 0.0f;
         } else {
 #pragma unroll
             for (int tt = 0; tt < kNT; ++tt) {
@@ -286,6 +297,7 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                         rb[4 * q + j] = da;
                         rg[4 * q + j] = da * ((ar[j] - b4[j]) * i4[j]);
                         out[t][4 * q + j] = g4[j] * da;
+                        if (kRunMax) gmax = fmaxf(gmax, fabsf(out[t][4 * q + j]));
                     }
                 }
                 asm volatile("" : "+a"(out[t]));                       // results wait in AGPRs: the VGPRs stay free for the loads
@@ -356,6 +368,7 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                         rb[4 * q + j] = da;
                         rg[4 * q + j] = fmaf(da, (ar[q][j] - b4[j]) * i4[j], dg_extra);
                         dst[4 * q + j] = g4[j] * da;
+                        if (kRunMax) gmax = fmaxf(gmax, fabsf(dst[4 * q + j]));
                     }
                 }
 #ifndef E3DGE_BWD_ABL_NO_REDUCE
@@ -389,6 +402,7 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                 rbh[r & 7] = da;
                 rgh[r & 7] = fmaf(da, (ar - e_b[j]) * e_i[j], dg_extra);
                 dst[r] = e_g[j] * da;
+                if (kRunMax) gmax = fmaxf(gmax, fabsf(dst[r]));
                 if (r == 3) fold_pending();                              // this tile's chunk barrier (k-step 2) has passed
                 if ((r & 7) == 7) {
                     reduce_half(r >> 3, rbh, rgh, slot_s + par * 256 + wave * 64);
@@ -577,10 +591,14 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
 
     f32x16 in[kNT], out[kNT];
     u32x4 inH[2 * kNT], inL[2 * kNT];
-    float inv_scale = 1.0f;
+    // F16 tangent chain: epilogue interleaved into the next GEMM tile + running column max.  The sdf chain keeps the
+    // epilogue after the tile (interleaved, the allocator spills ~30 registers inside the MFMA stream of that variant).
+    constexpr bool kInter = F16 && TANGENT;
+    float inv_scale = 1.0f, gmax = 0.0f;
     auto next_operand = [&]() {
         if (F16) {
-            inv_scale = scale_split(out, inH, inL);
+            inv_scale = kInter ? scale_split(out, inH, inL, gmax) : scale_split(out, inH, inL);
+            gmax = 0.0f;
         } else {
 #pragma unroll
             for (int tt = 0; tt < kNT; ++tt) {
@@ -632,7 +650,10 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
                     if (valid) *reinterpret_cast<f32x4*>(sp + l0 * kWidth + o) = x4;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
+                    {
                         out[t][4 * q + j] = cos_hw_f32(ar[j]) * (TANGENT ? x4[j] : g4[j] * x4[j]);
+                        if (kInter) gmax = fmaxf(gmax, fabsf(out[t][4 * q + j]));
+                    }
                 }
                 asm volatile("" : "+a"(out[t]));
             }
@@ -658,8 +679,21 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
                         const float ga = g4[j] * accv[4 * q + j];
                         st4[q][j] = TANGENT ? ga : accv[4 * q + j];
                         dst[4 * q + j] = cos_hw_f32(ar[q][j]) * ga;
+                        if (kInter) gmax = fmaxf(gmax, fabsf(dst[4 * q + j]));
                     }
                 }
+            };
+            // F16: the same work for tile tp issued from inside the next GEMM tile, one accumulator register per k-step; the
+            // 16-B stores go out as each quad completes (they are retired by the next tile's chunk wait)
+            f32x4 e_g = {0.f, 0.f, 0.f, 0.f}, e_st = e_g;
+            auto epi_step = [&](int tp, int r, f32x16& dst) {
+                const int q = r >> 2, j = r & 3;
+                if (j == 0) e_g = *reinterpret_cast<const f32x4*>(gl + 32 * tp + 8 * q + 4 * half);
+                const float ga = e_g[j] * prev[r];
+                e_st[j] = TANGENT ? ga : prev[r];
+                dst[r] = cos_hw_f32(argb[tp & 1][q][j]) * ga;
+                gmax = fmaxf(gmax, fabsf(dst[r]));
+                if (j == 3 && valid) *reinterpret_cast<f32x4*>(spl + 32 * tp + 8 * q + 4 * half) = e_st;
             };
 #pragma unroll
             for (int t = 0; t < kNT; ++t) {
@@ -669,7 +703,7 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
 #pragma unroll
                         for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(argb[(t - 1) & 1][q]));
                     }
-                    if (t > 1 && valid) {                                // tile t-2 finished during the previous GEMM tile
+                    if (!kInter && t > 1 && valid) {                     // tile t-2 finished during the previous GEMM tile
 #pragma unroll
                         for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(spl + 32 * (t - 2) + 8 * q + 4 * half) = st4[q];
                     }
@@ -681,18 +715,25 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
                     acc = big_tile<false, 0>(pipe.wcur, pipe.wnxt, lane, in, acc, ring, NoEpilogue(), sync_and_fetch, issue_piece);
                 } else {
                     f32x16 accb = zero16();
-                    big_tile_f16<false>(pipe.wcur, pipe.wnxt, lane, inH, inL, acc, accb, ringH, ringL, NoEpilogue(), sync_and_fetch, issue_piece);
+                    if (t == 0 || !kInter) {
+                        big_tile_f16<false>(pipe.wcur, pipe.wnxt, lane, inH, inL, acc, accb, ringH, ringL, NoEpilogue(), sync_and_fetch, issue_piece);
+                    } else {
+                        big_tile_f16<false>(pipe.wcur, pipe.wnxt, lane, inH, inL, acc, accb, ringH, ringL,
+                                            [&](int r) { epi_step(t - 1, r, out[t - 1]); }, sync_and_fetch, issue_piece);
+                        asm volatile("" : "+a"(out[t - 1]));
+                    }
                     acc = (acc + accb) * inv_scale;
                 }
                 pipe.advance();
-                if (t > 0) {
+                if (!kInter && t > 0) {
                     epilogue(t - 1, prev, argb[(t - 1) & 1], out[t - 1]);
                     asm volatile("" : "+a"(out[t - 1]));
                 }
                 prev = acc;
+                if (kInter) asm volatile("" : "+v"(prev));
             }
-            // tail of the layer: tile 6 is still pending in st4, tile 7 has no GEMM tile after it
-            if (valid) {
+            // tail of the layer: tile 6 is still pending in st4 (fp32 path), tile 7 has no GEMM tile after it
+            if (!kInter && valid) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(spl + 32 * (kNT - 2) + 8 * q + 4 * half) = st4[q];
             }
