@@ -139,22 +139,13 @@ __device__ __forceinline__ float acts16_get(const u32x4 (&aH)[2 * kNT], const u3
     return (r & 1) ? f16hi(aH[g][k]) + f16hi(aL[g][k]) : f16lo(aH[g][k]) + f16lo(aL[g][k]);
 }
 
-__device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
-}
-// Same with the instruction's immediate offset, which the hardware adds to BOTH the global and the LDS address
-// (the chunk image has the same layout on both sides), so the 8 pieces of a chunk share two address setups.
-template <int OFF_BYTES>
-__device__ __forceinline__ void glds16_off(const float* gsrc, float* ldst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)ldst, 16, OFF_BYTES, 0);
-}
-
-// The form the kernels use: scalar 64-bit base + per-lane 32-bit byte offset + immediate, LDS destination through M0.
-// hipcc never selects this addressing mode for the builtin (it builds a 64-bit VGPR address per piece: ~10 instructions
-// and two VGPRs each time); written out, a piece is s_mov m0 / s_nop / global_load_lds.  No other code in these kernels
-// uses M0.  The compiler does not count these in vmcnt; every consumer waits with an explicit vmcnt(0).
+// LDS-DMA (global_load_lds_dwordx4: 16 B per lane straight into LDS, wave-uniform LDS base in M0).  The instruction's
+// immediate offset is added to BOTH the global and the LDS address (validated on gfx950), so with the chunk image laid
+// out identically on both sides the pieces of a chunk differ only in that immediate.
+// Addressing: scalar 64-bit base + per-lane 32-bit byte offset + immediate.  hipcc never selects this mode for
+// __builtin_amdgcn_global_load_lds (it builds a 64-bit VGPR address per piece: ~10 instructions and two VGPRs each
+// time); written out, a piece is s_mov m0 / s_nop / global_load_lds.  No other code in these kernels uses M0.  The
+// compiler does not count these in vmcnt; every consumer waits with an explicit vmcnt(0).
 template <int OFF_BYTES>
 __device__ __forceinline__ void glds16_saddr(const void* sbase, uint32_t voff, uint32_t lds_addr) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
