@@ -15,6 +15,7 @@ Extra objects on the JSON line:
                 with HIP events on the launch stream inside the timed region, against the dense fp32 MFMA peak.
   cpu_baseline  the oracle restatement (oracle/renderer_ref.py, "port": it is bit-identical to the reference's
                 PyTorch path on the golden vectors) timed on this host's cores on a bounded sample.
+  c4_render_ms       (informational) one pose of the C4 sweep: 128x128 rays x 48 samples.
   train_step_ms      (informational) stage-1 training step of the renderer at 64x64x18 with eikonal terms, fwd + bwd.
   inversion_fwd_ms   (informational) pass #1 + pass #2 with texture FiLM + decoder to 1024^2, one image.
 """
@@ -49,6 +50,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inversion", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
+    ap.add_argument("--no-c4", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -173,6 +175,35 @@ def main():
         except Exception as exc:  # the headline metric must still be printed
             result["inversion_fwd_ms"] = None
             result["inversion_fwd_note"] = f"failed: {type(exc).__name__}: {exc}"
+
+    # ---------------------------------------------------------------- informational: C4 (128x128 rays x 48 samples), one pose
+    if rank == 0 and not args.no_c4:
+        try:
+            from e3dge_amd.volume_renderer import VolumeFeatureRenderer
+            r4 = VolumeFeatureRenderer(syn.rendering_opt(N_samples=48), out_im_res=128, mode='test')
+            r4.load_state_dict(renderer.state_dict())
+            r4 = r4.to(dev)
+            w4, _ = syn.synthetic_inputs(1, seed=1, device=dev)
+            p4, f4, n4, fa4, _ = generate_camera_params(128, dev, locations=torch.tensor([[0.45, 0.0]], device=dev))
+            with torch.no_grad():
+                for _ in range(3):
+                    r4.render(f4, p4, n4, fa4, w4)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(10):
+                    r4.render(f4, p4, n4, fa4, w4)
+                e1.record()
+                torch.cuda.synchronize()
+            ms4 = e0.elapsed_time(e1) / 10
+            result["c4_render_ms"] = ms4
+            result["c4_rays_per_sec"] = 128 * 128 / ms4 * 1e3
+            result["c4_algorithmic_tflops"] = 2 * MAC_PER_POINT * 48 * 128 * 128 / (ms4 * 1e-3) / 1e12
+            result["c4_note"] = "BASELINE configs[3]: one pose of the 120-pose sweep, 128x128 rays x 48 samples (786,432 points), film_params + render"
+            del r4
+        except Exception as exc:
+            result["c4_render_ms"] = None
+            result["c4_note"] = f"failed: {type(exc).__name__}: {exc}"
 
     # ---------------------------------------------------------------- informational: stage-1 training step of the renderer (C5)
     if rank == 0 and not args.no_train_step:
