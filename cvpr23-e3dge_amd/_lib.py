@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E3DGE_LIB_PATH") or os.path.join(_HERE, "lib", "libe3dge_hip.so")   # override: kernel A/B variants
-ABI_VERSION = 5
+ABI_VERSION = 6
 PREC_F32, PREC_F16X3 = 0, 1
 
 _c_float_p = ctypes.c_void_p     # device pointers travel as integers
@@ -56,6 +56,9 @@ SIGNATURES = {
     "e3dge_siren_sdf_grad": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _i64, _vp, _vp, _i32, _vp]),
     "e3dge_siren_tangent": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _i64, _vp, _i32, _vp]),
     "e3dge_siren_render_bwd": (_i32, [ctypes.POINTER(RenderBwdArgs), _vp]),
+    "e3dge_resblock_packed_floats": (_i64, []),
+    "e3dge_resblock_pack_weights": (_i32, [_vp] * 6 + [_i32, _vp]),
+    "e3dge_tex_modulations_fwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "e3dge_selftest_mfma": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "e3dge_selftest_mfma16": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "e3dge_selftest_sin": (_i32, [_vp, _vp, _i32, _vp]),

@@ -31,7 +31,8 @@ def rendering_opt(N_samples=24, **over):
                  camera=AttrDict(dist_radius=0.12, fov=6, azim=0.3, elev=0.15, uniform=False),
                  enable_local_model=False, return_feats=False, return_feats_layers=[1, 3, 5, 7],
                  local_modulation_layer_in_backbone=False, local_modulation_layer=False,
-                 use_integrated_surface_normal=False, sample_near_surface=False, sample_uniform_grid=False)
+                 use_integrated_surface_normal=False, sample_near_surface=False, sample_uniform_grid=False,
+                 L_pred_tex_modulations=False, residual_local_feats_dim=301)
     o.update(over)
     return o
 
@@ -71,6 +72,10 @@ def synthetic_tensor(key, shape, seed=0):
         else:                                                        # FiLMSiren 256(+3) -> 256
             fan_in = shape[1] if leaf == 'weight' else (259 if '.views_linears.' in key else 256)
             v = u(math.sqrt(6 / fan_in) / 25) if leaf == 'weight' else u(math.sqrt(1 / fan_in))
+        return torch.from_numpy(np.asarray(v, dtype=np.float32))
+    if '.local_feat_to_tex_modulations_linear.' in key:              # texture head: the reference zero-inits it (untestable)
+        v = math.sqrt(2.0 / shape[-1]) * rs.standard_normal(shape) * (0.5 if '.fc_1.' in key else 1.0) \
+            if leaf == 'weight' else 0.05 * rs.standard_normal(shape)
         return torch.from_numpy(np.asarray(v, dtype=np.float32))
     if key.startswith('style.') or ('.style.' not in key and key.split('.')[0] == 'style'):
         v = _kaiming_std(shape[-1]) * rs.standard_normal(shape) if leaf == 'weight' else u(math.sqrt(1 / 256))
@@ -129,3 +134,12 @@ def synthetic_tex_conditions(batch, res, n_samples, seed=5, device="cpu"):
     a = 0.1 * rs.standard_normal(shape).astype(np.float32)
     b = 0.05 * rs.standard_normal(shape).astype(np.float32)
     return torch.from_numpy(a).to(device), torch.from_numpy(b).to(device)
+
+
+def synthetic_local_feats(batch, res, n_samples, cin=301, seed=5, device='cpu'):
+    """(B, res, res, n_samples, cin) stand-in for the PIFu branch's per-point local features (feature-map samples and a
+    positional encoding in the reference): mixed magnitudes, some channels large."""
+    rs = np.random.RandomState(seed)
+    f = rs.standard_normal((batch, res, res, n_samples, cin)).astype(np.float32)
+    f *= (0.2 + 3.0 * rs.uniform(size=(1, 1, 1, 1, cin))).astype(np.float32)
+    return torch.from_numpy(f).to(device)

@@ -413,11 +413,83 @@ class _RenderQuery(torch.autograd.Function):
         return dstyles, None, None, None, None, None, None
 
 
+class ResnetBlockFC(nn.Module):
+    """The local branch's texture head (reference project/models/helper_modules/resnetfc.py:7-58 as built at
+    vendor/pifu/lib/model/HGPIFuGANNetResidualInputResnetFC.py:84-93): x (.., size_in) ->
+    shortcut(x) + fc_1(relu(fc_0(relu(x)))), one fused HIP launch (e3dge_tex_modulations_fwd).  Same parameter names
+    (fc_0, fc_1, shortcut) and the reference's zero initialisation, so checkpoints load unchanged."""
+
+    def __init__(self, size_in, size_out=512):
+        super().__init__()
+        if size_in > 320 or size_out != 512:
+            raise NotImplementedError(f"ResnetBlockFC({size_in}, {size_out}): the kernel covers size_in <= 320, size_out = 512")
+        self.size_in, self.size_h, self.size_out = size_in, min(size_in, size_out), size_out
+        self.fc_0 = nn.Linear(size_in, self.size_h)
+        self.fc_1 = nn.Linear(self.size_h, size_out)
+        self.shortcut = nn.Linear(size_in, size_out, bias=False)
+        for t in (self.fc_0.bias, self.fc_0.weight, self.fc_1.bias, self.fc_1.weight, self.shortcut.weight):
+            nn.init.zeros_(t)                                        # :88-93 (and resnetfc.py:36)
+        self._cache_key = None
+        self._cache = None
+
+    def device_image(self):
+        ps = [self.fc_0.weight, self.fc_0.bias, self.fc_1.weight, self.fc_1.bias, self.shortcut.weight]
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        if key != self._cache_key:
+            dev = ps[0].device
+            _lib.require_gpu(ps[0], "ResnetBlockFC weights")
+            lib = _lib.load()
+            packed = torch.empty(lib.e3dge_resblock_packed_floats(), device=dev, dtype=torch.float32)
+            c = [p.detach().contiguous().float() for p in ps]
+            with torch.cuda.device(dev):
+                rc = lib.e3dge_resblock_pack_weights(_lib.ptr(packed), *[_lib.ptr(t) for t in c], self.size_in,
+                                                     torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(rc, "e3dge_resblock_pack_weights")
+            self._cache, self._cache_key = packed, key
+        return self._cache
+
+    def forward(self, x):
+        """(.., size_in) -> (.., 512) like the reference module."""
+        a, b = self.tex_modulations(x)
+        return torch.cat([a, b], -1)
+
+    def tex_modulations(self, feats):
+        """feats (.., size_in) -> (alpha, beta), each (.., 256): the split the renderer's second pass consumes."""
+        _lib.require_gpu(feats, "feats")
+        if feats.shape[-1] != self.size_in:
+            raise RuntimeError(f"local features must have {self.size_in} channels, got {tuple(feats.shape)}")
+        if torch.is_grad_enabled() and (feats.requires_grad or self.fc_0.weight.requires_grad):
+            raise NotImplementedError("the texture head has no HIP backward (the second renderer pass runs under no_grad "
+                                      "in the reference's inference / stage-1 paths)")
+        lead = feats.shape[:-1]
+        f = feats.reshape(-1, self.size_in).contiguous().float()
+        n = f.shape[0]
+        alpha = torch.empty((n, 256), device=f.device, dtype=torch.float32)
+        beta = torch.empty((n, 256), device=f.device, dtype=torch.float32)
+        packed = self.device_image()
+        with torch.cuda.device(f.device):
+            rc = _lib.load().e3dge_tex_modulations_fwd(_lib.ptr(packed), _lib.ptr(f), self.size_in, n, _lib.ptr(alpha),
+                                                       _lib.ptr(beta), _lib.stream_of(f))
+        _lib.check(rc, "e3dge_tex_modulations_fwd")
+        return alpha.reshape(*lead, 256), beta.reshape(*lead, 256)
+
+
+class LocalTexHead(nn.Module):
+    """`netLocal` as far as this build goes: only the texture-modulation head (state-dict key
+    `netLocal.local_feat_to_tex_modulations_linear.*`).  The hourglass image filters and the feature query of the PIFu
+    branch are outside the path; their output, the (B,H,W,S,C) local features, comes in through
+    `local_data_batch['feats']`."""
+
+    def __init__(self, feats_dim):
+        super().__init__()
+        self.local_feat_to_tex_modulations_linear = ResnetBlockFC(feats_dim, 512)
+
+
 class SirenLocalGlobal(nn.Module):
-    """Holder that keeps the `network.netGlobal.*` checkpoint keys of the reference's local+global wrapper
-    (:267-558).  The PIFu local branch itself (netLocal) is outside this build; its OUTPUT --
-    per-point texture FiLM (alpha, beta), each (B,H,W,S,256) -- is accepted through
-    `local_data_batch['tex']` and applied inside the fused kernel (:217-220)."""
+    """Keeps the `network.netGlobal.*` / `network.netLocal.local_feat_to_tex_modulations_linear.*` checkpoint keys of
+    the reference's local+global wrapper (:267-558).  Second-pass inputs (`local_data_batch`): either the local features
+    'feats' (B,H,W,S,C) -- the texture FiLM (alpha, beta) is then computed by the fused head above (:327-336) -- or
+    'tex' = (alpha, beta) directly; both are applied inside the fused render kernel (:217-220)."""
 
     def __init__(self, D=8, W=256, style_dim=256, input_ch=3, input_ch_views=3, output_ch=4,
                  output_features=True, scene_scale=0.12, local_options=None, opt=None):
@@ -425,6 +497,10 @@ class SirenLocalGlobal(nn.Module):
         self.opt = opt
         self.netGlobal = SirenGenerator(opt, D, W, style_dim, input_ch, input_ch_views, output_ch,
                                         output_features, scene_scale)
+        if _opt_get(opt, 'L_pred_tex_modulations', False):
+            self.netLocal = LocalTexHead(int(_opt_get(opt, 'residual_local_feats_dim', 301)))
+        else:
+            self.netLocal = None
 
 
 class VolumeFeatureRenderer(nn.Module):
@@ -628,10 +704,15 @@ class VolumeFeatureRenderer(nn.Module):
         if self.enable_local_model and local_data_batch is not None:
             if 'tex' in local_data_batch:
                 tex = local_data_batch['tex']
+            elif local_data_batch.get('feats', None) is not None and self.network.netLocal is not None:
+                # already-queried local features (forward_local :434-437) -> texture FiLM (:327-336), fused head
+                with torch.no_grad():
+                    tex = self.network.netLocal.local_feat_to_tex_modulations_linear.tex_modulations(local_data_batch['feats'])
             else:
                 raise NotImplementedError(
-                    "local_data_batch must carry the texture FiLM conditions as local_data_batch['tex'] = (alpha, "
-                    "beta); computing them from 'feats' needs the PIFu head (SURVEY.md 8f-1)")
+                    "local_data_batch must carry the local features 'feats' (B,H,W,S,C) [with L_pred_tex_modulations] or "
+                    "the texture FiLM conditions 'tex' = (alpha, beta); filtering images and querying the PIFu feature "
+                    "maps is outside this build (SURVEY.md 8f-2)")
             self.local_batch = local_data_batch
         else:
             self.local_batch = None

@@ -243,6 +243,22 @@ int e3dge_siren_render_bwd(const E3dgeRenderBwdArgs* args, e3dge_stream_t stream
 
 
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Local-feature -> texture-FiLM head (second renderer pass): out = W_s x + W_1 relu(W_0 relu(x) + b_0) + b_1,
+ * (alpha, beta) = split(out, 256).  Replaces ResnetBlockFC.forward (project/models/helper_modules/resnetfc.py:49-58) as
+ * netLocal.local_feat_to_tex_modulations_linear (vendor/pifu/lib/model/HGPIFuGANNetResidualInputResnetFC.py:84-93), called
+ * in SirenLocalGlobal.forward_backbone (project/utils/volume_renderer.py:327-336).
+ *   w0 (cin, cin), b0 (cin)   fc_0        w1 (512, cin), b1 (512)   fc_1        ws (512, cin)   shortcut (no bias)
+ *   feats (n_pts, cin) row-major, cin <= 320        alpha, beta (n_pts, 256) out -- the tex_alpha / tex_beta inputs of
+ *   e3dge_siren_render_fwd.  Split-f16 contraction with per-point block scaling, fp32 accumulate.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int64_t e3dge_resblock_packed_floats(void);
+int e3dge_resblock_pack_weights(float* packed, const float* w0, const float* b0, const float* w1, const float* b1,
+                                const float* ws, int cin, e3dge_stream_t stream);
+int e3dge_tex_modulations_fwd(const float* packed, const float* feats, int cin, int64_t n_pts,
+                              float* alpha, float* beta, e3dge_stream_t stream);
+
+
 /* Layout self-test: runs a 32x32xK fp32-MFMA product with the fragment conventions the render kernel
  * relies on and writes it to c (32*32 floats, row-major) for the caller to compare with a @ b^T.
  * a: (32, k) row-major, b: (32, k) row-major, k multiple of 8, k <= 256. */

@@ -140,3 +140,15 @@ def query_points(sd, pts, viewdirs, styles, dist_radius=0.12, prefix='renderer.'
     vd = torch.zeros_like(pts) if viewdirs is None else viewdirs.to(dtype).expand(pts.shape)
     net_in = torch.cat([pts * (2 / (2 * dist_radius)), vd], -1)
     return siren_forward(sd, net_prefix, net_in, styles)
+
+
+def tex_modulations(sd, prefix, feats, dtype=torch.float32):
+    """ResnetBlockFC.forward (project/models/helper_modules/resnetfc.py:49-58) of
+    netLocal.local_feat_to_tex_modulations_linear, then the split of SirenLocalGlobal.forward_backbone (:331-336).
+    feats (.., cin) -> (alpha, beta), each (.., 256)."""
+    x = feats.to(dtype)
+    w = lambda k: _w(sd, prefix + k, dtype)
+    net = F.linear(torch.relu(x), w('fc_0.weight'), w('fc_0.bias'))
+    dx = F.linear(torch.relu(net), w('fc_1.weight'), w('fc_1.bias'))
+    out = F.linear(x, w('shortcut.weight')) + dx
+    return torch.split(out, 256, dim=-1)

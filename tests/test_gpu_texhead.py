@@ -1,0 +1,119 @@
+"""GPU: the local-feature -> texture-FiLM head (e3dge_tex_modulations_fwd) against the vectors recorded
+from the reference's ResnetBlockFC and against the oracle on other sizes; then through the renderer's second pass.
+
+Stated fp32 tolerance: outputs are O(10); the reference's own fp32 result is 9e-6 (abs) from the float64 evaluation on
+the fixture.  Bound: |hip - reference| <= 2e-5 * max(1, max|out|/10) (measured 4-9e-6) and |hip - f64| <= 3x the fp32 oracle's own
+distance (+1e-5)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import full_state_dict, load_golden, maxerr, record
+from oracle import renderer_ref
+
+import e3dge_amd  # noqa: F401
+from e3dge_amd import synthetic as syn
+from e3dge_amd.camera_utils import generate_camera_params
+from e3dge_amd.volume_renderer import ResnetBlockFC, VolumeFeatureRenderer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+PREFIX = 'renderer.network.netLocal.local_feat_to_tex_modulations_linear.'
+
+
+def make_head(cin):
+    h = ResnetBlockFC(cin, 512)
+    sd = {k: syn.synthetic_tensor(PREFIX + k, v.shape) for k, v in h.state_dict().items()}
+    h.load_state_dict(sd)
+    return h.to(DEV), {PREFIX + k: v for k, v in sd.items()}
+
+
+def test_texhead_against_reference_golden():
+    g = load_golden("texhead_301")
+    cin = int(g['cin'])
+    h, _ = make_head(cin)
+    shp = tuple(int(v) for v in g['feats_shape'])
+    feats = syn.synthetic_local_feats(shp[0], shp[1], shp[3], cin=cin, seed=int(g['feats_seed']), device=DEV).reshape(shp)
+    with torch.no_grad():
+        a, b = h.tex_modulations(feats)
+        both = h(feats)
+    assert tuple(a.shape) == shp[:-1] + (256,) and tuple(both.shape) == shp[:-1] + (512,)
+    e = dict(alpha_vs_ref=maxerr(a, g['ref_alpha']), beta_vs_ref=maxerr(b, g['ref_beta']),
+             alpha_vs_f64=maxerr(a, g['f64_alpha']), beta_vs_f64=maxerr(b, g['f64_beta']),
+             ref_vs_f64=float(max(np.abs(g['ref_alpha'] - g['f64_alpha']).max(), np.abs(g['ref_beta'] - g['f64_beta']).max())))
+    record("texhead_golden_301", **e)
+    assert max(e["alpha_vs_ref"], e["beta_vs_ref"]) <= 2e-5, e
+    assert max(e['alpha_vs_f64'], e['beta_vs_f64']) <= 3 * e['ref_vs_f64'] + 1e-5, e
+    assert torch.equal(both[..., :256], a) and torch.equal(both[..., 256:], b)
+
+
+@pytest.mark.parametrize("cin", [64, 256, 301, 320])
+@pytest.mark.parametrize("n", [1, 127, 129, 5000])
+def test_texhead_sizes_against_oracle(cin, n):
+    h, sd = make_head(cin)
+    rs = np.random.RandomState(cin + n)
+    feats = torch.from_numpy((rs.standard_normal((n, cin)) * (0.1 + 2 * rs.uniform(size=(1, cin)))).astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        a, b = h.tex_modulations(feats)
+        ra, rb = renderer_ref.tex_modulations(sd, PREFIX, feats.cpu())
+        ta, tb = renderer_ref.tex_modulations(sd, PREFIX, feats.cpu(), dtype=torch.float64)
+    scale = max(1.0, float(ta.abs().max()) / 10)
+    e = max(maxerr(a, ra), maxerr(b, rb))
+    e64, o64 = max(maxerr(a, ta), maxerr(b, tb)), max(maxerr(ra, ta), maxerr(rb, tb))
+    record(f"texhead_cin{cin}_n{n}", hip_vs_oracle=e, hip_vs_f64=e64, oracle_vs_f64=o64, out_max=float(ta.abs().max()))
+    assert e <= 2e-5 * scale and e64 <= 3 * o64 + 1e-5 * scale, (e, e64, o64)
+
+
+@pytest.mark.parametrize("mag", [1e-6, 1e+4])
+def test_texhead_input_magnitude(mag):
+    """Per-point block scaling of the operands: the relative error does not depend on the input's magnitude."""
+    h, sd = make_head(301)
+    rs = np.random.RandomState(3)
+    feats = torch.from_numpy((mag * rs.standard_normal((700, 301))).astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        a, b = h.tex_modulations(feats)
+        ta, tb = renderer_ref.tex_modulations(sd, PREFIX, feats.cpu(), dtype=torch.float64)
+    ref = torch.cat([ta, tb], -1)
+    # the bias terms are O(0.05): compare relative to the output's own scale
+    rel = float((torch.cat([a, b], -1).double().cpu() - ref).abs().max() / ref.abs().max())
+    record(f"texhead_magnitude_{mag:g}", rel_err=rel)
+    assert rel <= 5e-6, rel
+    with torch.no_grad():
+        assert torch.equal(*[h.tex_modulations(feats)[0] for _ in range(2)])
+        empty = h.tex_modulations(torch.empty(0, 301, device=DEV))
+    assert empty[0].shape == (0, 256)
+    with pytest.raises(NotImplementedError):            # no silent autograd gap
+        h.tex_modulations(feats)
+
+
+def test_second_pass_from_local_feats():
+    """VolumeFeatureRenderer.forward with local_data_batch={'feats': ...} (the reference's second pass with already
+    queried local features, :434-437 + :327-336 + :217-220) == the oracle's render with the oracle's (alpha, beta)."""
+    res, S = 8, 24
+    g, sd = full_state_dict(res=res, n_samples=S)
+    r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S, enable_local_model=True, L_pred_tex_modulations=True),
+                              out_im_res=res, mode='test')
+    own = {}
+    for k in r.state_dict():
+        if 'netLocal' in k:
+            own[k] = syn.synthetic_tensor('renderer.' + k, r.state_dict()[k].shape) * 0.05     # small FiLM perturbation
+        else:
+            own[k] = sd['renderer.' + k.replace('network.netGlobal.', 'network.')]
+    r.load_state_dict(own)
+    r = r.to(DEV)
+    sd_all = dict(sd)
+    sd_all.update({'renderer.' + k: v for k, v in own.items() if 'netLocal' in k})
+    wr, _ = syn.synthetic_inputs(1, seed=2, device=DEV)
+    poses, focal, near, far, _ = generate_camera_params(res, DEV, locations=torch.tensor([[0.2, 0.0]], device=DEV))
+    feats = syn.synthetic_local_feats(1, res, S, device=DEV)
+    with torch.no_grad():
+        out = r(poses, focal, near, far, styles=wr, local_data_batch={'feats': feats})
+        ta, tb = renderer_ref.tex_modulations(sd_all, PREFIX, feats.cpu())
+        c = lambda t: t.detach().cpu()
+        ref = renderer_ref.render(sd, c(poses), c(focal), c(near), c(far), c(wr), res=res, n_samples=S, tex=(ta, tb))
+        plain = renderer_ref.render(sd, c(poses), c(focal), c(near), c(far), c(wr), res=res, n_samples=S)
+    e = dict(features=maxerr(out['features'], ref['features']), rgb=maxerr(out['gen_thumb_imgs'], ref['gen_thumb_imgs']),
+             sdf=maxerr(out['sdf'], ref['sdf']), tex_effect=maxerr(ref['features'], plain['features']))
+    record("second_pass_from_local_feats", **e)
+    assert e['tex_effect'] > 1e-2                        # the modulation does something
+    assert e['features'] <= 1e-4 and e['rgb'] <= 5e-6 and e['sdf'] <= 1e-5, e

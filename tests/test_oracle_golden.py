@@ -163,3 +163,19 @@ def test_training_direction_restatement_matches_reference_gradients():
     assert abs(float(loss) - float(g['ref_loss'])) <= 1e-6 * abs(float(g['ref_loss']))
     rel = np.abs(s.grad.numpy() - g['ref_dstyles']).max() / np.abs(g['ref_dstyles']).max()
     assert rel <= 1e-6, rel
+
+
+def test_texhead_restatement_matches_reference_class():
+    """oracle/renderer_ref.tex_modulations against the vectors recorded from the reference's ResnetBlockFC
+    (oracle/gen_golden_texhead.py)."""
+    g = load_golden("texhead_301")
+    prefix = 'renderer.network.netLocal.local_feat_to_tex_modulations_linear.'
+    cin = int(g['cin'])
+    sd = {prefix + k: syn.synthetic_tensor(prefix + k, shp) for k, shp in
+          (('fc_0.weight', (cin, cin)), ('fc_0.bias', (cin,)), ('fc_1.weight', (512, cin)), ('fc_1.bias', (512,)),
+           ('shortcut.weight', (512, cin)))}
+    shp = tuple(int(v) for v in g['feats_shape'])
+    feats = syn.synthetic_local_feats(shp[0], shp[1], shp[3], cin=cin, seed=int(g['feats_seed'])).reshape(shp)
+    with torch.no_grad():
+        a, b = renderer_ref.tex_modulations(sd, prefix, feats)
+    assert np.abs(a.numpy() - g['ref_alpha']).max() == 0 and np.abs(b.numpy() - g['ref_beta']).max() == 0
