@@ -9,9 +9,9 @@
 // MFMA contractions (hi + lo, three products, fp32 accumulate) with per-point power-of-two block scaling of the B operand
 // (the inputs are unbounded), weights streamed L2 -> LDS by the shared ChunkPipe in 32-KiB chunks (32 output rows x 256 k).
 // K = 320 (Cin padded) is two chunks: a full one and one of which only the first four k-steps (64 k) are non-zero and
-// executed.  x is kept as packed (hi, lo) words (160 registers), relu(x) is formed from them on the fly per k-step
-// (integer sign masks), r = relu(net) is kept in fp32 (160 AGPRs) and split on the fly when it is an operand.  Neither
-// the (P, 301) hidden activations nor r ever touch memory; the output goes straight to (alpha, beta).
+// executed.  x and r = relu(net) are kept as packed (hi, lo) words (160 registers each); relu(x) is formed from x's words
+// on the fly per k-step (integer sign masks).  Neither the (P, 301) hidden activations nor r ever touch memory; the output
+// goes straight to (alpha, beta).
 #include "siren_common.h"
 
 namespace e3dge {
@@ -26,7 +26,8 @@ constexpr int kRbChunksG2 = kRbTilesOut * 4;                // per out tile: W_s
 constexpr int kRbChunks = kRbChunksG1 + kRbChunksG2;        // 84
 constexpr int64_t kRbOffBias0 = (int64_t)kRbChunks * kChunkFloats;    // b_0 [320]
 constexpr int64_t kRbOffBias1 = kRbOffBias0 + kRbKin;                 // b_1 [512]
-constexpr int64_t kRbPackedFloats = kRbOffBias1 + kRbOut;
+constexpr int64_t kRbOffAux = kRbOffBias1 + kRbOut;                   // [0] max_n ||W_0[n,:]||_2, [1] max |b_0|, [2..3] pad
+constexpr int64_t kRbPackedFloats = kRbOffAux + 4;
 
 constexpr int kRbXPitch = 36;             // floats per point row of the staging tile (16-B aligned rows)
 constexpr int kRbLdsW = 0;
@@ -45,7 +46,9 @@ resblock_pack_kernel(float* __restrict__ packed, const float* __restrict__ w0, c
                      const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ ws, int cin) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < kRbPackedFloats; e += (int64_t)gridDim.x * 256) {
         float v;
-        if (e >= kRbOffBias1) {
+        if (e >= kRbOffAux) {
+            continue;                                  // written by resblock_norm_kernel
+        } else if (e >= kRbOffBias1) {
             v = b1[e - kRbOffBias1];
         } else if (e >= kRbOffBias0) {
             const int n = (int)(e - kRbOffBias0);
@@ -80,6 +83,29 @@ resblock_pack_kernel(float* __restrict__ packed, const float* __restrict__ w0, c
         }
         packed[e] = v;
     }
+}
+
+// bound on the hidden activations: |net_n| <= ||W_0[n,:]||_2 ||relu(x)||_2 + |b_0[n]|.  The two weight-side factors:
+__global__ void __launch_bounds__(256)
+resblock_norm_kernel(float* __restrict__ aux, const float* __restrict__ w0, const float* __restrict__ b0, int cin) {
+    __shared__ float red[2][256];
+    float rn = 0.0f, bm = 0.0f;
+    for (int n = threadIdx.x; n < cin; n += 256) {
+        float ss = 0.0f;
+        for (int k = 0; k < cin; ++k) { const float w = w0[(int64_t)n * cin + k]; ss = fmaf(w, w, ss); }
+        rn = fmaxf(rn, sqrtf(ss));
+        bm = fmaxf(bm, fabsf(b0[n]));
+    }
+    red[0][threadIdx.x] = rn; red[1][threadIdx.x] = bm;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            red[0][threadIdx.x] = fmaxf(red[0][threadIdx.x], red[0][threadIdx.x + s]);
+            red[1][threadIdx.x] = fmaxf(red[1][threadIdx.x], red[1][threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { aux[0] = red[0][0]; aux[1] = red[1][0]; aux[2] = 0.0f; aux[3] = 0.0f; }
 }
 
 // one weight chunk against KSTEPS k-steps of a B operand produced by `opnd(g, H, L)`; the same ring / barrier / DMA protocol
@@ -176,10 +202,10 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
 
         // ---- 1. x: coalesced 32-feature slices through LDS, each lane keeps its point's values; then (hi, lo) ----
         u32x4 xH[kRbStepsIn], xL[kRbStepsIn];
-        float inv_x;
+        float inv_x, xnorm;
         {
             f32x16 xf[kRbTilesIn];
-            float m = 0.0f;
+            float m = 0.0f, ss = 0.0f;
             const long long sub0 = pt0 + (long long)sub * kTilePts;
 #pragma unroll
             for (int ft = 0; ft < kRbTilesIn; ++ft) {
@@ -198,11 +224,13 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 q4 = *reinterpret_cast<const f32x4*>(row + 8 * q);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { xf[ft][4 * q + j] = q4[j]; m = fmaxf(m, fabsf(q4[j])); }
+                    for (int j = 0; j < 4; ++j) { xf[ft][4 * q + j] = q4[j]; m = fmaxf(m, fabsf(q4[j])); ss = fmaf(q4[j], q4[j], ss); }
                 }
                 asm volatile("" : "+a"(xf[ft]));
             }
             m = fmaxf(m, xhalf(m));
+            ss += xhalf(ss);
+            xnorm = sqrtf(ss);
             const unsigned e = (__float_as_uint(m) >> 23) & 255u;
             const float sc = __uint_as_float((254u - e) << 23);
             inv_x = __uint_as_float((e > 8u ? e - 7u : 1u) << 23);
@@ -213,53 +241,53 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
                     SPLIT2_TO(xf[t][r] * sc, xf[t][r + 1] * sc, xH[2 * t + (r >> 3)][(r & 7) >> 1], xL[2 * t + (r >> 3)][(r & 7) >> 1]);
         }
 
-        // ---- 2. net = W_0 relu(x) + b_0 ; r = relu(net), kept in fp32 ----
-        f32x16 rf[kRbTilesIn];
-        float rmax = 0.0f;
+        // ---- 2. net = W_0 relu(x) + b_0 ; r = relu(net) as (hi, lo) words ----
+        // r has to be split tile by tile (keeping it in fp32 until its column maximum is known costs 160 more registers
+        // than there are), so its scale comes from the bound max|net| <= max_n ||W_0[n,:]|| * ||x|| + max|b_0| instead of the
+        // exact maximum: typically a few bits of headroom, i.e. the operand is still good to ~2^-21 of the column maximum.
+        u32x4 rH[kRbStepsIn], rL[kRbStepsIn];
+        float inv_r;
+        {
+            const float bound = fmaf(packed[kRbOffAux], xnorm, packed[kRbOffAux + 1]);
+            const unsigned er = (__float_as_uint(bound) >> 23) & 255u;     // bound < 2^(er-126)
+            const float sc_r = __uint_as_float((253u - er) << 23);          // r * sc_r < 1
+            inv_r = __uint_as_float((er > 8u ? er - 6u : 1u) << 23);        // 1 / (128 * sc_r)
 #pragma unroll
-        for (int t = 0; t < kRbTilesIn; ++t) {
-            f32x16 acc = zero16(), accb = zero16();
-            rb_tile<16, kSyncStep16>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
-                [&](int g, u32x4& H, u32x4& L) {
+            for (int t = 0; t < kRbTilesIn; ++t) {
+                f32x16 acc = zero16(), accb = zero16();
+                rb_tile<16, kSyncStep16>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
+                    [&](int g, u32x4& H, u32x4& L) {
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) { unsigned h, l; relu_hilo(xH[g][w], xL[g][w], h, l); H[w] = h; L[w] = l; }
-                }, chunk_sync, issue_piece);
-            pipe.advance();
-            rb_tile<4, 0>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
-                [&](int g, u32x4& H, u32x4& L) {
+                        for (int w = 0; w < 4; ++w) { unsigned h, l; relu_hilo(xH[g][w], xL[g][w], h, l); H[w] = h; L[w] = l; }
+                    }, chunk_sync, issue_piece);
+                pipe.advance();
+                rb_tile<4, 0>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
+                    [&](int g, u32x4& H, u32x4& L) {
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) { unsigned h, l; relu_hilo(xH[16 + g][w], xL[16 + g][w], h, l); H[w] = h; L[w] = l; }
-                }, chunk_sync, issue_piece);
-            pipe.advance();
-            const f32x16 sum = (acc + accb) * inv_x;
+                        for (int w = 0; w < 4; ++w) { unsigned h, l; relu_hilo(xH[16 + g][w], xL[16 + g][w], h, l); H[w] = h; L[w] = l; }
+                    }, chunk_sync, issue_piece);
+                pipe.advance();
+                const f32x16 sum = (acc + accb) * inv_x;
+                f32x16 rv;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(b0_s + 32 * t + 8 * q + 4 * half);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(b0_s + 32 * t + 8 * q + 4 * half);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = fmaxf(sum[4 * q + j] + b4[j], 0.0f);
-                    rf[t][4 * q + j] = v;
-                    rmax = fmaxf(rmax, v);
+                    for (int j = 0; j < 4; ++j) rv[4 * q + j] = fmaxf(sum[4 * q + j] + b4[j], 0.0f) * sc_r;
                 }
+#pragma unroll
+                for (int r = 0; r < 16; r += 2)
+                    SPLIT2_TO(rv[r], rv[r + 1], rH[2 * t + (r >> 3)][(r & 7) >> 1], rL[2 * t + (r >> 3)][(r & 7) >> 1]);
+                asm volatile("" : "+a"(rH[2 * t]), "+a"(rH[2 * t + 1]), "+a"(rL[2 * t]), "+a"(rL[2 * t + 1]));
             }
-            asm volatile("" : "+a"(rf[t]));
         }
-        rmax = fmaxf(rmax, xhalf(rmax));
-        const unsigned er = (__float_as_uint(rmax) >> 23) & 255u;
-        const float sc_r = __uint_as_float((254u - er) << 23);
-        const float inv_r = __uint_as_float((er > 8u ? er - 7u : 1u) << 23);
 
         // ---- 3. out = W_s x + W_1 r + b_1 -> alpha (tiles 0..7), beta (tiles 8..15) ----
-        auto r_operand = [&](int gg, u32x4& H, u32x4& L) {          // k-step gg of r, split on the fly
-            const int t = gg >> 1, r0 = 8 * (gg & 1);
+#ifdef E3DGE_RB_UNROLL2
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                unsigned h, l;
-                SPLIT2_TO(rf[t][r0 + 2 * w] * sc_r, rf[t][r0 + 2 * w + 1] * sc_r, h, l);
-                H[w] = h; L[w] = l;
-            }
-        };
-#pragma unroll
+#else
+#pragma unroll 1
+#endif
         for (int t = 0; t < kRbTilesOut; ++t) {
             f32x16 acc = zero16(), accb = zero16();
             rb_tile<16, kSyncStep16>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
@@ -271,10 +299,10 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
             f32x16 res = (acc + accb) * inv_x;
             acc = zero16(); accb = zero16();
             rb_tile<16, kSyncStep16>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
-                [&](int g, u32x4& H, u32x4& L) { r_operand(g, H, L); }, chunk_sync, issue_piece);
+                [&](int g, u32x4& H, u32x4& L) { H = rH[g]; L = rL[g]; }, chunk_sync, issue_piece);
             pipe.advance();
             rb_tile<4, 0>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
-                [&](int g, u32x4& H, u32x4& L) { r_operand(16 + g, H, L); }, chunk_sync, issue_piece);
+                [&](int g, u32x4& H, u32x4& L) { H = rH[16 + g]; L = rL[16 + g]; }, chunk_sync, issue_piece);
             pipe.advance();
             res = res + (acc + accb) * inv_r;
             float* __restrict__ dst = (t < 8 ? a.alpha : a.beta) + gpt * kWidth + 32 * (t & 7);
@@ -302,7 +330,10 @@ extern "C" int e3dge_resblock_pack_weights(float* packed, const float* w0, const
     E3DGE_REQUIRE(packed && w0 && b0 && w1 && b1 && ws, "resblock_pack_weights: null pointer");
     E3DGE_REQUIRE(cin >= 1 && cin <= kRbKin, "resblock_pack_weights: cin=%d outside [1, %d]", cin, kRbKin);
     resblock_pack_kernel<<<dim3(1024), dim3(256), 0, as_stream(stream)>>>(packed, w0, b0, w1, b1, ws, cin);
-    return check_launch("resblock_pack_weights");
+    int rc = check_launch("resblock_pack_weights");
+    if (rc) return rc;
+    resblock_norm_kernel<<<dim3(1), dim3(256), 0, as_stream(stream)>>>(packed + kRbOffAux, w0, b0, cin);
+    return check_launch("resblock_pack_weights(norms)");
 }
 
 extern "C" int e3dge_tex_modulations_fwd(const float* packed, const float* feats, int cin, int64_t n_pts,

@@ -20,15 +20,19 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def timed(fn, n=10, warm=3):
+def timed(fn, n=10, warm=3, rounds=3):
+    """Best of `rounds` averages over n calls (a single disturbed round must not decide an assertion)."""
     for _ in range(warm):
         fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
+    best = float("inf")
+    for _ in range(rounds):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / n * 1e3)
+    return best
 
 
 @pytest.mark.parametrize("batch", [1, 4])
@@ -108,3 +112,31 @@ def test_stage1_step_fused_vs_eager_same_gpu():
     record("stage1_fused_vs_eager_same_gpu", grad_rel_diff=rel, **t, speedup=t['eager_ms'] / t['hip_ms'])
     assert rel <= 2e-3
     assert t['hip_ms'] < t['eager_ms'], t
+
+
+def test_texhead_fused_vs_eager_same_gpu():
+    """Second-pass texture head at C2 size (98,304 points x 301 features): one fused launch vs the restatement's three
+    GEMMs + elementwise kernels in eager PyTorch on the same GPU."""
+    from e3dge_amd.volume_renderer import ResnetBlockFC
+    prefix = 'renderer.network.netLocal.local_feat_to_tex_modulations_linear.'
+    h = ResnetBlockFC(301, 512)
+    sd = {k: syn.synthetic_tensor(prefix + k, v.shape) for k, v in h.state_dict().items()}
+    h.load_state_dict(sd)
+    h = h.to(DEV)
+    sd_dev = {prefix + k: v.to(DEV) for k, v in sd.items()}
+    feats = syn.synthetic_local_feats(1, 64, 24, device=DEV)
+
+    def hip():
+        with torch.no_grad():
+            return h.tex_modulations(feats)
+
+    def eager():
+        with torch.no_grad():
+            return renderer_ref.tex_modulations(sd_dev, prefix, feats)
+    a, b = hip(), eager()
+    err = float(max((a[0] - b[0]).abs().max(), (a[1] - b[1]).abs().max()))
+    t = dict(hip_ms=timed(hip), eager_ms=timed(eager))
+    flops = 2 * (301 * 301 + 2 * 301 * 512) * feats.shape[1] * feats.shape[2] * feats.shape[3]
+    record("texhead_fused_vs_eager_same_gpu", max_abs_diff=err, **t, speedup=t['eager_ms'] / t['hip_ms'],
+           hip_algorithmic_tflops=flops / t['hip_ms'] / 1e9)
+    assert err <= 5e-5 and t['hip_ms'] < t['eager_ms'], (err, t)
