@@ -17,7 +17,7 @@ Extra objects on the JSON line:
                 PyTorch path on the golden vectors) timed on this host's cores on a bounded sample.
   c4_render_ms       (informational) one pose of the C4 sweep: 128x128 rays x 48 samples.
   train_step_ms      (informational) stage-1 training step of the renderer at 64x64x18 with eikonal terms, fwd + bwd.
-  inversion_fwd_ms   (informational) pass #1 + pass #2 with texture FiLM + decoder to 1024^2, one image.
+  inversion_fwd_ms   (informational) pass #1 + texture head + pass #2 with texture FiLM + decoder to 1024^2, one image.
 """
 import argparse
 import json
@@ -147,18 +147,22 @@ def main():
     if rank == 0 and not args.no_inversion:
         try:
             with torch.no_grad():
-                gl = G_pred_latents(syn.model_opt(), syn.rendering_opt(N_samples=N_SAMPLES, enable_local_model=True),
-                                    full_pipeline=True)
-                gl.load_state_dict({k.replace('renderer.network.', 'renderer.network.netGlobal.'): v for k, v in sd_cpu.items()})
+                gl = G_pred_latents(syn.model_opt(), syn.rendering_opt(N_samples=N_SAMPLES, enable_local_model=True,
+                                                                       L_pred_tex_modulations=True), full_pipeline=True)
+                sd_l = {k.replace('renderer.network.', 'renderer.network.netGlobal.'): v for k, v in sd_cpu.items()}
+                for k, v in gl.state_dict().items():
+                    if '.netLocal.' in k:                 # texture head: small synthetic weights (the reference zero-inits it)
+                        sd_l[k] = 0.05 * syn.synthetic_tensor(k, v.shape)
+                gl.load_state_dict(sd_l)
                 gl = gl.to(dev).eval()
                 w1, d1 = syn.synthetic_inputs(1, seed=1, device=dev)
                 p1, f1, n1, fa1, _ = generate_camera_params(RES, dev, locations=torch.zeros(1, 2, device=dev))
-                tex = syn.synthetic_tex_conditions(1, RES, N_SAMPLES, device=dev)
+                feats = syn.synthetic_local_feats(1, RES, N_SAMPLES, device=dev)      # what the PIFu branch would deliver
 
                 def inversion():
                     gl([w1, d1], p1, f1, n1, fa1, input_is_latent=True, sample_with_renderer=True)       # pass #1
                     return gl([w1, d1], p1, f1, n1, fa1, input_is_latent=True, randomize_noise=False,
-                              local_data_batch={'tex': tex})                                             # pass #2 + decoder
+                              local_data_batch={'feats': feats})                  # tex head + pass #2 + decoder
                 for _ in range(3):
                     inversion()
                 torch.cuda.synchronize()
@@ -168,8 +172,9 @@ def main():
                     o = inversion()
                 torch.cuda.synchronize()
                 result["inversion_fwd_ms"] = 1e3 * (time.perf_counter() - t1) / n_inv
-                result["inversion_fwd_note"] = ("pass#1 render + pass#2 render with (alpha,beta) texture FiLM + decoder 64^2->1024^2; "
-                                                "encoder / local-branch networks excluded (out of scope)")
+                result["inversion_fwd_note"] = ("pass#1 render + texture head on (64,64,24,301) local features + pass#2 render with the "
+                                                "resulting texture FiLM + decoder 64^2->1024^2; encoder and the local branch's image "
+                                                "filters / feature query excluded (out of scope)")
                 assert tuple(o['gen_imgs'].shape) == (1, 3, 1024, 1024)
             del gl
         except Exception as exc:  # the headline metric must still be printed

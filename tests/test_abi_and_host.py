@@ -110,6 +110,19 @@ def test_local_global_wrapper_keeps_netglobal_keys():
     keys = list(r.state_dict())
     assert 'sigmoid_beta' in keys and 'network.netGlobal.pts_linears.0.gamma.weight' in keys
     assert 'network.netGlobal.views_linears.weight' in keys and 'network.netGlobal.sigma_linear.bias' in keys
+    assert not any('netLocal' in k for k in keys)
+    # with the texture head enabled the reference's key path of the ResnetBlockFC appears, zero-initialised like there
+    r2 = VolumeFeatureRenderer(syn.rendering_opt(enable_local_model=True, L_pred_tex_modulations=True), mode='test')
+    pre = 'network.netLocal.local_feat_to_tex_modulations_linear.'
+    shapes = {k[len(pre):]: tuple(v.shape) for k, v in r2.state_dict().items() if k.startswith(pre)}
+    assert shapes == {'fc_0.weight': (301, 301), 'fc_0.bias': (301,), 'fc_1.weight': (512, 301), 'fc_1.bias': (512,),
+                      'shortcut.weight': (512, 301)}
+    assert all(float(v.abs().max()) == 0 for k, v in r2.state_dict().items() if k.startswith(pre))
+    assert lib_floats() == 84 * 8192 + 320 + 512 + 4
+
+
+def lib_floats():
+    return _lib.load().e3dge_resblock_packed_floats()
 
 
 def test_no_cpu_fallback_on_the_product_path():
