@@ -33,7 +33,7 @@ if REPO not in sys.path:
 
 RES, N_SAMPLES = 64, 24
 # HBM traffic of one 64x64x24 render launch measured with PMC counters (profiles/*_pmc.txt): KB -> bytes
-TRAFFIC_BYTES_PER_LAUNCH = {"f32": int((2 * 10432.5 + 11552) * 1024), "f16x3": int((2 * 17646.6 + 20762) * 1024)}
+TRAFFIC_BYTES_PER_LAUNCH = {"f32": int((2 * 8781.6 + 6688) * 1024), "f16x3": int((2 * 10343 + 13191.6) * 1024)}
 MAC_PER_POINT = 3 * 256 + 7 * 256 * 256 + 259 * 256 + 256 * 3 + 256       # 526,848
 FLOP_PER_RAY = 2 * MAC_PER_POINT * N_SAMPLES                               # 25.29 MFLOP
 BYTES_PER_RAY = (264 + 5 * N_SAMPLES) * 4                                  # mandatory outputs, 1,536 B

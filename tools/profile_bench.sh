@@ -7,7 +7,8 @@ TAG=${1:-r1}; shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 30 --warmup 5 --no-cpu-baseline $*"
+# only the headline workload in the profiled process: the informational legs launch the same kernels at other sizes
+BENCH="python $PWD/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-c4 --no-train-step --no-inversion $*"
 cd /tmp
 echo "== kernel trace" 
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1
@@ -18,7 +19,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_I
            "FETCH_SIZE" "WRITE_SIZE"; do
   name=$(echo $grp | cut -d' ' -f1)
   echo "== pmc $grp"
-  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc_$name" -o pmc -- $BENCH --no-inversion > "$OUT/pmc_$name.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d "$OUT/pmc_$name" -o pmc -- $BENCH > "$OUT/pmc_$name.log" 2>&1
   echo "rc=$?"
 done
 # compact summaries for profiles/
@@ -32,7 +33,7 @@ st = find("trace/**/*kernel_stats.csv")
 if st:
     rows = list(csv.DictReader(open(st)))
     with open(os.path.join(out, "kernel_stats_summary.txt"), "w") as f:
-        f.write("rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline\n")
+        f.write("rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-c4 --no-train-step --no-inversion\n")
         f.write(f"{'kernel':<90} {'calls':>6} {'total_ns':>14} {'avg_ns':>12} {'pct':>7}\n")
         for r in rows[:40]:
             f.write(f"{r['Name'][:90]:<90} {r['Calls']:>6} {r['TotalDurationNs']:>14} {float(r['AverageNs']):>12.0f} {r['Percentage']:>7}\n")
