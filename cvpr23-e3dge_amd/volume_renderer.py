@@ -176,6 +176,9 @@ class SirenGenerator(nn.Module):
                     _lib.ptr(w_view), _lib.ptr(b_view), _lib.ptr(w_rgb), _lib.ptr(b_rgb), _lib.ptr(w_sig),
                     _lib.ptr(b_sig), _lib.stream_of(packed))
             _lib.check(rc, "e3dge_siren_pack_weights")
+            # The f16x3 images carry the weights times 128 as f16 (max 65504): a checkpoint with |w| >= 256 in the
+            # 256-wide layers (trained ones are ~0.01) cannot use them; say so instead of producing infinities.
+            self._wmax = float(torch.maximum(w_hidden.abs().max(), w_view.abs().max()).item())
             layers = self._film_layers()
             wg = torch.stack([l.gamma.weight.detach() for l in layers]).contiguous()
             bg = torch.stack([l.gamma.bias.detach() for l in layers]).contiguous()
@@ -183,6 +186,13 @@ class SirenGenerator(nn.Module):
             bb = torch.stack([l.beta.bias.detach() for l in layers]).contiguous()
         self._cache, self._cache_key = (packed, wg, bg, wb, bb), key
         return self._cache
+
+    def check_mode(self, mode):
+        """Refuse the split-f16 kernels for weights outside their f16 range (see device_image)."""
+        if mode == "f16x3" and getattr(self, '_wmax', 0.0) >= 256.0:
+            raise RuntimeError(f"SIREN weights up to {self._wmax:g} do not fit the f16x3 weight image (|w| < 256); "
+                               "set E3DGE_MFMA_MODE=f32 / E3DGE_BWD_MODE=f32 for this checkpoint")
+        return MFMA_MODES[mode]
 
     def film_params(self, styles):
         """styles (B,9,256) [W+] or (B,256) [W, shared by all layers, reference :189-191] -> (B,9,2,256)."""
@@ -235,7 +245,7 @@ class SirenGenerator(nn.Module):
         with torch.cuda.device(pts.device):
             rc = _lib.load().e3dge_siren_points_fwd(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(pts), _lib.ptr(vd),
                                                     float(box_scale), B, N, _lib.ptr(sdf), _lib.ptr(raw), _lib.ptr(save_args),
-                                                    MFMA_MODES[mfma_mode or self.mfma_mode], _lib.stream_of(pts))
+                                                    self.check_mode(mfma_mode or self.mfma_mode), _lib.stream_of(pts))
         _lib.check(rc, "e3dge_siren_points_fwd")
         return sdf, raw
 
@@ -258,7 +268,7 @@ def sdf_gradient(siren, film, args, box_scale):
     eik = torch.empty((B, N, 3), device=args.device, dtype=torch.float32)
     with torch.cuda.device(args.device):
         rc = _lib.load().e3dge_siren_sdf_grad(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), None, float(box_scale),
-                                              B, N, _lib.ptr(rsave), _lib.ptr(eik), MFMA_MODES[siren.bwd_mode],
+                                              B, N, _lib.ptr(rsave), _lib.ptr(eik), siren.check_mode(siren.bwd_mode),
                                               _lib.stream_of(args))
     _lib.check(rc, "e3dge_siren_sdf_grad")
     return eik, rsave
@@ -272,7 +282,7 @@ def tangent_arguments(siren, film, args, v, box_scale):
     tang = torch.empty((B, N, 8, siren.W), device=args.device, dtype=torch.float32)
     with torch.cuda.device(args.device):
         rc = _lib.load().e3dge_siren_tangent(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), _lib.ptr(v), float(box_scale),
-                                             B, N, _lib.ptr(tang), MFMA_MODES[siren.bwd_mode], _lib.stream_of(args))
+                                             B, N, _lib.ptr(tang), siren.check_mode(siren.bwd_mode), _lib.stream_of(args))
     _lib.check(rc, "e3dge_siren_tangent")
     return tang
 
@@ -293,7 +303,7 @@ def siren_backward(siren, film, args, d_feat, d_rgb, d_sdf, tang=None, rsave=Non
     with torch.cuda.device(dev):
         rc = lib.e3dge_siren_bwd(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), _lib.ptr(d_feat), _lib.ptr(d_rgb),
                                  _lib.ptr(d_sdf), _lib.ptr(tang), _lib.ptr(rsave), _lib.ptr(wg), _lib.ptr(wb), B, N, _lib.ptr(partials),
-                                 _lib.ptr(dfilm), _lib.ptr(dstyles), MFMA_MODES[siren.bwd_mode], _lib.stream_of(args))
+                                 _lib.ptr(dfilm), _lib.ptr(dstyles), siren.check_mode(siren.bwd_mode), _lib.stream_of(args))
     _lib.check(rc, "e3dge_siren_bwd")
     return dstyles, dfilm
 
@@ -403,7 +413,7 @@ class _RenderQuery(torch.autograd.Function):
             far=_lib.ptr(far), wg=_lib.ptr(wg), wb=_lib.ptr(wb), d_rgb_map=_lib.ptr(d_rgb_map),
             d_feat_map=_lib.ptr(d_feat_map), d_xyz_map=_lib.ptr(d_xyz_map), d_depth_map=_lib.ptr(d_depth_map),
             d_sdf=_lib.ptr(d_sdf_in), tang=_lib.ptr(tang), rsave=_lib.ptr(rs), sigmoid_beta=ctx.sigmoid_beta, batch=B, height=H, width=H, n_samples=S,
-            force_background=int(bool(r.force_background)), precision=MFMA_MODES[siren.bwd_mode], d_rgb_pts=_lib.ptr(d_rgb_pts), d_sdf_pts=_lib.ptr(d_sdf_pts),
+            force_background=int(bool(r.force_background)), precision=siren.check_mode(siren.bwd_mode), d_rgb_pts=_lib.ptr(d_rgb_pts), d_sdf_pts=_lib.ptr(d_sdf_pts),
             partials=_lib.ptr(partials), dfilm=_lib.ptr(dfilm), dstyles=_lib.ptr(dstyles))
         with torch.cuda.device(dev):
             rc = lib.e3dge_siren_render_bwd(ctypes.byref(a), _lib.stream_of(film))
@@ -445,6 +455,9 @@ class ResnetBlockFC(nn.Module):
                 rc = lib.e3dge_resblock_pack_weights(_lib.ptr(packed), *[_lib.ptr(t) for t in c], self.size_in,
                                                      torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(rc, "e3dge_resblock_pack_weights")
+            wmax = max(float(t.abs().max().item()) for t in (c[0], c[2], c[4]))
+            if wmax >= 500.0:              # the image stores 128 * w as f16
+                raise RuntimeError(f"texture-head weights up to {wmax:g} do not fit the f16x3 weight image (|w| < 500)")
             self._cache, self._cache_key = packed, key
         return self._cache
 
@@ -664,7 +677,7 @@ class VolumeFeatureRenderer(nn.Module):
             sigmoid_beta=self._sigmoid_beta_value(),
             box_scale=float(self.box_scale), mask_depth_thresh=float(self.mask_depth_thresh),
             batch=B, height=H, width=Wd, n_samples=S, res=int(self.out_im_res),
-            force_background=int(bool(self.force_background)), precision=MFMA_MODES[self.siren.mfma_mode],
+            force_background=int(bool(self.force_background)), precision=self.siren.check_mode(self.siren.mfma_mode),
             rgb=_lib.ptr(out['rgb']), features=_lib.ptr(out['features']), xyz=_lib.ptr(out['xyz']),
             depth=_lib.ptr(out['depth']), mask=_lib.ptr(out['mask']), sdf=_lib.ptr(out['sdf']),
             weights=_lib.ptr(out['weights']), points=_lib.ptr(out['points']), rays_d=_lib.ptr(out['rays_d']),

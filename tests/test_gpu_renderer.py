@@ -209,3 +209,18 @@ def test_ragged_and_tiny_extents(sd):
         assert maxerr(raw[..., 3], ref[..., 3]) <= 1e-5 and maxerr(raw[..., 4:], ref[..., 4:]) <= 1e-4, n
     empty = r.run_network(torch.empty(1, 0, 1, 1, 3, device=DEV), torch.empty(1, 0, 1, 1, 3, device=DEV), styles=wr)
     assert empty.numel() == 0
+
+
+def test_f16x3_weight_range_is_checked(sd):
+    """The split-f16 weight image holds 128*w as f16: weights beyond its range are refused loudly, the fp32 kernel
+    still serves them."""
+    r = make_renderer(sd, 8, 18, mfma_mode="f16x3")
+    wr, _ = syn.synthetic_inputs(1, seed=1, device=DEV)
+    poses, focal, near, far, _ = generate_camera_params(8, DEV, locations=torch.zeros(1, 2, device=DEV))
+    with torch.no_grad():
+        r.siren.pts_linears[3].weight[5, 7] = 300.0
+        with pytest.raises(RuntimeError, match="f16x3"):
+            r(poses, focal, near, far, styles=wr)
+        r.siren.mfma_mode = "f32"
+        out = r(poses, focal, near, far, styles=wr)
+    assert torch.isfinite(out['features']).all()
