@@ -708,11 +708,9 @@ class VolumeFeatureRenderer(nn.Module):
     def forward(self, cam_poses, focal, near, far, styles=None, return_eikonal=False, geometry_sample=None,
                 return_surface_eikonal=False, local_data_batch=None, sample_mode=False, return_mesh=False,
                 mesh_with_shading=True, return_sdf_only=False, **kwargs):
-        if sample_mode:
-            raise NotImplementedError("sample_mode (near-surface / uniform-grid sampling) is not in this build")
         if return_mesh:
             raise NotImplementedError("marching-cubes mesh extraction is out of scope (SURVEY.md 2 #13)")
-        self.sample_mode = False
+        self.sample_mode = bool(sample_mode)
         tex = None
         if self.enable_local_model and local_data_batch is not None:
             if 'tex' in local_data_batch:
@@ -757,4 +755,65 @@ class VolumeFeatureRenderer(nn.Module):
                     continue
                 render_out[f'{k}_rec'] = self.run_network(samples, torch.zeros_like(samples), styles=styles,
                                                           return_sdf_only=True)
+        if self.sample_mode:
+            # pseudo ground truth for the 3-D supervision of stage 1 (render_rays :1297-1324, then collate_fn :1976-2043):
+            # sdf at jittered surface points and at uniform points of the scene box; xyz / mask keep the channel-last
+            # layout in this mode (:1951-1958)
+            B = cam_poses.shape[0]
+            xyz_cl = render_out['xyz'].permute(0, 2, 3, 1).contiguous()
+            if _opt_get(self.opt, 'sample_near_surface', False):
+                pts, sdf_s, valid = self.sample_near_surface_grid(
+                    xyz_cl, render_out['viewdirs'], float(_opt_get(self.opt, 'surface_sampling_stdv', 0.03)), styles,
+                    noise=kwargs.get('surface_noise', None))
+                render_out.update(points_near_surface=pts, points_near_surface_sdf=sdf_s, points_near_surface_valid_mask=valid)
+            if _opt_get(self.opt, 'sample_uniform_grid', False):
+                gp, gs, gm = self.sample_uniform_grid(B, int(_opt_get(self.opt, 'uniform_grid_sampling_num', 2048)),
+                                                      cam_poses.device, styles, uniform=kwargs.get('grid_uniform', None))
+                render_out.update(grid_random_pts=gp, grid_random_pts_sdf=gs, grid_sample_valid_mask=gm)
+            render_out['xyz'] = xyz_cl
+            render_out['mask'] = render_out['mask'].permute(0, 2, 3, 4, 1).contiguous()      # back to (B,H,W,1,1)
+            render_out = self.collate_fn(render_out)
+            self.sample_mode = False
+        return render_out
+
+    # -------------------------------------------------------------------------------------------------
+    def sample_uniform_grid(self, batch_size, num_sample_inout, device, styles, uniform=None):
+        """Uniform points of the scene box and their sdf (:945-963).  `uniform` (B,N,3) in [0,1) replaces the torch.rand
+        draw (tests)."""
+        u = torch.rand(batch_size, num_sample_inout, 3, device=device) if uniform is None else uniform
+        pts = (u * (self.B_MAX - self.B_MIN) + self.B_MIN).reshape(batch_size, num_sample_inout, 1, 1, 3)
+        sdf = self.run_network(pts, torch.zeros_like(pts), styles=styles, return_sdf_only=True)[..., 0]
+        pts = pts.reshape(batch_size, -1, 3)
+        sdf = sdf.reshape(batch_size, -1, 1)
+        return pts, sdf, torch.ones_like(sdf)
+
+    def sample_near_surface_grid(self, surface_points, viewdirs, normal_stdv, styles, multiplier=1, noise=None):
+        """Surface points (B,H,W,3) jittered by N(0, stdv^2) and their sdf (:965-1003).  `noise` replaces the
+        torch.randn_like draw (tests)."""
+        n = torch.randn_like(surface_points) if noise is None else noise
+        pts = (surface_points + n * normal_stdv).unsqueeze(-2)                           # (B,H,W,1,3)
+        valid = (pts.abs().max(dim=-1)[0] < self.dist_radius).int()                       # (B,H,W,1)
+        sdf = self.run_network(pts, viewdirs, styles=styles, return_sdf_only=True)[..., 0]   # (B,H,W,1)
+        return pts, sdf, valid
+
+    def collate_fn(self, render_out, match_inference_dim=True):
+        """Merge the sampled point sets into `uniform_pts`, `uniform_points_sdf`, `uniform_points_valid_mask`
+        (:1976-2043)."""
+        B = render_out['gen_thumb_imgs'].shape[0]
+        dev = render_out['gen_thumb_imgs'].device
+        P = [torch.empty(B, 0, 3, device=dev)]
+        S = [torch.empty(B, 0, 1, device=dev)]
+        M = [torch.empty(B, 0, 1, device=dev)]
+        if _opt_get(self.opt, 'sample_near_surface', False):
+            P.append(render_out['points_near_surface'].reshape(B, -1, 3))
+            S.append(render_out['points_near_surface_sdf'].reshape(B, -1, 1))
+            M.append(render_out['points_near_surface_valid_mask'].reshape(B, -1, 1).float())
+        if _opt_get(self.opt, 'sample_uniform_grid', False):
+            P.append(render_out['grid_random_pts'].reshape(B, -1, 3))
+            S.append(render_out['grid_random_pts_sdf'].reshape(B, -1, 1))
+            M.append(render_out['grid_sample_valid_mask'].reshape(B, -1, 1))
+        pts, sdf, msk = torch.cat(P, 1), torch.cat(S, 1), torch.cat(M, 1)
+        if match_inference_dim:
+            pts, sdf, msk = pts.reshape(B, -1, 1, 1, 3), sdf.reshape(B, -1, 1, 1, 1), msk.reshape(B, -1, 1, 1, 1)
+        render_out.update(uniform_pts=pts, uniform_points_sdf=sdf, uniform_points_valid_mask=msk)
         return render_out

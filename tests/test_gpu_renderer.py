@@ -224,3 +224,44 @@ def test_f16x3_weight_range_is_checked(sd):
         r.siren.mfma_mode = "f32"
         out = r(poses, focal, near, far, styles=wr)
     assert torch.isfinite(out['features']).all()
+
+
+def test_sample_mode_pseudo_ground_truth(sd):
+    """sample_mode=True (stage-1 3-D supervision sampling, render_rays :1297-1324 + collate_fn :1976-2043): jittered
+    surface points and uniform box points with their sdf, merged into uniform_pts / uniform_points_sdf / valid mask;
+    xyz and mask stay channel-last in this mode (:1951-1958).  The random draws are injected to compare with the oracle."""
+    res, S, n_grid = 8, 24, 200
+    r = make_renderer(sd, res, S, sample_near_surface=True, sample_uniform_grid=True, surface_sampling_stdv=0.03,
+                      uniform_grid_sampling_num=n_grid)
+    wr, _ = syn.synthetic_inputs(2, seed=4, device=DEV)
+    poses, focal, near, far, _ = generate_camera_params(res, DEV, batch=2, locations=torch.tensor([[0.1, 0.0], [-0.2, 0.1]], device=DEV))
+    rs = np.random.RandomState(12)
+    noise = T(rs.standard_normal((2, res, res, 3)).astype(np.float32))
+    uni = T(rs.uniform(size=(2, n_grid, 3)).astype(np.float32))
+    with torch.no_grad():
+        out = r(poses, focal, near, far, styles=wr, sample_mode=True, surface_noise=noise, grid_uniform=uni)
+        plain = r(poses, focal, near, far, styles=wr)
+        drawn = r(poses, focal, near, far, styles=wr, sample_mode=True)              # own torch.rand / randn draws
+    c = lambda t: t.detach().cpu()
+    assert tuple(out['xyz'].shape) == (2, res, res, 3) and tuple(out['mask'].shape) == (2, res, res, 1, 1)
+    assert torch.equal(out['xyz'], plain['xyz'].permute(0, 2, 3, 1)) and torch.equal(out['gen_thumb_imgs'], plain['gen_thumb_imgs'])
+    n_all = res * res + n_grid
+    assert tuple(out['uniform_pts'].shape) == (2, n_all, 1, 1, 3) and tuple(out['uniform_points_sdf'].shape) == (2, n_all, 1, 1, 1)
+    assert tuple(out['uniform_points_valid_mask'].shape) == (2, n_all, 1, 1, 1)
+    # expected point sets from the same draws
+    near_pts = c(out['xyz']) + c(noise) * 0.03
+    grid_pts = c(uni) * 0.24 - 0.12
+    exp_pts = torch.cat([near_pts.reshape(2, -1, 3), grid_pts], 1)
+    assert maxerr(out['uniform_pts'].reshape(2, -1, 3), exp_pts) <= 1e-7
+    vd = c(out['viewdirs']).unsqueeze(3)                                             # (B,H,W,1,3)
+    with torch.no_grad():
+        sdf_near = renderer_ref.query_points(sd, near_pts.unsqueeze(3), vd, c(wr))[..., 3]
+        sdf_grid = renderer_ref.query_points(sd, grid_pts.reshape(2, n_grid, 1, 1, 3), None, c(wr))[..., 3]
+    exp_sdf = torch.cat([sdf_near.reshape(2, -1), sdf_grid.reshape(2, -1)], 1)
+    assert maxerr(out['uniform_points_sdf'].reshape(2, -1), exp_sdf) <= 1e-5
+    exp_valid = torch.cat([(near_pts.abs().max(-1)[0] < 0.12).float().reshape(2, -1), torch.ones(2, n_grid)], 1)
+    assert torch.equal(c(out['uniform_points_valid_mask']).reshape(2, -1), exp_valid)
+    assert tuple(out['points_near_surface'].shape) == (2, res, res, 1, 3) and tuple(out['grid_random_pts'].shape) == (2, n_grid, 3)
+    # the unseeded call draws its own noise: same shapes, different points, all inside the box for the grid part
+    assert drawn['uniform_pts'].shape == out['uniform_pts'].shape and not torch.equal(drawn['uniform_pts'], out['uniform_pts'])
+    assert float(drawn['grid_random_pts'].abs().max()) <= 0.12
