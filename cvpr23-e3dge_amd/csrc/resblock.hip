@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
             m = fmaxf(m, xhalf(m));
             ss += xhalf(ss);
             xnorm = sqrtf(ss);
-            const unsigned e = (__float_as_uint(m) >> 23) & 255u;
+            const unsigned e = min((__float_as_uint(m) >> 23) & 255u, 254u);
             const float sc = __uint_as_float((254u - e) << 23);
             inv_x = __uint_as_float((e > 8u ? e - 7u : 1u) << 23);
 #pragma unroll
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
         float inv_r;
         {
             const float bound = fmaf(packed[kRbOffAux], xnorm, packed[kRbOffAux + 1]);
-            const unsigned er = (__float_as_uint(bound) >> 23) & 255u;     // bound < 2^(er-126)
+            const unsigned er = min((__float_as_uint(bound) >> 23) & 255u, 253u);   // bound < 2^(er-126)
             const float sc_r = __uint_as_float((253u - er) << 23);          // r * sc_r < 1
             inv_r = __uint_as_float((er > 8u ? er - 6u : 1u) << 23);        // 1 / (128 * sc_r)
 #pragma unroll

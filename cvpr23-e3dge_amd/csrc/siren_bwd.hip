@@ -82,7 +82,7 @@ __device__ __forceinline__ void sincos_hw_f32(float x, float& sn, float& cs) {
 // `m` = max |value| over this lane's 128 values (the producers keep it as a running max).
 __device__ __forceinline__ float scale_split(const f32x16 (&src)[kNT], u32x4 (&dH)[2 * kNT], u32x4 (&dL)[2 * kNT], float m) {
     m = fmaxf(m, xhalf(m));
-    const unsigned e = (__float_as_uint(m) >> 23) & 255u;               // m in [2^(e-127), 2^(e-126))
+    const unsigned e = min((__float_as_uint(m) >> 23) & 255u, 254u);    // m in [2^(e-127), 2^(e-126)); inf/nan: scale 0 -> NaN out
     const float sc = __uint_as_float((254u - e) << 23);                 // m * sc in [1, 2)   (m == 0: sc = 2^127, harmless)
     const float inv = __uint_as_float((e > 8u ? e - 7u : 1u) << 23);    // 1 / (128 * sc) = 2^(e-134)
 #pragma unroll
