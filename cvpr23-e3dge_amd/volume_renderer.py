@@ -357,13 +357,10 @@ class _RenderQuery(torch.autograd.Function):
     @staticmethod
     def differentiable(renderer, styles, focal, c2w, near, far, want_eik=False):
         vals = _RenderQuery.apply(styles, renderer, focal, c2w, near, far, bool(want_eik))
-        out = dict(renderer._last_render)          # non-tensor / view entries of the forward's dict
-        renderer._last_render = None
-        for k, v in zip(_DIFF_KEYS + _AUX_KEYS, vals):
-            out[k] = v
+        out = dict(zip(_DIFF_KEYS + _AUX_KEYS, vals))
         if not want_eik:
             out['eikonal_term'] = None
-        return out
+        return renderer._render_dict(out, c2w, near, far)
 
     @staticmethod
     def forward(ctx, styles, renderer, focal, c2w, near, far, want_eik):
@@ -376,7 +373,6 @@ class _RenderQuery(torch.autograd.Function):
             out['eikonal_term'] = eik.reshape(B, H, H, S, 3)
         else:
             out['eikonal_term'], rsave = torch.empty(0, device=c2w.device), torch.empty(0, device=c2w.device)
-        renderer._last_render = out
         ctx.renderer, ctx.styles_ndim, ctx.want_eik = renderer, styles.ndim, want_eik
         ctx.sigmoid_beta = renderer._sigmoid_beta_value()
         ctx.save_for_backward(film, args, out['sdf'], out['dists'], out['points'], out['hit_prob'],
@@ -685,15 +681,19 @@ class VolumeFeatureRenderer(nn.Module):
         with torch.cuda.device(dev):
             rc = _lib.load().e3dge_siren_render_fwd(ctypes.byref(args), _lib.stream_of(c2w))
         _lib.check(rc, "e3dge_siren_render_fwd")
-        rays_o = c2w[:, None, None, :3, -1].expand(B, H, Wd, 3)
-        return {
-            'rays_o': rays_o, 'rays_d': out['rays_d'], 'dists': out['dists'],
-            'near': near.reshape(B, 1, 1, 1).expand(B, H, Wd, 1), 'far': far.reshape(B, 1, 1, 1).expand(B, H, Wd, 1),
-            'hit_prob': out['weights'], 'surface_eikonal_term': None, 'points': out['points'], 'sdf': out['sdf'],
-            'gen_thumb_imgs': out['rgb'], 'features': out['features'], 'mask': out['mask'], 'xyz': out['xyz'],
-            'eikonal_term': None, 'depth': out['depth'],
-            'mesh': None, 'shading_mesh': None, 'debug_mesh': None, 'viewdirs': out['viewdirs'],
-        }
+        return self._render_dict({'rays_d': out['rays_d'], 'dists': out['dists'], 'hit_prob': out['weights'],
+                                  'points': out['points'], 'sdf': out['sdf'], 'gen_thumb_imgs': out['rgb'],
+                                  'features': out['features'], 'mask': out['mask'], 'xyz': out['xyz'],
+                                  'depth': out['depth'], 'viewdirs': out['viewdirs']}, c2w, near, far)
+
+    def _render_dict(self, tensors, c2w, near, far):
+        """The dict of render_rays + render (:1270-1287, :1695-1701) around the kernel's output tensors."""
+        B, H = c2w.shape[0], self.out_im_res
+        d = {'rays_o': c2w[:, None, None, :3, -1].expand(B, H, H, 3),
+             'near': near.reshape(B, 1, 1, 1).expand(B, H, H, 1), 'far': far.reshape(B, 1, 1, 1).expand(B, H, H, 1),
+             'surface_eikonal_term': None, 'eikonal_term': None, 'mesh': None, 'shading_mesh': None, 'debug_mesh': None}
+        d.update(tensors)
+        return d
 
     def _sigmoid_beta_value(self):
         """Host copy of the learned sigmoid_beta, refreshed only when the parameter changes (a `.item()` per

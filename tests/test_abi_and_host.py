@@ -147,8 +147,6 @@ def test_unsupported_options_fail_loudly():
         VolumeFeatureRenderer(syn.rendering_opt(depth=6))
     r = VolumeFeatureRenderer(syn.rendering_opt(), mode='test')
     with pytest.raises(NotImplementedError):
-        r(None, None, None, None, styles=None, sample_mode=True)
-    with pytest.raises(NotImplementedError):
         r(None, None, None, None, styles=None, return_mesh=True)
 
 
