@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E3DGE_LIB_PATH") or os.path.join(_HERE, "lib", "libe3dge_hip.so")   # override: kernel A/B variants
-ABI_VERSION = 6
+ABI_VERSION = 7
 PREC_F32, PREC_F16X3 = 0, 1
 
 _c_float_p = ctypes.c_void_p     # device pointers travel as integers
@@ -32,9 +32,18 @@ class RenderArgs(ctypes.Structure):
 class RenderBwdArgs(ctypes.Structure):
     """Mirror of struct E3dgeRenderBwdArgs (include/e3dge_hip.h)."""
     _fields_ = [(n, _vp) for n in ("packed", "film", "args", "sdf", "dists", "points", "weights", "t_vals", "near", "far",
-                                   "wg", "wb", "d_rgb_map", "d_feat_map", "d_xyz_map", "d_depth_map", "d_sdf", "tang", "rsave")] + [
+                                   "wg", "wb", "d_rgb_map", "d_feat_map", "d_xyz_map", "d_depth_map", "d_sdf", "tang", "rsave",
+                                   "d_weights", "tex_alpha")] + [
         ("sigmoid_beta", _f32), ("batch", _i32), ("height", _i32), ("width", _i32), ("n_samples", _i32),
-        ("force_background", _i32), ("precision", _i32)] + [(n, _vp) for n in ("d_rgb_pts", "d_sdf_pts", "partials", "dfilm", "dstyles")]
+        ("force_background", _i32), ("precision", _i32)] + [(n, _vp) for n in ("d_rgb_pts", "d_sdf_pts", "partials", "dfilm", "dstyles",
+                                                                                "d_tex_alpha", "d_tex_beta")]
+
+
+class SirenBwdArgs(ctypes.Structure):
+    """Mirror of struct E3dgeSirenBwdArgs (include/e3dge_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("packed", "film", "args", "d_feat", "d_rgb", "d_sdf", "tang", "rsave", "wg", "wb", "tex_alpha")] + [
+        ("batch", _i32), ("precision", _i32), ("n_pts", _i64), ("box_scale", _f32)] + [
+        (n, _vp) for n in ("partials", "dfilm", "dstyles", "d_pts", "d_tex_alpha", "d_tex_beta")]
 
 
 # name -> (restype, argtypes); every symbol include/e3dge_hip.h declares.
@@ -52,7 +61,7 @@ SIGNATURES = {
     "e3dge_siren_render_fwd": (_i32, [ctypes.POINTER(RenderArgs), _vp]),
     "e3dge_siren_points_fwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _i64, _vp, _vp, _vp, _i32, _vp]),
     "e3dge_siren_bwd_partial_floats": (_i64, [_i32, _i64]),
-    "e3dge_siren_bwd": (_i32, [_vp] * 10 + [_i32, _i64, _vp, _vp, _vp, _i32, _vp]),
+    "e3dge_siren_bwd": (_i32, [ctypes.POINTER(SirenBwdArgs), _vp]),
     "e3dge_siren_sdf_grad": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _i64, _vp, _vp, _i32, _vp]),
     "e3dge_siren_tangent": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _i64, _vp, _i32, _vp]),
     "e3dge_siren_render_bwd": (_i32, [ctypes.POINTER(RenderBwdArgs), _vp]),

@@ -344,12 +344,10 @@ extern "C" int e3dge_tex_modulations_fwd(const float* packed, const float* feats
     E3DGE_REQUIRE(cin >= 1 && cin <= kRbKin, "tex_modulations_fwd: cin=%d outside [1, %d]", cin, kRbKin);
     E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(alpha) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0,
                   "tex_modulations_fwd: packed/alpha/beta must be 16-B aligned");
-    static bool attr_done = false;
-    if (!attr_done) {
+    {   // per device, cheap: set on every launch
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kRbLdsBytes);
         if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(resblock): %s", hipGetErrorString(e));
-        attr_done = true;
     }
     ResblockK k{};
     k.packed = packed; k.feats = feats; k.alpha = alpha; k.beta = beta; k.n_pts = n_pts; k.cin = cin;

@@ -903,37 +903,19 @@ __global__ void selftest_sin_kernel(float* __restrict__ y, const float* __restri
     if (i < n) y[i] = mode ? sin_poly_f32(x[i]) : sin_f32(x[i]);
 }
 
-static int ensure_lds_attr() {
-    static bool done = false;
-    if (!done) {
-        const void* fns[8] = {
-            reinterpret_cast<const void*>(&siren_kernel<0, 0, false>), reinterpret_cast<const void*>(&siren_kernel<1, 0, false>),
-            reinterpret_cast<const void*>(&siren_kernel<0, 1, false>), reinterpret_cast<const void*>(&siren_kernel<1, 1, false>),
-            reinterpret_cast<const void*>(&siren_kernel<0, 0, true>), reinterpret_cast<const void*>(&siren_kernel<1, 0, true>),
-            reinterpret_cast<const void*>(&siren_kernel<0, 1, true>), reinterpret_cast<const void*>(&siren_kernel<1, 1, true>)};
-        for (const void* f : fns) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-            if (e != hipSuccess)
-                return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", kLdsBytes, hipGetErrorString(e));
-        }
-        done = true;
-    }
+template <int MODE>
+static int launch_siren(const SirenK& k, int precision, int64_t grid, hipStream_t st) {
+    typedef void (*KernelFn)(const SirenK);
+    static const KernelFn fns[4] = {&siren_kernel<MODE, 0, false>, &siren_kernel<MODE, 0, true>,
+                                    &siren_kernel<MODE, 1, false>, &siren_kernel<MODE, 1, true>};
+    const KernelFn fn = fns[2 * (precision == E3DGE_PREC_F16X3) + (k.save_args != nullptr)];
+    // the attribute is per device; setting it on every launch is cheap and keeps multi-GPU processes correct
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e != hipSuccess)
+        return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", kLdsBytes, hipGetErrorString(e));
+    fn<<<dim3((unsigned)grid), dim3(kThreads), kLdsBytes, st>>>(k);
     return E3DGE_OK;
 }
-
-template <int MODE>
-static void launch_siren(const SirenK& k, int precision, int64_t grid, hipStream_t st) {
-    const dim3 g((unsigned)grid), t(kThreads);
-    const bool save = k.save_args != nullptr;
-    if (precision == E3DGE_PREC_F16X3) {
-        if (save) siren_kernel<MODE, 1, true><<<g, t, kLdsBytes, st>>>(k);
-        else siren_kernel<MODE, 1, false><<<g, t, kLdsBytes, st>>>(k);
-    } else {
-        if (save) siren_kernel<MODE, 0, true><<<g, t, kLdsBytes, st>>>(k);
-        else siren_kernel<MODE, 0, false><<<g, t, kLdsBytes, st>>>(k);
-    }
-}
-
 // rays per workgroup: the largest R <= kRMax whose R*S is a multiple of 128 if one exists (no padded
 // lanes), else the R <= kRMax minimising padding; small images get fewer rays per workgroup so that the
 // grid still covers the 256 CUs.
@@ -999,8 +981,6 @@ extern "C" int e3dge_siren_render_fwd(const E3dgeRenderArgs* r, e3dge_stream_t s
     E3DGE_REQUIRE(r->sigmoid_beta != 0.0f, "siren_render_fwd: sigmoid_beta must be non-zero");
     E3DGE_REQUIRE(r->precision == E3DGE_PREC_F32 || r->precision == E3DGE_PREC_F16X3, "siren_render_fwd: precision=%d", r->precision);
     if (r->batch == 0) return E3DGE_OK;
-    int rc = ensure_lds_attr();
-    if (rc) return rc;
     const int64_t HW = (int64_t)r->height * r->width;
     E3DGE_REQUIRE(HW * r->batch * (int64_t)r->n_samples < ((int64_t)1 << 40), "siren_render_fwd: too many points");
     SirenK k{};
@@ -1016,7 +996,8 @@ extern "C" int e3dge_siren_render_fwd(const E3dgeRenderArgs* r, e3dge_stream_t s
     const int64_t grid = (int64_t)k.tiles_per_img * r->batch;
     E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_render_fwd: grid too large");
     k.save_args = r->save_args;
-    launch_siren<0>(k, r->precision, grid, as_stream(stream));
+    int rc = launch_siren<0>(k, r->precision, grid, as_stream(stream));
+    if (rc) return rc;
     return check_launch("siren_render_fwd");
 }
 
@@ -1030,8 +1011,6 @@ extern "C" int e3dge_siren_points_fwd(const float* packed, const float* film, co
     E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(film)) & 15) == 0,
                   "siren_points_fwd: packed/film must be 16-B aligned");
     if (batch == 0 || n_pts == 0) return E3DGE_OK;
-    int rc = ensure_lds_attr();
-    if (rc) return rc;
     SirenK k{};
     k.packed = packed; k.film = film; k.pts = pts; k.vdirs = viewdirs; k.box_scale = box_scale;
     k.batch = batch; k.n_pts = n_pts; k.sdf = sdf; k.raw = raw;
@@ -1045,7 +1024,8 @@ extern "C" int e3dge_siren_points_fwd(const float* packed, const float* film, co
     const int64_t grid = (int64_t)k.wgs_per_img * batch;
     E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_points_fwd: grid too large");
     k.save_args = save_args;
-    launch_siren<1>(k, precision, grid, as_stream(stream));
+    int rc = launch_siren<1>(k, precision, grid, as_stream(stream));
+    if (rc) return rc;
     return check_launch("siren_points_fwd");
 }
 

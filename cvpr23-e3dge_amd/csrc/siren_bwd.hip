@@ -31,6 +31,13 @@ struct SirenBwdK {
     const float* rsave;      // r_l = d sdf / d h_l of the sdf-chain kernel
     int precision;           // E3DGE_PREC_F32 / E3DGE_PREC_F16X3
     float* partials;         // (grid, 9, 2, 256): every workgroup writes its whole slice
+    // optional: gradient w.r.t. the query points, dL/dx = s W_0^T (gamma_0 * adj(a_0))  (batch, n_pts, 3), or null
+    float* d_pts;
+    float box_scale;
+    // optional second-pass texture FiLM h8' = (alpha + 1) h8 + beta in front of the view layer (:217-220):
+    const float* tex_alpha;  // (batch, n_pts, 256) the forward launch's alpha, or null
+    float* d_tex_alpha;      // (batch, n_pts, 256) out: dL/dalpha = dh8' * h8
+    float* d_tex_beta;       // (batch, n_pts, 256) out: dL/dbeta = dh8'
     long long n_pts;
     int batch, subtiles_per_wg, wgs_per_img;
 };
@@ -41,7 +48,8 @@ constexpr int kBwdLdsHead = kBwdLdsFilm + 9 * 3 * kWidth;        // w_sigma[256]
 constexpr int kBwdLdsAcc = kBwdLdsHead + 4 * kWidth;              // [9][2][256] this workgroup's d(gamma), d(beta)
 constexpr int kBwdLdsSlot = kBwdLdsAcc + 9 * 2 * kWidth;          // [2 parity][4 waves][2][32] per-tile wave sums
 constexpr int kBwdLdsSlot8 = kBwdLdsSlot + 2 * 4 * 2 * 32;        // [8 tiles][4 waves][2][32] view-layer wave sums
-constexpr int kBwdLdsFloats = kBwdLdsSlot8 + kNT * 4 * 2 * 32;
+constexpr int kBwdLdsW0 = kBwdLdsSlot8 + kNT * 4 * 2 * 32;         // [3][256] first-layer weights, column-major (d_pts)
+constexpr int kBwdLdsFloats = kBwdLdsW0 + 3 * kWidth;
 constexpr int kBwdLdsBytes = kBwdLdsFloats * 4;
 
 // Sum over the 32 lanes of a half for 8 per-lane values, entirely in the VALU (no LDS round trips: one wave per SIMD,
@@ -111,7 +119,11 @@ __device__ __forceinline__ float scale_split(const f32x16 (&src)[kNT], u32x4 (&d
 //       adj(gamma_l) = adj(a_l) z_l + (ta_l / gamma_l) cos(a_l) r_l ,   adj(beta_l) = adj(a_l)
 //   and the same transposed chain carries adj(h) downwards.
 // F16 = true: the eight GEMMs run as block-scaled split-f16 contractions (scale_split above) on the f16 matrix pipe.
-template <bool EIK, bool F16>
+// TEX = true: the forward pass applied the per-point texture FiLM between the sdf head and the view layer; GEMM 0's result
+//   is then dL/dh8', which yields dL/dalpha = dh8' * sin(a_7), dL/dbeta = dh8' (stored per point) and continues down the
+//   chain as (alpha + 1) * dh8'.  Only built without EIK (the eikonal losses live on the first pass).
+// DPTS = true: also write dL/dx of every query point (the first layer's input gradient).
+template <bool EIK, bool F16, bool TEX, bool DPTS>
 __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wbuf = smem + kBwdLdsW;
@@ -137,6 +149,11 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
         film_s[(l * 3 + 2) * kWidth + n] = 1.0f / g;
     }
     for (int i = tid; i < 4 * kWidth; i += kThreads) head_s[i] = packed[kOffWSigma + i];
+    float* const w0_s = smem + kBwdLdsW0;
+    if (DPTS) for (int i = tid; i < 3 * kWidth; i += kThreads) {
+        const int c = i >> 8, n = i & 255;           // fragment image of layer 0 (siren_pack_kernel): [t][m][lane], k = 2m + half
+        w0_s[i] = packed[kOffFirst + ((n >> 5) * 2 + (c >> 1)) * 64 + (c & 1) * 32 + (n & 31)];
+    }
     float* const acc_s = smem + kBwdLdsAcc;
     float* const slot_s = smem + kBwdLdsSlot;
     for (int i = tid; i < 9 * 2 * kWidth; i += kThreads) acc_s[i] = 0.0f;
@@ -212,6 +229,9 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
         const float* __restrict__ tp_ = EIK ? a.tang + gpt * (8 * kWidth) : nullptr;
         const float* __restrict__ rp_ = EIK ? a.rsave + gpt * (8 * kWidth) : nullptr;
         const float vmask = valid ? 1.0f : 0.0f;                      // padded lanes contribute nothing
+        const float* __restrict__ txa = TEX ? a.tex_alpha + gpt * kWidth : nullptr;
+        float* __restrict__ dta = TEX ? a.d_tex_alpha + gpt * kWidth : nullptr;
+        float* __restrict__ dtb = TEX ? a.d_tex_beta + gpt * kWidth : nullptr;
         const float dsdf = (a.d_sdf && valid) ? a.d_sdf[gpt] : 0.0f;
         float drgb[3] = {0.f, 0.f, 0.f};
         if (a.d_rgb && valid) { drgb[0] = a.d_rgb[gpt * 3]; drgb[1] = a.d_rgb[gpt * 3 + 1]; drgb[2] = a.d_rgb[gpt * 3 + 2]; }
@@ -348,11 +368,22 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                     const f32x4 g4 = *reinterpret_cast<const f32x4*>(fg + o), b4 = *reinterpret_cast<const f32x4*>(fg + kWidth + o),
                                 i4 = *reinterpret_cast<const f32x4*>(fg + 2 * kWidth + o);
                     const f32x4 ws = *reinterpret_cast<const f32x4*>(head_s + o);
+                    const bool tex_here = TEX && Gb == 0;                      // this GEMM's result is dL/dh8' (view-layer input)
+                    f32x4 al4 = {0.f, 0.f, 0.f, 0.f}, da4 = al4, db4 = al4;
+                    if (tex_here) al4 = *reinterpret_cast<const f32x4*>(txa + o);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float dh = fmaf(ws[j], sdf_term, dhv[4 * q + j]);   // padded lanes: in[] = 0 and dsdf = 0, so dh = 0
+                        float xin = dhv[4 * q + j];
+                        float tsn = 0.f, tcs = 0.f;
+                        if (TEX) {
+                            sincos_hw_f32(ar[q][j], tsn, tcs);
+                            if (tex_here) { da4[j] = xin * tsn; db4[j] = xin; xin = __fadd_rn(al4[j], 1.0f) * xin; }
+                        }
+                        const float dh = fmaf(ws[j], sdf_term, xin);   // padded lanes: in[] = 0 and dsdf = 0, so dh = 0
                         float da, dg_extra = 0.0f;
-                        if (EIK) {
+                        if (TEX) {
+                            da = dh * tcs;
+                        } else if (EIK) {
                             float sn, cs;
                             sincos_hw_f32(ar[q][j], sn, cs);
                             const float tr = vmask * tgb[q][j] * rsb[q][j];
@@ -370,6 +401,10 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                         dst[4 * q + j] = g4[j] * da;
                         if (kRunMax) gmax = fmaxf(gmax, fabsf(dst[4 * q + j]));
                     }
+                    if (tex_here && valid) {
+                        *reinterpret_cast<f32x4*>(dta + o) = da4;
+                        *reinterpret_cast<f32x4*>(dtb + o) = db4;
+                    }
                 }
 #ifndef E3DGE_BWD_ABL_NO_REDUCE
                 reduce_tile(Lm1, tp, rb, rg);
@@ -380,17 +415,28 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                 dst[0] += keep * 1e-30f;
 #endif
             };
+            f32x4 e_al = {0.f, 0.f, 0.f, 0.f}, e_da = e_al, e_db = e_al;
             auto epi_step = [&](int tp, int r, f32x16& dst) {           // tp, r: compile-time constants at every call site
                 const int q = r >> 2, j = r & 3;
+                const bool tex_here = TEX && Gb == 0;
                 if (j == 0) {
                     const int o = 32 * tp + 8 * q + 4 * half;
                     e_g = *reinterpret_cast<const f32x4*>(fg + o); e_b = *reinterpret_cast<const f32x4*>(fg + kWidth + o);
                     e_i = *reinterpret_cast<const f32x4*>(fg + 2 * kWidth + o); e_w = *reinterpret_cast<const f32x4*>(head_s + o);
+                    if (tex_here) e_al = *reinterpret_cast<const f32x4*>(txa + o);
                 }
                 const float ar = arg2[tp & 1][q][j];
-                const float dh = fmaf(e_w[j], sdf_term, prev[r]);
+                float xin = prev[r];
+                float tsn = 0.f, tcs = 0.f;
+                if (TEX) {
+                    sincos_hw_f32(ar, tsn, tcs);
+                    if (tex_here) { e_da[j] = xin * tsn; e_db[j] = xin; xin = __fadd_rn(e_al[j], 1.0f) * xin; }
+                }
+                const float dh = fmaf(e_w[j], sdf_term, xin);
                 float da, dg_extra = 0.0f;
-                if (EIK) {
+                if (TEX) {
+                    da = dh * tcs;
+                } else if (EIK) {
                     float sn, cs;
                     sincos_hw_f32(ar, sn, cs);
                     const float tr = vmask * tg2[tp & 1][q][j] * rs2[tp & 1][q][j];
@@ -403,6 +449,11 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                 rgh[r & 7] = fmaf(da, (ar - e_b[j]) * e_i[j], dg_extra);
                 dst[r] = e_g[j] * da;
                 if (kRunMax) gmax = fmaxf(gmax, fabsf(dst[r]));
+                if (tex_here && j == 3 && valid) {
+                    const int o = 32 * tp + 8 * q + 4 * half;
+                    *reinterpret_cast<f32x4*>(dta + o) = e_da;
+                    *reinterpret_cast<f32x4*>(dtb + o) = e_db;
+                }
                 if (r == 3) fold_pending();                              // this tile's chunk barrier (k-step 2) has passed
                 if ((r & 7) == 7) {
                     reduce_half(r >> 3, rbh, rgh, slot_s + par * 256 + wave * 64);
@@ -494,6 +545,31 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
 #ifdef E3DGE_BWD_TIMING
             t_tail += BT_NOW() - ct0;
 #endif
+        }
+        // ---- optional: dL/dx = s W_0^T g_0 (g_0 = gamma_0 * adj(a_0) is in out[]), like the sdf chain's last step ----
+        if (DPTS) {
+            int half_e = half;
+            asm volatile("" : "+v"(half_e));
+            float ex = 0.f, ey = 0.f, ez = 0.f;
+#pragma unroll
+            for (int t = 0; t < kNT; ++t) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = 32 * t + 8 * q + 4 * half_e;
+                    const f32x4 wx = *reinterpret_cast<const f32x4*>(w0_s + o), wy = *reinterpret_cast<const f32x4*>(w0_s + kWidth + o),
+                                wz = *reinterpret_cast<const f32x4*>(w0_s + 2 * kWidth + o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float g = out[t][4 * q + j];
+                        ex = fmaf(wx[j], g, ex); ey = fmaf(wy[j], g, ey); ez = fmaf(wz[j], g, ez);
+                    }
+                }
+            }
+            ex += xhalf(ex); ey += xhalf(ey); ez += xhalf(ez);
+            if (valid && half == 0) {
+                float* o = a.d_pts + gpt * 3;
+                o[0] = ex * a.box_scale; o[1] = ey * a.box_scale; o[2] = ez * a.box_scale;
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -793,6 +869,7 @@ struct CompositeBwdK {
     const float* d_xyzmap;   // (rays, 3) or null
     const float* d_depthmap; // (rays) or null
     const float* d_sdf_in;   // (rays, S) or null: gradient arriving at the per-point sdf output
+    const float* d_weights;  // (rays, S) or null: gradient arriving at the compositing weights (hit_prob)
     float* d_rgb_pts;        // (rays, S, 3) out
     float* d_sdf_pts;        // (rays, S) out
     float sigmoid_beta;
@@ -850,6 +927,7 @@ __global__ void __launch_bounds__(kThreads) composite_bwd_kernel(const Composite
                     const float z = nearv * (1.0f - tv) + farv * tv;
                     const float* pp = a.points + gpt * 3;
                     float dw = v[0] + dxyz[0] * pp[0] + dxyz[1] * pp[1] + dxyz[2] * pp[2] + ddepth * z;
+                    if (a.d_weights) dw += a.d_weights[gpt];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         const float rc = v[1 + c] + bhead[1 + c];
@@ -980,28 +1058,31 @@ static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfil
     E3DGE_REQUIRE((k.tang == nullptr) == (k.rsave == nullptr), "siren_bwd: tang and rsave must come together");
     E3DGE_REQUIRE(k.precision == E3DGE_PREC_F32 || k.precision == E3DGE_PREC_F16X3, "siren_bwd: precision=%d", k.precision);
     E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(k.tang) | reinterpret_cast<uintptr_t>(k.rsave)) & 15) == 0, "siren_bwd: tang/rsave must be 16-B aligned");
-    static bool attr_done = false;
-    if (!attr_done) {
-        const void* fns[4] = {reinterpret_cast<const void*>(&siren_bwd_kernel<false, false>), reinterpret_cast<const void*>(&siren_bwd_kernel<true, false>),
-                              reinterpret_cast<const void*>(&siren_bwd_kernel<false, true>), reinterpret_cast<const void*>(&siren_bwd_kernel<true, true>)};
-        for (const void* fn : fns) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsBytes);
-            if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(siren_bwd): %s", hipGetErrorString(e));
-        }
-        attr_done = true;
+    const bool tex = k.tex_alpha != nullptr;
+    E3DGE_REQUIRE(tex == (k.d_tex_alpha != nullptr) && tex == (k.d_tex_beta != nullptr), "siren_bwd: tex_alpha, d_tex_alpha, d_tex_beta must come together");
+    E3DGE_REQUIRE(!(tex && k.tang), "siren_bwd: the eikonal double backward is not available on the tex-FiLM pass");
+    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(k.tex_alpha) | reinterpret_cast<uintptr_t>(k.d_tex_alpha) | reinterpret_cast<uintptr_t>(k.d_tex_beta)) & 15) == 0,
+                  "siren_bwd: tex pointers must be 16-B aligned");
+    typedef void (*KernelFn)(const SirenBwdK);
+    // [dpts][eik][f16], then the two tex variants
+    static const KernelFn fns[10] = {
+        &siren_bwd_kernel<false, false, false, false>, &siren_bwd_kernel<false, true, false, false>,
+        &siren_bwd_kernel<true, false, false, false>, &siren_bwd_kernel<true, true, false, false>,
+        &siren_bwd_kernel<false, false, false, true>, &siren_bwd_kernel<false, true, false, true>,
+        &siren_bwd_kernel<true, false, false, true>, &siren_bwd_kernel<true, true, false, true>,
+        &siren_bwd_kernel<false, false, true, false>, &siren_bwd_kernel<false, true, true, false>};
+    E3DGE_REQUIRE(!(tex && k.d_pts), "siren_bwd: d_pts is not available on the tex-FiLM pass");
+    const int f16 = k.precision == E3DGE_PREC_F16X3;
+    const KernelFn fn = fns[tex ? 8 + f16 : 4 * (k.d_pts != nullptr) + 2 * (k.tang != nullptr) + f16];
+    {   // the attribute is per device (and cheap): set it on the launch's device every time
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsBytes);
+        if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(siren_bwd): %s", hipGetErrorString(e));
     }
     bwd_geometry(batch, n_pts, &k.subtiles_per_wg, &k.wgs_per_img);
     if (n_pts > 0) {
         const int64_t grid = (int64_t)k.wgs_per_img * batch;
         E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_bwd: grid too large");
-        const dim3 g3((unsigned)grid), b3(kThreads);
-        if (k.precision == E3DGE_PREC_F16X3) {
-            if (k.tang) siren_bwd_kernel<true, true><<<g3, b3, kBwdLdsBytes, st>>>(k);
-            else siren_bwd_kernel<false, true><<<g3, b3, kBwdLdsBytes, st>>>(k);
-        } else {
-            if (k.tang) siren_bwd_kernel<true, false><<<g3, b3, kBwdLdsBytes, st>>>(k);
-            else siren_bwd_kernel<false, false><<<g3, b3, kBwdLdsBytes, st>>>(k);
-        }
+        fn<<<dim3((unsigned)grid), dim3(kThreads), kBwdLdsBytes, st>>>(k);
         int rc = check_launch("siren_bwd");
         if (rc) return rc;
     }
@@ -1012,17 +1093,16 @@ static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfil
     return check_launch("siren_bwd(film)");
 }
 
-extern "C" int e3dge_siren_bwd(const float* packed, const float* film, const float* args, const float* d_feat,
-                               const float* d_rgb, const float* d_sdf, const float* tang, const float* rsave,
-                               const float* wg, const float* wb,
-                               int batch, int64_t n_pts, float* partials, float* dfilm, float* dstyles,
-                               int precision, e3dge_stream_t stream) {
-    E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "siren_bwd: bad sizes");
-    if (batch == 0) return E3DGE_OK;
+extern "C" int e3dge_siren_bwd(const E3dgeSirenBwdArgs* r, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(r != nullptr, "siren_bwd: null args");
+    E3DGE_REQUIRE(r->batch >= 0 && r->n_pts >= 0, "siren_bwd: bad sizes");
+    if (r->batch == 0) return E3DGE_OK;
     SirenBwdK k{};
-    k.packed = packed; k.film = film; k.args = args; k.d_feat = d_feat; k.d_rgb = d_rgb; k.d_sdf = d_sdf;
-    k.partials = partials; k.n_pts = n_pts; k.batch = batch; k.samples = 1; k.tang = tang; k.rsave = rsave; k.precision = precision;
-    return launch_bwd(k, wg, wb, dfilm, dstyles, as_stream(stream));
+    k.packed = r->packed; k.film = r->film; k.args = r->args; k.d_feat = r->d_feat; k.d_rgb = r->d_rgb; k.d_sdf = r->d_sdf;
+    k.partials = r->partials; k.n_pts = r->n_pts; k.batch = r->batch; k.samples = 1; k.tang = r->tang; k.rsave = r->rsave;
+    k.precision = r->precision; k.d_pts = r->d_pts; k.box_scale = r->box_scale;
+    k.tex_alpha = r->tex_alpha; k.d_tex_alpha = r->d_tex_alpha; k.d_tex_beta = r->d_tex_beta;
+    return launch_bwd(k, r->wg, r->wb, r->dfilm, r->dstyles, as_stream(stream));
 }
 
 extern "C" int e3dge_siren_render_bwd(const E3dgeRenderBwdArgs* r, e3dge_stream_t stream) {
@@ -1041,16 +1121,14 @@ extern "C" int e3dge_siren_render_bwd(const E3dgeRenderBwdArgs* r, e3dge_stream_
     c.packed = r->packed; c.args = r->args; c.sdf = r->sdf; c.dists = r->dists; c.points = r->points; c.weights = r->weights;
     c.t_vals = r->t_vals; c.near = r->near; c.far = r->far;
     c.d_rgbmap = r->d_rgb_map; c.d_featmap = r->d_feat_map; c.d_xyzmap = r->d_xyz_map; c.d_depthmap = r->d_depth_map;
-    c.d_sdf_in = r->d_sdf; c.d_rgb_pts = r->d_rgb_pts; c.d_sdf_pts = r->d_sdf_pts;
+    c.d_sdf_in = r->d_sdf; c.d_weights = r->d_weights; c.d_rgb_pts = r->d_rgb_pts; c.d_sdf_pts = r->d_sdf_pts;
     c.sigmoid_beta = r->sigmoid_beta; c.S = r->n_samples; c.force_bg = r->force_background;
     c.n_rays = HW * r->batch; c.rays_per_img = HW;
     const size_t lds = (size_t)4 * r->n_samples * kCbStride * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 1024 * kCbStride * 4);
         if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(composite_bwd): %s", hipGetErrorString(e));
-        attr_done = true;
     }
     int64_t grid = (c.n_rays + 3) / 4;
     if (grid > 256 * 16) grid = 256 * 16;
@@ -1061,6 +1139,7 @@ extern "C" int e3dge_siren_render_bwd(const E3dgeRenderBwdArgs* r, e3dge_stream_
     k.packed = r->packed; k.film = r->film; k.args = r->args; k.d_feat = nullptr; k.d_rgb = r->d_rgb_pts; k.d_sdf = r->d_sdf_pts;
     k.d_featmap = r->d_feat_map; k.weights = r->weights; k.samples = r->n_samples;
     k.partials = r->partials; k.n_pts = HW * r->n_samples; k.batch = r->batch; k.tang = r->tang; k.rsave = r->rsave; k.precision = r->precision;
+    k.tex_alpha = r->tex_alpha; k.d_tex_alpha = r->d_tex_alpha; k.d_tex_beta = r->d_tex_beta;
     return launch_bwd(k, r->wg, r->wb, r->dfilm, r->dstyles, st);
 }
 
@@ -1073,15 +1152,11 @@ static int launch_chain(const float* packed, const float* film, const float* arg
     E3DGE_REQUIRE(packed && film && args && save && (TANGENT ? seed != nullptr : eik != nullptr), "%s: null pointer", what);
     E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(args) | reinterpret_cast<uintptr_t>(save)) & 15) == 0,
                   "%s: packed/args/save must be 16-B aligned", what);
-    static bool attr_done = false;
-    if (!attr_done) {
-        const void* fns[2] = {reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, false>),
-                              reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, true>)};
-        for (const void* fn : fns) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kChLdsBytes);
-            if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
-        }
-        attr_done = true;
+    {   // per device, cheap: set on every launch
+        const void* fn = (precision == E3DGE_PREC_F16X3) ? reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, true>)
+                                                          : reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kChLdsBytes);
+        if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
     }
     SirenChainK k{};
     k.packed = packed; k.film = film; k.args = args; k.seed = seed; k.save = save; k.eik = eik; k.box_scale = box_scale;

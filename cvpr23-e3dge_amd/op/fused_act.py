@@ -9,7 +9,10 @@ evaluates from the saved OUTPUT (act=3, grad=1; fused_bias_act_kernel.cu:42).  `
 mask to any tensor and is linear in it, so its own backward is `_MaskedScale` again -- any order of
 differentiation w.r.t. the input is covered (the reference reaches second order, fused_act.py:19-52).
 
-GPU tensors only: the reference's CPU branch (:107-118) is restated in oracle/ops_ref.py, not here."""
+CPU tensors take a plain-PyTorch branch written here (the reference has one too, fused_act.py:107-118) so that host-side
+code -- building modules, shape checks, CPU unit tests of callers -- behaves as with the reference; it is ordinary torch
+autograd, not a kernel, and nothing on the GPU path ever routes through it.  Unlike the reference's CPU branch, which
+hard-codes the slope 0.2 (:112,115), it honours `negative_slope` like the GPU kernel does (identical at the default)."""
 import torch
 from torch import nn
 from torch.autograd import Function
@@ -77,7 +80,15 @@ class _BiasLrelu(Function):
         return gx, gb, None, None
 
 
+def _fused_leaky_relu_cpu(input, bias, negative_slope, scale):
+    if bias is not None:
+        input = input + bias.reshape(1, bias.shape[0], *([1] * (input.ndim - 2)))
+    return torch.nn.functional.leaky_relu(input, negative_slope=negative_slope) * scale
+
+
 def fused_leaky_relu(input, bias=None, negative_slope=0.2, scale=2 ** 0.5):
+    if isinstance(input, torch.Tensor) and input.device.type == "cpu":
+        return _fused_leaky_relu_cpu(input, bias, negative_slope, scale)
     _lib.require_gpu(input, "input")
     return _BiasLrelu.apply(input, bias, negative_slope, scale)
 
@@ -129,9 +140,13 @@ class _NoiseBiasLrelu(Function):
 def noise_bias_act(x, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5):
     """lrelu(x + noise_weight * noise + bias[None,:,None,None], slope) * scale for x (B,C,H,W) and noise
     (1|B,1,H,W) or None."""
+    if noise is not None and noise_weight is None:
+        raise RuntimeError("noise given without noise_weight")
+    if isinstance(x, torch.Tensor) and x.device.type == "cpu":
+        if noise is not None:
+            x = x + noise_weight * noise
+        return _fused_leaky_relu_cpu(x, bias, negative_slope, scale)
     _lib.require_gpu(x, "x")
     if noise is not None:
         _lib.require_gpu(noise, "noise")
-        if noise_weight is None:
-            raise RuntimeError("noise given without noise_weight")
     return _NoiseBiasLrelu.apply(x, noise, noise_weight, bias, negative_slope, scale)

@@ -10,10 +10,15 @@ upfirdn2d with the FIR flipped, up <-> down swapped and pads
 and the adjoint of that one is the original again -- so a single autograd.Function whose backward applies
 itself to the adjoint geometry covers first, second, ... order.
 
-`upfirdn2d_raw` keeps the argument list of the reference's pybind entry (upfirdn2d.cpp:12-23)."""
+`upfirdn2d_raw` keeps the argument list of the reference's pybind entry (upfirdn2d.cpp:12-23).
+
+CPU tensors take a plain-PyTorch branch written here (zero-insertion, pad / crop, one F.conv2d with the flipped FIR,
+strided slice -- the reference has a CPU branch too, upfirdn2d.py:146-200); ordinary torch autograd, never used for
+GPU tensors."""
 from typing import NamedTuple, Tuple
 
 import torch
+import torch.nn.functional as F
 from torch.autograd import Function
 
 from .. import _lib
@@ -88,7 +93,28 @@ class _UpFirDn(Function):
         return gx, None, None, None
 
 
+def _upfirdn2d_cpu(x, kernel, geo):
+    """(B,C,H,W) CPU tensor: up-sample by zero insertion, pad (negative = crop), correlate with the flipped FIR, decimate."""
+    (ux, uy), (dx, dy), (px0, px1, py0, py1) = geo.up, geo.down, geo.pad
+    B, C, H, W = x.shape
+    kh, kw = kernel.shape
+    v = x.reshape(B * C, 1, H, 1, W, 1)
+    v = F.pad(v, [0, ux - 1, 0, 0, 0, uy - 1]).reshape(B * C, 1, H * uy, W * ux)
+    v = F.pad(v, [max(px0, 0), max(px1, 0), max(py0, 0), max(py1, 0)])
+    v = v[:, :, max(-py0, 0):v.shape[2] - max(-py1, 0), max(-px0, 0):v.shape[3] - max(-px1, 0)]
+    if v.shape[2] < kh or v.shape[3] < kw:
+        raise RuntimeError(f"upfirdn2d: empty output for input {H}x{W}, up {geo.up}, down {geo.down}, pad {geo.pad}, "
+                           f"kernel {kh}x{kw}")
+    v = F.conv2d(v, torch.flip(kernel, [0, 1]).reshape(1, 1, kh, kw).to(v.dtype))
+    v = v[:, :, ::dy, ::dx]
+    return v.reshape(B, C, v.shape[2], v.shape[3])
+
+
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
+    if isinstance(input, torch.Tensor) and input.device.type == "cpu":
+        if input.ndim != 4 or kernel.ndim != 2:
+            raise RuntimeError("upfirdn2d expects input (B, C, H, W) and a 2-D FIR kernel")
+        return _upfirdn2d_cpu(input, kernel, Geometry((up, up), (down, down), (pad[0], pad[1], pad[0], pad[1])))
     _lib.require_gpu(input, "input")
     _lib.require_gpu(kernel, "kernel")
     if input.ndim != 4 or kernel.ndim != 2:

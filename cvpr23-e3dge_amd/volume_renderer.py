@@ -11,20 +11,26 @@ What is kept identical to the reference (so that `train_setup.py:98-100` can swa
   * `run_network(inputs, viewdirs, styles=...)` on arbitrary (B, ..., 3) point sets (:1052-1128).
 
 What differs: nothing is evaluated in PyTorch.  One `e3dge_film_params` launch turns the W+ codes into the 9
-(gamma, beta) pairs, one `e3dge_siren_render_fwd` launch does rays -> samples -> MLP -> composite.  Options
-the fused kernel does not cover (eikonal terms, stratified perturbation, density mode, mesh extraction,
-sample_mode) raise NotImplementedError instead of silently taking another path.
+(gamma, beta) pairs, one `e3dge_siren_render_fwd` launch does rays -> samples -> MLP -> composite; the eikonal terms,
+`sample_mode` and the training direction (gradient to the styles, to the second pass's texture FiLM and to query
+points) are further HIP launches.  Options the kernels do not cover (stratified perturbation, density
+mode, mesh extraction, gradients to the frozen generator weights) raise NotImplementedError instead of silently taking
+another path.
 """
 import ctypes
+import os
+import warnings
 
 import numpy as np
 import torch
 import torch.nn as nn
+from torch.autograd.function import once_differentiable
 
 from . import _lib
 
 
 MFMA_MODES = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3}
+_STRICT_CACHE = os.environ.get("E3DGE_STRICT_WEIGHT_CACHE", "0") not in ("", "0")
 
 
 def default_mfma_mode():
@@ -135,6 +141,7 @@ class SirenGenerator(nn.Module):
         self.sigma_linear = LinearLayer(W, 1, freq_init=True)
         self._cache_key = None
         self._cache = None
+        self._fingerprint = None
         self.mfma_mode = default_mfma_mode()
         self.bwd_mode = default_bwd_mode()
 
@@ -145,11 +152,36 @@ class SirenGenerator(nn.Module):
     def _key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
+    def invalidate(self):
+        """Drop the packed weight image.  The cache is keyed on (data_ptr, _version) of every parameter, which catches
+        optimizer steps, `load_state_dict`, `.to()` and in-place ops on the parameter itself -- but NOT writes through
+        `.data` (`p.data.mul_()`, the reference's EMA `accumulate()` in utils/training_utils.py:45 and ranger.py:178 do
+        that; they leave `_version` untouched).  Call this after such an update, or set E3DGE_STRICT_WEIGHT_CACHE=1 to
+        have every call compare a device-side fingerprint of the weights (one extra reduction + a host sync per call)."""
+        self._cache = self._cache_key = self._fingerprint = None
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def train(self, mode=True):
+        self.invalidate()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *a, **k):
+        self.invalidate()
+        return super()._load_from_state_dict(*a, **k)
+
+    def _weights_fingerprint(self):
+        with torch.no_grad():
+            return torch.stack(torch._foreach_norm([p.detach().reshape(-1) for p in self.parameters()]))
+
     def device_image(self):
-        """(packed, wg, bg, wb, bb): rebuilt only when a parameter changed (or moved)."""
+        """(packed, wg, bg, wb, bb): rebuilt only when a parameter changed (or moved); see invalidate()."""
         key = self._key()
         if self._cache is not None and key == self._cache_key:
-            return self._cache
+            if not _STRICT_CACHE or torch.equal(self._weights_fingerprint(), self._fingerprint):
+                return self._cache
         w0 = self.pts_linears[0].weight
         _lib.require_gpu(w0, "SirenGenerator parameters")
         lib = _lib.load()
@@ -177,22 +209,38 @@ class SirenGenerator(nn.Module):
                     _lib.ptr(b_sig), _lib.stream_of(packed))
             _lib.check(rc, "e3dge_siren_pack_weights")
             # The f16x3 images carry the weights times 128 as f16 (max 65504): a checkpoint with |w| >= 256 in the
-            # 256-wide layers (trained ones are ~0.01) cannot use them; say so instead of producing infinities.
+            # 256-wide layers (trained ones are ~0.01) cannot use them; check_mode() then selects the fp32 MFMA kernels.
             self._wmax = float(torch.maximum(w_hidden.abs().max(), w_view.abs().max()).item())
             layers = self._film_layers()
             wg = torch.stack([l.gamma.weight.detach() for l in layers]).contiguous()
             bg = torch.stack([l.gamma.bias.detach() for l in layers]).contiguous()
             wb = torch.stack([l.beta.weight.detach() for l in layers]).contiguous()
             bb = torch.stack([l.beta.bias.detach() for l in layers]).contiguous()
+            self._fingerprint = self._weights_fingerprint() if _STRICT_CACHE else None
         self._cache, self._cache_key = (packed, wg, bg, wb, bb), key
         return self._cache
 
     def check_mode(self, mode):
-        """Refuse the split-f16 kernels for weights outside their f16 range (see device_image)."""
+        """Precision selector for a launch.  Weights outside the f16x3 image's range (|w| >= 256, see device_image) fall
+        back to the fp32 MFMA kernels for this module, with one warning."""
         if mode == "f16x3" and getattr(self, '_wmax', 0.0) >= 256.0:
-            raise RuntimeError(f"SIREN weights up to {self._wmax:g} do not fit the f16x3 weight image (|w| < 256); "
-                               "set E3DGE_MFMA_MODE=f32 / E3DGE_BWD_MODE=f32 for this checkpoint")
+            if not getattr(self, '_warned_range', False):
+                warnings.warn(f"SIREN weights up to {self._wmax:g} do not fit the f16x3 weight image (|w| < 256); "
+                              "this module uses the fp32 MFMA kernels instead")
+                self._warned_range = True
+            mode = "f32"
         return MFMA_MODES[mode]
+
+    def require_frozen(self, what):
+        """The HIP backward returns gradients for the styles (and, where stated, points / texture FiLM) only; the
+        reference can also train the renderer (Generator.train_renderer = not freeze_renderer).  Make the frozen
+        generator an explicit precondition instead of a silent no-op."""
+        hot = [n for n, p in self.named_parameters() if p.requires_grad]
+        if hot:
+            raise NotImplementedError(
+                f"{what}: SIREN parameters require grad ({hot[0]}, ... {len(hot)} in all) but the HIP backward only "
+                "differentiates w.r.t. the styles (frozen generator, trainer.py:1568); call requires_grad_(False) on the "
+                "renderer or run under torch.no_grad()")
 
     def film_params(self, styles):
         """styles (B,9,256) [W+] or (B,256) [W, shared by all layers, reference :189-191] -> (B,9,2,256)."""
@@ -215,12 +263,14 @@ class SirenGenerator(nn.Module):
                      want_eikonal=False):
         """pts (B, N, 3) world-space, viewdirs (B, N, 3) or None -> (sdf (B,N), raw (B,N,260) or None)
         [, eikonal term d sdf / d pts (B,N,3) with want_eikonal].
-        When `styles` requires grad the call is differentiable w.r.t. it (HIP backward, e3dge_siren_bwd), the eikonal
-        term included.  d(outputs)/d(pts) beyond the eikonal term itself is not provided."""
+        Under grad mode the call is differentiable w.r.t. `styles` and w.r.t. `pts` (whichever requires grad): HIP
+        backward e3dge_siren_bwd, the eikonal term included -- d(eikonal)/d(pts) is the Hessian-vector product the
+        reference gets by keeping the surface point in the graph (:921-930).  View directions get no gradient."""
         _lib.require_gpu(pts, "pts")
         live = pts.shape[0] and pts.shape[1]
-        if torch.is_grad_enabled() and styles.requires_grad and live:
-            sdf, raw, eik = _PointsQuery.apply(styles, self, pts.detach(), None if viewdirs is None else viewdirs.detach(),
+        if torch.is_grad_enabled() and (styles.requires_grad or pts.requires_grad) and live:
+            self.require_frozen("query_points")
+            sdf, raw, eik = _PointsQuery.apply(styles, self, pts, None if viewdirs is None else viewdirs.detach(),
                                                box_scale, mfma_mode, bool(want_eikonal))
             raw = raw if want_raw else None
             return (sdf, raw, eik) if want_eikonal else (sdf, raw)
@@ -287,10 +337,12 @@ def tangent_arguments(siren, film, args, v, box_scale):
     return tang
 
 
-def siren_backward(siren, film, args, d_feat, d_rgb, d_sdf, tang=None, rsave=None):
+def siren_backward(siren, film, args, d_feat, d_rgb, d_sdf, tang=None, rsave=None, want_d_pts=False, box_scale=1.0,
+                   tex_alpha=None):
     """dL/d(styles) (B,9,256) and dL/d(film) (B,9,2,256) from the per-point output gradients (e3dge_siren_bwd).
     args (B,N,9,256) are the forward launch's saved pre-sine arguments; any of d_feat (B,N,256), d_rgb (B,N,3),
-    d_sdf (B,N) may be None.  tang + rsave add the gradient of a loss on the eikonal term."""
+    d_sdf (B,N) may be None.  tang + rsave add the gradient of a loss on the eikonal term.  Returns
+    (dstyles, dfilm, d_pts or None, (d_alpha, d_beta) or None)."""
     packed, wg, _, wb, _ = siren.device_image()
     B, N = args.shape[0], args.shape[1]
     dev = args.device
@@ -300,19 +352,28 @@ def siren_backward(siren, film, args, d_feat, d_rgb, d_sdf, tang=None, rsave=Non
     partials = torch.empty(max(n_part, 1), device=dev, dtype=torch.float32)
     dfilm = torch.empty((B, 9, 2, siren.W), device=dev, dtype=torch.float32)
     dstyles = torch.empty((B, 9, siren.W), device=dev, dtype=torch.float32)
+    d_pts = torch.empty((B, N, 3), device=dev, dtype=torch.float32) if want_d_pts else None
+    d_ta = d_tb = None
+    if tex_alpha is not None:
+        d_ta = torch.empty((B, N, siren.W), device=dev, dtype=torch.float32)
+        d_tb = torch.empty((B, N, siren.W), device=dev, dtype=torch.float32)
+    a = _lib.SirenBwdArgs(
+        packed=_lib.ptr(packed), film=_lib.ptr(film), args=_lib.ptr(args), d_feat=_lib.ptr(d_feat), d_rgb=_lib.ptr(d_rgb),
+        d_sdf=_lib.ptr(d_sdf), tang=_lib.ptr(tang), rsave=_lib.ptr(rsave), wg=_lib.ptr(wg), wb=_lib.ptr(wb),
+        tex_alpha=_lib.ptr(tex_alpha), batch=B, precision=siren.check_mode(siren.bwd_mode), n_pts=N, box_scale=float(box_scale),
+        partials=_lib.ptr(partials), dfilm=_lib.ptr(dfilm), dstyles=_lib.ptr(dstyles), d_pts=_lib.ptr(d_pts),
+        d_tex_alpha=_lib.ptr(d_ta), d_tex_beta=_lib.ptr(d_tb))
     with torch.cuda.device(dev):
-        rc = lib.e3dge_siren_bwd(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), _lib.ptr(d_feat), _lib.ptr(d_rgb),
-                                 _lib.ptr(d_sdf), _lib.ptr(tang), _lib.ptr(rsave), _lib.ptr(wg), _lib.ptr(wb), B, N, _lib.ptr(partials),
-                                 _lib.ptr(dfilm), _lib.ptr(dstyles), siren.check_mode(siren.bwd_mode), _lib.stream_of(args))
+        rc = lib.e3dge_siren_bwd(ctypes.byref(a), _lib.stream_of(args))
     _lib.check(rc, "e3dge_siren_bwd")
-    return dstyles, dfilm
+    return dstyles, dfilm, d_pts, (None if d_ta is None else (d_ta, d_tb))
 
 
 class _PointsQuery(torch.autograd.Function):
-    """run_network with a gradient path to the styles (the encoder's output): forward saves the pre-sine arguments,
-    backward is the fused HIP chain.  With want_eik the eikonal term d sdf / d x is a third, differentiable output
-    (the reference builds it with autograd.grad(create_graph=True), :796-802).  The points / view directions themselves
-    get no gradient (they are fixed samples)."""
+    """run_network with a gradient path to the styles (the encoder's output) and to the query points: forward saves the
+    pre-sine arguments, backward is the fused HIP chain.  With want_eik the eikonal term d sdf / d x is a third,
+    differentiable output (the reference builds it with autograd.grad(create_graph=True), :796-802).  View directions
+    get no gradient (they are fixed samples).  The backward is not itself differentiable (once_differentiable)."""
 
     @staticmethod
     def forward(ctx, styles, siren, pts, viewdirs, box_scale, mfma_mode, want_eik):
@@ -330,6 +391,7 @@ class _PointsQuery(torch.autograd.Function):
         return sdf, raw, eik
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, d_sdf, d_raw, d_eik):
         film, args, rsave = ctx.saved_tensors
         d_rgb = d_feat = None
@@ -340,34 +402,38 @@ class _PointsQuery(torch.autograd.Function):
         tang = rs = None
         if ctx.want_eik and d_eik is not None:
             tang, rs = tangent_arguments(ctx.siren, film, args, d_eik, ctx.box_scale), rsave
-        dstyles, _ = siren_backward(ctx.siren, film, args, d_feat, d_rgb, ds, tang, rs)
+        dstyles, _, d_pts, _ = siren_backward(ctx.siren, film, args, d_feat, d_rgb, ds, tang, rs,
+                                              want_d_pts=ctx.needs_input_grad[2], box_scale=ctx.box_scale)
         if ctx.styles_ndim == 2:                   # one W shared by the nine layers (reference :189-191)
             dstyles = dstyles.sum(1)
-        return dstyles, None, None, None, None, None, None
+        return (dstyles if ctx.needs_input_grad[0] else None), None, d_pts, None, None, None, None
 
 
-_DIFF_KEYS = ('gen_thumb_imgs', 'features', 'xyz', 'depth', 'sdf', 'eikonal_term')
-_AUX_KEYS = ('mask', 'hit_prob', 'points', 'rays_d', 'viewdirs', 'dists')
+_DIFF_KEYS = ('gen_thumb_imgs', 'features', 'xyz', 'depth', 'sdf', 'hit_prob', 'eikonal_term')
+_AUX_KEYS = ('mask', 'points', 'rays_d', 'viewdirs', 'dists')
 
 
 class _RenderQuery(torch.autograd.Function):
-    """VolumeFeatureRenderer.render with a gradient path from (rgb, features, xyz, depth, sdf) to the styles:
-    e3dge_siren_render_fwd with saved pre-sine arguments, e3dge_siren_render_bwd for the way back."""
+    """VolumeFeatureRenderer.render with a gradient path from (rgb, features, xyz, depth, sdf, hit_prob, eikonal term) to
+    the styles and -- on the second pass -- to the per-point texture FiLM (alpha, beta): e3dge_siren_render_fwd with saved
+    pre-sine arguments, e3dge_siren_render_bwd for the way back.  Cameras, near / far get no gradient."""
 
     @staticmethod
-    def differentiable(renderer, styles, focal, c2w, near, far, want_eik=False):
-        vals = _RenderQuery.apply(styles, renderer, focal, c2w, near, far, bool(want_eik))
+    def differentiable(renderer, styles, focal, c2w, near, far, want_eik=False, tex_conditions=None):
+        ta, tb = tex_conditions if tex_conditions is not None else (None, None)
+        vals = _RenderQuery.apply(styles, renderer, focal, c2w, near, far, bool(want_eik), ta, tb)
         out = dict(zip(_DIFF_KEYS + _AUX_KEYS, vals))
         if not want_eik:
             out['eikonal_term'] = None
         return renderer._render_dict(out, c2w, near, far)
 
     @staticmethod
-    def forward(ctx, styles, renderer, focal, c2w, near, far, want_eik):
+    def forward(ctx, styles, renderer, focal, c2w, near, far, want_eik, tex_alpha, tex_beta):
         B, H, S = c2w.shape[0], renderer.out_im_res, renderer.N_samples
         film = renderer.siren.film_params(styles)
         args = torch.empty((B, H * H * S, 9, renderer.siren.W), device=c2w.device, dtype=torch.float32)
-        out = renderer.render_with_film(film, focal, c2w, near, far, None, save_args=args)
+        tex = None if tex_alpha is None else (tex_alpha.detach(), tex_beta.detach())
+        out = renderer.render_with_film(film, focal, c2w, near, far, tex, save_args=args)
         if want_eik:
             eik, rsave = sdf_gradient(renderer.siren, film, args, renderer.box_scale)
             out['eikonal_term'] = eik.reshape(B, H, H, S, 3)
@@ -375,15 +441,18 @@ class _RenderQuery(torch.autograd.Function):
             out['eikonal_term'], rsave = torch.empty(0, device=c2w.device), torch.empty(0, device=c2w.device)
         ctx.renderer, ctx.styles_ndim, ctx.want_eik = renderer, styles.ndim, want_eik
         ctx.sigmoid_beta = renderer._sigmoid_beta_value()
+        ctx.has_tex = tex is not None
+        ta = tex[0].contiguous() if tex is not None else torch.empty(0, device=c2w.device)
         ctx.save_for_backward(film, args, out['sdf'], out['dists'], out['points'], out['hit_prob'],
-                              near.reshape(B).contiguous().float(), far.reshape(B).contiguous().float(), rsave)
+                              near.reshape(B).contiguous().float(), far.reshape(B).contiguous().float(), rsave, ta)
         aux = tuple(out[k] for k in _AUX_KEYS)
         ctx.mark_non_differentiable(*aux)
         return tuple(out[k] for k in _DIFF_KEYS) + aux
 
     @staticmethod
-    def backward(ctx, d_rgb, d_feat, d_xyz, d_depth, d_sdf, d_eik, *unused):
-        film, args, sdf, dists, points, weights, near, far, rsave = ctx.saved_tensors
+    @once_differentiable
+    def backward(ctx, d_rgb, d_feat, d_xyz, d_depth, d_sdf, d_hit, d_eik, *unused):
+        film, args, sdf, dists, points, weights, near, far, rsave, ta = ctx.saved_tensors
         r = ctx.renderer
         siren = r.siren
         B, H, S = film.shape[0], r.out_im_res, r.N_samples
@@ -392,6 +461,7 @@ class _RenderQuery(torch.autograd.Function):
         d_rgb_map, d_feat_map, d_xyz_map = rows(d_rgb, 3), rows(d_feat, siren.W), rows(d_xyz, 3)
         d_depth_map = None if d_depth is None else d_depth.reshape(B, H * H).contiguous().float()
         d_sdf_in = None if d_sdf is None else d_sdf.reshape(B, H * H * S).contiguous().float()
+        d_w_in = None if d_hit is None else d_hit.reshape(B, H * H * S).contiguous().float()
         packed, wg, _, wb, _ = siren.device_image()
         lib = _lib.load()
         n_pts = H * H * S
@@ -403,20 +473,62 @@ class _RenderQuery(torch.autograd.Function):
         tang = rs = None
         if ctx.want_eik and d_eik is not None:
             tang, rs = tangent_arguments(siren, film, args, d_eik, r.box_scale), rsave
+        d_ta = d_tb = tex_a = None
+        if ctx.has_tex:
+            tex_a = ta
+            d_ta = torch.empty((B, H, H, S, siren.W), device=dev, dtype=torch.float32)
+            d_tb = torch.empty((B, H, H, S, siren.W), device=dev, dtype=torch.float32)
         a = _lib.RenderBwdArgs(
             packed=_lib.ptr(packed), film=_lib.ptr(film), args=_lib.ptr(args), sdf=_lib.ptr(sdf), dists=_lib.ptr(dists),
             points=_lib.ptr(points), weights=_lib.ptr(weights), t_vals=_lib.ptr(r.t_vals), near=_lib.ptr(near),
             far=_lib.ptr(far), wg=_lib.ptr(wg), wb=_lib.ptr(wb), d_rgb_map=_lib.ptr(d_rgb_map),
             d_feat_map=_lib.ptr(d_feat_map), d_xyz_map=_lib.ptr(d_xyz_map), d_depth_map=_lib.ptr(d_depth_map),
-            d_sdf=_lib.ptr(d_sdf_in), tang=_lib.ptr(tang), rsave=_lib.ptr(rs), sigmoid_beta=ctx.sigmoid_beta, batch=B, height=H, width=H, n_samples=S,
+            d_sdf=_lib.ptr(d_sdf_in), tang=_lib.ptr(tang), rsave=_lib.ptr(rs), d_weights=_lib.ptr(d_w_in),
+            tex_alpha=_lib.ptr(tex_a), sigmoid_beta=ctx.sigmoid_beta, batch=B, height=H, width=H, n_samples=S,
             force_background=int(bool(r.force_background)), precision=siren.check_mode(siren.bwd_mode), d_rgb_pts=_lib.ptr(d_rgb_pts), d_sdf_pts=_lib.ptr(d_sdf_pts),
-            partials=_lib.ptr(partials), dfilm=_lib.ptr(dfilm), dstyles=_lib.ptr(dstyles))
+            partials=_lib.ptr(partials), dfilm=_lib.ptr(dfilm), dstyles=_lib.ptr(dstyles), d_tex_alpha=_lib.ptr(d_ta),
+            d_tex_beta=_lib.ptr(d_tb))
         with torch.cuda.device(dev):
             rc = lib.e3dge_siren_render_bwd(ctypes.byref(a), _lib.stream_of(film))
         _lib.check(rc, "e3dge_siren_render_bwd")
         if ctx.styles_ndim == 2:
             dstyles = dstyles.sum(1)
-        return dstyles, None, None, None, None, None, None
+        return (dstyles if ctx.needs_input_grad[0] else None), None, None, None, None, None, None, d_ta, d_tb
+
+
+def _resblock_backward_torch(x, w0, b0, w1, ws, dy):
+    """Backward of out = Ws x + W1 relu(W0 relu(x) + b0) + b1 on the GPU with library GEMMs (rocBLAS through torch): the
+    hidden activations are recomputed, nothing was saved by the fused forward.  Returns dx, dW0, db0, dW1, db1, dWs."""
+    r0 = torch.relu(x)
+    net = torch.addmm(b0, r0, w0.t())
+    r1 = torch.relu(net)
+    dnet = (dy @ w1) * (net > 0)
+    dx = dy @ ws + (dnet @ w0) * (x > 0)
+    return dx, dnet.t() @ r0, dnet.sum(0), dy.t() @ r1, dy.sum(0), dy.t() @ x
+
+
+class _TexHead(torch.autograd.Function):
+    """The fused texture head with a backward (stage-2 training differentiates the second pass,
+    e3dge_full_runner.py:185-317): forward = e3dge_tex_modulations_fwd, backward = GPU library GEMMs with recomputation."""
+
+    @staticmethod
+    def forward(ctx, feats2d, block, w0, b0, w1, b1, ws):
+        ctx.save_for_backward(feats2d, w0, b0, w1, ws)
+        return block._launch(feats2d)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_alpha, d_beta):
+        x, w0, b0, w1, ws = ctx.saved_tensors
+        if d_alpha is None:
+            d_alpha = torch.zeros_like(d_beta)
+        if d_beta is None:
+            d_beta = torch.zeros_like(d_alpha)
+        dy = torch.cat([d_alpha, d_beta], -1).contiguous()
+        dx, dw0, db0, dw1, db1, dws = _resblock_backward_torch(x, w0, b0, w1, ws, dy)
+        need = ctx.needs_input_grad
+        return (dx if need[0] else None, None, dw0 if need[2] else None, db0 if need[3] else None,
+                dw1 if need[4] else None, db1 if need[5] else None, dws if need[6] else None)
 
 
 class ResnetBlockFC(nn.Module):
@@ -438,10 +550,22 @@ class ResnetBlockFC(nn.Module):
         self._cache_key = None
         self._cache = None
 
+    def invalidate(self):
+        """Drop the packed weight image (needed after writes through `.data`; see SirenGenerator.invalidate)."""
+        self._cache = self._cache_key = None
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def train(self, mode=True):
+        self.invalidate()
+        return super().train(mode)
+
     def device_image(self):
         ps = [self.fc_0.weight, self.fc_0.bias, self.fc_1.weight, self.fc_1.bias, self.shortcut.weight]
         key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
-        if key != self._cache_key:
+        if key != self._cache_key or self._cache is None:
             dev = ps[0].device
             _lib.require_gpu(ps[0], "ResnetBlockFC weights")
             lib = _lib.load()
@@ -462,16 +586,8 @@ class ResnetBlockFC(nn.Module):
         a, b = self.tex_modulations(x)
         return torch.cat([a, b], -1)
 
-    def tex_modulations(self, feats):
-        """feats (.., size_in) -> (alpha, beta), each (.., 256): the split the renderer's second pass consumes."""
-        _lib.require_gpu(feats, "feats")
-        if feats.shape[-1] != self.size_in:
-            raise RuntimeError(f"local features must have {self.size_in} channels, got {tuple(feats.shape)}")
-        if torch.is_grad_enabled() and (feats.requires_grad or self.fc_0.weight.requires_grad):
-            raise NotImplementedError("the texture head has no HIP backward (the second renderer pass runs under no_grad "
-                                      "in the reference's inference / stage-1 paths)")
-        lead = feats.shape[:-1]
-        f = feats.reshape(-1, self.size_in).contiguous().float()
+    def _launch(self, f):
+        """f (n, size_in) contiguous fp32 on the GPU -> (alpha, beta), each (n, 256): one fused launch."""
         n = f.shape[0]
         alpha = torch.empty((n, 256), device=f.device, dtype=torch.float32)
         beta = torch.empty((n, 256), device=f.device, dtype=torch.float32)
@@ -480,6 +596,22 @@ class ResnetBlockFC(nn.Module):
             rc = _lib.load().e3dge_tex_modulations_fwd(_lib.ptr(packed), _lib.ptr(f), self.size_in, n, _lib.ptr(alpha),
                                                        _lib.ptr(beta), _lib.stream_of(f))
         _lib.check(rc, "e3dge_tex_modulations_fwd")
+        return alpha, beta
+
+    def tex_modulations(self, feats):
+        """feats (.., size_in) -> (alpha, beta), each (.., 256): the split the renderer's second pass consumes.
+        Differentiable (features and the five parameters) when anything requires grad: the backward recomputes the hidden
+        activations and uses library GEMMs (stage-2 training, e3dge_full_runner.py:185-317)."""
+        _lib.require_gpu(feats, "feats")
+        if feats.shape[-1] != self.size_in:
+            raise RuntimeError(f"local features must have {self.size_in} channels, got {tuple(feats.shape)}")
+        lead = feats.shape[:-1]
+        f = feats.reshape(-1, self.size_in).contiguous().float()
+        ps = (self.fc_0.weight, self.fc_0.bias, self.fc_1.weight, self.fc_1.bias, self.shortcut.weight)
+        if torch.is_grad_enabled() and (f.requires_grad or any(p.requires_grad for p in ps)) and f.shape[0]:
+            alpha, beta = _TexHead.apply(f, self, *ps)
+        else:
+            alpha, beta = self._launch(f)
         return alpha.reshape(*lead, 256), beta.reshape(*lead, 256)
 
 
@@ -492,6 +624,10 @@ class LocalTexHead(nn.Module):
     def __init__(self, feats_dim):
         super().__init__()
         self.local_feat_to_tex_modulations_linear = ResnetBlockFC(feats_dim, 512)
+
+    def tex_modulations_from_maps(self, renderer, cam_poses, focal, near, far, local_data_batch):
+        from .local_query import tex_modulations_from_maps
+        return tex_modulations_from_maps(self, renderer, cam_poses, focal, near, far, local_data_batch)
 
 
 class SirenLocalGlobal(nn.Module):
@@ -623,11 +759,15 @@ class VolumeFeatureRenderer(nn.Module):
         if not self.test and (self.perturb or self.raw_noise_std):
             raise NotImplementedError("stratified perturbation / raw noise (train-mode sampling) is not covered by "
                                       "the fused kernel; construct with mode='test' or perturb=0")
-        if torch.is_grad_enabled() and styles.requires_grad and c2w.shape[0]:
-            if tex_conditions is not None:
-                raise NotImplementedError("the HIP backward covers the global (first) renderer pass; the tex-FiLM pass "
-                                          "runs under no_grad in stage-1 training")
-            return _RenderQuery.differentiable(self, styles, focal, c2w, near, far, return_eikonal)
+        tex_grad = tex_conditions is not None and (tex_conditions[0].requires_grad or tex_conditions[1].requires_grad)
+        if torch.is_grad_enabled() and (styles.requires_grad or tex_grad) and c2w.shape[0]:
+            self.siren.require_frozen("VolumeFeatureRenderer.render")
+            if self.sigmoid_beta.requires_grad:
+                raise NotImplementedError("renderer.sigmoid_beta requires grad, but the HIP backward treats it as frozen "
+                                          "(trainer.py:1568); call requires_grad_(False) on the renderer")
+            if tex_conditions is not None and return_eikonal:
+                raise NotImplementedError("eikonal term together with the tex-FiLM pass")
+            return _RenderQuery.differentiable(self, styles, focal, c2w, near, far, return_eikonal, tex_conditions)
         film = self.siren.film_params(styles)
         if not return_eikonal:
             return self.render_with_film(film, focal, c2w, near, far, tex_conditions)
@@ -697,19 +837,41 @@ class VolumeFeatureRenderer(nn.Module):
 
     def _sigmoid_beta_value(self):
         """Host copy of the learned sigmoid_beta, refreshed only when the parameter changes (a `.item()` per
-        call would put a device synchronisation in front of every render)."""
+        call would put a device synchronisation in front of every render).  Writes through `.data` need invalidate()."""
         p = self.sigmoid_beta
         key = (p.data_ptr(), p._version)
-        if getattr(self, '_sb_key', None) != key:
+        if getattr(self, '_sb_key', None) != key or _STRICT_CACHE:
             self._sb_val, self._sb_key = float(p.detach().item()), key
         return self._sb_val
+
+    def invalidate(self):
+        """Forget every host / device copy derived from the parameters (packed SIREN image, texture-head image,
+        sigmoid_beta).  Needed only after updates that bypass autograd's version counter (`p.data.mul_()`, the reference's
+        EMA accumulate(), utils/training_utils.py:45); optimizer steps, load_state_dict, .to() and train()/eval() are
+        detected without it."""
+        self._sb_key = None
+        for m in self.modules():
+            if m is not self and hasattr(m, 'invalidate'):
+                m.invalidate()
+
+    def train(self, mode=True):
+        self._sb_key = None
+        return super().train(mode)
 
     # -------------------------------------------------------------------------------------------------
     def forward(self, cam_poses, focal, near, far, styles=None, return_eikonal=False, geometry_sample=None,
                 return_surface_eikonal=False, local_data_batch=None, sample_mode=False, return_mesh=False,
-                mesh_with_shading=True, return_sdf_only=False, **kwargs):
+                mesh_with_shading=True, return_sdf_only=False, sample_without_grad=False, **kwargs):
         if return_mesh:
             raise NotImplementedError("marching-cubes mesh extraction is out of scope (SURVEY.md 2 #13)")
+        if sample_without_grad and torch.is_grad_enabled():
+            # the reference detaches every output in this mode (:1291-1294); running the whole query without a graph is
+            # the same result without saving 9.2 KB of pre-sine arguments per point
+            with torch.no_grad():
+                return self.forward(cam_poses, focal, near, far, styles=styles, return_eikonal=return_eikonal,
+                                    geometry_sample=geometry_sample, return_surface_eikonal=return_surface_eikonal,
+                                    local_data_batch=local_data_batch, sample_mode=sample_mode, return_mesh=return_mesh,
+                                    mesh_with_shading=mesh_with_shading, return_sdf_only=return_sdf_only, **kwargs)
         self.sample_mode = bool(sample_mode)
         tex = None
         if self.enable_local_model and local_data_batch is not None:
@@ -717,24 +879,27 @@ class VolumeFeatureRenderer(nn.Module):
                 tex = local_data_batch['tex']
             elif local_data_batch.get('feats', None) is not None and self.network.netLocal is not None:
                 # already-queried local features (forward_local :434-437) -> texture FiLM (:327-336), fused head
-                with torch.no_grad():
-                    tex = self.network.netLocal.local_feat_to_tex_modulations_linear.tex_modulations(local_data_batch['feats'])
+                tex = self.network.netLocal.local_feat_to_tex_modulations_linear.tex_modulations(local_data_batch['feats'])
+            elif local_data_batch.get('feature_maps', None) is not None and self.network.netLocal is not None:
+                # feature maps of the local branch: the per-point query (projection + bilinear gather + positional
+                # encoding, e3dge_full_runner.py:185-317) runs in HIP and feeds the texture head directly
+                tex = self.network.netLocal.tex_modulations_from_maps(self, cam_poses, focal, near, far, local_data_batch)
             else:
                 raise NotImplementedError(
-                    "local_data_batch must carry the local features 'feats' (B,H,W,S,C) [with L_pred_tex_modulations] or "
-                    "the texture FiLM conditions 'tex' = (alpha, beta); filtering images and querying the PIFu feature "
-                    "maps is outside this build (SURVEY.md 8f-2)")
+                    "local_data_batch must carry the local features 'feats' (B,H,W,S,C) [with L_pred_tex_modulations], the "
+                    "local branch's 'feature_maps' or the texture FiLM conditions 'tex' = (alpha, beta); the hourglass image "
+                    "filters of the PIFu branch are outside this build (SURVEY.md 8f-2)")
             self.local_batch = local_data_batch
         else:
             self.local_batch = None
 
         render_out = self.render(focal, cam_poses, near, far, styles, tex_conditions=tex, return_eikonal=return_eikonal)
         if return_surface_eikonal:
-            # normal at the integrated surface point (:921-930).  The point itself is treated as a fixed sample: the
-            # term's gradient reaches the styles through the network, not through d xyz / d styles (a second
-            # derivative in x that the stage-1 losses never use -- they take xyz_rec_eikonal_term below).
+            # normal at the integrated surface point (:921-930).  As in the reference the point stays in the graph: the
+            # term's gradient reaches the styles through the network AND through d xyz / d styles (the Hessian-vector
+            # product e3dge_siren_bwd returns as d_pts, chained into the compositing backward as d_xyz).
             B = cam_poses.shape[0]
-            surf = render_out['xyz'].detach().permute(0, 2, 3, 1).reshape(B, -1, 3)
+            surf = render_out['xyz'].permute(0, 2, 3, 1).reshape(B, -1, 3)
             _, _, se = self.siren.query_points(surf, None, styles, self.box_scale, want_raw=False, want_eikonal=True)
             render_out['surface_eikonal_term'] = se.reshape(B, self.out_im_res, self.out_im_res, 1, 3)
 

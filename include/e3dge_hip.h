@@ -199,14 +199,28 @@ int e3dge_siren_points_fwd(const float* packed, const float* film, const float* 
  *   dstyles  (batch, 9, 256)    out  dL/d(styles)
  * precision: E3DGE_PREC_F32 (fp32 MFMA) or E3DGE_PREC_F16X3: every gradient operand is scaled per point by a power of
  * two into [1, 2), split into f16 hi + lo, three f16 MFMA products accumulated in fp32 -- same error as fp32.
- * No tex-FiLM (second pass) support: that pass runs under no_grad in the reference's stage-1 training.
+ * Optional outputs / inputs (NULL = absent):
+ *   d_pts (batch, n_pts, 3) out: dL/d(query points) = box_scale * W_0^T (gamma_0 * adj(a_0)) -- with tang/rsave this is
+ *     the Hessian-vector product the reference obtains by keeping xyz in the graph of the surface normals
+ *     (volume_renderer.py:921-930); box_scale as given to the forward launch.
+ *   tex_alpha (batch, n_pts, 256): the forward pass applied the texture FiLM h8' = (alpha+1) h8 + beta (:217-220);
+ *     d_tex_alpha, d_tex_beta (batch, n_pts, 256) out receive dL/dalpha, dL/dbeta (stage-2 training differentiates the
+ *     second pass, e3dge_full_runner.py:185-317).  Not combinable with tang/rsave.
  * ---------------------------------------------------------------------------------------------------------------- */
 int64_t e3dge_siren_bwd_partial_floats(int batch, int64_t n_pts);
-int e3dge_siren_bwd(const float* packed, const float* film, const float* args, const float* d_feat,
-                    const float* d_rgb, const float* d_sdf, const float* tang, const float* rsave,
-                    const float* wg, const float* wb,
-                    int batch, int64_t n_pts, float* partials, float* dfilm, float* dstyles, int precision,
-                    e3dge_stream_t stream);
+typedef struct E3dgeSirenBwdArgs {
+    const float* packed; const float* film; const float* args;
+    const float* d_feat; const float* d_rgb; const float* d_sdf;
+    const float* tang; const float* rsave;
+    const float* wg; const float* wb;
+    const float* tex_alpha;
+    int batch; int precision;
+    int64_t n_pts;
+    float box_scale;
+    float* partials; float* dfilm; float* dstyles;
+    float* d_pts; float* d_tex_alpha; float* d_tex_beta;
+} E3dgeSirenBwdArgs;
+int e3dge_siren_bwd(const E3dgeSirenBwdArgs* args, e3dge_stream_t stream);
 
 /* Eikonal term e = d sdf / d x (get_eikonal_term, volume_renderer.py:796-802) and its double backward.
  *   e3dge_siren_sdf_grad : from the saved arguments, e (batch, n_pts, 3) [world-space x: includes box_scale] and
@@ -226,18 +240,22 @@ int e3dge_siren_tangent(const float* packed, const float* film, const float* arg
  *   d_rgb_map (rays,3)  d_feat_map (rays,256)  d_xyz_map (rays,3)  d_depth_map (rays)  d_sdf (rays,S); any may be NULL.
  * args/sdf/dists/points/weights are the forward launch's outputs (save_args, sdf, dists, points, weights).
  * d_rgb_pts (rays,S,3) and d_sdf_pts (rays,S) are scratch the caller provides; partials as for e3dge_siren_bwd with
- * n_pts = H*W*S.  sigmoid_beta and the generator weights get no gradient (frozen in encoder training). */
+ * n_pts = H*W*S.  sigmoid_beta and the generator weights get no gradient (frozen in encoder training).
+ * d_weights (rays,S): gradient arriving at the compositing weights (`hit_prob`, read by cycle_runner.py:134), or NULL.
+ * tex_alpha / d_tex_alpha / d_tex_beta (rays,S,256): as in E3dgeSirenBwdArgs, for the second (texture-FiLM) pass. */
 typedef struct E3dgeRenderBwdArgs {
     const float* packed; const float* film; const float* args; const float* sdf; const float* dists;
     const float* points; const float* weights; const float* t_vals; const float* near; const float* far;
     const float* wg; const float* wb;
     const float* d_rgb_map; const float* d_feat_map; const float* d_xyz_map; const float* d_depth_map; const float* d_sdf;
     const float* tang; const float* rsave;
+    const float* d_weights; const float* tex_alpha;
     float sigmoid_beta;
     int batch, height, width, n_samples, force_background;
     int precision;           /* E3DGE_PREC_F32 or E3DGE_PREC_F16X3 (block-scaled split-f16 GEMMs, fp32 accumulate) */
     float* d_rgb_pts; float* d_sdf_pts; float* partials;
     float* dfilm; float* dstyles;
+    float* d_tex_alpha; float* d_tex_beta;
 } E3dgeRenderBwdArgs;
 int e3dge_siren_render_bwd(const E3dgeRenderBwdArgs* args, e3dge_stream_t stream);
 

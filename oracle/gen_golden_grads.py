@@ -22,7 +22,7 @@ GOLD = os.path.join(REPO, "tests", "golden")
 import e3dge_amd  # noqa: E402,F401
 from e3dge_amd import synthetic as syn  # noqa: E402
 from oracle import ref_harness  # noqa: E402
-from oracle.training_ref import restated, stage1_loss  # noqa: E402
+from oracle.training_ref import c5_loss, restated, restated_c5, stage1_loss  # noqa: E402
 from oracle.gen_golden import build_reference_generator, maxdiff, npf, save  # noqa: E402
 
 RES, S = 8, 18
@@ -80,6 +80,76 @@ def main():
          ref_uniform_pts_rec=npf(out['uniform_pts_rec']), ref_loss=np.float64(float(loss)), ref_dstyles=npf(ref_grad),
          f64_eikonal_term=npf(o64['eikonal_term']), f64_xyz_rec_eikonal_term=npf(o64['xyz_rec_eikonal_term']),
          f64_loss=np.float64(float(l64)), f64_dstyles=g64.detach().numpy().astype(np.float64))
+
+    main_c5(g, sd, cu)
+
+
+def main_c5(g, sd, cu):
+    """Second recorded step: SURVEY.md 8d's C5 loss -- mean(rgb^2) + mean((|eik|-1)^2) + mean(surf_eik^2) -- whose last term
+    reaches the styles also through the integrated surface point (the reference keeps xyz in the graph, :921-930), and a
+    third one that puts a weight on hit_prob (the compositing weights carry grad in the reference, cycle_runner.py:134)."""
+    wr, _ = syn.synthetic_inputs(1, seed=1)
+    c = cu.generate_camera_params(RES, 'cpu', locations=torch.tensor([[-0.15, 0.1]]), fov_ang=6, dist_radius=0.12)
+    poses, focal, near, far = c[0], c[1], c[2], c[3]
+    rs = np.random.RandomState(13)
+    g_hit = torch.from_numpy(rs.normal(size=(1, RES, RES, S, 1)).astype(np.float32))
+
+    def run_ref(loss_fn):
+        styles = wr.clone().requires_grad_(True)
+        out = g.renderer(poses, focal, near, far, styles=styles, return_eikonal=True, return_surface_eikonal=True)
+        loss = loss_fn(out)
+        loss.backward()
+        return out, loss.detach(), styles.grad.clone()
+
+    def run_mine(loss_fn, dt):
+        s = wr.detach().to(dt).requires_grad_(True)
+        o = restated_c5(sd, poses, focal, near, far, s, RES, S, dt)
+        l = loss_fn(o)
+        l.backward()
+        return o, l.detach(), s.grad
+
+    hit_loss = lambda o: c5_loss(o) + (o['hit_prob'] * g_hit.to(o['hit_prob'].dtype)).mean()
+    out, loss, ref_grad = run_ref(c5_loss)
+    _, loss_h, ref_grad_h = run_ref(hit_loss)
+    o32, l32, g32 = run_mine(c5_loss, torch.float32)
+    o64, l64, g64 = run_mine(c5_loss, torch.float64)
+    _, l64h, g64h = run_mine(hit_loss, torch.float64)
+    _, _, g32h = run_mine(hit_loss, torch.float32)
+    # how much of the gradient travels through d xyz / d styles: the same loss with the surface point detached
+    s = wr.detach().double().requires_grad_(True)
+    from oracle import renderer_ref
+    ro = renderer_ref.render(sd, poses, focal, near, far, s, res=RES, n_samples=S, dtype=torch.float64)
+    xs = ro['xyz'].detach().permute(0, 2, 3, 1).unsqueeze(3).clone().requires_grad_(True)
+    raw_s = renderer_ref.query_points(sd, xs, None, s, dtype=torch.float64)
+    se = torch.autograd.grad(raw_s[..., 3:4], xs, torch.ones_like(raw_s[..., 3:4]), create_graph=True)[0]
+    (se ** 2).mean().backward()
+    g_det = s.grad.clone()
+    s2 = wr.detach().double().requires_grad_(True)
+    o2 = restated_c5(sd, poses, focal, near, far, s2, RES, S, torch.float64)
+    (o2['surface_eikonal_term'] ** 2).mean().backward()
+    scale = float(ref_grad.abs().max())
+    report = dict(
+        restatement_vs_reference=dict(surface_eikonal_term=maxdiff(out['surface_eikonal_term'], o32['surface_eikonal_term']),
+                                      loss=abs(float(loss) - float(l32)), dstyles_rel=maxdiff(ref_grad, g32) / scale,
+                                      dstyles_hit_rel=maxdiff(ref_grad_h, g32h) / float(ref_grad_h.abs().max())),
+        reference_vs_f64=dict(surface_eikonal_term=maxdiff(out['surface_eikonal_term'], o64['surface_eikonal_term']),
+                              loss=abs(float(loss) - float(l64)), dstyles_rel=maxdiff(ref_grad, g64) / scale,
+                              dstyles_hit_rel=maxdiff(ref_grad_h, g64h) / float(ref_grad_h.abs().max())),
+        surf_term_grad_through_xyz=dict(with_xyz_max=float(s2.grad.abs().max()), detached_max=float(g_det.abs().max()),
+                                        difference_rel=float((s2.grad - g_det).abs().max() / s2.grad.abs().max())),
+        dstyles_max_abs=scale)
+    print(json.dumps(report, indent=1))
+    with open(os.path.join(GOLD, "grads_c5_report.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    save("grads_c5_8x18", poses=npf(poses), focal=npf(focal), near=npf(near), far=npf(far), res=np.int32(RES),
+         n_samples=np.int32(S), styles_seed=np.int32(1), g_hit=npf(g_hit),
+         ref_eikonal_term=npf(out['eikonal_term']), ref_surface_eikonal_term=npf(out['surface_eikonal_term']),
+         ref_loss=np.float64(float(loss)), ref_dstyles=npf(ref_grad), ref_loss_hit=np.float64(float(loss_h)),
+         ref_dstyles_hit=npf(ref_grad_h), f64_surface_eikonal_term=npf(o64['surface_eikonal_term']),
+         f64_loss=np.float64(float(l64)), f64_dstyles=g64.detach().numpy().astype(np.float64),
+         f64_loss_hit=np.float64(float(l64h)), f64_dstyles_hit=g64h.detach().numpy().astype(np.float64),
+         f64_dstyles_surf_only=s2.grad.detach().numpy().astype(np.float64),
+         f64_dstyles_surf_only_detached_xyz=g_det.detach().numpy().astype(np.float64))
 
 
 if __name__ == "__main__":

@@ -60,9 +60,13 @@ def test_render_bwd_args_struct_layout_matches_c():
 #include <stddef.h>
 #include "e3dge_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(E3dgeRenderBwdArgs), offsetof(E3dgeRenderBwdArgs, d_rgb_map),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(E3dgeRenderBwdArgs), offsetof(E3dgeRenderBwdArgs, d_rgb_map),
          offsetof(E3dgeRenderBwdArgs, tang), offsetof(E3dgeRenderBwdArgs, sigmoid_beta),
-         offsetof(E3dgeRenderBwdArgs, force_background), offsetof(E3dgeRenderBwdArgs, dstyles));
+         offsetof(E3dgeRenderBwdArgs, force_background), offsetof(E3dgeRenderBwdArgs, dstyles),
+         offsetof(E3dgeRenderBwdArgs, tex_alpha), offsetof(E3dgeRenderBwdArgs, d_tex_beta));
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(E3dgeSirenBwdArgs), offsetof(E3dgeSirenBwdArgs, tex_alpha),
+         offsetof(E3dgeSirenBwdArgs, precision), offsetof(E3dgeSirenBwdArgs, n_pts), offsetof(E3dgeSirenBwdArgs, box_scale),
+         offsetof(E3dgeSirenBwdArgs, d_tex_beta));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
@@ -70,15 +74,18 @@ int main(void) {
         exe = os.path.join(d, "t")
         subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), c, "-o", exe], check=True)
         got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
-    R = _lib.RenderBwdArgs
+    R, Sb = _lib.RenderBwdArgs, _lib.SirenBwdArgs
     assert got == [ctypes.sizeof(R), R.d_rgb_map.offset, R.tang.offset, R.sigmoid_beta.offset,
-                   R.force_background.offset, R.dstyles.offset]
+                   R.force_background.offset, R.dstyles.offset, R.tex_alpha.offset, R.d_tex_beta.offset,
+                   ctypes.sizeof(Sb), Sb.tex_alpha.offset, Sb.precision.offset, Sb.n_pts.offset, Sb.box_scale.offset,
+                   Sb.d_tex_beta.offset]
     # argument validation of the training entry points happens before any launch
     lib = _lib.load()
     assert lib.e3dge_siren_render_bwd(None, None) == -1
     bad = _lib.RenderBwdArgs(batch=1, height=4, width=4, n_samples=0)
     assert lib.e3dge_siren_render_bwd(ctypes.byref(bad), None) == -1 and b"n_samples" in lib.e3dge_last_error()
-    assert lib.e3dge_siren_bwd(None, None, None, None, None, None, None, None, None, None, 1, 10, None, None, None, 0, None) == -1
+    assert lib.e3dge_siren_bwd(None, None) == -1
+    assert lib.e3dge_siren_bwd(ctypes.byref(_lib.SirenBwdArgs(batch=1, n_pts=10)), None) == -1 and b"null" in lib.e3dge_last_error()
     assert lib.e3dge_siren_sdf_grad(None, None, None, None, 1.0, 1, 10, None, None, 0, None) == -1
     assert lib.e3dge_siren_tangent(None, None, None, None, 1.0, 1, 10, None, 0, None) == -1
     assert lib.e3dge_siren_bwd_partial_floats(2, 1000) == 2 * 8 * 9 * 2 * 256     # 8 sub-tiles -> 8 workgroups per image
@@ -129,14 +136,43 @@ def test_no_cpu_fallback_on_the_product_path():
     from e3dge_amd import op
     from e3dge_amd.volume_renderer import VolumeFeatureRenderer
     x = torch.randn(1, 2, 8, 8)
+    with pytest.raises(RuntimeError, match="GPU"):           # the raw kernel entry points have no CPU path
+        op.fused_bias_act(x, torch.zeros(2), None, 3, 0, 0.2, 1.0)
     with pytest.raises(RuntimeError, match="GPU"):
-        op.fused_leaky_relu(x, torch.zeros(2))
-    with pytest.raises(RuntimeError, match="GPU"):
-        op.upfirdn2d(x, torch.ones(4, 4))
+        op.upfirdn2d_raw(x.reshape(2, 8, 8, 1), torch.ones(4, 4), 1, 1, 1, 1, 0, 0, 0, 0)
     r = VolumeFeatureRenderer(syn.rendering_opt(), mode='test')
     cam = torch.zeros(1, 3, 4)
     with pytest.raises(RuntimeError, match="GPU"):
         r(cam, torch.ones(1, 1, 1), torch.ones(1, 1, 1), torch.ones(1, 1, 1), styles=torch.zeros(1, 9, 256))
+
+
+def test_op_cpu_branches_match_the_reference_vectors():
+    """`op.fused_leaky_relu` / `op.upfirdn2d` accept CPU tensors like the reference's wrappers do (fused_act.py:107-118,
+    upfirdn2d.py:146-200): own plain-torch code, checked against the vectors recorded from the reference, first-order
+    autograd included."""
+    from e3dge_amd import op
+    g = load_golden("upfirdn2d")
+    for name in ('blur_up', 'upsample', 'downsample', 'blur_down', 'k3', 'crop', 'big'):
+        x = torch.from_numpy(g[name + '_x']).requires_grad_(True)
+        cfg = [int(v) for v in g[name + '_cfg']]
+        y = op.upfirdn2d(x, torch.from_numpy(g[name + '_k']), up=cfg[0], down=cfg[1], pad=(cfg[2], cfg[3]))
+        gx, = torch.autograd.grad(y, x, torch.from_numpy(g[name + '_gy']))
+        np.testing.assert_allclose(y.detach().numpy(), g[name + '_y'], atol=2e-6)
+        np.testing.assert_allclose(gx.numpy(), g[name + '_gx'], atol=2e-6)
+    a = load_golden("fused_act")
+    for name in ('conv', 'mapping', 'nobias', 'ragged'):
+        x = torch.from_numpy(a[name + '_x']).requires_grad_(True)
+        b = torch.from_numpy(a[name + '_b']).requires_grad_(True) if name + '_b' in a.files else None
+        y = op.fused_leaky_relu(x, b, 0.2, float(a[name + '_scale']))
+        grads = torch.autograd.grad(y, [x] + ([b] if b is not None else []), torch.from_numpy(a[name + '_gy']))
+        np.testing.assert_allclose(y.detach().numpy(), a[name + '_y'], atol=2e-6)
+        np.testing.assert_allclose(grads[0].numpy(), a[name + '_gx'], atol=2e-6)
+        if b is not None:
+            np.testing.assert_allclose(grads[1].numpy(), a[name + '_gb'], rtol=1e-5, atol=1e-5)
+    m = op.FusedLeakyReLU(3)
+    assert tuple(m(torch.randn(2, 3, 4, 4)).shape) == (2, 3, 4, 4)
+    with pytest.raises(RuntimeError):
+        op.upfirdn2d(torch.zeros(1, 1, 2, 2), torch.ones(4, 4))       # empty output is an error here too
 
 
 def test_unsupported_options_fail_loudly():

@@ -349,6 +349,122 @@ def test_stage1_step_against_reference_golden_gradients():
     assert rel(out['surface_eikonal_term'], g['ref_surface_eikonal_term']) <= 1e-4
 
 
+@pytest.mark.parametrize("mode", ["f16x3", "f32"])
+def test_c5_step_against_reference_golden_gradients(mode):
+    """SURVEY.md 8d's C5 loss, mean(rgb^2) + mean((|eik|-1)^2) + mean(surf_eik^2), recorded from the reference
+    (tests/golden/grads_c5_8x18.npz): its last term reaches the styles also through the integrated surface point, which the
+    reference keeps in the graph (volume_renderer.py:921-930) -- here the Hessian-vector product d_pts of e3dge_siren_bwd
+    chained into the compositing backward.  Also a loss on hit_prob (compositing weights carry grad, cycle_runner.py:134)."""
+    from conftest import load_golden
+    from oracle.training_ref import c5_loss
+    g = load_golden("grads_c5_8x18")
+    res, S = int(g['res']), int(g['n_samples'])
+    sd_ = full_state_dict(res=res, n_samples=S)[1]
+    r = make_renderer(sd_, res, S, mfma_mode=mode)
+    wr, _ = syn.synthetic_inputs(1, seed=int(g['styles_seed']), device=DEV)
+    T = lambda k: torch.from_numpy(g[k]).to(DEV)
+    rel = lambda a, b: float(np.abs(a.detach().cpu().double().numpy() - b).max() / np.abs(b).max())
+
+    def step(loss_fn):
+        styles = wr.clone().requires_grad_(True)
+        out = r(T('poses'), T('focal'), T('near'), T('far'), styles=styles, return_eikonal=True, return_surface_eikonal=True)
+        loss = loss_fn(out)
+        loss.backward()
+        return out, float(loss.detach()), styles.grad
+    out, loss, grad = step(c5_loss)
+    _, loss_h, grad_h = step(lambda o: c5_loss(o) + (o['hit_prob'] * T('g_hit')).mean())
+    _, _, grad_s = step(lambda o: (o['surface_eikonal_term'] ** 2).mean())
+    e = dict(surf_eik_vs_ref=rel(out['surface_eikonal_term'], g['ref_surface_eikonal_term']),
+             loss_rel=abs(loss - float(g['ref_loss'])) / abs(float(g['ref_loss'])),
+             dstyles_vs_ref=rel(grad, g['ref_dstyles']), dstyles_vs_f64=rel(grad, g['f64_dstyles']),
+             ref_dstyles_vs_f64=float(np.abs(g['ref_dstyles'] - g['f64_dstyles']).max() / np.abs(g['f64_dstyles']).max()),
+             loss_hit_rel=abs(loss_h - float(g['ref_loss_hit'])) / abs(float(g['ref_loss_hit'])),
+             dstyles_hit_vs_ref=rel(grad_h, g['ref_dstyles_hit']), dstyles_hit_vs_f64=rel(grad_h, g['f64_dstyles_hit']),
+             surf_only_vs_f64=rel(grad_s, g['f64_dstyles_surf_only']),
+             surf_only_if_xyz_were_detached=rel(grad_s, g['f64_dstyles_surf_only_detached_xyz']))
+    record(f"c5_golden_8x18_{mode}", **e)
+    assert e['surf_eik_vs_ref'] <= 1e-4 and e['loss_rel'] <= 2e-5 and e['loss_hit_rel'] <= 2e-5, e
+    assert e['dstyles_vs_ref'] <= REL_TOL and e['dstyles_vs_f64'] <= max(REL_TOL, 3 * e['ref_dstyles_vs_f64']), e
+    assert e['dstyles_hit_vs_ref'] <= REL_TOL and e['dstyles_hit_vs_f64'] <= max(REL_TOL, 3 * e['ref_dstyles_vs_f64']), e
+    assert e['surf_only_vs_f64'] <= REL_TOL and e['surf_only_if_xyz_were_detached'] > 0.1, e   # the xyz path is really there
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f32"])
+def test_point_gradient_of_queries(sd, mode):
+    """d(loss)/d(pts) of a point query (first-order through sdf / raw, and the Hessian-vector product through the eikonal
+    term) against float64 autograd of the oracle."""
+    r = make_renderer(sd, 8, 18, mfma_mode=mode)
+    wr, _ = syn.synthetic_inputs(2, seed=3, device=DEV)
+    rs = np.random.RandomState(9)
+    n = 333
+    pts = torch.from_numpy((0.1 * rs.uniform(-1, 1, (2, n, 3))).astype(np.float32)).to(DEV)
+    G = torch.from_numpy(rs.normal(size=(2, n, 260)).astype(np.float32)).to(DEV)
+    Ge = torch.from_numpy(rs.normal(size=(2, n, 3)).astype(np.float32)).to(DEV)
+    for with_eik in (False, True):
+        x = pts.clone().requires_grad_(True)
+        styles = wr.clone().requires_grad_(True)
+        if with_eik:
+            sdf, raw, eik = r.siren.query_points(x, None, styles, r.box_scale, want_eikonal=True)
+            ((raw * G).sum() + (eik * Ge).sum() * 1e-2).backward()
+        else:
+            sdf, raw = r.siren.query_points(x, None, styles, r.box_scale)
+            (raw * G).sum().backward()
+        s = wr.detach().cpu().double().requires_grad_(True)
+        xo = pts.detach().cpu().double().requires_grad_(True)
+        raw_o = renderer_ref.query_points(sd, xo, None, s, dtype=torch.float64)
+        lo = (raw_o * G.cpu().double()).sum()
+        if with_eik:
+            eik_o = torch.autograd.grad(raw_o[..., 3:4], xo, torch.ones_like(raw_o[..., 3:4]), create_graph=True)[0]
+            lo = lo + (eik_o * Ge.cpu().double()).sum() * 1e-2
+        lo.backward()
+        e = dict(d_pts=rel_err(x.grad, xo.grad), d_styles=rel_err(styles.grad, s.grad))
+        record(f"point_gradient_{mode}_eik{int(with_eik)}", **e)
+        assert e['d_pts'] <= REL_TOL and e['d_styles'] <= REL_TOL, e
+    # points only (styles without grad): the same d_pts
+    x = pts.clone().requires_grad_(True)
+    sdf, raw = r.siren.query_points(x, None, wr, r.box_scale)
+    (raw * G).sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f32"])
+def test_tex_pass_backward_vs_oracle_autograd(sd, mode):
+    """Second (texture-FiLM) pass under grad: gradients w.r.t. the styles and the per-point (alpha, beta) against float64
+    autograd of the oracle (stage-2 training differentiates this pass, e3dge_full_runner.py:185-317)."""
+    from e3dge_amd.camera_utils import generate_camera_params
+    res, S = 8, 24
+    sd_ = full_state_dict(res=res, n_samples=S)[1]
+    r = make_renderer(sd_, res, S, mfma_mode=mode, enable_local_model=True)
+    wr, _ = syn.synthetic_inputs(1, seed=6, device=DEV)
+    poses, focal, near, far, _ = generate_camera_params(res, DEV, locations=torch.tensor([[0.15, -0.1]], device=DEV))
+    ta, tb = syn.synthetic_tex_conditions(1, res, S)
+    rs = np.random.RandomState(2)
+    g_feat = torch.from_numpy(rs.normal(size=(1, 256, res, res)).astype(np.float32))
+    g_rgb = torch.from_numpy(rs.normal(size=(1, 3, res, res)).astype(np.float32))
+
+    def loss_of(o, dt, dev):
+        return ((o['features'] * g_feat.to(dev, dt)).mean() + (o['gen_thumb_imgs'] * g_rgb.to(dev, dt)).mean()
+                + (o['depth'] ** 2).mean() + (o['sdf'] ** 2).mean())
+    styles = wr.clone().requires_grad_(True)
+    a_, b_ = ta.to(DEV).requires_grad_(True), tb.to(DEV).requires_grad_(True)
+    out = r(poses, focal, near, far, styles=styles, local_data_batch={'tex': (a_, b_)})
+    loss_of(out, torch.float32, DEV).backward()
+    c = lambda t: t.detach().cpu()
+    res_ = {}
+    for dt in (torch.float64, torch.float32):
+        s = c(wr).to(dt).requires_grad_(True)
+        ao, bo = ta.to(dt).requires_grad_(True), tb.to(dt).requires_grad_(True)
+        ro = renderer_ref.render(sd_, c(poses), c(focal), c(near), c(far), s, res=res, n_samples=S, tex=(ao, bo), dtype=dt)
+        loss_of(ro, dt, 'cpu').backward()
+        res_[dt] = (s.grad, ao.grad, bo.grad)
+    t64, t32 = res_[torch.float64], res_[torch.float32]
+    e = dict(d_styles=rel_err(styles.grad, t64[0]), d_alpha=rel_err(a_.grad, t64[1]), d_beta=rel_err(b_.grad, t64[2]),
+             oracle32_d_styles=rel_err(t32[0], t64[0]), oracle32_d_alpha=rel_err(t32[1], t64[1]))
+    record(f"tex_pass_backward_{mode}", **e)
+    assert e['d_styles'] <= max(REL_TOL, 3 * e['oracle32_d_styles']), e
+    assert e['d_alpha'] <= max(REL_TOL, 3 * e['oracle32_d_alpha']) and e['d_beta'] <= max(REL_TOL, 3 * e['oracle32_d_alpha']), e
+
+
 @pytest.mark.parametrize("scale", [1e-18, 1.0, 1e+12])
 def test_backward_block_scaling_is_scale_invariant(sd, scale):
     """The split-f16 backward scales every gradient column by a power of two: the relative error must not depend on

@@ -48,6 +48,7 @@ def make_renderer(sd, res, S, mfma_mode=None, **over):
         src = 'renderer.' + (k.replace('network.netGlobal.', 'network.') if pre != 'network.' else k)
         own[k] = sd[src]
     r.load_state_dict(own)
+    r.requires_grad_(False)        # frozen generator, as in encoder training (trainer.py:1568): gradients go to the styles
     return r.to(DEV)
 
 
@@ -211,19 +212,62 @@ def test_ragged_and_tiny_extents(sd):
     assert empty.numel() == 0
 
 
-def test_f16x3_weight_range_is_checked(sd):
-    """The split-f16 weight image holds 128*w as f16: weights beyond its range are refused loudly, the fp32 kernel
-    still serves them."""
+def test_f16x3_weight_range_falls_back_to_fp32(sd):
+    """The split-f16 weight image holds 128*w as f16: a module whose weights exceed that range is served by the fp32 MFMA
+    kernel automatically (one warning), with the same parity."""
     r = make_renderer(sd, 8, 18, mfma_mode="f16x3")
     wr, _ = syn.synthetic_inputs(1, seed=1, device=DEV)
     poses, focal, near, far, _ = generate_camera_params(8, DEV, locations=torch.zeros(1, 2, device=DEV))
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2['renderer.network.pts_linears.3.weight'][5, 7] = 300.0
     with torch.no_grad():
         r.siren.pts_linears[3].weight[5, 7] = 300.0
-        with pytest.raises(RuntimeError, match="f16x3"):
-            r(poses, focal, near, far, styles=wr)
-        r.siren.mfma_mode = "f32"
-        out = r(poses, focal, near, far, styles=wr)
+        with pytest.warns(UserWarning, match="fp32 MFMA"):
+            out = r(poses, focal, near, far, styles=wr)
+        c = lambda t: t.detach().cpu()
+        ref = renderer_ref.render(sd2, c(poses), c(focal), c(near), c(far), c(wr), res=8, n_samples=18)
     assert torch.isfinite(out['features']).all()
+    assert maxerr(out['features'], ref['features']) <= 1e-4 and maxerr(out['sdf'], ref['sdf']) <= 1e-5
+
+
+def test_weight_cache_sees_updates_and_invalidate(sd):
+    """The packed weight image follows parameter updates: in-place ops on the parameter are detected through its version
+    counter; writes through `.data` (the reference's EMA accumulate(), utils/training_utils.py:45) are not, and need
+    renderer.invalidate() -- after which the output changes."""
+    r = make_renderer(sd, 8, 18)
+    wr, _ = syn.synthetic_inputs(1, seed=1, device=DEV)
+    poses, focal, near, far, _ = generate_camera_params(8, DEV, locations=torch.zeros(1, 2, device=DEV))
+    with torch.no_grad():
+        base = r(poses, focal, near, far, styles=wr)['features'].clone()
+        r.siren.pts_linears[2].weight.mul_(1.01)                         # versioned in-place update
+        v1 = r(poses, focal, near, far, styles=wr)['features'].clone()
+        assert not torch.equal(base, v1)
+        r.siren.pts_linears[2].weight.data.mul_(1.01)                    # bypasses the version counter
+        r.sigmoid_beta.data.mul_(1.5)
+        r.invalidate()
+        v2 = r(poses, focal, near, far, styles=wr)
+        assert not torch.equal(v1, v2['features'])
+        sd2 = {k: v.clone() for k, v in sd.items()}
+        sd2['renderer.network.pts_linears.2.weight'] *= 1.01 * 1.01
+        sd2['renderer.sigmoid_beta'] *= 1.5
+        c = lambda t: t.detach().cpu()
+        ref = renderer_ref.render(sd2, c(poses), c(focal), c(near), c(far), c(wr), res=8, n_samples=18)
+    assert maxerr(v2['features'], ref['features']) <= 1e-4 and maxerr(v2['hit_prob'], ref['hit_prob']) <= 4e-6
+
+
+def test_grad_to_renderer_weights_is_refused(sd):
+    """Under grad mode with trainable SIREN parameters the reference would train them; the HIP backward does not, and says so."""
+    r = make_renderer(sd, 8, 18)
+    wr, _ = syn.synthetic_inputs(1, seed=1, device=DEV)
+    poses, focal, near, far, _ = generate_camera_params(8, DEV, locations=torch.zeros(1, 2, device=DEV))
+    for p_ in r.parameters():
+        p_.requires_grad_(True)
+    with pytest.raises(NotImplementedError, match="frozen"):
+        r(poses, focal, near, far, styles=wr.clone().requires_grad_(True))
+    for p_ in r.parameters():
+        p_.requires_grad_(False)
+    out = r(poses, focal, near, far, styles=wr.clone().requires_grad_(True), sample_without_grad=True)
+    assert not out['features'].requires_grad                              # :1291-1294: detached outputs
 
 
 def test_sample_mode_pseudo_ground_truth(sd):

@@ -82,8 +82,28 @@ def test_texhead_input_magnitude(mag):
         assert torch.equal(*[h.tex_modulations(feats)[0] for _ in range(2)])
         empty = h.tex_modulations(torch.empty(0, 301, device=DEV))
     assert empty[0].shape == (0, 256)
-    with pytest.raises(NotImplementedError):            # no silent autograd gap
-        h.tex_modulations(feats)
+
+
+def test_texhead_backward_against_f64_autograd():
+    """Stage-2 training differentiates the texture head (e3dge_full_runner.py:185-317): gradients w.r.t. the local features
+    and the five parameters against float64 autograd of the oracle.  Tolerance: 2e-5 of each gradient's maximum."""
+    h, sd = make_head(301)
+    rs = np.random.RandomState(5)
+    feats = torch.from_numpy(rs.standard_normal((515, 301)).astype(np.float32)).to(DEV).requires_grad_(True)
+    ga = torch.from_numpy(rs.standard_normal((515, 256)).astype(np.float32)).to(DEV)
+    gb = torch.from_numpy(rs.standard_normal((515, 256)).astype(np.float32)).to(DEV)
+    a, b = h.tex_modulations(feats)
+    ((a * ga).sum() + (b * gb).sum()).backward()
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    f64 = feats.detach().cpu().double().requires_grad_(True)
+    ta, tb = renderer_ref.tex_modulations(sd64, PREFIX, f64, dtype=torch.float64)
+    ((ta * ga.cpu().double()).sum() + (tb * gb.cpu().double()).sum()).backward()
+    errs = {'feats': float((feats.grad.cpu().double() - f64.grad).abs().max() / f64.grad.abs().max())}
+    for name, p_ in h.named_parameters():
+        t = sd64[PREFIX + name].grad
+        errs[name] = float((p_.grad.cpu().double() - t).abs().max() / t.abs().max())
+    record("texhead_backward", **errs)
+    assert max(errs.values()) <= 2e-5, errs
 
 
 def test_second_pass_from_local_feats():

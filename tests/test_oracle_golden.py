@@ -165,6 +165,28 @@ def test_training_direction_restatement_matches_reference_gradients():
     assert rel <= 1e-6, rel
 
 
+def test_c5_restatement_matches_reference_gradients():
+    """SURVEY.md 8d's C5 loss with the surface normal at the integrated point kept in the graph (:921-930) and a loss on
+    hit_prob: the restatement's autograd against the reference's recorded step (tests/golden/grads_c5_8x18.npz)."""
+    from oracle.training_ref import c5_loss, restated_c5
+    g = load_golden("grads_c5_8x18")
+    sd = full_state_dict(res=int(g['res']), n_samples=int(g['n_samples']))[1]
+    wr, _ = syn.synthetic_inputs(1, seed=int(g['styles_seed']))
+    T = torch.from_numpy
+    for key, extra in (('', None), ('_hit', T(g['g_hit']))):
+        s = wr.clone().requires_grad_(True)
+        o = restated_c5(sd, T(g['poses']), T(g['focal']), T(g['near']), T(g['far']), s, int(g['res']), int(g['n_samples']), torch.float32)
+        loss = c5_loss(o) if extra is None else c5_loss(o) + (o['hit_prob'] * extra).mean()
+        loss.backward()
+        assert abs(float(loss) - float(g['ref_loss' + key])) <= 1e-6 * abs(float(g['ref_loss' + key]))
+        rel = np.abs(s.grad.numpy() - g['ref_dstyles' + key]).max() / np.abs(g['ref_dstyles' + key]).max()
+        assert rel <= 5e-6, rel
+    assert np.abs(o['surface_eikonal_term'].detach().numpy() - g['ref_surface_eikonal_term']).max() <= 1e-6
+    # the path through the surface point is a large part of that term's gradient: detaching xyz changes it by ~50 %
+    d = np.abs(g['f64_dstyles_surf_only'] - g['f64_dstyles_surf_only_detached_xyz']).max() / np.abs(g['f64_dstyles_surf_only']).max()
+    assert d > 0.1
+
+
 def test_texhead_restatement_matches_reference_class():
     """oracle/renderer_ref.tex_modulations against the vectors recorded from the reference's ResnetBlockFC
     (oracle/gen_golden_texhead.py)."""

@@ -15,6 +15,7 @@ dev, res, S = "cuda:0", 64, 24
 r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S), out_im_res=res, mode='test')
 syn.load_synthetic(r, prefix='renderer.')
 r = r.to(dev)
+r.requires_grad_(False)
 wr, _ = syn.synthetic_inputs(1, seed=7, device=dev)
 poses, focal, near, far, _ = generate_camera_params(res, dev)
 film = r.siren.film_params(wr)

@@ -18,6 +18,7 @@ res, S = 64, 24
 r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S), out_im_res=res, mode='test')
 syn.load_synthetic(r, prefix='renderer.')
 r = r.to(dev)
+r.requires_grad_(False)
 wr, _ = syn.synthetic_inputs(batch, seed=7, device=dev)
 poses, focal, near, far, _ = generate_camera_params(res, dev, batch=batch)
 G = torch.randn(batch, 256, res, res, device=dev)
