@@ -2,224 +2,390 @@
 """bench.py -- the BASELINE.json metric on MI355X: rendered rays/s at 64x64 rays x 24 samples.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W
+
+`--gpus N` with N > 1 starts the N ranks itself (one process per GPU through torch.distributed.run, rendezvous on
+127.0.0.1) when it was not already launched by torchrun, and fails loudly if fewer than N GPUs are visible; when the driver
+launches it (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) RANK / LOCAL_RANK / WORLD_SIZE
+come from the environment as usual.
 
 One step = one pass of the hot path over one batch of synthetic input on every rank: W+ codes -> FiLM parameters
 (e3dge_film_params) -> fused ray generation + SIREN + compositing (e3dge_siren_render_fwd) for ONE 64x64 image
 x 24 samples per GPU (BASELINE.json configs[1]; inputs already resident in HBM).  Images shard across ranks
 with no data-path collective (weak scaling); `value` = rays rendered by all ranks / max-over-ranks time.
 
-Extra objects on the JSON line:
-  roofline      dominant kernel (siren_kernel<0>): algorithmic fp32 FLOPs per launch / its mean duration measured
-                with HIP events on the launch stream inside the timed region, against the dense fp32 MFMA peak.
-  cpu_baseline  the oracle restatement (oracle/renderer_ref.py, "port": it is bit-identical to the reference's
-                PyTorch path on the golden vectors) timed on this host's cores on a bounded sample.
-  c4_render_ms       (informational) one pose of the C4 sweep: 128x128 rays x 48 samples.
-  train_step_ms      (informational) stage-1 training step of the renderer at 64x64x18 with eikonal terms, fwd + bwd.
-  inversion_fwd_ms   (informational) pass #1 + texture head + pass #2 with texture FiLM + decoder to 1024^2, one image.
+Extra objects on the JSON line (DESIGN.md 5):
+  roofline      dominant kernel of the headline (default) mode: algorithmic FLOPs per launch / its mean duration measured
+                with HIP events on the launch stream inside the timed region.
+  modes         the same K-step measurement for BOTH contraction modes, f16x3 (default) and strict f32.
+  sustained     the K-step block repeated for >= 1 s: median and spread of rays/s (the K-step line alone is ~0.1 s).
+  c3            BASELINE configs[2]: per-image evaluation (pass #1, texture head, pass #2, decoder 64^2 -> 1024^2, 8 metric
+                scalars) sharded over the ranks with one all_gather of the metric rows.
+  c4            BASELINE configs[3]: the 120-pose sweep at 128x128x48, sequential and batched 8 poses per launch.
+  train_step_ms BASELINE configs[4], renderer part: stage-1 step at 64x64x18 with the eikonal losses, fwd + bwd.
+  inversion_fwd_ms  pass #1 + texture head + pass #2 + decoder to 1024^2, one image.
+  cpu_baseline  the oracle restatement (oracle/renderer_ref.py, "port": bit-identical to the reference's PyTorch path on
+                the golden vectors) timed on this host's cores on a bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 RES, N_SAMPLES = 64, 24
-# HBM traffic of one 64x64x24 render launch measured with PMC counters (profiles/*_pmc.txt): KB -> bytes
-TRAFFIC_BYTES_PER_LAUNCH = {"f32": int((2 * 8781.6 + 6688) * 1024), "f16x3": int((2 * 10343 + 13191.6) * 1024)}
 MAC_PER_POINT = 3 * 256 + 7 * 256 * 256 + 259 * 256 + 256 * 3 + 256       # 526,848 (SURVEY.md 8d)
 FLOP_PER_RAY = 2 * MAC_PER_POINT * N_SAMPLES                               # 25.29 MFLOP
 BYTES_PER_RAY = (264 + 5 * N_SAMPLES) * 4                                  # mandatory outputs, 1,536 B
 PEAK_F32_MFMA_TFLOPS = 157.3                                               # MI355X_MICROARCH.md (dense fp32 MFMA)
 PEAK_F16_MFMA_TFLOPS = 2500.0                                              # dense f16 / bf16 MFMA (NOT the 2:1-sparse figure)
+TRAFFIC_FILE = os.path.join(REPO, "profiles", "traffic_pmc.json")          # written by tools/profile_bench.sh (PMC passes)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (metric config: 1)")
+    ap.add_argument("--c3-images", type=int, default=16, help="images per rank in the C3 leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inversion", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
     ap.add_argument("--no-c4", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-c3", action="store_true")
+    ap.add_argument("--no-modes", action="store_true")
+    ap.add_argument("--no-sustained", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="only the K-step headline measurement (profiling runs)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous check only (gloo, no GPU work): prints the number of ranks that joined")
+    return ap.parse_args()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without torchrun: start the N ranks here.  Returns the children's exit code."""
+    if not args.dry_run:
+        import torch
+        n_vis = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_vis < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_vis} GPU(s) visible on this node")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["E3DGE_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline = args.no_inversion = args.no_train_step = args.no_c4 = args.no_c3 = True
+        args.no_modes = args.no_sustained = True
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or let bench.py start them)")
+
+    import torch
+    dist = None
+    if args.dry_run:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_joined": int(t.item()),
+                              "self_launched": os.environ.get("E3DGE_BENCH_SELF_LAUNCHED") == "1"}))
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
+    ranks_joined = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t)
+        ranks_joined = int(t.item())
+        if ranks_joined != world:
+            raise SystemExit(f"{ranks_joined} ranks joined the RCCL group, expected {world}")
 
     import e3dge_amd  # noqa: F401
-    from e3dge_amd import synthetic as syn
+    from e3dge_amd import sharded_eval, synthetic as syn
     from e3dge_amd.camera_utils import generate_camera_params
     from e3dge_amd.stylesdf_model import G_pred_latents
+    from e3dge_amd.volume_renderer import VolumeFeatureRenderer
 
     g = G_pred_latents(syn.model_opt(), syn.rendering_opt(N_samples=N_SAMPLES), full_pipeline=True)
     syn.load_synthetic(g)
-    sd_cpu = {k: v.clone() for k, v in g.state_dict().items()} if rank == 0 else None
+    sd_cpu = {k: v.clone() for k, v in g.state_dict().items()}
     g = g.to(dev).eval()
+    g.requires_grad_(False)
     renderer = g.renderer
     B = args.batch
     wr, wd = syn.synthetic_inputs(B, seed=1 + 17 * rank, device=dev)      # every rank renders its own image(s)
     poses, focal, near, far, _ = generate_camera_params(RES, dev, locations=torch.zeros(B, 2, device=dev))
     renderer.siren.device_image()                                          # weight image packed once, outside the loop
-
-    def step():
-        film = renderer.siren.film_params(wr)
-        return film
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    default_mode = renderer.siren.mfma_mode
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            renderer.render_with_film(step(), focal, poses, near, far)
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed_block(steps, with_events):
+        """K steps between barriers; returns (elapsed_s max over ranks, mean kernel ms or None, last output)."""
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if with_events else None
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            film = step()
-            ev[i][0].record()                                              # same stream the kernel is launched on
+        out = None
+        for i in range(steps):
+            film = renderer.siren.film_params(wr)
+            if ev:
+                ev[i][0].record()                                          # same stream the kernel is launched on
             out = renderer.render_with_film(film, focal, poses, near, far)
-            ev[i][1].record()
+            if ev:
+                ev[i][1].record()
         barrier()
-        elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
-    assert torch.isfinite(out['gen_thumb_imgs']).all()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(steps, 1) if ev else None
+        return elapsed, kern_ms, out
 
-    rays_per_step = B * RES * RES * world
-    value = rays_per_step * args.steps / elapsed
-    result = {
-        "metric": "rendered_rays_per_sec_64x64x24", "value": value, "unit": "rays/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C2: single-image W+ -> volume render, 64x64 rays x 24 samples per ray, "
-                               f"{B} image(s) per GPU per step (film_params + fused render launch)",
-                   "rays_per_gpu_per_step": B * RES * RES, "samples_per_ray": N_SAMPLES, "parallelism": f"images sharded x{world}"},
-    }
-    mode = renderer.siren.mfma_mode
-    result["dtype"] = "f32" if mode == "f32" else "f32 (operands split f16 hi+lo, 3 f16 MFMA products, fp32 accumulate)"
-    result["config"]["mfma_mode"] = mode
-    if rank == 0:
+    def roofline_of(mode, kern_ms):
         flops = FLOP_PER_RAY * B * RES * RES                    # ALGORITHMIC flops (one fp32 multiply-add per weight per point)
         achieved = flops / (kern_ms * 1e-3) / 1e12
         if mode == "f32":
             peak, note = PEAK_F32_MFMA_TFLOPS, "dense fp32 MFMA peak"
         else:   # every algorithmic product costs three f16 MFMA products
             peak, note = PEAK_F16_MFMA_TFLOPS / 3.0, "dense f16 MFMA peak / 3 (the split needs 3 f16 products per fp32-accurate product)"
-        result["roofline"] = {"bound": "mfma", "kernel": f"siren_kernel<0,{int(mode != 'f32')}> (e3dge_siren_render_fwd, {mode})",
-                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": note,
-                              "achieved_over_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
-                              "kernel_ms": kern_ms, "flop_per_launch": flops,
-                              "algorithmic_output_bytes_per_launch": BYTES_PER_RAY * B * RES * RES,
-                              "hbm_frac_of_8TBps": BYTES_PER_RAY * B * RES * RES / (kern_ms * 1e-3) / 8e12,
-                              "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(mode) if B == 1 else None,
-                              "traffic_note": "PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch, separate rocprofv3 --pmc passes, see profiles/"}
+        traffic, tnote = None, f"no {os.path.relpath(TRAFFIC_FILE, REPO)}"
+        try:
+            with open(TRAFFIC_FILE) as f:
+                tj = json.load(f)
+            ent = tj.get(mode)
+            if ent and B == 1:
+                traffic = int(2 * ent["FETCH_SIZE_KB"] * 1024 + ent["WRITE_SIZE_KB"] * 1024)
+                tnote = (f"NOT measured in this run: PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch from "
+                         f"{os.path.relpath(TRAFFIC_FILE, REPO)} ({tj.get('source', 'separate rocprofv3 --pmc passes')})")
+        except (OSError, ValueError, KeyError):
+            pass
+        return {"bound": "mfma", "kernel": f"siren_kernel<0,{int(mode != 'f32')}> (e3dge_siren_render_fwd, {mode})",
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": note,
+                "achieved_over_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "kernel_ms": kern_ms, "flop_per_launch": flops,
+                "algorithmic_output_bytes_per_launch": BYTES_PER_RAY * B * RES * RES,
+                "hbm_frac_of_8TBps": BYTES_PER_RAY * B * RES * RES / (kern_ms * 1e-3) / 8e12,
+                "traffic": traffic, "traffic_note": tnote}
 
-    # ---------------------------------------------------------------- informational: full inversion forward, one image
+    rays_per_step = B * RES * RES * world
+    dtype_of = lambda m: "f32" if m == "f32" else "f32 (operands split f16 hi+lo, 3 f16 MFMA products, fp32 accumulate)"
+
+    # ---------------------------------------------------------------- headline: W warm-up steps, exactly K timed steps
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            renderer.render_with_film(renderer.siren.film_params(wr), focal, poses, near, far)
+        elapsed, kern_ms, out = timed_block(args.steps, True)
+    assert torch.isfinite(out['gen_thumb_imgs']).all()
+    value = rays_per_step * args.steps / elapsed
+    result = {
+        "metric": "rendered_rays_per_sec_64x64x24", "value": value, "unit": "rays/s", "n_gpus": world, "ranks_joined": ranks_joined,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_of(default_mode), "data": "synthetic",
+        "config": {"workload": "C2: single-image W+ -> volume render, 64x64 rays x 24 samples per ray, "
+                               f"{B} image(s) per GPU per step (film_params + fused render launch)",
+                   "rays_per_gpu_per_step": B * RES * RES, "samples_per_ray": N_SAMPLES, "parallelism": f"images sharded x{world}",
+                   "mfma_mode": default_mode},
+    }
+    if rank == 0:
+        result["roofline"] = roofline_of(default_mode, kern_ms)
+
+    # ---------------------------------------------------------------- sustained: repeat the K-step block for >= 1 s
+    if not args.no_sustained:
+        blocks, t_start = [], time.perf_counter()
+        with torch.no_grad():
+            while True:
+                e, _, _ = timed_block(args.steps, False)
+                blocks.append(rays_per_step * args.steps / e)
+                done = max_over_ranks(time.perf_counter() - t_start)       # same decision on every rank
+                if done >= 1.0 and len(blocks) >= 3 or len(blocks) >= 200:
+                    break
+        result["sustained"] = {"blocks": len(blocks), "steps_per_block": args.steps, "seconds": done,
+                               "median_rays_per_s": statistics.median(blocks), "min_rays_per_s": min(blocks),
+                               "max_rays_per_s": max(blocks),
+                               "spread_frac": (max(blocks) - min(blocks)) / statistics.median(blocks)}
+
+    # ---------------------------------------------------------------- both contraction modes, same K-step measurement
+    if not args.no_modes:
+        modes = {}
+        for mode in ("f16x3", "f32"):
+            if mode == default_mode:
+                e_m, k_m = elapsed, kern_ms
+            else:
+                renderer.siren.mfma_mode = mode
+                with torch.no_grad():
+                    for _ in range(max(3, args.warmup // 4)):
+                        renderer.render_with_film(renderer.siren.film_params(wr), focal, poses, near, far)
+                    e_m, k_m, _ = timed_block(args.steps, True)
+                renderer.siren.mfma_mode = default_mode
+            rf = roofline_of(mode, k_m)
+            modes[mode] = {"value": rays_per_step * args.steps / e_m, "unit": "rays/s", "ms_per_step": 1e3 * e_m / args.steps,
+                           "kernel_ms": k_m, "dtype": dtype_of(mode), "achieved_tflops": rf["achieved"], "peak_tflops": rf["peak"],
+                           "frac": rf["frac"], "traffic": rf["traffic"]}
+        result["modes"] = modes
+
+    # ---------------------------------------------------------------- C3: per-image evaluation sharded over the ranks
+    gl = None
+    need_local = (not args.no_c3) or (rank == 0 and not args.no_inversion)
+    if need_local:
+        gl = G_pred_latents(syn.model_opt(), syn.rendering_opt(N_samples=N_SAMPLES, enable_local_model=True,
+                                                               L_pred_tex_modulations=True), full_pipeline=True)
+        sd_l = {k.replace('renderer.network.', 'renderer.network.netGlobal.'): v for k, v in sd_cpu.items()}
+        for k, v in gl.state_dict().items():
+            if '.netLocal.' in k:                 # texture head: small synthetic weights (the reference zero-inits it)
+                sd_l[k] = 0.05 * syn.synthetic_tensor(k, v.shape)
+        gl.load_state_dict(sd_l)
+        gl = gl.to(dev).eval()
+        gl.requires_grad_(False)
+        p1, f1, n1, fa1, _ = generate_camera_params(RES, dev, locations=torch.zeros(1, 2, device=dev))
+        feats = syn.synthetic_local_feats(1, RES, N_SAMPLES, device=dev)      # what the PIFu branch would deliver
+        target = torch.tanh(torch.randn(1, 3, 1024, 1024, device=dev, generator=torch.Generator(device=dev).manual_seed(7)))
+
+        def inversion(w_r, w_d):
+            gl([w_r, w_d], p1, f1, n1, fa1, input_is_latent=True, sample_with_renderer=True)       # pass #1
+            return gl([w_r, w_d], p1, f1, n1, fa1, input_is_latent=True, randomize_noise=False,
+                      local_data_batch={'feats': feats})                    # tex head + pass #2 + decoder
+
+    if not args.no_c3:
+        try:
+            n_units = args.c3_images * world
+            codes = [syn.synthetic_inputs(1, seed=1000 + i, device=dev) for i in sharded_eval.shard_indices(n_units, rank, world)]
+            mine = dict(zip(sharded_eval.shard_indices(n_units, rank, world), codes))
+
+            def unit(i):
+                w_r, w_d = mine[i]
+                o = inversion(w_r, w_d)
+                return sharded_eval.image_metrics(o['gen_imgs'], target)
+            with torch.no_grad():
+                for i in list(mine)[:2]:
+                    unit(i)
+                barrier()
+                t0 = time.perf_counter()
+                table = sharded_eval.evaluate_sharded(unit, n_units, rank, world, device=dev)   # one all_gather at the end
+                barrier()
+                e3 = max_over_ranks(time.perf_counter() - t0)
+            assert tuple(table.shape) == (n_units, 8) and torch.isfinite(table).all()
+            result["c3"] = {"images": n_units, "images_per_rank": args.c3_images, "images_per_s": n_units / e3,
+                            "ms_per_image_per_gpu": 1e3 * e3 / args.c3_images, "mean_psnr": float(table[:, 5].mean()),
+                            "mean_ssim": float(table[:, 6].mean()),
+                            "note": "BASELINE configs[2]: per image pass #1 render + texture head on (64,64,24,301) local features + "
+                                    "pass #2 render + decoder 64^2->1024^2 (cm=2) + 8 metric scalars (ArcFace / LPIPS terms need "
+                                    "pretrained nets: reported as 0); images i -> rank i mod W, one all_gather of the (n,8) rows"}
+        except Exception as exc:  # the headline metric must still be printed
+            result["c3"] = {"failed": f"{type(exc).__name__}: {exc}"}
+
+    # ---------------------------------------------------------------- full inversion forward, one image
     if rank == 0 and not args.no_inversion:
         try:
             with torch.no_grad():
-                gl = G_pred_latents(syn.model_opt(), syn.rendering_opt(N_samples=N_SAMPLES, enable_local_model=True,
-                                                                       L_pred_tex_modulations=True), full_pipeline=True)
-                sd_l = {k.replace('renderer.network.', 'renderer.network.netGlobal.'): v for k, v in sd_cpu.items()}
-                for k, v in gl.state_dict().items():
-                    if '.netLocal.' in k:                 # texture head: small synthetic weights (the reference zero-inits it)
-                        sd_l[k] = 0.05 * syn.synthetic_tensor(k, v.shape)
-                gl.load_state_dict(sd_l)
-                gl = gl.to(dev).eval()
                 w1, d1 = syn.synthetic_inputs(1, seed=1, device=dev)
-                p1, f1, n1, fa1, _ = generate_camera_params(RES, dev, locations=torch.zeros(1, 2, device=dev))
-                feats = syn.synthetic_local_feats(1, RES, N_SAMPLES, device=dev)      # what the PIFu branch would deliver
-
-                def inversion():
-                    gl([w1, d1], p1, f1, n1, fa1, input_is_latent=True, sample_with_renderer=True)       # pass #1
-                    return gl([w1, d1], p1, f1, n1, fa1, input_is_latent=True, randomize_noise=False,
-                              local_data_batch={'feats': feats})                  # tex head + pass #2 + decoder
                 for _ in range(3):
-                    inversion()
+                    inversion(w1, d1)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 n_inv = 10
                 for _ in range(n_inv):
-                    o = inversion()
+                    o = inversion(w1, d1)
                 torch.cuda.synchronize()
                 result["inversion_fwd_ms"] = 1e3 * (time.perf_counter() - t1) / n_inv
                 result["inversion_fwd_note"] = ("pass#1 render + texture head on (64,64,24,301) local features + pass#2 render with the "
                                                 "resulting texture FiLM + decoder 64^2->1024^2; encoder and the local branch's image "
-                                                "filters / feature query excluded (out of scope)")
+                                                "filters excluded (out of scope)")
                 assert tuple(o['gen_imgs'].shape) == (1, 3, 1024, 1024)
-            del gl
-        except Exception as exc:  # the headline metric must still be printed
+        except Exception as exc:
             result["inversion_fwd_ms"] = None
             result["inversion_fwd_note"] = f"failed: {type(exc).__name__}: {exc}"
+    del gl
 
-    # ---------------------------------------------------------------- informational: C4 (128x128 rays x 48 samples), one pose
+    # ---------------------------------------------------------------- C4: the 120-pose sweep at 128x128 rays x 48 samples
     if rank == 0 and not args.no_c4:
         try:
-            from e3dge_amd.volume_renderer import VolumeFeatureRenderer
+            import math
             r4 = VolumeFeatureRenderer(syn.rendering_opt(N_samples=48), out_im_res=128, mode='test')
             r4.load_state_dict(renderer.state_dict())
             r4 = r4.to(dev)
             w4, _ = syn.synthetic_inputs(1, seed=1, device=dev)
-            p4, f4, n4, fa4, _ = generate_camera_params(128, dev, locations=torch.tensor([[0.45, 0.0]], device=dev))
+            n_pose = 120                                                   # trainer.py:2349-2388: azim_k = 0.45 cos(pi k / 119)
+            traj = torch.tensor([[0.45 * math.cos(math.pi * k / (n_pose - 1)), 0.0] for k in range(n_pose)], device=dev)
+            p4, f4, n4, fa4, _ = generate_camera_params(128, dev, locations=traj)
+
+            def sweep(bsz):
+                wb = w4.expand(bsz, -1, -1).contiguous()
+                film = r4.siren.film_params(wb)                           # one latent for the whole sweep
+                for k in range(0, n_pose, bsz):
+                    o = r4.render_with_film(film[:min(bsz, n_pose - k)], f4[k:k + bsz], p4[k:k + bsz], n4[k:k + bsz], fa4[k:k + bsz])
+                return o
+            c4 = {}
             with torch.no_grad():
-                for _ in range(3):
-                    r4.render(f4, p4, n4, fa4, w4)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda.synchronize()
-                e0.record()
-                for _ in range(10):
-                    r4.render(f4, p4, n4, fa4, w4)
-                e1.record()
-                torch.cuda.synchronize()
-            ms4 = e0.elapsed_time(e1) / 10
-            result["c4_render_ms"] = ms4
-            result["c4_rays_per_sec"] = 128 * 128 / ms4 * 1e3
-            result["c4_algorithmic_tflops"] = 2 * MAC_PER_POINT * 48 * 128 * 128 / (ms4 * 1e-3) / 1e12
-            result["c4_note"] = "BASELINE configs[3]: one pose of the 120-pose sweep, 128x128 rays x 48 samples (786,432 points), film_params + render"
+                for label, bsz in (("sequential", 1), ("batched8", 8)):
+                    sweep(bsz)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    sweep(bsz)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1)
+                    c4[label] = {"total_ms": ms, "ms_per_pose": ms / n_pose, "rays_per_s": n_pose * 128 * 128 / ms * 1e3,
+                                 "algorithmic_tflops": 2 * MAC_PER_POINT * 48 * 128 * 128 * n_pose / (ms * 1e-3) / 1e12}
+            c4["note"] = "BASELINE configs[3]: 120 camera poses of one latent, 128x128 rays x 48 samples (786,432 points per pose)"
+            result["c4"] = c4
             del r4
         except Exception as exc:
-            result["c4_render_ms"] = None
-            result["c4_note"] = f"failed: {type(exc).__name__}: {exc}"
+            result["c4"] = {"failed": f"{type(exc).__name__}: {exc}"}
 
-    # ---------------------------------------------------------------- informational: stage-1 training step of the renderer (C5)
+    # ---------------------------------------------------------------- C5: stage-1 training step of the renderer
     if rank == 0 and not args.no_train_step:
         try:
-            from e3dge_amd.volume_renderer import VolumeFeatureRenderer
             S5 = 18                                                    # scripts/train/ffhq/stage1.sh
             r5 = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S5), out_im_res=RES, mode='test')
             r5.load_state_dict(renderer.state_dict())
             r5 = r5.to(dev)
-            for p_ in r5.parameters():
-                p_.requires_grad_(False)                               # frozen generator, gradient to the styles only
+            r5.requires_grad_(False)                                   # frozen generator, gradient to the styles only
             w5, _ = syn.synthetic_inputs(1, seed=1, device=dev)
             p5, f5, n5, fa5, _ = generate_camera_params(RES, dev, locations=torch.zeros(1, 2, device=dev))
 
@@ -245,8 +411,9 @@ def main():
             result["train_step_ms"] = ms
             result["train_step_rays_per_sec"] = RES * RES / ms * 1e3
             result["train_step_note"] = ("C5 renderer part, 1 image 64x64x18: forward saving arguments + eikonal term (sdf chain) + "
-                                         "surface normals, loss = mean(rgb^2) + mean((|eik|-1)^2) + mean(surf_eik^2), backward to the "
-                                         "styles incl. the double backward (tangent + second-order chain); fp32 MFMA backward")
+                                         "surface normals at the integrated point (kept in the graph), loss = mean(rgb^2) + "
+                                         "mean((|eik|-1)^2) + mean(surf_eik^2), backward to the styles incl. the double backward "
+                                         f"(tangent + second-order chain); backward mode {r5.siren.bwd_mode}")
             del r5
         except Exception as exc:
             result["train_step_ms"] = None

@@ -57,3 +57,41 @@ def evaluate_sharded(unit_fn, n_units, rank=0, world_size=1, device="cpu", group
         probe = unit_fn.__dict__.get('n_metrics', N_METRICS)
         local = torch.empty((0, probe), device=device)
     return gather_metric_rows(local, n_units, rank, world_size, group)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the 8 metric columns of one evaluated image (losses/builder.py:130-184)
+# ------------------------------------------------------------------------------------------------------------------
+def _gaussian_window(size, sigma, device, dtype):
+    x = torch.arange(size, device=device, dtype=dtype) - (size - 1) / 2
+    g = torch.exp(-(x ** 2) / (2 * sigma ** 2))
+    g = g / g.sum()
+    return g[:, None] * g[None, :]
+
+
+def ssim_index(x, y, window=5, max_val=1.0):
+    """Mean structural similarity with a Gaussian window (sigma 1.5, reflect padding) -- the quantity behind the
+    reference's `1 - kornia.losses.ssim_loss(pred, gt, 5)` (builder.py:166,181): ssim_loss = mean(clamp((1 - ssim)/2, 0, 1)),
+    so the reported SSIM column is 1 - that."""
+    import torch.nn.functional as F
+    C = x.shape[1]
+    w = _gaussian_window(window, 1.5, x.device, x.dtype).expand(C, 1, window, window).contiguous()
+    pad = window // 2
+    f = lambda t: F.conv2d(F.pad(t, [pad] * 4, mode='reflect'), w, groups=C)
+    mx, my = f(x), f(y)
+    sxx, syy, sxy = f(x * x) - mx * mx, f(y * y) - my * my, f(x * y) - mx * my
+    c1, c2 = (0.01 * max_val) ** 2, (0.03 * max_val) ** 2
+    ssim = ((2 * mx * my + c1) * (2 * sxy + c2)) / ((mx * mx + my * my + c1) * (sxx + syy + c2))
+    return 1 - torch.clamp((1 - ssim) / 2, 0, 1).mean()
+
+
+def image_metrics(pred, gt, l2_lambda=1.0):
+    """(8,) = [loss_l2, loss_id, loss_lpips, loss, mae, PSNR, SSIM, ID_SIM] for one predicted image against its target,
+    both (1,3,H,W) in [-1,1] (calc_2d_rec_loss, builder.py:130-184).  The two terms that need pretrained networks the
+    image does not have (ArcFace identity, LPIPS/VGG) are outside the hot path and reported as 0 (ID_SIM = 1 - 0), exactly
+    as the reference does when their lambdas are 0 (:145, :158-163)."""
+    mse = torch.mean((pred - gt) ** 2)
+    zero = torch.zeros((), device=pred.device, dtype=pred.dtype)
+    p01, g01 = pred / 2 + 0.5, gt / 2 + 0.5
+    psnr = 10.0 * torch.log10(1.0 / torch.mean((p01 - g01) ** 2))
+    return torch.stack([mse, zero, zero, mse * l2_lambda, torch.mean((pred - gt).abs()), psnr, ssim_index(pred, gt), 1 - zero])

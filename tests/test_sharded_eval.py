@@ -78,3 +78,39 @@ def test_two_rank_sharded_eval_matches_serial(tmp_path, n_units):
     np.testing.assert_array_equal(t0[:, 7], np.arange(n_units))  # global unit order restored
     np.testing.assert_allclose(t0, serial, rtol=0, atol=0)     # same process-local arithmetic -> identical rows
     assert not np.isnan(t0).any()                              # padding rows never leak
+
+
+def test_bench_self_launches_the_ranks():
+    """`python bench.py --gpus 2` without torchrun must start 2 ranks itself: the launcher + rendezvous path is
+    exercised here on CPU with --dry-run (gloo, no kernel work); on a GPU box the same path runs the bench over RCCL."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j == {"dry_run": True, "n_gpus": 2, "ranks_joined": 2, "self_launched": True}
+    # a world size that disagrees with --gpus is refused instead of silently running one rank
+    bad = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
+def test_image_metrics_columns():
+    """The 8 columns of builder.py:174-184 on a known pair: identical images -> l2 0, SSIM 1; PSNR formula; SSIM drops with noise."""
+    g = torch.Generator().manual_seed(0)
+    a = torch.tanh(torch.randn(1, 3, 32, 32, generator=g))
+    m = se.image_metrics(a, a + 0.1)
+    assert m.shape == (8,)
+    np.testing.assert_allclose(float(m[0]), 0.01, rtol=1e-5)                       # loss_l2
+    np.testing.assert_allclose(float(m[4]), 0.1, rtol=1e-5)                        # mae
+    np.testing.assert_allclose(float(m[5]), 10 * np.log10(1 / 0.0025), rtol=1e-4)   # PSNR on [0,1]-scaled images
+    assert float(m[1]) == 0 and float(m[2]) == 0 and float(m[7]) == 1               # pretrained-net terms
+    same = se.image_metrics(a, a.clone())
+    assert float(same[0]) == 0 and abs(float(same[6]) - 1) < 1e-6
+    noisy = se.image_metrics(a, a + 0.3 * torch.randn(a.shape, generator=g))
+    assert float(noisy[6]) < 0.95 and float(m[6]) < 1
