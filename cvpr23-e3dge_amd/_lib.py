@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E3DGE_LIB_PATH") or os.path.join(_HERE, "lib", "libe3dge_hip.so")   # override: kernel A/B variants
 ABI_VERSION = 7
 PREC_F32, PREC_F16X3 = 0, 1
+AMAX_FLOATS = 64 * 32           # E3DGE_AMAX_FLOATS: one amax buffer (include/e3dge_hip.h)
 
 _c_float_p = ctypes.c_void_p     # device pointers travel as integers
 _i32, _i64, _f32, _vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
@@ -46,6 +47,19 @@ class SirenBwdArgs(ctypes.Structure):
         (n, _vp) for n in ("partials", "dfilm", "dstyles", "d_pts", "d_tex_alpha", "d_tex_beta")]
 
 
+class ModconvArgs(ctypes.Structure):
+    """Mirror of struct E3dgeModconvArgs (include/e3dge_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("x", "wimg", "style", "demod", "in_amax", "s_amax", "noise", "noise_w", "bias", "y", "out_amax")] + [
+        ("negative_slope", _f32), ("act_scale", _f32)] + [(n, _i32) for n in ("act", "upsample", "batch", "ci", "co", "height", "width",
+                                                                                "noise_batch")]
+
+
+class ModLayer(ctypes.Structure):
+    """Mirror of struct E3dgeModLayer (include/e3dge_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("mod_weight", "mod_bias", "wsq", "style_out", "demod_out", "s_amax_out")] + [
+        (n, _i32) for n in ("ci", "co", "latent_index", "row_start", "co_start")] + [("lin_scale", _f32), ("lr_mul", _f32)]
+
+
 # name -> (restype, argtypes); every symbol include/e3dge_hip.h declares.
 SIGNATURES = {
     "e3dge_abi_version": (_i32, []),
@@ -55,6 +69,14 @@ SIGNATURES = {
     "e3dge_upfirdn2d": (_i32, [_vp, _vp, _vp, _i64] + [_i32] * 12 + [_vp]),
     "e3dge_upfirdn2d_out_size": (_i32, [_i32] * 6),
     "e3dge_modconv_weights": (_i32, [_vp, _vp, _vp, _f32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "e3dge_blur_noise_bias_act": (_i32, [_vp] * 6 + [_f32, _f32, _i64, _i64, _i32, _i32, _i32, _i32, _i64, _vp, _vp]),
+    "e3dge_torgb": (_i32, [_vp] * 7 + [_f32, _i32, _i32, _i32, _i32, _vp]),
+    "e3dge_decoder_styles": (_i32, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "e3dge_modconv_packed_words": (_i64, [_i32, _i32]),
+    "e3dge_modconv_pack_weights": (_i32, [_vp, _vp, _vp, _f32, _i32, _i32, _vp]),
+    "e3dge_modconv_demod": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "e3dge_amax": (_i32, [_vp, _vp, _i64, _vp]),
+    "e3dge_modconv3x3": (_i32, [ctypes.POINTER(ModconvArgs), _vp]),
     "e3dge_siren_packed_floats": (_i64, []),
     "e3dge_siren_pack_weights": (_i32, [_vp] * 11 + [_vp]),
     "e3dge_film_params": (_i32, [_vp] * 6 + [_i32, _vp]),

@@ -24,6 +24,15 @@ inline int check_launch(const char* what) {
 
 constexpr int kWave = 64;  // CDNA wavefront
 
+// "amax buffers": max |value| of an activation tensor, tracked by its producer so that the next modulated conv can pick
+// its power-of-two operand scale without another pass over the data.  kAmaxSlots slots, kAmaxStride floats (one 128-B
+// line) apart; producers atomically max into slot (block index mod slots) -- one word would serialise thousands of
+// atomics -- and the consumer takes the maximum over the slots.  Values are non-negative floats, compared as uint32.
+constexpr int kAmaxSlots = E3DGE_AMAX_SLOTS, kAmaxStride = E3DGE_AMAX_STRIDE;
+__device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
+    atomicMax(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+
 }  // namespace e3dge
 
 #define E3DGE_REQUIRE(cond, ...)                                        \

@@ -278,6 +278,100 @@ extern "C" int e3dge_noise_bias_act(float* y, const float* x, const float* noise
     return check_launch("noise_bias_act");
 }
 
+// ---------------------------------------------------------------------------------------------
+// ToRGB (stylesdf_model.py:510-541) in one pass: 1x1 modulated conv WITHOUT demodulation (:232), + bias, + the skip image
+// up-sampled by upfirdn2d(up=2, pad=(2,1)) with the 4x4 FIR (Upsample :96-119).  Bound: HBM (reads Ci floats per pixel).
+// 256 threads = 64 pixel lanes (4 adjacent pixels each, float4 loads) x 4 channel groups, partial sums folded through LDS.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRgbThreads = 256, kRgbMaxCi = 1024;
+__global__ void __launch_bounds__(kRgbThreads)
+torgb_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ weight,
+             const float* __restrict__ style, const float* __restrict__ bias, const float* __restrict__ skip,
+             const float* __restrict__ fir, float scale, int Ci, int H, int W, int blocks_per_img) {
+    __shared__ float wm[3 * kRgbMaxCi];
+    __shared__ float part[3][3][64][4];
+    const int b = blockIdx.x / blocks_per_img, blk = blockIdx.x - b * blocks_per_img;
+    const int pl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int HW = H * W;
+    for (int i = threadIdx.x; i < 3 * Ci; i += kRgbThreads) {
+        const int c = i / Ci, ci = i - c * Ci;
+        wm[i] = __fmul_rn(__fmul_rn(scale, weight[c * Ci + ci]), style[(int64_t)b * Ci + ci]);      // (scale * W) * s, :321
+    }
+    __syncthreads();
+    const int p0 = (blk * 64 + pl) * 4;                       // HW is a multiple of 4 (checked by the launcher)
+    const bool live = p0 < HW;
+    float acc[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (live) {
+        const int per = (Ci + 3) / 4, c0 = grp * per, c1 = min(Ci, c0 + per);
+        const float4* xp = reinterpret_cast<const float4*>(x + ((int64_t)b * Ci + c0) * HW + p0);
+#pragma unroll 8
+        for (int ci = c0; ci < c1; ++ci) {
+            const float4 v = *xp;
+            xp += HW / 4;
+            const float w0 = wm[ci], w1 = wm[Ci + ci], w2 = wm[2 * Ci + ci];
+            acc[0][0] = fmaf(w0, v.x, acc[0][0]); acc[0][1] = fmaf(w0, v.y, acc[0][1]); acc[0][2] = fmaf(w0, v.z, acc[0][2]); acc[0][3] = fmaf(w0, v.w, acc[0][3]);
+            acc[1][0] = fmaf(w1, v.x, acc[1][0]); acc[1][1] = fmaf(w1, v.y, acc[1][1]); acc[1][2] = fmaf(w1, v.z, acc[1][2]); acc[1][3] = fmaf(w1, v.w, acc[1][3]);
+            acc[2][0] = fmaf(w2, v.x, acc[2][0]); acc[2][1] = fmaf(w2, v.y, acc[2][1]); acc[2][2] = fmaf(w2, v.z, acc[2][2]); acc[2][3] = fmaf(w2, v.w, acc[2][3]);
+        }
+    }
+    if (grp > 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[grp - 1][c][pl][j] = acc[c][j];
+    }
+    __syncthreads();
+    if (grp != 0 || !live) return;
+    const int oy = p0 / W, ox = p0 - oy * W;                  // 4 pixels of one row (W % 4 == 0)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float conv = ((acc[c][j] + part[0][c][pl][j]) + part[1][c][pl][j]) + part[2][c][pl][j];
+            o[j] = conv + bias[c];
+        }
+        if (skip) {
+            // upfirdn2d(skip, fir, up=2, pad=(2,1)): only the taps with (o + k - 2) even meet a sample; same tap order
+            // (ky, then kx) and the same fma chain as e3dge_upfirdn2d, so the sum is bit-identical to it
+            const int h = H >> 1, w = W >> 1;
+            const float* sp = skip + ((int64_t)b * 3 + c) * h * w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = ox + j;
+                float u = 0.0f;
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const int ky = (oy & 1) + 2 * a, iy = (oy + ky - 2) >> 1;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int kx = (xx & 1) + 2 * e, ix = (xx + kx - 2) >> 1;
+                        if (iy >= 0 && iy < h && ix >= 0 && ix < w) u = fmaf(sp[iy * w + ix], fir[(3 - ky) * 4 + (3 - kx)], u);
+                    }
+                }
+                o[j] = o[j] + u;
+            }
+        }
+        *reinterpret_cast<float4*>(y + ((int64_t)b * 3 + c) * HW + p0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+extern "C" int e3dge_torgb(float* y, const float* x, const float* weight, const float* style, const float* bias,
+                           const float* skip, const float* fir, float scale, int batch, int ci, int height, int width,
+                           e3dge_stream_t stream) {
+    E3DGE_REQUIRE(batch >= 0 && ci >= 1 && ci <= kRgbMaxCi && height >= 1 && width >= 1, "torgb: bad sizes (ci <= %d)", kRgbMaxCi);
+    if (batch == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(y && x && weight && style && bias, "torgb: null pointer");
+    E3DGE_REQUIRE(skip == nullptr || fir != nullptr, "torgb: skip needs the 4x4 FIR");
+    E3DGE_REQUIRE(width % 4 == 0 && (skip == nullptr || (height % 2 == 0 && width % 2 == 0)), "torgb: width must be a multiple of 4 (and even extents with a skip)");
+    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "torgb: x / y must be 16-B aligned");
+    const int64_t hw = (int64_t)height * width;
+    E3DGE_REQUIRE(hw * ci < ((int64_t)1 << 31), "torgb: image too large");
+    const int bpi = (int)((hw / 4 + 63) / 64);
+    torgb_kernel<<<dim3((unsigned)(bpi * batch)), dim3(kRgbThreads), 0, as_stream(stream)>>>(y, x, weight, style, bias, skip, fir, scale, ci, height, width, bpi);
+    return check_launch("torgb");
+}
+
 extern "C" int e3dge_modconv_weights(float* out, const float* weight, const float* style, float scale,
                                      int demodulate, int transpose, int batch, int co, int ci, int kk,
                                      e3dge_stream_t stream) {

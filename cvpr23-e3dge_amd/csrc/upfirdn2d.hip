@@ -29,10 +29,22 @@ struct UpfirdnGeom {
 // ---------------------------------------------------------------------------------------------
 constexpr int kTileH = 32, kTileW = 64, kUpThreads = 256;
 
-template <int UP, int DN, int KH, int KW>
+// Optional fused tail (EPI): StyledConv's NoiseInjection + FusedLeakyReLU after the Blur of an up-sampling layer
+// (stylesdf_model.py:346, :459-466, :500-507) and the amax tracking the next modulated conv wants -- one pass less over
+// the activation than blur -> noise_bias_act.
+struct UpfirdnEpi {
+    const float* noise;       // (noise_batch, out_h * out_w) or null
+    const float* noise_w;     // device scalar
+    const float* bias;        // (channels) or null
+    float* out_amax;          // amax buffer (common.h) or null
+    float alpha, scale;
+    int channels, noise_batch;
+};
+
+template <int UP, int DN, int KH, int KW, bool EPI = false>
 __global__ void __launch_bounds__(kUpThreads)
 upfirdn2d_tiled_kernel(float* __restrict__ y, const float* __restrict__ x,
-                       const float* __restrict__ k, UpfirdnGeom g, int tiles_x, int tiles_y) {
+                       const float* __restrict__ k, UpfirdnGeom g, int tiles_x, int tiles_y, UpfirdnEpi ep = UpfirdnEpi{}) {
     constexpr int UH = (kTileH - 1) * DN + KH;           // rows of U needed by the tile
     constexpr int UW = (kTileW - 1) * DN + KW;
     constexpr int PITCH = (UW + 3) & ~3;                 // 16-B aligned rows for ds_read_b128
@@ -76,6 +88,10 @@ upfirdn2d_tiled_kernel(float* __restrict__ y, const float* __restrict__ x,
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     float* yp = y + plane * (int64_t)g.out_h * g.out_w;
     const bool vec_ok = (g.out_w & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+    float amax_l = 0.0f;
+    [[maybe_unused]] const float e_nw = (EPI && ep.noise) ? ep.noise_w[0] : 0.0f;
+    [[maybe_unused]] const float e_b = (EPI && ep.bias) ? ep.bias[(int)(plane % ep.channels)] : 0.0f;
+    [[maybe_unused]] const float* e_nz = (EPI && ep.noise) ? ep.noise + (ep.noise_batch > 1 ? (plane / ep.channels) : 0) * (int64_t)g.out_h * g.out_w : nullptr;
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int oyl = ty + rr * 16;
@@ -102,6 +118,19 @@ upfirdn2d_tiled_kernel(float* __restrict__ y, const float* __restrict__ x,
         if (oy < g.out_h) {
             const int ox = ox0 + tx * 4;
             float* dst = yp + (int64_t)oy * g.out_w + ox;
+            if (EPI) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (ox + j < g.out_w) {
+                        float v = acc[j];
+                        if (e_nz) v = __fadd_rn(v, __fmul_rn(e_nw, e_nz[(int64_t)oy * g.out_w + ox + j]));   // same rounding as noise_bias_act
+                        if (ep.bias) v = v + e_b;
+                        v = (v > 0.0f ? v : v * ep.alpha) * ep.scale;
+                        acc[j] = v;
+                        amax_l = fmaxf(amax_l, fabsf(v));
+                    }
+                }
+            }
             if (vec_ok && ox + 3 < g.out_w) {
                 *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
             } else {
@@ -110,6 +139,16 @@ upfirdn2d_tiled_kernel(float* __restrict__ y, const float* __restrict__ x,
                     if (ox + j < g.out_w) dst[j] = acc[j];
             }
         }
+    }
+    if (EPI && ep.out_amax) {                           // one atomic per block, spread over the buffer's slots
+        __shared__ float part[kUpThreads / 64];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax_l = fmaxf(amax_l, __shfl_xor(amax_l, off, kWave));
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = amax_l;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomic_max_nonneg(ep.out_amax + ((int)blockIdx.x & (kAmaxSlots - 1)) * kAmaxStride,
+                              fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
     }
 }
 
@@ -191,4 +230,25 @@ extern "C" int e3dge_upfirdn2d(float* y, const float* x, const float* k, int64_t
     if (blocks > 16384) blocks = 16384;
     upfirdn2d_generic_kernel<<<dim3((unsigned)blocks), dim3(kUpThreads), 0, st>>>(y, x, k, g, total);
     return check_launch("upfirdn2d(generic)");
+}
+
+extern "C" int e3dge_blur_noise_bias_act(float* y, const float* x, const float* k, const float* noise, const float* noise_weight,
+                                         const float* bias, float alpha, float scale, int64_t batch, int64_t channels,
+                                         int in_h, int in_w, int pad0, int pad1, int64_t noise_batch, float* out_amax,
+                                         e3dge_stream_t stream) {
+    E3DGE_REQUIRE(batch >= 0 && channels >= 1 && in_h >= 1 && in_w >= 1, "blur_noise_bias_act: bad extent");
+    const int out_h = e3dge_upfirdn2d_out_size(in_h, 1, 1, pad0, pad1, 4);
+    const int out_w = e3dge_upfirdn2d_out_size(in_w, 1, 1, pad0, pad1, 4);
+    E3DGE_REQUIRE(out_h > 0 && out_w > 0, "blur_noise_bias_act: empty output");
+    if (batch == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(x && y && k, "blur_noise_bias_act: null pointer");
+    E3DGE_REQUIRE(noise == nullptr || (noise_weight != nullptr && (noise_batch == 1 || noise_batch == batch)),
+                  "blur_noise_bias_act: noise needs noise_weight and noise_batch in {1, batch}");
+    UpfirdnGeom g{in_h, in_w, out_h, out_w, 1, 1, 1, 1, pad0, pad0, 4, 4};
+    UpfirdnEpi ep{noise, noise_weight, bias, out_amax, alpha, scale, (int)channels, (int)noise_batch};
+    const int tiles_x = (out_w + kTileW - 1) / kTileW, tiles_y = (out_h + kTileH - 1) / kTileH;
+    const int64_t blocks = (int64_t)tiles_x * tiles_y * batch * channels;
+    E3DGE_REQUIRE(blocks < ((int64_t)1 << 31), "blur_noise_bias_act: grid too large");
+    upfirdn2d_tiled_kernel<1, 1, 4, 4, true><<<dim3((unsigned)blocks), dim3(kUpThreads), 0, as_stream(stream)>>>(y, x, k, g, tiles_x, tiles_y, ep);
+    return check_launch("blur_noise_bias_act");
 }

@@ -11,7 +11,9 @@ What runs where: every elementwise / FIR / weight-preparation step is a hand-wri
 calls (MIOpen / rocBLAS through torch) -- SURVEY.md 8(d) lists them as "library, not hand-written".
 Discriminators, legacy encoders and noise projection onto meshes (:1192-1765, :375-457) are out of scope.
 """
+import ctypes
 import math
+import os
 import random
 
 import numpy as np
@@ -119,9 +121,20 @@ class EqualLinear(nn.Module):
         return F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
 
 
+def modconv_backend():
+    """'hip' (default): 3x3 modulated convolutions run on the fused implicit-GEMM kernel e3dge_modconv3x3.
+    E3DGE_MODCONV=library keeps the previous path (e3dge_modconv_weights + MIOpen convolution through torch)."""
+    v = os.environ.get("E3DGE_MODCONV", "hip")
+    if v not in ("hip", "library"):
+        raise RuntimeError(f"E3DGE_MODCONV must be 'hip' or 'library', got {v!r}")
+    return v
+
+
 class ModulatedConv2d(nn.Module):
-    """Reference :263-362.  Weight modulation + demodulation is one HIP launch (e3dge_modconv_weights) that
-    writes the per-sample weights directly in the grouped-conv (or transposed-conv) layout."""
+    """Reference :263-362.  3x3 layers on the inference path: one fused HIP launch (e3dge_modconv3x3) -- no per-sample
+    weights, modulation applied to the staged input, demodulation (+ noise, bias, lrelu for StyledConv) in the epilogue.
+    Other cases (1x1 ToRGB, down-sampling, anything under autograd): weight modulation + demodulation as one HIP launch
+    (e3dge_modconv_weights) that writes the per-sample weights in the grouped-conv layout, then a library convolution."""
 
     def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
                  downsample=False, blur_kernel=[1, 3, 3, 1]):
@@ -165,8 +178,95 @@ class ModulatedConv2d(nn.Module):
         _lib.check(rc, "e3dge_modconv_weights")
         return out
 
+    # ---- fused path --------------------------------------------------------------------------------------------
+    def fused_ok(self, input):
+        """3x3, no down-sampling, fp32 GPU tensors, channel counts the tiles cover, and no autograd graph needed."""
+        if self.kernel_size != 3 or self.downsample or modconv_backend() != "hip":
+            return False
+        if input.device.type != "cuda" or input.dtype != torch.float32:
+            return False
+        if self.in_channel % 16 or self.out_channel % 32:
+            return False
+        if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad or
+                                        self.modulation.weight.requires_grad):
+            return False
+        return True
+
+    def invalidate(self):
+        """Drop the packed weight image (needed after writes through `.data`; see SirenGenerator.invalidate)."""
+        self._img = self._img_key = None
+
+    def _apply(self, fn, *a, **k):
+        self._img = self._img_key = None
+        return super()._apply(fn, *a, **k)
+
+    def device_image(self):
+        """(image, wsq): the MFMA fragment image of scale * W (f16 hi/lo) and the per-(co,ci) squared norms."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if getattr(self, '_img', None) is None or self._img_key != key:
+            lib = _lib.load()
+            Co, Ci = self.out_channel, self.in_channel
+            img = torch.empty(lib.e3dge_modconv_packed_words(Co, Ci), device=w.device, dtype=torch.int32)
+            wsq = torch.empty((Co, Ci), device=w.device, dtype=torch.float32)
+            wc = w.detach().reshape(Co, Ci, 9).contiguous()
+            with torch.cuda.device(w.device):
+                rc = lib.e3dge_modconv_pack_weights(_lib.ptr(img), _lib.ptr(wsq), _lib.ptr(wc), float(self.scale), Co, Ci,
+                                                    _lib.stream_of(wc))
+            _lib.check(rc, "e3dge_modconv_pack_weights")
+            wmax = float(wc.abs().max().item()) * self.scale
+            if wmax >= 400.0:                      # the image stores 128 * scale * w as f16
+                raise RuntimeError(f"modulated-conv weights up to {wmax:g} (after the 1/sqrt(fan_in) scale) do not fit the "
+                                   "f16 image; set E3DGE_MODCONV=library for this checkpoint")
+            self._img, self._img_key = (img, wsq), key
+        return self._img
+
+    def forward_fused(self, input, style, noise=None, noise_weight=None, bias=None, negative_slope=0.2, act_scale=1.0,
+                      act=False, in_amax=None, out_amax=None, pre=None):
+        """The conv (stride-1: with StyledConv's tail when act=True; up-sampling: the transposed conv, BEFORE the blur).
+        in_amax / out_amax: amax buffers (_lib.AMAX_FLOATS floats, include/e3dge_hip.h): max|input| as tracked by the
+        producer of `input` (computed here with e3dge_amax when not supplied) / zero-initialised buffer receiving max|output|."""
+        B, Ci, H, W = input.shape
+        x = input.contiguous()
+        img, wsq = self.device_image()
+        lib = _lib.load()
+        dev = x.device
+        if pre is not None:           # (s, demod, s_amax) from Decoder's e3dge_decoder_styles launch
+            s, demod, s_amax = pre
+        else:
+            s = self.modulation(style).contiguous()
+            demod = torch.empty((B, self.out_channel), device=dev, dtype=torch.float32) if self.demodulate else None
+            s_amax = torch.empty(B, device=dev, dtype=torch.float32)
+        OH, OW = (2 * H + 1, 2 * W + 1) if self.upsample else (H, W)
+        y = torch.empty((B, self.out_channel, OH, OW), device=dev, dtype=torch.float32)
+        nz = None
+        if noise is not None:
+            nz = noise.contiguous()
+            if nz.shape[0] not in (1, B) or nz.numel() != nz.shape[0] * OH * OW:
+                raise RuntimeError(f"noise must be (1|B, 1, {OH}, {OW}); got {tuple(noise.shape)}")
+        with torch.cuda.device(dev):
+            st = _lib.stream_of(x)
+            if pre is None:
+                rc = lib.e3dge_modconv_demod(_lib.ptr(demod), _lib.ptr(s_amax), _lib.ptr(s), _lib.ptr(wsq), B, self.out_channel, Ci,
+                                             int(self.demodulate), st)
+                _lib.check(rc, "e3dge_modconv_demod")
+            if in_amax is None:       # the producer of `input` did not track max|input|: one extra pass over it
+                in_amax = torch.zeros(_lib.AMAX_FLOATS, device=dev, dtype=torch.float32)
+                _lib.check(lib.e3dge_amax(_lib.ptr(in_amax), _lib.ptr(x), x.numel(), st), "e3dge_amax")
+            a = _lib.ModconvArgs(x=_lib.ptr(x), wimg=_lib.ptr(img), style=_lib.ptr(s), demod=_lib.ptr(demod), in_amax=_lib.ptr(in_amax),
+                                 s_amax=_lib.ptr(s_amax), noise=_lib.ptr(nz), noise_w=_lib.ptr(noise_weight) if nz is not None else None,
+                                 bias=_lib.ptr(bias), y=_lib.ptr(y), out_amax=_lib.ptr(out_amax), negative_slope=float(negative_slope),
+                                 act_scale=float(act_scale), act=int(bool(act)), upsample=int(bool(self.upsample)), batch=B, ci=Ci,
+                                 co=self.out_channel, height=H, width=W, noise_batch=0 if nz is None else nz.shape[0])
+            rc = lib.e3dge_modconv3x3(ctypes.byref(a), st)
+        _lib.check(rc, "e3dge_modconv3x3")
+        return y
+
     def forward(self, input, style):
         B, Ci, H, W = input.shape
+        if self.fused_ok(input):
+            out = self.forward_fused(input, style)
+            return self.blur(out) if self.upsample else out
         s = self.modulation(style)
         if self.upsample:
             w = self._weights(s, transpose=True)
@@ -214,13 +314,44 @@ class StyledConv(nn.Module):
         self.bias = nn.Parameter(torch.zeros(1, out_channel, 1, 1))   # unused by forward, as in the reference (:491)
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None, transform=None, mesh_path=None):
-        out = self.conv(input, style)
+    def forward(self, input, style, noise=None, transform=None, mesh_path=None, in_amax=None, out_amax=None, pre=None):
+        conv = self.conv
+        if conv.fused_ok(input) and not (torch.is_grad_enabled() and (self.noise.weight.requires_grad or
+                                                                      self.activate.bias.requires_grad)):
+            B, _, H, W = input.shape
+            OH, OW = (2 * H, 2 * W) if conv.upsample else (H, W)
+            if noise is None:
+                noise = input.new_empty(B, 1, OH, OW).normal_()
+            act = self.activate
+            if not conv.upsample:     # conv + noise + bias + lrelu: one launch
+                return conv.forward_fused(input, style, noise=noise, noise_weight=self.noise.weight, bias=act.bias,
+                                          negative_slope=act.negative_slope, act_scale=act.scale, act=True, in_amax=in_amax,
+                                          out_amax=out_amax, pre=pre)
+            # transposed conv by output phase, then blur + noise + bias + lrelu in one pass
+            t = conv.forward_fused(input, style, in_amax=in_amax, pre=pre)
+            nz = noise.contiguous()
+            if nz.shape[0] not in (1, B) or nz.numel() != nz.shape[0] * OH * OW:
+                raise RuntimeError(f"noise must be (1|B, 1, {OH}, {OW}); got {tuple(noise.shape)}")
+            y = torch.empty((B, conv.out_channel, OH, OW), device=input.device, dtype=torch.float32)
+            k = conv.blur.kernel
+            with torch.cuda.device(input.device):
+                rc = _lib.load().e3dge_blur_noise_bias_act(
+                    _lib.ptr(y), _lib.ptr(t), _lib.ptr(k), _lib.ptr(nz), _lib.ptr(self.noise.weight), _lib.ptr(act.bias),
+                    float(act.negative_slope), float(act.scale), B, conv.out_channel, t.shape[2], t.shape[3],
+                    int(conv.blur.pad[0]), int(conv.blur.pad[1]), nz.shape[0], _lib.ptr(out_amax), _lib.stream_of(t))
+            _lib.check(rc, "e3dge_blur_noise_bias_act")
+            return y
+        out = conv(input, style)
         if noise is None:
             B, _, H, W = out.shape
             noise = out.new_empty(B, 1, H, W).normal_()
-        return noise_bias_act(out, noise, self.noise.weight, self.activate.bias, self.activate.negative_slope,
-                              self.activate.scale)
+        out = noise_bias_act(out, noise, self.noise.weight, self.activate.bias, self.activate.negative_slope,
+                             self.activate.scale)
+        if out_amax is not None and out.device.type == "cuda":   # a fused consumer follows: it needs max|out|
+            with torch.cuda.device(out.device):
+                oc = out.detach().contiguous()
+                _lib.check(_lib.load().e3dge_amax(_lib.ptr(out_amax), _lib.ptr(oc), oc.numel(), _lib.stream_of(oc)), "e3dge_amax")
+        return out
 
 
 class ToRGB(nn.Module):
@@ -232,7 +363,34 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
-    def forward(self, input, style, skip=None):
+    def fused_ok(self, input, skip):
+        if modconv_backend() != "hip" or input.device.type != "cuda" or input.dtype != torch.float32:
+            return False
+        if input.shape[3] % 4 or self.conv.in_channel > 1024:
+            return False
+        if skip is not None and (not self.upsample or tuple(skip.shape[2:]) != (input.shape[2] // 2, input.shape[3] // 2)
+                                 or input.shape[2] % 2):
+            return False
+        if torch.is_grad_enabled() and (input.requires_grad or self.bias.requires_grad or self.conv.weight.requires_grad or
+                                        (skip is not None and skip.requires_grad) or self.conv.modulation.weight.requires_grad):
+            return False
+        return True
+
+    def forward(self, input, style, skip=None, pre=None):
+        if self.fused_ok(input, skip):
+            # 1x1 modulated conv (no demodulation) + bias + FIR-up-sampled skip: one HBM pass (e3dge_torgb)
+            B, Ci, H, W = input.shape
+            x = input.contiguous()
+            s = pre[0] if pre is not None else self.conv.modulation(style).contiguous()
+            w = self.conv.weight.detach().reshape(3, Ci).contiguous()
+            y = torch.empty((B, 3, H, W), device=x.device, dtype=torch.float32)
+            sk = None if skip is None else skip.contiguous()
+            with torch.cuda.device(x.device):
+                rc = _lib.load().e3dge_torgb(_lib.ptr(y), _lib.ptr(x), _lib.ptr(w), _lib.ptr(s), _lib.ptr(self.bias.detach().reshape(3).contiguous()),
+                                             _lib.ptr(sk), _lib.ptr(self.upsample.kernel) if sk is not None else None,
+                                             float(self.conv.scale), B, Ci, H, W, _lib.stream_of(x))
+            _lib.check(rc, "e3dge_torgb")
+            return y
         out = self.conv(input, style) + self.bias
         if skip is not None:
             if self.upsample:
@@ -285,6 +443,62 @@ class Decoder(nn.Module):
     def mean_latent(self, renderer_latent):
         return self.style(renderer_latent).mean(0, keepdim=True)
 
+    # ---- all modulation vectors of one forward in two launches (e3dge_decoder_styles) ----------------------------------
+    def _mod_layers(self):
+        """[(ModulatedConv2d, latent index)] in execution order (conv1, to_rgb1, then per level up_conv, conv, to_rgb)."""
+        out = [(self.conv1.conv, 0), (self.to_rgb1.conv, 1)]
+        i = 1
+        for u in range(len(self.to_rgbs)):
+            out += [(self.convs[2 * u].conv, i), (self.convs[2 * u + 1].conv, i + 1), (self.to_rgbs[u].conv, i + 2)]
+            i += 2
+        return out
+
+    def _style_table(self, B, device):
+        layers = self._mod_layers()
+        wsqs = [m.device_image()[1] if m.kernel_size == 3 else None for m, _ in layers]
+        key = (B, str(device)) + tuple((m.modulation.weight.data_ptr(), m.modulation.weight._version, m.modulation.bias.data_ptr(),
+                                        m.modulation.bias._version, 0 if w is None else w.data_ptr()) for (m, _), w in zip(layers, wsqs))
+        if getattr(self, '_tab_key', None) != key:
+            import ctypes
+            pad4 = lambda n: (n + 3) // 4 * 4
+            total = sum(pad4(B * m.in_channel) + (pad4(B * m.out_channel) + pad4(B) if w is not None else 0) for (m, _), w in zip(layers, wsqs))
+            buf = torch.empty(total, device=device, dtype=torch.float32)
+            rows = (_lib.ModLayer * len(layers))()
+            views, off, row_start, co_start = [], 0, 0, 0
+            for j, ((m, li), w) in enumerate(zip(layers, wsqs)):
+                s_v = buf[off:off + B * m.in_channel].view(B, m.in_channel); off += pad4(B * m.in_channel)
+                d_v = a_v = None
+                if w is not None:
+                    d_v = buf[off:off + B * m.out_channel].view(B, m.out_channel); off += pad4(B * m.out_channel)
+                    a_v = buf[off:off + B]; off += pad4(B)
+                views.append((s_v, d_v, a_v))
+                mod = m.modulation
+                rows[j] = _lib.ModLayer(mod_weight=_lib.ptr(mod.weight), mod_bias=_lib.ptr(mod.bias), wsq=_lib.ptr(w),
+                                        style_out=_lib.ptr(s_v), demod_out=_lib.ptr(d_v) if (w is not None and m.demodulate) else None,
+                                        s_amax_out=_lib.ptr(a_v), ci=m.in_channel, co=m.out_channel if w is not None else 0,
+                                        latent_index=li, row_start=row_start, co_start=co_start, lin_scale=float(mod.scale),
+                                        lr_mul=float(mod.lr_mul))
+                row_start += m.in_channel
+                co_start += m.out_channel if w is not None else 0
+            raw = torch.frombuffer(bytearray(bytes(rows)), dtype=torch.uint8).to(device)
+            self._tab, self._tab_key = (raw, buf, views, len(layers), row_start, co_start), key
+        return self._tab
+
+    def _all_modulations(self, latent):
+        """[(s, demod, s_amax)] per modulated conv of the forward, or None when the fused path is not taken."""
+        if latent.device.type != "cuda" or modconv_backend() != "hip" or torch.is_grad_enabled() or latent.dtype != torch.float32:
+            return None
+        if any(m.kernel_size == 3 and (m.in_channel % 16 or m.out_channel % 32) for m, _ in self._mod_layers()):
+            return None
+        B = latent.shape[0]
+        raw, buf, views, n, rows, cos = self._style_table(B, latent.device)
+        lat = latent.contiguous()
+        with torch.cuda.device(latent.device):
+            rc = _lib.load().e3dge_decoder_styles(_lib.ptr(raw), n, rows, cos, _lib.ptr(lat), lat.shape[1], lat.shape[2], B,
+                                                  _lib.stream_of(lat))
+        _lib.check(rc, "e3dge_decoder_styles")
+        return views
+
     def get_latent(self, input):
         return self.style(input)
 
@@ -313,15 +527,22 @@ class Decoder(nn.Module):
         assert isinstance(styles, list), 'wrap latent code with list'
         latent, noise = self.styles_and_noise_forward(styles, noise, inject_index, truncation, truncation_latent,
                                                       input_is_latent, randomize_noise)
-        out = self.conv1(features, latent[:, 0], noise=noise[0])
-        skip = self.to_rgb1(out, latent[:, 1], skip=rgbd_in)
-        i = 1
+        # amax buffers (one row per activation): every fused layer leaves max|output| for the next one's operand scaling
+        track = features.device.type == "cuda" and modconv_backend() == "hip" and not torch.is_grad_enabled()
+        amax = torch.zeros((self.num_layers + 1, _lib.AMAX_FLOATS), device=features.device, dtype=torch.float32) if track else None
+        am = (lambda j: amax[j]) if track else (lambda j: None)
+        mods = self._all_modulations(latent) if track else None
+        pre = (lambda j: mods[j]) if mods is not None else (lambda j: None)
+        out = self.conv1(features, latent[:, 0], noise=noise[0], out_amax=am(1), pre=pre(0))
+        skip = self.to_rgb1(out, latent[:, 1], skip=rgbd_in, pre=pre(1))
+        i, j = 1, 2
         for up_conv, conv, n_up, n_conv, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2], noise[2::2],
                                                        self.to_rgbs):
-            out = up_conv(out, latent[:, i], noise=n_up)
-            out = conv(out, latent[:, i + 1], noise=n_conv)
-            skip = to_rgb(out, latent[:, i + 2], skip=skip)
+            out = up_conv(out, latent[:, i], noise=n_up, in_amax=am(i), out_amax=am(i + 1), pre=pre(j))
+            out = conv(out, latent[:, i + 1], noise=n_conv, in_amax=am(i + 1), out_amax=am(i + 2), pre=pre(j + 1))
+            skip = to_rgb(out, latent[:, i + 2], skip=skip, pre=pre(j + 2))
             i += 2
+            j += 3
         return skip, (latent if return_latents else None)
 
 

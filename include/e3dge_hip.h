@@ -86,6 +86,81 @@ int e3dge_modconv_weights(float* out, const float* weight, const float* style, f
                           int demodulate, int transpose, int batch, int co, int ci, int kk,
                           e3dge_stream_t stream);
 
+/*
+ * Fused modulated 3x3 convolution.  Replaces ModulatedConv2d.forward for kernel_size 3
+ * (project/models/stylesdf_model.py:317-362: weight modulation + demodulation + F.conv2d(padding=1, groups=B) or
+ * F.conv_transpose2d(stride=2, groups=B)) and, for the stride-1 layers, StyledConv's NoiseInjection + FusedLeakyReLU
+ * tail (:459-466, :500-507) in the epilogue.  No per-sample weight tensor exists: the style scales the input patch
+ * while it is staged, demod[b,co] scales the accumulators; the contraction runs as split-f16 (hi+lo, 3 products, fp32
+ * accumulate) MFMAs against a weight image packed once per layer.
+ *   e3dge_modconv_packed_words(co, ci): 32-bit words of the image.
+ *   e3dge_modconv_pack_weights: weight (co, ci, 3, 3) [ModulatedConv2d.weight[0]], scale = 1/sqrt(ci*9) (:302) ->
+ *       image, and wsq (co, ci) = sum_k (scale w)^2 for the demodulation.
+ *   e3dge_modconv_demod: style (batch, ci) [= modulation(style), :319] -> demod (batch, co) = rsqrt(sum_ci s^2 wsq + 1e-8)
+ *       (:323-324; skipped when demodulate == 0) and s_amax (batch) = max_ci |s|.
+ *   amax buffers: max|tensor| tracked by the producer of an activation, so the next conv can choose its operand scale
+ *       without re-reading the data: E3DGE_AMAX_FLOATS floats, zero-initialised by the caller; producers atomically max
+ *       into one of E3DGE_AMAX_SLOTS slots (E3DGE_AMAX_STRIDE floats apart), the consumer takes the maximum over the slots.
+ *   e3dge_amax: max|x| of a tensor into such a buffer (for inputs whose producer did not track it).
+ *   e3dge_modconv3x3: x (batch, ci, H, W) -> y (batch, co, H, W), or with upsample (batch, co, 2H+1, 2W+1) = the
+ *       transposed convolution BEFORE the FIR blur.  in_amax: amax buffer with max over slots >= max|x| (operand scaling;
+ *       any upper bound works, a tight one keeps full precision).  act != 0 (stride-1 only):
+ *       y = lrelu(conv * demod + noise_w[0] * noise[b % noise_batch] + bias[co], negative_slope) * act_scale.
+ *       out_amax (optional amax buffer) receives max|y|.  ci %% 16 == 0, co %% 32 == 0.
+ */
+#define E3DGE_AMAX_SLOTS 64
+#define E3DGE_AMAX_STRIDE 32
+#define E3DGE_AMAX_FLOATS (E3DGE_AMAX_SLOTS * E3DGE_AMAX_STRIDE)
+typedef struct E3dgeModconvArgs {
+    const float* x; const uint32_t* wimg; const float* style; const float* demod; const float* in_amax;
+    const float* s_amax; const float* noise; const float* noise_w; const float* bias;
+    float* y; float* out_amax;
+    float negative_slope, act_scale;
+    int act, upsample, batch, ci, co, height, width, noise_batch;
+} E3dgeModconvArgs;
+/* One row of the decoder's modulation table (device-resident array) for e3dge_decoder_styles: all layers' modulation
+ * vectors s = conv.modulation(latent[:, latent_index]) (EqualLinear, stylesdf_model.py:234-244 as used at :319), their
+ * demodulation factors and max|s| in two launches instead of ~4 tiny kernels per layer.  row_start / co_start are the prefix
+ * sums of ci / co over the table (co counts 0 for rows without demod_out). */
+typedef struct E3dgeModLayer {
+    const float* mod_weight;   /* (ci, style_dim)  conv.modulation.weight                                  */
+    const float* mod_bias;     /* (ci)             conv.modulation.bias                                    */
+    const float* wsq;          /* (co, ci) from e3dge_modconv_pack_weights, or NULL                         */
+    float* style_out;          /* (batch, ci) out                                                          */
+    float* demod_out;          /* (batch, co) out, or NULL (ToRGB: no demodulation)                         */
+    float* s_amax_out;         /* (batch) out, or NULL                                                     */
+    int ci, co, latent_index, row_start, co_start;
+    float lin_scale, lr_mul;   /* EqualLinear.scale = lr_mul / sqrt(style_dim), lr_mul                      */
+} E3dgeModLayer;
+int e3dge_decoder_styles(const E3dgeModLayer* table, int n_layers, int total_rows, int total_co, const float* latent,
+                         int n_latent, int style_dim, int batch, e3dge_stream_t stream);
+int64_t e3dge_modconv_packed_words(int co, int ci);
+int e3dge_modconv_pack_weights(uint32_t* image, float* wsq, const float* weight, float scale, int co, int ci,
+                               e3dge_stream_t stream);
+int e3dge_modconv_demod(float* demod, float* s_amax, const float* style, const float* wsq, int batch, int co, int ci,
+                        int demodulate, e3dge_stream_t stream);
+int e3dge_amax(float* out, const float* x, int64_t n, e3dge_stream_t stream);
+int e3dge_modconv3x3(const E3dgeModconvArgs* args, e3dge_stream_t stream);
+
+/*
+ * Blur + StyledConv tail of the up-sampling layers in one pass: y = lrelu(upfirdn2d(x, k, pad=(pad0,pad1)) +
+ * noise_weight[0] * noise + bias[c], alpha) * scale  (stylesdf_model.py:346 then :459-466, :500-507), k a 4x4 FIR.
+ * x (batch, channels, in_h, in_w) -> y (batch, channels, in_h+pad0+pad1-3, ...); noise (noise_batch, out_h*out_w) or NULL;
+ * out_amax: optional amax buffer (see e3dge_modconv3x3) receiving max|y|.
+ */
+int e3dge_blur_noise_bias_act(float* y, const float* x, const float* k, const float* noise, const float* noise_weight,
+                              const float* bias, float alpha, float scale, int64_t batch, int64_t channels, int in_h,
+                              int in_w, int pad0, int pad1, int64_t noise_batch, float* out_amax, e3dge_stream_t stream);
+
+/*
+ * ToRGB.forward (stylesdf_model.py:531-541) in one pass: 1x1 modulated conv without demodulation (weight (3, ci) =
+ * conv.weight[0,:,:,0,0], style (batch, ci) = conv.modulation(style), scale = 1/sqrt(ci)) + bias (3) + the skip image
+ * (batch, 3, H/2, W/2) up-sampled with upfirdn2d(up=2, pad=(2,1)) by the 4x4 FIR `fir` (Upsample.kernel), or NULL.
+ * x (batch, ci, H, W) -> y (batch, 3, H, W).  W %% 4 == 0.
+ */
+int e3dge_torgb(float* y, const float* x, const float* weight, const float* style, const float* bias, const float* skip,
+                const float* fir, float scale, int batch, int ci, int height, int width, e3dge_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * FiLM-SIREN volume renderer (reference: project/utils/volume_renderer.py)
  * ------------------------------------------------------------------------------------------ */

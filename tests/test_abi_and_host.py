@@ -91,6 +91,35 @@ int main(void) {
     assert lib.e3dge_siren_bwd_partial_floats(2, 1000) == 2 * 8 * 9 * 2 * 256     # 8 sub-tiles -> 8 workgroups per image
 
 
+def test_modconv_structs_layout_matches_c():
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "e3dge_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu\n", sizeof(E3dgeModconvArgs), offsetof(E3dgeModconvArgs, out_amax), offsetof(E3dgeModconvArgs, negative_slope),
+         offsetof(E3dgeModconvArgs, act), offsetof(E3dgeModconvArgs, noise_batch));
+  printf("%zu %zu %zu %zu %zu %d\n", sizeof(E3dgeModLayer), offsetof(E3dgeModLayer, s_amax_out), offsetof(E3dgeModLayer, ci),
+         offsetof(E3dgeModLayer, co_start), offsetof(E3dgeModLayer, lr_mul), E3DGE_AMAX_FLOATS);
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), c, "-o", exe], check=True)
+        got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    A, L = _lib.ModconvArgs, _lib.ModLayer
+    assert got == [ctypes.sizeof(A), A.out_amax.offset, A.negative_slope.offset, A.act.offset, A.noise_batch.offset,
+                   ctypes.sizeof(L), L.s_amax_out.offset, L.ci.offset, L.co_start.offset, L.lr_mul.offset, _lib.AMAX_FLOATS]
+    lib = _lib.load()
+    assert lib.e3dge_modconv3x3(None, None) == -1
+    bad = _lib.ModconvArgs(batch=1, ci=24, co=32, height=8, width=8)
+    assert lib.e3dge_modconv3x3(ctypes.byref(bad), None) == -1
+    assert lib.e3dge_modconv_packed_words(64, 32) == 2 * 2 * 9 * 2 * 64 * 4
+    assert lib.e3dge_torgb(None, None, None, None, None, None, None, 1.0, 1, 32, 8, 6, None) == -1
+    assert lib.e3dge_decoder_styles(None, 1, 1, 0, None, 1, 1, 1, None) == -1
+
+
 def test_host_helpers_that_need_no_gpu(lib):
     assert lib.e3dge_upfirdn2d_out_size(129, 1, 1, 1, 1, 4) == 128     # Blur after the 64->129 transposed conv
     assert lib.e3dge_upfirdn2d_out_size(64, 2, 1, 2, 1, 4) == 128      # skip Upsample
