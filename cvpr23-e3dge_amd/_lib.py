@@ -90,6 +90,8 @@ SIGNATURES = {
     "e3dge_resblock_packed_floats": (_i64, []),
     "e3dge_resblock_pack_weights": (_i32, [_vp] * 6 + [_i32, _vp]),
     "e3dge_tex_modulations_fwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
+    "e3dge_local_query": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "e3dge_pos_encoding": (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _vp]),
     "e3dge_selftest_mfma": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "e3dge_selftest_mfma16": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "e3dge_selftest_sin": (_i32, [_vp, _vp, _i32, _vp]),

@@ -352,6 +352,24 @@ int e3dge_tex_modulations_fwd(const float* packed, const float* feats, int cin, 
                               float* alpha, float* beta, e3dge_stream_t stream);
 
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Per-point query of the local branch's feature maps (project/trainers/E3DGE/e3dge_full_runner.py:185-317).
+ *   e3dge_local_query: replaces HGPIFuNetGAN.query(return_feat_only / return_projection_only / im_feat=...)
+ *       (vendor/pifu/lib/model/HGPIFuGANNet.py:85-151) = perspective projection (vendor/pifu/lib/geometry.py:101-129; the
+ *       sign of the depth is decided by the first point of the first sample, as there) + y flip + in-image mask + bilinear
+ *       gather index() (geometry.py:64-80: grid_sample, zeros padding, align_corners=False).
+ *       pts (batch, n_pts, 3) world space; calibs (batch, 3, 4); fmap_nhwc (batch, fh, fw, channels) CHANNEL-LAST, or NULL
+ *       for projection / mask only.  Features go to out[(b*n_pts + n) * ld + col_off + c]; in_img (1.0 / 0.0) to
+ *       in_img[(b*n_pts + n) * mask_ld + mask_off] (NULL = not wanted; may point into the same rows as `out`);
+ *       proj (batch, n_pts, 3) = (x, flipped y, depth) or NULL.  channels %% 4 == 0.
+ *   e3dge_pos_encoding: PosEncoding.forward (project/utils/misc_utils.py:148-185, logscale): pts (n_pts, 3) ->
+ *       out[n * ld + col_off + ...] = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(F-1) x), cos(2^(F-1) x)], 3 (2F+1) columns.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int e3dge_local_query(float* out, int ld, int col_off, float* in_img, int mask_ld, int mask_off, float* proj,
+                      const float* pts, const float* calibs, const float* fmap_nhwc, int batch, int64_t n_pts, int channels,
+                      int fh, int fw, e3dge_stream_t stream);
+int e3dge_pos_encoding(float* out, int ld, int col_off, const float* pts, int64_t n_pts, int n_freqs, e3dge_stream_t stream);
+
 /* Layout self-test: runs a 32x32xK fp32-MFMA product with the fragment conventions the render kernel
  * relies on and writes it to c (32*32 floats, row-major) for the caller to compare with a @ b^T.
  * a: (32, k) row-major, b: (32, k) row-major, k multiple of 8, k <= 256. */

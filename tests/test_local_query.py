@@ -1,0 +1,131 @@
+"""the per-point query of the local branch's feature maps -- projection + bilinear gather + in-image masks +
+positional encoding (HIP) + Fuse_sft_MLP -- against tests/golden/localquery_8x24.npz, recorded from the reference's own
+perspective / index / PosEncoding / Fuse_sft_MLP composed as que_render_given_ref does (oracle/gen_golden_localquery.py).
+
+Stated fp32 tolerance: gathered features are O(3); the projection is evaluated in a different fp32 order than BLAS' baddbmm
+(coordinates differ by ~1e-7, times the map's gradient ~ 30 per unit).  Bound: gathers 2e-5, positional encoding 2e-6,
+fused 301-channel features 1e-4 (the reference itself is 2.3e-5 from float64), masks identical."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, maxerr, record
+from oracle import local_ref
+
+import e3dge_amd  # noqa: F401
+from e3dge_amd import synthetic as syn
+
+PREFIX = 'Fuse_sft_block.'
+
+
+def fuse_state():
+    from e3dge_amd.local_query import Fuse_sft_MLP
+    m = Fuse_sft_MLP(257, 256)
+    sd = {}
+    for k, v in m.state_dict().items():
+        t = syn.synthetic_tensor(PREFIX + k, v.shape)
+        sd[k] = t / np.sqrt(v.shape[1]) if k.endswith('weight') else t
+    m.load_state_dict(sd)
+    return m, {PREFIX + k: v for k, v in sd.items()}
+
+
+def maps_of(g):
+    rs = np.random.RandomState(int(g['maps_seed']))
+    shp = tuple(int(v) for v in g['map_shape'])
+    ref_map = torch.from_numpy(rs.standard_normal(shp).astype(np.float32))
+    que_map = torch.from_numpy(rs.standard_normal(shp).astype(np.float32))
+    return ref_map, que_map
+
+
+def test_oracle_reproduces_the_reference_local_features():
+    g = load_golden("localquery_8x24")
+    _, sd = fuse_state()
+    ref_map, que_map = maps_of(g)
+    T = torch.from_numpy
+    with torch.no_grad():
+        feats, mask = local_ref.local_features(sd, PREFIX, T(g['points']), T(g['xyz']), ref_map, que_map, T(g['ref_calibs']), T(g['que_calibs']))
+        q = local_ref.query(T(g['points']).reshape(2, -1, 3).permute(0, 2, 1), T(g['ref_calibs']), ref_map)
+    assert maxerr(feats[:, :, :, ::4], g['ref_feats_s4']) == 0
+    assert np.array_equal(mask.reshape(2, -1).numpy(), g['ref_in_img'])
+    assert maxerr(q['proj_xy'], g['ref_proj_xy']) == 0 and maxerr(q['depth'], g['ref_depth']) == 0
+
+
+@pytest.mark.gpu
+def test_local_query_kernels_and_pipeline_on_gpu():
+    from e3dge_amd.local_query import local_features_from_maps, pos_encoding, query_feature_map
+    dev = "cuda:0"
+    g = load_golden("localquery_8x24")
+    fuse, sd = fuse_state()
+    fuse = fuse.to(dev).eval()
+    ref_map, que_map = maps_of(g)
+    T = lambda k: torch.from_numpy(g[k]).to(dev)
+    pts5 = T('points')
+    B, H, W, S, _ = pts5.shape
+    pts = pts5.reshape(B, -1, 3)
+    with torch.no_grad():
+        f3, in_img, proj = query_feature_map(pts, T('ref_calibs'), ref_map.to(dev), want_proj=True)
+        f2, _, _ = query_feature_map(pts, T('que_calibs'), que_map.to(dev))
+        pe = pos_encoding(pts5)
+        feats, mask = local_features_from_maps(dict(feature_maps=dict(ref=ref_map.to(dev), que=que_map.to(dev)), ref_calibs=T('ref_calibs'),
+                                                    que_calibs=T('que_calibs'), points=pts5, xyz=T('xyz'), fuse_sft_block=fuse))
+    e = dict(f3=maxerr(f3.reshape(B, H, W, S, -1)[:, :, :, ::12], g['ref_feature_3dprojection_s12']),
+             f2=maxerr(f2.reshape(B, H, W, S, -1)[:, :, :, ::12], g['ref_feature_2dalign_s12'][..., :256]),
+             proj_xy=maxerr(proj[..., :2].permute(0, 2, 1), g['ref_proj_xy']), depth=maxerr(proj[..., 2:3].permute(0, 2, 1), g['ref_depth']),
+             pe=maxerr(pe[:, :, :, ::4], g['ref_pe_s4']), feats=maxerr(feats[:, :, :, ::4], g['ref_feats_s4']),
+             feats_vs_f64=maxerr(feats[:, :, :, ::4], g['f64_feats_s4']),
+             ref_vs_f64=float(np.abs(g['ref_feats_s4'] - g['f64_feats_s4']).max()))
+    record("localquery_8x24", **e)
+    # points whose projection sits within 1e-6 of the image border may flip the mask; none do on this fixture
+    assert np.array_equal(in_img.cpu().numpy().astype(bool), g['ref_in_img']) and torch.equal(mask.reshape(B, -1), in_img)
+    assert e['proj_xy'] <= 2e-6 and e['depth'] <= 1e-6 and e['pe'] <= 2e-6, e
+    assert e['f3'] <= 2e-5 and e['f2'] <= 2e-5, e
+    assert e['feats'] <= 1e-4 and e['feats_vs_f64'] <= 3 * e['ref_vs_f64'] + 2e-5, e
+    assert tuple(feats.shape) == (B, H, W, S, 301)
+    # edge cases: projection only, points far outside every image (zeros padding), empty point set
+    far = torch.tensor([[[5.0, 5.0, 0.0], [0.0, 0.0, 0.0]]], device=dev)
+    with torch.no_grad():
+        fz, mz, _ = query_feature_map(far, T('ref_calibs')[:1], ref_map[:1].to(dev))
+        none, m0, _ = query_feature_map(pts[:, :0], T('ref_calibs'), ref_map.to(dev))
+        only_mask = query_feature_map(pts, T('ref_calibs'))[1]
+    assert float(fz[0, 0].abs().max()) == 0.0 and float(mz[0, 0]) == 0.0 and none.shape == (B, 0, 256)
+    assert torch.equal(only_mask, in_img)
+
+
+@pytest.mark.gpu
+def test_second_pass_from_feature_maps():
+    """VolumeFeatureRenderer.forward with local_data_batch={'feature_maps': ...}: query kernels -> Fuse_sft_MLP -> fused
+    texture head -> tex-FiLM render, against the oracle's render with the oracle's (alpha, beta)."""
+    from conftest import full_state_dict
+    from oracle import renderer_ref
+    from e3dge_amd.volume_renderer import VolumeFeatureRenderer
+    dev = "cuda:0"
+    g = load_golden("localquery_8x24")
+    res, S = 8, 24
+    fuse, fsd = fuse_state()
+    fuse = fuse.to(dev).eval()
+    _, sd = full_state_dict(res=res, n_samples=S)
+    r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S, enable_local_model=True, L_pred_tex_modulations=True), out_im_res=res, mode='test')
+    TP = 'renderer.network.netLocal.local_feat_to_tex_modulations_linear.'
+    own = {}
+    for k in r.state_dict():
+        own[k] = 0.05 * syn.synthetic_tensor('renderer.' + k, r.state_dict()[k].shape) if 'netLocal' in k else sd['renderer.' + k.replace('network.netGlobal.', 'network.')]
+    r.load_state_dict(own)
+    r = r.to(dev)
+    sd_all = dict(sd)
+    sd_all.update({'renderer.' + k: v for k, v in own.items() if 'netLocal' in k})
+    ref_map, que_map = maps_of(g)
+    T = lambda k: torch.from_numpy(g[k]).to(dev)
+    wr, _ = syn.synthetic_inputs(2, seed=int(g['styles_seed']), device=dev)
+    cam = (T('poses'), T('focal'), T('near'), T('far'))
+    with torch.no_grad():
+        p1 = r(*cam, styles=wr)
+        out = r(*cam, styles=wr, local_data_batch=dict(feature_maps=dict(ref=ref_map.to(dev), que=que_map.to(dev)), ref_calibs=T('ref_calibs'),
+                                                       que_calibs=T('que_calibs'), points=p1['points'], xyz=p1['xyz'], fuse_sft_block=fuse))
+        c = lambda t: t.detach().cpu()
+        feats, _ = local_ref.local_features(fsd, PREFIX, c(p1['points']), c(p1['xyz']), ref_map, que_map, c(T('ref_calibs')), c(T('que_calibs')))
+        tex = renderer_ref.tex_modulations(sd_all, TP, feats)
+        ref = renderer_ref.render(sd, *[c(t) for t in cam], c(wr), res=res, n_samples=S, tex=tex)
+    e = dict(features=maxerr(out['features'], ref['features']), rgb=maxerr(out['gen_thumb_imgs'], ref['gen_thumb_imgs']),
+             tex_effect=maxerr(ref['features'], c(p1['features'])))
+    record("second_pass_from_feature_maps", **e)
+    assert e['tex_effect'] > 1e-2 and e['features'] <= 1e-4 and e['rgb'] <= 5e-6, e
