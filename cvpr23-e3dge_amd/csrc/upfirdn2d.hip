@@ -59,10 +59,16 @@ upfirdn2d_tiled_kernel(float* __restrict__ y, const float* __restrict__ x,
 
     // ---- stage U (zero-inserted, padded) ----
     const int gy0 = oy0 * DN - g.pad_y0, gx0 = ox0 * DN - g.pad_x0;   // U-tile origin in up-sampled coords
-    for (int e = threadIdx.x; e < UH * PITCH; e += kUpThreads) {
+    // two phases so that all of a thread's loads are in flight together (a load -> LDS-store loop serialises on the HBM
+    // latency: one outstanding load per thread)
+    constexpr int NST = (UH * PITCH + kUpThreads - 1) / kUpThreads;
+    float sv[NST];
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+        const int e = threadIdx.x + it * kUpThreads;
         const int r = e / PITCH, c = e - r * PITCH;
         float v = 0.0f;
-        if (c < UW) {
+        if (e < UH * PITCH && c < UW) {
             const int sy = gy0 + r, sx = gx0 + c;
             if (sy >= 0 && sx >= 0) {
                 int iy = sy, ix = sx;
@@ -74,7 +80,12 @@ upfirdn2d_tiled_kernel(float* __restrict__ y, const float* __restrict__ x,
                 if (ok && iy < g.in_h && ix < g.in_w) v = xp[(int64_t)iy * g.in_w + ix];
             }
         }
-        u[e] = v;
+        sv[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+        const int e = threadIdx.x + it * kUpThreads;
+        if (e < UH * PITCH) u[e] = sv[it];
     }
     // flipped taps, wave-uniform
     float kf[KH][KW];
@@ -119,11 +130,22 @@ upfirdn2d_tiled_kernel(float* __restrict__ y, const float* __restrict__ x,
             const int ox = ox0 + tx * 4;
             float* dst = yp + (int64_t)oy * g.out_w + ox;
             if (EPI) {
+                float nzv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (e_nz) {
+                    const float* np_ = e_nz + (int64_t)oy * g.out_w + ox;
+                    if ((g.out_w & 3) == 0 && ox + 3 < g.out_w && (reinterpret_cast<uintptr_t>(e_nz) & 15) == 0) {
+                        const float4 q = *reinterpret_cast<const float4*>(np_);
+                        nzv[0] = q.x; nzv[1] = q.y; nzv[2] = q.z; nzv[3] = q.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (ox + j < g.out_w) nzv[j] = np_[j];
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (ox + j < g.out_w) {
                         float v = acc[j];
-                        if (e_nz) v = __fadd_rn(v, __fmul_rn(e_nw, e_nz[(int64_t)oy * g.out_w + ox + j]));   // same rounding as noise_bias_act
+                        if (e_nz) v = __fadd_rn(v, __fmul_rn(e_nw, nzv[j]));   // same rounding as noise_bias_act
                         if (ep.bias) v = v + e_b;
                         v = (v > 0.0f ? v : v * ep.alpha) * ep.scale;
                         acc[j] = v;

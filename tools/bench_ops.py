@@ -45,6 +45,29 @@ with torch.no_grad():
         t = timeit(lambda: op.upfirdn2d(s, k4, up=2, pad=(2, 1)))
         by = 4 * (s.numel() + 3 * 4 * L * L)
         cases.append(dict(op="upfirdn2d skip upsample (up2,4x4)", shape=[3, L, L], bytes=by, us=t * 1e6, GBps=by / t / 1e9))
+# round 2: the fused kernels of the decoder path
+from e3dge_amd import _lib  # noqa: E402
+from e3dge_amd.stylesdf_model import StyledConv, ToRGB  # noqa: E402
+lib = _lib.load()
+with torch.no_grad():
+    for C, L in [(256, 128), (128, 256), (64, 512), (32, 1024)]:
+        x = torch.randn(1, C, L + 1, L + 1, device=dev)
+        y = torch.empty(1, C, L, L, device=dev)
+        nz = torch.randn(1, L * L, device=dev); nw = torch.full((1,), 0.1, device=dev); b = torch.randn(C, device=dev)
+        am = torch.zeros(_lib.AMAX_FLOATS, device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        t = timeit(lambda: lib.e3dge_blur_noise_bias_act(y.data_ptr(), x.data_ptr(), k4.data_ptr(), nz.data_ptr(), nw.data_ptr(), b.data_ptr(),
+                                                         0.2, 2 ** 0.5, 1, C, L + 1, L + 1, 1, 1, 1, am.data_ptr(), st))
+        by = 4 * (x.numel() + y.numel() + nz.numel())
+        cases.append(dict(op="blur+noise+bias+lrelu (+amax), one pass", shape=[C, L + 1, L + 1], bytes=by, us=t * 1e6, GBps=by / t / 1e9))
+    for C, L in [(512, 64), (256, 128), (128, 256), (64, 512), (32, 1024)]:
+        m = ToRGB(C, 512, upsample=True).to(dev).eval()
+        x = torch.randn(1, C, L, L, device=dev); style = torch.randn(1, 512, device=dev)
+        skip = torch.randn(1, 3, L // 2, L // 2, device=dev)
+        t = timeit(lambda: m(x, style, skip=skip))
+        by = 4 * (x.numel() + 3 * L * L + skip.numel())
+        cases.append(dict(op="ToRGB fused (1x1 modconv + bias + up-sampled skip; includes the modulation GEMV launch)", shape=[C, L, L],
+                          bytes=by, us=t * 1e6, GBps=by / t / 1e9))
 for c in cases:
     c["frac_of_8TBps"] = c["GBps"] / 8000.0
     print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()}))

@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 # only the headline workload in the profiled process: the informational legs launch the same kernels at other sizes
-BENCH="python $PWD/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-c4 --no-train-step --no-inversion $*"
+BENCH="python $PWD/bench.py --steps 30 --warmup 5 --headline-only $*"
 cd /tmp
 echo "== kernel trace" 
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1
@@ -33,7 +33,7 @@ st = find("trace/**/*kernel_stats.csv")
 if st:
     rows = list(csv.DictReader(open(st)))
     with open(os.path.join(out, "kernel_stats_summary.txt"), "w") as f:
-        f.write("rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-c4 --no-train-step --no-inversion\n")
+        f.write("rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --headline-only\n")
         f.write(f"{'kernel':<90} {'calls':>6} {'total_ns':>14} {'avg_ns':>12} {'pct':>7}\n")
         for r in rows[:40]:
             f.write(f"{r['Name'][:90]:<90} {r['Calls']:>6} {r['TotalDurationNs']:>14} {float(r['AverageNs']):>12.0f} {r['Percentage']:>7}\n")
@@ -56,6 +56,16 @@ with open(os.path.join(out, "pmc_summary.txt"), "w") as f:
                 for cn, (tot, n) in sorted(cs.items()):
                     f.write(f"    {cn:<32} mean/dispatch = {tot / max(n,1):.6g}   (n={n})\n")
 print(open(os.path.join(out, "pmc_summary.txt")).read())
+# HBM traffic of the render kernel for bench.py's roofline.traffic (profiles/traffic_pmc.json is assembled from these)
+import json, re
+vals = {}
+txt = open(os.path.join(out, "pmc_summary.txt")).read()
+for blk in re.split(r"\n(?=\S)", txt):
+    if "siren_kernel<0" in blk:
+        for m in re.finditer(r"(FETCH_SIZE|WRITE_SIZE)\s+mean/dispatch = ([0-9.e+]+)", blk):
+            vals[m.group(1) + "_KB"] = float(m.group(2))
+json.dump(vals, open(os.path.join(out, "traffic.json"), "w"))
+print("traffic:", vals)
 PY
 ( cd "$OUT" && find . -type f | head -60 > "$OUT/files.txt"; cat "$OUT/files.txt" )
 # keep the merge-back small: drop anything above 2 MB (raw traces, databases)
