@@ -23,6 +23,7 @@
 //     LDS across the 128-point sub-tiles of a workgroup's ray block, so rays x samples can be tiled
 //     without aligning rays to tiles.
 #include "siren_common.h"
+#include "siren16.h"
 
 namespace e3dge {
 
@@ -763,6 +764,26 @@ siren_pack_kernel(float* __restrict__ packed, const float* __restrict__ w_first,
         } else if (e < kOffBig16) {
             const int r = (int)(e - kOffBHead);
             v = (r == 0) ? b_sigma[0] : b_rgb[r - 1];
+        } else if (e >= kOffBig16b) {
+            // 16x16x32 image (siren_common.h): [Lb][16 t][8 g][hl][lane][word k]
+            int64_t r = e - kOffBig16b;
+            const int k = r & 3; r >>= 2;
+            const int lane = r & 63; r >>= 6;
+            const int hl = r & 1; r >>= 1;
+            const int g = r & 7; r >>= 3;
+            const int t = r & 15; r >>= 4;
+            const int Lb = (int)r;
+            const int n = 16 * t + (lane & 15), q = lane >> 4;
+            unsigned word = 0;
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const int j = 2 * k + e2;
+                const int kk = 32 * g + 16 * (j >> 2) + 4 * q + (j & 3);
+                const float w = kW16Scale * ((Lb < 7) ? w_hidden[((int64_t)Lb * kWidth + n) * kWidth + kk] : w_view[(int64_t)n * 259 + kk]);
+                const _Float16 hi = (_Float16)w;
+                const _Float16 val = hl ? (_Float16)(w - (float)hi) : hi;
+                word |= (unsigned)__builtin_bit_cast(unsigned short, val) << (16 * e2);
+            }
+            v = __uint_as_float(word);
         } else if (e >= kOffBigT16) {
             // transposed f16x3 image: out row kin = 32t + (lane & 31), contraction index nn in the k-slot order of kOffBig16
             int64_t r = e - kOffBigT16;
@@ -906,9 +927,20 @@ __global__ void selftest_sin_kernel(float* __restrict__ y, const float* __restri
 template <int MODE>
 static int launch_siren(const SirenK& k, int precision, int64_t grid, hipStream_t st) {
     typedef void (*KernelFn)(const SirenK);
+    const int save = k.save_args != nullptr;
+    if (precision == E3DGE_PREC_F16X3) {
+        // second-generation split-f16 kernel: 8 waves x 16 points, v_mfma_f32_16x16x32_f16 (siren16.h)
+        static const KernelFn fns16[2] = {&siren16_kernel<MODE, false>, &siren16_kernel<MODE, true>};
+        const KernelFn fn = fns16[save];
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, k16LdsBytes);
+        if (e != hipSuccess)
+            return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", k16LdsBytes, hipGetErrorString(e));
+        fn<<<dim3((unsigned)grid), dim3(k16Threads), k16LdsBytes, st>>>(k);
+        return E3DGE_OK;
+    }
     static const KernelFn fns[4] = {&siren_kernel<MODE, 0, false>, &siren_kernel<MODE, 0, true>,
                                     &siren_kernel<MODE, 1, false>, &siren_kernel<MODE, 1, true>};
-    const KernelFn fn = fns[2 * (precision == E3DGE_PREC_F16X3) + (k.save_args != nullptr)];
+    const KernelFn fn = fns[2 * (precision == E3DGE_PREC_F16X3_V1) + save];
     // the attribute is per device; setting it on every launch is cheap and keeps multi-GPU processes correct
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e != hipSuccess)
@@ -916,6 +948,7 @@ static int launch_siren(const SirenK& k, int precision, int64_t grid, hipStream_
     fn<<<dim3((unsigned)grid), dim3(kThreads), kLdsBytes, st>>>(k);
     return E3DGE_OK;
 }
+
 // rays per workgroup: the largest R <= kRMax whose R*S is a multiple of 128 if one exists (no padded
 // lanes), else the R <= kRMax minimising padding; small images get fewer rays per workgroup so that the
 // grid still covers the 256 CUs.
@@ -979,7 +1012,7 @@ extern "C" int e3dge_siren_render_fwd(const E3dgeRenderArgs* r, e3dge_stream_t s
                     reinterpret_cast<uintptr_t>(r->tex_alpha) | reinterpret_cast<uintptr_t>(r->tex_beta)) & 15) == 0,
                   "siren_render_fwd: packed/film/tex pointers must be 16-B aligned");
     E3DGE_REQUIRE(r->sigmoid_beta != 0.0f, "siren_render_fwd: sigmoid_beta must be non-zero");
-    E3DGE_REQUIRE(r->precision == E3DGE_PREC_F32 || r->precision == E3DGE_PREC_F16X3, "siren_render_fwd: precision=%d", r->precision);
+    E3DGE_REQUIRE(r->precision == E3DGE_PREC_F32 || r->precision == E3DGE_PREC_F16X3 || r->precision == E3DGE_PREC_F16X3_V1, "siren_render_fwd: precision=%d", r->precision);
     if (r->batch == 0) return E3DGE_OK;
     const int64_t HW = (int64_t)r->height * r->width;
     E3DGE_REQUIRE(HW * r->batch * (int64_t)r->n_samples < ((int64_t)1 << 40), "siren_render_fwd: too many points");
@@ -1004,7 +1037,7 @@ extern "C" int e3dge_siren_render_fwd(const E3dgeRenderArgs* r, e3dge_stream_t s
 extern "C" int e3dge_siren_points_fwd(const float* packed, const float* film, const float* pts,
                                       const float* viewdirs, float box_scale, int batch, int64_t n_pts,
                                       float* sdf, float* raw, float* save_args, int precision, e3dge_stream_t stream) {
-    E3DGE_REQUIRE(precision == E3DGE_PREC_F32 || precision == E3DGE_PREC_F16X3, "siren_points_fwd: precision=%d", precision);
+    E3DGE_REQUIRE(precision == E3DGE_PREC_F32 || precision == E3DGE_PREC_F16X3 || precision == E3DGE_PREC_F16X3_V1, "siren_points_fwd: precision=%d", precision);
     E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "siren_points_fwd: bad sizes");
     if (batch == 0 || n_pts == 0) return E3DGE_OK;
     E3DGE_REQUIRE(packed && film && pts, "siren_points_fwd: null input pointer");
@@ -1039,6 +1072,12 @@ extern "C" int e3dge_selftest_mfma16(float* c, const float* a, const float* b, i
     E3DGE_REQUIRE(c && a && b && k > 0 && k <= 256 && (k % 16) == 0, "selftest_mfma16: bad arguments");
     selftest_mfma16_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(c, a, b, k);
     return check_launch("selftest_mfma16");
+}
+
+extern "C" int e3dge_selftest_mfma16x16(float* c, const float* a, const float* b, int k, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(c && a && b && k > 0 && k <= 256 && (k % 32) == 0, "selftest_mfma16x16: bad arguments");
+    selftest_mfma16x16_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(c, a, b, k);
+    return check_launch("selftest_mfma16x16");
 }
 
 extern "C" int e3dge_selftest_sin(float* y, const float* x, int n, e3dge_stream_t stream) {

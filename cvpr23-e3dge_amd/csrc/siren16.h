@@ -1,0 +1,688 @@
+// The split-f16 ("f16x3") fused renderer, second generation: 8 waves per workgroup (two per SIMD), 16 points per wave,
+// v_mfma_f32_16x16x32_f16.  Included by siren.hip (shares its launch code); see siren.hip for the reference lines of every
+// phase and DESIGN.md 4.1c for the numbers.
+//
+// Why: the first f16x3 kernel (one wave per SIMD, 32 points per wave, 32x32x16 MFMAs) keeps the matrix pipe 41 % busy -- with a
+// single wave on a SIMD every weight-fragment ds_read, every epilogue VALU op and every thin phase between the layers comes
+// straight out of the MFMA stream.  Halving the points per wave halves the register-resident state (64 + 64 registers of
+// packed f16 hi/lo activations instead of 128 + 128), so two waves fit on a SIMD and one wave's LDS reads / epilogue run
+// under the other's MFMAs.  Price: every wave still reads the whole weight chunk for its (now 16) points, so LDS read
+// traffic per point doubles (to ~60 % of the 256 B/clk ds_read_b128 rate) -- affordable, because the LDS itself was never
+// the bottleneck, the single wave's issue stream was.
+//
+// Fragment conventions (validated on the GPU by e3dge_selftest_mfma16x16): lane l, n = l & 15, q = l >> 4
+//   A (16 x 32): row n, k = 8q + j          B (32 x 16): column n, k = 8q + j          C/D (16 x 16): column n, rows 4q + r
+// Standard layers: A = weights (16 out features x 32 k), B = activations (32 k x 16 points): D[feature 16t + 4q + r][point n].
+// A lane's C/D registers of the tiles 2g, 2g+1 (features 32g + 16e + 4q + r) are its 8 k-slots of k-step g of the next layer
+// -- the weight image (kOffBig16b) is packed in that k order, so activations never leave the registers.
+// View layer: the same registers as the A operand, weights as B: D[point 4q + r][feature n] (features on lanes).
+#pragma once
+#include "siren_common.h"
+
+namespace e3dge {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int k16Threads = 512;
+constexpr int k16Tiles = 16;                     // 16-feature output tiles per layer
+constexpr int k16Steps = 8;                      // k-steps of 32 per tile
+constexpr int k16ChunkFloats = 16 * kWidth;      // one tile x K = 256: 16 KiB
+constexpr int k16Chunks = kBigLayers * k16Tiles; // 128 chunks per 128-point sub-tile
+constexpr int k16NBuf = 4;                       // LDS weight buffers (chunk g+3 is issued while tile g computes)
+constexpr int k16Slots = 2;                      // rays a 16-point slab can touch when S >= 16
+constexpr int k16Ring = 4;                       // k-steps of (hi, lo) fragments held in registers
+
+// ---- LDS carve (floats) ----
+constexpr int k16LdsW = 0;
+constexpr int k16LdsFilm = k16LdsW + k16NBuf * k16ChunkFloats;        // [9][2][256]
+constexpr int k16LdsHead = k16LdsFilm + 9 * 2 * kWidth;               // w_sigma[256], w_rgb[3][256], b_sigma, b_rgb[3]
+constexpr int k16LdsW0 = k16LdsHead + kHeadFloats;                    // [3][256] first-layer weights, column-major
+constexpr int k16LdsWvt = k16LdsW0 + 3 * kWidth;                      // [3][256] view-direction columns of the view layer, x128
+constexpr int k16LdsFeat = k16LdsWvt + 3 * kWidth;                    // [kRMax][kFPitch]
+constexpr int k16LdsPart = k16LdsFeat + kRMax * kFPitch;              // [8 waves][2 slots][256]
+constexpr int k16LdsAlpha = ((k16LdsPart + 8 * k16Slots * kWidth + 3) / 4) * 4;
+constexpr int k16LdsWgt = k16LdsAlpha + kTilePts;
+constexpr int k16LdsZ = k16LdsWgt + kTilePts;
+constexpr int k16LdsPts = k16LdsZ + kTilePts;                         // [128][3]
+constexpr int k16LdsRgb = k16LdsPts + kTilePts * 3;                   // [128][3]
+constexpr int k16LdsState = k16LdsRgb + kTilePts * 3;                 // [kRMax][12]
+constexpr int k16LdsWq = ((k16LdsState + kRMax * kStateStride + 3) / 4) * 4;   // [8 waves][2 slots][16 rows]
+constexpr int k16LdsVd = k16LdsWq + 8 * k16Slots * 16;                // [8 waves][16 points][4]: view direction (padded)
+constexpr int k16LdsFloats = k16LdsVd + 8 * 16 * 4;
+constexpr int k16LdsBytes = k16LdsFloats * 4;
+static_assert(k16LdsBytes <= 160 * 1024, "LDS budget");
+static_assert((k16LdsFilm % 4) == 0 && (k16LdsHead % 4) == 0 && (k16LdsW0 % 4) == 0 && (k16LdsWvt % 4) == 0, "alignment");
+
+__device__ __forceinline__ f32x4v mfma16x16(u32x4 a, u32x4 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4v zero4() { return f32x4v{0.f, 0.f, 0.f, 0.f}; }
+// acc + w * (f16 half `HI` of the packed word p), one instruction
+template <int HI> __device__ __forceinline__ float fma_mix_h(unsigned p, float w, float acc) {
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(w), "v"(acc));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p), "v"(w), "v"(acc));
+    return r;
+}
+// value r (0..3) of 16-feature tile t from the packed (hi, lo) activations
+__device__ __forceinline__ float act16_get(const u32x4 (&aH)[k16Steps], const u32x4 (&aL)[k16Steps], int t, int r) {
+    const int g = t >> 1, w = 2 * (t & 1) + (r >> 1);
+    return (r & 1) ? f16hi(aH[g][w]) + f16hi(aL[g][w]) : f16lo(aH[g][w]) + f16lo(aL[g][w]);
+}
+template <int CTRL> __device__ __forceinline__ float dpp16(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a row (every lane of the row gets the total)
+__device__ __forceinline__ float row_sum16(float x) {
+    x += dpp16<0x128>(x);    // row_ror:8
+    x += dpp16<0x124>(x);    // row_ror:4
+    x += dpp16<0x122>(x);    // row_ror:2
+    x += dpp16<0x121>(x);    // row_ror:1
+    return x;
+}
+
+// 16-KiB weight chunks through four LDS buffers; every wave moves a 2-KiB slice (two LDS-DMA pieces) of each chunk.
+//   tile g: sync() -> wait for everything but the chunk issued one tile ago, barrier (publishes chunk g+2, proves tile g-1
+//   is finished) -> issue chunk g+3 into the buffer tile g-1 used.  A chunk therefore has two tile times to arrive.
+struct ChunkPipe16 {
+    const char* img;
+    uint32_t voff, lds_base;
+    int idx, buf, use_buf;
+    float* wbuf;
+    const float* wcur;
+    const float* wnxt;
+    __device__ __forceinline__ void init(float* wbuf_, const float* image, int wave, int lane) {
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        wbuf = wbuf_;
+        img = reinterpret_cast<const char*>(image) + wave_u * 2048;
+        voff = (uint32_t)lane * 16u;
+        lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) float*)wbuf_ + (uint32_t)wave_u * 2048u;
+        idx = 0; buf = 0; use_buf = 0;
+        wcur = wbuf_; wnxt = wbuf_ + k16ChunkFloats;
+    }
+    __device__ __forceinline__ void issue_chunk() {
+        const char* s = img + (size_t)idx * (k16ChunkFloats * 4);
+        const uint32_t d = lds_base + (uint32_t)buf * (k16ChunkFloats * 4);
+        glds16_saddr<0>(s, voff, d);
+        glds16_saddr<1024>(s, voff, d);
+        idx = (idx + 1 == k16Chunks) ? 0 : idx + 1;
+        buf = (buf + 1 == k16NBuf) ? 0 : buf + 1;
+    }
+    __device__ __forceinline__ void prime() {
+        issue_chunk(); issue_chunk(); issue_chunk();
+    }
+    template <bool STRICT> __device__ __forceinline__ void sync() {
+        // STRICT (training: the epilogue's argument stores share vmcnt): wait for everything
+        if (STRICT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        __syncthreads();
+    }
+    __device__ __forceinline__ void advance() {
+        use_buf = (use_buf + 1 == k16NBuf) ? 0 : use_buf + 1;
+        wcur = wnxt;
+        wnxt = wbuf + ((use_buf + 1 == k16NBuf) ? 0 : use_buf + 1) * k16ChunkFloats;
+    }
+};
+
+// K = 256 contraction of one 16-feature tile: 8 k-steps x (hi*hi, lo*hi, hi*lo) on two alternating accumulators.
+// On entry the ring holds k-steps 0..2 of this chunk; on exit k-steps 0..2 of the next one.
+template <bool TRANSPOSED, bool STRICT, class Epi>
+__device__ __forceinline__ void tile16(ChunkPipe16& pipe, int lane, const u32x4 (&aH)[k16Steps], const u32x4 (&aL)[k16Steps],
+                                       f32x4v& acc, f32x4v& accb, u32x4 (&ringH)[k16Ring], u32x4 (&ringL)[k16Ring], Epi&& epi) {
+    const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(pipe.wcur) + lane;
+    const u32x4* __restrict__ wn = reinterpret_cast<const u32x4*>(pipe.wnxt) + lane;
+#pragma unroll
+    for (int g = 0; g < k16Steps; ++g) {
+        const int ga = g + k16Ring - 1;
+        ringH[ga % k16Ring] = (ga < k16Steps) ? wp[(ga * 2 + 0) * 64] : wn[((ga - k16Steps) * 2 + 0) * 64];
+        ringL[ga % k16Ring] = (ga < k16Steps) ? wp[(ga * 2 + 1) * 64] : wn[((ga - k16Steps) * 2 + 1) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x4 wh = ringH[g % k16Ring], wl = ringL[g % k16Ring];
+        f32x4v& x0 = (g & 1) ? accb : acc;
+        f32x4v& x1 = (g & 1) ? acc : accb;
+        if (!TRANSPOSED) {
+            x0 = mfma16x16(wh, aH[g], x0);
+            x1 = mfma16x16(wl, aH[g], x1);
+            x0 = mfma16x16(wh, aL[g], x0);
+        } else {
+            x0 = mfma16x16(aH[g], wh, x0);
+            x1 = mfma16x16(aH[g], wl, x1);
+            x0 = mfma16x16(aL[g], wh, x0);
+        }
+        if (g == 1) {
+            pipe.template sync<STRICT>();
+            pipe.issue_chunk();
+        }
+        epi(g);
+    }
+}
+
+template <int MODE, bool SAVE>
+__global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const wbuf = smem + k16LdsW;
+    float* const film_s = smem + k16LdsFilm;
+    float* const head_s = smem + k16LdsHead;
+    float* const w0_s = smem + k16LdsW0;
+    float* const wvt_s = smem + k16LdsWvt;
+    float* const feat_acc = smem + k16LdsFeat;
+    float* const part = smem + k16LdsPart;
+    float* const alpha_s = smem + k16LdsAlpha;
+    float* const wgt_s = smem + k16LdsWgt;
+    float* const z_s = smem + k16LdsZ;
+    float* const pts_s = smem + k16LdsPts;
+    float* const rgb_s = smem + k16LdsRgb;
+    float* const state = smem + k16LdsState;
+
+    const int tid_k = threadIdx.x;
+    // ---- work assignment (as siren_kernel) ----
+    int b, npts, n_sub;
+    int pix0 = 0, nrays = 0;
+    long long pt0 = 0;
+    const int S = (MODE == 0) ? a.S : 1;
+    if (MODE == 0) {
+        b = blockIdx.x / a.tiles_per_img;
+        const int tile = blockIdx.x - b * a.tiles_per_img;
+        const int HW = a.H * a.Wd;
+        pix0 = tile * a.R;
+        nrays = min(a.R, HW - pix0);
+        npts = nrays * S;
+    } else {
+        b = blockIdx.x / a.wgs_per_img;
+        const int wg = blockIdx.x - b * a.wgs_per_img;
+        pt0 = (long long)wg * a.subtiles_per_wg * kTilePts;
+        const long long rem = a.n_pts - pt0;
+        npts = (int)(rem < (long long)a.subtiles_per_wg * kTilePts ? rem : (long long)a.subtiles_per_wg * kTilePts);
+    }
+    n_sub = (npts + kTilePts - 1) / kTilePts;
+
+    const float* __restrict__ packed = a.packed;
+    const float* __restrict__ film_g = a.film + (int64_t)b * 9 * 2 * kWidth;
+    // FiLM block with the layer bias folded into the offset and the weights' factor 128 divided out of gamma (layers >= 1)
+    for (int i = tid_k; i < 9 * kWidth; i += k16Threads) {
+        const int l = i >> 8, n = i & 255;
+        const float gm = film_g[(l * 2 + 0) * kWidth + n], bt = film_g[(l * 2 + 1) * kWidth + n];
+        film_s[(l * 2 + 0) * kWidth + n] = (l >= 1) ? gm * (1.0f / kW16Scale) : gm;
+        film_s[(l * 2 + 1) * kWidth + n] = __fadd_rn(__fmul_rn(gm, packed[kOffBias + l * kWidth + n]), bt);
+    }
+    for (int i = tid_k; i < kHeadFloats; i += k16Threads) head_s[i] = packed[kOffWSigma + i];
+    for (int i = tid_k; i < 3 * kWidth; i += k16Threads) {
+        const int c = i >> 8, n = i & 255;           // fragment images of layer 0 / the view tail: [t][m][lane], k = 2m + half
+        const int src = ((n >> 5) * 2 + (c >> 1)) * 64 + (c & 1) * 32 + (n & 31);
+        w0_s[i] = packed[kOffFirst + src];
+        wvt_s[i] = packed[kOffVTail + src] * kW16Scale;
+    }
+    float cw[12] = {0}, focal = 1.f, nearv = 0.f, farv = 0.f;
+    if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) cw[i] = a.c2w[b * 12 + i];
+        focal = a.focal[b]; nearv = a.near[b]; farv = a.far[b];
+        for (int i = tid_k; i < kRMax * kStateStride; i += k16Threads) state[i] = 0.0f;
+        for (int i = tid_k; i < kRMax * kFPitch; i += k16Threads) feat_acc[i] = 0.0f;
+    }
+    const float* __restrict__ film = film_s;
+
+    ChunkPipe16 pipe;
+    pipe.init(wbuf, packed + kOffBig16b, tid_k >> 6, tid_k & 63);
+    pipe.prime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    u32x4 ringH[k16Ring], ringL[k16Ring];
+    {
+        const int lane0 = tid_k & 63;
+#pragma unroll
+        for (int g = 0; g < k16Ring - 1; ++g) {
+            ringH[g] = reinterpret_cast<const u32x4*>(pipe.wcur)[(g * 2 + 0) * 64 + lane0];
+            ringL[g] = reinterpret_cast<const u32x4*>(pipe.wcur)[(g * 2 + 1) * 64 + lane0];
+        }
+    }
+
+    // packed f16 (hi, lo) activations of this wave's 16 points: word 2e + (r >> 1), half r & 1 of in?[g] = feature 32g + 16e + 4q + r
+    u32x4 inH[k16Steps], inL[k16Steps], outH[k16Steps], outL[k16Steps];
+
+    for (int sub = 0; sub < n_sub; ++sub) {
+        int tid_o = tid_k;
+        asm volatile("" : "+v"(tid_o));                    // opaque: address math stays inside the sub-tile (no hoisted registers)
+        const int tid = tid_o, lane = tid & 63, wave = tid >> 6, q = lane >> 4, col = lane & 15;
+        // =====================================================================================
+        // 1. this lane's point (replicated over the four lane groups q)
+        // =====================================================================================
+        const int p_sub = 16 * wave + col;
+        const int p = sub * kTilePts + p_sub;
+        const bool valid = p < npts;
+        const int pc = valid ? p : (npts - 1);
+        float px = 0.f, py = 0.f, pz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f, zval = 0.f, dist = 0.f;
+        int ray_l = 0, s_idx = 0;
+        int64_t gpt;
+        if (MODE == 0) {
+            ray_l = pc / S;
+            s_idx = pc - ray_l * S;
+            const int pix = pix0 + ray_l;
+            const int iy = pix / a.Wd, ix = pix - iy * a.Wd;
+            gpt = ((int64_t)b * a.H * a.Wd + pix) * S + s_idx;
+            const float hres = (float)a.res * 0.5f;
+            const float d0 = __fdiv_rn(((float)ix + 0.5f) - hres, focal);
+            const float d1 = -__fdiv_rn(((float)iy + 0.5f) - hres, focal);
+            const float d2 = -1.0f;
+            float rd[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                rd[m] = __fadd_rn(__fadd_rn(__fmul_rn(d0, cw[4 * m + 0]), __fmul_rn(d1, cw[4 * m + 1])), __fmul_rn(d2, cw[4 * m + 2]));
+            const float dn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)));
+            vx = __fdiv_rn(d0, dn); vy = __fdiv_rn(d1, dn); vz = __fdiv_rn(d2, dn);
+            const float tv = a.t_vals[s_idx];
+            zval = __fadd_rn(__fmul_rn(nearv, __fsub_rn(1.0f, tv)), __fmul_rn(farv, tv));
+            px = __fadd_rn(cw[3], __fmul_rn(rd[0], zval));
+            py = __fadd_rn(cw[7], __fmul_rn(rd[1], zval));
+            pz = __fadd_rn(cw[11], __fmul_rn(rd[2], zval));
+            const float rdn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(rd[0], rd[0]), __fmul_rn(rd[1], rd[1])), __fmul_rn(rd[2], rd[2])));
+            if (s_idx + 1 < S) {
+                const float tn = a.t_vals[s_idx + 1];
+                const float zn = __fadd_rn(__fmul_rn(nearv, __fsub_rn(1.0f, tn)), __fmul_rn(farv, tn));
+                dist = __fmul_rn(__fsub_rn(zn, zval), rdn);
+            } else {
+                dist = __fmul_rn(1e10f, rdn);
+            }
+            if (valid && q == 0) {
+                if (a.points) { float* o = a.points + gpt * 3; o[0] = px; o[1] = py; o[2] = pz; }
+                if (a.dists) a.dists[gpt] = dist;
+                if (s_idx == 0) {
+                    const int64_t gr = (int64_t)b * a.H * a.Wd + pix;
+                    if (a.rays_d) { float* o = a.rays_d + gr * 3; o[0] = rd[0]; o[1] = rd[1]; o[2] = rd[2]; }
+                    if (a.viewdirs) { float* o = a.viewdirs + gr * 3; o[0] = vx; o[1] = vy; o[2] = vz; }
+                }
+            }
+        } else {
+            gpt = (int64_t)b * a.n_pts + pt0 + pc;
+            const float* pp = a.pts + gpt * 3;
+            px = pp[0]; py = pp[1]; pz = pp[2];
+            if (a.vdirs) { const float* vv = a.vdirs + gpt * 3; vx = vv[0]; vy = vv[1]; vz = vv[2]; }
+        }
+        float* const sv = (SAVE && valid) ? a.save_args + gpt * (9 * kWidth) : nullptr;
+        const int64_t gpt_block = (MODE == 0) ? ((int64_t)b * a.H * a.Wd + pix0) * S : (int64_t)b * a.n_pts + pt0;
+        // the view layer (features on lanes) needs the directions of the points 4q + r: through LDS
+        float* const vd_s = smem + k16LdsVd + wave * 64;
+        if (q == 0) { vd_s[col * 4 + 0] = vx; vd_s[col * 4 + 1] = vy; vd_s[col * 4 + 2] = vz; }
+
+        // =====================================================================================
+        // 2. layer 0 (3 -> 256) in the VALU: every lane its 4 features of each tile
+        // =====================================================================================
+        {
+            const float xs = __fmul_rn(px, a.box_scale), ys = __fmul_rn(py, a.box_scale), zs = __fmul_rn(pz, a.box_scale);
+#pragma unroll
+            for (int t = 0; t < k16Tiles; ++t) {
+                const int o = 16 * t + 4 * q;
+                const f32x4v wx = *reinterpret_cast<const f32x4v*>(w0_s + o), wy = *reinterpret_cast<const f32x4v*>(w0_s + kWidth + o),
+                             wz = *reinterpret_cast<const f32x4v*>(w0_s + 2 * kWidth + o);
+                const f32x4v g4 = *reinterpret_cast<const f32x4v*>(film + o), b4 = *reinterpret_cast<const f32x4v*>(film + kWidth + o);
+                f32x4v arg, v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float lin = fmaf(wz[r], zs, fmaf(wy[r], ys, wx[r] * xs));
+                    arg[r] = fmaf(g4[r], lin, b4[r]);
+                    v[r] = sin_f32(arg[r]);
+                }
+                if (SAVE && sv) *reinterpret_cast<f32x4v*>(sv + o) = arg;
+                SPLIT2_TO(v[0], v[1], inH[t >> 1][2 * (t & 1)], inL[t >> 1][2 * (t & 1)]);
+                SPLIT2_TO(v[2], v[3], inH[t >> 1][2 * (t & 1) + 1], inL[t >> 1][2 * (t & 1) + 1]);
+            }
+        }
+
+        // =====================================================================================
+        // 3. layers 1..7: 112 tiles; the FiLM + sine epilogue of tile t-1 issues inside tile t's MFMA stream
+        // =====================================================================================
+#pragma unroll 1
+        for (int L = 1; L < E3DGE_SIREN_DEPTH; ++L) {
+            const float* __restrict__ film_l = film + L * 2 * kWidth;
+            f32x4v prev = zero4();
+            auto finish = [&](int tp, const f32x4v& pv) {      // whole epilogue of tile tp (used for the layer's last tile)
+                const int o = 16 * tp + 4 * q;
+                const f32x4v g4 = *reinterpret_cast<const f32x4v*>(film_l + o), b4 = *reinterpret_cast<const f32x4v*>(film_l + kWidth + o);
+                f32x4v arg, v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { arg[r] = fmaf(g4[r], pv[r], b4[r]); v[r] = sin_f32(arg[r]); }
+                if (SAVE && sv) *reinterpret_cast<f32x4v*>(sv + L * kWidth + o) = arg;
+                SPLIT2_TO(v[0], v[1], outH[tp >> 1][2 * (tp & 1)], outL[tp >> 1][2 * (tp & 1)]);
+                SPLIT2_TO(v[2], v[3], outH[tp >> 1][2 * (tp & 1) + 1], outL[tp >> 1][2 * (tp & 1) + 1]);
+            };
+#pragma unroll
+            for (int t = 0; t < k16Tiles; ++t) {
+                f32x4v acc = zero4(), accb = zero4();
+                if (t == 0) {
+                    tile16<false, SAVE>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {});
+                } else {
+                    const int o = 16 * (t - 1) + 4 * q;
+                    f32x4v g4 = zero4(), b4 = zero4(), sarg = zero4();
+                    float xe = 0.f;
+                    tile16<false, SAVE>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [&](int g) {
+                        // spread over the k-steps: FiLM fetch at 0, one value per step at 1..4, stores / splits as values complete
+                        if (g == 0) {
+                            g4 = *reinterpret_cast<const f32x4v*>(film_l + o);
+                            b4 = *reinterpret_cast<const f32x4v*>(film_l + kWidth + o);
+                        } else if (g <= 4) {
+                            const int r = g - 1;
+                            const float arg = fmaf(g4[r], prev[r], b4[r]);
+                            const float x = sin_f32(arg);
+                            if (SAVE) sarg[r] = arg;
+                            if (r & 1) SPLIT2_TO(xe, x, outH[(t - 1) >> 1][2 * ((t - 1) & 1) + (r >> 1)], outL[(t - 1) >> 1][2 * ((t - 1) & 1) + (r >> 1)]);
+                            else xe = x;
+                        } else if (g == 5) {
+                            if (SAVE && sv) *reinterpret_cast<f32x4v*>(sv + L * kWidth + o) = sarg;
+                        }
+                    });
+                }
+                pipe.advance();
+                prev = acc + accb;
+            }
+            finish(k16Tiles - 1, prev);
+#pragma unroll
+            for (int g = 0; g < k16Steps; ++g) { inH[g] = outH[g]; inL[g] = outL[g]; }
+        }
+
+        // =====================================================================================
+        // 4. sdf head on the backbone output (features on registers): 64 features per lane, then over the 4 lane groups
+        // =====================================================================================
+        float sdf;
+        {
+            float acc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < k16Tiles; ++t) {
+                const f32x4v w4 = *reinterpret_cast<const f32x4v*>(head_s + 16 * t + 4 * q);
+                const int g = t >> 1, w0i = 2 * (t & 1);
+                acc = fma_mix_h<0>(inH[g][w0i], w4[0], acc); acc = fma_mix_h<0>(inL[g][w0i], w4[0], acc);
+                acc = fma_mix_h<1>(inH[g][w0i], w4[1], acc); acc = fma_mix_h<1>(inL[g][w0i], w4[1], acc);
+                acc = fma_mix_h<0>(inH[g][w0i + 1], w4[2], acc); acc = fma_mix_h<0>(inL[g][w0i + 1], w4[2], acc);
+                acc = fma_mix_h<1>(inH[g][w0i + 1], w4[3], acc); acc = fma_mix_h<1>(inL[g][w0i + 1], w4[3], acc);
+            }
+            acc += __shfl_xor(acc, 16, kWave);
+            acc += __shfl_xor(acc, 32, kWave);
+            sdf = acc + head_s[4 * kWidth];
+        }
+
+        if (MODE == 0) {
+            const float sg = __fdiv_rn(sigmoid_f32(__fdiv_rn(-sdf, a.sigmoid_beta)), a.sigmoid_beta);
+            const float alpha = __fsub_rn(1.0f, expf(-__fmul_rn(sg, dist)));
+            if (q == 0) {
+                alpha_s[p_sub] = valid ? alpha : 0.0f;
+                z_s[p_sub] = zval;
+                pts_s[p_sub * 3 + 0] = px; pts_s[p_sub * 3 + 1] = py; pts_s[p_sub * 3 + 2] = pz;
+                if (valid && a.sdf) a.sdf[gpt] = sdf;
+            }
+            __syncthreads();
+            // transmittance scan (:869-886): one thread per ray touching this sub-tile, front to back
+            const int sub_lo = sub * kTilePts;
+            const int sub_hi = min(sub_lo + kTilePts, npts);
+            const int r_first = sub_lo / S, r_last = (sub_hi - 1) / S;
+            for (int i = tid; i <= r_last - r_first; i += k16Threads) {
+                const int rl = r_first + i;
+                const int s_lo = max(0, sub_lo - rl * S), s_hi = min(S, sub_hi - rl * S);
+                float* st = state + rl * kStateStride;
+                float T = (s_lo == 0) ? 1.0f : st[0];
+                float wsum = (s_lo == 0) ? 0.0f : st[1];
+                float dep = st[2], x0 = st[3], x1 = st[4], x2 = st[5];
+                for (int s0 = s_lo; s0 < s_hi; s0 += 4) {
+                    float al[4], zz[4], p0[4], p1[4], p2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ps = min(rl * S + s0 + u, sub_hi - 1) - sub_lo;
+                        al[u] = alpha_s[ps]; zz[u] = z_s[ps];
+                        p0[u] = pts_s[ps * 3 + 0]; p1[u] = pts_s[ps * 3 + 1]; p2[u] = pts_s[ps * 3 + 2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int s = s0 + u;
+                        if (s < s_hi) {
+                            float w = __fmul_rn(al[u], T);
+                            if (a.force_bg && s == S - 1) w = __fsub_rn(1.0f, wsum);
+                            else wsum = __fadd_rn(wsum, w);
+                            T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.0f, al[u]), 1e-10f));
+                            wgt_s[rl * S + s - sub_lo] = w;
+                            dep = __fadd_rn(dep, __fmul_rn(w, zz[u]));
+                            x0 = __fadd_rn(x0, __fmul_rn(w, p0[u]));
+                            x1 = __fadd_rn(x1, __fmul_rn(w, p1[u]));
+                            x2 = __fadd_rn(x2, __fmul_rn(w, p2[u]));
+                        }
+                    }
+                }
+                st[0] = T; st[1] = wsum; st[2] = dep; st[3] = x0; st[4] = x1; st[5] = x2;
+            }
+            __syncthreads();
+            if (valid && q == 0 && a.weights) a.weights[gpt] = wgt_s[p_sub];
+        }
+
+        // optional per-point texture FiLM (:217-220), after the sdf head read h
+        if (MODE == 0 && a.tex_alpha) {
+            const float* __restrict__ ta = a.tex_alpha + gpt * kWidth;
+            const float* __restrict__ tb = a.tex_beta + gpt * kWidth;
+#pragma unroll
+            for (int t = 0; t < k16Tiles; ++t) {
+                const f32x4v a4 = *reinterpret_cast<const f32x4v*>(ta + 16 * t + 4 * q);
+                const f32x4v b4 = *reinterpret_cast<const f32x4v*>(tb + 16 * t + 4 * q);
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = __fadd_rn(__fmul_rn(__fadd_rn(a4[r], 1.0f), act16_get(inH, inL, t, r)), b4[r]);
+                SPLIT2_TO(y[0], y[1], inH[t >> 1][2 * (t & 1)], inL[t >> 1][2 * (t & 1)]);
+                SPLIT2_TO(y[2], y[3], inH[t >> 1][2 * (t & 1) + 1], inL[t >> 1][2 * (t & 1) + 1]);
+            }
+        }
+
+        // =====================================================================================
+        // 5. view layer (259 -> 256), TRANSPOSED: D[point 4q + r][feature 16t + col]
+        // =====================================================================================
+        float* const wq_s = smem + k16LdsWq + wave * (k16Slots * 16);
+        int slab_first_ray = 0, slab_nslots = 0;
+        const int slab_p0 = sub * kTilePts + 16 * wave;
+        if (MODE == 0) {
+            const int slab_hi = min(slab_p0 + 16, npts);
+            if (slab_hi > slab_p0) {
+                slab_first_ray = slab_p0 / S;
+                slab_nslots = (slab_hi - 1) / S - slab_first_ray + 1;
+            }
+            const int b1 = (slab_first_ray + 1) * S - slab_p0;
+            if (lane < 16) {                               // row = lane: composite weight of that point, by the ray it belongs to
+                const float w = (slab_p0 + lane < npts) ? wgt_s[16 * wave + lane] : 0.0f;
+                wq_s[lane] = (lane < b1) ? w : 0.0f;
+                wq_s[16 + lane] = (lane >= b1) ? w : 0.0f;
+            }
+        }
+        // (vd_s and wq_s were written by this wave's own lanes: no workgroup barrier needed, only the LDS ordering of a wave)
+        const f32x4v q0 = (MODE == 0) ? *reinterpret_cast<const f32x4v*>(wq_s + 4 * q) : zero4();
+        const f32x4v q1 = (MODE == 0) ? *reinterpret_cast<const f32x4v*>(wq_s + 16 + 4 * q) : zero4();
+        float dvx[4], dvy[4], dvz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dvx[r] = vd_s[(4 * q + r) * 4 + 0]; dvy[r] = vd_s[(4 * q + r) * 4 + 1]; dvz[r] = vd_s[(4 * q + r) * 4 + 2]; }
+        float prgb[3][4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) prgb[c][r] = 0.0f;
+        {
+            const float* __restrict__ film_v = film + 8 * 2 * kWidth;
+            const float* __restrict__ wrgb = head_s + kWidth;
+            f32x4v pv = zero4();
+            float e_gm = 0.f, e_bt = 0.f, e_w0 = 0.f, e_w1 = 0.f, e_w2 = 0.f, fa0 = 0.f, fa1 = 0.f;
+            int e_n = 0;
+            auto epi_begin = [&](int tp) {
+                e_n = 16 * tp + col;
+                e_gm = film_v[e_n]; e_bt = film_v[kWidth + e_n];
+                e_w0 = wrgb[e_n]; e_w1 = wrgb[kWidth + e_n]; e_w2 = wrgb[2 * kWidth + e_n];
+                fa0 = fa1 = 0.f;
+            };
+            auto epi_r = [&](int r) {
+                const float varg = fmaf(e_gm, pv[r], e_bt);
+                const float h = sin_f32(varg);
+                const int pr = slab_p0 + 4 * q + r;
+                if (SAVE && pr < npts) a.save_args[((gpt_block + pr) * 9 + 8) * kWidth + e_n] = varg;
+                prgb[0][r] = fmaf(e_w0, h, prgb[0][r]);
+                prgb[1][r] = fmaf(e_w1, h, prgb[1][r]);
+                prgb[2][r] = fmaf(e_w2, h, prgb[2][r]);
+                if (MODE == 0) {
+                    fa0 = fmaf(q0[r], h, fa0);
+                    fa1 = fmaf(q1[r], h, fa1);
+                } else if (a.raw) {
+                    if (pr < npts) a.raw[((int64_t)b * a.n_pts + pt0 + pr) * 260 + 4 + e_n] = h;
+                }
+            };
+            auto epi_end = [&]() {
+                if (MODE == 0) {
+                    fa0 += __shfl_xor(fa0, 16, kWave); fa0 += __shfl_xor(fa0, 32, kWave);
+                    fa1 += __shfl_xor(fa1, 16, kWave); fa1 += __shfl_xor(fa1, 32, kWave);
+                    if (q == 0) {
+                        float* pp = part + (wave * k16Slots) * kWidth + e_n;
+                        if (slab_nslots > 0) pp[0] = fa0;
+                        if (slab_nslots > 1) pp[kWidth] = fa1;
+                    }
+                }
+            };
+#pragma unroll 1
+            for (int t = 0; t < k16Tiles; ++t) {
+                f32x4v acc = zero4(), accb = zero4();
+                if (t == 0) {
+                    tile16<true, SAVE>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {});
+                } else {
+                    epi_begin(t - 1);
+                    tile16<true, SAVE>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [&](int g) { if (g >= 1 && g <= 4) epi_r(g - 1); });
+                    epi_end();
+                }
+                pipe.advance();
+                acc = acc + accb;
+                // view-direction columns (fp32, already x128 like the streamed weights)
+                const int n = 16 * t + col;
+                const float t0 = wvt_s[n], t1 = wvt_s[kWidth + n], t2 = wvt_s[2 * kWidth + n];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = fmaf(t2, dvz[r], fmaf(t1, dvy[r], fmaf(t0, dvx[r], acc[r])));
+                pv = acc;
+            }
+            epi_begin(k16Tiles - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) epi_r(r);
+            epi_end();
+        }
+
+        // =====================================================================================
+        // 6. rgb head: sum the per-lane partials over the 16 feature lanes of each lane group (DPP row rotations)
+        // =====================================================================================
+        float rgbv[3][4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rgbv[c][r] = row_sum16(prgb[c][r]) + head_s[4 * kWidth + 1 + c];
+        if (MODE == 0) {
+            if (col == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ps = 16 * wave + 4 * q + r;
+                    rgb_s[ps * 3 + 0] = sigmoid_f32(rgbv[0][r]);
+                    rgb_s[ps * 3 + 1] = sigmoid_f32(rgbv[1][r]);
+                    rgb_s[ps * 3 + 2] = sigmoid_f32(rgbv[2][r]);
+                }
+            }
+            __syncthreads();
+            const int sub_lo = sub * kTilePts;
+            const int sub_hi = min(sub_lo + kTilePts, npts);
+            const int r_first = sub_lo / S, r_last = (sub_hi - 1) / S;
+            for (int i = tid; i <= r_last - r_first; i += k16Threads) {
+                const int rl = r_first + i;
+                const int s_lo = max(0, sub_lo - rl * S), s_hi = min(S, sub_hi - rl * S);
+                float* st = state + rl * kStateStride;
+                float c0 = st[6], c1 = st[7], c2 = st[8];
+                for (int s0 = s_lo; s0 < s_hi; s0 += 4) {
+                    float ww[4], g0[4], g1[4], g2[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ps = min(rl * S + s0 + u, sub_hi - 1) - sub_lo;
+                        ww[u] = (s0 + u < s_hi) ? wgt_s[ps] : 0.0f;
+                        g0[u] = rgb_s[ps * 3 + 0]; g1[u] = rgb_s[ps * 3 + 1]; g2[u] = rgb_s[ps * 3 + 2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (s0 + u < s_hi) {
+                            c0 = __fadd_rn(c0, __fmul_rn(ww[u], g0[u]));
+                            c1 = __fadd_rn(c1, __fmul_rn(ww[u], g1[u]));
+                            c2 = __fadd_rn(c2, __fmul_rn(ww[u], g2[u]));
+                        }
+                }
+                st[6] = c0; st[7] = c1; st[8] = c2;
+            }
+            if (tid < kWidth) {   // ordered merge of the feature partials: slab by slab, ray slot by ray slot
+                const int n = tid;
+                for (int wv = 0; wv < 8; ++wv) {
+                    const int slab_lo = sub_lo + 16 * wv;
+                    const int slab_hi2 = min(slab_lo + 16, npts);
+                    if (slab_hi2 <= slab_lo) break;
+                    const int fr = slab_lo / S;
+                    const int ns = (slab_hi2 - 1) / S - fr + 1;
+                    for (int sl = 0; sl < ns; ++sl)
+                        feat_acc[(fr + sl) * kFPitch + n] += part[(wv * k16Slots + sl) * kWidth + n];
+                }
+            }
+            __syncthreads();
+        } else {
+            if (a.raw && col == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int pr = sub * kTilePts + 16 * wave + 4 * q + r;
+                    if (pr < npts) {
+                        float* o = a.raw + ((int64_t)b * a.n_pts + pt0 + pr) * 260;
+                        o[0] = rgbv[0][r]; o[1] = rgbv[1][r]; o[2] = rgbv[2][r];
+                    }
+                }
+            }
+            if (valid && q == 0) {
+                if (a.sdf) a.sdf[gpt] = sdf;
+                if (a.raw) a.raw[gpt * 260 + 3] = sdf;
+            }
+        }
+    }  // sub-tiles
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA in flight when the workgroup retires
+    if (MODE == 0) {
+        // 7. per-ray outputs, channel-first like VolumeFeatureRenderer.forward returns them (:1957-1968)
+        const int tid = tid_k;
+        const int HW = a.H * a.Wd;
+        if (a.features) {
+            float* fo = a.features + (int64_t)b * kWidth * HW + pix0;
+            for (int e = tid; e < nrays * kWidth; e += k16Threads) {
+                const int n = e / nrays, rl = e - n * nrays;
+                fo[(int64_t)n * HW + rl] = feat_acc[rl * kFPitch + n];
+            }
+        }
+        for (int rl = tid; rl < nrays; rl += k16Threads) {
+            const float* st = state + rl * kStateStride;
+            const int pix = pix0 + rl;
+            if (a.rgb) {
+                float* o = a.rgb + (int64_t)b * 3 * HW + pix;
+                o[0] = __fadd_rn(-1.0f, __fmul_rn(2.0f, st[6]));
+                o[HW] = __fadd_rn(-1.0f, __fmul_rn(2.0f, st[7]));
+                o[2 * HW] = __fadd_rn(-1.0f, __fmul_rn(2.0f, st[8]));
+            }
+            if (a.xyz) {
+                float* o = a.xyz + (int64_t)b * 3 * HW + pix;
+                o[0] = st[3]; o[HW] = st[4]; o[2 * HW] = st[5];
+            }
+            if (a.depth) a.depth[(int64_t)b * HW + pix] = st[2];
+            if (a.mask) a.mask[(int64_t)b * HW + pix] = (st[2] < a.mask_thresh) ? 1.0f : 0.0f;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Layout self-test of v_mfma_f32_16x16x32_f16 with the conventions above: c (16x16, row-major) = hi(a) hi(b)^T
+__global__ void __launch_bounds__(64)
+selftest_mfma16x16_kernel(float* __restrict__ cmat, const float* __restrict__ amat, const float* __restrict__ bmat, int k) {
+    const int lane = threadIdx.x, q = lane >> 4, n = lane & 15;
+    f32x4v acc = zero4();
+    for (int kb = 0; kb < k; kb += 32) {
+        u32x4 a4, b4, dummy;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            SPLIT2_TO(amat[n * k + kb + 8 * q + 2 * w], amat[n * k + kb + 8 * q + 2 * w + 1], a4[w], dummy[w]);
+            SPLIT2_TO(bmat[n * k + kb + 8 * q + 2 * w], bmat[n * k + kb + 8 * q + 2 * w + 1], b4[w], dummy[w]);
+        }
+        acc = mfma16x16(a4, b4, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cmat[(4 * q + r) * 16 + n] = acc[r];
+}
+
+}  // namespace e3dge

@@ -55,7 +55,13 @@ constexpr int64_t kOffBigT = kOffBig16 + (int64_t)kChunksPerPass * kChunkFloats;
 // f16x3 (hi, lo) image of the same transposed GEMMs, same chunk order and word layout as kOffBig16:
 // [Gb][8 out-tiles][16 k-steps][hi|lo][64 lanes][4 words of two f16], carrying the factor kW16Scale
 constexpr int64_t kOffBigT16 = kOffBigT + (int64_t)kChunksPerPass * kChunkFloats;
-constexpr int64_t kPackedFloats = kOffBigT16 + (int64_t)kChunksPerPass * kChunkFloats;
+// f16x3 image for the 8-wave forward kernel (siren16.h, v_mfma_f32_16x16x32_f16): the same 8 big layers as 128 chunks of
+// 16 KiB = one 16-feature output tile x K = 256:  [Lb][16 t][8 k-steps g][hi|lo][64 lanes][4 words of two f16]; lane l
+// (n = l & 15, q = l >> 4) holds, for j = 0..7,   128 * W[16t + n][32g + 16(j >> 2) + 4q + (j & 3)]
+// -- the k order in which a lane's C/D registers of two consecutive 16-feature tiles of the previous layer (rows 4q + r)
+// are the 8 k-slots of the next layer's operand.
+constexpr int64_t kOffBig16b = kOffBigT16 + (int64_t)kChunksPerPass * kChunkFloats;
+constexpr int64_t kPackedFloats = kOffBig16b + (int64_t)kChunksPerPass * kChunkFloats;
 // f16x3 image: the same 64 chunks of 32 KiB, each [16 k-steps g = 2c+s][hi, lo][64 lanes][8 f16]: lane l holds
 //   128 * W[32t + (l&31)][32c + 16s + (j&3) + 8(j>>2) + 4(l>>5)],  j = 0..7
 // split as hi = f16(v), lo = f16(v - hi).  The k order is the one in which a lane's C/D registers of the previous

@@ -29,7 +29,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib
 
 
-MFMA_MODES = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3}
+MFMA_MODES = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16x3_v1": _lib.PREC_F16X3_V1}
 _STRICT_CACHE = os.environ.get("E3DGE_STRICT_WEIGHT_CACHE", "0") not in ("", "0")
 
 

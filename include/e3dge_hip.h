@@ -171,7 +171,11 @@ int e3dge_torgb(float* y, const float* x, const float* weight, const float* styl
 
 /* How the 256-wide contractions are evaluated.  Both accumulate in fp32 and meet the same parity bounds. */
 #define E3DGE_PREC_F32 0          /* v_mfma_f32_32x32x2_f32 on fp32 operands                                     */
-#define E3DGE_PREC_F16X3 1        /* operands split as f16 hi+lo, 3 products on v_mfma_f32_32x32x16_f16 (~4x faster) */
+#define E3DGE_PREC_F16X3 1        /* operands split as f16 hi+lo, 3 f16 MFMA products per fp32 product, fp32 accumulate.  Forward
+                                     launches: 8 waves x 16 points on v_mfma_f32_16x16x32_f16; backward-type launches: 4 waves x 32
+                                     points on v_mfma_f32_32x32x16_f16 with per-point block scaling */
+#define E3DGE_PREC_F16X3_V1 2     /* forward launches only: the first-generation split-f16 kernel (4 waves x 32 points,
+                                     v_mfma_f32_32x32x16_f16), kept for A/B measurements */
 
 /* Number of floats of the packed weight image produced by e3dge_siren_pack_weights. */
 int64_t e3dge_siren_packed_floats(void);
@@ -376,6 +380,8 @@ int e3dge_pos_encoding(float* out, int ld, int col_off, const float* pts, int64_
 int e3dge_selftest_mfma(float* c, const float* a, const float* b, int k, e3dge_stream_t stream);
 /* The same with one f16 MFMA (v_mfma_f32_32x32x16_f16) per 16 k on the hi halves of a, b; k multiple of 16. */
 int e3dge_selftest_mfma16(float* c, const float* a, const float* b, int k, e3dge_stream_t stream);
+/* The same for v_mfma_f32_16x16x32_f16 (c: 16x16, a, b: (16, k) row-major, k multiple of 32). */
+int e3dge_selftest_mfma16x16(float* c, const float* a, const float* b, int k, e3dge_stream_t stream);
 /* Accuracy self-test of the kernel's sine: y[i] = sin(x[i]) with the device routine the SIREN layers use. */
 int e3dge_selftest_sin(float* y, const float* x, int n, e3dge_stream_t stream);
 /* The alternative 13-op polynomial sine (kernels built with -DE3DGE_POLY_SINE use it). */

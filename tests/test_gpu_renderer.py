@@ -34,7 +34,7 @@ def sd():
     return full_state_dict()[1]
 
 
-MODES = ["f16x3", "f32"]     # both contraction kernels must meet the same bounds
+MODES = ["f16x3", "f32", "f16x3_v1"]     # every contraction kernel must meet the same bounds
 
 
 def make_renderer(sd, res, S, mfma_mode=None, **over):

@@ -43,6 +43,20 @@ def test_f16_mfma_fragment_layout(lib):
         assert err == 0.0, err          # small dyadic rationals: every product and sum is exact
 
 
+def test_f16_mfma_16x16x32_fragment_layout(lib):
+    """v_mfma_f32_16x16x32_f16 with the conventions of the 8-wave forward kernel (siren16.h): A/B lane (n = l & 15, q = l >> 4)
+    holds k = 8q + j; C/D lane holds column n, rows 4q + r.  Asymmetric operands: a transposed or permuted mapping cannot pass."""
+    rs = np.random.RandomState(6)
+    for k in (32, 96, 256):
+        a = T((rs.randint(-8, 9, size=(16, k)) / 8.0).astype(np.float32))
+        b = T((rs.randint(-8, 9, size=(16, k)) / 4.0).astype(np.float32))
+        c = torch.full((16, 16), float('nan'), device=DEV)
+        _lib.check(lib.e3dge_selftest_mfma16x16(c.data_ptr(), a.data_ptr(), b.data_ptr(), k, _lib.stream_of(c)), "selftest_mfma16x16")
+        err = maxerr(c, a.double() @ b.double().t())
+        record("mfma16x16_layout", k=k, err=err)
+        assert err == 0.0, err
+
+
 def test_device_sine_accuracy(lib):
     rs = np.random.RandomState(1)
     x = np.concatenate([rs.uniform(-300, 300, 200000), rs.uniform(-4, 4, 50000), np.linspace(-50, 50, 20001),

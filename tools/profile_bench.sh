@@ -51,7 +51,7 @@ with open(os.path.join(out, "pmc_summary.txt"), "w") as f:
             a = agg[k][r['Counter_Name']]
             a[0] += float(r['Counter_Value']); a[1] += 1
         for k, cs in agg.items():
-            if 'siren_kernel' in k or 'upfirdn' in k or 'bias_act' in k or 'film' in k:
+            if 'siren_kernel' in k or 'siren16_kernel' in k or 'upfirdn' in k or 'bias_act' in k or 'film' in k:
                 f.write(f"{k}\n")
                 for cn, (tot, n) in sorted(cs.items()):
                     f.write(f"    {cn:<32} mean/dispatch = {tot / max(n,1):.6g}   (n={n})\n")
@@ -61,7 +61,7 @@ import json, re
 vals = {}
 txt = open(os.path.join(out, "pmc_summary.txt")).read()
 for blk in re.split(r"\n(?=\S)", txt):
-    if "siren_kernel<0" in blk:
+    if "siren_kernel<0" in blk or "siren16_kernel<0" in blk:
         for m in re.finditer(r"(FETCH_SIZE|WRITE_SIZE)\s+mean/dispatch = ([0-9.e+]+)", blk):
             vals[m.group(1) + "_KB"] = float(m.group(2))
 json.dump(vals, open(os.path.join(out, "traffic.json"), "w"))
