@@ -86,6 +86,30 @@ def ssim_index(x, y, window=5, max_val=1.0):
 
 
 def image_metrics(pred, gt, l2_lambda=1.0):
+    """The 8 metric columns of one image pair (see image_metrics_torch).  GPU fp32 tensors take the fused HIP kernel
+    e3dge_image_metrics (one pass over both images); anything else the plain-torch formulation."""
+    if pred.device.type == "cuda" and pred.dtype == torch.float32 and gt.dtype == torch.float32 and pred.ndim == 4 \
+            and pred.shape == gt.shape and not (torch.is_grad_enabled() and (pred.requires_grad or gt.requires_grad)):
+        from . import _lib
+        lib = _lib.load()
+        B, C, H, W = pred.shape
+        p, g = pred.contiguous(), gt.contiguous()
+        sums = torch.empty((B, 4), device=p.device, dtype=torch.float32)
+        scratch = torch.empty(lib.e3dge_image_metrics_scratch_floats(B, C, H, W), device=p.device, dtype=torch.float32)
+        with torch.cuda.device(p.device):
+            rc = lib.e3dge_image_metrics(_lib.ptr(sums), _lib.ptr(scratch), _lib.ptr(p), _lib.ptr(g), B, C, H, W, 1.0,
+                                         _lib.stream_of(p))
+        _lib.check(rc, "e3dge_image_metrics")
+        tot = sums.sum(0)                        # the reference's losses are means over the whole batch tensor
+        n = tot[3]
+        mse, mae, ssim_loss = tot[0] / n, tot[1] / n, tot[2] / n
+        zero = torch.zeros((), device=p.device, dtype=torch.float32)
+        psnr = 10.0 * torch.log10(1.0 / (mse * 0.25))           # images scaled to [0,1]: squared error / 4
+        return torch.stack([mse, zero, zero, mse * l2_lambda, mae, psnr, 1 - ssim_loss, 1 - zero])
+    return image_metrics_torch(pred, gt, l2_lambda)
+
+
+def image_metrics_torch(pred, gt, l2_lambda=1.0):
     """(8,) = [loss_l2, loss_id, loss_lpips, loss, mae, PSNR, SSIM, ID_SIM] for one predicted image against its target,
     both (1,3,H,W) in [-1,1] (calc_2d_rec_loss, builder.py:130-184).  The two terms that need pretrained networks the
     image does not have (ArcFace identity, LPIPS/VGG) are outside the hot path and reported as 0 (ID_SIM = 1 - 0), exactly

@@ -942,6 +942,59 @@ class VolumeFeatureRenderer(nn.Module):
         return render_out
 
     # -------------------------------------------------------------------------------------------------
+    def query_hitting_probability_fixed_interval(self, wd_space_pts, ref_img_info, return_type='weights'):
+        """Hit probability (or visibility) of world-space points as seen from a reference view (reference :1326-1495, caller
+        cycle_runner.py:139-158): for every point the ray from the reference camera through it is re-sampled at the
+        renderer's S fixed depths, the SDF network is queried there (fused point kernel, sdf only), the samples are
+        composited WITHOUT the far-plane stop (`no_force_stop`: last interval = first interval, no background weight,
+        :826-837, :884), and the per-sample value is linearly interpolated at the point's position along its ray.
+        wd_space_pts (B,H,W,S,3) -> (B,H,W,S,1).  Everything runs on the GPU; no gradient is provided."""
+        if return_type not in ('weights', 'visibility'):
+            raise ValueError("return_type must be 'weights' or 'visibility'")
+        if wd_space_pts.ndim != 5:
+            raise RuntimeError("wd_space_pts must be (B, H, W, S, 3)")
+        if not self.static_viewdirs:
+            raise NotImplementedError("static_viewdirs=False")
+        _lib.require_gpu(wd_space_pts, "wd_space_pts")
+        B, H, W, S = wd_space_pts.shape[:4]
+        Sn = self.N_samples
+        ro = ref_img_info['global_render_out']
+        poses = ref_img_info['cam_settings']['poses']                       # (B,3,4) c2w
+        extr = ref_img_info['cam_settings']['extrinsics']                   # (B,3,4) w2c
+        styles = ref_img_info['pred_latents'][0]
+        with torch.no_grad():
+            near = ro['near'].reshape(B, H * W, 1, 1)
+            far = ro['far'].reshape(B, H * W, 1, 1)
+            pts = wd_space_pts.reshape(B, H * W, S, 3)
+            # direction of the reference-view ray through each point, scaled like the mesh-grid directions (z = -1) (:1367-1379)
+            ref_space = torch.einsum('bij,bnsj->bnsi', extr[:, :, :3], pts) + extr[:, None, None, :, 3]
+            rays_d_ref = ref_space / (-ref_space[..., 2:3])
+            rays_d_wd = torch.einsum('bij,bnsj->bnsi', poses[:, :, :3], rays_d_ref)          # (B,HW,S,3)
+            t_vals = self.t_vals.reshape(1, 1, 1, Sn)
+            z_vals = near * (1. - t_vals) + far * t_vals                                      # (B,HW,1,Sn)
+            interval = (z_vals[..., 1:2] - z_vals[..., 0:1]) * rays_d_wd.norm(dim=-1, keepdim=True)   # (B,HW,S,1)
+            rays_o = poses[:, None, None, :, 3]                                              # (B,1,1,3)
+            q = rays_o.unsqueeze(3) + rays_d_wd.unsqueeze(3) * z_vals.reshape(B, H * W, 1, Sn, 1)     # (B,HW,S,Sn,3)
+            idx = (pts - q[..., 0, :]).norm(dim=-1, keepdim=True) / interval + 1e-5          # (B,HW,S,1)
+            lo = idx.floor().clamp(0, Sn - 1)
+            hi = idx.ceil().clamp(0, Sn - 1)
+            # sdf of all B*HW*S*Sn samples in one launch (view directions do not enter the sdf head)
+            sdf = self.siren.query_points(q.reshape(B, -1, 3), None, styles, self.box_scale, want_raw=False)[0]
+            sdf = sdf.reshape(B, H * W, S, Sn)
+            # volume_integration with no_force_stop (:826-837): viewdirs are unit vectors, so dists are the z spacings
+            dz = z_vals[..., 1:] - z_vals[..., :-1]
+            dists = torch.cat([dz, dz[..., 0:1]], -1)                                          # (B,HW,1,Sn)
+            beta = self.sigmoid_beta
+            sigma = torch.sigmoid(-sdf / beta) / beta
+            alpha = 1 - torch.exp(-sigma * dists)
+            vis = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1]), 1. - alpha + 1e-10], -1), -1)[..., :-1]
+            val = alpha * vis if return_type == 'weights' else vis
+            f = torch.gather(val, -1, lo.long())
+            c = torch.gather(val, -1, hi.long())
+            out = torch.lerp(f, c, idx - lo)
+        return out.reshape(B, H, W, S, 1)
+
+    # -------------------------------------------------------------------------------------------------
     def sample_uniform_grid(self, batch_size, num_sample_inout, device, styles, uniform=None):
         """Uniform points of the scene box and their sdf (:945-963).  `uniform` (B,N,3) in [0,1) replaces the torch.rand
         draw (tests)."""

@@ -374,6 +374,17 @@ int e3dge_local_query(float* out, int ld, int col_off, float* in_img, int mask_l
                       int fh, int fw, e3dge_stream_t stream);
 int e3dge_pos_encoding(float* out, int ld, int col_off, const float* pts, int64_t n_pts, int n_freqs, e3dge_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Per-image reconstruction metrics in one pass (the scalars the sharded evaluation all-gathers):
+ * replaces the MSE / L1 / PSNR / SSIM part of Loss.calc_2d_rec_loss (project/losses/builder.py:130-184; SSIM = kornia
+ * ssim_loss with a 5x5 Gaussian window, sigma 1.5, reflect padding, max_val as given -- the reference passes its [-1,1]
+ * images with max_val = 1).  pred, gt (batch, channels, H, W); scratch e3dge_image_metrics_scratch_floats() floats;
+ * sums (batch, 4) = [sum (p-g)^2, sum |p-g|, sum clamp((1-ssim)/2, 0, 1), element count] per image.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int64_t e3dge_image_metrics_scratch_floats(int batch, int channels, int height, int width);
+int e3dge_image_metrics(float* sums, float* scratch, const float* pred, const float* gt, int batch, int channels,
+                        int height, int width, float max_val, e3dge_stream_t stream);
+
 /* Layout self-test: runs a 32x32xK fp32-MFMA product with the fragment conventions the render kernel
  * relies on and writes it to c (32*32 floats, row-major) for the caller to compare with a @ b^T.
  * a: (32, k) row-major, b: (32, k) row-major, k multiple of 8, k <= 256. */

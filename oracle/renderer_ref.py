@@ -152,3 +152,47 @@ def tex_modulations(sd, prefix, feats, dtype=torch.float32):
     dx = F.linear(torch.relu(net), w('fc_1.weight'), w('fc_1.bias'))
     out = F.linear(x, w('shortcut.weight')) + dx
     return torch.split(out, 256, dim=-1)
+
+
+def query_hitting_probability_fixed_interval(sd, wd_space_pts, ref_poses, ref_extrinsics, near, far, styles, n_samples,
+                                             return_type='weights', dtype=torch.float32, prefix='renderer.'):
+    """VolumeFeatureRenderer.query_hitting_probability_fixed_interval (project/utils/volume_renderer.py:1326-1495) with
+    volume_integration(no_force_stop=True) (:826-837, :869-886).  wd_space_pts (B,H,W,S,3); near / far (B,H,W,1)."""
+    B, H, W, S = wd_space_pts.shape[:4]
+    Sn = n_samples
+    pts = wd_space_pts.to(dtype).reshape(B, H * W, S, 3)
+    t_vals = torch.linspace(0., 1. - 1 / Sn, steps=Sn).to(dtype).reshape(1, 1, 1, 1, Sn)     # :690-693
+    near = near.to(dtype).reshape(B, H * W, 1, 1, 1)
+    far = far.to(dtype).reshape(B, H * W, 1, 1, 1)
+    w2c = torch.cat((ref_extrinsics.to(dtype), torch.zeros_like(ref_extrinsics[..., 0:1, :]).to(dtype)), dim=-2)
+    w2c[..., -1, -1] = 1
+    homo = torch.cat((pts, torch.ones_like(pts[..., 0:1])), dim=-1).unsqueeze(-1)            # B HW S 4 1
+    ref_space = w2c.reshape(B, 1, 1, 4, 4) @ homo
+    rays_d_ref = ref_space[..., :3, :] / (-ref_space[..., 2:3, :])                            # B HW S 3 1
+    rays_d_wd = (ref_poses.to(dtype).reshape(B, 1, 1, 3, 4)[..., :3] @ rays_d_ref).permute(0, 1, 2, 4, 3)   # B HW S 1 3
+    rays_o = ref_poses.to(dtype)[..., 3:4].permute(0, 2, 1).reshape(B, 1, 1, 1, 3)
+    z_vals = near * (1. - t_vals) + far * t_vals                                              # B HW 1 1 S
+    interval = (z_vals[..., 1:2] - z_vals[..., 0:1]) * rays_d_wd.norm(dim=-1, keepdim=True).permute(0, 1, 2, 4, 3)
+    z_vals = z_vals.permute(0, 1, 2, 4, 3)                                                    # B HW 1 S 1
+    q = rays_o + rays_d_wd * z_vals                                                           # B HW S S 3
+    idx = (pts.unsqueeze(-2) - q[..., 0:1, :]).norm(dim=-1, keepdim=True) / interval + 1e-5   # B HW S 1 1
+    lo = torch.clamp(idx.floor().long(), min=0, max=Sn - 1)
+    hi = torch.clamp(idx.ceil().long(), min=0, max=Sn - 1)
+    viewdirs = F.normalize(rays_d_ref.squeeze(-1), dim=-1)                                    # static_viewdirs
+    out = torch.empty(B, H * W, S, 1, 1, dtype=dtype)
+    beta = sd[prefix + 'sigmoid_beta'].to(dtype)
+    for b in range(B):
+        raw = query_points(sd, q[b:b + 1], viewdirs[b:b + 1].unsqueeze(3).expand(q[b:b + 1].shape), styles[b:b + 1], dtype=dtype)
+        sdf = raw[..., 3:4]                                                                   # 1 HW S S 1
+        zv = z_vals[b:b + 1].squeeze(-1)                                                      # 1 HW 1 S
+        dists = zv[..., 1:] - zv[..., :-1]
+        dists = torch.cat([dists, dists[..., 0:1]], -1)
+        dists = dists * torch.norm(viewdirs[b:b + 1].unsqueeze(3), dim=-1)                    # :822-837 (norm of the unit view dirs)
+        sigma = torch.sigmoid(-sdf / beta) / beta
+        alpha = 1 - torch.exp(-sigma * dists.unsqueeze(-1))
+        vis = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1, :]), 1. - alpha + 1e-10], -2), -2)[..., :-1, :]
+        val = alpha * vis if return_type == 'weights' else vis
+        f = torch.gather(val, 3, lo[b:b + 1])
+        c = torch.gather(val, 3, hi[b:b + 1])
+        out[b:b + 1] = torch.lerp(f, c, idx[b:b + 1] - lo[b:b + 1])
+    return out.reshape(B, H, W, S, 1)
