@@ -205,7 +205,8 @@ def main():
                          f"{os.path.relpath(TRAFFIC_FILE, REPO)} ({tj.get('source', 'separate rocprofv3 --pmc passes')})")
         except (OSError, ValueError, KeyError):
             pass
-        return {"bound": "mfma", "kernel": f"siren_kernel<0,{int(mode != 'f32')}> (e3dge_siren_render_fwd, {mode})",
+        kname = {"f32": "siren_kernel<0,0,false>", "f16x3": "siren16_kernel<0,false>", "f16x3_v1": "siren_kernel<0,1,false>"}[mode]
+        return {"bound": "mfma", "kernel": f"{kname} (e3dge_siren_render_fwd, {mode})",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": note,
                 "achieved_over_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "kernel_ms": kern_ms, "flop_per_launch": flops,
                 "algorithmic_output_bytes_per_launch": BYTES_PER_RAY * B * RES * RES,

@@ -28,7 +28,15 @@ constexpr int k16Tiles = 16;                     // 16-feature output tiles per 
 constexpr int k16Steps = 8;                      // k-steps of 32 per tile
 constexpr int k16ChunkFloats = 16 * kWidth;      // one tile x K = 256: 16 KiB
 constexpr int k16Chunks = kBigLayers * k16Tiles; // 128 chunks per 128-point sub-tile
-constexpr int k16NBuf = 4;                       // LDS weight buffers (chunk g+3 is issued while tile g computes)
+#ifndef E3DGE_16_PAIR
+#define E3DGE_16_PAIR 1
+#endif
+// Workgroup barrier every tile (0) or every second tile (1).  With two waves per SIMD taking turns on the matrix pipe, a
+// barrier per 16-feature tile re-aligns them every ~1.3 k cycles: thread 0 of the first version spent 26 % of the kernel
+// waiting in s_barrier (tools/phase_timing.py).  Per pair: five buffers -- chunks 2k, 2k+1 being read, 2k+2 published for the
+// fragment ring's look-ahead, 2k+3 and 2k+4 in flight.
+constexpr bool k16Pair = E3DGE_16_PAIR != 0;
+constexpr int k16NBuf = k16Pair ? 5 : 4;          // LDS weight buffers
 constexpr int k16Slots = 2;                      // rays a 16-point slab can touch when S >= 16
 constexpr int k16Ring = 4;                       // k-steps of (hi, lo) fragments held in registers
 
@@ -81,9 +89,11 @@ __device__ __forceinline__ float row_sum16(float x) {
     return x;
 }
 
-// 16-KiB weight chunks through four LDS buffers; every wave moves a 2-KiB slice (two LDS-DMA pieces) of each chunk.
-//   tile g: sync() -> wait for everything but the chunk issued one tile ago, barrier (publishes chunk g+2, proves tile g-1
-//   is finished) -> issue chunk g+3 into the buffer tile g-1 used.  A chunk therefore has two tile times to arrive.
+// 16-KiB weight chunks through k16NBuf LDS buffers; every wave moves a 2-KiB slice (two LDS-DMA pieces) of each chunk.
+//   per tile (k16Pair = 0): tile g: sync() -> wait for everything but the chunk issued one tile ago, barrier (publishes chunk
+//   g+2, proves tile g-1 is finished) -> issue chunk g+3 into the buffer tile g-1 used: two tile times to arrive.
+//   per pair (k16Pair = 1): even tile 2k: sync() -> wait for all own DMA, barrier (publishes chunks 2k+1, 2k+2, proves the pair
+//   k-1 is finished) -> issue chunks 2k+3, 2k+4: again two tile times to arrive, half the barriers.
 struct ChunkPipe16 {
     const char* img;
     uint32_t voff, lds_base;
@@ -111,11 +121,23 @@ struct ChunkPipe16 {
     __device__ __forceinline__ void prime() {
         issue_chunk(); issue_chunk(); issue_chunk();
     }
+#ifdef E3DGE_PHASE_TIMING
+    unsigned long long t_vm = 0, t_bar = 0;
+#endif
     template <bool STRICT> __device__ __forceinline__ void sync() {
+#ifdef E3DGE_PHASE_TIMING
+        const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
         // STRICT (training: the epilogue's argument stores share vmcnt): wait for everything
-        if (STRICT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (STRICT || k16Pair) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#ifdef E3DGE_PHASE_TIMING
+        const unsigned long long c1 = __builtin_readcyclecounter();
+#endif
         __syncthreads();
+#ifdef E3DGE_PHASE_TIMING
+        t_vm += c1 - c0; t_bar += __builtin_readcyclecounter() - c1;
+#endif
     }
     __device__ __forceinline__ void advance() {
         use_buf = (use_buf + 1 == k16NBuf) ? 0 : use_buf + 1;
@@ -128,7 +150,8 @@ struct ChunkPipe16 {
 // On entry the ring holds k-steps 0..2 of this chunk; on exit k-steps 0..2 of the next one.
 template <bool TRANSPOSED, bool STRICT, class Epi>
 __device__ __forceinline__ void tile16(ChunkPipe16& pipe, int lane, const u32x4 (&aH)[k16Steps], const u32x4 (&aL)[k16Steps],
-                                       f32x4v& acc, f32x4v& accb, u32x4 (&ringH)[k16Ring], u32x4 (&ringL)[k16Ring], Epi&& epi) {
+                                       f32x4v& acc, f32x4v& accb, u32x4 (&ringH)[k16Ring], u32x4 (&ringL)[k16Ring], Epi&& epi,
+                                       bool even_tile) {
     const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(pipe.wcur) + lane;
     const u32x4* __restrict__ wn = reinterpret_cast<const u32x4*>(pipe.wnxt) + lane;
 #pragma unroll
@@ -149,13 +172,20 @@ __device__ __forceinline__ void tile16(ChunkPipe16& pipe, int lane, const u32x4 
             x1 = mfma16x16(aH[g], wl, x1);
             x0 = mfma16x16(aL[g], wh, x0);
         }
-        if (g == 1) {
+        if (g == 1 && (!k16Pair || even_tile)) {
             pipe.template sync<STRICT>();
             pipe.issue_chunk();
+            if (k16Pair) pipe.issue_chunk();
         }
         epi(g);
     }
 }
+
+#ifdef E3DGE_PHASE_TIMING
+#define PHASE16(i) do { if (MODE == 0 && blockIdx.x == 0 && tid == 0 && sub < 3) tstamp[sub * 6 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PHASE16(i) do { } while (0)
+#endif
 
 template <int MODE, bool SAVE>
 __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
@@ -239,11 +269,16 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
 
     // packed f16 (hi, lo) activations of this wave's 16 points: word 2e + (r >> 1), half r & 1 of in?[g] = feature 32g + 16e + 4q + r
     u32x4 inH[k16Steps], inL[k16Steps], outH[k16Steps], outL[k16Steps];
+#ifdef E3DGE_PHASE_TIMING
+    unsigned long long tstamp[18];
+    for (int i = 0; i < 18; ++i) tstamp[i] = 0;
+#endif
 
     for (int sub = 0; sub < n_sub; ++sub) {
         int tid_o = tid_k;
         asm volatile("" : "+v"(tid_o));                    // opaque: address math stays inside the sub-tile (no hoisted registers)
         const int tid = tid_o, lane = tid & 63, wave = tid >> 6, q = lane >> 4, col = lane & 15;
+        PHASE16(0);
         // =====================================================================================
         // 1. this lane's point (replicated over the four lane groups q)
         // =====================================================================================
@@ -328,6 +363,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             }
         }
 
+        PHASE16(1);
         // =====================================================================================
         // 3. layers 1..7: 112 tiles; the FiLM + sine epilogue of tile t-1 issues inside tile t's MFMA stream
         // =====================================================================================
@@ -349,7 +385,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             for (int t = 0; t < k16Tiles; ++t) {
                 f32x4v acc = zero4(), accb = zero4();
                 if (t == 0) {
-                    tile16<false, SAVE>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {});
+                    tile16<false, SAVE>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {}, (t & 1) == 0);
                 } else {
                     const int o = 16 * (t - 1) + 4 * q;
                     f32x4v g4 = zero4(), b4 = zero4(), sarg = zero4();
@@ -369,7 +405,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
                         } else if (g == 5) {
                             if (SAVE && sv) *reinterpret_cast<f32x4v*>(sv + L * kWidth + o) = sarg;
                         }
-                    });
+                    }, (t & 1) == 0);
                 }
                 pipe.advance();
                 prev = acc + accb;
@@ -379,6 +415,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             for (int g = 0; g < k16Steps; ++g) { inH[g] = outH[g]; inL[g] = outL[g]; }
         }
 
+        PHASE16(2);
         // =====================================================================================
         // 4. sdf head on the backbone output (features on registers): 64 features per lane, then over the 4 lane groups
         // =====================================================================================
@@ -466,6 +503,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             }
         }
 
+        PHASE16(3);
         // =====================================================================================
         // 5. view layer (259 -> 256), TRANSPOSED: D[point 4q + r][feature 16t + col]
         // =====================================================================================
@@ -538,10 +576,10 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             for (int t = 0; t < k16Tiles; ++t) {
                 f32x4v acc = zero4(), accb = zero4();
                 if (t == 0) {
-                    tile16<true, SAVE>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {});
+                    tile16<true, SAVE>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {}, (t & 1) == 0);
                 } else {
                     epi_begin(t - 1);
-                    tile16<true, SAVE>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [&](int g) { if (g >= 1 && g <= 4) epi_r(g - 1); });
+                    tile16<true, SAVE>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [&](int g) { if (g >= 1 && g <= 4) epi_r(g - 1); }, (t & 1) == 0);
                     epi_end();
                 }
                 pipe.advance();
@@ -559,6 +597,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             epi_end();
         }
 
+        PHASE16(4);
         // =====================================================================================
         // 6. rgb head: sum the per-lane partials over the 16 feature lanes of each lane group (DPP row rotations)
         // =====================================================================================
@@ -633,6 +672,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
                 if (a.raw) a.raw[gpt * 260 + 3] = sdf;
             }
         }
+        PHASE16(5);
     }  // sub-tiles
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA in flight when the workgroup retires
@@ -663,6 +703,15 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             if (a.depth) a.depth[(int64_t)b * HW + pix] = st[2];
             if (a.mask) a.mask[(int64_t)b * HW + pix] = (st[2] < a.mask_thresh) ? 1.0f : 0.0f;
         }
+#ifdef E3DGE_PHASE_TIMING
+        // profiling build: the first floats of `dists` carry thread 0's per-phase cycle counts (tools/phase_timing.py)
+        __syncthreads();
+        if (blockIdx.x == 0 && tid == 0 && a.dists) {
+            for (int i = 0; i < 18; ++i)
+                a.dists[i] = (i % 6 == 0) ? (float)(i / 6 ? tstamp[i] - tstamp[i - 1] : 0) : (float)(tstamp[i] - tstamp[i - 1]);
+            a.dists[18] = (float)pipe.t_vm; a.dists[19] = (float)pipe.t_bar;
+        }
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -24,5 +24,9 @@ with torch.no_grad():
 for sub in range(3):
     print(f"sub-tile {sub}: " + ", ".join(f"{names[i]}={d[sub * 6 + i]:.0f}" for i in range(6)))
 tot = sum(d)
-print("chunk_sync totals per wave (cycles over 192 tiles): " + "; ".join(f"w{w}: dma-wait={sync[3*w]:.0f} barrier={sync[3*w+1]:.0f} issue={sync[3*w+2]:.0f}" for w in range(4)))
-print("sum", tot, " mfma-only per sub-tile would be", 8224 * 64)
+if r.siren.mfma_mode == "f16x3":      # 8-wave kernel: thread 0's totals over 384 tiles
+    print(f"chunk sync totals of wave 0 (cycles over 384 tiles): dma-wait={sync[0]:.0f} barrier={sync[1]:.0f}")
+    print("sum", tot, " mfma-only per sub-tile would be", 16 * 24 * 128, "per wave,", 2 * 16 * 24 * 128, "per SIMD (two waves)")
+else:
+    print("chunk_sync totals per wave (cycles over 192 tiles): " + "; ".join(f"w{w}: dma-wait={sync[3*w]:.0f} barrier={sync[3*w+1]:.0f} issue={sync[3*w+2]:.0f}" for w in range(4)))
+    print("sum", tot, " mfma-only per sub-tile would be", 8224 * 64)
