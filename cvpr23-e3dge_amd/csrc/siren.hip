@@ -764,6 +764,26 @@ siren_pack_kernel(float* __restrict__ packed, const float* __restrict__ w_first,
         } else if (e < kOffBig16) {
             const int r = (int)(e - kOffBHead);
             v = (r == 0) ? b_sigma[0] : b_rgb[r - 1];
+        } else if (e >= kOffBigT16b) {
+            // transposed 16x16x32 image (siren_common.h): [Gb][16 t][8 g][hl][lane][word k], out row kin = 16t + (lane & 15)
+            int64_t r = e - kOffBigT16b;
+            const int k = r & 3; r >>= 2;
+            const int lane = r & 63; r >>= 6;
+            const int hl = r & 1; r >>= 1;
+            const int g = r & 7; r >>= 3;
+            const int t = r & 15; r >>= 4;
+            const int L = 8 - (int)r;
+            const int kin = 16 * t + (lane & 15), q = lane >> 4;
+            unsigned word = 0;
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const int j = 2 * k + e2;
+                const int nn = 32 * g + 16 * (j >> 2) + 4 * q + (j & 3);
+                const float w = kW16Scale * ((L == 8) ? w_view[(int64_t)nn * 259 + kin] : w_hidden[((int64_t)(L - 1) * kWidth + nn) * kWidth + kin]);
+                const _Float16 hi = (_Float16)w;
+                const _Float16 val = hl ? (_Float16)(w - (float)hi) : hi;
+                word |= (unsigned)__builtin_bit_cast(unsigned short, val) << (16 * e2);
+            }
+            v = __uint_as_float(word);
         } else if (e >= kOffBig16b) {
             // 16x16x32 image (siren_common.h): [Lb][16 t][8 g][hl][lane][word k]
             int64_t r = e - kOffBig16b;
@@ -1073,6 +1093,12 @@ extern "C" int e3dge_selftest_mfma16(float* c, const float* a, const float* b, i
     selftest_mfma16_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(c, a, b, k);
     return check_launch("selftest_mfma16");
 }
+
+#ifdef E3DGE_16_TRACE
+extern "C" int e3dge_debug_trace16(unsigned long long* out48) {
+    return hipMemcpyFromSymbol(out48, HIP_SYMBOL(e3dge::g_trace16), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int e3dge_selftest_mfma16x16(float* c, const float* a, const float* b, int k, e3dge_stream_t stream) {
     E3DGE_REQUIRE(c && a && b && k > 0 && k <= 256 && (k % 32) == 0, "selftest_mfma16x16: bad arguments");

@@ -29,16 +29,22 @@ constexpr int k16Steps = 8;                      // k-steps of 32 per tile
 constexpr int k16ChunkFloats = 16 * kWidth;      // one tile x K = 256: 16 KiB
 constexpr int k16Chunks = kBigLayers * k16Tiles; // 128 chunks per 128-point sub-tile
 #ifndef E3DGE_16_PAIR
-#define E3DGE_16_PAIR 1
+#define E3DGE_16_PAIR 0
 #endif
-// Workgroup barrier every tile (0) or every second tile (1).  With two waves per SIMD taking turns on the matrix pipe, a
-// barrier per 16-feature tile re-aligns them every ~1.3 k cycles: thread 0 of the first version spent 26 % of the kernel
-// waiting in s_barrier (tools/phase_timing.py).  Per pair: five buffers -- chunks 2k, 2k+1 being read, 2k+2 published for the
-// fragment ring's look-ahead, 2k+3 and 2k+4 in flight.
+// Workgroup barrier every tile (0, default) or every second tile (1).  Thread 0 spends 26 % of the kernel in s_barrier
+// (tools/phase_timing.py), but halving the barriers changed nothing (0.3140 vs 0.3145 ms, profiles/r2 notes in DESIGN 4.1c): the
+// wait is where the two waves of a SIMD queue for the matrix pipe, not a cost of the barrier itself.  Per pair needs five
+// buffers -- chunks 2k, 2k+1 being read, 2k+2 published for the fragment ring's look-ahead, 2k+3 and 2k+4 in flight.
 constexpr bool k16Pair = E3DGE_16_PAIR != 0;
+#ifndef E3DGE_16_ABL
+#define E3DGE_16_ABL 0      // timing ablation (wrong results): 4 = no workgroup barrier in the weight pipe
+#endif
 constexpr int k16NBuf = k16Pair ? 5 : 4;          // LDS weight buffers
 constexpr int k16Slots = 2;                      // rays a 16-point slab can touch when S >= 16
-constexpr int k16Ring = 4;                       // k-steps of (hi, lo) fragments held in registers
+#ifndef E3DGE_16_RING
+#define E3DGE_16_RING 2     // 2, 4 and 8 measure the same (0.320 / 0.320 / 0.323 ms): the fragment reads are not latency-exposed
+#endif
+constexpr int k16Ring = E3DGE_16_RING;           // k-steps of (hi, lo) fragments held in registers (must divide 8)
 
 // ---- LDS carve (floats) ----
 constexpr int k16LdsW = 0;
@@ -97,13 +103,15 @@ __device__ __forceinline__ float row_sum16(float x) {
 struct ChunkPipe16 {
     const char* img;
     uint32_t voff, lds_base;
-    int idx, buf, use_buf;
+    int idx, buf, use_buf, count;
     float* wbuf;
     const float* wcur;
     const float* wnxt;
-    __device__ __forceinline__ void init(float* wbuf_, const float* image, int wave, int lane) {
+    // `image` = first chunk of the cycle, `count_` chunks per 128-point sub-tile (the cycle then starts over)
+    __device__ __forceinline__ void init(float* wbuf_, const float* image, int wave, int lane, int count_ = k16Chunks) {
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         wbuf = wbuf_;
+        count = count_;
         img = reinterpret_cast<const char*>(image) + wave_u * 2048;
         voff = (uint32_t)lane * 16u;
         lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) float*)wbuf_ + (uint32_t)wave_u * 2048u;
@@ -115,7 +123,7 @@ struct ChunkPipe16 {
         const uint32_t d = lds_base + (uint32_t)buf * (k16ChunkFloats * 4);
         glds16_saddr<0>(s, voff, d);
         glds16_saddr<1024>(s, voff, d);
-        idx = (idx + 1 == k16Chunks) ? 0 : idx + 1;
+        idx = (idx + 1 == count) ? 0 : idx + 1;
         buf = (buf + 1 == k16NBuf) ? 0 : buf + 1;
     }
     __device__ __forceinline__ void prime() {
@@ -134,7 +142,9 @@ struct ChunkPipe16 {
 #ifdef E3DGE_PHASE_TIMING
         const unsigned long long c1 = __builtin_readcyclecounter();
 #endif
+#if !(E3DGE_16_ABL & 4)
         __syncthreads();
+#endif
 #ifdef E3DGE_PHASE_TIMING
         t_vm += c1 - c0; t_bar += __builtin_readcyclecounter() - c1;
 #endif
@@ -146,21 +156,37 @@ struct ChunkPipe16 {
     }
 };
 
+#ifdef E3DGE_16_TRACE
+// profiling build: s_memtime at the start of every k-step and after its MFMAs, for one tile of two partner waves
+// (tools/trace16.py).  Inline asm, so no s_waitcnt is placed behind the stamps; they are collected after the tile.
+__device__ unsigned long long g_trace16[2][24];
+#define TRACE16_STAMP(i) do { if (trace) asm volatile("s_memtime %0" : "=s"(tstamp[i])); } while (0)
+#else
+#define TRACE16_STAMP(i) do { } while (0)
+#endif
+
 // K = 256 contraction of one 16-feature tile: 8 k-steps x (hi*hi, lo*hi, hi*lo) on two alternating accumulators.
 // On entry the ring holds k-steps 0..2 of this chunk; on exit k-steps 0..2 of the next one.
-template <bool TRANSPOSED, bool STRICT, class Epi>
+// `hook()` runs once, after k-step 1: the chunk wait + workgroup barrier + next DMA issue (and whatever else has to sit there).
+template <bool TRANSPOSED, int RING = k16Ring, class Epi, class Hook>
 __device__ __forceinline__ void tile16(ChunkPipe16& pipe, int lane, const u32x4 (&aH)[k16Steps], const u32x4 (&aL)[k16Steps],
-                                       f32x4v& acc, f32x4v& accb, u32x4 (&ringH)[k16Ring], u32x4 (&ringL)[k16Ring], Epi&& epi,
-                                       bool even_tile) {
-    const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(pipe.wcur) + lane;
-    const u32x4* __restrict__ wn = reinterpret_cast<const u32x4*>(pipe.wnxt) + lane;
+                                       f32x4v& acc, f32x4v& accb, u32x4 (&ringH)[RING], u32x4 (&ringL)[RING], Epi&& epi,
+                                       Hook&& hook, int sbuf = -1, [[maybe_unused]] int trace = 0) {
+#ifdef E3DGE_16_TRACE
+    unsigned long long tstamp[24];
+#endif
+    // sbuf >= 0: the caller knows the buffer index statically (tile index mod k16NBuf in a fully unrolled layer): the fragment
+    // reads then are one base register + immediates instead of per-buffer address registers
+    const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(sbuf >= 0 ? pipe.wbuf + sbuf * k16ChunkFloats : pipe.wcur) + lane;
+    const u32x4* __restrict__ wn = reinterpret_cast<const u32x4*>(sbuf >= 0 ? pipe.wbuf + ((sbuf + 1) % k16NBuf) * k16ChunkFloats : pipe.wnxt) + lane;
 #pragma unroll
     for (int g = 0; g < k16Steps; ++g) {
-        const int ga = g + k16Ring - 1;
-        ringH[ga % k16Ring] = (ga < k16Steps) ? wp[(ga * 2 + 0) * 64] : wn[((ga - k16Steps) * 2 + 0) * 64];
-        ringL[ga % k16Ring] = (ga < k16Steps) ? wp[(ga * 2 + 1) * 64] : wn[((ga - k16Steps) * 2 + 1) * 64];
+        const int ga = g + RING - 1;
+        TRACE16_STAMP(3 * g);
+        ringH[ga % RING] = (ga < k16Steps) ? wp[(ga * 2 + 0) * 64] : wn[((ga - k16Steps) * 2 + 0) * 64];
+        ringL[ga % RING] = (ga < k16Steps) ? wp[(ga * 2 + 1) * 64] : wn[((ga - k16Steps) * 2 + 1) * 64];
         __builtin_amdgcn_sched_barrier(0);
-        const u32x4 wh = ringH[g % k16Ring], wl = ringL[g % k16Ring];
+        const u32x4 wh = ringH[g % RING], wl = ringL[g % RING];
         f32x4v& x0 = (g & 1) ? accb : acc;
         f32x4v& x1 = (g & 1) ? acc : accb;
         if (!TRANSPOSED) {
@@ -172,15 +198,21 @@ __device__ __forceinline__ void tile16(ChunkPipe16& pipe, int lane, const u32x4 
             x1 = mfma16x16(aH[g], wl, x1);
             x0 = mfma16x16(aL[g], wh, x0);
         }
-        if (g == 1 && (!k16Pair || even_tile)) {
-            pipe.template sync<STRICT>();
-            pipe.issue_chunk();
-            if (k16Pair) pipe.issue_chunk();
-        }
+        TRACE16_STAMP(3 * g + 1);
+        if (g == 1) hook();
         epi(g);
+        TRACE16_STAMP(3 * g + 2);
     }
+#ifdef E3DGE_16_TRACE
+    if (trace) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if ((threadIdx.x & 63) == 0)
+            for (int i = 0; i < 24; ++i) g_trace16[trace - 1][i] = tstamp[i];
+    }
+#endif
 }
 
+#ifndef E3DGE_16_HELPERS_ONLY
 #ifdef E3DGE_PHASE_TIMING
 #define PHASE16(i) do { if (MODE == 0 && blockIdx.x == 0 && tid == 0 && sub < 3) tstamp[sub * 6 + (i)] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -267,6 +299,21 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
         }
     }
 
+#ifdef E3DGE_16_TRACE
+    auto trace_sel = [&](int L, int t) {
+        const int w = __builtin_amdgcn_readfirstlane(tid_k >> 6);
+        return (MODE == 0 && blockIdx.x == 7 && L == 3 && t == 6 && (w == 0 || w == 4)) ? 1 + (w >> 2) : 0;
+    };
+#else
+    auto trace_sel = [](int, int) { return 0; };
+#endif
+    auto fwd_hook = [&](bool even_tile) {
+        if (!k16Pair || even_tile) {
+            pipe.template sync<SAVE>();
+            pipe.issue_chunk();
+            if (k16Pair) pipe.issue_chunk();
+        }
+    };
     // packed f16 (hi, lo) activations of this wave's 16 points: word 2e + (r >> 1), half r & 1 of in?[g] = feature 32g + 16e + 4q + r
     u32x4 inH[k16Steps], inL[k16Steps], outH[k16Steps], outL[k16Steps];
 #ifdef E3DGE_PHASE_TIMING
@@ -385,27 +432,40 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             for (int t = 0; t < k16Tiles; ++t) {
                 f32x4v acc = zero4(), accb = zero4();
                 if (t == 0) {
-                    tile16<false, SAVE>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {}, (t & 1) == 0);
+                    tile16<false>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {}, [&]() { fwd_hook((t & 1) == 0); });
                 } else {
                     const int o = 16 * (t - 1) + 4 * q;
-                    f32x4v g4 = zero4(), b4 = zero4(), sarg = zero4();
-                    float xe = 0.f;
-                    tile16<false, SAVE>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [&](int g) {
-                        // spread over the k-steps: FiLM fetch at 0, one value per step at 1..4, stores / splits as values complete
+                    f32x4v g4 = zero4(), b4 = zero4(), arg4 = zero4(), kf4 = zero4(), x4 = zero4();
+                    tile16<false>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [&](int g) {
+                        // the FiLM + sine + split of tile t-1's four values, staged over the k-steps with the four values side by
+                        // side: every slice is four independent instructions deep instead of one dependent chain (a lone chain
+                        // leaves the wave -- in order -- waiting on VALU latency with nothing else to issue)
                         if (g == 0) {
                             g4 = *reinterpret_cast<const f32x4v*>(film_l + o);
                             b4 = *reinterpret_cast<const f32x4v*>(film_l + kWidth + o);
-                        } else if (g <= 4) {
-                            const int r = g - 1;
-                            const float arg = fmaf(g4[r], prev[r], b4[r]);
-                            const float x = sin_f32(arg);
-                            if (SAVE) sarg[r] = arg;
-                            if (r & 1) SPLIT2_TO(xe, x, outH[(t - 1) >> 1][2 * ((t - 1) & 1) + (r >> 1)], outL[(t - 1) >> 1][2 * ((t - 1) & 1) + (r >> 1)]);
-                            else xe = x;
-                        } else if (g == 5) {
-                            if (SAVE && sv) *reinterpret_cast<f32x4v*>(sv + L * kWidth + o) = sarg;
+                        } else if (g == 1) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) arg4[r] = fmaf(g4[r], prev[r], b4[r]);
+#ifndef E3DGE_POLY_SINE      // sin_hw_f32 (siren_common.h) in stages: period index, reduced argument in revolutions, v_sin
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) kf4[r] = rintf(arg4[r] * 0.15915494f);
+                        } else if (g == 2) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) kf4[r] = fmaf(arg4[r], 6.4206382e-09f, fmaf(arg4[r], 0.15915494f, -kf4[r]));
+#endif
+                        } else if (g == 3) {
+#pragma unroll
+#ifndef E3DGE_POLY_SINE
+                            for (int r = 0; r < 4; ++r) x4[r] = __builtin_amdgcn_sinf(kf4[r]);
+#else
+                            for (int r = 0; r < 4; ++r) x4[r] = sin_poly_f32(arg4[r]);
+#endif
+                            if (SAVE && sv) *reinterpret_cast<f32x4v*>(sv + L * kWidth + o) = arg4;
+                        } else if (g == 4) {
+                            SPLIT2_TO(x4[0], x4[1], outH[(t - 1) >> 1][2 * ((t - 1) & 1)], outL[(t - 1) >> 1][2 * ((t - 1) & 1)]);
+                            SPLIT2_TO(x4[2], x4[3], outH[(t - 1) >> 1][2 * ((t - 1) & 1) + 1], outL[(t - 1) >> 1][2 * ((t - 1) & 1) + 1]);
                         }
-                    }, (t & 1) == 0);
+                    }, [&]() { fwd_hook((t & 1) == 0); }, -1, trace_sel(L, t));
                 }
                 pipe.advance();
                 prev = acc + accb;
@@ -576,10 +636,10 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             for (int t = 0; t < k16Tiles; ++t) {
                 f32x4v acc = zero4(), accb = zero4();
                 if (t == 0) {
-                    tile16<true, SAVE>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {}, (t & 1) == 0);
+                    tile16<true>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {}, [&]() { fwd_hook((t & 1) == 0); });
                 } else {
                     epi_begin(t - 1);
-                    tile16<true, SAVE>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [&](int g) { if (g >= 1 && g <= 4) epi_r(g - 1); }, (t & 1) == 0);
+                    tile16<true>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [&](int g) { if (g >= 1 && g <= 4) epi_r(g - 1); }, [&]() { fwd_hook((t & 1) == 0); });
                     epi_end();
                 }
                 pipe.advance();
@@ -733,5 +793,7 @@ selftest_mfma16x16_kernel(float* __restrict__ cmat, const float* __restrict__ am
 #pragma unroll
     for (int r = 0; r < 4; ++r) cmat[(4 * q + r) * 16 + n] = acc[r];
 }
+
+#endif  // E3DGE_16_HELPERS_ONLY
 
 }  // namespace e3dge

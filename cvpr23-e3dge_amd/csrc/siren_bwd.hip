@@ -1028,6 +1028,8 @@ film_bwd_kernel(float* __restrict__ dstyles, const float* __restrict__ dfilm, co
 
 }  // namespace e3dge
 
+#include "siren16_bwd.h"
+
 using namespace e3dge;
 
 static int bwd_geometry(int batch, int64_t n_pts, int* subtiles_per_wg, int* wgs_per_img) {
@@ -1056,7 +1058,7 @@ static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfil
                   "siren_bwd: packed/args/d_feat must be 16-B aligned");
     float* const partials = k.partials;
     E3DGE_REQUIRE((k.tang == nullptr) == (k.rsave == nullptr), "siren_bwd: tang and rsave must come together");
-    E3DGE_REQUIRE(k.precision == E3DGE_PREC_F32 || k.precision == E3DGE_PREC_F16X3, "siren_bwd: precision=%d", k.precision);
+    E3DGE_REQUIRE(k.precision >= E3DGE_PREC_F32 && k.precision <= E3DGE_PREC_F16X3_G2, "siren_bwd: precision=%d", k.precision);
     E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(k.tang) | reinterpret_cast<uintptr_t>(k.rsave)) & 15) == 0, "siren_bwd: tang/rsave must be 16-B aligned");
     const bool tex = k.tex_alpha != nullptr;
     E3DGE_REQUIRE(tex == (k.d_tex_alpha != nullptr) && tex == (k.d_tex_beta != nullptr), "siren_bwd: tex_alpha, d_tex_alpha, d_tex_beta must come together");
@@ -1072,17 +1074,26 @@ static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfil
         &siren_bwd_kernel<true, false, false, true>, &siren_bwd_kernel<true, true, false, true>,
         &siren_bwd_kernel<false, false, true, false>, &siren_bwd_kernel<false, true, true, false>};
     E3DGE_REQUIRE(!(tex && k.d_pts), "siren_bwd: d_pts is not available on the tex-FiLM pass");
-    const int f16 = k.precision == E3DGE_PREC_F16X3;
-    const KernelFn fn = fns[tex ? 8 + f16 : 4 * (k.d_pts != nullptr) + 2 * (k.tang != nullptr) + f16];
+    // second generation (8 waves x 16 points): [dpts][eik], then the tex variant
+    static const KernelFn fns16[5] = {
+        &siren16_bwd_kernel<false, false, false>, &siren16_bwd_kernel<true, false, false>,
+        &siren16_bwd_kernel<false, false, true>, &siren16_bwd_kernel<true, false, true>,
+        &siren16_bwd_kernel<false, true, false>};
+    const bool gen2 = k.precision == E3DGE_PREC_F16X3_G2;
+    const int f16 = k.precision != E3DGE_PREC_F32;
+    const KernelFn fn = gen2 ? fns16[tex ? 4 : 2 * (k.d_pts != nullptr) + (k.tang != nullptr)]
+                             : fns[tex ? 8 + f16 : 4 * (k.d_pts != nullptr) + 2 * (k.tang != nullptr) + f16];
+    k.precision = f16 ? E3DGE_PREC_F16X3 : E3DGE_PREC_F32;
+    const int lds_bytes = gen2 ? kB16LdsBytes : kBwdLdsBytes;
     {   // the attribute is per device (and cheap): set it on the launch's device every time
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kBwdLdsBytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(siren_bwd): %s", hipGetErrorString(e));
     }
     bwd_geometry(batch, n_pts, &k.subtiles_per_wg, &k.wgs_per_img);
     if (n_pts > 0) {
         const int64_t grid = (int64_t)k.wgs_per_img * batch;
         E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_bwd: grid too large");
-        fn<<<dim3((unsigned)grid), dim3(kThreads), kBwdLdsBytes, st>>>(k);
+        fn<<<dim3((unsigned)grid), dim3(gen2 ? k16Threads : kThreads), lds_bytes, st>>>(k);
         int rc = check_launch("siren_bwd");
         if (rc) return rc;
     }
@@ -1146,16 +1157,18 @@ extern "C" int e3dge_siren_render_bwd(const E3dgeRenderBwdArgs* r, e3dge_stream_
 template <bool TANGENT>
 static int launch_chain(const float* packed, const float* film, const float* args, const float* seed, float box_scale,
                         int batch, int64_t n_pts, float* save, float* eik, int precision, hipStream_t st, const char* what) {
-    E3DGE_REQUIRE(precision == E3DGE_PREC_F32 || precision == E3DGE_PREC_F16X3, "%s: precision=%d", what, precision);
+    E3DGE_REQUIRE(precision >= E3DGE_PREC_F32 && precision <= E3DGE_PREC_F16X3_G2, "%s: precision=%d", what, precision);
     E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "%s: bad sizes", what);
     if (batch == 0 || n_pts == 0) return E3DGE_OK;
     E3DGE_REQUIRE(packed && film && args && save && (TANGENT ? seed != nullptr : eik != nullptr), "%s: null pointer", what);
     E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(args) | reinterpret_cast<uintptr_t>(save)) & 15) == 0,
                   "%s: packed/args/save must be 16-B aligned", what);
+    const bool gen2 = precision == E3DGE_PREC_F16X3_G2;
     {   // per device, cheap: set on every launch
-        const void* fn = (precision == E3DGE_PREC_F16X3) ? reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, true>)
-                                                          : reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, false>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kChLdsBytes);
+        const void* fn = gen2 ? reinterpret_cast<const void*>(&siren16_chain_kernel<TANGENT>)
+                       : (precision != E3DGE_PREC_F32) ? reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, true>)
+                                                             : reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, false>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, gen2 ? kC16LdsBytes : kChLdsBytes);
         if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
     }
     SirenChainK k{};
@@ -1164,7 +1177,8 @@ static int launch_chain(const float* packed, const float* film, const float* arg
     bwd_geometry(batch, n_pts, &k.subtiles_per_wg, &k.wgs_per_img);
     const int64_t grid = (int64_t)k.wgs_per_img * batch;
     E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "%s: grid too large", what);
-    if (precision == E3DGE_PREC_F16X3) siren_chain_kernel<TANGENT, true><<<dim3((unsigned)grid), dim3(kThreads), kChLdsBytes, st>>>(k);
+    if (gen2) siren16_chain_kernel<TANGENT><<<dim3((unsigned)grid), dim3(k16Threads), kC16LdsBytes, st>>>(k);
+    else if (precision != E3DGE_PREC_F32) siren_chain_kernel<TANGENT, true><<<dim3((unsigned)grid), dim3(kThreads), kChLdsBytes, st>>>(k);
     else siren_chain_kernel<TANGENT, false><<<dim3((unsigned)grid), dim3(kThreads), kChLdsBytes, st>>>(k);
     return check_launch(what);
 }

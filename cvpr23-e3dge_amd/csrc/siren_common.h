@@ -61,7 +61,10 @@ constexpr int64_t kOffBigT16 = kOffBigT + (int64_t)kChunksPerPass * kChunkFloats
 // -- the k order in which a lane's C/D registers of two consecutive 16-feature tiles of the previous layer (rows 4q + r)
 // are the 8 k-slots of the next layer's operand.
 constexpr int64_t kOffBig16b = kOffBigT16 + (int64_t)kChunksPerPass * kChunkFloats;
-constexpr int64_t kPackedFloats = kOffBig16b + (int64_t)kChunksPerPass * kChunkFloats;
+// the transposed GEMMs in the same 16x16x32 fragment order, for the 8-wave backward / sdf-chain kernels (siren16_bwd.h):
+// [Gb = 0..7 <-> layer L = 8 - Gb][16 t][8 g][hi|lo][64 lanes][4 words]; lane l holds 128 * W_L[32g + 16(j >> 2) + 4q + (j & 3)][16t + n]
+constexpr int64_t kOffBigT16b = kOffBig16b + (int64_t)kChunksPerPass * kChunkFloats;
+constexpr int64_t kPackedFloats = kOffBigT16b + (int64_t)kChunksPerPass * kChunkFloats;
 // f16x3 image: the same 64 chunks of 32 KiB, each [16 k-steps g = 2c+s][hi, lo][64 lanes][8 f16]: lane l holds
 //   128 * W[32t + (l&31)][32c + 16s + (j&3) + 8(j>>2) + 4(l>>5)],  j = 0..7
 // split as hi = f16(v), lo = f16(v - hi).  The k order is the one in which a lane's C/D registers of the previous

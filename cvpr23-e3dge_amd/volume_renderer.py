@@ -30,6 +30,8 @@ from . import _lib
 
 
 MFMA_MODES = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16x3_v1": _lib.PREC_F16X3_V1}
+# backward-type launches additionally know the experimental 8-wave layout (E3DGE_PREC_F16X3_G2; tools/bwd_ab.py)
+BWD_MODES = dict(MFMA_MODES, f16x3_g2=_lib.PREC_F16X3_G2)
 _STRICT_CACHE = os.environ.get("E3DGE_STRICT_WEIGHT_CACHE", "0") not in ("", "0")
 
 
@@ -48,8 +50,8 @@ def default_bwd_mode():
     gradient operand per point by a power of two before the (hi, lo) split."""
     import os
     mode = os.environ.get("E3DGE_BWD_MODE", default_mfma_mode())
-    if mode not in MFMA_MODES:
-        raise RuntimeError(f"E3DGE_BWD_MODE must be one of {sorted(MFMA_MODES)}, got {mode!r}")
+    if mode not in BWD_MODES:
+        raise RuntimeError(f"E3DGE_BWD_MODE must be one of {sorted(BWD_MODES)}, got {mode!r}")
     return mode
 
 
@@ -223,13 +225,13 @@ class SirenGenerator(nn.Module):
     def check_mode(self, mode):
         """Precision selector for a launch.  Weights outside the f16x3 image's range (|w| >= 256, see device_image) fall
         back to the fp32 MFMA kernels for this module, with one warning."""
-        if mode == "f16x3" and getattr(self, '_wmax', 0.0) >= 256.0:
+        if mode != "f32" and getattr(self, "_wmax", 0.0) >= 256.0:
             if not getattr(self, '_warned_range', False):
                 warnings.warn(f"SIREN weights up to {self._wmax:g} do not fit the f16x3 weight image (|w| < 256); "
                               "this module uses the fp32 MFMA kernels instead")
                 self._warned_range = True
             mode = "f32"
-        return MFMA_MODES[mode]
+        return BWD_MODES[mode]
 
     def require_frozen(self, what):
         """The HIP backward returns gradients for the styles (and, where stated, points / texture FiLM) only; the

@@ -174,8 +174,12 @@ int e3dge_torgb(float* y, const float* x, const float* weight, const float* styl
 #define E3DGE_PREC_F16X3 1        /* operands split as f16 hi+lo, 3 f16 MFMA products per fp32 product, fp32 accumulate.  Forward
                                      launches: 8 waves x 16 points on v_mfma_f32_16x16x32_f16; backward-type launches: 4 waves x 32
                                      points on v_mfma_f32_32x32x16_f16 with per-point block scaling */
-#define E3DGE_PREC_F16X3_V1 2     /* forward launches only: the first-generation split-f16 kernel (4 waves x 32 points,
-                                     v_mfma_f32_32x32x16_f16), kept for A/B measurements */
+#define E3DGE_PREC_F16X3_V1 2     /* forward launches: the first-generation split-f16 kernel (4 waves x 32 points,
+                                     v_mfma_f32_32x32x16_f16), kept for A/B measurements; backward-type launches: same as
+                                     E3DGE_PREC_F16X3 */
+#define E3DGE_PREC_F16X3_G2 3     /* backward-type launches only (e3dge_siren_bwd / _render_bwd / _sdf_grad / _tangent): the
+                                     8-wave x 16-point layout of the forward kernel applied to the backward chains.  Same results
+                                     within rounding, not faster -- kept for A/B measurements (tools/bwd_ab.py) */
 
 /* Number of floats of the packed weight image produced by e3dge_siren_pack_weights. */
 int64_t e3dge_siren_packed_floats(void);

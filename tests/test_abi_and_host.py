@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.e3dge_abi_version() == _lib.ABI_VERSION
     # fp32 fragment image + small blocks, the f16x3 (hi, lo) image of the same 64 chunks, the transposed fp32 and f16x3 images
     # ... and the 16x16x32 image of the 8-wave forward kernel
-    assert lib.e3dge_siren_packed_floats() == (64 * 8192 + 2 * 1024 + 9 * 256 + 4 * 256 + 4) + 4 * 64 * 8192
+    assert lib.e3dge_siren_packed_floats() == (64 * 8192 + 2 * 1024 + 9 * 256 + 4 * 256 + 4) + 5 * 64 * 8192
 
 
 def test_render_args_struct_layout_matches_c():

@@ -40,7 +40,8 @@ MODES = ["f16x3", "f32", "f16x3_v1"]     # every contraction kernel must meet th
 def make_renderer(sd, res, S, mfma_mode=None, **over):
     r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S, **over), out_im_res=res, mode='test')
     if mfma_mode is not None:
-        r.siren.mfma_mode = mfma_mode
+        # 'f16x3_g2' exists for the backward-type kernels only (8-wave layout, kept for A/B): forward stays f16x3
+        r.siren.mfma_mode = "f16x3" if mfma_mode == "f16x3_g2" else mfma_mode
         r.siren.bwd_mode = mfma_mode          # the backward-type kernels run in the same mode
     pre = 'network.netGlobal.' if over.get('enable_local_model') else 'network.'
     own = {}
