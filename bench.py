@@ -21,6 +21,7 @@ Extra objects on the JSON line:
   c3            BASELINE configs[2]: per-image evaluation (pass #1, texture head, pass #2, decoder 64^2 -> 1024^2, 8 metric
                 scalars) sharded over the ranks with one all_gather of the metric rows.
   c4            BASELINE configs[3]: the 120-pose sweep at 128x128x48, sequential and batched 8 poses per launch.
+  surface       surface extraction, device half: 128x128 rays x 128 samples + align_volume.
   train_step_ms BASELINE configs[4], renderer part: stage-1 step at 64x64x18 with the eikonal losses, fwd + bwd.
   inversion_fwd_ms  pass #1 + texture head + pass #2 + decoder to 1024^2, one image.
   cpu_baseline  the oracle restatement (oracle/renderer_ref.py, "port": bit-identical to the reference's PyTorch path on
@@ -59,6 +60,7 @@ def parse_args():
     ap.add_argument("--no-inversion", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
     ap.add_argument("--no-c4", action="store_true")
+    ap.add_argument("--no-surface", action="store_true")
     ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--no-modes", action="store_true")
     ap.add_argument("--no-sustained", action="store_true")
@@ -94,7 +96,7 @@ def self_launch(args):
 def main():
     args = parse_args()
     if args.headline_only:
-        args.no_cpu_baseline = args.no_inversion = args.no_train_step = args.no_c4 = args.no_c3 = True
+        args.no_cpu_baseline = args.no_inversion = args.no_train_step = args.no_c4 = args.no_c3 = args.no_surface = True
         args.no_modes = args.no_sustained = True
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -378,6 +380,42 @@ def main():
             del r4
         except Exception as exc:
             result["c4"] = {"failed": f"{type(exc).__name__}: {exc}"}
+
+    # ---------------------------------------------------------------- surface extraction: 128^3 SDF volume + align_volume
+    if rank == 0 and not args.no_surface:
+        try:
+            from e3dge_amd import mesh_utils
+            rs_ = VolumeFeatureRenderer(syn.rendering_opt(N_samples=128), out_im_res=128, mode='test')   # train_setup.py:112-126
+            rs_.load_state_dict(renderer.state_dict())
+            rs_ = rs_.to(dev)
+            ws_, _ = syn.synthetic_inputs(1, seed=1, device=dev)
+            ps_, fs_, ns_, fas_, _ = generate_camera_params(128, dev, locations=torch.zeros(1, 2, device=dev))
+            with torch.no_grad():
+                def extract():
+                    o = rs_(ps_, fs_, ns_, fas_, styles=ws_)
+                    return mesh_utils.align_volume(o['sdf'])
+                for _ in range(2):
+                    extract()
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                torch.cuda.synchronize()
+                ev[0].record()
+                for _ in range(5):
+                    o = rs_(ps_, fs_, ns_, fas_, styles=ws_)
+                ev[1].record()
+                for _ in range(5):
+                    mesh_utils.align_volume(o['sdf'])
+                ev[2].record()
+                torch.cuda.synchronize()
+                ms_r, ms_a = ev[0].elapsed_time(ev[1]) / 5, ev[1].elapsed_time(ev[2]) / 5
+            result["surface"] = {"render_ms": ms_r, "align_volume_ms": ms_a, "points": 128 ** 3,
+                                 "points_per_s": 128 ** 3 / ms_r * 1e3,
+                                 "algorithmic_tflops": 2 * MAC_PER_POINT * 128 ** 3 / (ms_r * 1e-3) / 1e12,
+                                 "align_volume_GBps": 8 * 128 ** 3 / (ms_a * 1e-3) / 1e9,
+                                 "note": "surf_extraction generator (train_setup.py:112-126): 128x128 rays x 128 samples, then "
+                                         "align_volume (mesh_utils.py:17-44); marching cubes (CPU, third-party) not included"}
+            del rs_
+        except Exception as exc:
+            result["surface"] = {"failed": f"{type(exc).__name__}: {exc}"}
 
     # ---------------------------------------------------------------- C5: stage-1 training step of the renderer
     if rank == 0 and not args.no_train_step:

@@ -94,6 +94,7 @@ SIGNATURES = {
     "e3dge_pos_encoding": (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _vp]),
     "e3dge_image_metrics_scratch_floats": (_i64, [_i32, _i32, _i32, _i32]),
     "e3dge_image_metrics": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "e3dge_align_volume": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "e3dge_selftest_mfma": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "e3dge_selftest_mfma16": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "e3dge_selftest_mfma16x16": (_i32, [_vp, _vp, _vp, _i32, _vp]),

@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             for (int t = 0; t < k16Tiles; ++t) {
                 f32x4v acc = zero4(), accb = zero4();
                 if (t == 0) {
-                    tile16<false>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {}, [&]() { fwd_hook((t & 1) == 0); });
+                    tile16<false>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {}, [&]() { fwd_hook((t & 1) == 0); }, k16Pair ? -1 : t % k16NBuf);
                 } else {
                     const int o = 16 * (t - 1) + 4 * q;
                     f32x4v g4 = zero4(), b4 = zero4(), arg4 = zero4(), kf4 = zero4(), x4 = zero4();
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
                             SPLIT2_TO(x4[0], x4[1], outH[(t - 1) >> 1][2 * ((t - 1) & 1)], outL[(t - 1) >> 1][2 * ((t - 1) & 1)]);
                             SPLIT2_TO(x4[2], x4[3], outH[(t - 1) >> 1][2 * ((t - 1) & 1) + 1], outL[(t - 1) >> 1][2 * ((t - 1) & 1) + 1]);
                         }
-                    }, [&]() { fwd_hook((t & 1) == 0); }, -1, trace_sel(L, t));
+                    }, [&]() { fwd_hook((t & 1) == 0); }, k16Pair ? -1 : t % k16NBuf, trace_sel(L, t));
                 }
                 pipe.advance();
                 prev = acc + accb;

@@ -864,8 +864,6 @@ class VolumeFeatureRenderer(nn.Module):
     def forward(self, cam_poses, focal, near, far, styles=None, return_eikonal=False, geometry_sample=None,
                 return_surface_eikonal=False, local_data_batch=None, sample_mode=False, return_mesh=False,
                 mesh_with_shading=True, return_sdf_only=False, sample_without_grad=False, **kwargs):
-        if return_mesh:
-            raise NotImplementedError("marching-cubes mesh extraction is out of scope (SURVEY.md 2 #13)")
         if sample_without_grad and torch.is_grad_enabled():
             # the reference detaches every output in this mode (:1291-1294); running the whole query without a graph is
             # the same result without saving 9.2 KB of pre-sine arguments per point
@@ -896,6 +894,17 @@ class VolumeFeatureRenderer(nn.Module):
             self.local_batch = None
 
         render_out = self.render(focal, cam_poses, near, far, styles, tex_conditions=tex, return_eikonal=return_eikonal)
+        if return_mesh:
+            # surface extraction (:1703-1731): the rendered SDF volume onto the regular grid in HIP; marching cubes itself is
+            # third-party CPU code -- 'mesh' is filled when scikit-image / trimesh are installed, 'aligned_sdf' always
+            from . import mesh_utils
+            render_out['aligned_sdf'] = mesh_utils.align_volume(render_out['sdf'].detach())
+            try:
+                mesh, verts, faces = mesh_utils.marching_cubes_mesh(render_out['aligned_sdf'])
+                render_out['mesh'], render_out['shaded_mesh'] = mesh, mesh
+            except (ImportError, ValueError) as e:           # ValueError: no zero crossing (the reference prints and goes on)
+                render_out['mesh'] = render_out['shaded_mesh'] = None
+                render_out['mesh_error'] = str(e)
         if return_surface_eikonal:
             # normal at the integrated surface point (:921-930).  As in the reference the point stays in the graph: the
             # term's gradient reaches the styles through the network AND through d xyz / d styles (the Hessian-vector

@@ -389,6 +389,16 @@ int64_t e3dge_image_metrics_scratch_floats(int batch, int channels, int height, 
 int e3dge_image_metrics(float* sums, float* scratch, const float* pred, const float* gt, int batch, int channels,
                         int height, int width, float max_val, e3dge_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Surface extraction, device half: replaces align_volume (project/utils/mesh_utils.py:17-44; called on the rendered
+ * 128^3 SDF volume at volume_renderer.py:1706, before the CPU marching cubes).  volume, out (batch, height, width, depth,
+ * channels), not aliased; xs (width), ys (height), zs (depth) = linspace(-1, 1, n) and coef (depth) = linspace(far / near,
+ * 1, depth) as the caller's torch.linspace produced them.  out[b, y, x, z] = trilinear border-clamped lookup
+ * (grid_sample, align_corners) at (xs[x] coef[z], ys[y] coef[z], zs[z]), or 1 where that point leaves [-1, 1]^3.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int e3dge_align_volume(float* out, const float* volume, const float* xs, const float* ys, const float* zs, const float* coef,
+                       int batch, int height, int width, int depth, int channels, e3dge_stream_t stream);
+
 /* Layout self-test: runs a 32x32xK fp32-MFMA product with the fragment conventions the render kernel
  * relies on and writes it to c (32*32 floats, row-major) for the caller to compare with a @ b^T.
  * a: (32, k) row-major, b: (32, k) row-major, k multiple of 8, k <= 256. */

@@ -212,7 +212,7 @@ def test_unsupported_options_fail_loudly():
     with pytest.raises(NotImplementedError):
         VolumeFeatureRenderer(syn.rendering_opt(depth=6))
     r = VolumeFeatureRenderer(syn.rendering_opt(), mode='test')
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU path"):        # the product path never falls back to the CPU
         r(None, None, None, None, styles=None, return_mesh=True)
 
 
