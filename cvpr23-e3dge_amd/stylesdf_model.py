@@ -592,6 +592,51 @@ class Generator(nn.Module):
         return styles
 
 
+    def init_forward(self, *a, **k):
+        raise NotImplementedError("sphere-initialisation pre-training (mlp_init_pass, reference :923-932) is outside this build")
+
+    def data_sample_forward(self, *a, **k):
+        raise NotImplementedError("sdf_sample_pass (reference :905-921) is outside this build")
+
+    def forward(self, styles, cam_poses, focals, near=0.88, far=1.12, return_latents=False, inject_index=None,
+                truncation=1, truncation_latent=None, input_is_latent=False, noise=None, randomize_noise=True,
+                return_sdf=False, return_xyz=False, return_eikonal=False, project_noise=False, return_mesh=False,
+                mesh_with_shading=True, mesh_path=None, pred_decoder_latents=None, sample_mode=False,
+                diable_decoder_inference=False):
+        """The base class entry (reference :934-1020) -- what the surface-extraction generator `surface_g_ema` is called
+        through (train_setup.py:112-126): tuple (rgb or None, thumb [, xyz] [, sdf] [, eikonal_term] [, mask]).
+        [`diable_decoder_inference` is the reference's spelling.]"""
+        if project_noise:
+            raise NotImplementedError("project_noise is out of scope")
+        # as the reference: no renderer graph when its weights are frozen
+        with torch.set_grad_enabled(torch.is_grad_enabled() and self.is_train and self.train_renderer):
+            latent = self.styles_and_noise_forward(styles, inject_index, truncation, truncation_latent, input_is_latent)
+            sample_batch = self.renderer(cam_poses, focals, near, far, styles=latent[0], return_eikonal=return_eikonal,
+                                         sample_mode=sample_mode, return_mesh=return_mesh, mesh_with_shading=mesh_with_shading)
+            if sample_mode:
+                return sample_batch
+        rgb = decoder_latent = None
+        if self.full_pipeline and not diable_decoder_inference:
+            decoder_latent = latent if pred_decoder_latents is None else pred_decoder_latents
+            rgb, decoder_latent = self.decoder(sample_batch['features'], decoder_latent, transform=None,
+                                               return_latents=return_latents, inject_index=inject_index, truncation=truncation,
+                                               truncation_latent=truncation_latent, noise=noise,
+                                               input_is_latent=input_is_latent, randomize_noise=randomize_noise,
+                                               mesh_path=mesh_path)
+        if return_latents:
+            return rgb, decoder_latent
+        out = (rgb, sample_batch['gen_thumb_imgs'])
+        if return_xyz:
+            out += (sample_batch['xyz'],)
+        if return_sdf:
+            out += (sample_batch['sdf'],)
+        if return_eikonal:
+            out += (sample_batch['eikonal_term'],)
+        if return_xyz:
+            out += (sample_batch['mask'],)
+        return out
+
+
 class G_pred_latents(Generator):
     """The generator entry the runners call (reference :1023-1172, call site trainer.py:881-897):
     `generator([w_renderer, w_decoder], cam_poses, focals, near, far, input_is_latent=True, ...) -> dict`."""

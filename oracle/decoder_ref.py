@@ -51,16 +51,25 @@ def decoder_mapping(sd, w, prefix='decoder.style.', lr_mul=0.01):
     return x
 
 
+def modulated_weights(weight, s, demodulate=True):
+    """The per-sample kernels of ModulatedConv2d.forward: weight (1, Co, Ci, k, k), modulation s (B, Ci) ->
+    (B, Co, Ci, k, k) = scale * weight * s (:321) [* rsqrt(sum over (Ci, k, k) of its square + 1e-8) (:325-326)]."""
+    _, Co, Ci, k, _ = weight.shape
+    B = s.shape[0]
+    w = (1 / math.sqrt(Ci * k * k)) * weight * s.reshape(B, 1, Ci, 1, 1)
+    if demodulate:
+        w = w * torch.rsqrt(w.pow(2).sum([2, 3, 4]) + 1e-8).reshape(B, Co, 1, 1, 1)
+    return w
+
+
 def modulated_conv(sd, prefix, x, style, demodulate=True, upsample=False):
     """ModulatedConv2d.forward :317-362 (no downsample branch on this path)."""
     dt = x.dtype
     weight = _w(sd, prefix + 'weight', dt)                          # (1, Co, Ci, k, k)
     _, Co, Ci, k, _ = weight.shape
     B, _, H, W = x.shape
-    s = equal_linear(sd, prefix + 'modulation.', style).reshape(B, 1, Ci, 1, 1)   # bias_init 1 lives in the weights
-    w = (1 / math.sqrt(Ci * k * k)) * weight * s                    # :321
-    if demodulate:
-        w = w * torch.rsqrt(w.pow(2).sum([2, 3, 4]) + 1e-8).reshape(B, Co, 1, 1, 1)   # :325-326
+    s = equal_linear(sd, prefix + 'modulation.', style)             # bias_init 1 lives in the weights
+    w = modulated_weights(weight, s, demodulate)
     if upsample:
         wt = w.transpose(1, 2).reshape(B * Ci, Co, k, k)            # :333-338
         out = F.conv_transpose2d(x.reshape(1, B * Ci, H, W), wt, padding=0, stride=2, groups=B)

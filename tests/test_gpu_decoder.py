@@ -80,3 +80,51 @@ def test_generator_call_surface(gen):
     with torch.no_grad():
         rnd = g([wr, wd], T(gold['poses']), T(gold['focal']), T(gold['near']), T(gold['far']), input_is_latent=True)
     assert torch.isfinite(rnd['gen_imgs']).all() and not torch.equal(rnd['gen_imgs'], out['gen_imgs'])
+
+
+def test_z_space_input_with_truncation_against_reference(gen):
+    """input_is_latent=False + truncation < 1 end to end (styles_and_noise_forward :869-903, decoder side :692-740): the z code
+    goes through the renderer's mapping network, is pulled towards the mean latent, the decoder maps it again."""
+    g, sd = gen
+    gold = load_golden("generator_z_base")
+    z = T(gold['z'])
+    with torch.no_grad():
+        mean_r = g.style(T(gold['z_mean'])).mean(0, keepdim=True)
+        mean_d = g.decoder.mean_latent(mean_r)
+        out = g([z], T(gold['poses']), T(gold['focal']), T(gold['near']), T(gold['far']), input_is_latent=False, truncation=0.7,
+                truncation_latent=[mean_r, mean_d], randomize_noise=False)
+        plain = g([z], T(gold['poses']), T(gold['focal']), T(gold['near']), T(gold['far']), input_is_latent=False,
+                  randomize_noise=False)
+    e = dict(mean_r=maxerr(mean_r, gold['ref_mean_r']), mean_d=maxerr(mean_d, gold['ref_mean_d']),
+             mean_d_scale=float(np.abs(gold['ref_mean_d']).max()),
+             styles=maxerr(out['styles'], gold['ref_styles']), thumb=maxerr(out['gen_thumb_imgs'], gold['ref_gen_thumb_imgs']),
+             depth=maxerr(out['depth'], gold['ref_depth']), gen_imgs=maxerr(out['gen_imgs'][:, :, ::2, ::2], gold['ref_gen_imgs_sub2']),
+             plain_thumb=maxerr(plain['gen_thumb_imgs'], gold['ref_plain_thumb']))
+    record("generator_z_truncation", **e)
+    assert tuple(out['styles'].shape) == (1, 256)
+    assert e['mean_r'] <= 2e-5 and e['mean_d'] <= 2e-4 * e['mean_d_scale'] and e['styles'] <= 2e-5
+    assert e['thumb'] <= 2e-5 and e['plain_thumb'] <= 2e-5 and e['depth'] <= 1e-5
+    assert e['gen_imgs'] <= IMG_ATOL
+    assert maxerr(out['gen_thumb_imgs'], plain['gen_thumb_imgs']) > 1e-3            # truncation really moved the latent
+
+
+def test_base_generator_forward_as_the_surface_extraction_generator_calls_it():
+    """Generator.forward of the base class (:934-1020) with full_pipeline=False, return_sdf / return_xyz (train_setup.py:112-126)."""
+    from e3dge_amd.stylesdf_model import Generator
+    gold = load_golden("generator_z_base")
+    gs = Generator(syn.model_opt(size=256, channel_multiplier=1, renderer_spatial_output_dim=16), syn.rendering_opt(N_samples=16),
+                   full_pipeline=False)
+    syn.load_synthetic(gs)
+    gs = gs.to(DEV).eval()
+    wr, _ = syn.synthetic_inputs(1, seed=int(gold['s_styles_seed']), device=DEV)
+    with torch.no_grad():
+        tup = gs([wr], T(gold['s_poses']), T(gold['s_focal']), T(gold['s_near']), T(gold['s_far']), input_is_latent=True,
+                 return_sdf=True, return_xyz=True)
+        two = gs([wr], T(gold['s_poses']), T(gold['s_focal']), T(gold['s_near']), T(gold['s_far']), input_is_latent=True)
+    assert len(tup) == 5 and tup[0] is None and len(two) == 2
+    e = dict(thumb=maxerr(tup[1], gold['s_ref_thumb']), xyz=maxerr(tup[2], gold['s_ref_xyz']), sdf=maxerr(tup[3], gold['s_ref_sdf']),
+             mask=maxerr(tup[4], gold['s_ref_mask']))
+    record("base_generator_forward", **e)
+    assert e['thumb'] <= 5e-6 and e['xyz'] <= 2e-6 and e['sdf'] <= 2e-5 and e['mask'] == 0
+    with pytest.raises(NotImplementedError):
+        gs.init_forward([wr], None, None)

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import load_golden, maxerr, record
-from oracle import ops_ref
+from oracle import decoder_ref, ops_ref
 
 import e3dge_amd  # noqa: F401
 from e3dge_amd import _lib, op
@@ -204,9 +204,8 @@ def test_modconv_weights_kernel():
         w = torch.from_numpy(rs.standard_normal((Co, Ci, k * k)).astype(np.float32))
         s = torch.from_numpy((1 + 0.1 * rs.standard_normal((B, Ci))).astype(np.float32))
         scale = 1 / np.sqrt(Ci * k * k)
-        ww = scale * w[None] * s[:, None, :, None]
-        if demod:
-            ww = ww * torch.rsqrt(ww.pow(2).sum([2, 3]) + 1e-8)[:, :, None, None]
+        # the oracle's restatement of ModulatedConv2d's weight preparation (oracle/decoder_ref.py, reference :321-326)
+        ww = decoder_ref.modulated_weights(w.view(1, Co, Ci, k, k), s, bool(demod)).reshape(B, Co, Ci, k * k)
         want = ww.transpose(1, 2).reshape(B * Ci, Co, k * k) if tr else ww.reshape(B * Co, Ci, k * k)
         out = torch.empty(want.shape, device=DEV)
         lib = _lib.load()
