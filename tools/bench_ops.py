@@ -1,5 +1,5 @@
 """HBM roofline of the stream ops at the decoder's real sizes (B=1, 1024^2 generator): GB/s = algorithmic bytes /
-mean kernel time (HIP events on the launch stream), against 8 TB/s peak (6.3 TB/s achievable, MI355X_MICROARCH.md).
+mean kernel time (HIP events around a replayed HIP graph of 30 launches), against 8 TB/s peak (6.3 TB/s achievable, MI355X_MICROARCH.md).
 Prints one JSON line per case."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,18 +13,37 @@ k4 = (make_kernel([1, 3, 3, 1]) * 4).to(dev)
 
 
 def timeit(fn, n=30, warm=5):
+    """Mean GPU time of one call.  The n calls are captured into one HIP graph and replayed, so the figure is the kernels'
+    own back-to-back time: launched one by one from Python the small cases measure the host's launch rate (~17 us per call)
+    instead.  Falls back to plain event timing if the capture fails."""
     for _ in range(warm):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    e0.record()
-    for _ in range(n):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(n):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        TIMING.append("hip graph replay")
+    except Exception as exc:                                   # noqa: BLE001
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        TIMING.append(f"eager launches ({type(exc).__name__})")
     return e0.elapsed_time(e1) / n * 1e-3
 
 
+TIMING = []
 cases = []
 with torch.no_grad():
     for C, L in [(256, 128), (128, 256), (64, 512), (32, 1024)]:
@@ -55,9 +74,9 @@ with torch.no_grad():
         y = torch.empty(1, C, L, L, device=dev)
         nz = torch.randn(1, L * L, device=dev); nw = torch.full((1,), 0.1, device=dev); b = torch.randn(C, device=dev)
         am = torch.zeros(_lib.AMAX_FLOATS, device=dev)
-        st = torch.cuda.current_stream().cuda_stream
         t = timeit(lambda: lib.e3dge_blur_noise_bias_act(y.data_ptr(), x.data_ptr(), k4.data_ptr(), nz.data_ptr(), nw.data_ptr(), b.data_ptr(),
-                                                         0.2, 2 ** 0.5, 1, C, L + 1, L + 1, 1, 1, 1, am.data_ptr(), st))
+                                                         0.2, 2 ** 0.5, 1, C, L + 1, L + 1, 1, 1, 1, am.data_ptr(),
+                                                         torch.cuda.current_stream().cuda_stream))
         by = 4 * (x.numel() + y.numel() + nz.numel())
         cases.append(dict(op="blur+noise+bias+lrelu (+amax), one pass", shape=[C, L + 1, L + 1], bytes=by, us=t * 1e6, GBps=by / t / 1e9))
     for C, L in [(512, 64), (256, 128), (128, 256), (64, 512), (32, 1024)]:
@@ -68,6 +87,7 @@ with torch.no_grad():
         by = 4 * (x.numel() + 3 * L * L + skip.numel())
         cases.append(dict(op="ToRGB fused (1x1 modconv + bias + up-sampled skip; includes the modulation GEMV launch)", shape=[C, L, L],
                           bytes=by, us=t * 1e6, GBps=by / t / 1e9))
-for c in cases:
+for c, how in zip(cases, TIMING):
     c["frac_of_8TBps"] = c["GBps"] / 8000.0
+    c["timing"] = how
     print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()}))
