@@ -23,7 +23,8 @@ Extra objects on the JSON line:
   c4            BASELINE configs[3]: the 120-pose sweep at 128x128x48, sequential and batched 8 poses per launch.
   surface       surface extraction, device half: 128x128 rays x 128 samples + align_volume.
   train_step_ms BASELINE configs[4], renderer part: stage-1 step at 64x64x18 with the eikonal losses, fwd + bwd.
-  inversion_fwd_ms  pass #1 + texture head + pass #2 + decoder to 1024^2, one image.
+  inversion_fwd_ms  pass #1 + texture head + pass #2 + decoder to 1024^2, one image (inversion_fwd_graph_ms: the same launches
+                replayed as one HIP graph).
   cpu_baseline  the oracle restatement (oracle/renderer_ref.py, "port": bit-identical to the reference's PyTorch path on
                 the golden vectors) timed on this host's cores on a bounded sample.
 """
@@ -339,6 +340,23 @@ def main():
                                                 "resulting texture FiLM + decoder 64^2->1024^2; encoder and the local branch's image "
                                                 "filters excluded (out of scope)")
                 assert tuple(o['gen_imgs'].shape) == (1, 3, 1024, 1024)
+                ref_img = o['gen_imgs'].clone()
+            # the same ~60 launches replayed as one HIP graph (cvpr23-e3dge_amd/graphs.py)
+            try:
+                from e3dge_amd.graphs import GraphedCall
+                gi = GraphedCall(lambda a, b: inversion(a, b)['gen_imgs'], w1, d1)
+                img_g = gi(w1, d1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(n_inv):
+                    img_g = gi(w1, d1)
+                torch.cuda.synchronize()
+                result["inversion_fwd_graph_ms"] = 1e3 * (time.perf_counter() - t1) / n_inv
+                result["inversion_fwd_graph_max_abs_diff_vs_eager"] = float((img_g - ref_img).abs().max())
+                del gi
+            except Exception as exc:
+                result["inversion_fwd_graph_ms"] = None
+                result["inversion_fwd_graph_note"] = f"capture failed: {type(exc).__name__}: {exc}"
         except Exception as exc:
             result["inversion_fwd_ms"] = None
             result["inversion_fwd_note"] = f"failed: {type(exc).__name__}: {exc}"
