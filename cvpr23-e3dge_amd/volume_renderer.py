@@ -30,6 +30,7 @@ from . import _lib
 
 
 MFMA_MODES = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16x3_v1": _lib.PREC_F16X3_V1}
+_SIDE_STREAM = __import__("os").environ.get("E3DGE_SIDE_STREAM", "1") != "0"   # surface-normal query beside the sdf chain
 # backward-type launches additionally know the experimental 8-wave layout (E3DGE_PREC_F16X3_G2; tools/bwd_ab.py)
 BWD_MODES = dict(MFMA_MODES, f16x3_g2=_lib.PREC_F16X3_G2)
 _STRICT_CACHE = os.environ.get("E3DGE_STRICT_WEIGHT_CACHE", "0") not in ("", "0")
@@ -415,6 +416,34 @@ _DIFF_KEYS = ('gen_thumb_imgs', 'features', 'xyz', 'depth', 'sdf', 'hit_prob', '
 _AUX_KEYS = ('mask', 'points', 'rays_d', 'viewdirs', 'dists')
 
 
+class _EikShared:
+    """What the eikonal tap below and _RenderQuery.backward share: the tangent arguments of the incoming d(eikonal term)."""
+    __slots__ = ("siren", "film", "args", "box_scale", "tang", "d_eik")
+
+    def __init__(self):
+        self.siren = self.film = self.args = self.box_scale = self.tang = self.d_eik = None
+
+
+class _EikTap(torch.autograd.Function):
+    """Identity on the eikonal term whose backward launches the tangent kernel (e3dge_siren_tangent) as soon as
+    d(eikonal term) exists.  _RenderQuery.backward also needs d(xyz), which arrives from the surface-normal query's backward
+    on the side stream; started from here, the 7-GEMM tangent pass of the ray samples runs beside that instead of after it."""
+
+    @staticmethod
+    def forward(ctx, eik, shared):
+        ctx.shared = shared
+        return eik.view_as(eik)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_eik):
+        sh = ctx.shared
+        if d_eik is not None and sh.args is not None:
+            sh.d_eik = d_eik
+            sh.tang = tangent_arguments(sh.siren, sh.film, sh.args, d_eik, sh.box_scale)
+        return d_eik, None
+
+
 class _RenderQuery(torch.autograd.Function):
     """VolumeFeatureRenderer.render with a gradient path from (rgb, features, xyz, depth, sdf, hit_prob, eikonal term) to
     the styles and -- on the second pass -- to the per-point texture FiLM (alpha, beta): e3dge_siren_render_fwd with saved
@@ -423,19 +452,26 @@ class _RenderQuery(torch.autograd.Function):
     @staticmethod
     def differentiable(renderer, styles, focal, c2w, near, far, want_eik=False, tex_conditions=None):
         ta, tb = tex_conditions if tex_conditions is not None else (None, None)
-        vals = _RenderQuery.apply(styles, renderer, focal, c2w, near, far, bool(want_eik), ta, tb)
+        shared = _EikShared() if want_eik else None
+        vals = _RenderQuery.apply(styles, renderer, focal, c2w, near, far, bool(want_eik), ta, tb, shared)
         out = dict(zip(_DIFF_KEYS + _AUX_KEYS, vals))
         if not want_eik:
             out['eikonal_term'] = None
+        elif out['eikonal_term'].requires_grad:
+            out['eikonal_term'] = _EikTap.apply(out['eikonal_term'], shared)
         return renderer._render_dict(out, c2w, near, far)
 
     @staticmethod
-    def forward(ctx, styles, renderer, focal, c2w, near, far, want_eik, tex_alpha, tex_beta):
+    def forward(ctx, styles, renderer, focal, c2w, near, far, want_eik, tex_alpha, tex_beta, shared=None):
         B, H, S = c2w.shape[0], renderer.out_im_res, renderer.N_samples
         film = renderer.siren.film_params(styles)
         args = torch.empty((B, H * H * S, 9, renderer.siren.W), device=c2w.device, dtype=torch.float32)
         tex = None if tex_alpha is None else (tex_alpha.detach(), tex_beta.detach())
         out = renderer.render_with_film(film, focal, c2w, near, far, tex, save_args=args)
+        # marks "xyz is ready" on the launch stream: the surface-normal query that follows in forward() depends on this launch
+        # only, not on the sdf chain below, and runs beside it on a side stream
+        renderer._render_done = torch.cuda.Event()
+        renderer._render_done.record(torch.cuda.current_stream(c2w.device))
         if want_eik:
             eik, rsave = sdf_gradient(renderer.siren, film, args, renderer.box_scale)
             out['eikonal_term'] = eik.reshape(B, H, H, S, 3)
@@ -444,6 +480,9 @@ class _RenderQuery(torch.autograd.Function):
         ctx.renderer, ctx.styles_ndim, ctx.want_eik = renderer, styles.ndim, want_eik
         ctx.sigmoid_beta = renderer._sigmoid_beta_value()
         ctx.has_tex = tex is not None
+        ctx.shared = shared
+        if shared is not None:
+            shared.siren, shared.film, shared.args, shared.box_scale = renderer.siren, film, args, renderer.box_scale
         ta = tex[0].contiguous() if tex is not None else torch.empty(0, device=c2w.device)
         ctx.save_for_backward(film, args, out['sdf'], out['dists'], out['points'], out['hit_prob'],
                               near.reshape(B).contiguous().float(), far.reshape(B).contiguous().float(), rsave, ta)
@@ -474,7 +513,15 @@ class _RenderQuery(torch.autograd.Function):
         dstyles = torch.empty((B, 9, siren.W), device=dev, dtype=torch.float32)
         tang = rs = None
         if ctx.want_eik and d_eik is not None:
-            tang, rs = tangent_arguments(siren, film, args, d_eik, r.box_scale), rsave
+            sh = ctx.shared
+            if (sh is not None and sh.tang is not None and sh.d_eik.data_ptr() == d_eik.data_ptr()
+                    and sh.d_eik.shape == d_eik.shape):                     # launched early by _EikTap.backward
+                tang = sh.tang
+            else:
+                tang = tangent_arguments(siren, film, args, d_eik, r.box_scale)
+            if sh is not None:
+                sh.tang = sh.d_eik = sh.args = sh.film = None
+            rs = rsave
         d_ta = d_tb = tex_a = None
         if ctx.has_tex:
             tex_a = ta
@@ -495,7 +542,7 @@ class _RenderQuery(torch.autograd.Function):
         _lib.check(rc, "e3dge_siren_render_bwd")
         if ctx.styles_ndim == 2:
             dstyles = dstyles.sum(1)
-        return (dstyles if ctx.needs_input_grad[0] else None), None, None, None, None, None, None, d_ta, d_tb
+        return (dstyles if ctx.needs_input_grad[0] else None), None, None, None, None, None, None, d_ta, d_tb, None
 
 
 def _resblock_backward_torch(x, w0, b0, w1, ws, dy):
@@ -709,6 +756,8 @@ class VolumeFeatureRenderer(nn.Module):
         self.register_buffer('B_MIN', -torch.Tensor([self.dist_radius] * 3), persistent=False)
         self.local_batch = None
         self.sample_mode = False
+        self._side_streams = {}            # per device: stream of the surface-normal query (forward())
+        self._render_done = None
         self.mask_depth_thresh = 1.08                            # :910
         self._check_supported()
 
@@ -910,9 +959,30 @@ class VolumeFeatureRenderer(nn.Module):
             # term's gradient reaches the styles through the network AND through d xyz / d styles (the Hessian-vector
             # product e3dge_siren_bwd returns as d_pts, chained into the compositing backward as d_xyz).
             B = cam_poses.shape[0]
-            surf = render_out['xyz'].permute(0, 2, 3, 1).reshape(B, -1, 3)
-            _, _, se = self.siren.query_points(surf, None, styles, self.box_scale, want_raw=False, want_eikonal=True)
-            render_out['surface_eikonal_term'] = se.reshape(B, self.out_im_res, self.out_im_res, 1, 3)
+            dev = cam_poses.device
+            ev = getattr(self, '_render_done', None)
+            self._render_done = None
+            if ev is not None and return_eikonal and _SIDE_STREAM:
+                # 4,096 surface points are 32 workgroups; the sdf chain of the ray samples, still running on the launch stream,
+                # leaves a quarter of the CUs free at S = 18: the two overlap.  autograd runs this query's backward on the side
+                # stream as well and orders it against the consumers of its gradients.
+                cur = torch.cuda.current_stream(dev)
+                side = self._side_streams.setdefault(str(dev), torch.cuda.Stream(device=dev))
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    surf = render_out['xyz'].permute(0, 2, 3, 1).reshape(B, -1, 3)
+                    _, _, se = self.siren.query_points(surf, None, styles, self.box_scale, want_raw=False, want_eikonal=True)
+                    se = se.reshape(B, self.out_im_res, self.out_im_res, 1, 3)
+                render_out['xyz'].record_stream(side)
+                if torch.is_tensor(styles):
+                    styles.record_stream(side)
+                cur.wait_stream(side)
+                se.record_stream(cur)
+                render_out['surface_eikonal_term'] = se
+            else:
+                surf = render_out['xyz'].permute(0, 2, 3, 1).reshape(B, -1, 3)
+                _, _, se = self.siren.query_points(surf, None, styles, self.box_scale, want_raw=False, want_eikonal=True)
+                render_out['surface_eikonal_term'] = se.reshape(B, self.out_im_res, self.out_im_res, 1, 3)
 
         if geometry_sample:   # 3-D supervision re-queries (:1916-1949)
             corpus = ['uniform_pts'] + (['xyz'] if geometry_sample.get('xyz', None) is not None else [])
