@@ -24,7 +24,8 @@ class GraphedCall:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        # captured on the stream the warm-up ran on: per-stream scratch (the decoder's modulation tables) already exists there
+        with torch.cuda.graph(self.graph, stream=side), torch.no_grad():
             self.outputs = fn(*self._static_in)
 
     def __call__(self, *inputs):

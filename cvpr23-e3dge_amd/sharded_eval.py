@@ -46,11 +46,28 @@ def gather_metric_rows(local_rows, n_units, rank, world_size, group=None):
     return out
 
 
-def evaluate_sharded(unit_fn, n_units, rank=0, world_size=1, device="cpu", group=None):
+def evaluate_sharded(unit_fn, n_units, rank=0, world_size=1, device="cpu", group=None, n_streams=1):
     """Runs `unit_fn(i) -> (M,) tensor of metric scalars` for the units this rank owns and returns the (n_units, M)
     table (identical on all ranks).  `unit_fn` is where the hot path is called (renderer / generator forward on
-    this rank's GPU); nothing is exchanged between ranks until the final gather."""
-    rows = [unit_fn(i).reshape(-1).to(device) for i in shard_indices(n_units, rank, world_size)]
+    this rank's GPU); nothing is exchanged between ranks until the final gather.
+    n_streams > 1 (GPU only): the rank's units are issued round-robin on that many HIP streams -- units are independent, and
+    one unit's small launches (the decoder's first levels, metric folds) leave CUs idle that the next unit's kernels fill."""
+    mine = list(shard_indices(n_units, rank, world_size))
+    if n_streams > 1 and torch.device(device).type == "cuda" and mine:
+        cur = torch.cuda.current_stream(device)
+        streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        rows = [unit_fn(mine[0]).reshape(-1).to(device)]       # first unit on the caller's stream: lazily built weight images
+        for st in streams:                                     # (packed once, then read-only) exist before the fan-out
+            st.wait_stream(cur)
+        for j, i in enumerate(mine[1:]):
+            with torch.cuda.stream(streams[j % n_streams]):
+                row = unit_fn(i).reshape(-1).to(device)
+            row.record_stream(cur)
+            rows.append(row)
+        for st in streams:
+            cur.wait_stream(st)
+    else:
+        rows = [unit_fn(i).reshape(-1).to(device) for i in mine]
     if rows:
         local = torch.stack(rows)
     else:

@@ -458,7 +458,13 @@ class Decoder(nn.Module):
         wsqs = [m.device_image()[1] if m.kernel_size == 3 else None for m, _ in layers]
         key = (B, str(device)) + tuple((m.modulation.weight.data_ptr(), m.modulation.weight._version, m.modulation.bias.data_ptr(),
                                         m.modulation.bias._version, 0 if w is None else w.data_ptr()) for (m, _), w in zip(layers, wsqs))
-        if getattr(self, '_tab_key', None) != key:
+        # one table (and one output buffer) per stream: two forwards in flight on different streams must not share it
+        slot = (B, str(device), torch.cuda.current_stream(device).cuda_stream)
+        tabs = self.__dict__.setdefault('_tabs', {})
+        hit = tabs.get(slot)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        if True:
             import ctypes
             pad4 = lambda n: (n + 3) // 4 * 4
             total = sum(pad4(B * m.in_channel) + (pad4(B * m.out_channel) + pad4(B) if w is not None else 0) for (m, _), w in zip(layers, wsqs))
@@ -481,8 +487,10 @@ class Decoder(nn.Module):
                 row_start += m.in_channel
                 co_start += m.out_channel if w is not None else 0
             raw = torch.frombuffer(bytearray(bytes(rows)), dtype=torch.uint8).to(device)
-            self._tab, self._tab_key = (raw, buf, views, len(layers), row_start, co_start), key
-        return self._tab
+            if len(tabs) > 8:
+                tabs.clear()
+            tabs[slot] = (key, (raw, buf, views, len(layers), row_start, co_start))
+        return tabs[slot][1]
 
     def _all_modulations(self, latent):
         """[(s, demod, s_amax)] per modulated conv of the forward, or None when the fused path is not taken."""
