@@ -240,6 +240,10 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
     float* const state = smem + k16LdsState;
 
     const int tid_k = threadIdx.x;
+#ifdef E3DGE_PHASE_TIMING
+    const unsigned long long t_entry = __builtin_readcyclecounter();
+    unsigned long long t_loop0 = 0, t_loop1 = 0;
+#endif
     // ---- work assignment (as siren_kernel) ----
     int b, npts, n_sub;
     int pix0 = 0, nrays = 0;
@@ -263,6 +267,10 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
 
     const float* __restrict__ packed = a.packed;
     const float* __restrict__ film_g = a.film + (int64_t)b * 9 * 2 * kWidth;
+    // first weight chunks on their way (L2 -> LDS by DMA) while the tables below are built
+    ChunkPipe16 pipe;
+    pipe.init(wbuf, packed + kOffBig16b, tid_k >> 6, tid_k & 63);
+    pipe.prime();
     // FiLM block with the layer bias folded into the offset and the weights' factor 128 divided out of gamma (layers >= 1)
     for (int i = tid_k; i < 9 * kWidth; i += k16Threads) {
         const int l = i >> 8, n = i & 255;
@@ -287,9 +295,6 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
     }
     const float* __restrict__ film = film_s;
 
-    ChunkPipe16 pipe;
-    pipe.init(wbuf, packed + kOffBig16b, tid_k >> 6, tid_k & 63);
-    pipe.prime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     u32x4 ringH[k16Ring], ringL[k16Ring];
@@ -324,6 +329,9 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
     for (int i = 0; i < 18; ++i) tstamp[i] = 0;
 #endif
 
+#ifdef E3DGE_PHASE_TIMING
+    t_loop0 = __builtin_readcyclecounter();
+#endif
     for (int sub = 0; sub < n_sub; ++sub) {
         int tid_o = tid_k;
         asm volatile("" : "+v"(tid_o));                    // opaque: address math stays inside the sub-tile (no hoisted registers)
@@ -816,6 +824,9 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
         PHASE16(5);
     }  // sub-tiles
 
+#ifdef E3DGE_PHASE_TIMING
+    t_loop1 = __builtin_readcyclecounter();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA in flight when the workgroup retires
     if (MODE == 0) {
         // 7. per-ray outputs, channel-first like VolumeFeatureRenderer.forward returns them (:1957-1968)
@@ -851,6 +862,9 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             for (int i = 0; i < 18; ++i)
                 a.dists[i] = (i % 6 == 0) ? (float)(i / 6 ? tstamp[i] - tstamp[i - 1] : 0) : (float)(tstamp[i] - tstamp[i - 1]);
             a.dists[18] = (float)pipe.t_vm; a.dists[19] = (float)pipe.t_bar;
+            a.dists[20] = (float)(t_loop0 - t_entry);                            // prologue: LDS tables, first weight chunks
+            a.dists[21] = (float)(t_loop1 - t_loop0);                            // all sub-tiles
+            a.dists[22] = (float)(__builtin_readcyclecounter() - t_loop1);       // per-ray outputs (up to this thread's last store)
         }
 #endif
     }

@@ -27,6 +27,7 @@ tot = sum(d)
 if r.siren.mfma_mode == "f16x3":      # 8-wave kernel: thread 0's totals over 384 tiles
     print(f"chunk sync totals of wave 0 (cycles over 384 tiles): dma-wait={sync[0]:.0f} barrier={sync[1]:.0f}")
     print("sum", tot, " mfma-only per sub-tile would be", 16 * 24 * 128, "per wave,", 2 * 16 * 24 * 128, "per SIMD (two waves)")
+    print(f"workgroup 0, thread 0: prologue {sync[2]:.0f} cycles, sub-tile loop {sync[3]:.0f}, per-ray output stores {sync[4]:.0f}")
 else:
     print("chunk_sync totals per wave (cycles over 192 tiles): " + "; ".join(f"w{w}: dma-wait={sync[3*w]:.0f} barrier={sync[3*w+1]:.0f} issue={sync[3*w+2]:.0f}" for w in range(4)))
     print("sum", tot, " mfma-only per sub-tile would be", 8224 * 64)
