@@ -485,3 +485,34 @@ def test_backward_block_scaling_is_scale_invariant(sd, scale):
     e = rel_err(styles.grad, s.grad)
     record(f"bwd_scale_invariance_{scale:g}", rel_err_vs_f64=e)
     assert torch.isfinite(styles.grad).all() and e <= REL_TOL, e
+
+
+def test_stream_overlap_of_the_training_step_changes_no_bit(sd, monkeypatch):
+    """The surface-normal query on a side stream + the early tangent launch (volume_renderer._SIDE_STREAM, _EikTap) only
+    reorder launches: values, loss and gradient are bit-identical to the serial order, also when repeated (the kernels are
+    deterministic, so any race between the streams would show up here)."""
+    from e3dge_amd import volume_renderer as vr
+    from e3dge_amd.camera_utils import generate_camera_params
+    res, S = 16, 18
+    r = make_renderer(full_state_dict(res=res, n_samples=S)[1], res, S)
+    wr, _ = syn.synthetic_inputs(2, seed=21, device=DEV)
+    poses, focal, near, far, _ = generate_camera_params(res, DEV, locations=torch.tensor([[0.1, 0.05], [-0.2, 0.0]], device=DEV))
+
+    def step():
+        s_ = wr.clone().requires_grad_(True)
+        o = r(poses, focal, near, far, styles=s_, return_eikonal=True, return_surface_eikonal=True)
+        loss = ((o['gen_thumb_imgs'] ** 2).mean() + ((o['eikonal_term'].norm(dim=-1) - 1) ** 2).mean()
+                + (o['surface_eikonal_term'] ** 2).mean())
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), s_.grad.clone(), o['surface_eikonal_term'].detach().clone()
+    results = {}
+    for flag in (True, False):
+        monkeypatch.setattr(vr, "_SIDE_STREAM", flag)
+        results[flag] = [step() for _ in range(3)]
+    ref = results[False][0]
+    for flag in (True, False):
+        for got in results[flag]:
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b)
+    assert torch.isfinite(ref[1]).all() and float(ref[1].abs().max()) > 0
