@@ -28,21 +28,15 @@ constexpr int k16Tiles = 16;                     // 16-feature output tiles per 
 constexpr int k16Steps = 8;                      // k-steps of 32 per tile
 constexpr int k16ChunkFloats = 16 * kWidth;      // one tile x K = 256: 16 KiB
 constexpr int k16Chunks = kBigLayers * k16Tiles; // 128 chunks per 128-point sub-tile
-#ifndef E3DGE_16_PAIR
-#define E3DGE_16_PAIR 0
-#endif
-// Workgroup barrier every tile (0, default) or every second tile (1).  Thread 0 spends 26 % of the kernel in s_barrier
-// (tools/phase_timing.py), but halving the barriers changed nothing (0.3140 vs 0.3145 ms, profiles/r2 notes in DESIGN 4.1c): the
-// wait is where the two waves of a SIMD queue for the matrix pipe, not a cost of the barrier itself.  Per pair needs five
-// buffers -- chunks 2k, 2k+1 being read, 2k+2 published for the fragment ring's look-ahead, 2k+3 and 2k+4 in flight.
-constexpr bool k16Pair = E3DGE_16_PAIR != 0;
+// One workgroup barrier per tile.  (Per two tiles with a fifth LDS buffer measured the same, 0.3140 vs 0.3145 ms: the wait at
+// the barrier is where the two waves of a SIMD queue for the matrix pipe, not a cost of the barrier -- removed)
 #ifndef E3DGE_16_SPLIT
 #define E3DGE_16_SPLIT 0     // 1 = hidden layers with the two waves of a SIMD in opposite phases (measured 5 % SLOWER)
 #endif
 #ifndef E3DGE_16_ABL
 #define E3DGE_16_ABL 0      // timing ablation (wrong results): 4 = no workgroup barrier in the weight pipe
 #endif
-constexpr int k16NBuf = k16Pair ? 5 : 4;          // LDS weight buffers
+constexpr int k16NBuf = 4;                       // LDS weight buffers
 constexpr int k16Slots = 2;                      // rays a 16-point slab can touch when S >= 16
 #ifndef E3DGE_16_RING
 #define E3DGE_16_RING 2     // 2, 4 and 8 measure the same (0.320 / 0.320 / 0.323 ms): the fragment reads are not latency-exposed
@@ -99,10 +93,8 @@ __device__ __forceinline__ float row_sum16(float x) {
 }
 
 // 16-KiB weight chunks through k16NBuf LDS buffers; every wave moves a 2-KiB slice (two LDS-DMA pieces) of each chunk.
-//   per tile (k16Pair = 0): tile g: sync() -> wait for everything but the chunk issued one tile ago, barrier (publishes chunk
-//   g+2, proves tile g-1 is finished) -> issue chunk g+3 into the buffer tile g-1 used: two tile times to arrive.
-//   per pair (k16Pair = 1): even tile 2k: sync() -> wait for all own DMA, barrier (publishes chunks 2k+1, 2k+2, proves the pair
-//   k-1 is finished) -> issue chunks 2k+3, 2k+4: again two tile times to arrive, half the barriers.
+//   tile g: sync() -> wait for everything but the chunk issued one tile ago, barrier (publishes chunk g+2, proves tile g-1 is
+//   finished) -> issue chunk g+3 into the buffer tile g-1 used: two tile times to arrive.
 struct ChunkPipe16 {
     const char* img;
     uint32_t voff, lds_base;
@@ -140,7 +132,7 @@ struct ChunkPipe16 {
         const unsigned long long c0 = __builtin_readcyclecounter();
 #endif
         // STRICT (training: the epilogue's argument stores share vmcnt): wait for everything
-        if (STRICT || k16Pair) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (STRICT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
 #ifdef E3DGE_PHASE_TIMING
         const unsigned long long c1 = __builtin_readcyclecounter();
@@ -315,12 +307,9 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
 #else
     auto trace_sel = [](int, int) { return 0; };
 #endif
-    auto fwd_hook = [&](bool even_tile) {
-        if (!k16Pair || even_tile) {
-            pipe.template sync<SAVE>();
-            pipe.issue_chunk();
-            if (k16Pair) pipe.issue_chunk();
-        }
+    auto fwd_hook = [&]() {
+        pipe.template sync<SAVE>();
+        pipe.issue_chunk();
     };
     // packed f16 (hi, lo) activations of this wave's 16 points: word 2e + (r >> 1), half r & 1 of in?[g] = feature 32g + 16e + 4q + r
     u32x4 inH[k16Steps], inL[k16Steps], outH[k16Steps], outL[k16Steps];
@@ -474,7 +463,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
                     for (int g = 0; g < k16Steps; ++g) { inH[g] = outH[g]; inL[g] = outL[g]; }
                 }
             };
-            static_assert(k16Steps % k16Ring == 0 && !k16Pair && k16NBuf == 4 && k16Tiles % k16NBuf == 0, "role-split schedule");
+            static_assert(k16Steps % k16Ring == 0 && k16NBuf == 4 && k16Tiles % k16NBuf == 0, "role-split schedule");
 #pragma unroll 1
             for (int L = 1; L < E3DGE_SIREN_DEPTH; ++L) {
 #pragma unroll
@@ -519,7 +508,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             for (int t = 0; t < k16Tiles; ++t) {
                 f32x4v acc = zero4(), accb = zero4();
                 if (t == 0) {
-                    tile16<false>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {}, [&]() { fwd_hook((t & 1) == 0); }, k16Pair ? -1 : t % k16NBuf);
+                    tile16<false>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {}, [&]() { fwd_hook(); }, t % k16NBuf);
                 } else {
                     const int o = 16 * (t - 1) + 4 * q;
                     f32x4v g4 = zero4(), b4 = zero4(), arg4 = zero4(), kf4 = zero4(), x4 = zero4();
@@ -552,7 +541,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
                             SPLIT2_TO(x4[0], x4[1], outH[(t - 1) >> 1][2 * ((t - 1) & 1)], outL[(t - 1) >> 1][2 * ((t - 1) & 1)]);
                             SPLIT2_TO(x4[2], x4[3], outH[(t - 1) >> 1][2 * ((t - 1) & 1) + 1], outL[(t - 1) >> 1][2 * ((t - 1) & 1) + 1]);
                         }
-                    }, [&]() { fwd_hook((t & 1) == 0); }, k16Pair ? -1 : t % k16NBuf, trace_sel(L, t));
+                    }, [&]() { fwd_hook(); }, t % k16NBuf, trace_sel(L, t));
                 }
                 pipe.advance();
                 prev = acc + accb;
@@ -725,10 +714,10 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             for (int t = 0; t < k16Tiles; ++t) {
                 f32x4v acc = zero4(), accb = zero4();
                 if (t == 0) {
-                    tile16<true>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {}, [&]() { fwd_hook((t & 1) == 0); });
+                    tile16<true>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [](int) {}, [&]() { fwd_hook(); });
                 } else {
                     epi_begin(t - 1);
-                    tile16<true>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [&](int g) { if (g >= 1 && g <= 4) epi_r(g - 1); }, [&]() { fwd_hook((t & 1) == 0); });
+                    tile16<true>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [&](int g) { if (g >= 1 && g <= 4) epi_r(g - 1); }, [&]() { fwd_hook(); });
                     epi_end();
                 }
                 pipe.advance();

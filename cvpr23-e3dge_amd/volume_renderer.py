@@ -30,7 +30,7 @@ from . import _lib
 
 
 MFMA_MODES = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16x3_v1": _lib.PREC_F16X3_V1}
-_SIDE_STREAM = __import__("os").environ.get("E3DGE_SIDE_STREAM", "1") != "0"   # surface-normal query beside the sdf chain
+_SIDE_STREAM = os.environ.get("E3DGE_SIDE_STREAM", "1") != "0"     # surface-normal query beside the sdf chain (forward())
 # backward-type launches additionally know the experimental 8-wave layout (E3DGE_PREC_F16X3_G2; tools/bwd_ab.py)
 BWD_MODES = dict(MFMA_MODES, f16x3_g2=_lib.PREC_F16X3_G2)
 _STRICT_CACHE = os.environ.get("E3DGE_STRICT_WEIGHT_CACHE", "0") not in ("", "0")
