@@ -281,31 +281,51 @@ extern "C" int e3dge_noise_bias_act(float* y, const float* x, const float* noise
 // ---------------------------------------------------------------------------------------------
 // ToRGB (stylesdf_model.py:510-541) in one pass: 1x1 modulated conv WITHOUT demodulation (:232), + bias, + the skip image
 // up-sampled by upfirdn2d(up=2, pad=(2,1)) with the 4x4 FIR (Upsample :96-119).  Bound: HBM (reads Ci floats per pixel).
-// 256 threads = 64 pixel lanes (4 adjacent pixels each, float4 loads) x 4 channel groups, partial sums folded through LDS.
+// 256 threads = pixel lanes (4 adjacent pixels each, float4 loads) x channel groups, partial sums folded through LDS in group order.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRgbThreads = 256, kRgbMaxCi = 1024;
+// G channel groups x (256 / G) pixel lanes of 4 adjacent pixels.  G follows the channel count (16 for Ci >= 256, 4 for 128, 1
+// below): the deep, small levels (512 x 64^2) need the channels spread over threads to have enough loads in flight -- a thread
+// walking 128 channels eight at a time took 16 us for 8 MB --, the wide, shallow ones (32 x 1024^2) are a plain stream with
+// every channel of a pixel in one thread and no reduction.
+template <int G>
 __global__ void __launch_bounds__(kRgbThreads)
 torgb_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ weight,
              const float* __restrict__ style, const float* __restrict__ bias, const float* __restrict__ skip,
              const float* __restrict__ fir, float scale, int Ci, int H, int W, int blocks_per_img) {
+    constexpr int PL = kRgbThreads / G;                        // pixel lanes per workgroup
     __shared__ float wm[3 * kRgbMaxCi];
-    __shared__ float part[3][3][64][4];
+    __shared__ float part[G > 1 ? G - 1 : 1][3][PL][4];
     const int b = blockIdx.x / blocks_per_img, blk = blockIdx.x - b * blocks_per_img;
-    const int pl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int pl = threadIdx.x % PL, grp = threadIdx.x / PL;
     const int HW = H * W;
     for (int i = threadIdx.x; i < 3 * Ci; i += kRgbThreads) {
         const int c = i / Ci, ci = i - c * Ci;
         wm[i] = __fmul_rn(__fmul_rn(scale, weight[c * Ci + ci]), style[(int64_t)b * Ci + ci]);      // (scale * W) * s, :321
     }
     __syncthreads();
-    const int p0 = (blk * 64 + pl) * 4;                       // HW is a multiple of 4 (checked by the launcher)
+    const int p0 = (blk * PL + pl) * 4;                        // HW is a multiple of 4 (checked by the launcher)
     const bool live = p0 < HW;
     float acc[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     if (live) {
-        const int per = (Ci + 3) / 4, c0 = grp * per, c1 = min(Ci, c0 + per);
+        const int per = (Ci + G - 1) / G, c0 = grp * per, c1 = min(Ci, c0 + per);
         const float4* xp = reinterpret_cast<const float4*>(x + ((int64_t)b * Ci + c0) * HW + p0);
-#pragma unroll 8
-        for (int ci = c0; ci < c1; ++ci) {
+        constexpr int UN = 16;                                 // loads in flight per thread
+        int ci = c0;
+        for (; ci + UN <= c1; ci += UN) {
+            float4 v[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) v[u] = xp[(int64_t)u * (HW / 4)];
+            xp += (int64_t)UN * (HW / 4);
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const float w0 = wm[ci + u], w1 = wm[Ci + ci + u], w2 = wm[2 * Ci + ci + u];
+                acc[0][0] = fmaf(w0, v[u].x, acc[0][0]); acc[0][1] = fmaf(w0, v[u].y, acc[0][1]); acc[0][2] = fmaf(w0, v[u].z, acc[0][2]); acc[0][3] = fmaf(w0, v[u].w, acc[0][3]);
+                acc[1][0] = fmaf(w1, v[u].x, acc[1][0]); acc[1][1] = fmaf(w1, v[u].y, acc[1][1]); acc[1][2] = fmaf(w1, v[u].z, acc[1][2]); acc[1][3] = fmaf(w1, v[u].w, acc[1][3]);
+                acc[2][0] = fmaf(w2, v[u].x, acc[2][0]); acc[2][1] = fmaf(w2, v[u].y, acc[2][1]); acc[2][2] = fmaf(w2, v[u].z, acc[2][2]); acc[2][3] = fmaf(w2, v[u].w, acc[2][3]);
+            }
+        }
+        for (; ci < c1; ++ci) {
             const float4 v = *xp;
             xp += HW / 4;
             const float w0 = wm[ci], w1 = wm[Ci + ci], w2 = wm[2 * Ci + ci];
@@ -314,13 +334,15 @@ torgb_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __
             acc[2][0] = fmaf(w2, v.x, acc[2][0]); acc[2][1] = fmaf(w2, v.y, acc[2][1]); acc[2][2] = fmaf(w2, v.z, acc[2][2]); acc[2][3] = fmaf(w2, v.w, acc[2][3]);
         }
     }
-    if (grp > 0) {
+    if (G > 1) {
+        if (grp > 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) part[grp - 1][c][pl][j] = acc[c][j];
+                for (int j = 0; j < 4; ++j) part[grp - 1][c][pl][j] = acc[c][j];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (grp != 0 || !live) return;
     const int oy = p0 / W, ox = p0 - oy * W;                  // 4 pixels of one row (W % 4 == 0)
 #pragma unroll
@@ -328,7 +350,11 @@ torgb_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __
         float o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float conv = ((acc[c][j] + part[0][c][pl][j]) + part[1][c][pl][j]) + part[2][c][pl][j];
+            float conv = acc[c][j];
+            if (G > 1) {
+#pragma unroll
+                for (int gq = 0; gq < G - 1; ++gq) conv += part[gq][c][pl][j];       // fixed order: group 0, 1, 2, ...
+            }
             o[j] = conv + bias[c];
         }
         if (skip) {
@@ -367,8 +393,17 @@ extern "C" int e3dge_torgb(float* y, const float* x, const float* weight, const 
     E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "torgb: x / y must be 16-B aligned");
     const int64_t hw = (int64_t)height * width;
     E3DGE_REQUIRE(hw * ci < ((int64_t)1 << 31), "torgb: image too large");
-    const int bpi = (int)((hw / 4 + 63) / 64);
-    torgb_kernel<<<dim3((unsigned)(bpi * batch)), dim3(kRgbThreads), 0, as_stream(stream)>>>(y, x, weight, style, bias, skip, fir, scale, ci, height, width, bpi);
+    hipStream_t st = as_stream(stream);
+    if (ci >= 256) {
+        const int bpi = (int)((hw / 4 + 15) / 16);
+        torgb_kernel<16><<<dim3((unsigned)(bpi * batch)), dim3(kRgbThreads), 0, st>>>(y, x, weight, style, bias, skip, fir, scale, ci, height, width, bpi);
+    } else if (ci > 64) {
+        const int bpi = (int)((hw / 4 + 63) / 64);
+        torgb_kernel<4><<<dim3((unsigned)(bpi * batch)), dim3(kRgbThreads), 0, st>>>(y, x, weight, style, bias, skip, fir, scale, ci, height, width, bpi);
+    } else {
+        const int bpi = (int)((hw / 4 + 255) / 256);
+        torgb_kernel<1><<<dim3((unsigned)(bpi * batch)), dim3(kRgbThreads), 0, st>>>(y, x, weight, style, bias, skip, fir, scale, ci, height, width, bpi);
+    }
     return check_launch("torgb");
 }
 
