@@ -14,7 +14,10 @@ import torch
 
 class AttrDict(dict):
     """Minimal stand-in for the Munch objects the reference passes around (attribute + key access)."""
-    __getattr__ = dict.get
+    def __getattr__(self, k):
+        if k.startswith('__'):                  # copy / pickle probe for dunder hooks: a missing one must raise, not be None
+            raise AttributeError(k)
+        return self.get(k)
 
     def __setattr__(self, k, v):
         self[k] = v

@@ -31,6 +31,17 @@ from . import _lib
 
 MFMA_MODES = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16x3_v1": _lib.PREC_F16X3_V1}
 _SIDE_STREAM = os.environ.get("E3DGE_SIDE_STREAM", "1") != "0"     # surface-normal query beside the sdf chain (forward())
+_SIDE_STREAMS = {}                                                     # per device (module level: modules stay deep-copyable)
+
+
+def _side_stream(dev):
+    key = str(dev)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 # backward-type launches additionally know the experimental 8-wave layout (E3DGE_PREC_F16X3_G2; tools/bwd_ab.py)
 BWD_MODES = dict(MFMA_MODES, f16x3_g2=_lib.PREC_F16X3_G2)
 _STRICT_CACHE = os.environ.get("E3DGE_STRICT_WEIGHT_CACHE", "0") not in ("", "0")
@@ -756,7 +767,6 @@ class VolumeFeatureRenderer(nn.Module):
         self.register_buffer('B_MIN', -torch.Tensor([self.dist_radius] * 3), persistent=False)
         self.local_batch = None
         self.sample_mode = False
-        self._side_streams = {}            # per device: stream of the surface-normal query (forward())
         self._render_done = None
         self.mask_depth_thresh = 1.08                            # :910
         self._check_supported()
@@ -967,7 +977,7 @@ class VolumeFeatureRenderer(nn.Module):
                 # leaves a quarter of the CUs free at S = 18: the two overlap.  autograd runs this query's backward on the side
                 # stream as well and orders it against the consumers of its gradients.
                 cur = torch.cuda.current_stream(dev)
-                side = self._side_streams.setdefault(str(dev), torch.cuda.Stream(device=dev))
+                side = _side_stream(dev)
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
                     surf = render_out['xyz'].permute(0, 2, 3, 1).reshape(B, -1, 3)

@@ -246,3 +246,14 @@ def test_synthetic_weights_are_key_deterministic():
     c = syn.synthetic_tensor('renderer.network.pts_linears.4.weight', (256, 256))
     assert torch.equal(a, b) and not torch.equal(a, c)
     assert float(a.abs().max()) <= np.sqrt(6 / 256) / 25 + 1e-9
+
+
+def test_modules_are_deep_copyable():
+    """Runners copy generators (EMA copies, `surface_g_ema`): no stream / ctypes / lambda state may sit on the modules."""
+    import copy
+    from e3dge_amd.stylesdf_model import G_pred_latents
+    g = G_pred_latents(syn.model_opt(size=128, channel_multiplier=1, renderer_spatial_output_dim=16), syn.rendering_opt(),
+                       full_pipeline=True)
+    g2 = copy.deepcopy(g)
+    assert g2.state_dict().keys() == g.state_dict().keys()
+    assert g2.renderer.opt.N_samples == g.renderer.opt.N_samples and g2.renderer.opt.no_such_option is None
