@@ -159,39 +159,60 @@ __global__ void __launch_bounds__(kMcThreads) modconv_kernel(const ModconvK a) {
             glds16_saddr<0>(reinterpret_cast<const void*>(su), (uint32_t)lane * 16u, (uint32_t)__builtin_amdgcn_readfirstlane((int)dst));
         }
     };
-    // Every thread issues exactly NIT * 8 loads (addresses clamped into the image, out-of-image values zeroed when they
-    // are consumed): the end-of-step wait below relies on that count.
+    // The geometry of a patch item (which pixel of the patch, which global element, inside the image or not) depends on the tile
+    // only; a tile has n_chunks steps.  It is computed when a tile's first chunk comes by and kept in NIT registers each for the
+    // load and the store side (they run one or two steps apart): with 16-32 chunks per tile on the deep layers the per-step
+    // index arithmetic was 15-30 % of a step (E3DGE_MC_TIMING).
+    unsigned ld_off[NIT];                 // element offset of the item within a 16-channel block of the image being loaded
+    int st_pix[NIT];                      // patch pixel index of the item, or -1: not an item / outside the image (stores zeros)
+    int st_h[NIT];
     auto load_input = [&](int step, float (&pr)[NIT][8]) {
         int k, c, b, cb, ty, tx;
         step_of(step, k, c);
         tile_of(k, b, cb, ty, tx);
-        const int oy = ty * TH - 1, ox = tx * TW - 1;                        // patch origin (same for both variants)
-        const float* __restrict__ bp = a.x + ((size_t)b * a.Ci + c * kMcChunk) * HW;
+        if (c == 0 || step == 0) {
+            const int oy = ty * TH - 1, ox = tx * TW - 1;                    // patch origin (same for both variants)
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int q = min(tid + it * kMcThreads, 2 * NPIX - 1);
-            const int h = q / NPIX, pix = q - h * NPIX;
-            const int prow = pix / PW, pcol = pix - prow * PW;
-            const int gy = min(max(oy + prow, 0), a.H - 1), gx = min(max(ox + pcol, 0), a.W - 1);
-            // wave-uniform 64-bit base + 32-bit lane offset (16 channels x HW elements < 2^31): no 64-bit address per load
-            const unsigned off = (unsigned)(8 * h * HW + gy * a.W + gx);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pr[it][j] = bp[off + (unsigned)(j * HW)];
+            for (int it = 0; it < NIT; ++it) {
+                const int q = min(tid + it * kMcThreads, 2 * NPIX - 1);
+                const int h = q / NPIX, pix = q - h * NPIX;
+                const int prow = pix / PW, pcol = pix - prow * PW;
+                const int gy = min(max(oy + prow, 0), a.H - 1), gx = min(max(ox + pcol, 0), a.W - 1);
+                // wave-uniform 64-bit base + 32-bit lane offset (16 channels x HW elements < 2^31): no 64-bit address per load
+                ld_off[it] = (unsigned)(8 * h * HW + gy * a.W + gx);
+            }
         }
+        const float* __restrict__ bp = a.x + ((size_t)b * a.Ci + c * kMcChunk) * HW;
+        // every thread issues exactly NIT * 8 loads (addresses clamped into the image, out-of-image values zeroed when they
+        // are consumed): the end-of-step wait below relies on that count
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pr[it][j] = bp[ld_off[it] + (unsigned)(j * HW)];
     };
     auto store_input = [&](int step, int buf, const float (&pr)[NIT][8]) {
         int k, c, b, cb, ty, tx;
         step_of(step, k, c);
-        tile_of(k, b, cb, ty, tx);
-        const int oy = ty * TH - 1, ox = tx * TW - 1;
+        if (c == 0 || step == 0) {
+            tile_of(k, b, cb, ty, tx);
+            const int oy = ty * TH - 1, ox = tx * TW - 1;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int q = tid + it * kMcThreads;
-            if (q < 2 * NPIX) {
+            for (int it = 0; it < NIT; ++it) {
+                const int q = tid + it * kMcThreads;
                 const int h = q / NPIX, pix = q - h * NPIX;
                 const int prow = pix / PW, pcol = pix - prow * PW;
                 const int gy = oy + prow, gx = ox + pcol;
                 const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                st_h[it] = h;
+                st_pix[it] = (q < 2 * NPIX) ? (inside ? pix : -1 - pix) : (int)0x40000000;       // >= 0 inside, < 0 zero-fill, big: none
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (st_pix[it] != (int)0x40000000) {
+                const bool inside = st_pix[it] >= 0;
+                const int pix = inside ? st_pix[it] : -1 - st_pix[it];
+                const int h = st_h[it];
                 const float* sp = s_lds + c * kMcChunk + 8 * h;
                 const f32x4 s0 = *reinterpret_cast<const f32x4*>(sp), s1 = *reinterpret_cast<const f32x4*>(sp + 4);
                 u32x4 hi, lo;
