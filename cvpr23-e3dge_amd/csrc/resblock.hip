@@ -7,9 +7,10 @@
 //
 // Same machine as the SIREN kernels: 4 waves x 32 points per workgroup, a point's whole state in one lane pair, split-f16
 // MFMA contractions (hi + lo, three products, fp32 accumulate) with per-point power-of-two block scaling of the B operand
-// (the inputs are unbounded), weights streamed L2 -> LDS by the shared ChunkPipe in 32-KiB chunks (32 output rows x 256 k).
-// K = 320 (Cin padded) is two chunks: a full one and one of which only the first four k-steps (64 k) are non-zero and
-// executed.  x and r = relu(net) are kept as packed (hi, lo) words (160 registers each); relu(x) is formed from x's words
+// (the inputs are unbounded), weights streamed L2 -> LDS in 20-KiB chunks (32 output rows x 160 k: K = 320, Cin padded, is
+// two equal chunks of ten k-steps) through a ring of kRbNBuf LDS buffers (RbPipe below).  With one wave per SIMD nothing
+// else covers a chunk that has not landed, so a chunk's DMA is issued kRbNBuf - 1 chunks before it is read and the chunk
+// barrier waits with a COUNTED vmcnt that leaves the younger chunks in flight.  x and r = relu(net) are kept as packed (hi, lo) words (160 registers each); relu(x) is formed from x's words
 // on the fly per k-step (integer sign masks).  Neither the (P, 301) hidden activations nor r ever touch memory; the output
 // goes straight to (alpha, beta).
 #include "siren_common.h"
@@ -21,25 +22,35 @@ constexpr int kRbTilesIn = kRbKin / 32;   // 10
 constexpr int kRbStepsIn = kRbKin / 16;   // 20 k-steps of 16
 constexpr int kRbOut = 512;
 constexpr int kRbTilesOut = kRbOut / 32;  // 16
-constexpr int kRbChunksG1 = kRbTilesIn * 2;                 // W_0: per out tile chunk A (k 0..255), chunk B (k 256..319)
+constexpr int kRbCSteps = kRbStepsIn / 2;                   // 10 k-steps per chunk
+constexpr int kRbChunkFloats = kRbCSteps * 2 * 64 * 4;      // [k-step][hi|lo][lane][4 words] = 5120 floats = 20 KiB
+constexpr int kRbPieces = kRbChunkFloats * 4 / (4 * 64 * 16);   // 5 LDS-DMA pieces (16 B per lane) per wave and chunk
+#ifndef E3DGE_RB_NBUF
+#define E3DGE_RB_NBUF 5
+#endif
+constexpr int kRbNBuf = E3DGE_RB_NBUF;                      // LDS weight buffers
+#ifndef E3DGE_RB_RING
+#define E3DGE_RB_RING 2
+#endif
+constexpr int kRbRing = E3DGE_RB_RING;                      // k-steps of (hi, lo) weight fragments held: 1 consumed + the rest in flight
+constexpr int kRbChunksG1 = kRbTilesIn * 2;                 // W_0: per out tile chunk A (k 0..159), chunk B (k 160..319)
 constexpr int kRbChunksG2 = kRbTilesOut * 4;                // per out tile: W_s A, W_s B, W_1 A, W_1 B
 constexpr int kRbChunks = kRbChunksG1 + kRbChunksG2;        // 84
-constexpr int64_t kRbOffBias0 = (int64_t)kRbChunks * kChunkFloats;    // b_0 [320]
+constexpr int64_t kRbOffBias0 = (int64_t)kRbChunks * kRbChunkFloats;  // b_0 [320]
 constexpr int64_t kRbOffBias1 = kRbOffBias0 + kRbKin;                 // b_1 [512]
 constexpr int64_t kRbOffAux = kRbOffBias1 + kRbOut;                   // [0] max_n ||W_0[n,:]||_2, [1] max |b_0|, [2..3] pad
 constexpr int64_t kRbPackedFloats = kRbOffAux + 4;
 
-constexpr int kRbXPitch = 36;             // floats per point row of the staging tile (16-B aligned rows)
 constexpr int kRbLdsW = 0;
-constexpr int kRbLdsX = kRbLdsW + kNBuf * kChunkFloats;               // [128][36] staging of one 32-feature slice of x
-constexpr int kRbLdsB = kRbLdsX + kTilePts * kRbXPitch;               // b_0 [320], b_1 [512]
+constexpr int kRbLdsB = kRbLdsW + kRbNBuf * kRbChunkFloats;           // b_0 [320], b_1 [512]
 constexpr int kRbLdsFloats = kRbLdsB + kRbKin + kRbOut;
 constexpr int kRbLdsBytes = kRbLdsFloats * 4;
 static_assert(kRbLdsBytes <= 160 * 1024, "LDS budget");
+static_assert(kRbNBuf >= 3 && kRbPieces == 5, "chunk pipeline shape");
 
 // ---------------------------------------------------------------------------------------------------------------
-// weight image: [chunk][16 k-steps][hi|lo][64 lanes][4 words of two f16], value kW16Scale * W[n][k] with
-// n = 32 t + (lane & 31), k = 256 * half_chunk + (k-slot order of kOffBig16); rows / columns beyond the real sizes are 0
+// weight image: [chunk][10 k-steps][hi|lo][64 lanes][4 words of two f16], value kW16Scale * W[n][k] with
+// n = 32 t + (lane & 31), k = 160 * half_chunk + (k-slot order of kOffBig16); rows / columns beyond the real sizes are 0
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 resblock_pack_kernel(float* __restrict__ packed, const float* __restrict__ w0, const float* __restrict__ b0,
@@ -58,8 +69,8 @@ resblock_pack_kernel(float* __restrict__ packed, const float* __restrict__ w0, c
             const int k = r & 3; r >>= 2;
             const int lane = r & 63; r >>= 6;
             const int hl = r & 1; r >>= 1;
-            const int g = r & 15; r >>= 4;
-            const int chunk = (int)r;
+            const int chunk = (int)(r / kRbCSteps);
+            const int g = (int)(r - (int64_t)chunk * kRbCSteps);
             int t, kc, which;                         // which: 0 = W_0, 1 = W_s, 2 = W_1
             if (chunk < kRbChunksG1) { t = chunk >> 1; kc = chunk & 1; which = 0; }
             else { const int c2 = chunk - kRbChunksG1; t = c2 >> 2; kc = c2 & 1; which = 1 + ((c2 >> 1) & 1); }
@@ -67,7 +78,8 @@ resblock_pack_kernel(float* __restrict__ packed, const float* __restrict__ w0, c
             unsigned word = 0;
             for (int e2 = 0; e2 < 2; ++e2) {
                 const int j = 2 * k + e2;
-                const int kk = 256 * kc + 32 * (g >> 1) + 16 * (g & 1) + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
+                const int gg = kRbCSteps * kc + g;     // k-step of the whole contraction: two per 32-feature tile of x / r
+                const int kk = 32 * (gg >> 1) + 16 * (gg & 1) + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
                 float w = 0.0f;
                 if (kk < cin) {
                     if (which == 0) { if (n < cin) w = w0[(int64_t)n * cin + kk]; }       // fc_0: (cin, cin)
@@ -108,41 +120,100 @@ resblock_norm_kernel(float* __restrict__ aux, const float* __restrict__ w0, cons
     if (threadIdx.x == 0) { aux[0] = red[0][0]; aux[1] = red[1][0]; aux[2] = 0.0f; aux[3] = 0.0f; }
 }
 
-// one weight chunk against KSTEPS k-steps of a B operand produced by `opnd(g, H, L)`; the same ring / barrier / DMA protocol
-// as big_tile_f16 (siren_common.h), with the chunk barrier after k-step SYNC and the 8 DMA pieces spread over the rest
-template <int KSTEPS, int SYNC, class Opnd, class Sync, class Dma>
+// The weight-chunk pipeline of this kernel (cf. ChunkPipe in siren_common.h, which the 8-wave SIREN kernels use with three
+// 32-KiB buffers and a plain vmcnt(0)).  Chunk c lives in buffer c % kRbNBuf; wave w copies bytes [5 w, 5 w + 5) KiB of a
+// chunk in five 1-KiB LDS-DMA pieces.  sync(), early in chunk c: every wave waits until ITS pieces of chunk c+1 have landed
+// -- in-order completion: at most the 5 (kRbNBuf - 3) pieces of the chunks after it may still be outstanding; output stores
+// and x loads in the queue only make the wait stricter, never laxer --, the barrier publishes chunk c+1 and proves that
+// everybody has left chunk c-1, whose buffer the DMA of chunk c + kRbNBuf - 1 may now overwrite.  Chunk indices wrap
+// after `count`; chunks fetched past the end of the work land in buffers nobody reads (the kernel ends with vmcnt(0)).
+struct RbPipe {
+    const char* img;          // image + this wave's 5-KiB slice (wave-uniform)
+    const char* src;          // chunk being issued
+    uint32_t voff;            // lane * 16
+    uint32_t lds_base;        // LDS byte address of wbuf + this wave's slice
+    uint32_t lds_dst;         // ... of the buffer being filled
+    int idx, count, buf, use_buf;
+    float* wbuf;
+    const float* wcur;
+    const float* wnxt;
+    static constexpr int kSliceBytes = kRbPieces * 1024;
+    __device__ __forceinline__ void init(float* wbuf_, const float* image, int wave, int lane, int count_) {
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        wbuf = wbuf_;
+        img = reinterpret_cast<const char*>(image) + wave_u * kSliceBytes;
+        voff = (uint32_t)lane * 16u;
+        lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) float*)wbuf_ + (uint32_t)wave_u * kSliceBytes;
+        count = count_;
+        idx = 0; buf = 0; use_buf = 0;
+        src = img;
+        lds_dst = lds_base;
+        wcur = wbuf_; wnxt = wbuf_ + kRbChunkFloats;
+    }
+    __device__ __forceinline__ void issue_piece(int i) {     // i is a compile-time constant at every call site
+        switch (i) {
+            case 0: glds16_saddr<0>(src, voff, lds_dst); break;
+            case 1: glds16_saddr<1024>(src, voff, lds_dst); break;
+            case 2: glds16_saddr<2048>(src, voff, lds_dst); break;
+            case 3: glds16_saddr<3072>(src, voff, lds_dst); break;
+            default: glds16_saddr<0>(src + 4096, voff, lds_dst + 4096u); break;     // the immediate is 13-bit signed
+        }
+        if (i == kRbPieces - 1) {
+            idx = (idx + 1 == count) ? 0 : idx + 1;
+            src = img + (size_t)idx * (kRbChunkFloats * 4);
+            buf = (buf + 1 == kRbNBuf) ? 0 : buf + 1;
+            lds_dst = lds_base + (uint32_t)buf * (kRbChunkFloats * 4);
+        }
+    }
+    __device__ __forceinline__ void prime() {
+        for (int c = 0; c < kRbNBuf - 1; ++c)
+#pragma unroll
+            for (int i = 0; i < kRbPieces; ++i) issue_piece(i);
+    }
+    __device__ __forceinline__ void sync() {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kRbPieces * (kRbNBuf - 3)) : "memory");
+        __syncthreads();
+    }
+    __device__ __forceinline__ void advance() {
+        use_buf = (use_buf + 1 == kRbNBuf) ? 0 : use_buf + 1;
+        wcur = wnxt;
+        wnxt = wbuf + ((use_buf + 1 == kRbNBuf) ? 0 : use_buf + 1) * kRbChunkFloats;
+    }
+};
+
+// one weight chunk against its KSTEPS k-steps of a B operand produced by `opnd(g, H, L)`; the same operand ring as
+// big_tile_f16 (siren_common.h), with the chunk barrier after k-step SYNC and the DMA pieces of the chunk kRbNBuf - 1
+// ahead handed out one per k-step after it
+// POS is the chunk's position inside its output tile (tiles have an even number of chunks): ten k-steps per chunk do not
+// divide a ring of four, so the slot of k-step g is (g + 10 POS) % kRbRing -- a compile-time rotation
+template <int KSTEPS, int SYNC, int POS, class Opnd, class Sync, class Dma, class Step>
 __device__ __forceinline__ void rb_tile(const float* __restrict__ wchunk, const float* __restrict__ wnext, int lane,
-                                        f32x16& acc, f32x16& accb, u32x4 (&ringH)[kRing16], u32x4 (&ringL)[kRing16],
-                                        Opnd&& opnd, Sync&& sync, Dma&& dma) {
+                                        f32x16& acc, f32x16& accb, u32x4 (&ringH)[kRbRing], u32x4 (&ringL)[kRbRing],
+                                        Opnd&& opnd, Sync&& sync, Dma&& dma, Step&& step) {
     const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(wchunk) + lane;
     const u32x4* __restrict__ wn = reinterpret_cast<const u32x4*>(wnext) + lane;
-    constexpr int kAvail = KSTEPS - SYNC - 1;                 // k-steps after the barrier
-    constexpr int kPer = (8 + kAvail - 1) / kAvail;           // DMA pieces per such step
-    static_assert(kAvail >= 1 && SYNC + kRing16 - 1 >= 0, "tile too short");
+    constexpr int PH = (POS * KSTEPS) % kRbRing;
+    static_assert((2 * KSTEPS) % kRbRing == 0, "ring rotation must close over a pair of chunks");
+    static_assert(KSTEPS - SYNC - 1 >= kRbPieces, "tile too short");
 #pragma unroll
     for (int g = 0; g < KSTEPS; ++g) {
-        const int ga = g + kRing16 - 1;
+        step(POS * KSTEPS + g);
+        const int ga = g + kRbRing - 1;
         // the next chunk may only be touched after this tile's barrier
-        static_assert(KSTEPS - (kRing16 - 1) > SYNC, "ring would read the next chunk before the barrier");
-        ringH[ga % kRing16] = (ga < KSTEPS) ? wp[(ga * 2 + 0) * 64] : wn[((ga - KSTEPS) * 2 + 0) * 64];
-        ringL[ga % kRing16] = (ga < KSTEPS) ? wp[(ga * 2 + 1) * 64] : wn[((ga - KSTEPS) * 2 + 1) * 64];
+        static_assert(KSTEPS - (kRbRing - 1) > SYNC, "ring would read the next chunk before the barrier");
+        ringH[(ga + PH) % kRbRing] = (ga < KSTEPS) ? wp[(ga * 2 + 0) * 64] : wn[((ga - KSTEPS) * 2 + 0) * 64];
+        ringL[(ga + PH) % kRbRing] = (ga < KSTEPS) ? wp[(ga * 2 + 1) * 64] : wn[((ga - KSTEPS) * 2 + 1) * 64];
         __builtin_amdgcn_sched_barrier(0);
-        const u32x4 wh = ringH[g % kRing16], wl = ringL[g % kRing16];
+        const u32x4 wh = ringH[(g + PH) % kRbRing], wl = ringL[(g + PH) % kRbRing];
         u32x4 bH, bL;
         opnd(g, bH, bL);
         f32x16& x0 = (g & 1) ? accb : acc;
-        f32x16& x1 = (g & 1) ? acc : accb;
         x0 = mfma16(wh, bH, x0);
+        f32x16& x1 = (g & 1) ? acc : accb;
         x1 = mfma16(wl, bH, x1);
         x0 = mfma16(wh, bL, x0);
         if (g == SYNC) sync();
-        if (g > SYNC) {
-#pragma unroll
-            for (int i = 0; i < kPer; ++i) {
-                const int piece = (g - SYNC - 1) * kPer + i;
-                if (piece < 8) dma(piece);
-            }
-        }
+        if (g > SYNC && g - SYNC - 1 < kRbPieces) dma(g - SYNC - 1);
     }
 }
 
@@ -155,18 +226,46 @@ struct ResblockK {
     int cin, subtiles_per_wg;
 };
 
-// relu on a packed (hi, lo) pair of two f16 values each: both halves are cleared where hi is negative
+// relu on a packed (hi, lo) pair of two f16 values each: both halves are cleared where hi is negative.  Three VALU ops a
+// word: packed integer max against 0 on the bit patterns (negative f16 <=> negative int16), packed arithmetic shift for the
+// sign mask, and-not.  The first two are volatile asm ON PURPOSE: the ten output tiles of phase 2 are unrolled and apply this
+// to the same x words, and as plain C++ the compiler keeps the results of the first tile alive for the others -- 160 more
+// live registers, i.e. spills whose reloads wait for all weight DMA in flight.
 __device__ __forceinline__ void relu_hilo(unsigned h, unsigned l, unsigned& rh, unsigned& rl) {
-    const unsigned s = h & 0x80008000u;
-    const unsigned keep = ~((s - (s >> 15)) | s);
-    rh = h & keep;
-    rl = l & keep;
+    unsigned neg;
+    asm volatile("v_pk_max_i16 %0, %1, 0" : "=v"(rh) : "v"(h));
+    asm volatile("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(neg) : "v"(h));
+    rl = l & ~neg;
 }
+
+#ifdef E3DGE_RB_TRACE
+// (tag, s_memtime) pairs of one wave (tools/rb_trace.py): tag = 1000 * phase + 100 * what + index
+__device__ unsigned long long g_rb_trace[640];
+#if E3DGE_RB_TRACE > 1
+#define RB_STAMP(tag) do { if (tr_on) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)); \
+                                        if ((tid_k & 63) == 0 && tr_i < 320) { g_rb_trace[2 * tr_i] = (tag); g_rb_trace[2 * tr_i + 1] = t_; } \
+                                        ++tr_i; } } while (0)
+#else       // coarse: the four phase boundaries only, held in SGPRs until the sub-tile ends (leaves the register allocation alone)
+#define RB_STAMP(tag) do { if ((tag) >= 1000) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_ts[(tag) / 1000 - 1])); \
+                             if ((tag) == 4000 && tr_sub && (tid_k & 63) == 0) {                                                    \
+                                 for (int i_ = 0; i_ < 4; ++i_) { g_rb_trace[2 * i_] = 1000 * (i_ + 1); g_rb_trace[2 * i_ + 1] = tr_ts[i_]; } \
+                                 g_rb_trace[9] = 0; } } } while (0)
+#endif
+#ifndef E3DGE_RB_TRACE_T2
+#define E3DGE_RB_TRACE_T2 1
+#endif
+#ifndef E3DGE_RB_TRACE_T3
+#define E3DGE_RB_TRACE_T3 5
+#endif
+#else
+#define RB_STAMP(tag) do { } while (0)
+#endif
+
+struct __attribute__((packed, aligned(4))) F4u { float v[4]; };        // 16-byte load at 4-byte alignment
 
 __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wbuf = smem + kRbLdsW;
-    float* const xs = smem + kRbLdsX;
     float* const b0_s = smem + kRbLdsB;
     float* const b1_s = b0_s + kRbKin;
 
@@ -176,18 +275,35 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
     const int npts = (int)(rem < (long long)a.subtiles_per_wg * kTilePts ? rem : (long long)a.subtiles_per_wg * kTilePts);
     const int n_sub = (npts + kTilePts - 1) / kTilePts;
     const float* __restrict__ packed = a.packed;
+    float* const out_a = a.alpha + pt0 * kWidth;            // wave-uniform bases of this workgroup's rows
+    float* const out_b = a.beta + pt0 * kWidth;
     for (int i = tid_k; i < kRbKin + kRbOut; i += kThreads) b0_s[i] = packed[kRbOffBias0 + i];
 
-    ChunkPipe pipe;
-    pipe.init(wbuf, packed, tid_k >> 6, tid_k & 63, 0, kRbChunks);
+    RbPipe pipe;
+    pipe.init(wbuf, packed, tid_k >> 6, tid_k & 63, kRbChunks);
     pipe.prime();
     auto issue_piece = [&](int i) { pipe.issue_piece(i); };
+#ifdef E3DGE_RB_TRACE
+    bool tr_on = false, tr_sub = false;
+    int tr_i = 0;
+    unsigned long long tr_ts[4] = {0, 0, 0, 0};
+    auto chunk_sync = [&]() {
+        RB_STAMP(100);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kRbPieces * (kRbNBuf - 3)) : "memory");
+        RB_STAMP(200);
+        __syncthreads();
+        RB_STAMP(300);
+    };
+    auto kstep = [&](int g) { RB_STAMP(g); };
+#else
     auto chunk_sync = [&]() { pipe.sync(); };
+    auto kstep = [](int) {};
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    u32x4 ringH[kRing16], ringL[kRing16];
+    u32x4 ringH[kRbRing], ringL[kRbRing];
 #pragma unroll
-    for (int g = 0; g < kRing16 - 1; ++g) {
+    for (int g = 0; g < kRbRing - 1; ++g) {
         ringH[g] = reinterpret_cast<const u32x4*>(pipe.wcur)[(g * 2 + 0) * 64 + (tid_k & 63)];
         ringL[g] = reinterpret_cast<const u32x4*>(pipe.wcur)[(g * 2 + 1) * 64 + (tid_k & 63)];
     }
@@ -198,34 +314,87 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
         const int tid = tid_o, lane = tid & 63, wave = tid >> 6, half = lane >> 5, col = lane & 31;
         const int p = sub * kTilePts + 32 * wave + col;
         const bool valid = p < npts;
-        const long long gpt = pt0 + (valid ? p : npts - 1);
+        const int pc = valid ? p : npts - 1;                 // padded lanes shadow the last valid point
+        const long long gpt = pt0 + pc;
+        // output position as a 32-bit offset from the workgroup's first row: a 64-bit per-lane address held across the
+        // tile loop gets spilled, and its reload waits for every weight DMA in flight
+        const unsigned out_off = (unsigned)pc * kWidth + 4u * half;
 
-        // ---- 1. x: coalesced 32-feature slices through LDS, each lane keeps its point's values; then (hi, lo) ----
+#ifdef E3DGE_RB_TRACE
+        tr_sub = blockIdx.x == 7 && (tid_k >> 6) == 0 && sub == 1;
+        tr_on = tr_sub;
+        if (tr_on) tr_i = 0;
+        RB_STAMP(1000);
+#endif
+        // ---- 1. x: each lane keeps its point's values; then (hi, lo) ----
         u32x4 xH[kRbStepsIn], xL[kRbStepsIn];
         float inv_x, xnorm;
         {
             f32x16 xf[kRbTilesIn];
             float m = 0.0f, ss = 0.0f;
-            const long long sub0 = pt0 + (long long)sub * kTilePts;
+            // this lane's point, straight from global memory: register r = 4q + j of tile ft is feature 32 ft + 8 q + 4 half + j,
+            // i.e. one 16-byte load per (tile, q) at 4-byte alignment (rows are cin floats).  Branch-free on purpose: all 40
+            // loads of the sub-tile are in flight together.  (Loads under a per-quad `if (quad inside the row)` each got their
+            // own vmcnt(0) -- 40 serialized round trips that also drained the weight DMA: 59 of the 177 kcycles of a sub-tile.
+            // The first version staged 32-feature slices through LDS: ten load -> barrier -> read rounds.)  A quad that sticks
+            // out of its row reads into the next row and is zeroed afterwards; only at the very end of the tensor would that
+            // leave the buffer, so the start of every read is clamped to the last legal one and the (at most one) wave that
+            // was clamped shifts its elements back into place.  Padded lanes read the last valid point.
+            const long long total = a.n_pts * (long long)a.cin;
+            const long long row0 = gpt * a.cin;
+            if (total >= 4) {
+                const long long sl = total - 4 - row0;                      // last legal start, relative to this row
+                const int slack = (int)(sl < 4096 ? sl : 4096);
+                const float* __restrict__ xr = a.feats + row0;
+#pragma unroll
+                for (int ft = 0; ft < kRbTilesIn; ++ft) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int f0 = 32 * ft + 8 * q + 4 * half;          // first feature of this quad
+                        const F4u v = *reinterpret_cast<const F4u*>(xr + min(f0, slack));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) xf[ft][4 * q + j] = v.v[j];
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(slack < kRbKin - 4)) {      // wave-uniform, true for the tensor's last rows only
+#pragma unroll
+                    for (int ft = 0; ft < kRbTilesIn; ++ft) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int f0 = 32 * ft + 8 * q + 4 * half;
+                            const int d = f0 - min(f0, slack);              // the read started d elements early
+                            float v[4], w[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = xf[ft][4 * q + j];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                w[j] = v[j];
+                                if (j + 1 < 4) w[j] = d == 1 ? v[j + 1] : w[j];
+                                if (j + 2 < 4) w[j] = d == 2 ? v[j + 2] : w[j];
+                                if (j + 3 < 4) w[j] = d == 3 ? v[j + 3] : w[j];
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) xf[ft][4 * q + j] = w[j];
+                        }
+                    }
+                }
+                const int lim = a.cin - 4 * half;                           // feature 32 ft + 8 q + j is real iff below lim
+#pragma unroll
+                for (int ft = 0; ft < kRbTilesIn; ++ft)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xf[ft][r] = (32 * ft + 8 * (r >> 2) + (r & 3) < lim) ? xf[ft][r] : 0.0f;
+            } else {                                                        // fewer than four floats in the whole tensor
+#pragma unroll
+                for (int ft = 0; ft < kRbTilesIn; ++ft)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xf[ft][r] = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) if (half == 0 && j < a.cin) xf[0][j] = a.feats[row0 + j];
+            }
 #pragma unroll
             for (int ft = 0; ft < kRbTilesIn; ++ft) {
-                __syncthreads();                            // previous slice consumed
-                // 128 points x 32 features = 4096 floats, 16 per thread: lane <-> feature, so a wave instruction reads
-                // two 128-byte row segments
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int e = i * kThreads + tid, pp = e >> 5, f = 32 * ft + (e & 31);
-                    const long long gp = sub0 + pp;
-                    xs[pp * kRbXPitch + (e & 31)] = (gp < pt0 + npts && f < a.cin) ? a.feats[gp * a.cin + f] : 0.0f;
-                }
-                __syncthreads();
-                const float* row = xs + (32 * wave + col) * kRbXPitch + 4 * half;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 q4 = *reinterpret_cast<const f32x4*>(row + 8 * q);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { xf[ft][4 * q + j] = q4[j]; m = fmaxf(m, fabsf(q4[j])); ss = fmaf(q4[j], q4[j], ss); }
-                }
+                for (int r = 0; r < 16; ++r) { m = fmaxf(m, fabsf(xf[ft][r])); ss = fmaf(xf[ft][r], xf[ft][r], ss); }
                 asm volatile("" : "+a"(xf[ft]));
             }
             m = fmaxf(m, xhalf(m));
@@ -235,38 +404,53 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
             const float sc = __uint_as_float((254u - e) << 23);
             inv_x = __uint_as_float((e > 8u ? e - 7u : 1u) << 23);
 #pragma unroll
-            for (int t = 0; t < kRbTilesIn; ++t)
+            for (int t = 0; t < kRbTilesIn; ++t) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2)
                     SPLIT2_TO(xf[t][r] * sc, xf[t][r + 1] * sc, xH[2 * t + (r >> 3)][(r & 7) >> 1], xL[2 * t + (r >> 3)][(r & 7) >> 1]);
+                // x is used by VALU code (the relu of phase 2): keep its words in the VGPR half, next to the weight ring and
+                // the epilogue temporaries; the r words (160) and the accumulators take the AGPR half
+                asm volatile("" : "+v"(xH[2 * t]), "+v"(xH[2 * t + 1]), "+v"(xL[2 * t]), "+v"(xL[2 * t + 1]));
+            }
         }
 
+        RB_STAMP(2000);
+#if defined(E3DGE_RB_TRACE) && E3DGE_RB_TRACE > 1
+        tr_on = false;
+#endif
         // ---- 2. net = W_0 relu(x) + b_0 ; r = relu(net) as (hi, lo) words ----
         // r has to be split tile by tile (keeping it in fp32 until its column maximum is known costs 160 more registers
         // than there are), so its scale comes from the bound max|net| <= max_n ||W_0[n,:]|| * ||x|| + max|b_0| instead of the
         // exact maximum: typically a few bits of headroom, i.e. the operand is still good to ~2^-21 of the column maximum.
         u32x4 rH[kRbStepsIn], rL[kRbStepsIn];
-        float inv_r;
+        float inv_r, x_to_r;
         {
             const float bound = fmaf(packed[kRbOffAux], xnorm, packed[kRbOffAux + 1]);
             const unsigned er = min((__float_as_uint(bound) >> 23) & 255u, 253u);   // bound < 2^(er-126)
             const float sc_r = __uint_as_float((253u - er) << 23);          // r * sc_r < 1
             inv_r = __uint_as_float((er > 8u ? er - 6u : 1u) << 23);        // 1 / (128 * sc_r)
+            x_to_r = inv_x / inv_r;
 #pragma unroll
             for (int t = 0; t < kRbTilesIn; ++t) {
+#if defined(E3DGE_RB_TRACE) && E3DGE_RB_TRACE > 1
+                tr_on = tr_sub && t == E3DGE_RB_TRACE_T2;
+#endif
                 f32x16 acc = zero16(), accb = zero16();
-                rb_tile<16, kSyncStep16>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
+                rb_tile<kRbCSteps, kSyncStep16, 0>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
                     [&](int g, u32x4& H, u32x4& L) {
 #pragma unroll
                         for (int w = 0; w < 4; ++w) { unsigned h, l; relu_hilo(xH[g][w], xL[g][w], h, l); H[w] = h; L[w] = l; }
-                    }, chunk_sync, issue_piece);
+                    }, chunk_sync, issue_piece, kstep);
                 pipe.advance();
-                rb_tile<4, 0>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
+                rb_tile<kRbCSteps, kSyncStep16, 1>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
                     [&](int g, u32x4& H, u32x4& L) {
 #pragma unroll
-                        for (int w = 0; w < 4; ++w) { unsigned h, l; relu_hilo(xH[16 + g][w], xL[16 + g][w], h, l); H[w] = h; L[w] = l; }
-                    }, chunk_sync, issue_piece);
+                        for (int w = 0; w < 4; ++w) {
+                            unsigned h, l; relu_hilo(xH[kRbCSteps + g][w], xL[kRbCSteps + g][w], h, l); H[w] = h; L[w] = l;
+                        }
+                    }, chunk_sync, issue_piece, kstep);
                 pipe.advance();
+                RB_STAMP(400);
                 const f32x16 sum = (acc + accb) * inv_x;
                 f32x16 rv;
 #pragma unroll
@@ -279,9 +463,14 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
                 for (int r = 0; r < 16; r += 2)
                     SPLIT2_TO(rv[r], rv[r + 1], rH[2 * t + (r >> 3)][(r & 7) >> 1], rL[2 * t + (r >> 3)][(r & 7) >> 1]);
                 asm volatile("" : "+a"(rH[2 * t]), "+a"(rH[2 * t + 1]), "+a"(rL[2 * t]), "+a"(rL[2 * t + 1]));
+                RB_STAMP(500);
             }
         }
 
+#ifdef E3DGE_RB_TRACE
+        tr_on = tr_sub;
+#endif
+        RB_STAMP(3000);
         // ---- 3. out = W_s x + W_1 r + b_1 -> alpha (tiles 0..7), beta (tiles 8..15) ----
 #ifdef E3DGE_RB_UNROLL2
 #pragma unroll
@@ -289,32 +478,43 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
 #pragma unroll 1
 #endif
         for (int t = 0; t < kRbTilesOut; ++t) {
+#if defined(E3DGE_RB_TRACE) && E3DGE_RB_TRACE > 1
+            tr_on = tr_sub && t == E3DGE_RB_TRACE_T3;
+#endif
             f32x16 acc = zero16(), accb = zero16();
-            rb_tile<16, kSyncStep16>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
-                [&](int g, u32x4& H, u32x4& L) { H = xH[g]; L = xL[g]; }, chunk_sync, issue_piece);
+            rb_tile<kRbCSteps, kSyncStep16, 0>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
+                [&](int g, u32x4& H, u32x4& L) { H = xH[g]; L = xL[g]; }, chunk_sync, issue_piece, kstep);
             pipe.advance();
-            rb_tile<4, 0>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
-                [&](int g, u32x4& H, u32x4& L) { H = xH[16 + g]; L = xL[16 + g]; }, chunk_sync, issue_piece);
+            rb_tile<kRbCSteps, kSyncStep16, 1>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
+                [&](int g, u32x4& H, u32x4& L) { H = xH[kRbCSteps + g]; L = xL[kRbCSteps + g]; }, chunk_sync, issue_piece, kstep);
             pipe.advance();
-            f32x16 res = (acc + accb) * inv_x;
-            acc = zero16(); accb = zero16();
-            rb_tile<16, kSyncStep16>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
-                [&](int g, u32x4& H, u32x4& L) { H = rH[g]; L = rL[g]; }, chunk_sync, issue_piece);
+            // one accumulator pair for both products: W_s x is rescaled (a power of two, exact) to the scale of W_1 r
+            RB_STAMP(600);
+            acc = (acc + accb) * x_to_r;
+            accb = zero16();
+            rb_tile<kRbCSteps, kSyncStep16, 2>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
+                [&](int g, u32x4& H, u32x4& L) { H = rH[g]; L = rL[g]; }, chunk_sync, issue_piece, kstep);
             pipe.advance();
-            rb_tile<4, 0>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
-                [&](int g, u32x4& H, u32x4& L) { H = rH[16 + g]; L = rL[16 + g]; }, chunk_sync, issue_piece);
+            rb_tile<kRbCSteps, kSyncStep16, 3>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
+                [&](int g, u32x4& H, u32x4& L) { H = rH[kRbCSteps + g]; L = rL[kRbCSteps + g]; }, chunk_sync, issue_piece, kstep);
             pipe.advance();
-            res = res + (acc + accb) * inv_r;
-            float* __restrict__ dst = (t < 8 ? a.alpha : a.beta) + gpt * kWidth + 32 * (t & 7);
+            RB_STAMP(700);
+            const f32x16 res = (acc + accb) * inv_r;
+            float* __restrict__ dst = (t < 8 ? out_a : out_b) + (out_off + 32u * (t & 7));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(b1_s + 32 * t + 8 * q + 4 * half);
                 f32x4 o4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o4[j] = res[4 * q + j] + b4[j];
-                if (valid) *reinterpret_cast<f32x4*>(dst + 8 * q + 4 * half) = o4;
+                if (valid) *reinterpret_cast<f32x4*>(dst + 8 * q) = o4;
             }
+            RB_STAMP(800);
         }
+#ifdef E3DGE_RB_TRACE
+        tr_on = tr_sub;
+#endif
+        RB_STAMP(4000);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -322,6 +522,12 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
 }  // namespace e3dge
 
 using namespace e3dge;
+
+#ifdef E3DGE_RB_TRACE
+extern "C" int e3dge_debug_rb_trace(unsigned long long* out640) {
+    return hipMemcpyFromSymbol(out640, HIP_SYMBOL(e3dge::g_rb_trace), sizeof(unsigned long long) * 640) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int64_t e3dge_resblock_packed_floats(void) { return kRbPackedFloats; }
 

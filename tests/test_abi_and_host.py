@@ -155,7 +155,7 @@ def test_local_global_wrapper_keeps_netglobal_keys():
     assert shapes == {'fc_0.weight': (301, 301), 'fc_0.bias': (301,), 'fc_1.weight': (512, 301), 'fc_1.bias': (512,),
                       'shortcut.weight': (512, 301)}
     assert all(float(v.abs().max()) == 0 for k, v in r2.state_dict().items() if k.startswith(pre))
-    assert lib_floats() == 84 * 8192 + 320 + 512 + 4
+    assert lib_floats() == 84 * 5120 + 320 + 512 + 4          # 84 weight chunks of 20 KiB, b_0, b_1, 4 bound scalars
 
 
 def lib_floats():

@@ -64,6 +64,29 @@ def test_texhead_sizes_against_oracle(cin, n):
     assert e <= 2e-5 * scale and e64 <= 3 * o64 + 1e-5 * scale, (e, e64, o64)
 
 
+@pytest.mark.parametrize("cin", [1, 2, 3, 5, 7, 62, 299, 301, 302, 303, 317])
+@pytest.mark.parametrize("n", [1, 2, 33])
+def test_texhead_ragged_row_ends(cin, n):
+    """Rows are read in 16-byte pieces at 4-byte alignment; a piece that sticks out of its row reads into the next row and
+    is zeroed, and the pieces at the very end of the tensor are clamped and shifted back.  The tensor sits at an odd offset
+    inside a NaN-filled buffer: any element taken from outside its row (or outside the tensor) poisons the output."""
+    h, sd = make_head(cin)
+    rs = np.random.RandomState(1000 * cin + n)
+    x = (rs.standard_normal((n, cin)) * (0.1 + 2 * rs.uniform(size=(1, cin)))).astype(np.float32)
+    buf = torch.full((3 + n * cin + 64,), float('nan'), device=DEV)
+    buf[3:3 + n * cin] = torch.from_numpy(x).reshape(-1).to(DEV)
+    feats = buf[3:3 + n * cin].view(n, cin)
+    assert feats.is_contiguous() and feats.data_ptr() % 16 != 0
+    with torch.no_grad():
+        a, b = h.tex_modulations(feats)
+        ra, rb = renderer_ref.tex_modulations(sd, PREFIX, torch.from_numpy(x))
+    assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
+    scale = max(1.0, float(ra.abs().max()) / 10)
+    e = max(maxerr(a, ra), maxerr(b, rb))
+    record(f"texhead_ragged_cin{cin}_n{n}", hip_vs_oracle=e)
+    assert e <= 2e-5 * scale, e
+
+
 @pytest.mark.parametrize("mag", [1e-6, 1e+4])
 def test_texhead_input_magnitude(mag):
     """Per-point block scaling of the operands: the relative error does not depend on the input's magnitude."""
