@@ -213,7 +213,7 @@ __device__ __forceinline__ void rb_tile(const float* __restrict__ wchunk, const 
         x1 = mfma16(wl, bH, x1);
         x0 = mfma16(wh, bL, x0);
         if (g == SYNC) sync();
-        if (g > SYNC && g - SYNC - 1 < kRbPieces) dma(g - SYNC - 1);
+        if (g > SYNC && g - SYNC - 1 < kRbPieces) dma(g - SYNC - 1);     // (all five right after the barrier: same time)
     }
 }
 
@@ -423,92 +423,111 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
         // than there are), so its scale comes from the bound max|net| <= max_n ||W_0[n,:]|| * ||x|| + max|b_0| instead of the
         // exact maximum: typically a few bits of headroom, i.e. the operand is still good to ~2^-21 of the column maximum.
         u32x4 rH[kRbStepsIn], rL[kRbStepsIn];
-        float inv_r, x_to_r;
+        float inv_r;
         {
             const float bound = fmaf(packed[kRbOffAux], xnorm, packed[kRbOffAux + 1]);
             const unsigned er = min((__float_as_uint(bound) >> 23) & 255u, 253u);   // bound < 2^(er-126)
             const float sc_r = __uint_as_float((253u - er) << 23);          // r * sc_r < 1
             inv_r = __uint_as_float((er > 8u ? er - 6u : 1u) << 23);        // 1 / (128 * sc_r)
-            x_to_r = inv_x / inv_r;
+            // Two accumulator pairs (P, Q).  A tile's epilogue -- 170 VALU instructions in phase 2 -- would otherwise run with the
+            // matrix pipe idle (one wave per SIMD: nothing else to issue), so it is deferred: tile t accumulates into one pair
+            // while the finished pair of tile t-1 is turned into r words in four slices, hooked in front of k-steps 1..4.
+            auto r_slice = [&](int T, int q, const f32x16& a0, const f32x16& a1) {         // registers 4q..4q+3 of tile T
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(b0_s + 32 * T + 8 * q + 4 * half);
+                float rv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rv[j] = fmaxf((a0[4 * q + j] + a1[4 * q + j]) * inv_x + b4[j], 0.0f) * sc_r;
+                const int r = 4 * q;
+                SPLIT2_TO(rv[0], rv[1], rH[2 * T + (r >> 3)][(r & 7) >> 1], rL[2 * T + (r >> 3)][(r & 7) >> 1]);
+                SPLIT2_TO(rv[2], rv[3], rH[2 * T + (r >> 3)][((r + 2) & 7) >> 1], rL[2 * T + (r >> 3)][((r + 2) & 7) >> 1]);
+            };
+            f32x16 P0, P1, Q0, Q1;
 #pragma unroll
             for (int t = 0; t < kRbTilesIn; ++t) {
 #if defined(E3DGE_RB_TRACE) && E3DGE_RB_TRACE > 1
                 tr_on = tr_sub && t == E3DGE_RB_TRACE_T2;
 #endif
-                f32x16 acc = zero16(), accb = zero16();
-                rb_tile<kRbCSteps, kSyncStep16, 0>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
+                f32x16& A0 = (t & 1) ? Q0 : P0;
+                f32x16& A1 = (t & 1) ? Q1 : P1;
+                const f32x16& B0 = (t & 1) ? P0 : Q0;                       // the pair tile t-1 left behind
+                const f32x16& B1 = (t & 1) ? P1 : Q1;
+                auto hook = [&](int g) {
+                    kstep(g);
+                    if (t > 0 && g >= 1 && g <= 4) r_slice(t - 1, g - 1, B0, B1);
+                };
+                A0 = zero16(); A1 = zero16();
+                rb_tile<kRbCSteps, kSyncStep16, 0>(pipe.wcur, pipe.wnxt, lane, A0, A1, ringH, ringL,
                     [&](int g, u32x4& H, u32x4& L) {
 #pragma unroll
                         for (int w = 0; w < 4; ++w) { unsigned h, l; relu_hilo(xH[g][w], xL[g][w], h, l); H[w] = h; L[w] = l; }
-                    }, chunk_sync, issue_piece, kstep);
+                    }, chunk_sync, issue_piece, hook);
                 pipe.advance();
-                rb_tile<kRbCSteps, kSyncStep16, 1>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
+                if (t > 0) asm volatile("" : "+a"(rH[2 * (t > 0 ? t - 1 : 0)]), "+a"(rH[2 * (t > 0 ? t - 1 : 0) + 1]),
+                                             "+a"(rL[2 * (t > 0 ? t - 1 : 0)]), "+a"(rL[2 * (t > 0 ? t - 1 : 0) + 1]));
+                rb_tile<kRbCSteps, kSyncStep16, 1>(pipe.wcur, pipe.wnxt, lane, A0, A1, ringH, ringL,
                     [&](int g, u32x4& H, u32x4& L) {
 #pragma unroll
                         for (int w = 0; w < 4; ++w) {
                             unsigned h, l; relu_hilo(xH[kRbCSteps + g][w], xL[kRbCSteps + g][w], h, l); H[w] = h; L[w] = l;
                         }
-                    }, chunk_sync, issue_piece, kstep);
+                    }, chunk_sync, issue_piece, hook);
                 pipe.advance();
-                RB_STAMP(400);
-                const f32x16 sum = (acc + accb) * inv_x;
-                f32x16 rv;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(b0_s + 32 * t + 8 * q + 4 * half);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) rv[4 * q + j] = fmaxf(sum[4 * q + j] + b4[j], 0.0f) * sc_r;
-                }
-#pragma unroll
-                for (int r = 0; r < 16; r += 2)
-                    SPLIT2_TO(rv[r], rv[r + 1], rH[2 * t + (r >> 3)][(r & 7) >> 1], rL[2 * t + (r >> 3)][(r & 7) >> 1]);
-                asm volatile("" : "+a"(rH[2 * t]), "+a"(rH[2 * t + 1]), "+a"(rL[2 * t]), "+a"(rL[2 * t + 1]));
-                RB_STAMP(500);
             }
-        }
+            RB_STAMP(400);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r_slice(kRbTilesIn - 1, q, Q0, Q1);   // the last tile (odd) sat in Q
+            asm volatile("" : "+a"(rH[18]), "+a"(rH[19]), "+a"(rL[18]), "+a"(rL[19]));
+            RB_STAMP(500);
 
 #ifdef E3DGE_RB_TRACE
-        tr_on = tr_sub;
+            tr_on = tr_sub;
 #endif
-        RB_STAMP(3000);
-        // ---- 3. out = W_s x + W_1 r + b_1 -> alpha (tiles 0..7), beta (tiles 8..15) ----
-#ifdef E3DGE_RB_UNROLL2
-#pragma unroll
-#else
-#pragma unroll 1
-#endif
-        for (int t = 0; t < kRbTilesOut; ++t) {
-#if defined(E3DGE_RB_TRACE) && E3DGE_RB_TRACE > 1
-            tr_on = tr_sub && t == E3DGE_RB_TRACE_T3;
-#endif
-            f32x16 acc = zero16(), accb = zero16();
-            rb_tile<kRbCSteps, kSyncStep16, 0>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
-                [&](int g, u32x4& H, u32x4& L) { H = xH[g]; L = xL[g]; }, chunk_sync, issue_piece, kstep);
-            pipe.advance();
-            rb_tile<kRbCSteps, kSyncStep16, 1>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
-                [&](int g, u32x4& H, u32x4& L) { H = xH[kRbCSteps + g]; L = xL[kRbCSteps + g]; }, chunk_sync, issue_piece, kstep);
-            pipe.advance();
-            // one accumulator pair for both products: W_s x is rescaled (a power of two, exact) to the scale of W_1 r
-            RB_STAMP(600);
-            acc = (acc + accb) * x_to_r;
-            accb = zero16();
-            rb_tile<kRbCSteps, kSyncStep16, 2>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
-                [&](int g, u32x4& H, u32x4& L) { H = rH[g]; L = rL[g]; }, chunk_sync, issue_piece, kstep);
-            pipe.advance();
-            rb_tile<kRbCSteps, kSyncStep16, 3>(pipe.wcur, pipe.wnxt, lane, acc, accb, ringH, ringL,
-                [&](int g, u32x4& H, u32x4& L) { H = rH[kRbCSteps + g]; L = rL[kRbCSteps + g]; }, chunk_sync, issue_piece, kstep);
-            pipe.advance();
-            RB_STAMP(700);
-            const f32x16 res = (acc + accb) * inv_r;
-            float* __restrict__ dst = (t < 8 ? out_a : out_b) + (out_off + 32u * (t & 7));
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(b1_s + 32 * t + 8 * q + 4 * half);
+            RB_STAMP(3000);
+            // ---- 3. out = W_s x + W_1 r + b_1 -> alpha (tiles 0..7), beta (tiles 8..15) ----
+            // W_s x accumulates in P, W_1 r in Q.  P is folded into `px` in front of k-steps 20..23 (while Q runs); Q is folded,
+            // biased and stored in front of k-steps 1..4 of the NEXT tile (while P runs): no k-step waits for an epilogue.
+            f32x16 px;
+            auto out_slice = [&](int tp, int q) {                           // registers 4q..4q+3 of output tile tp
+                float* __restrict__ dst = (tp < 8 ? out_a : out_b) + (out_off + 32u * (tp & 7));
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(b1_s + 32 * tp + 8 * q + 4 * half);
                 f32x4 o4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o4[j] = res[4 * q + j] + b4[j];
+                for (int j = 0; j < 4; ++j) o4[j] = px[4 * q + j] + (Q0[4 * q + j] + Q1[4 * q + j]) * inv_r + b4[j];
                 if (valid) *reinterpret_cast<f32x4*>(dst + 8 * q) = o4;
+            };
+#pragma unroll 1
+            for (int t = 0; t < kRbTilesOut; ++t) {
+#if defined(E3DGE_RB_TRACE) && E3DGE_RB_TRACE > 1
+                tr_on = tr_sub && t == E3DGE_RB_TRACE_T3;
+#endif
+                auto hook = [&](int g) {
+                    kstep(g);
+                    if (g >= 1 && g <= 4 && t > 0) out_slice(t - 1, g - 1);
+                    if (g >= 20 && g <= 23) {
+                        const int q = g - 20;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) px[4 * q + j] = (P0[4 * q + j] + P1[4 * q + j]) * inv_x;
+                    }
+                };
+                P0 = zero16(); P1 = zero16();
+                rb_tile<kRbCSteps, kSyncStep16, 0>(pipe.wcur, pipe.wnxt, lane, P0, P1, ringH, ringL,
+                    [&](int g, u32x4& H, u32x4& L) { H = xH[g]; L = xL[g]; }, chunk_sync, issue_piece, hook);
+                pipe.advance();
+                rb_tile<kRbCSteps, kSyncStep16, 1>(pipe.wcur, pipe.wnxt, lane, P0, P1, ringH, ringL,
+                    [&](int g, u32x4& H, u32x4& L) { H = xH[kRbCSteps + g]; L = xL[kRbCSteps + g]; }, chunk_sync, issue_piece, hook);
+                pipe.advance();
+                RB_STAMP(600);
+                Q0 = zero16(); Q1 = zero16();
+                rb_tile<kRbCSteps, kSyncStep16, 2>(pipe.wcur, pipe.wnxt, lane, Q0, Q1, ringH, ringL,
+                    [&](int g, u32x4& H, u32x4& L) { H = rH[g]; L = rL[g]; }, chunk_sync, issue_piece, hook);
+                pipe.advance();
+                rb_tile<kRbCSteps, kSyncStep16, 3>(pipe.wcur, pipe.wnxt, lane, Q0, Q1, ringH, ringL,
+                    [&](int g, u32x4& H, u32x4& L) { H = rH[kRbCSteps + g]; L = rL[kRbCSteps + g]; }, chunk_sync, issue_piece, hook);
+                pipe.advance();
+                RB_STAMP(700);
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out_slice(kRbTilesOut - 1, q);
             RB_STAMP(800);
         }
 #ifdef E3DGE_RB_TRACE
