@@ -136,14 +136,25 @@ __global__ void __launch_bounds__(kMcThreads) modconv_kernel(const ModconvK a) {
         ty = t % a.tiles_y; t /= a.tiles_y;
         cb = t % a.co_blocks; b = t / a.co_blocks;
     };
-    auto step_of = [&](int step, int& k, int& c) { k = step / a.n_chunks; c = step - k * a.n_chunks; };
+    // Position of a step: tile k (of this workgroup) and chunk c, with the tile's coordinates.  Three cursors walk the steps
+    // (current, +1 for the weight DMA and the LDS stores, +kMcAhead for the global loads) and are ADVANCED, not recomputed:
+    // step / n_chunks and the three divisions of tile_of for each of them were ~10 scalar divisions per step -- 13 SALU
+    // instructions per MFMA in the counters (profiles/r2_pmc_issue_modconv.txt), all in the issue stream of the same waves.
+    struct Pos { int k, c, b, cb, ty, tx; };
+    auto pos_at = [&](int step) {
+        Pos p;
+        p.k = step / a.n_chunks; p.c = step - p.k * a.n_chunks;
+        tile_of(p.k, p.b, p.cb, p.ty, p.tx);
+        return p;
+    };
+    auto advance = [&](Pos& p) {
+        if (++p.c == a.n_chunks) { p.c = 0; ++p.k; tile_of(p.k, p.b, p.cb, p.ty, p.tx); }
+    };
 
     // ---- staging ----------------------------------------------------------------------------------------------------
     float preg[kMcAhead][NIT][8];
-    auto issue_weights = [&](int step, int buf) {
-        int k, c, b, cb, ty, tx;
-        step_of(step, k, c);
-        tile_of(k, b, cb, ty, tx);
+    auto issue_weights = [&](const Pos& ps, int buf) {
+        const int c = ps.c, cb = ps.cb;
         // NCTB slabs of 18 KiB = 18 LDS-DMA pieces of 1 KiB each; pieces are dealt round-robin to the 8 waves
         const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         for (int piece = wave_u; piece < NCTB * 18; piece += 8) {
@@ -166,11 +177,9 @@ __global__ void __launch_bounds__(kMcThreads) modconv_kernel(const ModconvK a) {
     unsigned ld_off[NIT];                 // element offset of the item within a 16-channel block of the image being loaded
     int st_pix[NIT];                      // patch pixel index of the item, or -1: not an item / outside the image (stores zeros)
     int st_h[NIT];
-    auto load_input = [&](int step, float (&pr)[NIT][8]) {
-        int k, c, b, cb, ty, tx;
-        step_of(step, k, c);
-        tile_of(k, b, cb, ty, tx);
-        if (c == 0 || step == 0) {
+    auto load_input = [&](const Pos& ps, bool first, float (&pr)[NIT][8]) {
+        const int c = ps.c, b = ps.b, ty = ps.ty, tx = ps.tx;
+        if (c == 0 || first) {
             const int oy = ty * TH - 1, ox = tx * TW - 1;                    // patch origin (same for both variants)
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
@@ -190,12 +199,10 @@ __global__ void __launch_bounds__(kMcThreads) modconv_kernel(const ModconvK a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) pr[it][j] = bp[ld_off[it] + (unsigned)(j * HW)];
     };
-    auto store_input = [&](int step, int buf, const float (&pr)[NIT][8]) {
-        int k, c, b, cb, ty, tx;
-        step_of(step, k, c);
-        if (c == 0 || step == 0) {
-            tile_of(k, b, cb, ty, tx);
-            const int oy = ty * TH - 1, ox = tx * TW - 1;
+    auto store_input = [&](const Pos& ps, bool first, int buf, const float (&pr)[NIT][8]) {
+        const int c = ps.c;
+        if (c == 0 || first) {
+            const int oy = ps.ty * TH - 1, ox = ps.tx * TW - 1;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int q = tid + it * kMcThreads;
@@ -235,9 +242,8 @@ __global__ void __launch_bounds__(kMcThreads) modconv_kernel(const ModconvK a) {
     };
 
     // epilogue constants of tile k into e_lds[k & 1] (threads < 32 * NCTB; a barrier separates this from the tile's epilogue)
-    auto load_epilogue_consts = [&](int k) {
-        int b, cb, ty, tx;
-        tile_of(k, b, cb, ty, tx);
+    auto load_epilogue_consts = [&](const Pos& ps) {
+        const int k = ps.k, b = ps.b, cb = ps.cb;
         if (tid < 32 * NCTB) {
             const int co = cb * NCTB * 32 + tid;
             const float oscale = __uint_as_float((scale_exponent(xmax * a.s_amax[b]) - 21u) << 23);
@@ -248,19 +254,18 @@ __global__ void __launch_bounds__(kMcThreads) modconv_kernel(const ModconvK a) {
     };
 
     // ---- prologue: step 0 into buffers 0 (and, two steps ahead, step 1 on its way) ----------------------------------
-    int b_lds;
-    {
-        int k0, c0, cb, ty, tx;
-        step_of(0, k0, c0);
-        tile_of(k0, b_lds, cb, ty, tx);
-        load_style(b_lds);
-        load_epilogue_consts(k0);
-    }
-    issue_weights(0, 0);
-    load_input(0, preg[0]);
-    if (kMcAhead == 2 && nsteps > 1) load_input(1, preg[1]);
+    Pos p_cur = pos_at(0);                               // the step being computed
+    Pos p_nx1 = p_cur; advance(p_nx1);                   // step + 1
+    Pos p_nxa = p_nx1;                                   // step + kMcAhead
+    if (kMcAhead == 2) advance(p_nxa);
+    int b_lds = p_cur.b;
+    load_style(b_lds);
+    load_epilogue_consts(p_cur);
+    issue_weights(p_cur, 0);
+    load_input(p_cur, true, preg[0]);
+    if (kMcAhead == 2 && nsteps > 1) load_input(p_nx1, false, preg[1]);
     __syncthreads();                                   // s_lds visible
-    store_input(0, 0, preg[0]);
+    store_input(p_cur, true, 0, preg[0]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef E3DGE_MC_TIMING
@@ -273,12 +278,11 @@ __global__ void __launch_bounds__(kMcThreads) modconv_kernel(const ModconvK a) {
     // pr_load: registers the prefetch of this step goes to; pr_store: registers holding the patch of step+1
     auto run_step = [&](int step, float (&pr_load)[NIT][8], const float (&pr_store)[NIT][8]) {
         const int cur = step & 1;
-        int k, c;
-        step_of(step, k, c);
+        const int k = p_cur.k, c = p_cur.c;
         const bool has1 = step + 1 < nsteps, hasp = step + kMcAhead < nsteps;
-        if (has1) issue_weights(step + 1, cur ^ 1);
+        if (has1) issue_weights(p_nx1, cur ^ 1);
         auto do_issue = [&]() {
-            if (hasp) load_input(step + kMcAhead, pr_load);
+            if (hasp) load_input(p_nxa, false, pr_load);
             MC_T(0);
         };
         auto do_compute = [&]() {
@@ -328,8 +332,7 @@ __global__ void __launch_bounds__(kMcThreads) modconv_kernel(const ModconvK a) {
             MC_T(1);
             // ---- epilogue of a finished tile ----
             if (c == a.n_chunks - 1) {
-                int b, cb, ty, tx;
-                tile_of(k, b, cb, ty, tx);
+                const int b = p_cur.b, cb = p_cur.cb, ty = p_cur.ty, tx = p_cur.tx;
                 const float nw = (a.noise && a.noise_w) ? a.noise_w[0] : 0.0f;
                 const float* __restrict__ ec = e_lds + (k & 1) * (2 * 32 * NCTB);
 #pragma unroll
@@ -366,17 +369,15 @@ __global__ void __launch_bounds__(kMcThreads) modconv_kernel(const ModconvK a) {
         };
         auto do_convert = [&]() {
         if (has1) {
-                int k1, c1, b1, cb, ty, tx;
-                step_of(step + 1, k1, c1);
-                tile_of(k1, b1, cb, ty, tx);
+                const int c1 = p_nx1.c, b1 = p_nx1.b;
                 if (b1 != b_lds) {                          // next tile belongs to another sample (rare): its style into LDS
                     __syncthreads();                        // nobody still reads the old s_lds (all readers are behind us)
                     load_style(b1);
                     b_lds = b1;
                     __syncthreads();
                 }
-                store_input(step + 1, cur ^ 1, pr_store);
-                if (c1 == 0) load_epilogue_consts(k1);      // first step of the next tile follows: its epilogue constants
+                store_input(p_nx1, false, cur ^ 1, pr_store);
+                if (c1 == 0) load_epilogue_consts(p_nx1);      // first step of the next tile follows: its epilogue constants
             }
             MC_T(3);
         };
@@ -399,6 +400,9 @@ __global__ void __launch_bounds__(kMcThreads) modconv_kernel(const ModconvK a) {
         MC_T(4);
         __syncthreads();
         MC_T(5);
+        p_cur = p_nx1;
+        advance(p_nx1);
+        if (kMcAhead == 2) advance(p_nxa); else p_nxa = p_nx1;
     };
     if (kMcAhead == 2) {
         for (int step = 0; step < nsteps; step += 2) {
