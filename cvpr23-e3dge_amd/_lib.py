@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E3DGE_LIB_PATH") or os.path.join(_HERE, "lib", "libe3dge_hip.so")   # override: kernel A/B variants
-ABI_VERSION = 7
+ABI_VERSION = 8
 PREC_F32, PREC_F16X3, PREC_F16X3_V1, PREC_F16X3_G2 = 0, 1, 2, 3
 AMAX_FLOATS = 64 * 32           # E3DGE_AMAX_FLOATS: one amax buffer (include/e3dge_hip.h)
 
@@ -94,6 +94,7 @@ SIGNATURES = {
     "e3dge_pos_encoding": (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _vp]),
     "e3dge_image_metrics_scratch_floats": (_i64, [_i32, _i32, _i32, _i32]),
     "e3dge_image_metrics": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "e3dge_image_metric_row": (_i32, [_vp, _vp, _i32, _f32, _vp]),
     "e3dge_align_volume": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "e3dge_selftest_mfma": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "e3dge_selftest_mfma16": (_i32, [_vp, _vp, _vp, _i32, _vp]),

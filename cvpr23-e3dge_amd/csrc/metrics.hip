@@ -110,9 +110,28 @@ image_metrics_fold_kernel(float* __restrict__ out, const float* __restrict__ par
     if (threadIdx.x == 3) out[b * 4 + 3] = count;
 }
 
+// the eight reported columns from the per-image sums (builder.py:174-184): means over the whole batch tensor, PSNR on images
+// rescaled to [0, 1] (squared error / 4); the identity / LPIPS columns are the reference's values at lambda = 0
+__global__ void image_metric_row_kernel(float* __restrict__ row, const float* __restrict__ sums, int batch, float l2_lambda) {
+    if (threadIdx.x != 0) return;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, n = 0.f;
+    for (int b = 0; b < batch; ++b) { t0 += sums[b * 4]; t1 += sums[b * 4 + 1]; t2 += sums[b * 4 + 2]; n += sums[b * 4 + 3]; }
+    const float mse = t0 / n, mae = t1 / n, ssim_loss = t2 / n;
+    row[0] = mse; row[1] = 0.0f; row[2] = 0.0f; row[3] = mse * l2_lambda; row[4] = mae;
+    row[5] = 10.0f * log10f(1.0f / (mse * 0.25f));
+    row[6] = 1.0f - ssim_loss; row[7] = 1.0f;
+}
+
 }  // namespace e3dge
 
 using namespace e3dge;
+
+extern "C" int e3dge_image_metric_row(float* row, const float* sums, int batch, float l2_lambda, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(batch >= 1, "image_metric_row: batch=%d", batch);
+    E3DGE_REQUIRE(row && sums, "image_metric_row: null pointer");
+    image_metric_row_kernel<<<dim3(1), dim3(64), 0, as_stream(stream)>>>(row, sums, batch, l2_lambda);
+    return check_launch("image_metric_row");
+}
 
 extern "C" int64_t e3dge_image_metrics_scratch_floats(int batch, int channels, int height, int width) {
     if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0) return 0;

@@ -388,6 +388,11 @@ int e3dge_pos_encoding(float* out, int ld, int col_off, const float* pts, int64_
 int64_t e3dge_image_metrics_scratch_floats(int batch, int channels, int height, int width);
 int e3dge_image_metrics(float* sums, float* scratch, const float* pred, const float* gt, int batch, int channels,
                         int height, int width, float max_val, e3dge_stream_t stream);
+/* The eight columns builder.py:174-184 reports, from those sums (means over the whole batch tensor, as the reference's
+ * losses are): row (8) = [loss_l2 = MSE, loss_id = 0, loss_lpips = 0, loss = l2_lambda * MSE, mae, PSNR of the images
+ * rescaled to [0,1], SSIM = 1 - ssim_loss, ID_SIM = 1] -- the identity / LPIPS networks are outside the path and their
+ * columns are what the reference reports with those lambdas at 0 (:145, :158-163). */
+int e3dge_image_metric_row(float* row, const float* sums, int batch, float l2_lambda, e3dge_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Surface extraction, device half: replaces align_volume (project/utils/mesh_utils.py:17-44; called on the rendered
