@@ -27,3 +27,6 @@ def test_image_metrics_kernel_vs_torch(shape):
     same = se.image_metrics(gt, gt.clone())
     assert float(same[0]) == 0.0 and abs(float(same[6]) - 1) < 1e-6
     assert torch.equal(se.image_metrics(pred, gt), a)               # fixed-order fold: bit-reproducible
+    half = se.image_metrics(pred, gt, l2_lambda=0.5)                # the row kernel (e3dge_image_metric_row) applies the weight
+    assert float(half[3]) == 0.5 * float(a[0]) and torch.equal(half[[0, 4, 5, 6]], a[[0, 4, 5, 6]])
+    assert float(a[1]) == 0.0 and float(a[2]) == 0.0 and float(a[7]) == 1.0
