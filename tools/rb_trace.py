@@ -1,6 +1,9 @@
-"""Timeline of the texture-head kernel for one wave (workgroup 7, wave 0, second sub-tile): s_memtime stamps at the phase
-boundaries and, inside one tile of each GEMM phase, at every k-step and around every chunk wait.
-Needs a -DE3DGE_RB_TRACE build (tools/build_variant.sh rbtrace -DE3DGE_RB_TRACE [-DE3DGE_RB_TRACE_T2=1 -DE3DGE_RB_TRACE_T3=5])."""
+"""Timeline of the texture-head kernel for one wave (workgroup 7, wave 0, second sub-tile).
+  -DE3DGE_RB_TRACE=1: s_memtime at the four phase boundaries, held in SGPRs -- leaves the k-loops' register allocation alone;
+                      use this one for numbers (profiles/r2_rb_trace_phases.txt).
+  -DE3DGE_RB_TRACE=2: additionally every k-step and chunk wait of one tile per GEMM phase (-DE3DGE_RB_TRACE_T2=1
+                      -DE3DGE_RB_TRACE_T3=5).  The stamp code spills inside the loops: structure only.
+tools/build_variant.sh rbtrace -DE3DGE_RB_TRACE=1 ; E3DGE_LIB_PATH=cvpr23-e3dge_amd/lib/variants/lib_rbtrace.so python tools/rb_trace.py"""
 import ctypes
 import os
 import sys
