@@ -10,9 +10,10 @@
 // (the inputs are unbounded), weights streamed L2 -> LDS in 20-KiB chunks (32 output rows x 160 k: K = 320, Cin padded, is
 // two equal chunks of ten k-steps) through a ring of kRbNBuf LDS buffers (RbPipe below).  With one wave per SIMD nothing
 // else covers a chunk that has not landed, so a chunk's DMA is issued kRbNBuf - 1 chunks before it is read and the chunk
-// barrier waits with a COUNTED vmcnt that leaves the younger chunks in flight.  x and r = relu(net) are kept as packed (hi, lo) words (160 registers each); relu(x) is formed from x's words
-// on the fly per k-step (integer sign masks).  Neither the (P, 301) hidden activations nor r ever touch memory; the output
-// goes straight to (alpha, beta).
+// barrier waits with a COUNTED vmcnt that leaves the younger chunks in flight.  x and r = relu(net) are kept as packed
+// (hi, lo) words (160 registers each); relu(x) is formed from x's words on the fly per k-step (packed integer ops).  Neither
+// the (P, 301) hidden activations nor r ever touch memory; the output goes straight to (alpha, beta).  DESIGN.md 4.7 has the
+// measurements behind every choice here (tools/rb_trace.py, profiles/r2_pmc_issue_texhead.txt).
 #include "siren_common.h"
 
 namespace e3dge {
