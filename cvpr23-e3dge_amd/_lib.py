@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E3DGE_LIB_PATH") or os.path.join(_HERE, "lib", "libe3dge_hip.so")   # override: kernel A/B variants
-ABI_VERSION = 8
+ABI_VERSION = 9
 PREC_F32, PREC_F16X3, PREC_F16X3_V1, PREC_F16X3_G2 = 0, 1, 2, 3
 AMAX_FLOATS = 64 * 32           # E3DGE_AMAX_FLOATS: one amax buffer (include/e3dge_hip.h)
 
@@ -60,6 +60,32 @@ class ModLayer(ctypes.Structure):
         (n, _i32) for n in ("ci", "co", "latent_index", "row_start", "co_start")] + [("lin_scale", _f32), ("lr_mul", _f32)]
 
 
+DEC2_MAX_UP = 6                 # E3DGE_DEC2_MAX_UP
+
+
+class Dec2Conv(ctypes.Structure):
+    """Mirror of struct E3dgeDec2Conv (include/e3dge_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("wpre", "style", "demod", "wimg", "noise", "noise_w", "noise_amax", "bias")] + [
+        ("bias_amax", _f32), ("ci", _i32), ("co", _i32), ("noise_batch", _i32)]
+
+
+class Dec2Rgb(ctypes.Structure):
+    """Mirror of struct E3dgeDec2Rgb (include/e3dge_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("weight", "style", "bias", "wm", "out")] + [("scale", _f32), ("ci", _i32)]
+
+
+class Dec2Plan(ctypes.Structure):
+    """Mirror of struct E3dgeDec2Plan (include/e3dge_hip.h)."""
+    _fields_ = [("batch", _i32), ("n_up", _i32), ("in_res", _i32), ("in_ch", _i32),
+                ("features", _vp), ("skip_in", _vp), ("mod_table", _vp), ("latent", _vp),
+                ("n_mod", _i32), ("mod_rows", _i32), ("mod_co", _i32), ("n_latent", _i32), ("style_dim", _i32), ("reserved0", _i32),
+                ("conv1", Dec2Conv), ("rgb1", Dec2Rgb),
+                ("up", Dec2Conv * DEC2_MAX_UP), ("conv", Dec2Conv * DEC2_MAX_UP), ("rgb", Dec2Rgb * DEC2_MAX_UP),
+                ("act", _vp * (2 * DEC2_MAX_UP + 2)), ("tbuf", _vp * DEC2_MAX_UP), ("amax", _vp), ("meta", _vp),
+                ("fir_blur", _vp), ("fir_up", _vp), ("negative_slope", _f32), ("act_scale", _f32),
+                ("kernel_ms", ctypes.POINTER(ctypes.c_float)), ("n_kernel_ms", _i32), ("reserved1", _i32)]
+
+
 # name -> (restype, argtypes); every symbol include/e3dge_hip.h declares.
 SIGNATURES = {
     "e3dge_abi_version": (_i32, []),
@@ -77,6 +103,13 @@ SIGNATURES = {
     "e3dge_modconv_demod": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "e3dge_amax": (_i32, [_vp, _vp, _i64, _vp]),
     "e3dge_modconv3x3": (_i32, [ctypes.POINTER(ModconvArgs), _vp]),
+    "e3dge_dec2_act_words": (_i64, [_i32, _i32, _i32]),
+    "e3dge_dec2_tbuf_floats": (_i64, [_i32, _i32, _i32]),
+    "e3dge_dec2_prepack_weights": (_i32, [_vp, _vp, _f32, _i32, _i32, _vp]),
+    "e3dge_dec2_num_launches": (_i32, [_i32]),
+    "e3dge_dec2_forward": (_i32, [ctypes.POINTER(Dec2Plan), _vp]),
+    "e3dge_dec2_pack": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "e3dge_dec2_unpack": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "e3dge_siren_packed_floats": (_i64, []),
     "e3dge_siren_pack_weights": (_i32, [_vp] * 11 + [_vp]),
     "e3dge_film_params": (_i32, [_vp] * 6 + [_i32, _vp]),

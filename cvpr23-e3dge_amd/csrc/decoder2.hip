@@ -1,0 +1,994 @@
+// Packed decoder pipeline ("dec2"): the StyleGAN2 up-sampler of Decoder.forward (project/models/stylesdf_model.py:741-797)
+// with every activation kept in the layout the f16 matrix pipe consumes (include/e3dge_hip.h, "Packed decoder pipeline").
+//
+// Why (round-3 measurements of modconv.hip): with fp32 planes between the kernels every convolution step
+// had to load its input patch into registers, multiply by the style, split it into f16 hi/lo and write it to LDS -- and
+// every co-block repeated that for the same patch.  The MFMA phase was 25-33 % of a step.  Here the PRODUCER of an
+// activation does the split once, in its epilogue, and stores 16-byte entries of eight channels per pixel (hi plane, lo
+// plane, one-entry zero border); a convolution stages both operands by LDS-DMA (global_load_lds_dwordx4) and its waves
+// issue nothing but DMA pieces, ds_read_b128 and MFMAs until a tile's epilogue.  The modulation moves to the weights:
+// w'' = ((scale W) s) demod per sample, rounded as the reference rounds it (:319-326), rebuilt by one streaming launch
+// per forward.  The operand scale of a packed tensor comes from an a-priori bound (demodulated filters have unit norm,
+// the FIR taps of a phase sum to one), so a producer can scale before it has seen its own maximum.
+#include "decoder_common.h"
+#include <stdlib.h>
+#include <math.h>
+
+namespace e3dge {
+
+constexpr int kPkSlab = 9 * 2 * 1024;            // bytes of one weight slab: (32 co) x (16 ci) x 9 taps x (hi, lo)
+
+__device__ __forceinline__ uint32_t lds_u32(const void* p) {
+    return (uint32_t)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {       // make wave-uniformity explicit for an SGPR operand
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    return reinterpret_cast<const void*>(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+}
+// q / d for 0 <= q < 2^24, d > 0 (float reciprocal + fix-up)
+__device__ __forceinline__ int div_small(int q, int d, float rcp) {
+    int i = (int)((float)q * rcp);
+    if (i * d > q) --i;
+    if ((i + 1) * d <= q) ++i;
+    return i;
+}
+__device__ __forceinline__ float pow2_bits(unsigned biased) { return __uint_as_float(biased << 23); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 (B, C, R, R) <-> packed
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+pk_pack_kernel(uint32_t* __restrict__ out, int* __restrict__ meta, const float* __restrict__ x, const float* __restrict__ amax,
+               int C, int R) {
+    const int lane = threadIdx.x & 63;
+    const unsigned eb = scale_exponent(amax_read(amax, lane));
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) meta[0] = (int)eb;
+    const float sc = pow2_bits(268u - eb);
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= R * R) return;
+    const int y = p / R, xx = p - y * R, g = blockIdx.y, b = blockIdx.z, G = C >> 3;
+    const int64_t HW = (int64_t)R * R;
+    const float* __restrict__ src = x + ((int64_t)b * C + 8 * g) * HW + p;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[j * HW] * sc;
+    u32x4 hi, lo;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) SPLIT2_TO(v[2 * w], v[2 * w + 1], hi[w], lo[w]);
+    const int64_t plane = (int64_t)(R + 2) * (R + 2);
+    const int64_t e = ((int64_t)(b * G + g) * 2) * plane + (int64_t)(y + 1) * (R + 2) + xx + 1;
+    reinterpret_cast<u32x4*>(out)[e] = hi;
+    reinterpret_cast<u32x4*>(out)[e + plane] = lo;
+}
+
+__global__ void __launch_bounds__(256)
+pk_unpack_kernel(float* __restrict__ x, const uint32_t* __restrict__ in, const int* __restrict__ meta, int C, int R) {
+    const float inv = pow2_bits((unsigned)meta[0] - 14u);                 // 2^(eb - 141)
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= R * R) return;
+    const int y = p / R, xx = p - y * R, g = blockIdx.y, b = blockIdx.z, G = C >> 3;
+    const int64_t HW = (int64_t)R * R, plane = (int64_t)(R + 2) * (R + 2);
+    const int64_t e = ((int64_t)(b * G + g) * 2) * plane + (int64_t)(y + 1) * (R + 2) + xx + 1;
+    const u32x4 hi = reinterpret_cast<const u32x4*>(in)[e], lo = reinterpret_cast<const u32x4*>(in)[e + plane];
+    float* __restrict__ dst = x + ((int64_t)b * C + 8 * g) * HW + p;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        dst[(2 * w) * HW] = (f16lo(hi[w]) + f16lo(lo[w])) * inv;
+        dst[(2 * w + 1) * HW] = (f16hi(hi[w]) + f16hi(lo[w])) * inv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weights: wpre (once per weight update) and the per-sample images + ToRGB tables (once per forward)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+pk_prepack_kernel(float* __restrict__ wpre, const float* __restrict__ w, float scale, int Co, int Ci, int n_chunks, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        int64_t r = e;
+        const int j = r & 7; r >>= 3;
+        const int l = r & 63; r >>= 6;
+        const int tap = (int)(r % 9); r /= 9;
+        const int c = (int)(r % n_chunks);
+        const int t = (int)(r / n_chunks);
+        const int co = 32 * t + (l & 31), ci = 16 * c + 8 * (l >> 5) + j;
+        wpre[e] = (co < Co && ci < Ci) ? __fmul_rn(scale, w[((int64_t)co * Ci + ci) * 9 + tap]) : 0.0f;
+    }
+}
+
+struct PkWConv { const float* wpre; const float* style; const float* demod; uint32_t* img; int co, ci, n_chunks; int n_items; int64_t words; };
+struct PkWRgb { const float* w; const float* style; float* wm; float scale; int ci; };
+struct PkWTab { PkWConv conv[2 * E3DGE_DEC2_MAX_UP + 1]; PkWRgb rgb[E3DGE_DEC2_MAX_UP + 1]; int n_conv, n_rgb; };
+
+__global__ void __launch_bounds__(256) pk_weights_kernel(const PkWTab tab) {
+    const int layer = blockIdx.y, b = blockIdx.z;
+    if (layer < tab.n_conv) {
+        const PkWConv L = tab.conv[layer];
+        const float* __restrict__ st = L.style + (size_t)b * L.ci;
+        const float* __restrict__ dm = L.demod + (size_t)b * L.co;
+        u32x4* __restrict__ img = reinterpret_cast<u32x4*>(L.img + (size_t)b * L.words);
+        for (int item = blockIdx.x * 256 + threadIdx.x; item < L.n_items; item += gridDim.x * 256) {
+            const int l = item & 63;
+            int r = item >> 6;
+            const int tap = r % 9; r /= 9;
+            const int c = r % L.n_chunks;
+            const int t = r / L.n_chunks;
+            const int co = 32 * t + (l & 31), ci0 = 16 * c + 8 * (l >> 5);
+            const f32x4 w0 = reinterpret_cast<const f32x4*>(L.wpre)[(size_t)item * 2], w1 = reinterpret_cast<const f32x4*>(L.wpre)[(size_t)item * 2 + 1];
+            const float d = co < L.co ? dm[co] : 0.0f;
+            u32x4 hi, lo;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                unsigned hw = 0, lw = 0;
+#pragma unroll
+                for (int e2 = 0; e2 < 2; ++e2) {
+                    const int j = 2 * w + e2;
+                    const float wv = j < 4 ? w0[j] : w1[j - 4];
+                    const float s = (ci0 + j) < L.ci ? st[ci0 + j] : 0.0f;
+                    const float v = kW16Scale * __fmul_rn(__fmul_rn(wv, s), d);        // ((scale W) s) demod, then the exact x128
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 lv = (_Float16)(v - (float)h);
+                    hw |= (unsigned)__builtin_bit_cast(unsigned short, h) << (16 * e2);
+                    lw |= (unsigned)__builtin_bit_cast(unsigned short, lv) << (16 * e2);
+                }
+                hi[w] = hw; lo[w] = lw;
+            }
+            const size_t frag = ((size_t)(t * L.n_chunks + c) * 9 + tap) * 2;           // [co_tile][chunk][tap][hi|lo][lane]
+            img[frag * 64 + l] = hi;
+            img[(frag + 1) * 64 + l] = lo;
+        }
+    } else if (layer - tab.n_conv < tab.n_rgb) {
+        const PkWRgb L = tab.rgb[layer - tab.n_conv];
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * L.ci; i += gridDim.x * 256) {
+            const int ci = i % L.ci;
+            L.wm[(size_t)b * 3 * L.ci + i] = __fmul_rn(__fmul_rn(L.scale, L.w[i]), L.style[(size_t)b * L.ci + ci]);   // (scale W) s, :321
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// convolutions
+// ---------------------------------------------------------------------------------------------------------------------
+struct PkConvK {
+    const unsigned char* x;        // packed input (B, Ci/8, 2, H+2, W+2) x 16 B
+    const unsigned char* wimg;     // per-sample weight images
+    int64_t wimg_bytes;            // bytes per sample
+    const int* in_meta;            // eb of the input
+    const float* in_amax;          // measured max |input| (amax buffer)
+    const float* noise; const float* noise_w; const float* noise_amax; const float* bias;
+    unsigned char* y;              // stride-1: packed output (B, Co/8, 2, H+2, W+2)
+    float* t;                      // up-sampling: fp32 (B, Co, 2H+3, 2W+4), T(y, x) at [y + 1][x + 2]
+    int* out_meta;
+    float* out_amax;
+    float bias_amax, knorm, slope, act_scale;
+    int B, Ci, Co, H, W;
+    int n_chunks, noise_batch;
+    int tiles_x, tiles_y, co_blocks, n_tiles;
+    // up-sampling: positions (i, j) in [0, H] x [0, W] are processed per column block [j0, j0 + cwb), flattened q = i cwb + (j - j0)
+    int cw, cwl, nblk, tpf, tpl;   // block width (all but the last / the last), blocks, WG tiles per full / last block
+};
+
+// one LDS-DMA piece (64 lanes x 16 B -> 1 KiB of LDS at lds_dst), global address = wave-uniform base + per-lane byte offset
+__device__ __forceinline__ void dma_piece(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    glds16_saddr<0>(uniform_ptr(sbase), voff, (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_dst));
+}
+
+// XCD-aware tile order (MI355X_MICROARCH: block b runs on XCD b % 8, each XCD has its own L2): workgroup-tile t -> logical
+// tile id such that every XCD walks one CONTIGUOUS range of logical ids; logical ids put the co-blocks of one pixel tile
+// next to each other (they read the same input patch) and neighbouring pixel tiles after that (they share halos).
+__device__ __forceinline__ int xcd_logical(int t, int n_tiles) {
+    const int nq = n_tiles >> 3, nr = n_tiles & 7, xcd = t & 7, slot = t >> 3;
+    return (xcd < nr ? xcd * (nq + 1) : nr * (nq + 1) + (xcd - nr) * nq) + slot;
+}
+
+// ---- stride-1 3x3, pad 1 ---------------------------------------------------------------------------------------------
+// Workgroup tile: (32 NCT WCO) output channels x (NPY WY) rows x (32 NPX WX) columns; a wave owns NCT co-tiles x NPY x NPX
+// pixel tiles of 32 columns.  Steps = (tile, 16-channel chunk) of a persistent workgroup; two LDS stages; per step ONE barrier:
+//     wait for my DMA pieces of this step | barrier | issue the DMA of step + 1 | 9 taps of MFMAs from this stage | [epilogue]
+// The patch (+halo) of a step is four planes [k-half][hi|lo] of NPIX 16-byte entries, fetched as 1-KiB pieces whose lanes walk
+// the patch row-major (the source address is per lane, the LDS side is linear); weight slabs are 18 pieces each.
+template <int NCT, int NPY, int NPX, int WCO, int WY, int WX>
+__global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkConvK a) {
+    constexpr int NW = WCO * WY * WX;
+    constexpr int TH = NPY * WY, TW = 32 * NPX * WX, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, NPP = (NPIX + 63) / 64;
+    constexpr int NCTB = NCT * WCO, XPLANE = NPIX * 16, XST = 4 * XPLANE, WST = NCTB * kPkSlab, STAGE = XST + WST;
+    constexpr int NWP = NCTB * 18, NPIECE = NWP + 4 * NPP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pk[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wx = wave % WX, wy = (wave / WX) % WY, wco = wave / (WX * WY);
+    const int my_tiles = (a.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nsteps = my_tiles * a.n_chunks;
+    if (nsteps <= 0) return;
+    const int HP = a.H + 2, WP = a.W + 2, G = a.Ci >> 3, GO = a.Co >> 3;
+    const int64_t plane_b = (int64_t)HP * WP * 16;                  // bytes of one (g, hl) plane (input and output alike)
+
+    // operand scales: the input's eb from its producer; the output's from the a-priori bound (header comment)
+    const unsigned eb_in = (unsigned)a.in_meta[0];
+    const float oscale = pow2_bits(eb_in - 21u);                     // 1 / (128 * 2^(141 - eb_in))
+    const float nw = a.noise ? a.noise_w[0] : 0.0f;
+    const float nza = a.noise ? fabsf(nw) * amax_read(a.noise_amax, lane) : 0.0f;
+    const float bound = a.act_scale * (amax_read(a.in_amax, lane) * a.knorm * 1.002f + nza + a.bias_amax) * 1.001f;
+    const unsigned eb_out = scale_exponent(bound);
+    const float sc_out = pow2_bits(268u - eb_out);
+    if (blockIdx.x == 0 && tid == 0) a.out_meta[0] = (int)eb_out;
+
+    struct Pos { int k, c, b, cb, ty, tx; };
+    auto tile_of = [&](Pos& p) {
+        if (p.k >= my_tiles) return;
+        int L = xcd_logical((int)blockIdx.x + p.k * (int)gridDim.x, a.n_tiles);
+        p.cb = L % a.co_blocks; L /= a.co_blocks;
+        p.tx = L % a.tiles_x; L /= a.tiles_x;
+        p.ty = L % a.tiles_y; p.b = L / a.tiles_y;
+    };
+    auto advance = [&](Pos& p) { if (++p.c == a.n_chunks) { p.c = 0; ++p.k; tile_of(p); } };
+
+    auto issue = [&](const Pos& ps, int stage) {
+        const uint32_t xl = lds_u32(smem_pk + stage * STAGE), wl = xl + XST;
+        const unsigned char* wsrc = a.wimg + (int64_t)ps.b * a.wimg_bytes + ((int64_t)(ps.cb * NCTB) * a.n_chunks + ps.c) * kPkSlab;
+        const unsigned char* xsrc = a.x + ((int64_t)(ps.b * G + 2 * ps.c) * 2) * plane_b;
+        const int gy0 = ps.ty * TH, gx0 = ps.tx * TW;
+        for (int i = wave; i < NPIECE; i += NW) {
+            if (i < NWP) {
+                const int ct = i / 18, pc = i - ct * 18;
+                dma_piece(wsrc + (int64_t)ct * a.n_chunks * kPkSlab + pc * 1024, (uint32_t)lane * 16u, wl + ct * kPkSlab + pc * 1024);
+            } else {
+                const int p = i - NWP, pl = p / NPP, pp = p - pl * NPP;
+                const int e = pp * 64 + lane;
+                if (e < NPIX) {
+                    const int prow = e / PW, pcol = e - prow * PW;
+                    // clamped into the padded image: tiles that overhang a small image read (and compute) garbage that is never stored
+                    const int gy = min(gy0 + prow, HP - 1), gx = min(gx0 + pcol, WP - 1);
+                    dma_piece(xsrc + pl * plane_b, (uint32_t)(gy * WP + gx) * 16u, xl + pl * XPLANE + pp * 1024);
+                }
+            }
+        }
+    };
+
+    Pos p_cur{0, 0, 0, 0, 0, 0};
+    tile_of(p_cur);
+    Pos p_nx1 = p_cur; advance(p_nx1);
+    issue(p_cur, 0);
+
+    f32x16 acc[NCT][NPY * NPX];
+    float amax_l = 0.0f;
+    const int prow0 = wy * NPY, pcol0 = wx * NPX * 32 + col;
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        // my pieces of this step have landed; after the barrier everybody's have, and nobody still reads the other stage
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (step + 1 < nsteps) issue(p_nx1, cur ^ 1);
+        if (p_cur.c == 0) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < NPY * NPX; ++pt) acc[ct][pt] = zero16();
+        }
+        {
+            const unsigned char* xb = smem_pk + cur * STAGE + (size_t)(half * 2) * XPLANE;
+            const unsigned char* wb = smem_pk + cur * STAGE + XST + (size_t)(wco * NCT) * kPkSlab + lane * 16;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                u32x4 ah[NCT], al[NCT], bh[NPY * NPX], bl[NPY * NPX];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    ah[ct] = *reinterpret_cast<const u32x4*>(wb + ct * kPkSlab + (tap * 2 + 0) * 1024);
+                    al[ct] = *reinterpret_cast<const u32x4*>(wb + ct * kPkSlab + (tap * 2 + 1) * 1024);
+                }
+#pragma unroll
+                for (int py = 0; py < NPY; ++py)
+#pragma unroll
+                    for (int px = 0; px < NPX; ++px) {
+                        const int pix = (prow0 + py + ky) * PW + pcol0 + 32 * px + kx;
+                        bh[py * NPX + px] = *reinterpret_cast<const u32x4*>(xb + pix * 16);
+                        bl[py * NPX + px] = *reinterpret_cast<const u32x4*>(xb + XPLANE + pix * 16);
+                    }
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < NPY * NPX; ++pt) {
+                        f32x16& d = acc[ct][pt];
+                        d = mfma16(ah[ct], bh[pt], d);
+                        d = mfma16(al[ct], bh[pt], d);
+                        d = mfma16(ah[ct], bl[pt], d);
+                    }
+                if (tap % 3 == 2) __builtin_amdgcn_sched_barrier(0);      // keep the fragment reads of later taps from piling up
+            }
+        }
+        if (p_cur.c == a.n_chunks - 1) {                    // ---- epilogue: noise + bias + lrelu, then split for the next conv ----
+            const int b = p_cur.b;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int cot = p_cur.cb * NCTB + wco * NCT + ct;
+#pragma unroll
+                for (int py = 0; py < NPY; ++py)
+#pragma unroll
+                    for (int px = 0; px < NPX; ++px) {
+                        const int oy = p_cur.ty * TH + prow0 + py, ox = p_cur.tx * TW + pcol0 + 32 * px;
+                        const bool ok = oy < a.H && ox < a.W;
+                        const float nz = (ok && a.noise) ? __fmul_rn(nw, a.noise[(int64_t)(a.noise_batch > 1 ? b : 0) * a.H * a.W + (int64_t)oy * a.W + ox]) : 0.0f;
+                        const f32x16& d = acc[ct][py * NPX + px];
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int co0 = cot * 32 + 8 * g4 + 4 * half;
+                            float v[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float t = __fadd_rn(__fadd_rn(d[4 * g4 + j] * oscale, nz), a.bias[co0 + j]);
+                                t = (t > 0.0f ? t : t * a.slope) * a.act_scale;
+                                if (ok) amax_l = fmaxf(amax_l, fabsf(t));
+                                v[j] = t * sc_out;
+                            }
+                            unsigned h0, l0, h1, l1;
+                            SPLIT2_TO(v[0], v[1], h0, l0);
+                            SPLIT2_TO(v[2], v[3], h1, l1);
+                            if (ok) {
+                                unsigned char* dst = a.y + ((int64_t)(b * GO + cot * 4 + g4) * 2) * plane_b + ((int64_t)(oy + 1) * WP + ox + 1) * 16 + half * 8;
+                                *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+                                *reinterpret_cast<uint2*>(dst + plane_b) = make_uint2(l0, l1);
+                            }
+                        }
+                    }
+            }
+        }
+        p_cur = p_nx1;
+        advance(p_nx1);
+    }
+    if (a.out_amax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax_l = fmaxf(amax_l, __shfl_xor(amax_l, off, kWave));
+        if (lane == 0) atomic_max_nonneg(a.out_amax + (((int)blockIdx.x * NW + wave) & (kAmaxSlots - 1)) * kAmaxStride, amax_l);
+    }
+}
+
+// ---- stride-2 transposed 3x3 (conv_transpose2d, padding 0) by output phase ---------------------------------------------
+// Position (i, j) in [0, H] x [0, W] produces out(2i + ey, 2j + ex); tap (ky, kx) feeds phase (ky & 1, kx & 1) from
+// x[i - (ky == 2)][j - (kx == 2)]: 4 + 2 + 2 + 1 taps, four distinct input shifts.  Positions are FLATTENED inside column
+// blocks of <= 129 columns (q = i cwb + jj), a workgroup tile is Q consecutive q: no tile is wasted on the +1 position per
+// row/column (the planar kernel spent 1.55x / 1.27x the useful MFMA work at 64^2 / 128^2).  The patch is the rows
+// [i_lo, i_hi + 1] x columns [j0, j0 + cwb] of the padded input.
+template <int NCT, int NPT, int WCO, int WQ, int NPIXMAX>
+__global__ void __launch_bounds__(64 * WCO * WQ) pkconv_up_kernel(const PkConvK a) {
+    constexpr int NW = WCO * WQ, Q = 32 * NPT * WQ;
+    constexpr int NCTB = NCT * WCO, XPLANE = NPIXMAX * 16, XST = 4 * XPLANE, WST = NCTB * kPkSlab, STAGE = XST + WST;
+    constexpr int NWP = NCTB * 18;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pk[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave % WQ, wco = wave / WQ;
+    const int my_tiles = (a.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nsteps = my_tiles * a.n_chunks;
+    if (nsteps <= 0) return;
+    const int HP = a.H + 2, WP = a.W + 2, G = a.Ci >> 3;
+    const int64_t plane_b = (int64_t)HP * WP * 16;
+    const int TR = 2 * a.H + 3, TP = 2 * a.W + 4;
+    const float oscale = pow2_bits((unsigned)a.in_meta[0] - 21u);
+    const int tiles_per_img = (a.nblk - 1) * a.tpf + a.tpl;
+
+    struct Pos { int k, c, b, cb, j0, cwb, q0, i_lo, npix; };
+    auto tile_of = [&](Pos& p) {
+        if (p.k >= my_tiles) return;
+        int L = xcd_logical((int)blockIdx.x + p.k * (int)gridDim.x, a.n_tiles);
+        p.cb = L % a.co_blocks; L /= a.co_blocks;
+        const int idx = L % tiles_per_img; p.b = L / tiles_per_img;
+        int blk, qt;
+        if (idx < (a.nblk - 1) * a.tpf) { blk = idx / a.tpf; qt = idx - blk * a.tpf; p.cwb = a.cw; }
+        else { blk = a.nblk - 1; qt = idx - blk * a.tpf; p.cwb = a.cwl; }
+        p.j0 = blk * a.cw;
+        p.q0 = qt * Q;
+        const int qlast = min(p.q0 + Q, (a.H + 1) * p.cwb) - 1;
+        p.i_lo = p.q0 / p.cwb;
+        p.npix = (qlast / p.cwb - p.i_lo + 2) * (p.cwb + 1);
+    };
+    auto advance = [&](Pos& p) { if (++p.c == a.n_chunks) { p.c = 0; ++p.k; tile_of(p); } };
+
+    auto issue = [&](const Pos& ps, int stage) {
+        const uint32_t xl = lds_u32(smem_pk + stage * STAGE), wl = xl + XST;
+        const unsigned char* wsrc = a.wimg + (int64_t)ps.b * a.wimg_bytes + ((int64_t)(ps.cb * NCTB) * a.n_chunks + ps.c) * kPkSlab;
+        const unsigned char* xsrc = a.x + ((int64_t)(ps.b * G + 2 * ps.c) * 2) * plane_b + ((int64_t)ps.i_lo * WP + ps.j0) * 16;
+        const int pwr = ps.cwb + 1, npp = (ps.npix + 63) >> 6;
+        const float rcp = 1.0f / (float)pwr;
+        const int npiece = NWP + 4 * npp;
+        for (int i = wave; i < npiece; i += NW) {
+            if (i < NWP) {
+                const int ct = i / 18, pc = i - ct * 18;
+                dma_piece(wsrc + (int64_t)ct * a.n_chunks * kPkSlab + pc * 1024, (uint32_t)lane * 16u, wl + ct * kPkSlab + pc * 1024);
+            } else {
+                const int p = i - NWP, pl = p / npp, pp = p - pl * npp;
+                const int e = pp * 64 + lane;
+                if (e < ps.npix) {
+                    const int prow = div_small(e, pwr, rcp), pcol = e - prow * pwr;
+                    dma_piece(xsrc + pl * plane_b, (uint32_t)(prow * WP + pcol) * 16u, xl + pl * XPLANE + pp * 1024);
+                }
+            }
+        }
+    };
+
+    Pos p_cur{0, 0, 0, 0, 0, 1, 0, 0, 0};
+    tile_of(p_cur);
+    Pos p_nx1 = p_cur; advance(p_nx1);
+    issue(p_cur, 0);
+
+    f32x16 acc[4][NCT][NPT];
+    float amax_l = 0.0f;
+    int pixb[NPT], pi[NPT], pj[NPT];        // patch index of the position's (a = 0, b = 0) entry; its (i, j); j < 0: no position
+    int pwr_cur = 1;
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (step + 1 < nsteps) issue(p_nx1, cur ^ 1);
+        if (p_cur.c == 0) {
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt) acc[ph][ct][pt] = zero16();
+            const int cwb = p_cur.cwb, qn = (a.H + 1) * cwb;
+            const float rcp = 1.0f / (float)cwb;
+            pwr_cur = cwb + 1;
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+                const int q = p_cur.q0 + (wq * NPT + pt) * 32 + col;
+                const int qc = min(q, qn - 1);
+                const int i = div_small(qc, cwb, rcp), jj = qc - i * cwb;
+                pixb[pt] = (i - p_cur.i_lo) * pwr_cur + jj;
+                pi[pt] = i;
+                pj[pt] = q < qn ? p_cur.j0 + jj : -1;
+            }
+        }
+        {
+            const unsigned char* xb = smem_pk + cur * STAGE + (size_t)(half * 2) * XPLANE;
+            const unsigned char* wb = smem_pk + cur * STAGE + XST + (size_t)(wco * NCT) * kPkSlab + lane * 16;
+            u32x4 bh[NPT][4], bl[NPT][4];       // shift s = 2 a + b: rows i - 1 + a, columns j - 1 + b of the input
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int pix = pixb[pt] + (s >> 1) * pwr_cur + (s & 1);
+                    bh[pt][s] = *reinterpret_cast<const u32x4*>(xb + pix * 16);
+                    bl[pt][s] = *reinterpret_cast<const u32x4*>(xb + XPLANE + pix * 16);
+                }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const int s = (ky == 2 ? 0 : 2) + (kx == 2 ? 0 : 1), ph = (ky & 1) * 2 + (kx & 1);
+                u32x4 ah[NCT], al[NCT];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    ah[ct] = *reinterpret_cast<const u32x4*>(wb + ct * kPkSlab + (tap * 2 + 0) * 1024);
+                    al[ct] = *reinterpret_cast<const u32x4*>(wb + ct * kPkSlab + (tap * 2 + 1) * 1024);
+                }
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt) {
+                        f32x16& d = acc[ph][ct][pt];
+                        d = mfma16(ah[ct], bh[pt][s], d);
+                        d = mfma16(al[ct], bh[pt][s], d);
+                        d = mfma16(ah[ct], bl[pt][s], d);
+                    }
+                if (tap % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (p_cur.c == a.n_chunks - 1) {                    // ---- epilogue: the four phases of a position as two float2 rows ----
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int cot = p_cur.cb * NCTB + wco * NCT + ct;
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) {
+                    if (pj[pt] >= 0) {
+                        float* tp = a.t + (((int64_t)p_cur.b * a.Co + cot * 32 + 4 * half) * TR + 2 * pi[pt] + 1) * TP + 2 * pj[pt] + 2;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float* tr = tp + (int64_t)((r & 3) + 8 * (r >> 2)) * TR * TP;
+#pragma unroll
+                            for (int ey = 0; ey < 2; ++ey) {
+                                const float v0 = acc[2 * ey][ct][pt][r] * oscale, v1 = acc[2 * ey + 1][ct][pt][r] * oscale;
+                                amax_l = fmaxf(amax_l, fmaxf(fabsf(v0), fabsf(v1)));
+                                *reinterpret_cast<float2*>(tr + ey * TP) = make_float2(v0, v1);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        p_cur = p_nx1;
+        advance(p_nx1);
+    }
+    if (a.out_amax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax_l = fmaxf(amax_l, __shfl_xor(amax_l, off, kWave));
+        if (lane == 0) atomic_max_nonneg(a.out_amax + (((int)blockIdx.x * NW + wave) & (kAmaxSlots - 1)) * kAmaxStride, amax_l);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Blur of an up-sampling layer + StyledConv's tail, T (fp32, zero-bordered) -> packed:  u = lrelu(upfirdn2d(T, k, pad (1, 1))
+// + noise_w noise + bias) * act_scale  (stylesdf_model.py:346, :459-466, :500-507).  Workgroup = 8 channels (one packed entry
+// group) x 16 rows x 64 columns; a thread finishes 4 adjacent pixels of all 8 channels and stores their hi / lo entries.
+// Tap order per output (ky, then kx; one fma chain) is the one of e3dge_upfirdn2d.
+// ---------------------------------------------------------------------------------------------------------------------
+struct PkBlurK {
+    const float* t; unsigned char* y; const float* fir; const float* noise; const float* noise_w; const float* noise_amax;
+    const float* bias; const float* t_amax; int* out_meta; float* out_amax;
+    float bias_amax, slope, act_scale;
+    int B, C, R, noise_batch, tiles_x, tiles_y;
+};
+constexpr int kPbRows = 16, kPbCols = 64, kPbU = kPbRows + 3, kPbPitch = 68;
+
+__global__ void __launch_bounds__(256) pk_blur_kernel(const PkBlurK a) {
+    __shared__ __attribute__((aligned(16))) float u[8 * kPbU * kPbPitch];
+    const int tid = threadIdx.x, lane = tid & 63;
+    int bid = blockIdx.x;
+    const int tx_i = bid % a.tiles_x; bid /= a.tiles_x;
+    const int ty_i = bid % a.tiles_y; bid /= a.tiles_y;
+    const int G = a.C >> 3, g = bid % G, b = bid / G;
+    const int R = a.R, TR = R + 3, TP = R + 4;
+    const int oy0 = ty_i * kPbRows, ox0 = tx_i * kPbCols;
+
+    const float nw = a.noise ? a.noise_w[0] : 0.0f;
+    const float nza = a.noise ? fabsf(nw) * amax_read(a.noise_amax, lane) : 0.0f;
+    const float bound = a.act_scale * (amax_read(a.t_amax, lane) * 1.001f + nza + a.bias_amax) * 1.001f;
+    const unsigned eb = scale_exponent(bound);
+    const float sc = pow2_bits(268u - eb);
+    if (blockIdx.x == 0 && tid == 0) a.out_meta[0] = (int)eb;
+
+    // stage 8 planes of 19 x 68 (T rows oy0 - 1 .., columns ox0 - 1 ..; the T buffer carries its own zero border)
+    constexpr int NE = 8 * kPbU * kPbPitch, NIT = (NE + 255) / 256;
+    const float* __restrict__ tb = a.t + ((int64_t)b * a.C + 8 * g) * TR * TP;
+    float sv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = min(tid + it * 256, NE - 1);
+        const int ch = idx / (kPbU * kPbPitch), rem = idx - ch * (kPbU * kPbPitch);
+        const int r = rem / kPbPitch, c = rem - r * kPbPitch;
+        const int row = min(oy0 + r, TR - 1), cc = min(ox0 + c + 1, TP - 1);       // T(y, x) lives at [y + 1][x + 2]
+        sv[it] = tb[((int64_t)ch * TR + row) * TP + cc];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < NE) u[idx] = sv[it];
+    }
+    float kf[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kf[p][q] = a.fir[(3 - p) * 4 + (3 - q)];
+    __syncthreads();
+
+    const int tx = tid & 15, ty = tid >> 4;
+    const int oy = oy0 + ty, ox = ox0 + 4 * tx;
+    const bool row_ok = oy < R;
+    float nz[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.noise && row_ok) {
+        const float* np_ = a.noise + (int64_t)(a.noise_batch > 1 ? b : 0) * R * R + (int64_t)oy * R + ox;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (ox + j < R) nz[j] = __fmul_rn(nw, np_[j]);
+    }
+    float amax_l = 0.0f;
+    u32x4 hi[4], lo[4];                      // per pixel j: four words = eight channels
+#pragma unroll
+    for (int cp = 0; cp < 4; ++cp) {         // channel pairs (2 cp, 2 cp + 1) -> word cp of every pixel
+        float v[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int ch = 2 * cp + e;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                const float* row = u + (ch * kPbU + ty + ky) * kPbPitch + 4 * tx;
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(row), q1 = *reinterpret_cast<const f32x4*>(row + 4);
+                const float in[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(in[j + kx], kf[ky][kx], acc[j]);
+            }
+            const float bv = a.bias ? a.bias[8 * g + ch] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = acc[j];
+                if (a.noise) t = __fadd_rn(t, nz[j]);
+                t = t + bv;
+                t = (t > 0.0f ? t : t * a.slope) * a.act_scale;
+                if (row_ok && ox + j < R) amax_l = fmaxf(amax_l, fabsf(t));
+                v[e][j] = t * sc;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) SPLIT2_TO(v[0][j], v[1][j], hi[j][cp], lo[j][cp]);
+    }
+    if (row_ok) {
+        const int64_t plane = (int64_t)(R + 2) * (R + 2);
+        u32x4* __restrict__ dst = reinterpret_cast<u32x4*>(a.y) + ((int64_t)(b * G + g) * 2) * plane + (int64_t)(oy + 1) * (R + 2) + ox + 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (ox + j < R) { dst[j] = hi[j]; dst[plane + j] = lo[j]; }
+    }
+    if (a.out_amax) {
+        __shared__ float part[4];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax_l = fmaxf(amax_l, __shfl_xor(amax_l, off, kWave));
+        if (lane == 0) part[tid >> 6] = amax_l;
+        __syncthreads();
+        if (tid == 0) atomic_max_nonneg(a.out_amax + ((int)blockIdx.x & (kAmaxSlots - 1)) * kAmaxStride,
+                                        fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ToRGB on a packed activation (stylesdf_model.py:531-541): 1x1 modulated conv without demodulation (table wm = (scale W) s
+// from the weights launch) + bias + the FIR-up-sampled skip image.  Bound: HBM (4 B per input element).  A thread owns one
+// pixel and a slice of the channel groups (16-byte entries, coalesced across pixels); slices fold through LDS in order.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int GS>
+__global__ void __launch_bounds__(256)
+pk_torgb_kernel(float* __restrict__ y, const unsigned char* __restrict__ x, const int* __restrict__ meta, const float* __restrict__ wm_g,
+                const float* __restrict__ bias, const float* __restrict__ skip, const float* __restrict__ fir, int Ci, int R,
+                int blocks_per_img) {
+    constexpr int PL = 256 / GS;
+    __shared__ float wm[3 * 1024];
+    __shared__ float part[GS > 1 ? GS - 1 : 1][3][PL];
+    const int b = blockIdx.x / blocks_per_img, blk = blockIdx.x - b * blocks_per_img;
+    const int pl = threadIdx.x % PL, grp = threadIdx.x / PL;
+    for (int i = threadIdx.x; i < 3 * Ci; i += 256) wm[i] = wm_g[(size_t)b * 3 * Ci + i];
+    __syncthreads();
+    const float inv = pow2_bits((unsigned)meta[0] - 14u);
+    const int p = blk * PL + pl, HW = R * R;
+    const bool live = p < HW;
+    const int oy = live ? p / R : 0, ox = live ? p - oy * R : 0;
+    float acc[3] = {0.f, 0.f, 0.f};
+    if (live) {
+        const int G = Ci >> 3, per = (G + GS - 1) / GS, g0 = grp * per, g1 = min(G, g0 + per);
+        const int64_t plane = (int64_t)(R + 2) * (R + 2);
+        const u32x4* __restrict__ xp = reinterpret_cast<const u32x4*>(x) + ((int64_t)(b * G + g0) * 2) * plane + (int64_t)(oy + 1) * (R + 2) + ox + 1;
+        auto fold = [&](int gi, const u32x4& h, const u32x4& l) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float v0 = f16lo(h[w]) + f16lo(l[w]), v1 = f16hi(h[w]) + f16hi(l[w]);
+                const int ci = 8 * gi + 2 * w;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = fmaf(wm[c * Ci + ci + 1], v1, fmaf(wm[c * Ci + ci], v0, acc[c]));
+            }
+        };
+        int gi = g0;
+        for (; gi + 4 <= g1; gi += 4) {
+            u32x4 h[4], l[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { h[q] = xp[(int64_t)(2 * q) * plane]; l[q] = xp[(int64_t)(2 * q + 1) * plane]; }
+            xp += 8 * plane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fold(gi + q, h[q], l[q]);
+        }
+        for (; gi < g1; ++gi) {
+            const u32x4 h = xp[0], l = xp[plane];
+            xp += 2 * plane;
+            fold(gi, h, l);
+        }
+    }
+    if (GS > 1) {
+        if (grp > 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) part[grp - 1][c][pl] = acc[c];
+        }
+        __syncthreads();
+    }
+    if (grp != 0 || !live) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float conv = acc[c];
+        if (GS > 1) {
+#pragma unroll
+            for (int q = 0; q < GS - 1; ++q) conv += part[q][c][pl];
+        }
+        float o = conv * inv + bias[c];
+        if (skip) {      // upfirdn2d(skip, fir, up=2, pad=(2,1)): same taps, same order as e3dge_torgb / e3dge_upfirdn2d
+            const int h = R >> 1, w = R >> 1;
+            const float* sp = skip + ((int64_t)b * 3 + c) * h * w;
+            float uacc = 0.0f;
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const int ky = (oy & 1) + 2 * p2, iy = (oy + ky - 2) >> 1;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int kx = (ox & 1) + 2 * e, ix = (ox + kx - 2) >> 1;
+                    if (iy >= 0 && iy < h && ix >= 0 && ix < w) uacc = fmaf(sp[iy * w + ix], fir[(3 - ky) * 4 + (3 - kx)], uacc);
+                }
+            }
+            o = o + uacc;
+        }
+        y[((int64_t)b * 3 + c) * HW + p] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NCT, int NPY, int NPX, int WCO, int WY, int WX>
+static int launch_s1(PkConvK k, hipStream_t st, const char* what) {
+    constexpr int TH = NPY * WY, TW = 32 * NPX * WX, NPIX = (TH + 2) * (TW + 2), NCTB = NCT * WCO;
+    constexpr int lds = 2 * (4 * NPIX * 16 + NCTB * kPkSlab);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    E3DGE_REQUIRE(k.Co % (32 * NCTB) == 0, "%s: Co=%d not a multiple of %d", what, k.Co, 32 * NCTB);
+    k.tiles_y = (k.H + TH - 1) / TH;
+    k.tiles_x = (k.W + TW - 1) / TW;
+    k.co_blocks = k.Co / (32 * NCTB);
+    const int64_t n_tiles = (int64_t)k.B * k.co_blocks * k.tiles_y * k.tiles_x;
+    E3DGE_REQUIRE(n_tiles < ((int64_t)1 << 30), "%s: too many tiles", what);
+    k.n_tiles = (int)n_tiles;
+    auto fn = &pkconv_s1_kernel<NCT, NPY, NPX, WCO, WY, WX>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+    int grid = 256 * ((160 * 1024) / lds >= 2 ? 2 : 1);
+    if (grid > k.n_tiles) grid = k.n_tiles;
+    fn<<<dim3((unsigned)grid), dim3(64 * WCO * WY * WX), lds, st>>>(k);
+    return check_launch(what);
+}
+
+constexpr int kUpNpixMax = 528;
+template <int NCT, int NPT, int WCO, int WQ>
+static int launch_up(PkConvK k, hipStream_t st, const char* what) {
+    constexpr int Q = 32 * NPT * WQ, NCTB = NCT * WCO;
+    constexpr int lds = 2 * (4 * kUpNpixMax * 16 + NCTB * kPkSlab);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    E3DGE_REQUIRE(k.Co % (32 * NCTB) == 0, "%s: Co=%d not a multiple of %d", what, k.Co, 32 * NCTB);
+    k.co_blocks = k.Co / (32 * NCTB);
+    k.cw = k.W + 1 < 129 ? k.W + 1 : 129;
+    k.nblk = (k.W + 1 + k.cw - 1) / k.cw;
+    k.cwl = k.W + 1 - (k.nblk - 1) * k.cw;
+    for (int wdt : {k.cw, k.cwl}) {
+        const int rows = (Q - 1) / wdt + 3;
+        E3DGE_REQUIRE(rows * (wdt + 1) <= kUpNpixMax || (k.H + 2) * (wdt + 1) <= kUpNpixMax, "%s: patch of a %d-column block exceeds the LDS plane", what, wdt);
+    }
+    k.tpf = ((k.H + 1) * k.cw + Q - 1) / Q;
+    k.tpl = ((k.H + 1) * k.cwl + Q - 1) / Q;
+    const int64_t n_tiles = (int64_t)k.B * k.co_blocks * ((int64_t)(k.nblk - 1) * k.tpf + k.tpl);
+    E3DGE_REQUIRE(n_tiles < ((int64_t)1 << 30), "%s: too many tiles", what);
+    k.n_tiles = (int)n_tiles;
+    auto fn = &pkconv_up_kernel<NCT, NPT, WCO, WQ, kUpNpixMax>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+    int grid = 256 * ((160 * 1024) / lds >= 2 ? 2 : 1);
+    if (grid > k.n_tiles) grid = k.n_tiles;
+    fn<<<dim3((unsigned)grid), dim3(64 * WCO * WQ), lds, st>>>(k);
+    return check_launch(what);
+}
+
+static int shape_override(const char* name) {      // E3DGE_DEC2_S1 / E3DGE_DEC2_UP = variant index (tuning runs); -1: automatic
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : -1;
+}
+
+static int conv_s1(PkConvK k, hipStream_t st) {
+    int v = shape_override("E3DGE_DEC2_S1");
+    const int64_t px = (int64_t)k.H * k.W;
+    if (v < 0) {
+        if (k.Co % 64 != 0) v = 3;
+        else if (px <= 64 * 64) v = 0;
+        else if (px <= 128 * 128) v = 1;
+        else v = 2;
+    }
+    if (k.Co % 64 != 0 && v != 3 && v != 4) v = 3;
+    switch (v) {
+        case 0: return launch_s1<1, 1, 1, 2, 4, 1>(k, st, "dec2 conv<64co,4x32>");
+        case 1: return launch_s1<1, 1, 2, 2, 4, 1>(k, st, "dec2 conv<64co,4x64>");
+        case 2: return launch_s1<2, 1, 2, 1, 8, 1>(k, st, "dec2 conv<64co,8x64>");
+        case 3: return launch_s1<1, 1, 2, 1, 8, 1>(k, st, "dec2 conv<32co,8x64>");
+        default: return launch_s1<1, 2, 2, 1, 4, 1>(k, st, "dec2 conv<32co,8x64,4w>");
+    }
+}
+
+static int conv_up(PkConvK k, hipStream_t st) {
+    int v = shape_override("E3DGE_DEC2_UP");
+    if (v < 0) {
+        if (k.Co % 64 != 0) v = 2;
+        else if ((int64_t)k.H * k.W <= 64 * 64) v = 0;
+        else v = 1;
+    }
+    if (k.Co % 64 != 0 && v != 2 && v != 3) v = 2;
+    switch (v) {
+        case 0: return launch_up<1, 1, 2, 4>(k, st, "dec2 convT<64co,128q>");
+        case 1: return launch_up<2, 1, 1, 8>(k, st, "dec2 convT<64co,256q>");
+        case 2: return launch_up<1, 2, 1, 4>(k, st, "dec2 convT<32co,256q,4w>");
+        default: return launch_up<1, 1, 1, 8>(k, st, "dec2 convT<32co,256q>");
+    }
+}
+
+static int launch_torgb(float* y, const unsigned char* x, const int* meta, const float* wm, const float* bias, const float* skip,
+                        const float* fir, int B, int Ci, int R, hipStream_t st) {
+    E3DGE_REQUIRE(Ci % 8 == 0 && Ci <= 1024, "dec2 torgb: ci=%d", Ci);
+    const int64_t hw = (int64_t)R * R;
+    const int gs = Ci >= 512 ? 16 : (Ci >= 256 ? 8 : (Ci >= 128 ? 4 : (Ci >= 64 ? 2 : 1)));
+    const int pl = 256 / gs, bpi = (int)((hw + pl - 1) / pl);
+    dim3 grid((unsigned)(bpi * B)), th(256);
+    switch (gs) {
+        case 16: pk_torgb_kernel<16><<<grid, th, 0, st>>>(y, x, meta, wm, bias, skip, fir, Ci, R, bpi); break;
+        case 8: pk_torgb_kernel<8><<<grid, th, 0, st>>>(y, x, meta, wm, bias, skip, fir, Ci, R, bpi); break;
+        case 4: pk_torgb_kernel<4><<<grid, th, 0, st>>>(y, x, meta, wm, bias, skip, fir, Ci, R, bpi); break;
+        case 2: pk_torgb_kernel<2><<<grid, th, 0, st>>>(y, x, meta, wm, bias, skip, fir, Ci, R, bpi); break;
+        default: pk_torgb_kernel<1><<<grid, th, 0, st>>>(y, x, meta, wm, bias, skip, fir, Ci, R, bpi); break;
+    }
+    return check_launch("dec2 torgb");
+}
+
+static int check_conv(const E3dgeDec2Conv& c, const char* what) {
+    E3DGE_REQUIRE(c.wpre && c.style && c.demod && c.wimg && c.bias, "dec2 %s: null pointer", what);
+    E3DGE_REQUIRE(c.ci > 0 && c.co > 0 && c.ci % 16 == 0 && c.co % 32 == 0 && c.ci <= 1024, "dec2 %s: needs ci %% 16 == 0, co %% 32 == 0 (got %d, %d)", what, c.ci, c.co);
+    E3DGE_REQUIRE(c.noise == nullptr || (c.noise_w && c.noise_amax && c.noise_batch >= 1), "dec2 %s: noise needs noise_w, noise_amax, noise_batch", what);
+    return E3DGE_OK;
+}
+
+}  // namespace e3dge
+
+using namespace e3dge;
+
+extern "C" int64_t e3dge_dec2_act_words(int batch, int channels, int res) {
+    if (batch <= 0 || channels <= 0 || res <= 0) return 0;
+    return (int64_t)batch * ((channels + 7) / 8) * 2 * (res + 2) * (res + 2) * 4;
+}
+extern "C" int64_t e3dge_dec2_tbuf_floats(int batch, int co, int in_res) {
+    if (batch <= 0 || co <= 0 || in_res <= 0) return 0;
+    return (int64_t)batch * co * (2 * in_res + 3) * (2 * in_res + 4);
+}
+extern "C" int e3dge_dec2_num_launches(int n_up) { return 6 + 4 * n_up; }
+
+extern "C" int e3dge_dec2_prepack_weights(float* wpre, const float* weight, float scale, int co, int ci, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(wpre && weight && co > 0 && ci > 0, "dec2_prepack_weights: bad arguments");
+    E3DGE_REQUIRE(co % 32 == 0 && ci % 16 == 0, "dec2_prepack_weights: needs co %% 32 == 0 and ci %% 16 == 0");
+    const int64_t n = (int64_t)co * ci * 9;
+    pk_prepack_kernel<<<dim3(512), dim3(256), 0, as_stream(stream)>>>(wpre, weight, scale, co, ci, ci / 16, n);
+    return check_launch("dec2_prepack_weights");
+}
+
+extern "C" int e3dge_dec2_pack(uint32_t* packed, int32_t* meta, const float* x, const float* amax, int batch, int channels, int res,
+                               e3dge_stream_t stream) {
+    E3DGE_REQUIRE(packed && meta && x && amax && batch >= 0 && channels > 0 && channels % 8 == 0 && res > 0, "dec2_pack: bad arguments");
+    if (batch == 0) return E3DGE_OK;
+    pk_pack_kernel<<<dim3((unsigned)((res * res + 255) / 256), (unsigned)(channels / 8), (unsigned)batch), dim3(256), 0, as_stream(stream)>>>(packed, meta, x, amax, channels, res);
+    return check_launch("dec2_pack");
+}
+extern "C" int e3dge_dec2_unpack(float* x, const uint32_t* packed, const int32_t* meta, int batch, int channels, int res,
+                                 e3dge_stream_t stream) {
+    E3DGE_REQUIRE(packed && meta && x && batch >= 0 && channels > 0 && channels % 8 == 0 && res > 0, "dec2_unpack: bad arguments");
+    if (batch == 0) return E3DGE_OK;
+    pk_unpack_kernel<<<dim3((unsigned)((res * res + 255) / 256), (unsigned)(channels / 8), (unsigned)batch), dim3(256), 0, as_stream(stream)>>>(x, packed, meta, channels, res);
+    return check_launch("dec2_unpack");
+}
+
+extern "C" int e3dge_dec2_forward(const E3dgeDec2Plan* P, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(P != nullptr, "dec2_forward: null plan");
+    E3DGE_REQUIRE(P->batch >= 0 && P->n_up >= 0 && P->n_up <= E3DGE_DEC2_MAX_UP && P->in_res >= 4 && P->in_ch > 0 && P->in_ch % 16 == 0,
+                  "dec2_forward: bad sizes (batch %d, n_up %d, in_res %d, in_ch %d)", P->batch, P->n_up, P->in_res, P->in_ch);
+    if (P->batch == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(P->features && P->mod_table && P->latent && P->amax && P->meta && P->fir_blur && P->fir_up, "dec2_forward: null pointer");
+    int rc = check_conv(P->conv1, "conv1");
+    if (rc) return rc;
+    E3DGE_REQUIRE(P->conv1.ci == P->in_ch, "dec2_forward: conv1.ci != in_ch");
+    E3DGE_REQUIRE(P->skip_in == nullptr, "dec2_forward: rgbd_in is not supported by the packed pipeline");
+    E3DGE_REQUIRE(P->rgb1.ci == P->conv1.co, "dec2_forward: rgb1.ci != conv1.co");
+    for (int u = 0, prev = P->conv1.co; u < P->n_up; ++u) {
+        if ((rc = check_conv(P->up[u], "up")) != 0 || (rc = check_conv(P->conv[u], "conv")) != 0) return rc;
+        E3DGE_REQUIRE(P->tbuf[u] && P->act[2 + 2 * u] && P->act[3 + 2 * u] && P->rgb[u].out && P->rgb[u].wm && P->rgb[u].weight && P->rgb[u].style && P->rgb[u].bias,
+                      "dec2_forward: level %d workspace / ToRGB pointer missing", u);
+        E3DGE_REQUIRE(P->up[u].ci == prev && P->conv[u].ci == P->up[u].co && P->rgb[u].ci == P->conv[u].co, "dec2_forward: level %d channel chain", u);
+        E3DGE_REQUIRE((int64_t)(1 + (P->up[u].co + 7) / 8) * 8 * ((int64_t)P->in_res << (u + 1)) * ((int64_t)P->in_res << (u + 1)) * P->batch < ((int64_t)1 << 31),
+                      "dec2_forward: level %d activation too large for 32-bit offsets", u);
+        prev = P->conv[u].co;
+    }
+    E3DGE_REQUIRE(P->act[0] && P->act[1] && P->rgb1.out && P->rgb1.wm && P->rgb1.weight && P->rgb1.style && P->rgb1.bias, "dec2_forward: workspace missing");
+    hipStream_t st = as_stream(stream);
+    const int B = P->batch, n_l = e3dge_dec2_num_launches(P->n_up);
+    const bool timing = P->kernel_ms != nullptr;
+    E3DGE_REQUIRE(!timing || P->n_kernel_ms >= n_l, "dec2_forward: kernel_ms needs %d entries", n_l);
+    hipEvent_t ev[8 + 4 * E3DGE_DEC2_MAX_UP];
+    int n_ev = 0;
+    auto mark = [&]() { if (timing) { hipEventCreate(&ev[n_ev]); hipEventRecord(ev[n_ev], st); ++n_ev; } };
+    auto finish = [&](int code) {
+        if (timing) {
+            if (code == 0) {
+                hipEventSynchronize(ev[n_ev - 1]);
+                for (int i = 0; i + 1 < n_ev; ++i) hipEventElapsedTime(&P->kernel_ms[i], ev[i], ev[i + 1]);
+            }
+            for (int i = 0; i < n_ev; ++i) hipEventDestroy(ev[i]);
+        }
+        return code;
+    };
+#define DEC2_STEP(expr) do { rc = (expr); if (rc) return finish(rc); mark(); } while (0)
+
+    hipError_t he = hipMemsetAsync(P->amax, 0, sizeof(float) * E3DGE_AMAX_FLOATS * (3 * P->n_up + 2), st);
+    if (he != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "dec2_forward: hipMemsetAsync: %s", hipGetErrorString(he));
+    mark();
+    // 1. all modulation vectors + demodulation factors
+    DEC2_STEP(e3dge_decoder_styles(P->mod_table, P->n_mod, P->mod_rows, P->mod_co, P->latent, P->n_latent, P->style_dim, B, stream));
+    // 2, 3. features -> packed
+    const float* amax0 = P->amax;
+    DEC2_STEP(e3dge_amax(P->amax, P->features, (int64_t)B * P->in_ch * P->in_res * P->in_res, stream));
+    DEC2_STEP(e3dge_dec2_pack(P->act[0], P->meta, P->features, amax0, B, P->in_ch, P->in_res, stream));
+    // 4. per-sample weight images + ToRGB tables
+    {
+        PkWTab tab{};
+        auto add_conv = [&](const E3dgeDec2Conv& c) {
+            PkWConv& w = tab.conv[tab.n_conv++];
+            w.wpre = c.wpre; w.style = c.style; w.demod = c.demod; w.img = c.wimg; w.co = c.co; w.ci = c.ci; w.n_chunks = c.ci / 16;
+            w.n_items = (c.co / 32) * (c.ci / 16) * 9 * 64;
+            w.words = e3dge_modconv_packed_words(c.co, c.ci);
+        };
+        auto add_rgb = [&](const E3dgeDec2Rgb& r) {
+            PkWRgb& w = tab.rgb[tab.n_rgb++];
+            w.w = r.weight; w.style = r.style; w.wm = r.wm; w.scale = r.scale; w.ci = r.ci;
+        };
+        add_conv(P->conv1);
+        for (int u = 0; u < P->n_up; ++u) { add_conv(P->up[u]); add_conv(P->conv[u]); }
+        add_rgb(P->rgb1);
+        for (int u = 0; u < P->n_up; ++u) add_rgb(P->rgb[u]);
+        pk_weights_kernel<<<dim3(96, (unsigned)(tab.n_conv + tab.n_rgb), (unsigned)B), dim3(256), 0, st>>>(tab);
+        DEC2_STEP(check_launch("dec2 weights"));
+    }
+    auto conv_args = [&](const E3dgeDec2Conv& c, int res) {
+        PkConvK k{};
+        k.wimg = reinterpret_cast<const unsigned char*>(c.wimg);
+        k.wimg_bytes = e3dge_modconv_packed_words(c.co, c.ci) * 4;
+        k.noise = c.noise; k.noise_w = c.noise_w; k.noise_amax = c.noise_amax; k.bias = c.bias; k.bias_amax = c.bias_amax;
+        k.knorm = sqrtf(9.0f * (float)c.ci);
+        k.slope = P->negative_slope; k.act_scale = P->act_scale;
+        k.B = B; k.Ci = c.ci; k.Co = c.co; k.H = res; k.W = res; k.n_chunks = c.ci / 16; k.noise_batch = c.noise_batch;
+        return k;
+    };
+    // 5, 6. conv1 + ToRGB
+    int res = P->in_res;
+    {
+        PkConvK k = conv_args(P->conv1, res);
+        k.x = reinterpret_cast<const unsigned char*>(P->act[0]); k.in_meta = P->meta; k.in_amax = P->amax;
+        k.y = reinterpret_cast<unsigned char*>(P->act[1]); k.out_meta = P->meta + 1; k.out_amax = P->amax + E3DGE_AMAX_FLOATS;
+        DEC2_STEP(conv_s1(k, st));
+        DEC2_STEP(launch_torgb(P->rgb1.out, reinterpret_cast<const unsigned char*>(P->act[1]), P->meta + 1, P->rgb1.wm, P->rgb1.bias,
+                               nullptr, nullptr, B, P->rgb1.ci, res, st));
+    }
+    const float* skip = P->rgb1.out;
+    int prev_act = 1;
+    for (int u = 0; u < P->n_up; ++u) {
+        const E3dgeDec2Conv& cu = P->up[u];
+        const E3dgeDec2Conv& cc = P->conv[u];
+        float* am_t = P->amax + (int64_t)E3DGE_AMAX_FLOATS * (2 + 3 * u);
+        float* am_u = am_t + E3DGE_AMAX_FLOATS;
+        float* am_v = am_u + E3DGE_AMAX_FLOATS;
+        {   // transposed conv -> T
+            PkConvK k = conv_args(cu, res);
+            k.noise = nullptr; k.noise_w = nullptr; k.noise_amax = nullptr;
+            k.x = reinterpret_cast<const unsigned char*>(P->act[prev_act]); k.in_meta = P->meta + prev_act;
+            k.in_amax = P->amax + (int64_t)E3DGE_AMAX_FLOATS * (prev_act == 1 ? 1 : 4 + 3 * (u - 1));
+            k.t = P->tbuf[u]; k.out_amax = am_t;
+            DEC2_STEP(conv_up(k, st));
+        }
+        res *= 2;
+        {   // blur + noise + bias + lrelu -> packed
+            PkBlurK k{};
+            k.t = P->tbuf[u]; k.y = reinterpret_cast<unsigned char*>(P->act[2 + 2 * u]); k.fir = P->fir_blur;
+            k.noise = cu.noise; k.noise_w = cu.noise_w; k.noise_amax = cu.noise_amax; k.bias = cu.bias; k.bias_amax = cu.bias_amax;
+            k.t_amax = am_t; k.out_meta = P->meta + 2 + 2 * u; k.out_amax = am_u;
+            k.slope = P->negative_slope; k.act_scale = P->act_scale;
+            k.B = B; k.C = cu.co; k.R = res; k.noise_batch = cu.noise_batch;
+            k.tiles_x = (res + kPbCols - 1) / kPbCols; k.tiles_y = (res + kPbRows - 1) / kPbRows;
+            const int64_t blocks = (int64_t)k.tiles_x * k.tiles_y * (cu.co / 8) * B;
+                pk_blur_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(k);
+            DEC2_STEP(check_launch("dec2 blur"));
+        }
+        {   // stride-1 conv
+            PkConvK k = conv_args(cc, res);
+            k.x = reinterpret_cast<const unsigned char*>(P->act[2 + 2 * u]); k.in_meta = P->meta + 2 + 2 * u; k.in_amax = am_u;
+            k.y = reinterpret_cast<unsigned char*>(P->act[3 + 2 * u]); k.out_meta = P->meta + 3 + 2 * u; k.out_amax = am_v;
+            DEC2_STEP(conv_s1(k, st));
+        }
+        DEC2_STEP(launch_torgb(P->rgb[u].out, reinterpret_cast<const unsigned char*>(P->act[3 + 2 * u]), P->meta + 3 + 2 * u, P->rgb[u].wm,
+                               P->rgb[u].bias, skip, P->fir_up, B, P->rgb[u].ci, res, st));
+        skip = P->rgb[u].out;
+        prev_act = 3 + 2 * u;
+    }
+#undef DEC2_STEP
+    return finish(E3DGE_OK);
+}

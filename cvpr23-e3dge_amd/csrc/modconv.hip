@@ -23,6 +23,7 @@
 //     The up-sampling layers run the transposed convolution by output phase (4 + 2 + 2 + 1 taps, no multiplications by the
 //     zeros of a zero-insertion) and write the (2H+1)^2 map the FIR blur consumes.
 #include "siren_common.h"
+#include "decoder_common.h"
 
 namespace e3dge {
 
@@ -83,20 +84,6 @@ struct ModconvK {
     int tiles_x, tiles_y, co_blocks, n_tiles, n_chunks, noise_batch;
 };
 
-
-// max over the kAmaxSlots slots of an amax buffer (producers spread their atomics over the slots), wave-uniform
-__device__ __forceinline__ float amax_read(const float* p, int lane) {
-    float m = p[(lane & (kAmaxSlots - 1)) * kAmaxStride];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
-    return m;
-}
-// power-of-two operand scale for a bound on |s x|: sc = 2^(141 - eb) puts bound * sc into [2^14, 2^15);
-// 1 / (128 * sc) = 2^(eb - 148) undoes it together with the weights' factor 128.
-__device__ __forceinline__ unsigned scale_exponent(float bound) {
-    unsigned eb = (__float_as_uint(bound) >> 23) & 255u;          // bound in [2^(eb-127), 2^(eb-126))
-    return eb < 22u ? 22u : (eb > 250u ? 250u : eb);
-}
 
 // UP=false: stride-1 3x3, pad 1.   UP=true: stride-2 transposed 3x3 (conv_transpose2d, padding 0), tiled over input
 // positions (i, j) in [0, H] x [0, W]; output (2i+ey, 2j+ex).

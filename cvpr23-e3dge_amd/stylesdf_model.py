@@ -6,9 +6,11 @@ conv.modulation.*, noise.weight, bias, activate.bias}`, `decoder.convs.{i}.*`, `
 `decoder.noises.noise_{i}`; blur kernels are buffers) and the `G_pred_latents.forward` keyword surface that
 `trainer.py:881-897` drives.
 
-What runs where: every elementwise / FIR / weight-preparation step is a hand-written HIP kernel
-(e3dge_amd.op, e3dge_modconv_weights); the dense 3x3 / 1x1 convolutions and the tiny style GEMVs are library
-calls (MIOpen / rocBLAS through torch) -- SURVEY.md 8(d) lists them as "library, not hand-written".
+What runs where: Decoder.forward without an autograd graph is ONE native call (e3dge_dec2_forward, csrc/decoder2.hip):
+activations stay in the split-f16 packed layout of the matrix pipe between the kernels, the 3x3 modulated convolutions,
+the blur, ToRGB and the modulation GEMVs are hand-written HIP kernels.  `E3DGE_DECODER=planar` keeps the round-2 path
+(fp32 planes between fused kernels, e3dge_modconv3x3 etc.); anything that needs an autograd graph through the decoder
+uses weight modulation as a HIP launch (e3dge_modconv_weights) + library convolutions (MIOpen through torch).
 Discriminators, legacy encoders and noise projection onto meshes (:1192-1765, :375-457) are out of scope.
 """
 import ctypes
@@ -121,6 +123,15 @@ class EqualLinear(nn.Module):
         return F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
 
 
+def decoder_backend():
+    """'packed' (default): Decoder.forward without an autograd graph runs as one native call on split-f16 packed activations
+    (e3dge_dec2_forward).  E3DGE_DECODER=planar keeps the round-2 chain of fused kernels over fp32 planes."""
+    v = os.environ.get("E3DGE_DECODER", "packed")
+    if v not in ("packed", "planar"):
+        raise RuntimeError(f"E3DGE_DECODER must be 'packed' or 'planar', got {v!r}")
+    return v
+
+
 def modconv_backend():
     """'hip' (default): 3x3 modulated convolutions run on the fused implicit-GEMM kernel e3dge_modconv3x3.
     E3DGE_MODCONV=library keeps the previous path (e3dge_modconv_weights + MIOpen convolution through torch)."""
@@ -179,8 +190,10 @@ class ModulatedConv2d(nn.Module):
         return out
 
     # ---- fused path --------------------------------------------------------------------------------------------
-    def fused_ok(self, input):
-        """3x3, no down-sampling, fp32 GPU tensors, channel counts the tiles cover, and no autograd graph needed."""
+    def fused_ok(self, input, style=None):
+        """3x3, no down-sampling, fp32 GPU tensors, channel counts the tiles cover, and no autograd graph needed: the
+        fused kernels write into fresh buffers without a grad_fn, so anything that requires grad -- the input, the weights,
+        the modulation layer, or the STYLE (latent optimisation with a frozen decoder) -- takes the library path."""
         if self.kernel_size != 3 or self.downsample or modconv_backend() != "hip":
             return False
         if input.device.type != "cuda" or input.dtype != torch.float32:
@@ -188,17 +201,36 @@ class ModulatedConv2d(nn.Module):
         if self.in_channel % 16 or self.out_channel % 32:
             return False
         if torch.is_grad_enabled() and (input.requires_grad or self.weight.requires_grad or
-                                        self.modulation.weight.requires_grad):
+                                        self.modulation.weight.requires_grad or
+                                        (self.modulation.bias is not None and self.modulation.bias.requires_grad) or
+                                        (style is not None and style.requires_grad)):
             return False
         return True
 
     def invalidate(self):
-        """Drop the packed weight image (needed after writes through `.data`; see SirenGenerator.invalidate)."""
+        """Drop the packed weight images (needed after writes through `.data`; see SirenGenerator.invalidate)."""
         self._img = self._img_key = None
+        self._wpre = self._wpre_key = None
 
     def _apply(self, fn, *a, **k):
         self._img = self._img_key = None
+        self._wpre = self._wpre_key = None
         return super()._apply(fn, *a, **k)
+
+    def device_wpre(self):
+        """scale * W re-arranged in MFMA A-fragment element order (fp32): what the per-forward weights launch of the packed
+        decoder pipeline streams (e3dge_dec2_prepack_weights)."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if getattr(self, '_wpre', None) is None or self._wpre_key != key:
+            Co, Ci = self.out_channel, self.in_channel
+            wpre = torch.empty(Co * Ci * 9, device=w.device, dtype=torch.float32)
+            wc = w.detach().reshape(Co, Ci, 9).contiguous()
+            with torch.cuda.device(w.device):
+                rc = _lib.load().e3dge_dec2_prepack_weights(_lib.ptr(wpre), _lib.ptr(wc), float(self.scale), Co, Ci, _lib.stream_of(wc))
+            _lib.check(rc, "e3dge_dec2_prepack_weights")
+            self._wpre, self._wpre_key = wpre, key
+        return self._wpre
 
     def device_image(self):
         """(image, wsq): the MFMA fragment image of scale * W (f16 hi/lo) and the per-(co,ci) squared norms."""
@@ -264,7 +296,7 @@ class ModulatedConv2d(nn.Module):
 
     def forward(self, input, style):
         B, Ci, H, W = input.shape
-        if self.fused_ok(input):
+        if self.fused_ok(input, style):
             out = self.forward_fused(input, style)
             return self.blur(out) if self.upsample else out
         s = self.modulation(style)
@@ -316,8 +348,8 @@ class StyledConv(nn.Module):
 
     def forward(self, input, style, noise=None, transform=None, mesh_path=None, in_amax=None, out_amax=None, pre=None):
         conv = self.conv
-        if conv.fused_ok(input) and not (torch.is_grad_enabled() and (self.noise.weight.requires_grad or
-                                                                      self.activate.bias.requires_grad)):
+        if conv.fused_ok(input, style) and not (torch.is_grad_enabled() and (self.noise.weight.requires_grad or
+                                                                             self.activate.bias.requires_grad)):
             B, _, H, W = input.shape
             OH, OW = (2 * H, 2 * W) if conv.upsample else (H, W)
             if noise is None:
@@ -363,7 +395,7 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
-    def fused_ok(self, input, skip):
+    def fused_ok(self, input, skip, style=None):
         if modconv_backend() != "hip" or input.device.type != "cuda" or input.dtype != torch.float32:
             return False
         if input.shape[3] % 4 or self.conv.in_channel > 1024:
@@ -371,13 +403,16 @@ class ToRGB(nn.Module):
         if skip is not None and (not self.upsample or tuple(skip.shape[2:]) != (input.shape[2] // 2, input.shape[3] // 2)
                                  or input.shape[2] % 2):
             return False
+        mod = self.conv.modulation
         if torch.is_grad_enabled() and (input.requires_grad or self.bias.requires_grad or self.conv.weight.requires_grad or
-                                        (skip is not None and skip.requires_grad) or self.conv.modulation.weight.requires_grad):
+                                        (skip is not None and skip.requires_grad) or mod.weight.requires_grad or
+                                        (mod.bias is not None and mod.bias.requires_grad) or
+                                        (style is not None and style.requires_grad)):
             return False
         return True
 
     def forward(self, input, style, skip=None, pre=None):
-        if self.fused_ok(input, skip):
+        if self.fused_ok(input, skip, style):
             # 1x1 modulated conv (no demodulation) + bias + FIR-up-sampled skip: one HBM pass (e3dge_torgb)
             B, Ci, H, W = input.shape
             x = input.contiguous()
@@ -487,8 +522,9 @@ class Decoder(nn.Module):
                 row_start += m.in_channel
                 co_start += m.out_channel if w is not None else 0
             raw = torch.frombuffer(bytearray(bytes(rows)), dtype=torch.uint8).to(device)
-            if len(tabs) > 8:
-                tabs.clear()
+            tabs.pop(slot, None)
+            while len(tabs) >= 8:                      # evict the oldest slot only: a captured graph may still replay the others
+                tabs.pop(next(iter(tabs)))
             tabs[slot] = (key, (raw, buf, views, len(layers), row_start, co_start))
         return tabs[slot][1]
 
@@ -506,6 +542,197 @@ class Decoder(nn.Module):
                                                   _lib.stream_of(lat))
         _lib.check(rc, "e3dge_decoder_styles")
         return views
+
+    # ---- packed pipeline: the whole forward as one native call (e3dge_dec2_forward, csrc/decoder2.hip) -----------------
+    def _dec2_ok(self, features, latent, noise, rgbd_in):
+        """fp32 GPU tensors, no autograd graph through the decoder, channel counts the MFMA tiles cover."""
+        if decoder_backend() != "packed" or modconv_backend() != "hip" or rgbd_in is not None:
+            return False
+        if features.device.type != "cuda" or features.dtype != torch.float32 or latent.dtype != torch.float32:
+            return False
+        if features.ndim != 4 or features.shape[2] != features.shape[3] or features.shape[2] < 4:
+            return False
+        if len(self.to_rgbs) > _lib.DEC2_MAX_UP or features.shape[0] < 1:
+            return False
+        if torch.is_grad_enabled() and (features.requires_grad or latent.requires_grad or
+                                        any(p.requires_grad for p in self.parameters())):
+            return False
+        for m, _ in self._mod_layers():
+            if m.kernel_size == 3 and (m.in_channel % 16 or m.out_channel % 32 or not m.demodulate or m.in_channel > 1024):
+                return False
+        if features.shape[1] != self.conv1.conv.in_channel:
+            return False
+        B, res = features.shape[0], features.shape[2]
+        # 32-bit byte offsets inside one packed tensor / element offsets inside a T buffer
+        top = res << len(self.to_rgbs)
+        if B * max(self.channels.get(top, 16), 16) * (top + 4) * (top + 4) * 4 >= 2 ** 31:
+            return False
+        return all(n is None or (n.device == features.device and n.dtype == torch.float32) for n in noise)
+
+    def _noise_amax(self, nz):
+        """amax buffer with max|noise| (the packed producers need it for their operand-scale bound); cached per tensor version."""
+        cache = self.__dict__.setdefault('_nz_amax', {})
+        key = (nz.data_ptr(), nz._version, tuple(nz.shape), str(nz.device))
+        hit = cache.get(key)
+        if hit is None:
+            hit = torch.zeros(_lib.AMAX_FLOATS, device=nz.device, dtype=torch.float32)
+            with torch.cuda.device(nz.device):
+                _lib.check(_lib.load().e3dge_amax(_lib.ptr(hit), _lib.ptr(nz), nz.numel(), _lib.stream_of(nz)), "e3dge_amax")
+            if len(cache) >= 64:
+                cache.pop(next(iter(cache)))
+            cache[key] = hit
+        return hit
+
+    def _dec2_state(self, B, res, device):
+        """Workspace + plan of the packed pipeline for one (batch, input resolution, device, stream): packed activation
+        buffers (zero-filled ONCE: their borders are the convolutions' zero padding and no kernel writes them), T buffers,
+        per-sample weight images, ToRGB tables, amax / meta blocks, and the E3dgeDec2Plan struct with every static pointer
+        filled in.  Rebuilt when a parameter tensor is replaced."""
+        lib = _lib.load()
+        layers = self._mod_layers()
+        convs3 = [self.conv1] + list(self.convs)
+        rgbs = [self.to_rgb1] + list(self.to_rgbs)
+        tab = self._style_table(B, device)                 # has its own cache; rebuilt when a modulation layer / wsq changes
+        pkey = (id(tab[0]),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        slot = (B, res, str(device), torch.cuda.current_stream(device).cuda_stream)
+        states = self.__dict__.setdefault('_dec2', {})
+        hit = states.get(slot)
+        if hit is not None and hit['key'] == pkey:
+            return hit
+        n_up = len(self.to_rgbs)
+        raw, buf, views, n_mod, rows, cos = tab
+        f32 = dict(device=device, dtype=torch.float32)
+        keep = [raw, buf]
+        plan = _lib.Dec2Plan()
+        plan.batch, plan.n_up, plan.in_res, plan.in_ch = B, n_up, res, self.conv1.conv.in_channel
+        plan.mod_table = _lib.ptr(raw)
+        plan.n_mod, plan.mod_rows, plan.mod_co = n_mod, rows, cos
+        plan.n_latent, plan.style_dim = self.n_latent, self.style_dim
+        plan.negative_slope, plan.act_scale = float(self.conv1.activate.negative_slope), float(self.conv1.activate.scale)
+
+        def fill_conv(dst, sc, view):
+            m = sc.conv
+            wimg = torch.empty(B * lib.e3dge_modconv_packed_words(m.out_channel, m.in_channel), device=device, dtype=torch.int32)
+            bias = sc.activate.bias.detach()
+            keep.extend([wimg, bias])
+            dst.wpre, dst.style, dst.demod, dst.wimg = _lib.ptr(m.device_wpre()), _lib.ptr(view[0]), _lib.ptr(view[1]), _lib.ptr(wimg)
+            dst.noise_w, dst.bias = _lib.ptr(sc.noise.weight), _lib.ptr(bias)
+            dst.bias_amax = float(bias.abs().max().item())
+            dst.ci, dst.co = m.in_channel, m.out_channel
+
+        def fill_rgb(dst, tr, view, r):
+            m = tr.conv
+            w = m.weight.detach().reshape(3, m.in_channel)
+            wm = torch.empty((B, 3, m.in_channel), **f32)
+            out = torch.empty((B, 3, r, r), **f32)
+            bias = tr.bias.detach().reshape(3)
+            keep.extend([w, wm, out, bias])
+            dst.weight, dst.style, dst.bias, dst.wm, dst.out = _lib.ptr(w), _lib.ptr(view[0]), _lib.ptr(bias), _lib.ptr(wm), _lib.ptr(out)
+            dst.scale, dst.ci = float(m.scale), m.in_channel
+            return out
+
+        def packed(ch, r):
+            t = torch.zeros(lib.e3dge_dec2_act_words(B, ch, r), device=device, dtype=torch.int32)
+            keep.append(t)
+            return t
+        acts = [packed(self.conv1.conv.in_channel, res), packed(self.conv1.conv.out_channel, res)]
+        fill_conv(plan.conv1, self.conv1, views[0])
+        outs = [fill_rgb(plan.rgb1, self.to_rgb1, views[1], res)]
+        r = res
+        for u in range(n_up):
+            up_c, cv, tr = self.convs[2 * u], self.convs[2 * u + 1], self.to_rgbs[u]
+            fill_conv(plan.up[u], up_c, views[2 + 3 * u])
+            fill_conv(plan.conv[u], cv, views[3 + 3 * u])
+            tb = torch.zeros(lib.e3dge_dec2_tbuf_floats(B, up_c.conv.out_channel, r), **f32)
+            keep.append(tb)
+            plan.tbuf[u] = _lib.ptr(tb)
+            r *= 2
+            acts += [packed(up_c.conv.out_channel, r), packed(cv.conv.out_channel, r)]
+            outs.append(fill_rgb(plan.rgb[u], tr, views[4 + 3 * u], r))
+        for i, t in enumerate(acts):
+            plan.act[i] = _lib.ptr(t)
+        amax = torch.zeros((3 * n_up + 2, _lib.AMAX_FLOATS), **f32)
+        meta = torch.zeros(2 * n_up + 2, device=device, dtype=torch.int32)
+        fir_blur = (self.convs[0].conv.blur.kernel if n_up else self.conv1.conv.weight.new_zeros(4, 4)).detach().contiguous()
+        fir_up = (self.to_rgbs[0].upsample.kernel if n_up else fir_blur).detach().contiguous()
+        keep += [amax, meta, fir_blur, fir_up]
+        plan.amax, plan.meta, plan.fir_blur, plan.fir_up = _lib.ptr(amax), _lib.ptr(meta), _lib.ptr(fir_blur), _lib.ptr(fir_up)
+        st = dict(key=pkey, plan=plan, keep=keep, acts=acts, outs=outs, meta=meta, amax=amax, n_launch=lib.e3dge_dec2_num_launches(n_up))
+        states.pop(slot, None)
+        while len(states) >= 4:
+            states.pop(next(iter(states)))
+        states[slot] = st
+        return st
+
+    def _forward_packed(self, features, latent, noise, kernel_ms=None):
+        """Decoder.forward body on the packed pipeline; `kernel_ms` (list) receives the HIP-event time of every launch
+        (synchronous; for bench.py / tools).  The returned image is a fresh tensor; skip images live in the workspace."""
+        B, res = features.shape[0], features.shape[2]
+        dev = features.device
+        st = self._dec2_state(B, res, dev)
+        plan = st['plan']
+        x = features.contiguous()
+        lat = latent.contiguous()
+        convs3 = [self.conv1] + list(self.convs)
+        hold = [x, lat]
+        r = res
+        for i, sc in enumerate(convs3):
+            if i >= 1 and i % 2 == 1:
+                r *= 2
+            nz = noise[i]
+            if nz is None:                                   # NoiseInjection's own noise (reference :371-373)
+                nz = torch.empty((B, 1, r, r), device=dev, dtype=torch.float32).normal_()
+            nz = nz.contiguous()
+            if nz.shape[0] not in (1, B) or nz.numel() != nz.shape[0] * r * r:
+                raise RuntimeError(f"noise[{i}] must be (1|B, 1, {r}, {r}); got {tuple(nz.shape)}")
+            dst = plan.conv1 if i == 0 else (plan.up[(i - 1) // 2] if i % 2 == 1 else plan.conv[(i - 1) // 2])
+            am = self._noise_amax(nz)
+            dst.noise, dst.noise_amax, dst.noise_batch = _lib.ptr(nz), _lib.ptr(am), nz.shape[0]
+            hold += [nz, am]
+        out = torch.empty_like(st['outs'][-1])
+        last = plan.rgb[len(self.to_rgbs) - 1] if len(self.to_rgbs) else plan.rgb1
+        last.out = _lib.ptr(out)
+        plan.features, plan.latent = _lib.ptr(x), _lib.ptr(lat)
+        ms = None
+        if kernel_ms is not None:
+            ms = (ctypes.c_float * st['n_launch'])()
+            plan.kernel_ms, plan.n_kernel_ms = ctypes.cast(ms, ctypes.POINTER(ctypes.c_float)), st['n_launch']
+        else:
+            plan.kernel_ms, plan.n_kernel_ms = None, 0
+        with torch.cuda.device(dev):
+            rc = _lib.load().e3dge_dec2_forward(ctypes.byref(plan), _lib.stream_of(x))
+        _lib.check(rc, "e3dge_dec2_forward")
+        if ms is not None:
+            kernel_ms[:] = list(ms)
+        st['hold'] = hold            # inputs of the launches just queued stay alive until the next call on this stream
+        return out
+
+    def dec2_launch_names(self):
+        """Labels of the launches of one packed forward, in the order of `kernel_ms`."""
+        names = ["styles", "amax(features)", "pack(features)", "weights", "conv1", "to_rgb1"]
+        for u in range(len(self.to_rgbs)):
+            names += [f"up{u}.convT", f"up{u}.blur", f"conv{u}", f"to_rgb{u}"]
+        return names
+
+    def dec2_unpack(self, index, features_shape):
+        """Debug / test view of a packed activation of the LAST packed forward with this batch and resolution:
+        index 0 = packed features, 1 = conv1 output, 2 + 2u = blur output of level u, 3 + 2u = conv output of level u."""
+        B, res = features_shape[0], features_shape[2]
+        dev = next(self.parameters()).device
+        st = self._dec2_state(B, res, dev)
+        chans = [self.conv1.conv.in_channel, self.conv1.conv.out_channel]
+        ress = [res, res]
+        r = res
+        for u in range(len(self.to_rgbs)):
+            r *= 2
+            chans += [self.convs[2 * u].conv.out_channel, self.convs[2 * u + 1].conv.out_channel]
+            ress += [r, r]
+        out = torch.empty((B, chans[index], ress[index], ress[index]), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            rc = _lib.load().e3dge_dec2_unpack(_lib.ptr(out), _lib.ptr(st['acts'][index]), st['meta'][index:].data_ptr(), B, chans[index],
+                                               ress[index], torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "e3dge_dec2_unpack")
+        return out
 
     def get_latent(self, input):
         return self.style(input)
@@ -535,6 +762,8 @@ class Decoder(nn.Module):
         assert isinstance(styles, list), 'wrap latent code with list'
         latent, noise = self.styles_and_noise_forward(styles, noise, inject_index, truncation, truncation_latent,
                                                       input_is_latent, randomize_noise)
+        if self._dec2_ok(features, latent, noise, rgbd_in):
+            return self._forward_packed(features, latent, noise), (latent if return_latents else None)
         # amax buffers (one row per activation): every fused layer leaves max|output| for the next one's operand scaling
         track = features.device.type == "cuda" and modconv_backend() == "hip" and not torch.is_grad_enabled()
         amax = torch.zeros((self.num_layers + 1, _lib.AMAX_FLOATS), device=features.device, dtype=torch.float32) if track else None

@@ -161,6 +161,88 @@ int e3dge_blur_noise_bias_act(float* y, const float* x, const float* k, const fl
 int e3dge_torgb(float* y, const float* x, const float* weight, const float* style, const float* bias, const float* skip,
                 const float* fir, float scale, int batch, int ci, int height, int width, e3dge_stream_t stream);
 
+/*
+ * ---- Packed decoder pipeline ("dec2"): Decoder.forward (project/models/stylesdf_model.py:741-797) as ONE native call ----
+ *
+ * The up-sampler's activations never exist as fp32 planes between its kernels.  Every producer writes its output already
+ * split for the f16 matrix pipe, in the layout the next convolution's LDS-DMA consumes verbatim:
+ *
+ *   packed tensor (batch, C/8, 2, H+2, W+2) of 16-byte entries:  entry (b, g, hl, y, x) = the eight f16 values
+ *       hl = 0: hi = f16_rtz(v * 2^(141 - eb)),   hl = 1: lo = f16(v * 2^(141 - eb) - hi)       of channels 8g .. 8g+7
+ *   at pixel (y-1, x-1); the one-entry border is zero (= the convolutions' zero padding) and is never written by a
+ *   producer, so the caller zero-fills a packed buffer ONCE (workspace) and reuses it.  eb (one int per tensor, in
+ *   `meta`) is the biased exponent of an a-priori bound on max|v| that the producer computes before its first store:
+ *   stride-1 conv: act_scale * (amax_in * sqrt(9 ci) + |noise_w| amax_noise + max|bias|) (Cauchy-Schwarz: demodulated
+ *   filters have unit norm); blur: act_scale * (amax_T + ...).  The bound may be 2^12 loose before the representation
+ *   (22 bits relative to the tensor's maximum) degrades to fp32's 24.
+ *
+ * Weights: per sample, w'' = ((scale W) s) demod exactly as the reference rounds them (:319-326), times 128, split into
+ * f16 hi/lo MFMA A-fragments (e3dge_modconv_packed_words words per sample), rebuilt by one launch per forward from the
+ * pre-arranged fp32 image `wpre` (e3dge_dec2_prepack_weights, once per weight update).
+ *
+ * Kernels of one forward, all launched by e3dge_dec2_forward on `stream` (nothing else, no allocation, no sync unless
+ * kernel_ms is given): styles (2), amax + pack of the features, per-sample weights, conv1, ToRGB, then per level: transposed
+ * conv by output phase -> fp32 T, blur + noise + bias + lrelu -> packed, stride-1 conv (+ noise + bias + lrelu) -> packed,
+ * ToRGB (+ FIR-up-sampled skip).  The convolutions stage BOTH operands by LDS-DMA (no VGPR staging, no conversion).
+ */
+#define E3DGE_DEC2_MAX_UP 6
+typedef struct E3dgeDec2Conv {
+    const float* wpre;        /* e3dge_dec2_prepack_weights image of ModulatedConv2d.weight (co*ci*9 floats)            */
+    const float* style;       /* (batch, ci)  conv.modulation(latent) -- written by the styles launch of this call       */
+    const float* demod;       /* (batch, co)  demodulation factors    -- idem                                            */
+    uint32_t* wimg;           /* workspace: batch * e3dge_modconv_packed_words(co, ci) words                              */
+    const float* noise;       /* (noise_batch, 1, OH, OW) or NULL                                                        */
+    const float* noise_w;     /* NoiseInjection.weight (device scalar), required with noise                              */
+    const float* noise_amax;  /* amax buffer holding max|noise| (e3dge_amax), required with noise                        */
+    const float* bias;        /* (co) FusedLeakyReLU.bias                                                                */
+    float bias_amax;          /* max|bias| (host value, computed when the weights are packed)                            */
+    int32_t ci, co, noise_batch;
+} E3dgeDec2Conv;
+typedef struct E3dgeDec2Rgb {
+    const float* weight;      /* (3, ci) ToRGB.conv.weight                                                               */
+    const float* style;       /* (batch, ci)                                                                             */
+    const float* bias;        /* (3)                                                                                     */
+    float* wm;                /* workspace (batch, 3, ci): (scale W) s                                                   */
+    float* out;               /* (batch, 3, res, res): this level's image (the last one is Decoder.forward's result)     */
+    float scale;              /* 1 / sqrt(ci)                                                                            */
+    int32_t ci;
+} E3dgeDec2Rgb;
+typedef struct E3dgeDec2Plan {
+    int32_t batch, n_up, in_res, in_ch;
+    const float* features;                         /* (batch, in_ch, in_res, in_res) fp32                                 */
+    const float* skip_in;                          /* rgbd_in of Decoder.forward (batch, 3, in_res, in_res) or NULL        */
+    const E3dgeModLayer* mod_table;                /* device table for the styles launch (see e3dge_decoder_styles)        */
+    const float* latent;                           /* (batch, n_latent, style_dim)                                        */
+    int32_t n_mod, mod_rows, mod_co, n_latent, style_dim, reserved0;
+    E3dgeDec2Conv conv1;
+    E3dgeDec2Rgb rgb1;
+    E3dgeDec2Conv up[E3DGE_DEC2_MAX_UP];           /* up-sampling StyledConv of level u (convs[2u])                        */
+    E3dgeDec2Conv conv[E3DGE_DEC2_MAX_UP];         /* stride-1 StyledConv of level u (convs[2u+1])                         */
+    E3dgeDec2Rgb rgb[E3DGE_DEC2_MAX_UP];
+    uint32_t* act[2 * E3DGE_DEC2_MAX_UP + 2];      /* packed workspaces: [0] features, [1] conv1 out, [2+2u] blur out, [3+2u] conv out */
+    float* tbuf[E3DGE_DEC2_MAX_UP];                /* (batch, co, 2H+3, 2W+4) fp32, zero-filled once: transposed-conv outputs */
+    float* amax;                                   /* (3 n_up + 2) amax buffers (zeroed by the call): [0] features, [1] conv1 out, [2+3u] T, [3+3u] blur out, [4+3u] conv out */
+    int32_t* meta;                                 /* (2 n_up + 2) ints: eb of act[i]                                      */
+    const float* fir_blur;                         /* 4x4 taps of the up-sampling convs' Blur (make_kernel * 4)            */
+    const float* fir_up;                           /* 4x4 taps of ToRGB's Upsample                                        */
+    float negative_slope, act_scale;
+    float* kernel_ms;                              /* host array, n_kernel_ms floats, or NULL: HIP-event time of every launch (makes the call synchronous) */
+    int32_t n_kernel_ms, reserved1;
+} E3dgeDec2Plan;
+/* 32-bit words of a packed tensor / floats of a T buffer / floats of a wpre image */
+int64_t e3dge_dec2_act_words(int batch, int channels, int res);
+int64_t e3dge_dec2_tbuf_floats(int batch, int co, int in_res);
+/* weight (co, ci, 3, 3) -> wpre[t][c][tap][lane][j] = scale * weight[32t + (lane & 31)][16c + 8 (lane >> 5) + j][tap] */
+int e3dge_dec2_prepack_weights(float* wpre, const float* weight, float scale, int co, int ci, e3dge_stream_t stream);
+/* launches per forward with n_up levels (= number of kernel_ms entries written): 6 + 4 n_up */
+int e3dge_dec2_num_launches(int n_up);
+int e3dge_dec2_forward(const E3dgeDec2Plan* plan, e3dge_stream_t stream);
+/* stand-alone pieces (tests, tools): fp32 (batch, c, res, res) <-> packed; both use meta[0] / amax as e3dge_dec2_forward does */
+int e3dge_dec2_pack(uint32_t* packed, int32_t* meta, const float* x, const float* amax, int batch, int channels, int res,
+                    e3dge_stream_t stream);
+int e3dge_dec2_unpack(float* x, const uint32_t* packed, const int32_t* meta, int batch, int channels, int res,
+                      e3dge_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * FiLM-SIREN volume renderer (reference: project/utils/volume_renderer.py)
  * ------------------------------------------------------------------------------------------ */

@@ -1,0 +1,175 @@
+"""GPU: the packed decoder pipeline (csrc/decoder2.hip, e3dge_dec2_forward) -- Decoder.forward of
+project/models/stylesdf_model.py:741-797 as one native call on split-f16 packed activations.
+
+What is pinned here: (i) the packed <-> fp32 conversion, (ii) every intermediate activation against the planar (round-2)
+kernels on the same GPU, (iii) the image against the CPU oracle (fp32 and float64) on shapes the oracle finishes in seconds,
+incl. batch > 1, per-sample noise, tiles that overhang a small image, (iv) independence of the input magnitude (the operand
+scale comes from an a-priori bound).  The reference goldens (decoder_256, generator_256, c3_eval_1024, generator_z_base) reach
+this path through Decoder.forward in test_gpu_decoder.py / test_c3_eval.py.
+
+Tolerance: image 1e-4 absolute on images of magnitude ~3, intermediates 2e-5 of the tensor's maximum."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import full_state_dict, maxerr, record
+from oracle import decoder_ref
+
+import e3dge_amd  # noqa: F401
+from e3dge_amd import _lib
+from e3dge_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+IMG_ATOL = 1e-4
+
+
+def _planar(dec, feats, wd, noise):
+    os.environ["E3DGE_DECODER"] = "planar"
+    try:
+        return dec(feats, [wd], input_is_latent=True, noise=noise, randomize_noise=False)[0]
+    finally:
+        os.environ.pop("E3DGE_DECODER", None)
+
+
+def test_pack_unpack_roundtrip():
+    lib = _lib.load()
+    torch.manual_seed(0)
+    for (B, C, R, mag) in ((1, 16, 8, 1.0), (2, 64, 33, 1e-4), (1, 32, 64, 3e4), (3, 8, 5, 1.0)):
+        x = (torch.randn(B, C, R, R, device=DEV) * mag).contiguous()
+        x[0, 0, 0, 0] = 0.0
+        am = torch.zeros(_lib.AMAX_FLOATS, device=DEV)
+        pk = torch.zeros(lib.e3dge_dec2_act_words(B, C, R), device=DEV, dtype=torch.int32)
+        meta = torch.zeros(1, device=DEV, dtype=torch.int32)
+        y = torch.empty_like(x)
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.e3dge_amax(am.data_ptr(), x.data_ptr(), x.numel(), st), "amax")
+        _lib.check(lib.e3dge_dec2_pack(pk.data_ptr(), meta.data_ptr(), x.data_ptr(), am.data_ptr(), B, C, R, st), "pack")
+        _lib.check(lib.e3dge_dec2_unpack(y.data_ptr(), pk.data_ptr(), meta.data_ptr(), B, C, R, st), "unpack")
+        rel = float((y - x).abs().max() / x.abs().max())
+        record("dec2_pack_roundtrip", B=B, C=C, R=R, mag=mag, rel=rel)
+        assert rel <= 2.0 ** -20
+        # the one-entry border stays zero
+        v = pk.view(B, C // 8, 2, R + 2, R + 2, 4)
+        assert int(v[:, :, :, 0].abs().max()) == 0 and int(v[:, :, :, :, 0].abs().max()) == 0
+        assert int(v[:, :, :, R + 1].abs().max()) == 0 and int(v[:, :, :, :, R + 1].abs().max()) == 0
+
+
+@pytest.fixture(scope="module")
+def gen256():
+    g, sd = full_state_dict(size=256, cm=1)
+    return g.to(DEV).eval(), sd
+
+
+def test_every_stage_against_the_planar_kernels(gen256):
+    g, sd = gen256
+    dec = g.decoder
+    _, wd = syn.synthetic_inputs(1, seed=1, device=DEV)
+    wd = wd[:, :dec.n_latent].contiguous()
+    feats = (0.5 * torch.randn(1, 256, 64, 64, device=DEV, generator=torch.Generator(DEV).manual_seed(3))).contiguous()
+    noise = [getattr(dec.noises, f"noise_{i}") for i in range(dec.num_layers)]
+    with torch.no_grad():
+        os.environ["E3DGE_DECODER"] = "planar"
+        try:
+            am = torch.zeros((dec.num_layers + 1, _lib.AMAX_FLOATS), device=DEV)
+            mods = dec._all_modulations(wd)
+            ref = [dec.conv1(feats, wd[:, 0], noise=noise[0], out_amax=am[1], pre=mods[0])]
+            i, j = 1, 2
+            for u in range(len(dec.to_rgbs)):
+                ref.append(dec.convs[2 * u](ref[-1], wd[:, i], noise=noise[2 * u + 1], in_amax=am[i], out_amax=am[i + 1], pre=mods[j]))
+                ref.append(dec.convs[2 * u + 1](ref[-1], wd[:, i + 1], noise=noise[2 * u + 2], in_amax=am[i + 1], out_amax=am[i + 2], pre=mods[j + 1]))
+                i += 2
+                j += 3
+        finally:
+            os.environ.pop("E3DGE_DECODER", None)
+        ref_img = _planar(dec, feats, wd, noise)
+        ms = []
+        img = dec._forward_packed(feats, wd, noise, kernel_ms=ms)
+        assert len(ms) == _lib.load().e3dge_dec2_num_launches(len(dec.to_rgbs)) and all(t > 0 for t in ms)
+        errs = {}
+        for k, r in enumerate(ref):
+            got = dec.dec2_unpack(1 + k, feats.shape)
+            errs[f"act{1 + k}"] = maxerr(got, r) / float(r.abs().max())
+        errs["img"] = maxerr(img, ref_img)
+    record("dec2_stages_256", **errs)
+    for k, v in errs.items():
+        assert v <= (IMG_ATOL if k == "img" else 2e-5), (k, v)
+    # the default Decoder.forward takes the packed path and returns the same tensor values
+    with torch.no_grad():
+        img2, _ = dec(feats, [wd], input_is_latent=True, randomize_noise=False)
+    assert torch.equal(img2, img)
+
+
+@pytest.mark.parametrize("B,res,size,per_sample_noise", [(2, 16, 128, True), (1, 8, 32, False), (3, 16, 64, False)])
+def test_image_against_the_oracle_small_shapes(B, res, size, per_sample_noise):
+    g, sd = full_state_dict(size=size, cm=1, res=res)
+    g = g.to(DEV).eval()
+    dec = g.decoder
+    _, wd = syn.synthetic_inputs(B, seed=5, device=DEV)
+    wd = wd[:, :dec.n_latent].contiguous()
+    gen = torch.Generator(DEV).manual_seed(11)
+    feats = (0.7 * torch.randn(B, 256, res, res, device=DEV, generator=gen)).contiguous()
+    noise = []
+    for i in range(dec.num_layers):
+        r = getattr(dec.noises, f"noise_{i}").shape[-1]
+        noise.append(torch.randn(B if per_sample_noise else 1, 1, r, r, device=DEV, generator=gen))
+    with torch.no_grad():
+        img, _ = dec(feats, [wd], input_is_latent=True, noise=noise, randomize_noise=False)
+        planar = _planar(dec, feats, wd, noise)
+    c = lambda t: t.detach().cpu()
+    o32 = decoder_ref.decoder_forward(sd, c(feats), c(wd), noises=[c(n) for n in noise])
+    o64 = decoder_ref.decoder_forward(sd, c(feats), c(wd), noises=[c(n) for n in noise], dtype=torch.float64)
+    e = dict(vs_f32=maxerr(img, o32), vs_f64=maxerr(img, o64), f32_vs_f64=maxerr(o32, o64), planar_vs_f64=maxerr(planar, o64),
+             img_max=float(o64.abs().max()))
+    record(f"dec2_oracle_B{B}_res{res}_size{size}", **e)
+    assert tuple(img.shape) == (B, 3, size, size)
+    assert e['vs_f32'] <= IMG_ATOL and e['vs_f64'] <= max(IMG_ATOL, 3 * e['f32_vs_f64'])
+
+
+def test_input_magnitude_does_not_matter(gen256):
+    """The operand scale of every packed tensor comes from a bound; scaling the feature map by 2^k scales conv1's output
+    only through the noise / bias terms -- compare against the planar path at each magnitude instead of assuming linearity."""
+    g, sd = gen256
+    dec = g.decoder
+    _, wd = syn.synthetic_inputs(1, seed=2, device=DEV)
+    wd = wd[:, :dec.n_latent].contiguous()
+    base = torch.randn(1, 256, 64, 64, device=DEV, generator=torch.Generator(DEV).manual_seed(4))
+    noise = [getattr(dec.noises, f"noise_{i}") for i in range(dec.num_layers)]
+    out = {}
+    for mag in (1e-5, 1.0, 1e4):
+        feats = (base * mag).contiguous()
+        with torch.no_grad():
+            img, _ = dec(feats, [wd], input_is_latent=True, randomize_noise=False)
+            ref = _planar(dec, feats, wd, noise)
+        out[str(mag)] = maxerr(img, ref) / float(ref.abs().max())
+        assert torch.isfinite(img).all()
+    record("dec2_magnitude", **out)
+    assert max(out.values()) <= 2e-5
+
+
+def test_falls_back_when_a_graph_is_needed():
+    """A latent that requires grad must not take the packed (graph-less) path: the gradient w.r.t. the decoder latent exists
+    and matches the library path (fused kernels silently dropped dL/d(style))."""
+    _, wd = syn.synthetic_inputs(1, seed=2, device=DEV)
+    feats = 0.5 * torch.randn(1, 256, 16, 16, device=DEV)
+    gs, _ = full_state_dict(size=64, cm=1, res=16)          # a small decoder keeps the library path cheap
+    ds = gs.decoder.to(DEV).eval()
+    for p in ds.parameters():
+        p.requires_grad_(False)
+    wl = wd[:, :ds.n_latent].detach().clone().requires_grad_(True)
+    img, _ = ds(feats, [wl], input_is_latent=True, randomize_noise=False)
+    assert img.requires_grad
+    (img ** 2).mean().backward()
+    assert wl.grad is not None and float(wl.grad.abs().max()) > 0
+    os.environ["E3DGE_MODCONV"] = "library"
+    try:
+        wl2 = wl.detach().clone().requires_grad_(True)
+        img2, _ = ds(feats, [wl2], input_is_latent=True, randomize_noise=False)
+        (img2 ** 2).mean().backward()
+    finally:
+        os.environ.pop("E3DGE_MODCONV", None)
+    rel = float((wl.grad - wl2.grad).abs().max() / wl2.grad.abs().max())
+    record("dec2_latent_grad_fallback", rel=rel)
+    assert rel <= 1e-4
