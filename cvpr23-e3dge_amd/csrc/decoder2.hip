@@ -18,6 +18,22 @@ namespace e3dge {
 
 constexpr int kPkSlab = 9 * 2 * 1024;            // bytes of one weight slab: (32 co) x (16 ci) x 9 taps x (hi, lo)
 
+// -DE3DGE_PK_TIMING: waves 0 and NW-1 of workgroup 0 accumulate shader-cycle deltas per phase of a step (0: vmcnt + barrier,
+// 1: DMA issue, 2: fragment reads + MFMAs, 3: epilogue) and leave them in the unused floats of the output amax buffer's first
+// line (tools/dec2_check.py --timing).
+#ifdef E3DGE_PK_TIMING
+#define PK_T(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
+#define PK_T_INIT unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter(); const unsigned long long tbegin = tlast
+#define PK_T_DONE(NW_) do { if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == (NW_) - 1) && a.out_amax) { \
+        float* o_ = a.out_amax + 1 + (wave == 0 ? 0 : 8); \
+        for (int i_ = 0; i_ < 4; ++i_) o_[i_] = (float)tacc[i_]; \
+        o_[4] = (float)(__builtin_readcyclecounter() - tbegin); o_[5] = (float)nsteps; } } while (0)
+#else
+#define PK_T(i) do { } while (0)
+#define PK_T_INIT do { } while (0)
+#define PK_T_DONE(NW_) do { } while (0)
+#endif
+
 __device__ __forceinline__ uint32_t lds_u32(const void* p) {
     return (uint32_t)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
 }
@@ -223,12 +239,18 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
     };
     auto advance = [&](Pos& p) { if (++p.c == a.n_chunks) { p.c = 0; ++p.k; tile_of(p); } };
 
-    auto issue = [&](const Pos& ps, int stage) {
+    // this wave's DMA pieces j_lo <= j < j_hi of step `ps` (piece index wave + j NW) into LDS stage `stage`.  Inside the main loop
+    // the pieces of step + 1 are dealt out behind the MFMAs of the first taps: a dedicated issue phase had all eight waves
+    // stalled on the CU's one vector-memory path at the same time (2.2-3.5 k cycles of a 12 k-cycle step, E3DGE_PK_TIMING).
+    constexpr int NPW = (NPIECE + NW - 1) / NW, PPT = (NPW + 5) / 6;
+    auto issue = [&](const Pos& ps, int stage, int j_lo, int j_hi) {
         const uint32_t xl = lds_u32(smem_pk + stage * STAGE), wl = xl + XST;
         const unsigned char* wsrc = a.wimg + (int64_t)ps.b * a.wimg_bytes + ((int64_t)(ps.cb * NCTB) * a.n_chunks + ps.c) * kPkSlab;
         const unsigned char* xsrc = a.x + ((int64_t)(ps.b * G + 2 * ps.c) * 2) * plane_b;
         const int gy0 = ps.ty * TH, gx0 = ps.tx * TW;
-        for (int i = wave; i < NPIECE; i += NW) {
+        for (int j = j_lo; j < j_hi; ++j) {
+            const int i = wave + j * NW;
+            if (i >= NPIECE) break;
             if (i < NWP) {
                 const int ct = i / 18, pc = i - ct * 18;
                 dma_piece(wsrc + (int64_t)ct * a.n_chunks * kPkSlab + pc * 1024, (uint32_t)lane * 16u, wl + ct * kPkSlab + pc * 1024);
@@ -248,17 +270,19 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
     Pos p_cur{0, 0, 0, 0, 0, 0};
     tile_of(p_cur);
     Pos p_nx1 = p_cur; advance(p_nx1);
-    issue(p_cur, 0);
+    issue(p_cur, 0, 0, NPW);
 
     f32x16 acc[NCT][NPY * NPX];
     float amax_l = 0.0f;
     const int prow0 = wy * NPY, pcol0 = wx * NPX * 32 + col;
+    PK_T_INIT;
 
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
         // my pieces of this step have landed; after the barrier everybody's have, and nobody still reads the other stage
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (step + 1 < nsteps) issue(p_nx1, cur ^ 1);
+        PK_T(0);
+        const bool has_next = step + 1 < nsteps;
         if (p_cur.c == 0) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
@@ -294,9 +318,11 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
                         d = mfma16(al[ct], bh[pt], d);
                         d = mfma16(ah[ct], bl[pt], d);
                     }
+                if (has_next && tap * PPT < NPW) issue(p_nx1, cur ^ 1, tap * PPT, min((tap + 1) * PPT, NPW));
                 if (tap % 3 == 2) __builtin_amdgcn_sched_barrier(0);      // keep the fragment reads of later taps from piling up
             }
         }
+        PK_T(2);
         if (p_cur.c == a.n_chunks - 1) {                    // ---- epilogue: noise + bias + lrelu, then split for the next conv ----
             const int b = p_cur.b;
 #pragma unroll
@@ -311,28 +337,45 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
                         const float nz = (ok && a.noise) ? __fmul_rn(nw, a.noise[(int64_t)(a.noise_batch > 1 ? b : 0) * a.H * a.W + (int64_t)oy * a.W + ox]) : 0.0f;
                         const f32x16& d = acc[ct][py * NPX + px];
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const int co0 = cot * 32 + 8 * g4 + 4 * half;
-                            float v[4];
+                        for (int gp = 0; gp < 2; ++gp) {         // channel groups 2 gp, 2 gp + 1 of this co-tile
+                            unsigned hw[2][2], lw[2][2];         // [group][word]: this lane's four channels of each group
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                float t = __fadd_rn(__fadd_rn(d[4 * g4 + j] * oscale, nz), a.bias[co0 + j]);
-                                t = (t > 0.0f ? t : t * a.slope) * a.act_scale;
-                                if (ok) amax_l = fmaxf(amax_l, fabsf(t));
-                                v[j] = t * sc_out;
+                            for (int e = 0; e < 2; ++e) {
+                                const int g4 = 2 * gp + e, co0 = cot * 32 + 8 * g4 + 4 * half;
+                                float v[4];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    float t = __fadd_rn(__fadd_rn(d[4 * g4 + j] * oscale, nz), a.bias[co0 + j]);
+                                    t = (t > 0.0f ? t : t * a.slope) * a.act_scale;
+                                    if (ok) amax_l = fmaxf(amax_l, fabsf(t));
+                                    v[j] = t * sc_out;
+                                }
+                                SPLIT2_TO(v[0], v[1], hw[e][0], lw[e][0]);
+                                SPLIT2_TO(v[2], v[3], hw[e][1], lw[e][1]);
                             }
-                            unsigned h0, l0, h1, l1;
-                            SPLIT2_TO(v[0], v[1], h0, l0);
-                            SPLIT2_TO(v[2], v[3], h1, l1);
+                            // half exchange (v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second): afterwards
+                            // lanes 0-31 hold the whole 16-byte entry of group 2 gp, lanes 32-63 that of group 2 gp + 1 -> one 16-byte
+                            // store per plane instead of two 8-byte ones (the epilogue was store-issue bound, guide T21)
+#pragma unroll
+                            for (int w = 0; w < 2; ++w) {
+                                auto rh = __builtin_amdgcn_permlane32_swap(hw[0][w], hw[1][w], false, false);
+                                hw[0][w] = rh[0]; hw[1][w] = rh[1];
+                                auto rl = __builtin_amdgcn_permlane32_swap(lw[0][w], lw[1][w], false, false);
+                                lw[0][w] = rl[0]; lw[1][w] = rl[1];
+                            }
                             if (ok) {
-                                unsigned char* dst = a.y + ((int64_t)(b * GO + cot * 4 + g4) * 2) * plane_b + ((int64_t)(oy + 1) * WP + ox + 1) * 16 + half * 8;
-                                *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-                                *reinterpret_cast<uint2*>(dst + plane_b) = make_uint2(l0, l1);
+                                unsigned char* dst = a.y + ((int64_t)(b * GO + cot * 4 + 2 * gp + half) * 2) * plane_b + ((int64_t)(oy + 1) * WP + ox + 1) * 16;
+                                u32x4 eh, el;
+                                eh[0] = hw[0][0]; eh[1] = hw[0][1]; eh[2] = hw[1][0]; eh[3] = hw[1][1];
+                                el[0] = lw[0][0]; el[1] = lw[0][1]; el[2] = lw[1][0]; el[3] = lw[1][1];
+                                *reinterpret_cast<u32x4*>(dst) = eh;
+                                *reinterpret_cast<u32x4*>(dst + plane_b) = el;
                             }
                         }
                     }
             }
         }
+        PK_T(3);
         p_cur = p_nx1;
         advance(p_nx1);
     }
@@ -341,6 +384,7 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
         for (int off = 32; off > 0; off >>= 1) amax_l = fmaxf(amax_l, __shfl_xor(amax_l, off, kWave));
         if (lane == 0) atomic_max_nonneg(a.out_amax + (((int)blockIdx.x * NW + wave) & (kAmaxSlots - 1)) * kAmaxStride, amax_l);
     }
+    PK_T_DONE(NW);
 }
 
 // ---- stride-2 transposed 3x3 (conv_transpose2d, padding 0) by output phase ---------------------------------------------
@@ -384,14 +428,17 @@ __global__ void __launch_bounds__(64 * WCO * WQ) pkconv_up_kernel(const PkConvK 
     };
     auto advance = [&](Pos& p) { if (++p.c == a.n_chunks) { p.c = 0; ++p.k; tile_of(p); } };
 
-    auto issue = [&](const Pos& ps, int stage) {
+    constexpr int NPW = (NWP + 4 * ((NPIXMAX + 63) / 64) + NW - 1) / NW, PPT = (NPW + 5) / 6;   // piece slots per wave (upper bound), per tap
+    auto issue = [&](const Pos& ps, int stage, int j_lo, int j_hi) {
         const uint32_t xl = lds_u32(smem_pk + stage * STAGE), wl = xl + XST;
         const unsigned char* wsrc = a.wimg + (int64_t)ps.b * a.wimg_bytes + ((int64_t)(ps.cb * NCTB) * a.n_chunks + ps.c) * kPkSlab;
         const unsigned char* xsrc = a.x + ((int64_t)(ps.b * G + 2 * ps.c) * 2) * plane_b + ((int64_t)ps.i_lo * WP + ps.j0) * 16;
         const int pwr = ps.cwb + 1, npp = (ps.npix + 63) >> 6;
         const float rcp = 1.0f / (float)pwr;
         const int npiece = NWP + 4 * npp;
-        for (int i = wave; i < npiece; i += NW) {
+        for (int j = j_lo; j < j_hi; ++j) {
+            const int i = wave + j * NW;
+            if (i >= npiece) break;
             if (i < NWP) {
                 const int ct = i / 18, pc = i - ct * 18;
                 dma_piece(wsrc + (int64_t)ct * a.n_chunks * kPkSlab + pc * 1024, (uint32_t)lane * 16u, wl + ct * kPkSlab + pc * 1024);
@@ -409,17 +456,19 @@ __global__ void __launch_bounds__(64 * WCO * WQ) pkconv_up_kernel(const PkConvK 
     Pos p_cur{0, 0, 0, 0, 0, 1, 0, 0, 0};
     tile_of(p_cur);
     Pos p_nx1 = p_cur; advance(p_nx1);
-    issue(p_cur, 0);
+    issue(p_cur, 0, 0, NPW);
 
     f32x16 acc[4][NCT][NPT];
     float amax_l = 0.0f;
     int pixb[NPT], pi[NPT], pj[NPT];        // patch index of the position's (a = 0, b = 0) entry; its (i, j); j < 0: no position
     int pwr_cur = 1;
+    PK_T_INIT;
 
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        if (step + 1 < nsteps) issue(p_nx1, cur ^ 1);
+        PK_T(0);
+        const bool has_next = step + 1 < nsteps;
         if (p_cur.c == 0) {
 #pragma unroll
             for (int ph = 0; ph < 4; ++ph)
@@ -471,9 +520,11 @@ __global__ void __launch_bounds__(64 * WCO * WQ) pkconv_up_kernel(const PkConvK 
                         d = mfma16(al[ct], bh[pt][s], d);
                         d = mfma16(ah[ct], bl[pt][s], d);
                     }
+                if (has_next && tap * PPT < NPW) issue(p_nx1, cur ^ 1, tap * PPT, min((tap + 1) * PPT, NPW));
                 if (tap % 3 == 2) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        PK_T(2);
         if (p_cur.c == a.n_chunks - 1) {                    // ---- epilogue: the four phases of a position as two float2 rows ----
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
@@ -496,6 +547,7 @@ __global__ void __launch_bounds__(64 * WCO * WQ) pkconv_up_kernel(const PkConvK 
                 }
             }
         }
+        PK_T(3);
         p_cur = p_nx1;
         advance(p_nx1);
     }
@@ -504,6 +556,7 @@ __global__ void __launch_bounds__(64 * WCO * WQ) pkconv_up_kernel(const PkConvK 
         for (int off = 32; off > 0; off >>= 1) amax_l = fmaxf(amax_l, __shfl_xor(amax_l, off, kWave));
         if (lane == 0) atomic_max_nonneg(a.out_amax + (((int)blockIdx.x * NW + wave) & (kAmaxSlots - 1)) * kAmaxStride, amax_l);
     }
+    PK_T_DONE(NW);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -738,13 +791,19 @@ static int launch_up(PkConvK k, hipStream_t st, const char* what) {
     static_assert(lds <= 160 * 1024, "LDS budget");
     E3DGE_REQUIRE(k.Co % (32 * NCTB) == 0, "%s: Co=%d not a multiple of %d", what, k.Co, 32 * NCTB);
     k.co_blocks = k.Co / (32 * NCTB);
-    k.cw = k.W + 1 < 129 ? k.W + 1 : 129;
-    k.nblk = (k.W + 1 + k.cw - 1) / k.cw;
-    k.cwl = k.W + 1 - (k.nblk - 1) * k.cw;
-    for (int wdt : {k.cw, k.cwl}) {
-        const int rows = (Q - 1) / wdt + 3;
-        E3DGE_REQUIRE(rows * (wdt + 1) <= kUpNpixMax || (k.H + 2) * (wdt + 1) <= kUpNpixMax, "%s: patch of a %d-column block exceeds the LDS plane", what, wdt);
+    // column blocks: the fewest equal-width blocks whose patch (rows spanned by Q consecutive positions + 1, block width + 1
+    // columns) fits the LDS plane.  Q = 256: 65 -> one block, 129 -> one, 257 -> 129 + 128, 513 -> 4 x 103 + 101.
+    auto fits = [&](int wdt) {
+        int rows = (Q - 1) / wdt + 3;
+        if (rows > k.H + 2) rows = k.H + 2;
+        return rows * (wdt + 1) <= kUpNpixMax;
+    };
+    k.nblk = 0;
+    for (int nb = 1; nb <= k.W + 1 && nb <= 256; ++nb) {
+        const int cw = (k.W + 1 + nb - 1) / nb, cwl = k.W + 1 - (nb - 1) * cw;
+        if (cwl >= 1 && fits(cw) && fits(cwl)) { k.nblk = nb; k.cw = cw; k.cwl = cwl; break; }
     }
+    E3DGE_REQUIRE(k.nblk > 0, "%s: no column blocking of %d positions fits the LDS plane", what, k.W + 1);
     k.tpf = ((k.H + 1) * k.cw + Q - 1) / Q;
     k.tpl = ((k.H + 1) * k.cwl + Q - 1) / Q;
     const int64_t n_tiles = (int64_t)k.B * k.co_blocks * ((int64_t)(k.nblk - 1) * k.tpf + k.tpl);

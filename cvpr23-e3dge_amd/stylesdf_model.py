@@ -711,7 +711,7 @@ class Decoder(nn.Module):
         """Labels of the launches of one packed forward, in the order of `kernel_ms`."""
         names = ["styles", "amax(features)", "pack(features)", "weights", "conv1", "to_rgb1"]
         for u in range(len(self.to_rgbs)):
-            names += [f"up{u}.convT", f"up{u}.blur", f"conv{u}", f"to_rgb{u}"]
+            names += [f"L{u}.convT", f"L{u}.blur", f"L{u}.conv", f"L{u}.to_rgb"]
         return names
 
     def dec2_unpack(self, index, features_shape):

@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--oracle", action="store_true")
     ap.add_argument("--sweep", action="store_true")
+    ap.add_argument("--timing", action="store_true", help="-DE3DGE_PK_TIMING build (E3DGE_LIB_PATH): per-phase cycles of the convolutions")
     ap.add_argument("--scale", type=float, default=0.5, help="std of the synthetic feature map")
     a = ap.parse_args()
     torch.manual_seed(0)
@@ -105,6 +106,19 @@ def main():
         errs["img"] = [float((img - ref_img).abs().max()), float(ref_img.abs().max())]
         emit(what="packed_vs_planar [max abs err, max abs ref]", **tag, **errs, finite=bool(torch.isfinite(img).all()))
         emit(what="kernel_ms", **tag, names=dec.dec2_launch_names(), ms=[round(x, 4) for x in ms], total=round(sum(ms), 4))
+        if a.timing:
+            st = dec._dec2_state(a.batch, a.res, torch.device(DEV))
+            am = st['amax'].cpu()
+            rows = {"conv1": 1}
+            for u in range(len(dec.to_rgbs)):
+                rows[f"L{u}.convT"] = 2 + 3 * u
+                rows[f"L{u}.conv"] = 4 + 3 * u
+            for name, r in rows.items():
+                for wv, off in (("w0", 1), ("wl", 9)):
+                    d = am[r, off:off + 6].tolist()
+                    steps = max(d[5], 1)
+                    emit(what="phase_cycles_per_step", layer=name, wave=wv, steps=int(steps), total=round(d[4] / steps), wait_barrier=round(d[0] / steps),
+                         issue=round(d[1] / steps), mfma=round(d[2] / steps), epilogue=round(d[3] / steps))
         if a.oracle:
             from oracle import decoder_ref
             c = lambda t: t.detach().cpu()
@@ -140,7 +154,7 @@ def main():
                             out = dec._forward_packed(feats, wd, noise, kernel_ms=m)
                             acc.append(m)
                         med = [sorted(col)[len(col) // 2] for col in zip(*acc)]
-                        sel = {n: round(t, 4) for n, t in zip(names, med) if (key == "conv" and n.startswith("conv")) or (key == "convT" and n.endswith("convT"))}
+                        sel = {n: round(t, 4) for n, t in zip(names, med) if (key == "conv" and n.endswith("conv")) or (key == "conv" and n == "conv1") or (key == "convT" and n.endswith("convT"))}
                         emit(what="sweep", var=var, variant=v, **tag, ms=sel, img_err=float((out - ref_img).abs().max()))
                     except RuntimeError as e:
                         emit(what="sweep", var=var, variant=v, **tag, error=str(e)[:200])
