@@ -13,6 +13,7 @@
 #include "decoder_common.h"
 #include <stdlib.h>
 #include <math.h>
+#include <type_traits>
 
 namespace e3dge {
 
@@ -21,13 +22,20 @@ constexpr int kPkSlab = 9 * 2 * 1024;            // bytes of one weight slab: (3
 // -DE3DGE_PK_TIMING: waves 0 and NW-1 of workgroup 0 accumulate shader-cycle deltas per phase of a step (0: vmcnt + barrier,
 // 1: DMA issue, 2: fragment reads + MFMAs, 3: epilogue) and leave them in the unused floats of the output amax buffer's first
 // line (tools/dec2_check.py --timing).
+#ifndef E3DGE_PK_OVL
+#define E3DGE_PK_OVL 0
+#endif
+#ifndef E3DGE_PK_EPI_VALU
+#define E3DGE_PK_EPI_VALU 8      // VALU instructions of a finished tile's epilogue scheduled behind each MFMA of the next tile
+#endif
 #ifdef E3DGE_PK_TIMING
 #define PK_T(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[i] += now_ - tlast; tlast = now_; } while (0)
-#define PK_T_INIT unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter(); const unsigned long long tbegin = tlast
+#define PK_T_INIT unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter(); const unsigned long long tbegin = tlast
 #define PK_T_DONE(NW_) do { if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == (NW_) - 1) && a.out_amax) { \
         float* o_ = a.out_amax + 1 + (wave == 0 ? 0 : 8); \
         for (int i_ = 0; i_ < 4; ++i_) o_[i_] = (float)tacc[i_]; \
-        o_[4] = (float)(__builtin_readcyclecounter() - tbegin); o_[5] = (float)nsteps; } } while (0)
+        o_[4] = (float)(__builtin_readcyclecounter() - tbegin); o_[5] = (float)nsteps; \
+        if (wave == 0) for (int i_ = 0; i_ < 4; ++i_) a.out_amax[17 + i_] = (float)tacc[4 + i_]; } } while (0)
 #else
 #define PK_T(i) do { } while (0)
 #define PK_T_INIT do { } while (0)
@@ -176,6 +184,8 @@ struct PkConvK {
     float* t;                      // up-sampling: fp32 (B, Co, 2H+3, 2W+4), T(y, x) at [y + 1][x + 2]
     int* out_meta;
     float* out_amax;
+    // fused ToRGB of the last convolution (RGB variants): (B, 3, Co) table, (3) bias, skip (B, 3, H/2, W/2) or null, 4x4 FIR, out (B, 3, H, W)
+    const float* rgb_wm; const float* rgb_bias; const float* rgb_skip; const float* rgb_fir; float* rgb_out;
     float bias_amax, knorm, slope, act_scale;
     int B, Ci, Co, H, W;
     int n_chunks, noise_batch;
@@ -200,16 +210,21 @@ __device__ __forceinline__ int xcd_logical(int t, int n_tiles) {
 // ---- stride-1 3x3, pad 1 ---------------------------------------------------------------------------------------------
 // Workgroup tile: (32 NCT WCO) output channels x (NPY WY) rows x (32 NPX WX) columns; a wave owns NCT co-tiles x NPY x NPX
 // pixel tiles of 32 columns.  Steps = (tile, 16-channel chunk) of a persistent workgroup; two LDS stages; per step ONE barrier:
-//     wait for my DMA pieces of this step | barrier | issue the DMA of step + 1 | 9 taps of MFMAs from this stage | [epilogue]
+//     wait for my DMA pieces of this step | barrier | 9 taps of MFMAs from this stage, the DMA pieces of step + 1 dealt out
+//     behind the first six taps | [epilogue]
 // The patch (+halo) of a step is four planes [k-half][hi|lo] of NPIX 16-byte entries, fetched as 1-KiB pieces whose lanes walk
 // the patch row-major (the source address is per lane, the LDS side is linear); weight slabs are 18 pieces each.
-template <int NCT, int NPY, int NPX, int WCO, int WY, int WX>
+// RGB = true (last convolution of the decoder, tile covers all output channels): ToRGB (:531-541) happens in the epilogue --
+// the activation is reduced against the 3 x Co table (scale W) s from LDS, + bias + FIR-up-sampled skip -- and is never stored.
+template <int NCT, int NPY, int NPX, int WCO, int WY, int WX, bool RGB>
 __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkConvK a) {
-    constexpr int NW = WCO * WY * WX;
+    static_assert(!RGB || WCO == 1, "fused ToRGB needs every output channel of a pixel in one wave");
+    constexpr int NW = WCO * WY * WX, NT = 64 * NW;
     constexpr int TH = NPY * WY, TW = 32 * NPX * WX, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, NPP = (NPIX + 63) / 64;
     constexpr int NCTB = NCT * WCO, XPLANE = NPIX * 16, XST = 4 * XPLANE, WST = NCTB * kPkSlab, STAGE = XST + WST;
-    constexpr int NWP = NCTB * 18, NPIECE = NWP + 4 * NPP;
+    constexpr int NWP = NCTB * 18, NPIECE = NWP + 4 * NPP, NPT = NPY * NPX;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pk[];
+    float* const tab = reinterpret_cast<float*>(smem_pk + 2 * STAGE);      // [Co] activation bias, then (RGB) [3][Co] table
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wx = wave % WX, wy = (wave / WX) % WY, wco = wave / (WX * WY);
@@ -223,11 +238,16 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
     const unsigned eb_in = (unsigned)a.in_meta[0];
     const float oscale = pow2_bits(eb_in - 21u);                     // 1 / (128 * 2^(141 - eb_in))
     const float nw = a.noise ? a.noise_w[0] : 0.0f;
-    const float nza = a.noise ? fabsf(nw) * amax_read(a.noise_amax, lane) : 0.0f;
-    const float bound = a.act_scale * (amax_read(a.in_amax, lane) * a.knorm * 1.002f + nza + a.bias_amax) * 1.001f;
-    const unsigned eb_out = scale_exponent(bound);
-    const float sc_out = pow2_bits(268u - eb_out);
-    if (blockIdx.x == 0 && tid == 0) a.out_meta[0] = (int)eb_out;
+    float sc_out = 1.0f;
+    if (!RGB) {
+        const float nza = a.noise ? fabsf(nw) * amax_read(a.noise_amax, lane) : 0.0f;
+        const float bound = a.act_scale * (amax_read(a.in_amax, lane) * a.knorm * 1.002f + nza + a.bias_amax) * 1.001f;
+        const unsigned eb_out = scale_exponent(bound);
+        sc_out = pow2_bits(268u - eb_out);
+        if (blockIdx.x == 0 && tid == 0) a.out_meta[0] = (int)eb_out;
+    }
+    for (int i = tid; i < a.Co; i += NT) tab[i] = a.bias[i];        // read after >= 1 step-top barrier
+    int b_tab = -1;
 
     struct Pos { int k, c, b, cb, ty, tx; };
     auto tile_of = [&](Pos& p) {
@@ -272,30 +292,158 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
     Pos p_nx1 = p_cur; advance(p_nx1);
     issue(p_cur, 0, 0, NPW);
 
-    f32x16 acc[NCT][NPY * NPX];
+    f32x16 acc[NCT][NPT];                                // the tile being accumulated
+    f32x16 fin[NCT][NPT];                                // the finished tile: its epilogue runs under the NEXT tile's first MFMAs
+    float nzr[NPT], nzf[NPT];                            // noise of the tile's pixels (being fetched / of the finished tile)
+    float skr[RGB ? NPT : 1][3], skf[RGB ? NPT : 1][3];  // (RGB) the FIR-up-sampled skip image at the tile's pixels, idem
+    float rgbp[RGB ? NPT : 1][3];                        // (RGB) partial channel sums of the finished tile
+    Pos p_fin{0, 0, 0, 0, 0, 0};
+    bool pending = false;
     float amax_l = 0.0f;
     const int prow0 = wy * NPY, pcol0 = wx * NPX * 32 + col;
+    const float kmul = RGB ? a.act_scale : a.act_scale * sc_out;      // lrelu(t) * act_scale * 2^k == (lrelu(t) * act_scale) * 2^k exactly
+    const float kinv = RGB ? 1.0f : 1.0f / sc_out;
     PK_T_INIT;
+
+    // One slice of a finished tile's epilogue: pixel tile pt, co-tile ct, channel group g4 = 2 gp + e (four values per lane):
+    // conv * 2^-s + noise_w noise + bias -> lrelu * sqrt 2 (:459-466, :500-507; same roundings), then either the f16 hi/lo split
+    // -- after the second group of a pair one 16-byte store per plane -- or (RGB) the ToRGB partial sums.  NH = 4 NCT NPT slices
+    // per tile, dealt out over the nine taps of the next step and interleaved with its MFMAs (sched_group_barrier below): in
+    // program order behind the MFMAs they would not overlap at all -- a wave issues in order, and its partner on the SIMD runs
+    // the same phase (measured: moving the epilogue into the MFMA phase without the interleave changed nothing).
+    constexpr int NH = 4 * NCT * NPT;
+    // E3DGE_PK_OVL: 0 never, 1 whenever two accumulator sets fit (NCT NPT <= 2; four tiles + their copy + the slices' temporaries
+    // spill 252-348 B), 2 only for the fused-ToRGB kernels
+    constexpr bool OVL = E3DGE_PK_OVL == 1 ? NCT * NPT <= 2 : (E3DGE_PK_OVL == 2 ? (RGB && NCT * NPT <= 2) : false);
+    unsigned shw[2], slw[2];                         // words of the pair's first group, kept until the second is done
+    float m8 = 0.0f;
+    auto epi_slice = [&](int h) {
+        const int e = h & 1, gp = (h >> 1) & 1, ct = (h >> 2) % NCT, pt = (h >> 2) / NCT;
+        const int b = p_fin.b, cot = p_fin.cb * NCTB + wco * NCT + ct;
+        const int oy = p_fin.ty * TH + prow0 + pt / NPX, ox = p_fin.tx * TW + pcol0 + 32 * (pt % NPX);
+        const bool ok = oy < a.H && ox < a.W;
+        const float nz = __fmul_rn(nw, nzf[pt]);
+        const f32x16& d = fin[ct][pt];
+        if (RGB && ct == 0 && gp == 0 && e == 0) { rgbp[pt][0] = 0.0f; rgbp[pt][1] = 0.0f; rgbp[pt][2] = 0.0f; }
+        const int g4 = 2 * gp + e, co0 = cot * 32 + 8 * g4 + 4 * half;
+        const f32x4 bs = *reinterpret_cast<const f32x4*>(tab + co0);
+        float v[4];
+        if (e == 0) m8 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = __fadd_rn(fmaf(d[4 * g4 + j], oscale, nz), bs[j]);        // (acc * 2^-s is exact: one rounding, as conv + noise)
+            v[j] = fmaxf(t, t * a.slope) * kmul;                                       // lrelu for 0 <= slope <= 1
+            m8 = fmaxf(m8, fabsf(v[j]));
+        }
+        if (RGB) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(tab + a.Co + c * a.Co + co0);
+                rgbp[pt][c] += fmaf(w4[3], v[3], fmaf(w4[2], v[2], fmaf(w4[1], v[1], w4[0] * v[0])));
+            }
+            if (ct == NCT - 1 && gp == 1 && e == 1) {   // last slice of this pixel tile: fold the halves, + bias + up-sampled skip
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rgbp[pt][c] += __shfl_xor(rgbp[pt][c], 32, kWave);
+                if (ok && half == 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        a.rgb_out[((int64_t)b * 3 + c) * a.H * a.W + (int64_t)oy * a.W + ox] = (rgbp[pt][c] + a.rgb_bias[c]) + skf[pt][c];
+                }
+            }
+            return;
+        }
+        unsigned h0, l0, h1, l1;
+        SPLIT2_TO(v[0], v[1], h0, l0);
+        SPLIT2_TO(v[2], v[3], h1, l1);
+        if (e == 0) { shw[0] = h0; shw[1] = h1; slw[0] = l0; slw[1] = l1; return; }
+        if (ok) amax_l = fmaxf(amax_l, m8);
+        // half exchange (v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second): afterwards lanes 0-31
+        // hold the whole 16-byte entry of group 2 gp, lanes 32-63 that of group 2 gp + 1 -> one 16-byte store per plane instead of
+        // two 8-byte ones (the epilogue was store-issue bound, guide T21)
+        auto r0 = __builtin_amdgcn_permlane32_swap(shw[0], h0, false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(shw[1], h1, false, false);
+        auto r2 = __builtin_amdgcn_permlane32_swap(slw[0], l0, false, false);
+        auto r3 = __builtin_amdgcn_permlane32_swap(slw[1], l1, false, false);
+        if (ok) {
+            unsigned char* dst = a.y + ((int64_t)(b * GO + cot * 4 + 2 * gp + half) * 2) * plane_b + ((int64_t)(oy + 1) * WP + ox + 1) * 16;
+            u32x4 eh, el;
+            eh[0] = r0[0]; eh[1] = r1[0]; eh[2] = r0[1]; eh[3] = r1[1];
+            el[0] = r2[0]; el[1] = r3[0]; el[2] = r2[1]; el[3] = r3[1];
+            *reinterpret_cast<u32x4*>(dst) = eh;
+            *reinterpret_cast<u32x4*>(dst + plane_b) = el;
+        }
+    };
 
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
         // my pieces of this step have landed; after the barrier everybody's have, and nobody still reads the other stage
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         PK_T(0);
-        const bool has_next = step + 1 < nsteps;
+        const bool has_next = step + 1 < nsteps, last_chunk = p_cur.c == a.n_chunks - 1;
+        const bool do_epi = pending;                     // (a tile's epilogue runs in the step after its last chunk)
         if (p_cur.c == 0) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-                for (int pt = 0; pt < NPY * NPX; ++pt) acc[ct][pt] = zero16();
+                for (int pt = 0; pt < NPT; ++pt) acc[ct][pt] = zero16();
         }
-        {
+        // (scale W) s of this tile's sample.  Written in the tile's SECOND step: during its first one other waves may still be reading the
+        // previous sample's table for the finished tile's epilogue; the host requires n_chunks >= 2, so a barrier lies before its readers.
+        if (RGB && p_cur.c == 1 && p_cur.b != b_tab) {
+            b_tab = p_cur.b;
+            for (int i = tid; i < 3 * a.Co; i += NT) tab[a.Co + i] = a.rgb_wm[(size_t)b_tab * 3 * a.Co + i];
+        }
+        // The epilogue's per-pixel inputs are requested here, while nothing else is in flight, and waited for behind tap 0 -- before
+        // this step's DMA pieces go out: a wait inside the epilogue would also wait for every DMA piece issued since (vmcnt is in order).
+        // (Branch-free: a load inside a divergent `if` gets its own s_waitcnt vmcnt(0) -- twelve serialized L2 round trips per pixel tile
+        // for the skip image in the first version of this block.  Indices are clamped into the image, out-of-image taps get weight 0.)
+        if (last_chunk) {
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+                const int oy = p_cur.ty * TH + prow0 + pt / NPX, ox = p_cur.tx * TW + pcol0 + 32 * (pt % NPX);
+                const int oyc = min(oy, a.H - 1), oxc = min(ox, a.W - 1);
+                nzr[pt] = a.noise ? a.noise[(int64_t)(a.noise_batch > 1 ? p_cur.b : 0) * a.H * a.W + (int64_t)oyc * a.W + oxc] : 0.0f;
+                if (RGB) {
+                    const int h2 = a.H >> 1, w2 = a.W >> 1;
+                    float sv[3][4], fw[4];
+#pragma unroll
+                    for (int p2 = 0; p2 < 2; ++p2) {        // upfirdn2d(skip, fir, up=2, pad=(2,1)): taps and order of e3dge_upfirdn2d
+                        const int ky = (oyc & 1) + 2 * p2, iy = (oyc + ky - 2) >> 1;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int kx = (oxc & 1) + 2 * e, ix = (oxc + kx - 2) >> 1;
+                            const bool in = iy >= 0 && iy < h2 && ix >= 0 && ix < w2;
+                            const int off = min(max(iy, 0), h2 - 1) * w2 + min(max(ix, 0), w2 - 1);
+                            const float f = a.rgb_skip ? a.rgb_fir[(3 - ky) * 4 + (3 - kx)] : 0.0f;
+                            fw[2 * p2 + e] = in ? f : 0.0f;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c)
+                                sv[c][2 * p2 + e] = a.rgb_skip ? a.rgb_skip[((int64_t)p_cur.b * 3 + c) * h2 * w2 + off] : 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float uacc = 0.0f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) uacc = fmaf(sv[c][q], fw[q], uacc);     // (a tap with weight 0 leaves the chain's value unchanged)
+                        skr[pt][c] = uacc;
+                    }
+                }
+            }
+        }
+        // The nine taps exist twice -- with and without the finished tile's epilogue -- because the slices must share basic blocks
+        // with the MFMAs for the scheduler to thread them in between (a runtime `if (do_epi)` around each slice kept them apart).
+        auto taps = [&](auto epi_tag) {
+            constexpr bool EPI = decltype(epi_tag)::value;
             const unsigned char* xb = smem_pk + cur * STAGE + (size_t)(half * 2) * XPLANE;
             const unsigned char* wb = smem_pk + cur * STAGE + XST + (size_t)(wco * NCT) * kPkSlab + lane * 16;
+#ifdef E3DGE_PK_TIMING
+            unsigned long long tl2 = __builtin_readcyclecounter();
+#endif
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int ky = tap / 3, kx = tap % 3;
-                u32x4 ah[NCT], al[NCT], bh[NPY * NPX], bl[NPY * NPX];
+                u32x4 ah[NCT], al[NCT], bh[NPT], bl[NPT];
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) {
                     ah[ct] = *reinterpret_cast<const u32x4*>(wb + ct * kPkSlab + (tap * 2 + 0) * 1024);
@@ -312,77 +460,71 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-                    for (int pt = 0; pt < NPY * NPX; ++pt) {
+                    for (int pt = 0; pt < NPT; ++pt) {
                         f32x16& d = acc[ct][pt];
                         d = mfma16(ah[ct], bh[pt], d);
                         d = mfma16(al[ct], bh[pt], d);
                         d = mfma16(ah[ct], bl[pt], d);
                     }
-                if (has_next && tap * PPT < NPW) issue(p_nx1, cur ^ 1, tap * PPT, min((tap + 1) * PPT, NPW));
-                if (tap % 3 == 2) __builtin_amdgcn_sched_barrier(0);      // keep the fragment reads of later taps from piling up
-            }
-        }
-        PK_T(2);
-        if (p_cur.c == a.n_chunks - 1) {                    // ---- epilogue: noise + bias + lrelu, then split for the next conv ----
-            const int b = p_cur.b;
+                if (EPI) {                               // this tap's slices of the finished tile, threaded between its MFMAs
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const int cot = p_cur.cb * NCTB + wco * NCT + ct;
+                    for (int h = 0; h < NH; ++h)
+                        if (h * 9 / NH == tap) epi_slice(h);
 #pragma unroll
-                for (int py = 0; py < NPY; ++py)
-#pragma unroll
-                    for (int px = 0; px < NPX; ++px) {
-                        const int oy = p_cur.ty * TH + prow0 + py, ox = p_cur.tx * TW + pcol0 + 32 * px;
-                        const bool ok = oy < a.H && ox < a.W;
-                        const float nz = (ok && a.noise) ? __fmul_rn(nw, a.noise[(int64_t)(a.noise_batch > 1 ? b : 0) * a.H * a.W + (int64_t)oy * a.W + ox]) : 0.0f;
-                        const f32x16& d = acc[ct][py * NPX + px];
-#pragma unroll
-                        for (int gp = 0; gp < 2; ++gp) {         // channel groups 2 gp, 2 gp + 1 of this co-tile
-                            unsigned hw[2][2], lw[2][2];         // [group][word]: this lane's four channels of each group
-#pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const int g4 = 2 * gp + e, co0 = cot * 32 + 8 * g4 + 4 * half;
-                                float v[4];
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    float t = __fadd_rn(__fadd_rn(d[4 * g4 + j] * oscale, nz), a.bias[co0 + j]);
-                                    t = (t > 0.0f ? t : t * a.slope) * a.act_scale;
-                                    if (ok) amax_l = fmaxf(amax_l, fabsf(t));
-                                    v[j] = t * sc_out;
-                                }
-                                SPLIT2_TO(v[0], v[1], hw[e][0], lw[e][0]);
-                                SPLIT2_TO(v[2], v[3], hw[e][1], lw[e][1]);
-                            }
-                            // half exchange (v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second): afterwards
-                            // lanes 0-31 hold the whole 16-byte entry of group 2 gp, lanes 32-63 that of group 2 gp + 1 -> one 16-byte
-                            // store per plane instead of two 8-byte ones (the epilogue was store-issue bound, guide T21)
-#pragma unroll
-                            for (int w = 0; w < 2; ++w) {
-                                auto rh = __builtin_amdgcn_permlane32_swap(hw[0][w], hw[1][w], false, false);
-                                hw[0][w] = rh[0]; hw[1][w] = rh[1];
-                                auto rl = __builtin_amdgcn_permlane32_swap(lw[0][w], lw[1][w], false, false);
-                                lw[0][w] = rl[0]; lw[1][w] = rl[1];
-                            }
-                            if (ok) {
-                                unsigned char* dst = a.y + ((int64_t)(b * GO + cot * 4 + 2 * gp + half) * 2) * plane_b + ((int64_t)(oy + 1) * WP + ox + 1) * 16;
-                                u32x4 eh, el;
-                                eh[0] = hw[0][0]; eh[1] = hw[0][1]; eh[2] = hw[1][0]; eh[3] = hw[1][1];
-                                el[0] = lw[0][0]; el[1] = lw[0][1]; el[2] = lw[1][0]; el[3] = lw[1][1];
-                                *reinterpret_cast<u32x4*>(dst) = eh;
-                                *reinterpret_cast<u32x4*>(dst + plane_b) = el;
-                            }
-                        }
+                    for (int i = 0; i < 3 * NCT * NPT; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, E3DGE_PK_EPI_VALU, 0);   // then this many VALU instructions of the slices
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (tap == 0 && last_chunk) {
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt) {
+                        asm volatile("" : "+v"(nzr[pt]));      // the compiler's vmcnt wait lands here
+                        if (RGB) asm volatile("" : "+v"(skr[pt][0]), "+v"(skr[pt][1]), "+v"(skr[pt][2]));
+                    }
+                }
+                if (has_next && tap * PPT < NPW) issue(p_nx1, cur ^ 1, tap * PPT, min((tap + 1) * PPT, NPW));
+                if (tap % 3 == 2 || EPI) __builtin_amdgcn_sched_barrier(0);      // keep the fragment reads of later taps from piling up
+#ifdef E3DGE_PK_TIMING
+                if (tap == 0 || tap == 8) { const unsigned long long n2_ = __builtin_readcyclecounter();
+                    tacc[(EPI ? 4 : 6) + (tap == 8)] += n2_ - tl2; tl2 = n2_; }
+#endif
+            }
+        };
+        if (OVL && do_epi) taps(std::true_type{}); else taps(std::false_type{});
+        PK_T(2);
+        pending = false;
+        if (last_chunk) {                                // hand the tile over; its epilogue runs during the next step (or after the loop)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) fin[ct][pt] = acc[ct][pt];
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+                nzf[pt] = nzr[pt];
+                if (RGB) { skf[pt][0] = skr[pt][0]; skf[pt][1] = skr[pt][1]; skf[pt][2] = skr[pt][2]; }
+            }
+            p_fin = p_cur;
+            pending = OVL;
+            if (!OVL) {
+#pragma unroll
+                for (int h = 0; h < NH; ++h) epi_slice(h);
             }
         }
         PK_T(3);
         p_cur = p_nx1;
         advance(p_nx1);
     }
-    if (a.out_amax) {
+    if (RGB) __syncthreads();                              // the table of the last tile's sample may have been written in the last step
+    if (pending) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) epi_slice(h);
+    }
+    if (!RGB && a.out_amax) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) amax_l = fmaxf(amax_l, __shfl_xor(amax_l, off, kWave));
-        if (lane == 0) atomic_max_nonneg(a.out_amax + (((int)blockIdx.x * NW + wave) & (kAmaxSlots - 1)) * kAmaxStride, amax_l);
+        if (lane == 0) atomic_max_nonneg(a.out_amax + (((int)blockIdx.x * NW + wave) & (kAmaxSlots - 1)) * kAmaxStride, amax_l * kinv);
     }
     PK_T_DONE(NW);
 }
@@ -590,22 +732,23 @@ __global__ void __launch_bounds__(256) pk_blur_kernel(const PkBlurK a) {
     const float sc = pow2_bits(268u - eb);
     if (blockIdx.x == 0 && tid == 0) a.out_meta[0] = (int)eb;
 
-    // stage 8 planes of 19 x 68 (T rows oy0 - 1 .., columns ox0 - 1 ..; the T buffer carries its own zero border)
-    constexpr int NE = 8 * kPbU * kPbPitch, NIT = (NE + 255) / 256;
+    // stage 8 planes of 19 rows x 17 groups of four columns: T rows oy0 - 1 .., columns ox0 - 2 .. (one column more than the taps
+    // need: with T(y, x) stored at [y + 1][x + 2] every group is one aligned 16-byte load; the T buffer carries its own zero border)
+    constexpr int NGR = kPbPitch / 4, NE = 8 * kPbU * NGR, NIT = (NE + 255) / 256;
     const float* __restrict__ tb = a.t + ((int64_t)b * a.C + 8 * g) * TR * TP;
-    float sv[NIT];
+    f32x4 sv[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int idx = min(tid + it * 256, NE - 1);
-        const int ch = idx / (kPbU * kPbPitch), rem = idx - ch * (kPbU * kPbPitch);
-        const int r = rem / kPbPitch, c = rem - r * kPbPitch;
-        const int row = min(oy0 + r, TR - 1), cc = min(ox0 + c + 1, TP - 1);       // T(y, x) lives at [y + 1][x + 2]
-        sv[it] = tb[((int64_t)ch * TR + row) * TP + cc];
+        const int ch = idx / (kPbU * NGR), rem = idx - ch * (kPbU * NGR);
+        const int r = rem / NGR, cg = rem - r * NGR;
+        const int row = min(oy0 + r, TR - 1), cc = min(ox0 + 4 * cg, TP - 4);
+        sv[it] = *reinterpret_cast<const f32x4*>(tb + ((int64_t)ch * TR + row) * TP + cc);
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int idx = tid + it * 256;
-        if (idx < NE) u[idx] = sv[it];
+        if (idx < NE) *reinterpret_cast<f32x4*>(u + 4 * idx) = sv[it];       // u[ch][r][4 cg ..]: the same linear order
     }
     float kf[4][4];
 #pragma unroll
@@ -640,7 +783,7 @@ __global__ void __launch_bounds__(256) pk_blur_kernel(const PkBlurK a) {
 #pragma unroll
                 for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(in[j + kx], kf[ky][kx], acc[j]);
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(in[j + kx + 1], kf[ky][kx], acc[j]);     // u column c <-> x = ox0 - 2 + c
             }
             const float bv = a.bias ? a.bias[8 * g + ch] : 0.0f;
 #pragma unroll
@@ -656,21 +799,32 @@ __global__ void __launch_bounds__(256) pk_blur_kernel(const PkBlurK a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) SPLIT2_TO(v[0][j], v[1][j], hi[j][cp], lo[j][cp]);
     }
-    if (row_ok) {
-        const int64_t plane = (int64_t)(R + 2) * (R + 2);
-        u32x4* __restrict__ dst = reinterpret_cast<u32x4*>(a.y) + ((int64_t)(b * G + g) * 2) * plane + (int64_t)(oy + 1) * (R + 2) + ox + 1;
+    // Store through LDS: a thread holds four ADJACENT pixels, so its 16-byte stores would leave 48-byte gaps between lanes (every
+    // store instruction touching 32 lines for 1 KiB).  The staging buffer is free now: entries go to LDS as [plane][row][pixel]
+    // and come back in linear order -- each store instruction then writes 64 consecutive entries of one output row.
+    __syncthreads();
+    u32x4* const eb_lds = reinterpret_cast<u32x4*>(u);              // 2 planes x 16 rows x 64 pixels x 16 B = 32 KiB
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (ox + j < R) { dst[j] = hi[j]; dst[plane + j] = lo[j]; }
+    for (int j = 0; j < 4; ++j) {
+        eb_lds[(0 * kPbRows + ty) * kPbCols + 4 * tx + j] = hi[j];
+        eb_lds[(1 * kPbRows + ty) * kPbCols + 4 * tx + j] = lo[j];
+    }
+    __syncthreads();
+    {
+        const int64_t plane = (int64_t)(R + 2) * (R + 2);
+        u32x4* __restrict__ dst = reinterpret_cast<u32x4*>(a.y) + ((int64_t)(b * G + g) * 2) * plane;
+#pragma unroll
+        for (int it = 0; it < 2 * kPbRows * kPbCols / 256; ++it) {
+            const int e = tid + it * 256;
+            const int hl = e / (kPbRows * kPbCols), rem = e - hl * (kPbRows * kPbCols);
+            const int r = rem / kPbCols, c = rem - r * kPbCols;
+            if (oy0 + r < R && ox0 + c < R) dst[hl * plane + (int64_t)(oy0 + r + 1) * (R + 2) + ox0 + c + 1] = eb_lds[e];
+        }
     }
     if (a.out_amax) {
-        __shared__ float part[4];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) amax_l = fmaxf(amax_l, __shfl_xor(amax_l, off, kWave));
-        if (lane == 0) part[tid >> 6] = amax_l;
-        __syncthreads();
-        if (tid == 0) atomic_max_nonneg(a.out_amax + ((int)blockIdx.x & (kAmaxSlots - 1)) * kAmaxStride,
-                                        fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
+        if (lane == 0) atomic_max_nonneg(a.out_amax + (((int)blockIdx.x * 4 + (tid >> 6)) & (kAmaxSlots - 1)) * kAmaxStride, amax_l);
     }
 }
 
@@ -762,19 +916,22 @@ pk_torgb_kernel(float* __restrict__ y, const unsigned char* __restrict__ x, cons
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NCT, int NPY, int NPX, int WCO, int WY, int WX>
+template <int NCT, int NPY, int NPX, int WCO, int WY, int WX, bool RGB = false>
 static int launch_s1(PkConvK k, hipStream_t st, const char* what) {
     constexpr int TH = NPY * WY, TW = 32 * NPX * WX, NPIX = (TH + 2) * (TW + 2), NCTB = NCT * WCO;
-    constexpr int lds = 2 * (4 * NPIX * 16 + NCTB * kPkSlab);
-    static_assert(lds <= 160 * 1024, "LDS budget");
+    constexpr int lds_stages = 2 * (4 * NPIX * 16 + NCTB * kPkSlab);
+    static_assert(lds_stages <= 160 * 1024, "LDS budget");
+    const int lds = lds_stages + 4 * k.Co * (RGB ? 4 : 1);         // + bias table (+ ToRGB table)
+    E3DGE_REQUIRE(lds <= 160 * 1024, "%s: LDS budget with Co=%d", what, k.Co);
     E3DGE_REQUIRE(k.Co % (32 * NCTB) == 0, "%s: Co=%d not a multiple of %d", what, k.Co, 32 * NCTB);
     k.tiles_y = (k.H + TH - 1) / TH;
     k.tiles_x = (k.W + TW - 1) / TW;
     k.co_blocks = k.Co / (32 * NCTB);
+    E3DGE_REQUIRE(!RGB || (k.co_blocks == 1 && k.n_chunks >= 2 && k.rgb_wm && k.rgb_bias && k.rgb_out), "%s: fused ToRGB needs one co-block and >= 32 input channels", what);
     const int64_t n_tiles = (int64_t)k.B * k.co_blocks * k.tiles_y * k.tiles_x;
     E3DGE_REQUIRE(n_tiles < ((int64_t)1 << 30), "%s: too many tiles", what);
     k.n_tiles = (int)n_tiles;
-    auto fn = &pkconv_s1_kernel<NCT, NPY, NPX, WCO, WY, WX>;
+    auto fn = &pkconv_s1_kernel<NCT, NPY, NPX, WCO, WY, WX, RGB>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
     int grid = 256 * ((160 * 1024) / lds >= 2 ? 2 : 1);
@@ -823,7 +980,18 @@ static int shape_override(const char* name) {      // E3DGE_DEC2_S1 / E3DGE_DEC2
     return (v && *v) ? atoi(v) : -1;
 }
 
+// can the last convolution also do ToRGB?  (one co-block, every channel of a pixel in one wave: the 32- and 64-channel tiles)
+static bool s1_can_fuse_rgb(int co, int ci) {
+    const char* v = getenv("E3DGE_DEC2_FUSE_RGB");
+    if (v && *v && atoi(v) == 0) return false;
+    return (co == 32 || co == 64) && ci >= 32;
+}
+
 static int conv_s1(PkConvK k, hipStream_t st) {
+    if (k.rgb_out) {
+        if (k.Co == 32) return launch_s1<1, 1, 2, 1, 8, 1, true>(k, st, "dec2 conv+rgb<32co,8x64>");
+        return launch_s1<2, 1, 2, 1, 8, 1, true>(k, st, "dec2 conv+rgb<64co,8x64>");
+    }
     int v = shape_override("E3DGE_DEC2_S1");
     const int64_t px = (int64_t)k.H * k.W;
     if (v < 0) {
@@ -844,9 +1012,9 @@ static int conv_s1(PkConvK k, hipStream_t st) {
 
 static int conv_up(PkConvK k, hipStream_t st) {
     int v = shape_override("E3DGE_DEC2_UP");
-    if (v < 0) {
-        if (k.Co % 64 != 0) v = 2;
-        else if ((int64_t)k.H * k.W <= 64 * 64) v = 0;
+    if (v < 0) {      // measured per layer (tools/dec2_check.py --sweep, 1024^2 / channel multiplier 2)
+        if (k.Co % 64 != 0) v = 3;
+        else if ((int64_t)k.H * k.W <= 64 * 64) v = 3;
         else v = 1;
     }
     if (k.Co % 64 != 0 && v != 2 && v != 3) v = 2;
@@ -1037,14 +1205,19 @@ extern "C" int e3dge_dec2_forward(const E3dgeDec2Plan* P, e3dge_stream_t stream)
                 pk_blur_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(k);
             DEC2_STEP(check_launch("dec2 blur"));
         }
+        const bool fuse_rgb = u == P->n_up - 1 && s1_can_fuse_rgb(cc.co, cc.ci);   // the last activation is never stored
         {   // stride-1 conv
             PkConvK k = conv_args(cc, res);
             k.x = reinterpret_cast<const unsigned char*>(P->act[2 + 2 * u]); k.in_meta = P->meta + 2 + 2 * u; k.in_amax = am_u;
             k.y = reinterpret_cast<unsigned char*>(P->act[3 + 2 * u]); k.out_meta = P->meta + 3 + 2 * u; k.out_amax = am_v;
+            if (fuse_rgb) {
+                k.rgb_wm = P->rgb[u].wm; k.rgb_bias = P->rgb[u].bias; k.rgb_skip = skip; k.rgb_fir = P->fir_up; k.rgb_out = P->rgb[u].out;
+            }
             DEC2_STEP(conv_s1(k, st));
         }
-        DEC2_STEP(launch_torgb(P->rgb[u].out, reinterpret_cast<const unsigned char*>(P->act[3 + 2 * u]), P->meta + 3 + 2 * u, P->rgb[u].wm,
-                               P->rgb[u].bias, skip, P->fir_up, B, P->rgb[u].ci, res, st));
+        if (fuse_rgb) mark();         // (keeps the kernel_ms slots aligned: this level's ToRGB entry reads 0)
+        else DEC2_STEP(launch_torgb(P->rgb[u].out, reinterpret_cast<const unsigned char*>(P->act[3 + 2 * u]), P->meta + 3 + 2 * u, P->rgb[u].wm,
+                                    P->rgb[u].bias, skip, P->fir_up, B, P->rgb[u].ci, res, st));
         skip = P->rgb[u].out;
         prev_act = 3 + 2 * u;
     }

@@ -550,7 +550,7 @@ class Decoder(nn.Module):
             return False
         if features.device.type != "cuda" or features.dtype != torch.float32 or latent.dtype != torch.float32:
             return False
-        if features.ndim != 4 or features.shape[2] != features.shape[3] or features.shape[2] < 4:
+        if features.ndim != 4 or features.shape[2] != features.shape[3] or features.shape[2] < 4 or features.shape[2] % 2:
             return False
         if len(self.to_rgbs) > _lib.DEC2_MAX_UP or features.shape[0] < 1:
             return False

@@ -70,6 +70,7 @@ def test_every_stage_against_the_planar_kernels(gen256):
     wd = wd[:, :dec.n_latent].contiguous()
     feats = (0.5 * torch.randn(1, 256, 64, 64, device=DEV, generator=torch.Generator(DEV).manual_seed(3))).contiguous()
     noise = [getattr(dec.noises, f"noise_{i}") for i in range(dec.num_layers)]
+    os.environ["E3DGE_DEC2_FUSE_RGB"] = "0"          # keep the last activation (the default build folds ToRGB into the last conv)
     with torch.no_grad():
         os.environ["E3DGE_DECODER"] = "planar"
         try:
@@ -93,13 +94,16 @@ def test_every_stage_against_the_planar_kernels(gen256):
             got = dec.dec2_unpack(1 + k, feats.shape)
             errs[f"act{1 + k}"] = maxerr(got, r) / float(r.abs().max())
         errs["img"] = maxerr(img, ref_img)
+        os.environ.pop("E3DGE_DEC2_FUSE_RGB")
+        img_fused = dec._forward_packed(feats, wd, noise)
+        errs["img_fused_rgb"] = maxerr(img_fused, ref_img)
     record("dec2_stages_256", **errs)
     for k, v in errs.items():
-        assert v <= (IMG_ATOL if k == "img" else 2e-5), (k, v)
+        assert v <= (IMG_ATOL if k.startswith("img") else 2e-5), (k, v)
     # the default Decoder.forward takes the packed path and returns the same tensor values
     with torch.no_grad():
         img2, _ = dec(feats, [wd], input_is_latent=True, randomize_noise=False)
-    assert torch.equal(img2, img)
+    assert torch.equal(img2, img_fused)
 
 
 @pytest.mark.parametrize("B,res,size,per_sample_noise", [(2, 16, 128, True), (1, 8, 32, False), (3, 16, 64, False)])

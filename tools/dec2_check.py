@@ -98,7 +98,8 @@ def main():
         img = dec._forward_packed(feats, wd, noise, kernel_ms=ms)
         torch.cuda.synchronize()
         errs = {}
-        for k, ref in enumerate(ref_stages):
+        fused = os.environ.get("E3DGE_DEC2_FUSE_RGB", "1") != "0"
+        for k, ref in enumerate(ref_stages[:-1] if fused else ref_stages):     # (the last activation is not stored when ToRGB is fused)
             got = dec.dec2_unpack(1 + k, feats.shape)
             errs[f"act{1 + k}"] = [float((got - ref).abs().max()), float(ref.abs().max())]
         got0 = dec.dec2_unpack(0, feats.shape)
@@ -119,6 +120,8 @@ def main():
                     steps = max(d[5], 1)
                     emit(what="phase_cycles_per_step", layer=name, wave=wv, steps=int(steps), total=round(d[4] / steps), wait_barrier=round(d[0] / steps),
                          issue=round(d[1] / steps), mfma=round(d[2] / steps), epilogue=round(d[3] / steps))
+                t4 = am[r, 17:21].tolist()
+                emit(what="tap_cycles_total(w0)", layer=name, epi_step_tap0=round(t4[0]), epi_step_taps1_8=round(t4[1]), other_step_tap0=round(t4[2]), other_step_taps1_8=round(t4[3]))
         if a.oracle:
             from oracle import decoder_ref
             c = lambda t: t.detach().cpu()
