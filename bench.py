@@ -28,6 +28,10 @@ Extra objects on the JSON line:
   train_step_ms BASELINE configs[4], renderer part: stage-1 step at 64x64x18 with the eikonal losses, fwd + bwd.
   inversion_fwd_ms  pass #1 + texture head + pass #2 + decoder to 1024^2, one image (inversion_fwd_graph_ms: the same launches
                 replayed as one HIP graph).
+  train_step    (all ranks) the same step with the encoder's 1.03 GB fp32 gradient all-reduce (trainer.py:1737-1778 through DDP,
+                dist_utils.py:108-130) emulated on a side stream: allreduce_ms, overlapped ms, overlap_frac.
+  inversion     per-kernel table of the inversion forward (HIP events): ms, bound, achieved / peak, frac for both render passes, the
+                texture head and every launch of the decoder.
   cpu_baseline  the oracle restatement (oracle/renderer_ref.py, "port": bit-identical to the reference's PyTorch path on
                 the golden vectors) timed on this host's cores on a bounded sample.
 """
@@ -50,7 +54,38 @@ FLOP_PER_RAY = 2 * MAC_PER_POINT * N_SAMPLES                               # 25.
 BYTES_PER_RAY = (264 + 5 * N_SAMPLES) * 4                                  # mandatory outputs, 1,536 B
 PEAK_F32_MFMA_TFLOPS = 157.3                                               # MI355X_MICROARCH.md (dense fp32 MFMA)
 PEAK_F16_MFMA_TFLOPS = 2500.0                                              # dense f16 / bf16 MFMA (NOT the 2:1-sparse figure)
-TRAFFIC_FILE = os.path.join(REPO, "profiles", "traffic_pmc.json")          # written by tools/profile_bench.sh (PMC passes)
+TRAFFIC_FILE = os.path.join(REPO, "profiles", "traffic_pmc.json")          # written by tools/refresh_traffic.sh (PMC passes)
+PEAK_HBM_GBPS = 8000.0                                                     # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s copy ceiling)
+C3_IMAGES = 2824                                                           # project/utils/setup/train_setup.py:332
+ENCODER_GRAD_BYTES = 1.03e9                                                # fp32 gradient volume of the encoder per step
+
+
+def kernel_source_digest():
+    """Digest of the render-kernel sources: stamps profiles/traffic_pmc.json so that a stale PMC figure is detectable."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("siren.hip", "siren16.h", "siren_common.h"):
+        with open(os.path.join(REPO, "cvpr23-e3dge_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pin_rank(local_rank, world):
+    """One contiguous core set per rank (8 Python launchers on a 256-core host would otherwise share cores and oversubscribe the
+    BLAS / OpenMP pools); returns (cores, threads)."""
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None, None
+    per = max(1, len(avail) // max(world, 1))
+    mine = avail[local_rank * per:(local_rank + 1) * per] or avail
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None, None
+    nt = max(1, min(8, len(mine)))
+    os.environ.setdefault("OMP_NUM_THREADS", str(nt))
+    return len(mine), nt
 
 
 def parse_args():
@@ -59,7 +94,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (metric config: 1)")
-    ap.add_argument("--c3-images", type=int, default=16, help="images per rank in the C3 leg")
+    ap.add_argument("--c3-images", type=int, default=0,
+                    help="images per rank in the C3 leg (0 = the whole evaluation set split over the ranks: ceil(2824 / N))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-inversion", action="store_true")
     ap.add_argument("--no-train-step", action="store_true")
@@ -116,18 +152,34 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or let bench.py start them)")
 
+    cores_pinned, host_threads = pin_rank(local_rank, world)
     import torch
+    if host_threads:
+        torch.set_num_threads(host_threads)
+    c3_per_rank = args.c3_images if args.c3_images > 0 else -(-C3_IMAGES // world)
     dist = None
     if args.dry_run:
+        # launcher / rendezvous / work-split check without a GPU: every rank reports its shard of the legs, rank 0 prints the plan
         import torch.distributed as dist
+        from e3dge_amd import sharded_eval as se
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         t = torch.ones(1)
         dist.all_reduce(t)
+        mine = torch.tensor([len(se.shard_indices(c3_per_rank * world, rank, world)), len(se.shard_indices(120, rank, world)),
+                             cores_pinned or 0], dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        g = torch.zeros(1024)                 # stands in for the 1.03 GB gradient bucket
+        dist.all_reduce(g)
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_joined": int(t.item()),
-                              "self_launched": os.environ.get("E3DGE_BENCH_SELF_LAUNCHED") == "1"}))
+                              "self_launched": os.environ.get("E3DGE_BENCH_SELF_LAUNCHED") == "1",
+                              "c3": {"images": c3_per_rank * world, "images_per_rank": [int(a[0]) for a in allr]},
+                              "c4": {"poses": 120, "poses_per_rank": [int(a[1]) for a in allr]},
+                              "train_step": {"allreduce_bytes": ENCODER_GRAD_BYTES, "ranks": world},
+                              "cores_per_rank": [int(a[2]) for a in allr], "host_threads": host_threads}))
         dist.destroy_process_group()
         return
     if not torch.cuda.is_available():
@@ -178,6 +230,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_ranks(x):
+        """[x of rank 0, ..., x of rank W-1]"""
+        if dist is None:
+            return [x]
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
     def timed_block(steps, with_events):
         """K steps between barriers; returns (elapsed_s max over ranks, mean kernel ms or None, last output)."""
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if with_events else None
@@ -191,8 +252,11 @@ def main():
             out = renderer.render_with_film(film, focal, poses, near, far)
             if ev:
                 ev[i][1].record()
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0                                     # this rank's own K steps (before the closing barrier)
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+        timed_block.own_s = own
         kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(steps, 1) if ev else None
         return elapsed, kern_ms, out
 
@@ -221,8 +285,10 @@ def main():
             ent = tj.get(mode)
             if ent and B == 1:
                 traffic = int(2 * ent["FETCH_SIZE_KB"] * 1024 + ent["WRITE_SIZE_KB"] * 1024)
+                stale = tj.get("kernel_source_digest") != kernel_source_digest()
                 tnote = (f"NOT measured in this run: PMC FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE per launch from "
-                         f"{os.path.relpath(TRAFFIC_FILE, REPO)} ({tj.get('source', 'separate rocprofv3 --pmc passes')})")
+                         f"{os.path.relpath(TRAFFIC_FILE, REPO)} (tools/refresh_traffic.sh, separate rocprofv3 --pmc passes; taken at git "
+                         f"{tj.get('git', '?')}, kernel sources {'CHANGED since: STALE' if stale else 'unchanged since'})")
         except (OSError, ValueError, KeyError):
             pass
         kname = {"f32": "siren_kernel<0,0,false>", "f16x3": "siren16_kernel<0,false>", "f16x3_v1": "siren_kernel<0,1,false>"}[mode]
@@ -243,10 +309,13 @@ def main():
             renderer.render_with_film(renderer.siren.film_params(wr), focal, poses, near, far)
         elapsed, kern_ms, out = timed_block(args.steps, True)
     assert torch.isfinite(out['gen_thumb_imgs']).all()
+    per_rank_ms = [1e3 * x / args.steps for x in all_ranks(timed_block.own_s)]
     value = rays_per_step * args.steps / elapsed
     result = {
         "metric": "rendered_rays_per_sec_64x64x24", "value": value, "unit": "rays/s", "n_gpus": world, "ranks_joined": ranks_joined,
         "steps": args.steps, "warmup": args.warmup, "prewarm_ms": args.prewarm_ms, "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step_per_rank": {"min": min(per_rank_ms), "max": max(per_rank_ms)}, "cores_per_rank": cores_pinned,
+        "host_threads_per_rank": host_threads,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_of(default_mode), "data": "synthetic",
         "config": {"workload": "C2: single-image W+ -> volume render, 64x64 rays x 24 samples per ray, "
                                f"{B} image(s) per GPU per step (film_params + fused render launch)",
@@ -289,6 +358,8 @@ def main():
                            "kernel_ms": k_m, "dtype": dtype_of(mode), "achieved_tflops": rf["achieved"], "peak_tflops": rf["peak"],
                            "frac": rf["frac"], "traffic": rf["traffic"]}
         result["modes"] = modes
+        result["strict_f32_rays_per_s"] = modes["f32"]["value"]
+        result["strict_f32_frac"] = modes["f32"]["frac"]
 
     # ---------------------------------------------------------------- C3: per-image evaluation sharded over the ranks
     gl = None
@@ -312,29 +383,100 @@ def main():
             return gl([w_r, w_d], p1, f1, n1, fa1, input_is_latent=True, randomize_noise=False,
                       local_data_batch={'feats': feats})                    # tex head + pass #2 + decoder
 
+    def inversion_kernel_table(gl_, w_r, w_d, out2):
+        """[{name, ms, bound, achieved, peak, unit, frac}]: both render passes, the texture head, every launch of the decoder."""
+        def ev_ms(fn, n=10):
+            fn()
+            ts = []
+            for _ in range(n):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            return statistics.median(ts)
+
+        def row(name, ms, flops=0.0, nbytes=0.0):
+            t_f = flops / (PEAK_F16_MFMA_TFLOPS / 3.0 * 1e12)
+            t_b = nbytes / (PEAK_HBM_GBPS * 1e9)
+            if ms <= 0:
+                return {"name": name, "ms": 0.0, "note": "fused into the previous launch"}
+            if t_f >= t_b:
+                return {"name": name, "ms": ms, "bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / 3.0,
+                        "unit": "TFLOP/s", "frac": t_f / (ms * 1e-3), "hbm_GBps": nbytes / (ms * 1e-3) / 1e9}
+            return {"name": name, "ms": ms, "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                    "frac": t_b / (ms * 1e-3), "mfma_TFLOPs": flops / (ms * 1e-3) / 1e12}
+        rr = gl_.renderer
+        film = rr.siren.film_params(w_r)
+        head = rr.network.netLocal.local_feat_to_tex_modulations_linear
+        tex = head.tex_modulations(feats)
+        n_pts = RES * RES * N_SAMPLES
+        rows = [row("render pass #1 (siren16_kernel)", ev_ms(lambda: rr.render_with_film(film, f1, p1, n1, fa1)),
+                    flops=FLOP_PER_RAY * RES * RES, nbytes=BYTES_PER_RAY * RES * RES),
+                row("texture head (resblock_kernel, 301 -> 512)", ev_ms(lambda: head.tex_modulations(feats)),
+                    flops=2 * 398825 * n_pts, nbytes=n_pts * (301 + 512) * 4),
+                row("render pass #2 with texture FiLM", ev_ms(lambda: rr.render_with_film(film, f1, p1, n1, fa1, tex_conditions=tex)),
+                    flops=FLOP_PER_RAY * RES * RES, nbytes=(BYTES_PER_RAY + 2 * 256 * 4 * N_SAMPLES) * RES * RES)]
+        dec = gl_.decoder
+        latent, noise = dec.styles_and_noise_forward([w_d], None, input_is_latent=True, randomize_noise=False)
+        fmap = out2['features'].contiguous()
+        if not dec._dec2_ok(fmap, latent, noise, None):
+            return rows + [{"name": "decoder", "note": "packed pipeline not taken (E3DGE_DECODER=planar or unsupported shape)"}]
+        acc = []
+        for _ in range(10):
+            ms = []
+            dec._forward_packed(fmap, latent, noise, kernel_ms=ms)
+            acc.append(ms)
+        med = [statistics.median(c) for c in zip(*acc)]
+        names = dec.dec2_launch_names()
+        convs = [dec.conv1.conv] + [c.conv for c in dec.convs]
+        r = fmap.shape[2]
+        sizes = {}
+        wbytes = sum(c.in_channel * c.out_channel * 9 for c in convs) * 8           # wpre read + hi/lo image written
+        c0 = convs[0]
+        sizes["styles"] = (0.0, sum(m.in_channel for m, _ in dec._mod_layers()) * dec.style_dim * 4.0)
+        sizes["amax(features)"] = (0.0, 4.0 * fmap.numel())
+        sizes["pack(features)"] = (0.0, 8.0 * fmap.numel())
+        sizes["weights"] = (0.0, float(wbytes))
+        sizes["conv1"] = (2.0 * 9 * c0.in_channel * c0.out_channel * r * r, 4.0 * (c0.in_channel + c0.out_channel) * r * r)
+        sizes["to_rgb1"] = (0.0, 4.0 * c0.out_channel * r * r)
+        for u in range(len(dec.to_rgbs)):
+            cu, cc = convs[1 + 2 * u], convs[2 + 2 * u]
+            t_b = 4.0 * cu.out_channel * (2 * r + 1) ** 2
+            sizes[f"L{u}.convT"] = (2.0 * 9 * cu.in_channel * cu.out_channel * r * r, 4.0 * cu.in_channel * r * r + t_b)
+            r *= 2
+            sizes[f"L{u}.blur"] = (0.0, t_b + 4.0 * cu.out_channel * r * r)
+            last = u == len(dec.to_rgbs) - 1
+            sizes[f"L{u}.conv"] = (2.0 * 9 * cc.in_channel * cc.out_channel * r * r, 4.0 * (cc.in_channel + cc.out_channel) * r * r)
+            sizes[f"L{u}.to_rgb"] = (0.0, 4.0 * cc.out_channel * r * r + 12.0 * r * r)
+            if last and med[names.index(f"L{u}.to_rgb")] < 1e-3:           # ToRGB folded into the conv: the activation is never stored
+                sizes[f"L{u}.conv"] = (sizes[f"L{u}.conv"][0], 4.0 * cc.in_channel * r * r + 12.0 * r * r)
+        return rows + [row("decoder: " + n, t, *sizes[n]) for n, t in zip(names, med)]
+
     if not args.no_c3:
         try:
-            n_units = args.c3_images * world
-            codes = [syn.synthetic_inputs(1, seed=1000 + i, device=dev) for i in sharded_eval.shard_indices(n_units, rank, world)]
-            mine = dict(zip(sharded_eval.shard_indices(n_units, rank, world), codes))
+            n_units = c3_per_rank * world
+            # (64 distinct latent pairs cycled over the set: building 2,824 synthetic codes is host time, not the workload)
+            pool = [syn.synthetic_inputs(1, seed=1000 + i, device=dev) for i in range(64)]
 
             def unit(i):
-                w_r, w_d = mine[i]
+                w_r, w_d = pool[(i * 7 + rank) % 64]
                 o = inversion(w_r, w_d)
                 return sharded_eval.image_metrics(o['gen_imgs'], target)
             with torch.no_grad():
                 # one untimed pass over this rank's images: after the seconds of host-side model construction above the GPU
                 # has clocked down, and the first ~50 ms of load run at half speed (tools/time_c3.py: 5.1 ms per image in a
                 # first pass, 2.3 ms in every later one); a 2,824-image evaluation is steady state
-                sharded_eval.evaluate_sharded(unit, n_units, rank, world, device=dev)
+                sharded_eval.evaluate_sharded(unit, min(n_units, 64 * world), rank, world, device=dev)
                 barrier()
                 t0 = time.perf_counter()
                 table = sharded_eval.evaluate_sharded(unit, n_units, rank, world, device=dev)   # one all_gather at the end
                 barrier()
                 e3 = max_over_ranks(time.perf_counter() - t0)
             assert tuple(table.shape) == (n_units, 8) and torch.isfinite(table).all()
-            result["c3"] = {"images": n_units, "images_per_rank": args.c3_images, "images_per_s": n_units / e3,
-                            "ms_per_image_per_gpu": 1e3 * e3 / args.c3_images, "mean_psnr": float(table[:, 5].mean()),
+            result["c3"] = {"images": n_units, "images_per_rank": c3_per_rank, "images_per_s": n_units / e3, "wall_s": e3,
+                            "ms_per_image_per_gpu": 1e3 * e3 / c3_per_rank, "mean_psnr": float(table[:, 5].mean()),
                             "mean_ssim": float(table[:, 6].mean()),
                             "note": "BASELINE configs[2]: per image pass #1 render + texture head on (64,64,24,301) local features + "
                                     "pass #2 render + decoder 64^2->1024^2 (cm=2) + 8 metric scalars (ArcFace / LPIPS terms need "
@@ -362,6 +504,10 @@ def main():
                                                 "filters excluded (out of scope)")
                 assert tuple(o['gen_imgs'].shape) == (1, 3, 1024, 1024)
                 ref_img = o['gen_imgs'].clone()
+                result["inversion"] = {"kernels": inversion_kernel_table(gl, w1, d1, o), "note": (
+                    "HIP-event time of every launch group of one inversion forward (median of 10), against the roofline that bounds "
+                    "it: mfma = algorithmic FLOPs / (dense f16 MFMA peak / 3: split-f16 needs three products), hbm = algorithmic "
+                    "bytes / 8 TB/s; `bound` is the larger of the two minimum times, frac = that minimum time / measured time")}
             # the same ~60 launches replayed as one HIP graph (cvpr23-e3dge_amd/graphs.py)
             try:
                 from e3dge_amd.graphs import GraphedCall
@@ -384,7 +530,7 @@ def main():
     del gl
 
     # ---------------------------------------------------------------- C4: the 120-pose sweep at 128x128 rays x 48 samples
-    if rank == 0 and not args.no_c4:
+    if not args.no_c4:
         try:
             import math
             r4 = VolumeFeatureRenderer(syn.rendering_opt(N_samples=48), out_im_res=128, mode='test')
@@ -393,29 +539,32 @@ def main():
             w4, _ = syn.synthetic_inputs(1, seed=1, device=dev)
             n_pose = 120                                                   # trainer.py:2349-2388: azim_k = 0.45 cos(pi k / 119)
             traj = torch.tensor([[0.45 * math.cos(math.pi * k / (n_pose - 1)), 0.0] for k in range(n_pose)], device=dev)
-            p4, f4, n4, fa4, _ = generate_camera_params(128, dev, locations=traj)
+            mine4 = list(sharded_eval.shard_indices(n_pose, rank, world))     # pose k -> rank k mod W
+            p4, f4, n4, fa4, _ = generate_camera_params(128, dev, locations=traj[mine4])
+            n_mine = len(mine4)
 
             def sweep(bsz):
                 wb = w4.expand(bsz, -1, -1).contiguous()
                 film = r4.siren.film_params(wb)                           # one latent for the whole sweep
-                for k in range(0, n_pose, bsz):
-                    o = r4.render_with_film(film[:min(bsz, n_pose - k)], f4[k:k + bsz], p4[k:k + bsz], n4[k:k + bsz], fa4[k:k + bsz])
+                o = None
+                for k in range(0, n_mine, bsz):
+                    o = r4.render_with_film(film[:min(bsz, n_mine - k)], f4[k:k + bsz], p4[k:k + bsz], n4[k:k + bsz], fa4[k:k + bsz])
                 return o
             c4 = {}
             spin(args.prewarm_ms / 2)
             with torch.no_grad():
                 for label, bsz in (("sequential", 1), ("batched8", 8)):
                     sweep(bsz)
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    torch.cuda.synchronize()
-                    e0.record()
+                    barrier()
+                    t0 = time.perf_counter()
                     sweep(bsz)
-                    e1.record()
-                    torch.cuda.synchronize()
-                    ms = e0.elapsed_time(e1)
-                    c4[label] = {"total_ms": ms, "ms_per_pose": ms / n_pose, "rays_per_s": n_pose * 128 * 128 / ms * 1e3,
+                    barrier()
+                    ms = 1e3 * max_over_ranks(time.perf_counter() - t0)      # wall time of the whole 120-pose sweep over all ranks
+                    c4[label] = {"sweep_ms": ms, "ms_per_pose": ms / n_pose, "rays_per_s": n_pose * 128 * 128 / ms * 1e3,
                                  "algorithmic_tflops": 2 * MAC_PER_POINT * 48 * 128 * 128 * n_pose / (ms * 1e-3) / 1e12}
-            c4["note"] = "BASELINE configs[3]: 120 camera poses of one latent, 128x128 rays x 48 samples (786,432 points per pose)"
+            c4["poses_per_rank"] = [int(x) for x in all_ranks(float(n_mine))]
+            c4["note"] = ("BASELINE configs[3]: 120 camera poses of one latent, 128x128 rays x 48 samples (786,432 points per pose), "
+                          "pose k -> rank k mod W, wall time between barriers")
             result["c4"] = c4
             del r4
         except Exception as exc:
@@ -459,14 +608,14 @@ def main():
             result["surface"] = {"failed": f"{type(exc).__name__}: {exc}"}
 
     # ---------------------------------------------------------------- C5: stage-1 training step of the renderer
-    if rank == 0 and not args.no_train_step:
+    if not args.no_train_step:
         try:
             S5 = 18                                                    # scripts/train/ffhq/stage1.sh
             r5 = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S5), out_im_res=RES, mode='test')
             r5.load_state_dict(renderer.state_dict())
             r5 = r5.to(dev)
             r5.requires_grad_(False)                                   # frozen generator, gradient to the styles only
-            w5, _ = syn.synthetic_inputs(1, seed=1, device=dev)
+            w5, _ = syn.synthetic_inputs(1, seed=1 + rank, device=dev)
             p5, f5, n5, fa5, _ = generate_camera_params(RES, dev, locations=torch.zeros(1, 2, device=dev))
 
             def train_step():
@@ -476,25 +625,55 @@ def main():
                         + (o['surface_eikonal_term'] ** 2).mean())
                 loss.backward()
                 return s_.grad
+
+            def wall_ms(fn, n):
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                barrier()
+                return 1e3 * max_over_ranks(time.perf_counter() - t0) / n
             spin(args.prewarm_ms / 2)
             for _ in range(3):
-                train_step()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            n_tr = 10
-            for _ in range(n_tr):
                 gr = train_step()
-            e1.record()
-            torch.cuda.synchronize()
+            n_tr = 10
+            ms = wall_ms(train_step, n_tr)
             assert torch.isfinite(gr).all()
-            ms = e0.elapsed_time(e1) / n_tr
             result["train_step_ms"] = ms
-            result["train_step_rays_per_sec"] = RES * RES / ms * 1e3
-            result["train_step_note"] = ("C5 renderer part, 1 image 64x64x18: forward saving arguments + eikonal term (sdf chain) + "
+            result["train_step_rays_per_sec"] = world * RES * RES / ms * 1e3
+            result["train_step_note"] = ("C5 renderer part, 1 image 64x64x18 per GPU: forward saving arguments + eikonal term (sdf chain) + "
                                          "surface normals at the integrated point (kept in the graph), loss = mean(rgb^2) + "
                                          "mean((|eik|-1)^2) + mean(surf_eik^2), backward to the styles incl. the double backward "
-                                         f"(tangent + second-order chain); backward mode {r5.siren.bwd_mode}")
+                                         f"(tangent + second-order chain); backward mode {r5.siren.bwd_mode}; max over ranks between barriers")
+            ts = {"ranks": world, "step_ms": ms}
+            if dist is not None:
+                # stage 1 trains the encoder under DDP -- 1.03 GB of fp32 gradients all-reduced per step
+                # (trainer.py:1737-1778, dist_utils.py:108-130).  The encoder is out of scope; its collective is emulated with a
+                # bucket of that size on a side stream, issued at the start of the renderer's step as DDP overlaps it with backward.
+                bucket = torch.zeros(int(ENCODER_GRAD_BYTES // 4), device=dev)
+                side = torch.cuda.Stream(device=dev)
+
+                def ar_only():
+                    with torch.cuda.stream(side):
+                        dist.all_reduce(bucket)
+                    side.synchronize()
+
+                def both():
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(side):
+                        dist.all_reduce(bucket)
+                    train_step()
+                    torch.cuda.current_stream(dev).wait_stream(side)
+                for _ in range(2):
+                    ar_only()
+                    both()
+                t_ar = wall_ms(ar_only, 5)
+                t_both = wall_ms(both, 5)
+                ts.update(allreduce_bytes=ENCODER_GRAD_BYTES, allreduce_ms=t_ar, step_with_allreduce_ms=t_both,
+                          allreduce_busbw_GBps=2 * (world - 1) / world * ENCODER_GRAD_BYTES / (t_ar * 1e-3) / 1e9,
+                          overlap_frac=(ms + t_ar - t_both) / min(ms, t_ar))
+                del bucket
+            result["train_step"] = ts
             del r5
         except Exception as exc:
             result["train_step_ms"] = None

@@ -25,6 +25,11 @@ def query_feature_map(pts, calibs, fmap=None, out=None, col_off=0, mask_out=None
     are written into out[..., col_off:col_off+C]; with `mask_out` (B,N,ld') the mask goes to mask_out[..., mask_off]."""
     _lib.require_gpu(pts, "pts")
     _lib.require_gpu(calibs, "calibs")
+    if torch.is_grad_enabled() and (pts.requires_grad or (fmap is not None and fmap.requires_grad)):
+        # the reference's index() is grid_sample_gradfix: differentiable w.r.t. the feature map (stage-2 training trains the
+        # hourglass filters through it).  The gather kernel has no backward yet -- refuse rather than drop the gradient.
+        raise NotImplementedError("e3dge_local_query has no backward: detach the feature map / points (the hourglass filters "
+                                  "that produce them are outside this build) or run under torch.no_grad()")
     B, N, _ = pts.shape
     dev = pts.device
     p = pts.contiguous()
@@ -81,7 +86,13 @@ class _ResnetBlockFCLib(nn.Module):
         self.fc_0 = nn.Linear(size_in, size_h)
         self.fc_1 = nn.Linear(size_h, size_out)
         self.shortcut = nn.Linear(size_in, size_out, bias=False) if size_in != size_out else None
+        # the reference's initialisation (resnetfc.py:33-47): zero biases, kaiming fan-in weights, fc_1.weight zero
+        nn.init.constant_(self.fc_0.bias, 0.0)
+        nn.init.kaiming_normal_(self.fc_0.weight, a=0, mode="fan_in")
+        nn.init.constant_(self.fc_1.bias, 0.0)
         nn.init.zeros_(self.fc_1.weight)
+        if self.shortcut is not None:
+            nn.init.kaiming_normal_(self.shortcut.weight, a=0, mode="fan_in")
 
     def forward(self, x):
         net = self.fc_0(torch.relu(x))

@@ -932,6 +932,7 @@ class VolumeFeatureRenderer(nn.Module):
                                     local_data_batch=local_data_batch, sample_mode=sample_mode, return_mesh=return_mesh,
                                     mesh_with_shading=mesh_with_shading, return_sdf_only=return_sdf_only, **kwargs)
         self.sample_mode = bool(sample_mode)
+        self._render_done = None          # (an event left by an earlier grad-mode render that nobody consumed must not order THIS call)
         tex = None
         if self.enable_local_model and local_data_batch is not None:
             if 'tex' in local_data_batch:

@@ -93,7 +93,13 @@ def test_bench_self_launches_the_ranks():
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
-    assert j == {"dry_run": True, "n_gpus": 2, "ranks_joined": 2, "self_launched": True}
+    assert j["dry_run"] is True and j["n_gpus"] == 2 and j["ranks_joined"] == 2 and j["self_launched"] is True
+    # the work split bench.py --gpus N will use: C3 at the evaluation set's size, C4 poses k -> rank k mod W,
+    # the stage-1 step on every rank with the encoder's 1.03 GB gradient all-reduce, one core set per rank
+    assert j["c3"]["images"] == 2824 and j["c3"]["images_per_rank"] == [1412, 1412]
+    assert j["c4"] == {"poses": 120, "poses_per_rank": [60, 60]}
+    assert j["train_step"] == {"allreduce_bytes": 1.03e9, "ranks": 2}
+    assert len(j["cores_per_rank"]) == 2 and all(c >= 1 for c in j["cores_per_rank"]) and j["host_threads"] >= 1
     # a world size that disagrees with --gpus is refused instead of silently running one rank
     bad = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-run"],
                          env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=600)
