@@ -1,0 +1,78 @@
+"""Stress fixtures from the REAL reference (authoring container only; TEST INFRASTRUCTURE): trained-like weight magnitudes and
+unit-variance styles instead of the init-range synthetic ones.
+
+    python oracle/gen_golden_stress.py      # writes tests/golden/stress_{x4,x32}.npz + stress_report.json
+
+For each variant of cvpr23-e3dge_amd/synthetic.py:stress_state_dict it records, from the reference itself
+(project/utils/volume_renderer.py:53-71 FiLMSiren, :107-114 LinearLayer, :921-930 / :1183-1287 render path;
+project/models/stylesdf_model.py:741-797 Decoder.forward): a 16x16x24 render (B = 1) and the 256^2 decoder image on the
+float64 feature map (rounded to fp32; the tests regenerate it with the oracle), next to the float64 evaluation of the restatement.
+With hidden weights x4 / x32 eight sine layers at
+|argument| >> 30 amplify fp32 rounding by orders of magnitude -- the reference's own fp32 result is then far from float64, and
+the tests bound |hip - float64| by a multiple of |reference - float64| per output instead of an absolute number."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+GOLD = os.path.join(REPO, "tests", "golden")
+
+import e3dge_amd  # noqa: E402,F401
+from e3dge_amd import synthetic as syn  # noqa: E402
+from oracle import decoder_ref, ref_harness, renderer_ref  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+KEYS = ['sdf', 'gen_thumb_imgs', 'features', 'depth', 'hit_prob', 'xyz']
+npf = lambda t: t.detach().cpu().numpy().astype(np.float32)
+md = lambda a, b: float((a.double() - b.double()).abs().max())
+
+
+def main():
+    vr, sm, cu, op = ref_harness.modules()
+    report = {}
+    res, S = 16, 24
+    for variant in syn.STRESS_VARIANTS:
+        g = sm.G_pred_latents(syn.model_opt(size=256, channel_multiplier=1, renderer_spatial_output_dim=res),
+                              syn.rendering_opt(N_samples=S), full_pipeline=True).eval()
+        sd = syn.stress_state_dict(syn.synthetic_state_dict(g), variant)
+        missing, unexpected = g.load_state_dict(sd, strict=False)
+        assert not unexpected and all(k.endswith('.kernel') for k in missing)
+        wr, wd = syn.stress_inputs(variant, 1, seed=21)
+        wd = wd[:, :g.decoder.n_latent]
+        c = cu.generate_camera_params(res, 'cpu', locations=torch.tensor([[0.15, -0.05]]), fov_ang=6, dist_radius=0.12)
+        poses, focal, near, far = c[0], c[1], c[2], c[3]
+        with torch.no_grad():
+            out = g([wr, None], poses, focal, near, far, input_is_latent=True, renderer_only=True)
+            mine = renderer_ref.render(sd, poses, focal, near, far, wr, res=res, n_samples=S)
+            truth = renderer_ref.render(sd, poses, focal, near, far, wr, res=res, n_samples=S, dtype=torch.float64)
+            # decoder on a well-defined feature map (the float64 one rounded to fp32), so that its parity does not inherit the
+            # renderer's amplification
+            feats = truth['features'].float()
+            img, _ = g.decoder(feats, [wd], input_is_latent=True, randomize_noise=False)
+            img_mine = decoder_ref.decoder_forward(sd, feats, wd)
+            img64 = decoder_ref.decoder_forward(sd, feats, wd, dtype=torch.float64)
+        rep = {"restatement_vs_reference": {k: md(out[k], mine[k]) for k in KEYS}, "reference_vs_f64": {k: md(out[k], truth[k]) for k in KEYS},
+               "scale": {k: float(truth[k].abs().max()) for k in KEYS},
+               "decoder": {"restatement_vs_reference": md(img, img_mine), "reference_vs_f64": md(img, img64), "scale": float(img64.abs().max())}}
+        report[variant] = rep
+        print(variant, json.dumps(rep))
+        # (the decoder image is stored on every second pixel, the 256-channel map on every fourth channel: 0.5 MB per variant)
+        arrays = dict(poses=npf(poses), focal=npf(focal), near=npf(near), far=npf(far), res=np.int32(res), n_samples=np.int32(S),
+                      styles_seed=np.int32(21), ref_img_sub2=npf(img[:, :, ::2, ::2]), f64_img_sub2=npf(img64[:, :, ::2, ::2]))
+        for k in KEYS:
+            r, t = (out[k][:, ::4], truth[k][:, ::4]) if k == 'features' else (out[k], truth[k])
+            arrays['ref_' + k] = npf(r)
+            arrays['f64_' + k] = t.numpy().astype(np.float64)
+        np.savez_compressed(os.path.join(GOLD, f"stress_{variant}.npz"), **arrays)
+        print("  wrote", f"stress_{variant}.npz", os.path.getsize(os.path.join(GOLD, f"stress_{variant}.npz")) / 1e3, "kB")
+    with open(os.path.join(GOLD, "stress_report.json"), "w") as f:
+        json.dump(report, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

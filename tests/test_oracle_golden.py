@@ -201,3 +201,22 @@ def test_texhead_restatement_matches_reference_class():
     with torch.no_grad():
         a, b = renderer_ref.tex_modulations(sd, prefix, feats)
     assert np.abs(a.numpy() - g['ref_alpha']).max() == 0 and np.abs(b.numpy() - g['ref_beta']).max() == 0
+
+
+@pytest.mark.parametrize("variant", ["wide", "s2", "x4", "x32"])
+def test_stress_fixtures_are_reproduced_by_the_oracle(variant):
+    """tests/golden/stress_*.npz (trained-like magnitudes, recorded from the reference by oracle/gen_golden_stress.py): the
+    restatement reproduces the reference bit for bit there too, renderer and decoder."""
+    g = load_golden(f"stress_{variant}")
+    sd = syn.stress_state_dict(full_state_dict(size=256, cm=1, res=16)[1], variant)
+    wr, wd = syn.stress_inputs(variant, 1, seed=int(g['styles_seed']))
+    c = lambda k: torch.from_numpy(g[k])
+    with torch.no_grad():
+        o = renderer_ref.render(sd, c('poses'), c('focal'), c('near'), c('far'), wr, res=16, n_samples=24)
+        t = renderer_ref.render(sd, c('poses'), c('focal'), c('near'), c('far'), wr, res=16, n_samples=24, dtype=torch.float64)
+        for k in ('sdf', 'gen_thumb_imgs', 'depth', 'hit_prob', 'xyz'):
+            assert float((o[k] - c('ref_' + k)).abs().max()) == 0.0, k
+        assert float((o['features'][:, ::4] - c('ref_features')).abs().max()) == 0.0
+        if variant in ("wide", "x32"):
+            img = decoder_ref.decoder_forward(sd, t['features'].float(), wd)
+            assert float((img[:, :, ::2, ::2] - c('ref_img_sub2')).abs().max()) == 0.0
