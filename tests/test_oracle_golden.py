@@ -218,5 +218,5 @@ def test_stress_fixtures_are_reproduced_by_the_oracle(variant):
             assert float((o[k] - c('ref_' + k)).abs().max()) == 0.0, k
         assert float((o['features'][:, ::4] - c('ref_features')).abs().max()) == 0.0
         if variant in ("wide", "x32"):
-            img = decoder_ref.decoder_forward(sd, t['features'].float(), wd)
+            img = decoder_ref.decoder_forward(sd, c('feats'), wd)
             assert float((img[:, :, ::2, ::2] - c('ref_img_sub2')).abs().max()) == 0.0
