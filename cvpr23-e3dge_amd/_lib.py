@@ -128,6 +128,8 @@ SIGNATURES = {
     "e3dge_image_metrics_scratch_floats": (_i64, [_i32, _i32, _i32, _i32]),
     "e3dge_image_metrics": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "e3dge_image_metric_row": (_i32, [_vp, _vp, _i32, _f32, _vp]),
+    "e3dge_hitprob_points": (_i32, [_vp] * 8 + [_i32, _i64, _i32, _i32, _vp]),
+    "e3dge_hitprob_composite": (_i32, [_vp] * 6 + [_f32, _i32, _i32, _i64, _i32, _i32, _vp]),
     "e3dge_align_volume": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "e3dge_selftest_mfma": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "e3dge_selftest_mfma16": (_i32, [_vp, _vp, _vp, _i32, _vp]),

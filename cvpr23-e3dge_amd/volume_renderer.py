@@ -1055,35 +1055,27 @@ class VolumeFeatureRenderer(nn.Module):
         extr = ref_img_info['cam_settings']['extrinsics']                   # (B,3,4) w2c
         styles = ref_img_info['pred_latents'][0]
         with torch.no_grad():
-            near = ro['near'].reshape(B, H * W, 1, 1)
-            far = ro['far'].reshape(B, H * W, 1, 1)
-            pts = wd_space_pts.reshape(B, H * W, S, 3)
-            # direction of the reference-view ray through each point, scaled like the mesh-grid directions (z = -1) (:1367-1379)
-            ref_space = torch.einsum('bij,bnsj->bnsi', extr[:, :, :3], pts) + extr[:, None, None, :, 3]
-            rays_d_ref = ref_space / (-ref_space[..., 2:3])
-            rays_d_wd = torch.einsum('bij,bnsj->bnsi', poses[:, :, :3], rays_d_ref)          # (B,HW,S,3)
-            t_vals = self.t_vals.reshape(1, 1, 1, Sn)
-            z_vals = near * (1. - t_vals) + far * t_vals                                      # (B,HW,1,Sn)
-            interval = (z_vals[..., 1:2] - z_vals[..., 0:1]) * rays_d_wd.norm(dim=-1, keepdim=True)   # (B,HW,S,1)
-            rays_o = poses[:, None, None, :, 3]                                              # (B,1,1,3)
-            q = rays_o.unsqueeze(3) + rays_d_wd.unsqueeze(3) * z_vals.reshape(B, H * W, 1, Sn, 1)     # (B,HW,S,Sn,3)
-            idx = (pts - q[..., 0, :]).norm(dim=-1, keepdim=True) / interval + 1e-5          # (B,HW,S,1)
-            lo = idx.floor().clamp(0, Sn - 1)
-            hi = idx.ceil().clamp(0, Sn - 1)
-            # sdf of all B*HW*S*Sn samples in one launch (view directions do not enter the sdf head)
-            sdf = self.siren.query_points(q.reshape(B, -1, 3), None, styles, self.box_scale, want_raw=False)[0]
-            sdf = sdf.reshape(B, H * W, S, Sn)
-            # volume_integration with no_force_stop (:826-837): viewdirs are unit vectors, so dists are the z spacings
-            dz = z_vals[..., 1:] - z_vals[..., :-1]
-            dists = torch.cat([dz, dz[..., 0:1]], -1)                                          # (B,HW,1,Sn)
-            beta = self.sigmoid_beta
-            sigma = torch.sigmoid(-sdf / beta) / beta
-            alpha = 1 - torch.exp(-sigma * dists)
-            vis = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1]), 1. - alpha + 1e-10], -1), -1)[..., :-1]
-            val = alpha * vis if return_type == 'weights' else vis
-            f = torch.gather(val, -1, lo.long())
-            c = torch.gather(val, -1, hi.long())
-            out = torch.lerp(f, c, idx - lo)
+            lib = _lib.load()
+            dev = wd_space_pts.device
+            N = H * W
+            near = ro['near'].reshape(B, N).contiguous().float()
+            far = ro['far'].reshape(B, N).contiguous().float()
+            pts = wd_space_pts.reshape(B, N, S, 3).contiguous().float()
+            pc, ec, tv = poses[:, :3, :4].contiguous().float(), extr[:, :3, :4].contiguous().float(), self.t_vals.contiguous()
+            q = torch.empty((B, N * S * Sn, 3), device=dev, dtype=torch.float32)
+            aux = torch.empty((B, N, S, 4), device=dev, dtype=torch.float32)
+            out = torch.empty((B, N, S), device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                st = _lib.stream_of(pts)
+                # launch 1: the Sn samples of the reference camera's ray through every point + where the point sits between them
+                _lib.check(lib.e3dge_hitprob_points(_lib.ptr(q), _lib.ptr(aux), _lib.ptr(pts), _lib.ptr(pc), _lib.ptr(ec), _lib.ptr(near),
+                                                    _lib.ptr(far), _lib.ptr(tv), B, N, S, Sn, st), "e3dge_hitprob_points")
+                # launch 2: sdf of all B*HW*S*Sn samples (view directions do not enter the sdf head)
+                sdf = self.siren.query_points(q, None, styles, self.box_scale, want_raw=False)[0]
+                # launch 3: alpha, transmittance scan without the far-plane stop, interpolation
+                _lib.check(lib.e3dge_hitprob_composite(_lib.ptr(out), _lib.ptr(sdf.contiguous()), _lib.ptr(aux), _lib.ptr(near), _lib.ptr(far),
+                                                       _lib.ptr(tv), float(self._sigmoid_beta_value()), int(return_type == 'visibility'),
+                                                       B, N, S, Sn, st), "e3dge_hitprob_composite")
         return out.reshape(B, H, W, S, 1)
 
     # -------------------------------------------------------------------------------------------------

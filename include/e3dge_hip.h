@@ -243,6 +243,20 @@ int e3dge_dec2_pack(uint32_t* packed, int32_t* meta, const float* x, const float
 int e3dge_dec2_unpack(float* x, const uint32_t* packed, const int32_t* meta, int batch, int channels, int res,
                       e3dge_stream_t stream);
 
+/*
+ * Reference-view hit probability (VolumeFeatureRenderer.query_hitting_probability_fixed_interval,
+ * project/utils/volume_renderer.py:1326-1495; compositing with no_force_stop :826-837, :884).
+ *   e3dge_hitprob_points: pts (batch, rays, s_pts, 3) world-space points of the query view, poses / extrinsics (batch, 3, 4) of the
+ *       reference view (c2w / w2c), near / far (batch, rays), t_vals (n_samples) -> q (batch, rays, s_pts, n_samples, 3): the samples
+ *       of the reference camera's ray through every point, and aux (batch, rays, s_pts, 4) = (lo, hi, frac, index) of the interpolation.
+ *   e3dge_hitprob_composite: sdf (batch, rays, s_pts, n_samples) at q [e3dge_siren_points_fwd] -> out (batch, rays, s_pts): the
+ *       compositing weight (visibility == 0) or transmittance (visibility != 0) interpolated at the point.
+ */
+int e3dge_hitprob_points(float* q, float* aux, const float* pts, const float* poses, const float* extrinsics, const float* near,
+                         const float* far, const float* t_vals, int batch, int64_t rays, int s_pts, int n_samples, e3dge_stream_t stream);
+int e3dge_hitprob_composite(float* out, const float* sdf, const float* aux, const float* near, const float* far, const float* t_vals,
+                            float sigmoid_beta, int visibility, int batch, int64_t rays, int s_pts, int n_samples, e3dge_stream_t stream);
+
 /* --------------------------------------------------------------------------------------------
  * FiLM-SIREN volume renderer (reference: project/utils/volume_renderer.py)
  * ------------------------------------------------------------------------------------------ */
