@@ -828,6 +828,161 @@ __global__ void __launch_bounds__(256) pk_blur_kernel(const PkBlurK a) {
     }
 }
 
+// The same operation as a PERSISTENT, software-pipelined kernel (default; E3DGE_DEC2_BLUR=1 selects the one above).  The
+// one-shot form is load -> barrier -> compute -> barrier -> store per workgroup with three workgroups per CU: at most ~40 KB per
+// CU are in flight and it streamed 3.0-3.1 TB/s whatever the staging / store pattern (round-3 measurements).  Here a 512-thread
+// workgroup walks 8-row tiles with tile k + 1 arriving by LDS-DMA (per-lane source address, 24 pieces of 1 KiB dealt out between
+// the channel computations of tile k) and the entries leaving LDS-transposed (1 KiB per store instruction); 70 KB of LDS, so two
+// workgroups share a CU and cover each other's waits (cold T rows return after ~3 k cycles under load: one tile of prefetch
+// per workgroup is not enough on its own -- measured with E3DGE_PK_TIMING).  A thread finishes 4 adjacent pixels of 2 channels.
+constexpr int kPb2Rows = 8, kPb2U = kPb2Rows + 3, kPb2Threads = 512;
+constexpr int kPb2StageBytes = 8 * kPb2U * kPbPitch * 4, kPb2EntryBytes = 2 * kPb2Rows * kPbCols * 16;
+constexpr int kPb2Lds = 2 * kPb2StageBytes + kPb2EntryBytes + 4096;        // + bias table (C <= 1024)
+
+__global__ void __launch_bounds__(kPb2Threads) pk_blur2_kernel(const PkBlurK a, int n_tiles, int tiles_y2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pb[];
+    unsigned char* const eb_lds = smem_pb + 2 * kPb2StageBytes;
+    float* const bias_s = reinterpret_cast<float*>(eb_lds + kPb2EntryBytes);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = a.C >> 3, R = a.R, TR = R + 3, TP = R + 4;
+    const int my_tiles = (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (my_tiles <= 0) return;
+
+    const float nw = a.noise ? a.noise_w[0] : 0.0f;
+    const float nza = a.noise ? fabsf(nw) * amax_read(a.noise_amax, lane) : 0.0f;
+    const float bound = a.act_scale * (amax_read(a.t_amax, lane) * 1.001f + nza + a.bias_amax) * 1.001f;
+    const unsigned eb = scale_exponent(bound);
+    const float kmul = a.act_scale * pow2_bits(268u - eb), kinv = 1.0f / pow2_bits(268u - eb);
+    if (blockIdx.x == 0 && tid == 0) a.out_meta[0] = (int)eb;
+    for (int i = tid; i < a.C; i += kPb2Threads) bias_s[i] = a.bias ? a.bias[i] : 0.0f;
+    float kf[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kf[p][q] = a.fir[(3 - p) * 4 + (3 - q)];
+
+    struct Tile { int b, g, oy0, ox0; };
+    auto tile_at = [&](int k) {
+        int L = xcd_logical((int)blockIdx.x + k * (int)gridDim.x, n_tiles);
+        Tile t;
+        const int tx_i = L % a.tiles_x; L /= a.tiles_x;
+        const int ty_i = L % tiles_y2; L /= tiles_y2;
+        t.g = L % G; t.b = L / G;
+        t.oy0 = ty_i * kPb2Rows; t.ox0 = tx_i * kPbCols;
+        return t;
+    };
+    constexpr int NGR = kPbPitch / 4, NE = 8 * kPb2U * NGR, NPC = (NE + 63) / 64, NPW = (NPC + 7) / 8;   // 1496 groups of four floats, 24 pieces
+    // this wave's pieces j_lo <= j < j_hi (piece wave + 8 j) of tile t; T rows oy0 - 1 .., columns ox0 - 2 .. (T(y, x) lives at
+    // [y + 1][x + 2]: every group of four is one aligned 16-byte element; the T buffer carries its own zero border)
+    auto issue = [&](const Tile& t, int buf, int j_lo, int j_hi) {
+        const float* tb = a.t + ((int64_t)t.b * a.C + 8 * t.g) * TR * TP;
+        const uint32_t dst = lds_u32(smem_pb + buf * kPb2StageBytes);
+        for (int j = j_lo; j < j_hi; ++j) {
+            const int pc = wave + 8 * j;
+            if (pc >= NPC) break;
+            const int e = pc * 64 + lane;
+            if (e < NE) {
+                const int ch = e / (kPb2U * NGR), rem = e - ch * (kPb2U * NGR);
+                const int r = rem / NGR, cg = rem - r * NGR;
+                const int row = min(t.oy0 + r, TR - 1), cc = min(t.ox0 + 4 * cg, TP - 4);
+                dma_piece(tb, (uint32_t)((ch * TR + row) * TP + cc) * 4u, dst + pc * 1024);
+            }
+        }
+    };
+    const int cq = tid >> 7, t7 = tid & 127, tx = t7 & 15, ty = t7 >> 4;       // channel quarter (2 channels), 4-pixel group, row
+    auto load_noise = [&](const Tile& t, float (&nz)[4]) {
+        const int oy = min(t.oy0 + ty, R - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ox = min(t.ox0 + 4 * tx + j, R - 1);
+            nz[j] = a.noise ? a.noise[(int64_t)(a.noise_batch > 1 ? t.b : 0) * R * R + (int64_t)oy * R + ox] : 0.0f;
+        }
+    };
+
+    Tile t_cur = tile_at(0), t_nx = t_cur;
+    float nz[4], nz_next[4] = {0.f, 0.f, 0.f, 0.f};
+    issue(t_cur, 0, 0, NPW);
+    load_noise(t_cur, nz_next);
+    float amax_l = 0.0f;
+    PK_T_INIT;
+    const int nsteps = my_tiles;
+    for (int k = 0; k < my_tiles; ++k) {
+        // tile k (and its noise) has landed, tile k - 1's stores are out; after the barrier nobody reads the buffers reused below
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        PK_T(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(nz_next[j])); nz[j] = __fmul_rn(nw, nz_next[j]); }
+        const bool has_next = k + 1 < my_tiles;
+        if (has_next) {
+            t_nx = tile_at(k + 1);
+            issue(t_nx, (k + 1) & 1, 0, 1);
+        }
+        PK_T(1);
+        // ---- compute tile k: 4 pixels x 2 channels per thread ----
+        const float* u = reinterpret_cast<const float*>(smem_pb + (k & 1) * kPb2StageBytes);
+        const bool ok_row = t_cur.oy0 + ty < R;
+        float v[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int ch = 2 * cq + e;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                const float* row = u + (ch * kPb2U + ty + ky) * kPbPitch + 4 * tx;
+                const f32x4 q0 = *reinterpret_cast<const f32x4*>(row), q1 = *reinterpret_cast<const f32x4*>(row + 4);
+                const float in[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+#pragma unroll
+                for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] = fmaf(in[j + kx + 1], kf[ky][kx], acc[j]);     // u column c <-> x = ox0 - 2 + c
+            }
+            const float bv = bias_s[8 * t_cur.g + ch];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float tv = acc[j];
+                if (a.noise) tv = __fadd_rn(tv, nz[j]);
+                tv = tv + bv;
+                tv = fmaxf(tv, tv * a.slope) * kmul;                   // lrelu (0 <= slope <= 1) * act_scale * 2^k
+                if (ok_row && t_cur.ox0 + 4 * tx + j < R) amax_l = fmaxf(amax_l, fabsf(tv));
+                v[e][j] = tv;
+            }
+            if (has_next) issue(t_nx, (k + 1) & 1, 1 + e * (NPW / 2), e == 1 ? NPW : 1 + (NPW / 2));
+        }
+        if (has_next) load_noise(t_nx, nz_next);
+        PK_T(2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                  // word cq of the pixel's hi and lo entries
+            unsigned hw, lw;
+            SPLIT2_TO(v[0][j], v[1][j], hw, lw);
+            const int pix = ty * kPbCols + 4 * tx + j;
+            *reinterpret_cast<unsigned*>(eb_lds + (size_t)pix * 16 + 4 * cq) = hw;
+            *reinterpret_cast<unsigned*>(eb_lds + (size_t)(kPb2Rows * kPbCols + pix) * 16 + 4 * cq) = lw;
+        }
+        __syncthreads();
+        {   // entries [plane][row][pixel] come back in linear order: 1 KiB per store instruction
+            const int64_t plane = (int64_t)(R + 2) * (R + 2);
+            u32x4* __restrict__ dst = reinterpret_cast<u32x4*>(a.y) + ((int64_t)(t_cur.b * G + t_cur.g) * 2) * plane;
+#pragma unroll
+            for (int it = 0; it < 2 * kPb2Rows * kPbCols / kPb2Threads; ++it) {
+                const int e = tid + it * kPb2Threads;
+                const int hl = e / (kPb2Rows * kPbCols), rem = e - hl * (kPb2Rows * kPbCols);
+                const int r = rem / kPbCols, c = rem - r * kPbCols;
+                if (t_cur.oy0 + r < R && t_cur.ox0 + c < R)
+                    dst[hl * plane + (int64_t)(t_cur.oy0 + r + 1) * (R + 2) + t_cur.ox0 + c + 1] = reinterpret_cast<const u32x4*>(eb_lds)[e];
+            }
+        }
+        PK_T(3);
+        t_cur = t_nx;
+    }
+    if (a.out_amax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax_l = fmaxf(amax_l, __shfl_xor(amax_l, off, kWave));
+        if (lane == 0) atomic_max_nonneg(a.out_amax + (((int)blockIdx.x * 8 + wave) & (kAmaxSlots - 1)) * kAmaxStride, amax_l * kinv);
+    }
+    PK_T_DONE(8);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // ToRGB on a packed activation (stylesdf_model.py:531-541): 1x1 modulated conv without demodulation (table wm = (scale W) s
 // from the weights launch) + bias + the FIR-up-sampled skip image.  Bound: HBM (4 B per input element).  A thread owns one
@@ -1202,7 +1357,19 @@ extern "C" int e3dge_dec2_forward(const E3dgeDec2Plan* P, e3dge_stream_t stream)
             k.B = B; k.C = cu.co; k.R = res; k.noise_batch = cu.noise_batch;
             k.tiles_x = (res + kPbCols - 1) / kPbCols; k.tiles_y = (res + kPbRows - 1) / kPbRows;
             const int64_t blocks = (int64_t)k.tiles_x * k.tiles_y * (cu.co / 8) * B;
+            if (shape_override("E3DGE_DEC2_BLUR") == 1) {
                 pk_blur_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(k);
+            } else {
+                E3DGE_REQUIRE(cu.co <= 1024 && blocks < ((int64_t)1 << 30), "dec2 blur: too many channels / tiles");
+                auto fn = &pk_blur2_kernel;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kPb2Lds);
+                if (e != hipSuccess) return finish(fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(dec2 blur): %s", hipGetErrorString(e)));
+                const int tiles_y2 = (res + kPb2Rows - 1) / kPb2Rows;
+                const int64_t tiles2 = (int64_t)k.tiles_x * tiles_y2 * (cu.co / 8) * B;
+                E3DGE_REQUIRE(tiles2 < ((int64_t)1 << 30), "dec2 blur: too many tiles");
+                const int grid = tiles2 < 512 ? (int)tiles2 : 512;        // two 70-KB workgroups per CU
+                fn<<<dim3((unsigned)grid), dim3(kPb2Threads), kPb2Lds, st>>>(k, (int)tiles2, tiles_y2);
+            }
             DEC2_STEP(check_launch("dec2 blur"));
         }
         const bool fuse_rgb = u == P->n_up - 1 && s1_can_fuse_rgb(cc.co, cc.ci);   // the last activation is never stored
