@@ -450,7 +450,9 @@ def main():
             last = u == len(dec.to_rgbs) - 1
             sizes[f"L{u}.conv"] = (2.0 * 9 * cc.in_channel * cc.out_channel * r * r, 4.0 * (cc.in_channel + cc.out_channel) * r * r)
             sizes[f"L{u}.to_rgb"] = (0.0, 4.0 * cc.out_channel * r * r + 12.0 * r * r)
-            if last and med[names.index(f"L{u}.to_rgb")] < 1e-3:           # ToRGB folded into the conv: the activation is never stored
+            if med[names.index(f"L{u}.blur")] == 0.0:                      # blur folded into the transposed conv: T never exists
+                sizes[f"L{u}.convT"] = (sizes[f"L{u}.convT"][0], 4.0 * cu.in_channel * (r // 2) ** 2 + 4.0 * cu.out_channel * r * r)
+            if last and med[names.index(f"L{u}.to_rgb")] == 0.0:           # ToRGB folded into the conv: the activation is never stored
                 sizes[f"L{u}.conv"] = (sizes[f"L{u}.conv"][0], 4.0 * cc.in_channel * r * r + 12.0 * r * r)
         return rows + [row("decoder: " + n, t, *sizes[n]) for n, t in zip(names, med)]
 

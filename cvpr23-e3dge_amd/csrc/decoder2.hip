@@ -701,6 +701,201 @@ __global__ void __launch_bounds__(64 * WCO * WQ) pkconv_up_kernel(const PkConvK 
     PK_T_DONE(NW);
 }
 
+// ---- up-sampling StyledConv in ONE kernel: transposed conv by output phase + blur + noise + bias + lrelu -> packed ------
+// At the two highest resolutions the intermediate T = conv_transpose(x) (fp32, (2H+1)^2) is the dominant HBM traffic of the
+// decoder (written by the conv, read by the blur: 268 MB of 615 MB at 1024^2).  Here it never leaves the CU: a workgroup owns a
+// block of 16 x 32 POSITIONS (i0 - 1 .. i0 + 14) x (j0 - 1 .. j0 + 30) -- one position row per MFMA column tile, two rows per
+// wave -- accumulates the four output phases over all input channels, then, eight output channels at a time, writes the
+// 32 x 64 patch of T into LDS (zeros for positions outside the image = the blur's padding), blurs it (4x4 FIR, same tap order as
+// e3dge_upfirdn2d), applies StyledConv's tail and stores 28 x 60 pixels of packed entries.  Recomputed halo: 512 / 420 positions.
+// The operand scale of the output cannot come from max|T| (T is produced here): |T| <= amax_in sqrt(4 ci) (at most four taps
+// of a unit-norm demodulated filter reach one output phase).
+constexpr int kUbTH = 14, kUbTW = 30, kUbPR = kUbTH + 3, kUbPC = kUbTW + 3, kUbNpix = kUbPR * kUbPC;     // patch 17 x 33 entries
+constexpr int kUbTlBytes = 8 * 32 * 64 * 4;
+
+__global__ void __launch_bounds__(512) pkconv_upblur_kernel(const PkConvK a, const float* __restrict__ fir) {
+    constexpr int NW = 8, NPT = 2, XPLANE = kUbNpix * 16, XST = 4 * XPLANE, WST = kPkSlab, STAGE = XST + WST;
+    constexpr int NWP = 18, NPP = (kUbNpix + 63) / 64, NPIECE = NWP + 4 * NPP, NPW = (NPIECE + NW - 1) / NW, PPT = (NPW + 5) / 6;
+    static_assert(kUbTlBytes <= 2 * STAGE, "the T patch aliases the staging buffers");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pk[];
+    float* const tl = reinterpret_cast<float*>(smem_pk);                     // [8 ch][32 rows][64 cols], aliases the stages
+    float* const bias_s = reinterpret_cast<float*>(smem_pk + 2 * STAGE);
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int my_tiles = (a.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (my_tiles <= 0) return;
+    const int HP = a.H + 2, WP = a.W + 2, G = a.Ci >> 3, GO = a.Co >> 3, R = 2 * a.H;
+    const int64_t plane_b = (int64_t)HP * WP * 16, oplane = (int64_t)(R + 2) * (R + 2);
+    const float oscale = pow2_bits((unsigned)a.in_meta[0] - 21u);
+    const float nw = a.noise ? a.noise_w[0] : 0.0f;
+    const float nza = a.noise ? fabsf(nw) * amax_read(a.noise_amax, lane) : 0.0f;
+    const float bound = a.act_scale * (amax_read(a.in_amax, lane) * a.knorm * 1.002f + nza + a.bias_amax) * 1.001f;   // knorm = sqrt(4 ci)
+    const unsigned eb_out = scale_exponent(bound);
+    const float kmul = a.act_scale * pow2_bits(268u - eb_out), kinv = 1.0f / pow2_bits(268u - eb_out);
+    if (blockIdx.x == 0 && tid == 0) a.out_meta[0] = (int)eb_out;
+    for (int i = tid; i < a.Co; i += 512) bias_s[i] = a.bias[i];
+    float kf[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) kf[p][q] = fir[(3 - p) * 4 + (3 - q)];
+
+    // blur-phase role of this thread: output row ry (0..27), pixels 4 gx .. 4 gx + 3 (gx 0..14); threads 420.. idle there
+    const int ry = tid / 15, gx = tid - ry * 15;
+    const bool blur_thread = tid < 28 * 15;
+    float amax_l = 0.0f;
+
+    for (int k = 0; k < my_tiles; ++k) {
+        int L = xcd_logical((int)blockIdx.x + k * (int)gridDim.x, a.n_tiles);
+        const int cb = L % a.co_blocks; L /= a.co_blocks;
+        const int txi = L % a.tiles_x; L /= a.tiles_x;
+        const int tyi = L % a.tiles_y, b = L / a.tiles_y;
+        const int i0 = tyi * kUbTH, j0 = txi * kUbTW;                    // first position whose outputs this tile stores
+        auto issue = [&](int c, int stage, int j_lo, int j_hi) {
+            const uint32_t xl = lds_u32(smem_pk + stage * STAGE), wl = xl + XST;
+            const unsigned char* wsrc = a.wimg + (int64_t)b * a.wimg_bytes + ((int64_t)cb * a.n_chunks + c) * kPkSlab;
+            const unsigned char* xsrc = a.x + ((int64_t)(b * G + 2 * c) * 2) * plane_b;
+            for (int j = j_lo; j < j_hi; ++j) {
+                const int i = wave + j * NW;
+                if (i >= NPIECE) break;
+                if (i < NWP) {
+                    dma_piece(wsrc + i * 1024, (uint32_t)lane * 16u, wl + i * 1024);
+                } else {
+                    const int p = i - NWP, pl = p / NPP, pp = p - pl * NPP;
+                    const int e = pp * 64 + lane;
+                    if (e < kUbNpix) {
+                        const int prow = e / kUbPC, pcol = e - prow * kUbPC;
+                        // padded input rows i0 - 1 + prow, clamped into the buffer: positions outside the image are zeroed below
+                        const int gy = min(max(i0 - 1 + prow, 0), HP - 1), gx_ = min(max(j0 - 1 + pcol, 0), WP - 1);
+                        dma_piece(xsrc + pl * plane_b, (uint32_t)(gy * WP + gx_) * 16u, xl + pl * XPLANE + pp * 1024);
+                    }
+                }
+            }
+        };
+        __syncthreads();                                  // the previous tile's last blur round has finished reading tl
+        issue(0, 0, 0, NPW);
+        // the blur threads' noise (the same for every channel), requested while the tile's first weights are on their way
+        float nzv[4] = {0.f, 0.f, 0.f, 0.f};
+        const int oy = 2 * i0 + ry, ox0 = 2 * j0 + 4 * gx;
+        if (blur_thread && a.noise) {
+            const int oyc = min(oy, R - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                nzv[j] = a.noise[(int64_t)(a.noise_batch > 1 ? b : 0) * R * R + (int64_t)oyc * R + min(ox0 + j, R - 1)];
+        }
+
+        f32x16 acc[4][NPT];
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) acc[ph][pt] = zero16();
+        for (int c = 0; c < a.n_chunks; ++c) {
+            const int cur = c & 1;
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            const bool has_next = c + 1 < a.n_chunks;
+            const unsigned char* xb = smem_pk + cur * STAGE + (size_t)(half * 2) * XPLANE;
+            const unsigned char* wb = smem_pk + cur * STAGE + XST + lane * 16;
+            u32x4 bh[NPT][4], bl[NPT][4];       // shift s = 2 a + b: input rows i - 1 + a, columns j - 1 + b
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+                for (int sft = 0; sft < 4; ++sft) {
+                    const int pix = (wave * NPT + pt + (sft >> 1)) * kUbPC + col + (sft & 1);
+                    bh[pt][sft] = *reinterpret_cast<const u32x4*>(xb + pix * 16);
+                    bl[pt][sft] = *reinterpret_cast<const u32x4*>(xb + XPLANE + pix * 16);
+                }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const int sft = (ky == 2 ? 0 : 2) + (kx == 2 ? 0 : 1), ph = (ky & 1) * 2 + (kx & 1);
+                const u32x4 ah = *reinterpret_cast<const u32x4*>(wb + (tap * 2 + 0) * 1024);
+                const u32x4 al = *reinterpret_cast<const u32x4*>(wb + (tap * 2 + 1) * 1024);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) {
+                    f32x16& d = acc[ph][pt];
+                    d = mfma16(ah, bh[pt][sft], d);
+                    d = mfma16(al, bh[pt][sft], d);
+                    d = mfma16(ah, bl[pt][sft], d);
+                }
+                if (has_next && tap * PPT < NPW) issue(c + 1, cur ^ 1, tap * PPT, min((tap + 1) * PPT, NPW));
+                if (tap % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- epilogue: eight output channels per round through the LDS patch of T ----
+        bool pos_ok[NPT];
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+            const int pi = i0 - 1 + wave * NPT + pt, pj = j0 - 1 + col;
+            pos_ok[pt] = pi >= 0 && pi <= a.H && pj >= 0 && pj <= a.W;
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            __syncthreads();                              // staging buffers (first round) / the previous round's readers are done
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) {
+                const int prow = wave * NPT + pt;
+#pragma unroll
+                for (int jr = 0; jr < 4; ++jr) {          // channel 4 half + jr of the group
+                    float* trow = tl + ((size_t)(4 * half + jr) * 32 + 2 * prow) * 64 + 2 * col;
+#pragma unroll
+                    for (int ey = 0; ey < 2; ++ey) {
+                        const float v0 = pos_ok[pt] ? acc[2 * ey][pt][4 * g4 + jr] * oscale : 0.0f;
+                        const float v1 = pos_ok[pt] ? acc[2 * ey + 1][pt][4 * g4 + jr] * oscale : 0.0f;
+                        *reinterpret_cast<float2*>(trow + ey * 64) = make_float2(v0, v1);
+                    }
+                }
+            }
+            __syncthreads();
+            if (blur_thread) {
+                const int cot = cb, gout = cot * 4 + g4;
+                u32x4 hi[4], lo[4];
+#pragma unroll
+                for (int cp = 0; cp < 4; ++cp) {
+                    float v[2][4];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int ch = 2 * cp + e;
+                        float ac[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ky = 0; ky < 4; ++ky) {
+                            const float* row = tl + ((size_t)ch * 32 + ry + 1 + ky) * 64 + 4 * gx;      // tl row <-> y = 2 i0 - 2 + row
+                            const f32x4 q0 = *reinterpret_cast<const f32x4*>(row), q1 = *reinterpret_cast<const f32x4*>(row + 4);
+                            const float in[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+#pragma unroll
+                            for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) ac[j] = fmaf(in[j + kx + 1], kf[ky][kx], ac[j]);   // tl column <-> x = 2 j0 - 2 + column
+                        }
+                        const float bv = bias_s[gout * 8 + ch];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float tv = ac[j];
+                            if (a.noise) tv = __fadd_rn(tv, __fmul_rn(nw, nzv[j]));
+                            tv = tv + bv;
+                            tv = fmaxf(tv, tv * a.slope) * kmul;
+                            if (oy < R && ox0 + j < R) amax_l = fmaxf(amax_l, fabsf(tv));
+                            v[e][j] = tv;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) SPLIT2_TO(v[0][j], v[1][j], hi[j][cp], lo[j][cp]);
+                }
+                if (oy < R) {
+                    u32x4* __restrict__ dst = reinterpret_cast<u32x4*>(a.y) + ((int64_t)(b * GO + gout) * 2) * oplane + (int64_t)(oy + 1) * (R + 2) + ox0 + 1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (ox0 + j < R) { dst[j] = hi[j]; dst[oplane + j] = lo[j]; }
+                }
+            }
+        }
+    }
+    if (a.out_amax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax_l = fmaxf(amax_l, __shfl_xor(amax_l, off, kWave));
+        if (lane == 0) atomic_max_nonneg(a.out_amax + (((int)blockIdx.x * NW + wave) & (kAmaxSlots - 1)) * kAmaxStride, amax_l * kinv);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Blur of an up-sampling layer + StyledConv's tail, T (fp32, zero-bordered) -> packed:  u = lrelu(upfirdn2d(T, k, pad (1, 1))
 // + noise_w noise + bias) * act_scale  (stylesdf_model.py:346, :459-466, :500-507).  Workgroup = 8 channels (one packed entry
@@ -1130,6 +1325,32 @@ static int launch_up(PkConvK k, hipStream_t st, const char* what) {
     return check_launch(what);
 }
 
+static int launch_upblur(PkConvK k, const float* fir, hipStream_t st) {
+    constexpr int lds = 2 * (4 * kUbNpix * 16 + kPkSlab) + 4096;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    E3DGE_REQUIRE(k.Co % 32 == 0 && k.Co <= 1024 && k.y && k.out_meta, "dec2 convT+blur: bad arguments");
+    k.co_blocks = k.Co / 32;
+    k.tiles_y = (k.H + kUbTH - 1) / kUbTH;
+    k.tiles_x = (k.W + kUbTW - 1) / kUbTW;
+    const int64_t n_tiles = (int64_t)k.B * k.co_blocks * k.tiles_y * k.tiles_x;
+    E3DGE_REQUIRE(n_tiles < ((int64_t)1 << 30), "dec2 convT+blur: too many tiles");
+    k.n_tiles = (int)n_tiles;
+    auto fn = &pkconv_upblur_kernel;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(dec2 convT+blur): %s", hipGetErrorString(e));
+    const int grid = k.n_tiles < 256 ? k.n_tiles : 256;
+    fn<<<dim3((unsigned)grid), dim3(512), lds, st>>>(k, fir);
+    return check_launch("dec2 convT+blur");
+}
+
+// fuse the blur into the transposed convolution?  Measured at every level of the 1024^2 / channel-multiplier-2 decoder
+// (tools/dec2_check.py, one MI355X): 93 vs 75 + 19 us (64 -> 128), 68 vs 63 + 28, 90 vs 71 + 46, 108 vs 70 + 84 (512 -> 1024):
+// never slower, so it is the default; E3DGE_DEC2_UPBLUR=0 keeps the two-kernel form (T in HBM) for A/B and tests.
+static bool use_upblur(int) {
+    const char* v = getenv("E3DGE_DEC2_UPBLUR");
+    return !(v && *v && atoi(v) == 0);
+}
+
 static int shape_override(const char* name) {      // E3DGE_DEC2_S1 / E3DGE_DEC2_UP = variant index (tuning runs); -1: automatic
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : -1;
@@ -1268,13 +1489,17 @@ extern "C" int e3dge_dec2_forward(const E3dgeDec2Plan* P, e3dge_stream_t stream)
     const bool timing = P->kernel_ms != nullptr;
     E3DGE_REQUIRE(!timing || P->n_kernel_ms >= n_l, "dec2_forward: kernel_ms needs %d entries", n_l);
     hipEvent_t ev[8 + 4 * E3DGE_DEC2_MAX_UP];
+    bool fused_away[8 + 4 * E3DGE_DEC2_MAX_UP] = {};
     int n_ev = 0;
-    auto mark = [&]() { if (timing) { hipEventCreate(&ev[n_ev]); hipEventRecord(ev[n_ev], st); ++n_ev; } };
+    auto mark = [&](bool fused = false) { if (timing) { hipEventCreate(&ev[n_ev]); hipEventRecord(ev[n_ev], st); fused_away[n_ev] = fused; ++n_ev; } };
     auto finish = [&](int code) {
         if (timing) {
             if (code == 0) {
                 hipEventSynchronize(ev[n_ev - 1]);
-                for (int i = 0; i + 1 < n_ev; ++i) hipEventElapsedTime(&P->kernel_ms[i], ev[i], ev[i + 1]);
+                for (int i = 0; i + 1 < n_ev; ++i) {
+                    hipEventElapsedTime(&P->kernel_ms[i], ev[i], ev[i + 1]);
+                    if (fused_away[i + 1]) P->kernel_ms[i] = 0.0f;        // this launch does not exist: its work is part of the previous one
+                }
             }
             for (int i = 0; i < n_ev; ++i) hipEventDestroy(ev[i]);
         }
@@ -1339,6 +1564,16 @@ extern "C" int e3dge_dec2_forward(const E3dgeDec2Plan* P, e3dge_stream_t stream)
         float* am_t = P->amax + (int64_t)E3DGE_AMAX_FLOATS * (2 + 3 * u);
         float* am_u = am_t + E3DGE_AMAX_FLOATS;
         float* am_v = am_u + E3DGE_AMAX_FLOATS;
+        if (use_upblur(res)) {   // transposed conv + blur + noise + bias + lrelu -> packed in one launch, T stays on chip
+            PkConvK k = conv_args(cu, res);
+            k.knorm = sqrtf(4.0f * (float)cu.ci);
+            k.x = reinterpret_cast<const unsigned char*>(P->act[prev_act]); k.in_meta = P->meta + prev_act;
+            k.in_amax = P->amax + (int64_t)E3DGE_AMAX_FLOATS * (prev_act == 1 ? 1 : 4 + 3 * (u - 1));
+            k.y = reinterpret_cast<unsigned char*>(P->act[2 + 2 * u]); k.out_meta = P->meta + 2 + 2 * u; k.out_amax = am_u;
+            DEC2_STEP(launch_upblur(k, P->fir_blur, st));
+            mark(true);                   // (keeps the kernel_ms slots aligned: this level's blur entry reads 0)
+            res *= 2;
+        } else {
         {   // transposed conv -> T
             PkConvK k = conv_args(cu, res);
             k.noise = nullptr; k.noise_w = nullptr; k.noise_amax = nullptr;
@@ -1372,6 +1607,7 @@ extern "C" int e3dge_dec2_forward(const E3dgeDec2Plan* P, e3dge_stream_t stream)
             }
             DEC2_STEP(check_launch("dec2 blur"));
         }
+        }
         const bool fuse_rgb = u == P->n_up - 1 && s1_can_fuse_rgb(cc.co, cc.ci);   // the last activation is never stored
         {   // stride-1 conv
             PkConvK k = conv_args(cc, res);
@@ -1382,7 +1618,7 @@ extern "C" int e3dge_dec2_forward(const E3dgeDec2Plan* P, e3dge_stream_t stream)
             }
             DEC2_STEP(conv_s1(k, st));
         }
-        if (fuse_rgb) mark();         // (keeps the kernel_ms slots aligned: this level's ToRGB entry reads 0)
+        if (fuse_rgb) mark(true);     // (keeps the kernel_ms slots aligned: this level's ToRGB entry reads 0)
         else DEC2_STEP(launch_torgb(P->rgb[u].out, reinterpret_cast<const unsigned char*>(P->act[3 + 2 * u]), P->meta + 3 + 2 * u, P->rgb[u].wm,
                                     P->rgb[u].bias, skip, P->fir_up, B, P->rgb[u].ci, res, st));
         skip = P->rgb[u].out;

@@ -63,7 +63,10 @@ def gen256():
     return g.to(DEV).eval(), sd
 
 
-def test_every_stage_against_the_planar_kernels(gen256):
+@pytest.mark.parametrize("upblur", ["1", "0"])
+def test_every_stage_against_the_planar_kernels(gen256, upblur, monkeypatch):
+    """upblur = 1 (default): transposed conv + blur in one kernel (T stays in LDS); 0: two kernels with T in HBM."""
+    monkeypatch.setenv("E3DGE_DEC2_UPBLUR", upblur)
     g, sd = gen256
     dec = g.decoder
     _, wd = syn.synthetic_inputs(1, seed=1, device=DEV)
@@ -88,7 +91,9 @@ def test_every_stage_against_the_planar_kernels(gen256):
         ref_img = _planar(dec, feats, wd, noise)
         ms = []
         img = dec._forward_packed(feats, wd, noise, kernel_ms=ms)
-        assert len(ms) == _lib.load().e3dge_dec2_num_launches(len(dec.to_rgbs)) and all(t > 0 for t in ms)
+        names = dec.dec2_launch_names()
+        assert len(ms) == _lib.load().e3dge_dec2_num_launches(len(dec.to_rgbs)) == len(names)
+        assert all((t == 0) == (upblur == "1" and n.endswith(".blur")) for n, t in zip(names, ms)), list(zip(names, ms))
         errs = {}
         for k, r in enumerate(ref):
             got = dec.dec2_unpack(1 + k, feats.shape)
@@ -97,7 +102,7 @@ def test_every_stage_against_the_planar_kernels(gen256):
         os.environ.pop("E3DGE_DEC2_FUSE_RGB")
         img_fused = dec._forward_packed(feats, wd, noise)
         errs["img_fused_rgb"] = maxerr(img_fused, ref_img)
-    record("dec2_stages_256", **errs)
+    record(f"dec2_stages_256_upblur{upblur}", **errs)
     for k, v in errs.items():
         assert v <= (IMG_ATOL if k.startswith("img") else 2e-5), (k, v)
     # the default Decoder.forward takes the packed path and returns the same tensor values
