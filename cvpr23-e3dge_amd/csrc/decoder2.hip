@@ -710,15 +710,19 @@ __global__ void __launch_bounds__(64 * WCO * WQ) pkconv_up_kernel(const PkConvK 
 // e3dge_upfirdn2d), applies StyledConv's tail and stores 28 x 60 pixels of packed entries.  Recomputed halo: 512 / 420 positions.
 // The operand scale of the output cannot come from max|T| (T is produced here): |T| <= amax_in sqrt(4 ci) (at most four taps
 // of a unit-norm demodulated filter reach one output phase).
-constexpr int kUbTH = 14, kUbTW = 30, kUbPR = kUbTH + 3, kUbPC = kUbTW + 3, kUbNpix = kUbPR * kUbPC;     // patch 17 x 33 entries
-constexpr int kUbTlBytes = 8 * 32 * 64 * 4;
+// NPT = position rows per wave: 2 -> 16 x 32 positions, 28 x 60 pixels per tile; 1 -> 8 x 32 positions, 12 x 60 pixels (more,
+// smaller tiles for the deep low-resolution levels, whose 16-row tiling leaves half of the CUs without a tile).
+constexpr int kUbTW = 30, kUbPC = kUbTW + 3;
 
+template <int NPT>
 __global__ void __launch_bounds__(512) pkconv_upblur_kernel(const PkConvK a, const float* __restrict__ fir) {
-    constexpr int NW = 8, NPT = 2, XPLANE = kUbNpix * 16, XST = 4 * XPLANE, WST = kPkSlab, STAGE = XST + WST;
+    constexpr int kUbTH = 8 * NPT - 2, kUbPR = kUbTH + 3, kUbNpix = kUbPR * kUbPC, kUbTlBytes = 8 * (16 * NPT) * 64 * 4;
+    constexpr int TLR = 16 * NPT, ORows = 2 * kUbTH;                         // rows of the T patch / output rows of a tile
+    constexpr int NW = 8, XPLANE = kUbNpix * 16, XST = 4 * XPLANE, WST = kPkSlab, STAGE = XST + WST;
     constexpr int NWP = 18, NPP = (kUbNpix + 63) / 64, NPIECE = NWP + 4 * NPP, NPW = (NPIECE + NW - 1) / NW, PPT = (NPW + 5) / 6;
     static_assert(kUbTlBytes <= 2 * STAGE, "the T patch aliases the staging buffers");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pk[];
-    float* const tl = reinterpret_cast<float*>(smem_pk);                     // [8 ch][32 rows][64 cols], aliases the stages
+    float* const tl = reinterpret_cast<float*>(smem_pk);                     // [8 ch][TLR rows][64 cols], aliases the stages
     float* const bias_s = reinterpret_cast<float*>(smem_pk + 2 * STAGE);
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -740,10 +744,12 @@ __global__ void __launch_bounds__(512) pkconv_upblur_kernel(const PkConvK a, con
 #pragma unroll
         for (int q = 0; q < 4; ++q) kf[p][q] = fir[(3 - p) * 4 + (3 - q)];
 
-    // blur-phase role of this thread: output row ry (0..27), pixels 4 gx .. 4 gx + 3 (gx 0..14); threads 420.. idle there
+    // blur-phase role of this thread: output row ry (0 .. ORows - 1), pixels 4 gx .. 4 gx + 3 (gx 0..14); the other threads idle there
     const int ry = tid / 15, gx = tid - ry * 15;
-    const bool blur_thread = tid < 28 * 15;
+    const bool blur_thread = tid < ORows * 15;
     float amax_l = 0.0f;
+    PK_T_INIT;
+    const int nsteps = my_tiles;
 
     for (int k = 0; k < my_tiles; ++k) {
         int L = xcd_logical((int)blockIdx.x + k * (int)gridDim.x, a.n_tiles);
@@ -792,6 +798,7 @@ __global__ void __launch_bounds__(512) pkconv_upblur_kernel(const PkConvK a, con
         for (int c = 0; c < a.n_chunks; ++c) {
             const int cur = c & 1;
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            PK_T(0);
             const bool has_next = c + 1 < a.n_chunks;
             const unsigned char* xb = smem_pk + cur * STAGE + (size_t)(half * 2) * XPLANE;
             const unsigned char* wb = smem_pk + cur * STAGE + XST + lane * 16;
@@ -820,6 +827,7 @@ __global__ void __launch_bounds__(512) pkconv_upblur_kernel(const PkConvK a, con
                 if (has_next && tap * PPT < NPW) issue(c + 1, cur ^ 1, tap * PPT, min((tap + 1) * PPT, NPW));
                 if (tap % 3 == 2) __builtin_amdgcn_sched_barrier(0);
             }
+            PK_T(1);
         }
         // ---- epilogue: eight output channels per round through the LDS patch of T ----
         bool pos_ok[NPT];
@@ -836,7 +844,7 @@ __global__ void __launch_bounds__(512) pkconv_upblur_kernel(const PkConvK a, con
                 const int prow = wave * NPT + pt;
 #pragma unroll
                 for (int jr = 0; jr < 4; ++jr) {          // channel 4 half + jr of the group
-                    float* trow = tl + ((size_t)(4 * half + jr) * 32 + 2 * prow) * 64 + 2 * col;
+                    float* trow = tl + ((size_t)(4 * half + jr) * TLR + 2 * prow) * 64 + 2 * col;
 #pragma unroll
                     for (int ey = 0; ey < 2; ++ey) {
                         const float v0 = pos_ok[pt] ? acc[2 * ey][pt][4 * g4 + jr] * oscale : 0.0f;
@@ -846,6 +854,7 @@ __global__ void __launch_bounds__(512) pkconv_upblur_kernel(const PkConvK a, con
                 }
             }
             __syncthreads();
+            PK_T(2);
             if (blur_thread) {
                 const int cot = cb, gout = cot * 4 + g4;
                 u32x4 hi[4], lo[4];
@@ -858,7 +867,7 @@ __global__ void __launch_bounds__(512) pkconv_upblur_kernel(const PkConvK a, con
                         float ac[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int ky = 0; ky < 4; ++ky) {
-                            const float* row = tl + ((size_t)ch * 32 + ry + 1 + ky) * 64 + 4 * gx;      // tl row <-> y = 2 i0 - 2 + row
+                            const float* row = tl + ((size_t)ch * TLR + ry + 1 + ky) * 64 + 4 * gx;     // tl row <-> y = 2 i0 - 2 + row
                             const f32x4 q0 = *reinterpret_cast<const f32x4*>(row), q1 = *reinterpret_cast<const f32x4*>(row + 4);
                             const float in[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
 #pragma unroll
@@ -887,6 +896,7 @@ __global__ void __launch_bounds__(512) pkconv_upblur_kernel(const PkConvK a, con
                         if (ox0 + j < R) { dst[j] = hi[j]; dst[oplane + j] = lo[j]; }
                 }
             }
+            PK_T(3);
         }
     }
     if (a.out_amax) {
@@ -894,6 +904,7 @@ __global__ void __launch_bounds__(512) pkconv_upblur_kernel(const PkConvK a, con
         for (int off = 32; off > 0; off >>= 1) amax_l = fmaxf(amax_l, __shfl_xor(amax_l, off, kWave));
         if (lane == 0) atomic_max_nonneg(a.out_amax + (((int)blockIdx.x * NW + wave) & (kAmaxSlots - 1)) * kAmaxStride, amax_l * kinv);
     }
+    PK_T_DONE(NW);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1325,22 +1336,30 @@ static int launch_up(PkConvK k, hipStream_t st, const char* what) {
     return check_launch(what);
 }
 
-static int launch_upblur(PkConvK k, const float* fir, hipStream_t st) {
-    constexpr int lds = 2 * (4 * kUbNpix * 16 + kPkSlab) + 4096;
-    static_assert(lds <= 160 * 1024, "LDS budget");
-    E3DGE_REQUIRE(k.Co % 32 == 0 && k.Co <= 1024 && k.y && k.out_meta, "dec2 convT+blur: bad arguments");
+template <int NPT>
+static int launch_upblur_t(PkConvK k, const float* fir, hipStream_t st) {
+    constexpr int TH = 8 * NPT - 2, lds = 2 * (4 * (TH + 3) * kUbPC * 16 + kPkSlab) + 4096;
+    static_assert(lds <= 160 * 1024 && 8 * 16 * NPT * 64 * 4 <= lds - 4096, "LDS budget");
     k.co_blocks = k.Co / 32;
-    k.tiles_y = (k.H + kUbTH - 1) / kUbTH;
+    k.tiles_y = (k.H + TH - 1) / TH;
     k.tiles_x = (k.W + kUbTW - 1) / kUbTW;
     const int64_t n_tiles = (int64_t)k.B * k.co_blocks * k.tiles_y * k.tiles_x;
     E3DGE_REQUIRE(n_tiles < ((int64_t)1 << 30), "dec2 convT+blur: too many tiles");
     k.n_tiles = (int)n_tiles;
-    auto fn = &pkconv_upblur_kernel;
+    auto fn = &pkconv_upblur_kernel<NPT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(dec2 convT+blur): %s", hipGetErrorString(e));
-    const int grid = k.n_tiles < 256 ? k.n_tiles : 256;
+    const int wgs = (160 * 1024) / lds >= 2 ? 512 : 256;
+    const int grid = k.n_tiles < wgs ? k.n_tiles : wgs;
     fn<<<dim3((unsigned)grid), dim3(512), lds, st>>>(k, fir);
     return check_launch("dec2 convT+blur");
+}
+static int shape_override(const char* name);
+static int launch_upblur(PkConvK k, const float* fir, hipStream_t st) {
+    E3DGE_REQUIRE(k.Co % 32 == 0 && k.Co <= 1024 && k.y && k.out_meta, "dec2 convT+blur: bad arguments");
+    // tiles of 14 x 30 positions (two position rows per wave).  The 6 x 30 form (E3DGE_DEC2_UPBLUR_NPT=1) gives the 64^2 level 264
+    // tiles instead of 120 for the 256 CUs but re-streams every weight slab twice as often: 115 vs 96 us there, slower everywhere.
+    return shape_override("E3DGE_DEC2_UPBLUR_NPT") == 1 ? launch_upblur_t<1>(k, fir, st) : launch_upblur_t<2>(k, fir, st);
 }
 
 // fuse the blur into the transposed convolution?  Measured at every level of the 1024^2 / channel-multiplier-2 decoder
