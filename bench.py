@@ -647,7 +647,19 @@ def main():
                                          "surface normals at the integrated point (kept in the graph), loss = mean(rgb^2) + "
                                          "mean((|eik|-1)^2) + mean(surf_eik^2), backward to the styles incl. the double backward "
                                          f"(tangent + second-order chain); backward mode {r5.siren.bwd_mode}; max over ranks between barriers")
-            ts = {"ranks": world, "step_ms": ms}
+            # roofline of the step as a whole: 30 GEMM chains of 131,072 FLOP per point (forward 8 + sdf chain 7 + tangent 7
+            # + second-order backward 8) over 64*64*18 ray samples + 4,096 surface points, and the saved state -- 9 x 256 pre-sine
+            # arguments written once and read three times, r_l and ta_l (8 x 256 each) written and read once = 66 KB per ray sample
+            n_samp, n_surf = RES * RES * S5, RES * RES
+            flop_step = 30 * 131072.0 * (n_samp + n_surf)
+            bytes_step = n_samp * (9 * 256 * 4 * 4 + 2 * 8 * 256 * 4 * 2) + n_surf * (9 * 256 * 4 * 2 + 8 * 256 * 4 * 2)
+            t_f, t_b = flop_step / (PEAK_F16_MFMA_TFLOPS / 3 * 1e12), bytes_step / (PEAK_HBM_GBPS * 1e9)
+            ts = {"ranks": world, "step_ms": ms,
+                  "roofline": {"bound": "hbm" if t_b >= t_f else "mfma", "achieved": bytes_step / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS,
+                               "unit": "GB/s", "frac": max(t_b, t_f) / (ms * 1e-3), "algorithmic_bytes_per_step": bytes_step,
+                               "flop_per_step": flop_step, "mfma_frac": t_f / (ms * 1e-3), "traffic": None,
+                               "note": "whole step (eight launches of ~0.3-0.8 ms): saved-state traffic bounds it, not the 30 GEMM chains; "
+                                       "measured FETCH/WRITE per kernel: profiles/r3_train_step_pmc.txt"}}
             if dist is not None:
                 # stage 1 trains the encoder under DDP -- 1.03 GB of fp32 gradients all-reduced per step
                 # (trainer.py:1737-1778, dist_utils.py:108-130).  The encoder is out of scope; its collective is emulated with a

@@ -1,0 +1,41 @@
+"""The stage-1 (C5) renderer step of bench.py alone -- 64x64 rays x 18 samples, eikonal + surface-normal terms, backward to the
+styles -- N times: run under rocprofv3 (--kernel-trace --stats / --pmc FETCH_SIZE / WRITE_SIZE) for its per-kernel composition and
+HBM traffic.   python tools/c5_step.py [iters]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import e3dge_amd  # noqa: F401,E402
+from e3dge_amd import synthetic as syn  # noqa: E402
+from e3dge_amd.camera_utils import generate_camera_params  # noqa: E402
+from e3dge_amd.volume_renderer import VolumeFeatureRenderer  # noqa: E402
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = "cuda:0"
+r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=18), out_im_res=64, mode='test')
+syn.load_synthetic(r, prefix='renderer.')
+r = r.to(dev)
+r.requires_grad_(False)
+w, _ = syn.synthetic_inputs(1, seed=1, device=dev)
+p, f, n, fa, _ = generate_camera_params(64, dev, locations=torch.zeros(1, 2, device=dev))
+
+
+def step():
+    s = w.clone().requires_grad_(True)
+    o = r(p, f, n, fa, styles=s, return_eikonal=True, return_surface_eikonal=True)
+    ((o['gen_thumb_imgs'] ** 2).mean() + ((o['eikonal_term'].norm(dim=-1) - 1) ** 2).mean() + (o['surface_eikonal_term'] ** 2).mean()).backward()
+    return s.grad
+
+
+for _ in range(3):
+    step()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize()
+a.record()
+for _ in range(iters):
+    g = step()
+b.record()
+torch.cuda.synchronize()
+print(f"stage-1 step 64x64x18: {a.elapsed_time(b) / iters:.3f} ms; |dstyles| max {float(g.abs().max()):.3e}")
