@@ -744,9 +744,11 @@ __global__ void __launch_bounds__(512) pkconv_upblur_kernel(const PkConvK a, con
 #pragma unroll
         for (int q = 0; q < 4; ++q) kf[p][q] = fir[(3 - p) * 4 + (3 - q)];
 
-    // blur-phase role of this thread: output row ry (0 .. ORows - 1), pixels 4 gx .. 4 gx + 3 (gx 0..14); the other threads idle there
-    const int ry = tid / 15, gx = tid - ry * 15;
-    const bool blur_thread = tid < ORows * 15;
+    // blur-phase role of this thread: output row ry (0 .. ORows - 1), pixels 4 gx .. 4 gx + 3 (gx 0..14).  Sixteen lanes per row
+    // (gx = 15 idles): with fifteen, the 16-lane groups of a ds_read_b128 straddled two rows of the 256-byte-pitch patch and a
+    // quarter of the LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT 2.2e6 of 8.5e6, profiles/r3_decoder_pmc.txt).
+    const int ry = tid >> 4, gx = tid & 15;
+    const bool blur_thread = ry < ORows && gx < 15;
     float amax_l = 0.0f;
     PK_T_INIT;
     const int nsteps = my_tiles;

@@ -123,6 +123,12 @@ class EqualLinear(nn.Module):
         return F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
 
 
+import weakref
+
+_DEC2_STATES = weakref.WeakKeyDictionary()          # Decoder -> {(batch, res, device, stream): workspace + E3dgeDec2Plan}
+_DEC2_NOISE_AMAX = weakref.WeakKeyDictionary()      # Decoder -> {noise tensor version: amax buffer}
+
+
 def decoder_backend():
     """'packed' (default): Decoder.forward without an autograd graph runs as one native call on split-f16 packed activations
     (e3dge_dec2_forward).  E3DGE_DECODER=planar keeps the round-2 chain of fused kernels over fp32 planes."""
@@ -571,7 +577,7 @@ class Decoder(nn.Module):
 
     def _noise_amax(self, nz):
         """amax buffer with max|noise| (the packed producers need it for their operand-scale bound); cached per tensor version."""
-        cache = self.__dict__.setdefault('_nz_amax', {})
+        cache = _DEC2_NOISE_AMAX.setdefault(self, {})
         key = (nz.data_ptr(), nz._version, tuple(nz.shape), str(nz.device))
         hit = cache.get(key)
         if hit is None:
@@ -595,7 +601,7 @@ class Decoder(nn.Module):
         tab = self._style_table(B, device)                 # has its own cache; rebuilt when a modulation layer / wsq changes
         pkey = (id(tab[0]),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         slot = (B, res, str(device), torch.cuda.current_stream(device).cuda_stream)
-        states = self.__dict__.setdefault('_dec2', {})
+        states = _DEC2_STATES.setdefault(self, {})      # module level (weak): ctypes plans must not sit on a deep-copyable module
         hit = states.get(slot)
         if hit is not None and hit['key'] == pkey:
             return hit

@@ -121,6 +121,35 @@ int main(void) {
     assert lib.e3dge_decoder_styles(None, 1, 1, 0, None, 1, 1, 1, None) == -1
 
 
+def test_dec2_structs_layout_matches_c():
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "e3dge_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu\n", sizeof(E3dgeDec2Conv), offsetof(E3dgeDec2Conv, bias_amax), offsetof(E3dgeDec2Conv, noise_batch), sizeof(E3dgeDec2Rgb));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %d\n", sizeof(E3dgeDec2Plan), offsetof(E3dgeDec2Plan, conv1), offsetof(E3dgeDec2Plan, up),
+         offsetof(E3dgeDec2Plan, rgb), offsetof(E3dgeDec2Plan, act), offsetof(E3dgeDec2Plan, amax), offsetof(E3dgeDec2Plan, negative_slope),
+         offsetof(E3dgeDec2Plan, kernel_ms), E3DGE_DEC2_MAX_UP);
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), c, "-o", exe], check=True)
+        got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    C, R, P = _lib.Dec2Conv, _lib.Dec2Rgb, _lib.Dec2Plan
+    assert got == [ctypes.sizeof(C), C.bias_amax.offset, C.noise_batch.offset, ctypes.sizeof(R), ctypes.sizeof(P), P.conv1.offset, P.up.offset,
+                   P.rgb.offset, P.act.offset, P.amax.offset, P.negative_slope.offset, P.kernel_ms.offset, _lib.DEC2_MAX_UP]
+    lib = _lib.load()
+    assert lib.e3dge_dec2_forward(None, None) == -1
+    assert lib.e3dge_dec2_forward(ctypes.byref(P(batch=1, n_up=7, in_res=64, in_ch=256)), None) == -1       # more levels than the plan holds
+    assert lib.e3dge_dec2_num_launches(4) == 22
+    assert lib.e3dge_dec2_act_words(1, 32, 1024) == 4 * 2 * 1026 * 1026 * 4 and lib.e3dge_dec2_tbuf_floats(2, 32, 512) == 2 * 32 * 1027 * 1028
+    assert lib.e3dge_dec2_pack(None, None, None, None, 1, 12, 8, None) == -1
+    assert lib.e3dge_hitprob_points(None, None, None, None, None, None, None, None, 1, 4, 4, 1, None) == -1
+
+
 def test_host_helpers_that_need_no_gpu(lib):
     assert lib.e3dge_upfirdn2d_out_size(129, 1, 1, 1, 1, 4) == 128     # Blur after the 64->129 transposed conv
     assert lib.e3dge_upfirdn2d_out_size(64, 2, 1, 2, 1, 4) == 128      # skip Upsample

@@ -182,3 +182,48 @@ def test_falls_back_when_a_graph_is_needed():
     rel = float((wl.grad - wl2.grad).abs().max() / wl2.grad.abs().max())
     record("dec2_latent_grad_fallback", rel=rel)
     assert rel <= 1e-4
+
+
+def test_a_decoder_that_ran_the_packed_path_is_still_deep_copyable_and_the_copy_runs(gen256):
+    """Runners deep-copy generators (EMA / surface copies): the native plan (ctypes pointers) lives outside the module."""
+    import copy
+    g, sd = gen256
+    dec = g.decoder
+    _, wd = syn.synthetic_inputs(1, seed=1, device=DEV)
+    wd = wd[:, :dec.n_latent].contiguous()
+    feats = 0.5 * torch.randn(1, 256, 64, 64, device=DEV)
+    with torch.no_grad():
+        a, _ = dec(feats, [wd], input_is_latent=True, randomize_noise=False)
+        dec2 = copy.deepcopy(dec)
+        b, _ = dec2(feats, [wd], input_is_latent=True, randomize_noise=False)
+    assert torch.equal(a, b)
+
+
+def test_local_query_refuses_to_drop_a_gradient():
+    """the feature-map gather has no backward; a map (or points) that requires grad must raise, not silently detach."""
+    from e3dge_amd.local_query import query_feature_map
+    pts = torch.rand(1, 16, 3, device=DEV)
+    calib = torch.eye(4, device=DEV)[None, :3].contiguous()
+    fmap = torch.randn(1, 8, 4, 4, device=DEV, requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        query_feature_map(pts, calib, fmap)
+    with torch.no_grad():
+        f, m, _ = query_feature_map(pts, calib, fmap)
+    assert tuple(f.shape) == (1, 16, 8)
+
+
+def test_stale_render_event_is_dropped():
+    """a grad-mode render that never consumed its completion event must not order (or break deepcopy of) a later call."""
+    import copy
+    from test_gpu_renderer import make_renderer
+    from e3dge_amd.camera_utils import generate_camera_params
+    sd = full_state_dict(res=8, n_samples=18)[1]
+    r = make_renderer(sd, 8, 18)
+    wr, _ = syn.synthetic_inputs(1, seed=1, device=DEV)
+    p, f, n, fa, _ = generate_camera_params(8, DEV, locations=torch.zeros(1, 2, device=DEV))
+    s = wr.clone().requires_grad_(True)
+    r(p, f, n, fa, styles=s, return_eikonal=True)                 # grad mode, no surface query: leaves an event behind
+    with torch.no_grad():
+        o = r(p, f, n, fa, styles=wr, return_eikonal=True, return_surface_eikonal=True)
+    assert getattr(r, '_render_done', None) is None and torch.isfinite(o['surface_eikonal_term']).all()
+    copy.deepcopy(r)
