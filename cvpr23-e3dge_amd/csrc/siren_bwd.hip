@@ -196,7 +196,13 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
     // F16: running max |g| of the layer being produced (this lane's 128 values).  With the two extra streams of the EIK
     // variant one more live register tips the allocator into spilling inside the MFMA stream, so that variant takes
     // the max in a separate pass over out[] instead.
-    constexpr bool kRunMax = F16 && !EIK;
+    // Round 3: the running maximum is off for every variant (E3DGE_BWD_RUNMAX=1 restores it where EIK is off): with it the three
+    // default-mode variants without the eikonal streams spilled 36 / 116 / 192 bytes per lane; the separate pass costs
+    // 128 v_max per layer and wave.
+#ifndef E3DGE_BWD_RUNMAX
+#define E3DGE_BWD_RUNMAX 0
+#endif
+    constexpr bool kRunMax = E3DGE_BWD_RUNMAX != 0 && F16 && !EIK;
     float gmax = 0.0f;
     // g_L of a finished layer (out[], fp32) becomes the B operand of the next GEMM
     auto next_operand = [&]() {
