@@ -385,16 +385,19 @@ def main():
 
     def inversion_kernel_table(gl_, w_r, w_d, out2):
         """[{name, ms, bound, achieved, peak, unit, frac}]: both render passes, the texture head, every launch of the decoder."""
-        def ev_ms(fn, n=10):
+        def ev_ms(fn, n=10, rounds=5):
+            """ms per call: n calls back to back between one pair of events (a lone call after a sync measures the idle GPU's
+            launch latency and clock ramp, not the kernel), median over `rounds`"""
             fn()
             ts = []
-            for _ in range(n):
+            for _ in range(rounds):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                fn()
+                for _ in range(n):
+                    fn()
                 e1.record()
                 torch.cuda.synchronize()
-                ts.append(e0.elapsed_time(e1))
+                ts.append(e0.elapsed_time(e1) / n)
             return statistics.median(ts)
 
         def row(name, ms, flops=0.0, nbytes=0.0):
