@@ -17,6 +17,8 @@
 
 namespace e3dge {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int kPkSlab = 9 * 2 * 1024;            // bytes of one weight slab: (32 co) x (16 ci) x 9 taps x (hi, lo)
 
 // -DE3DGE_PK_TIMING: waves 0 and NW-1 of workgroup 0 accumulate shader-cycle deltas per phase of a step (0: vmcnt + barrier,
@@ -832,12 +834,22 @@ __global__ void __launch_bounds__(512) pkconv_upblur_kernel(const PkConvK a, con
             PK_T(1);
         }
         // ---- epilogue: eight output channels per round through the LDS patch of T ----
+        // The patch is stored with CHANNEL PAIRS interleaved -- tl[pair][row][col][2] -- so that the FIR and the tail run on
+        // v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two channels per instruction; the even-aligned register pairs come straight out
+        // of the ds_read_b128): 256 instead of 512 FMA instructions per thread and round.  (Packed fp32 next to MFMAs is an
+        // anti-lever, MI355X_MICROARCH; this phase has no MFMAs.)
         bool pos_ok[NPT];
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt) {
             const int pi = i0 - 1 + wave * NPT + pt, pj = j0 - 1 + col;
             pos_ok[pt] = pi >= 0 && pi <= a.H && pj >= 0 && pj <= a.W;
         }
+        f32x2 nz2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float t_ = a.noise ? __fmul_rn(nw, nzv[j]) : 0.0f; nz2[j] = f32x2{t_, t_}; }
+        bool px_ok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) px_ok[j] = oy < R && ox0 + j < R;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             __syncthreads();                              // staging buffers (first round) / the previous round's readers are done
@@ -845,57 +857,62 @@ __global__ void __launch_bounds__(512) pkconv_upblur_kernel(const PkConvK a, con
             for (int pt = 0; pt < NPT; ++pt) {
                 const int prow = wave * NPT + pt;
 #pragma unroll
-                for (int jr = 0; jr < 4; ++jr) {          // channel 4 half + jr of the group
-                    float* trow = tl + ((size_t)(4 * half + jr) * TLR + 2 * prow) * 64 + 2 * col;
+                for (int q = 0; q < 2; ++q) {             // channel pair 2 half + q of the group: channels 4 half + 2 q, + 1
+                    float* trow = tl + (((size_t)(2 * half + q) * TLR + 2 * prow) * 64 + 2 * col) * 2;
 #pragma unroll
                     for (int ey = 0; ey < 2; ++ey) {
-                        const float v0 = pos_ok[pt] ? acc[2 * ey][pt][4 * g4 + jr] * oscale : 0.0f;
-                        const float v1 = pos_ok[pt] ? acc[2 * ey + 1][pt][4 * g4 + jr] * oscale : 0.0f;
-                        *reinterpret_cast<float2*>(trow + ey * 64) = make_float2(v0, v1);
+                        f32x4 v4;                           // (column 2 col: channels e = 0, 1), (column 2 col + 1: e = 0, 1)
+                        v4[0] = pos_ok[pt] ? acc[2 * ey][pt][4 * g4 + 2 * q] * oscale : 0.0f;
+                        v4[1] = pos_ok[pt] ? acc[2 * ey][pt][4 * g4 + 2 * q + 1] * oscale : 0.0f;
+                        v4[2] = pos_ok[pt] ? acc[2 * ey + 1][pt][4 * g4 + 2 * q] * oscale : 0.0f;
+                        v4[3] = pos_ok[pt] ? acc[2 * ey + 1][pt][4 * g4 + 2 * q + 1] * oscale : 0.0f;
+                        *reinterpret_cast<f32x4*>(trow + ey * 128) = v4;
                     }
                 }
             }
             __syncthreads();
             PK_T(2);
             if (blur_thread) {
-                const int cot = cb, gout = cot * 4 + g4;
+                const int gout = cb * 4 + g4;
                 u32x4 hi[4], lo[4];
+                float m = 0.0f;
 #pragma unroll
                 for (int cp = 0; cp < 4; ++cp) {
-                    float v[2][4];
+                    f32x2 ac[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int ch = 2 * cp + e;
-                        float ac[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int ky = 0; ky < 4; ++ky) {
+                        const float* row = tl + (((size_t)cp * TLR + ry + 1 + ky) * 64 + 4 * gx) * 2;     // tl row <-> y = 2 i0 - 2 + row
+                        f32x2 in[8];
 #pragma unroll
-                        for (int ky = 0; ky < 4; ++ky) {
-                            const float* row = tl + ((size_t)ch * TLR + ry + 1 + ky) * 64 + 4 * gx;     // tl row <-> y = 2 i0 - 2 + row
-                            const f32x4 q0 = *reinterpret_cast<const f32x4*>(row), q1 = *reinterpret_cast<const f32x4*>(row + 4);
-                            const float in[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-#pragma unroll
-                            for (int kx = 0; kx < 4; ++kx)
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) ac[j] = fmaf(in[j + kx + 1], kf[ky][kx], ac[j]);   // tl column <-> x = 2 j0 - 2 + column
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 q4 = *reinterpret_cast<const f32x4*>(row + 4 * i);
+                            in[2 * i] = f32x2{q4[0], q4[1]};
+                            in[2 * i + 1] = f32x2{q4[2], q4[3]};
                         }
-                        const float bv = bias_s[gout * 8 + ch];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float tv = ac[j];
-                            if (a.noise) tv = __fadd_rn(tv, __fmul_rn(nw, nzv[j]));
-                            tv = tv + bv;
-                            tv = fmaxf(tv, tv * a.slope) * kmul;
-                            if (oy < R && ox0 + j < R) amax_l = fmaxf(amax_l, fabsf(tv));
-                            v[e][j] = tv;
+                        for (int kx = 0; kx < 4; ++kx) {
+                            const f32x2 kk = f32x2{kf[ky][kx], kf[ky][kx]};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) ac[j] = __builtin_elementwise_fma(in[j + kx + 1], kk, ac[j]);   // tl column <-> x = 2 j0 - 2 + column
                         }
                     }
+                    const f32x2 bv = *reinterpret_cast<const f32x2*>(bias_s + gout * 8 + 2 * cp);
+                    const f32x2 sl = f32x2{a.slope, a.slope}, km = f32x2{kmul, kmul};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) SPLIT2_TO(v[0][j], v[1][j], hi[j][cp], lo[j][cp]);
+                    for (int j = 0; j < 4; ++j) {
+                        f32x2 tv = (ac[j] + nz2[j]) + bv;                    // (conv + noise) + bias, as the unfused kernels round it
+                        const f32x2 ls = tv * sl;
+                        tv = f32x2{fmaxf(tv[0], ls[0]), fmaxf(tv[1], ls[1])} * km;     // lrelu (0 <= slope <= 1) * act_scale * 2^k
+                        if (px_ok[j]) m = fmaxf(m, fmaxf(fabsf(tv[0]), fabsf(tv[1])));
+                        SPLIT2_TO(tv[0], tv[1], hi[j][cp], lo[j][cp]);
+                    }
                 }
+                amax_l = fmaxf(amax_l, m);
                 if (oy < R) {
                     u32x4* __restrict__ dst = reinterpret_cast<u32x4*>(a.y) + ((int64_t)(b * GO + gout) * 2) * oplane + (int64_t)(oy + 1) * (R + 2) + ox0 + 1;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (ox0 + j < R) { dst[j] = hi[j]; dst[oplane + j] = lo[j]; }
+                        if (px_ok[j]) { dst[j] = hi[j]; dst[oplane + j] = lo[j]; }
                 }
             }
             PK_T(3);
