@@ -134,6 +134,9 @@ SIGNATURES = {
     "e3dge_selftest_mfma": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "e3dge_selftest_mfma16": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "e3dge_selftest_mfma16x16": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "e3dge_ws_image_bytes": (_i64, [_i32]),
+    "e3dge_ws_pack": (_i32, [_vp, _vp, _i32, _vp]),
+    "e3dge_ws_chain": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "e3dge_selftest_sin": (_i32, [_vp, _vp, _i32, _vp]),
     "e3dge_selftest_sin_poly": (_i32, [_vp, _vp, _i32, _vp]),
 }
