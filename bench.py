@@ -489,6 +489,55 @@ def main():
         except Exception as exc:  # the headline metric must still be printed
             result["c3"] = {"failed": f"{type(exc).__name__}: {exc}"}
 
+    # ---------------------------------------------------------------- second-pass local features from feature maps
+    if rank == 0 and not args.no_inversion:
+        try:
+            from e3dge_amd.local_query import Fuse_sft_MLP, local_features_from_maps
+
+            def ev_ms2(fn, n=5, rounds=3):
+                fn()
+                ts = []
+                for _ in range(rounds):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(n):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1) / n)
+                return statistics.median(ts)
+            with torch.no_grad():
+                g0 = torch.Generator().manual_seed(5)
+                fuse = Fuse_sft_MLP()
+                for prm in fuse.parameters():
+                    prm.copy_(torch.randn(prm.shape, generator=g0) * (0.1 if prm.ndim == 1 else 1.0 / prm.shape[1] ** 0.5))
+                fuse = fuse.to(dev).eval()
+                Hh, Ss = 64, 24
+                maps = {k: torch.randn(1, 256, 128, 128, generator=g0).to(dev) for k in ("ref", "que")}
+                cal = torch.tensor([[[60.0, 0, 0, 64], [0, 60.0, 0, 64], [0, 0, 1, 0]]], device=dev)
+                pts = (torch.rand(1, Hh, Hh, Ss, 3, generator=g0) - 0.5).to(dev)
+                ldb = {'feature_maps': maps, 'ref_calibs': cal, 'que_calibs': cal, 'points': pts,
+                       'xyz': (torch.rand(1, 3, Hh, Hh, generator=g0) - 0.5).to(dev), 'fuse_sft_block': fuse}
+                enc_in = torch.randn(1, Hh * Hh * Ss, 513, generator=g0).to(dev)
+                spin(args.prewarm_ms / 4)
+                t_nat = ev_ms2(lambda: fuse.fuse(enc_in, enc_in[..., 257:]))
+                t_all = ev_ms2(lambda: local_features_from_maps(ldb))
+                os.environ["E3DGE_FUSE"] = "torch"
+                try:
+                    t_lib = ev_ms2(lambda: fuse.fuse(enc_in, enc_in[..., 257:]))
+                finally:
+                    os.environ.pop("E3DGE_FUSE", None)
+            n_p = Hh * Hh * Ss
+            result["local_features"] = {
+                "points": n_p, "from_maps_ms": t_all, "fuse_sft_mlp_ms": t_nat, "fuse_sft_mlp_torch_ms": t_lib,
+                "fuse_algorithmic_tflops": 2.0 * 9 * 65536 * n_p / t_nat / 1e9,
+                "fuse_hbm_GBps": (513 + 9 * 256 + 8 * 256 + 5 * 256) * 4.0 * n_p / t_nat / 1e6,
+                "note": "que_render_given_ref's per-point features from two (1,256,128,128) maps: 3 gathers + Fuse_sft_MLP (nine "
+                        "e3dge_ws_linear launches: 590 k MAC per point; bytes = what the nine launches read and write) + positional "
+                        "encoding -> (1,64,64,24,301); the torch figure is the same module through library GEMMs (E3DGE_FUSE=torch)"}
+        except Exception as exc:
+            result["local_features"] = {"failed": f"{type(exc).__name__}: {exc}"}
+
     # ---------------------------------------------------------------- full inversion forward, one image
     if rank == 0 and not args.no_inversion:
         try:

@@ -86,6 +86,13 @@ class Dec2Plan(ctypes.Structure):
                 ("kernel_ms", ctypes.POINTER(ctypes.c_float)), ("n_kernel_ms", _i32), ("reserved1", _i32)]
 
 
+class WsLinear(ctypes.Structure):
+    """Mirror of struct E3dgeWsLinear (include/e3dge_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("wimg", "x", "amax_in", "bias", "colw", "m", "r1", "r2", "y", "amax_out")] + [("n_rows", _i64)] + [
+        (n, _i32) for n in ("ld_x", "off_x", "ld_m", "off_m", "ld_r1", "off_r1", "ld_r2", "off_r2", "ld_y", "off_y", "pre_relu", "post")] + [
+        ("slope", _f32), ("w_fuse", _f32)]
+
+
 # name -> (restype, argtypes); every symbol include/e3dge_hip.h declares.
 SIGNATURES = {
     "e3dge_abi_version": (_i32, []),
@@ -137,6 +144,7 @@ SIGNATURES = {
     "e3dge_ws_image_bytes": (_i64, [_i32]),
     "e3dge_ws_pack": (_i32, [_vp, _vp, _i32, _vp]),
     "e3dge_ws_chain": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "e3dge_ws_linear": (_i32, [ctypes.POINTER(WsLinear), _vp]),
     "e3dge_selftest_sin": (_i32, [_vp, _vp, _i32, _vp]),
     "e3dge_selftest_sin_poly": (_i32, [_vp, _vp, _i32, _vp]),
 }

@@ -13,7 +13,9 @@
 // A = weights (feature 32 wave + 16 ft + n), B = activations (point 16 pt + n of the set): D[feature][point].
 // LDS image of a set: [hi | lo][k-step g = 0..7][pt 2][q 4][n 16] x 16 B = the 8 features 32 g + 8 q .. + 7 of point 16 pt + n.
 #define E3DGE_16_HELPERS_ONLY
+#include <string.h>
 #include "siren16.h"
+#include "decoder_common.h"
 
 namespace e3dge {
 
@@ -273,6 +275,157 @@ ws_chain_kernel(const u32x4* __restrict__ wimg, const float* __restrict__ film, 
 }  // namespace e3dge
 
 namespace e3dge {
+// =====================================================================================================================
+// One 256 x 256 linear layer on rows of a matrix, weight-stationary (the layers of Fuse_sft_MLP, local_query.py):
+//     y[row, off_y + f] = post( sum_k W[f][k] pre(x[row, off_x + k]) + bias[f] + colw[f] pre(m[row]) + r1[row, f] + r2[row, f] )
+// pre = relu or identity; post = identity | leaky relu | the SFT fuse  D + w (D S + v)  with D = r1, S = r2.
+// A workgroup keeps the whole weight image in registers for its lifetime (8 waves x 32 output features, as ws_chain_kernel)
+// and walks groups of 64 rows: the rows of group g + 1 are fetched (global -> registers) before the contraction of group g
+// and converted / written to the other LDS buffer after it.  Operand scale: 2^(141 - eb) with eb from the input tensor's amax
+// buffer (decoder_common.h), so any magnitude works; the output's amax is tracked for the next layer.
+// =====================================================================================================================
+struct __attribute__((packed, aligned(4))) F4U { float v[4]; };      // 16-byte access at 4-byte alignment (row pitch 513 floats)
+
+struct WsLinK {
+    const u32x4* wimg; const float* x; const float* amax_in; const float* bias; const float* colw; const float* m;
+    const float* r1; const float* r2; float* y; float* amax_out;
+    int64_t n_rows;
+    int ld_x, off_x, ld_m, off_m, ld_r1, off_r1, ld_r2, off_r2, ld_y, off_y;
+    int pre_relu, post;
+    float slope, w_fuse;
+};
+constexpr int kWlRows = 64, kWlBufBytes = 2 * kWsSetBytes;
+
+__global__ void __launch_bounds__(kWsThreads) ws_linear_kernel(const WsLinK a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* const tab = reinterpret_cast<float*>(smem + 2 * kWlBufBytes);           // bias[256], colw[256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, q = lane >> 4;
+    const int64_t n_groups = (a.n_rows + kWlRows - 1) / kWlRows;
+    if ((int64_t)blockIdx.x >= n_groups) return;
+    const unsigned eb = a.amax_in ? scale_exponent(amax_read(a.amax_in, lane)) : 127u + 14u;
+    const float in_scale = __uint_as_float((268u - eb) << 23), oscale = __uint_as_float((eb - 21u) << 23);
+    if (tid < kWidth) { tab[tid] = a.bias ? a.bias[tid] : 0.0f; tab[kWidth + tid] = a.colw ? a.colw[tid] : 0.0f; }
+    WsRegs R;
+#pragma unroll
+    for (int g = 0; g < kWsSteps; ++g) ws_load_w(R, a.wimg, 0, wave, lane, g);
+
+    // staging: this lane's 8 columns 32 wave + 8 q .. + 7 of the rows 16 t + n (t = 0..3) of a group
+    // (two of the four row tiles at a time -- half = the LDS set they belong to: 16 staging registers live across a contraction)
+    f32x4 sa[2], sb[2];
+    auto stage_load = [&](int64_t grp, int half) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int64_t row = grp * kWlRows + 32 * half + 16 * t + n;
+            if (row < a.n_rows) {
+                const float* p = a.x + row * a.ld_x + a.off_x + 32 * wave + 8 * q;
+                const F4U u0 = *reinterpret_cast<const F4U*>(p), u1 = *reinterpret_cast<const F4U*>(p + 4);
+                sa[t] = f32x4{u0.v[0], u0.v[1], u0.v[2], u0.v[3]};
+                sb[t] = f32x4{u1.v[0], u1.v[1], u1.v[2], u1.v[3]};
+            } else {
+                sa[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                sb[t] = sa[t];
+            }
+        }
+    };
+    auto stage_write = [&](int buf, int half) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 u = sa[t], w = sb[t];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (a.pre_relu) { u[i] = fmaxf(u[i], 0.0f); w[i] = fmaxf(w[i], 0.0f); }
+                u[i] *= in_scale; w[i] *= in_scale;
+            }
+            const HiLo p0 = split2(u[0], u[1]), p1 = split2(u[2], u[3]), p2 = split2(w[0], w[1]), p3 = split2(w[2], w[3]);
+            char* o = smem + buf * kWlBufBytes + half * kWsSetBytes + (((wave * 2 + t) * 4 + q) * 16 + n) * 16;
+            *reinterpret_cast<u32x4*>(o) = u32x4{p0.h, p1.h, p2.h, p3.h};
+            *reinterpret_cast<u32x4*>(o + kWsHalfBytes) = u32x4{p0.l, p1.l, p2.l, p3.l};
+        }
+    };
+    float amax_l = 0.0f;
+    stage_load(blockIdx.x, 0);
+    stage_write(0, 0);
+    stage_load(blockIdx.x, 1);
+    stage_write(0, 1);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x, buf ^= 1) {
+        const bool has_next = grp + gridDim.x < n_groups;
+#pragma unroll 1
+        for (int st = 0; st < 2; ++st) {
+            if (has_next) stage_load(grp + gridDim.x, st);
+            const char* xr = smem + buf * kWlBufBytes + st * kWsSetBytes + (q * 16 + n) * 16;
+            WsAcc acc;
+            u32x4 xh[2][2], xl[2][2];
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                xh[0][pt] = *reinterpret_cast<const u32x4*>(xr + pt * 1024);
+                xl[0][pt] = *reinterpret_cast<const u32x4*>(xr + pt * 1024 + kWsHalfBytes);
+            }
+#pragma unroll
+            for (int g = 0; g < kWsSteps; ++g) {
+                if (g + 1 < kWsSteps) {
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt) {
+                        xh[(g + 1) & 1][pt] = *reinterpret_cast<const u32x4*>(xr + (g + 1) * 2048 + pt * 1024);
+                        xl[(g + 1) & 1][pt] = *reinterpret_cast<const u32x4*>(xr + (g + 1) * 2048 + pt * 1024 + kWsHalfBytes);
+                    }
+                }
+#pragma unroll
+                for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                        for (int pt = 0; pt < 2; ++pt) {
+                            const u32x4 wa = (pass == 1) ? R.wl[ft][g] : R.wh[ft][g];
+                            const u32x4 xb = (pass == 2) ? xl[g & 1][pt] : xh[g & 1][pt];
+                            acc.t[ft][pt] = mfma16x16(wa, xb, (g == 0 && pass == 0) ? zero4() : acc.t[ft][pt]);
+                        }
+            }
+            // ---- post: this lane's features 32 wave + 16 ft + 4 q .. + 3 of the rows 16 pt + n of the set ----
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int64_t row = grp * kWlRows + st * 32 + 16 * pt + n;
+                const bool ok = row < a.n_rows;
+                float mv = 0.0f;
+                if (a.m && ok) { mv = a.m[row * a.ld_m + a.off_m]; if (a.pre_relu) mv = fmaxf(mv, 0.0f); }
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft) {
+                    const int f0 = 32 * wave + 16 * ft + 4 * q;
+                    const f32x4v b4 = *reinterpret_cast<const f32x4v*>(tab + f0), c4 = *reinterpret_cast<const f32x4v*>(tab + kWidth + f0);
+                    float v[4], d1[4] = {0.f, 0.f, 0.f, 0.f}, d2[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (a.r1 && ok) { const F4U u = *reinterpret_cast<const F4U*>(a.r1 + row * a.ld_r1 + a.off_r1 + f0); d1[0] = u.v[0]; d1[1] = u.v[1]; d1[2] = u.v[2]; d1[3] = u.v[3]; }
+                    if (a.r2 && ok) { const F4U u = *reinterpret_cast<const F4U*>(a.r2 + row * a.ld_r2 + a.off_r2 + f0); d2[0] = u.v[0]; d2[1] = u.v[1]; d2[2] = u.v[2]; d2[3] = u.v[3]; }
+                    F4U out;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float t = fmaf(acc.t[ft][pt][i], oscale, b4[i]);
+                        t = fmaf(c4[i], mv, t);
+                        if (a.post == 2) {
+                            t = fmaf(a.w_fuse, fmaf(d1[i], d2[i], t), d1[i]);                  // D + w (D S + shift)
+                        } else {
+                            t = (t + d1[i]) + d2[i];
+                            if (a.post == 1) t = fmaxf(t, t * a.slope);                         // leaky relu, 0 <= slope <= 1
+                        }
+                        out.v[i] = t;
+                        if (ok) amax_l = fmaxf(amax_l, fabsf(t));
+                    }
+                    if (ok) *reinterpret_cast<F4U*>(a.y + row * a.ld_y + a.off_y + f0) = out;
+                }
+            }
+            if (has_next) stage_write(buf ^ 1, st);
+        }
+        __syncthreads();
+    }
+    if (a.amax_out) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax_l = fmaxf(amax_l, __shfl_xor(amax_l, off, kWave));
+        if (lane == 0) atomic_max_nonneg(a.amax_out + (((int)blockIdx.x * 8 + wave) & (kAmaxSlots - 1)) * kAmaxStride, amax_l);
+    }
+}
+}  // namespace e3dge
+
+namespace e3dge {
 // weight image of ws_chain_kernel from fp32 weights (n_layers, 256 out, 256 in): word `wd` (two f16) of lane l (n = l & 15,
 // q = l >> 4) of [layer][wave][g][ft][hi | lo] holds 128 W[32 wave + 16 ft + n][32 g + 8 q + 2 wd], + 1 -- hi = round-toward-zero
 // f16 of the scaled value, lo = f16 of the remainder (as split2)
@@ -316,4 +469,28 @@ extern "C" int e3dge_ws_chain(const void* wimg, const float* film, const float* 
     ws_chain_kernel<<<dim3(grid), dim3(kWsThreads), lds, as_stream(stream)>>>(reinterpret_cast<const u32x4*>(wimg), film, x0, y, n_layers,
                                                                              n_points / 128, dbg);
     return check_launch("ws_chain");
+}
+
+static_assert(sizeof(E3dgeWsLinear) == sizeof(e3dge::WsLinK), "E3dgeWsLinear mirrors WsLinK");
+
+extern "C" int e3dge_ws_linear(const E3dgeWsLinear* args, e3dge_stream_t stream) {
+    using namespace e3dge;
+    E3DGE_REQUIRE(args && args->wimg && args->x && args->y, "ws_linear: null pointer");
+    E3DGE_REQUIRE(args->n_rows >= 0 && args->ld_x >= args->off_x + 256 && args->ld_y >= args->off_y + 256 && args->off_x >= 0 && args->off_y >= 0,
+                  "ws_linear: a 256-column block must fit the row pitch (x: ld %d off %d, y: ld %d off %d)", args->ld_x, args->off_x, args->ld_y, args->off_y);
+    E3DGE_REQUIRE(args->post >= 0 && args->post <= 2 && (args->post != 2 || (args->r1 && args->r2)), "ws_linear: post must be 0, 1 or 2 (2 needs r1 = D and r2 = S)");
+    E3DGE_REQUIRE((!args->r1 || args->ld_r1 >= args->off_r1 + 256) && (!args->r2 || args->ld_r2 >= args->off_r2 + 256) && (!args->m || args->ld_m > args->off_m),
+                  "ws_linear: residual / column operand does not fit its row pitch");
+    E3DGE_REQUIRE(!args->colw == !args->m, "ws_linear: colw and m come together");
+    E3DGE_REQUIRE(args->post != 1 || (args->slope >= 0.0f && args->slope <= 1.0f), "ws_linear: leaky slope must be in [0, 1]");
+    if (args->n_rows == 0) return E3DGE_OK;
+    WsLinK k;
+    memcpy(&k, args, sizeof(k));
+    const int lds = 2 * kWlBufBytes + 2 * kWidth * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ws_linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(ws_linear): %s", hipGetErrorString(e));
+    const int64_t n_groups = (k.n_rows + kWlRows - 1) / kWlRows;
+    const int grid = n_groups < 256 ? (int)n_groups : 256;
+    ws_linear_kernel<<<dim3((unsigned)grid), dim3(kWsThreads), lds, as_stream(stream)>>>(k);
+    return check_launch("ws_linear");
 }

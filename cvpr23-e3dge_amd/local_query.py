@@ -11,12 +11,28 @@
 What runs where: projection + bilinear gather + masks (e3dge_local_query) and the positional encoding (e3dge_pos_encoding)
 are HIP kernels that write straight into the column slices of the buffers the MLPs read (no concatenation copies); the
 texture head is the fused HIP kernel of round 1.  Fuse_sft_MLP (590 k MAC per point: a ResnetBlockFC(513 -> 256) and four
-256x256 linears) is, for now, GPU library GEMMs through torch -- the next kernel to write.  The hourglass
-image filters that PRODUCE the feature maps stay outside the path."""
+256x256 linears) runs as nine weight-stationary split-f16 launches (e3dge_ws_linear, round 3) when no autograd graph is
+needed, as torch modules (library GEMMs) otherwise.  The hourglass image filters that PRODUCE the feature maps stay outside the
+path."""
+import ctypes
+import os
+import weakref
+
 import torch
 from torch import nn
 
 from . import _lib
+
+_FUSE_IMAGES = weakref.WeakKeyDictionary()          # Fuse_sft_MLP -> packed weight images of its nine 256 x 256 blocks
+
+
+def native_fuse_backend():
+    """'hip' (default): Fuse_sft_MLP without an autograd graph runs as nine e3dge_ws_linear launches; E3DGE_FUSE=torch keeps
+    the library-GEMM modules (A/B, tests)."""
+    v = os.environ.get("E3DGE_FUSE", "hip")
+    if v not in ("hip", "torch"):
+        raise RuntimeError(f"E3DGE_FUSE must be 'hip' or 'torch', got {v!r}")
+    return v
 
 
 def query_feature_map(pts, calibs, fmap=None, out=None, col_off=0, mask_out=None, mask_off=0, want_proj=False):
@@ -112,10 +128,110 @@ class Fuse_sft_MLP(nn.Module):
     def forward(self, enc_feat, dec_feat, w=1):
         return self.fuse(torch.cat([enc_feat, dec_feat], dim=-1), dec_feat, w)
 
-    def fuse(self, enc_in, dec_feat, w=1):
-        """enc_in = cat(enc_feat, dec_feat) already laid out in one buffer (the query kernels write it that way)."""
+    def fuse(self, enc_in, dec_feat, w=1, out=None, out_off=0):
+        """enc_in = cat(enc_feat, dec_feat) already laid out in one buffer (the query kernels write it that way).  With `out`
+        (..., ld) the result goes to out[..., out_off:out_off + out_ch] (and that view is returned).
+        GPU, fp32, no autograd graph: nine launches of e3dge_ws_linear (weight-stationary split-f16, csrc/siren_ws.hip); otherwise
+        the torch modules (library GEMMs) -- that is the training path."""
+        if self._native_ok(enc_in):
+            return self._fuse_native(enc_in, float(w), out, out_off)
         e = self.encode_enc(enc_in)
-        return dec_feat + w * (dec_feat * self.scale(e) + self.shift(e))
+        res = dec_feat + w * (dec_feat * self.scale(e) + self.shift(e))
+        if out is None:
+            return res
+        out[..., out_off:out_off + res.shape[-1]] = res
+        return out[..., out_off:out_off + res.shape[-1]]
+
+    # ---- native path ----------------------------------------------------------------------------------------------------
+    def _native_ok(self, enc_in):
+        if native_fuse_backend() != "hip" or enc_in.device.type != "cuda" or enc_in.dtype != torch.float32:
+            return False
+        fc0 = self.encode_enc.fc_0
+        if fc0.out_features != 256 or self.encode_enc.fc_1.out_features != 256 or fc0.in_features not in (512, 513):
+            return False
+        if enc_in.shape[-1] != fc0.in_features or self.encode_enc.shortcut is None:
+            return False
+        if torch.is_grad_enabled() and (enc_in.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False
+        return all(p.device == enc_in.device and p.dtype == torch.float32 for p in self.parameters())
+
+    def _images(self, device):
+        """Packed weight images (e3dge_ws_pack) of the nine 256 x 256 blocks, bias / mask-column vectors; rebuilt when a
+        parameter changes.  Kept outside the module (weak map): modules stay deep-copyable and state_dict-clean."""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device),)
+        hit = _FUSE_IMAGES.get(self)
+        if hit is not None and hit['key'] == key:
+            return hit
+        lib = _lib.load()
+        enc, n_in = self.encode_enc, self.encode_enc.fc_0.in_features
+        has_col = n_in == 513
+        b_off = 257 if has_col else 256                       # first column of the 3D-projected (dec) block
+
+        def img(w):
+            w = w.detach().contiguous()
+            t = torch.empty(lib.e3dge_ws_image_bytes(1), dtype=torch.uint8, device=device)
+            with torch.cuda.device(device):
+                _lib.check(lib.e3dge_ws_pack(_lib.ptr(t), _lib.ptr(w), 1, _lib.stream_of(w)), "e3dge_ws_pack")
+            return t
+        f0, sc = enc.fc_0.weight, enc.shortcut.weight
+        hit = dict(key=key, b_off=b_off, has_col=has_col,
+                   f0a=img(f0[:, :256]), f0b=img(f0[:, b_off:]), f1=img(enc.fc_1.weight), sa=img(sc[:, :256]), sb=img(sc[:, b_off:]),
+                   sc1=img(self.scale[0].weight), sc2=img(self.scale[2].weight), sh1=img(self.shift[0].weight), sh2=img(self.shift[2].weight),
+                   f0col=f0[:, 256].detach().contiguous() if has_col else None, scol=sc[:, 256].detach().contiguous() if has_col else None,
+                   b0=enc.fc_0.bias.detach().contiguous(), b1=enc.fc_1.bias.detach().contiguous(),
+                   bsc1=self.scale[0].bias.detach().contiguous(), bsc2=self.scale[2].bias.detach().contiguous(),
+                   bsh1=self.shift[0].bias.detach().contiguous(), bsh2=self.shift[2].bias.detach().contiguous(),
+                   slope=float(self.scale[1].negative_slope))
+        _FUSE_IMAGES[self] = hit
+        return hit
+
+    def _fuse_native(self, enc_in, w, out, out_off):
+        lead = enc_in.shape[:-1]
+        x = enc_in.reshape(-1, enc_in.shape[-1])
+        if not x.is_contiguous():
+            x = x.contiguous()
+        N, ld = x.shape
+        dev = x.device
+        I = self._images(dev)
+        if out is None:
+            out = torch.empty(lead + (256,), device=dev, dtype=torch.float32)
+            out_off = 0
+        o2 = out.reshape(-1, out.shape[-1])
+        if o2.data_ptr() != out.data_ptr() or not o2.is_contiguous():
+            raise RuntimeError("Fuse_sft_MLP.fuse: `out` must be a contiguous (..., ld) buffer")
+        if N == 0:
+            return out[..., out_off:out_off + 256]
+        lib = _lib.load()
+        A, Bf, C = (torch.empty((N, 256), device=dev, dtype=torch.float32) for _ in range(3))
+        am = torch.zeros((5, _lib.AMAX_FLOATS), device=dev, dtype=torch.float32)       # x, net, e, h1, h2
+        st = _lib.stream_of(x)
+        b_off = I['b_off']
+
+        def lin(wimg, xin, ld_x, off_x, amax_in, y, ld_y=256, off_y=0, bias=None, col=None, r1=None, r1_ld=256, r1_off=0, r2=None,
+                pre_relu=False, post=0, amax_out=None):
+            a = _lib.WsLinear()
+            a.wimg, a.x, a.amax_in, a.bias = _lib.ptr(wimg), _lib.ptr(xin), _lib.ptr(amax_in), _lib.ptr(bias)
+            a.colw, a.m = (_lib.ptr(col), _lib.ptr(x)) if col is not None else (None, None)
+            a.r1, a.r2, a.y, a.amax_out = _lib.ptr(r1), _lib.ptr(r2), _lib.ptr(y), _lib.ptr(amax_out)
+            a.n_rows = N
+            a.ld_x, a.off_x, a.ld_m, a.off_m = ld_x, off_x, ld, 256
+            a.ld_r1, a.off_r1, a.ld_r2, a.off_r2, a.ld_y, a.off_y = r1_ld, r1_off, 256, 0, ld_y, off_y
+            a.pre_relu, a.post, a.slope, a.w_fuse = int(pre_relu), post, I['slope'], w
+            _lib.check(lib.e3dge_ws_linear(ctypes.byref(a), st), "e3dge_ws_linear")
+        with torch.cuda.device(dev):
+            _lib.check(lib.e3dge_amax(_lib.ptr(am[0]), _lib.ptr(x), x.numel(), st), "e3dge_amax")
+            # ResnetBlockFC: net = fc_0(relu(x)), dx = fc_1(relu(net)), e = shortcut(x) + dx  (K = 513 as two 256-blocks + the mask column)
+            lin(I['f0a'], x, ld, 0, am[0], A, pre_relu=True)
+            lin(I['f0b'], x, ld, b_off, am[0], Bf, bias=I['b0'], col=I['f0col'], r1=A, pre_relu=True, amax_out=am[1])
+            lin(I['f1'], Bf, 256, 0, am[1], A, bias=I['b1'], pre_relu=True)
+            lin(I['sa'], x, ld, 0, am[0], C)
+            lin(I['sb'], x, ld, b_off, am[0], Bf, col=I['scol'], r1=C, r2=A, amax_out=am[2])
+            # SFT branches on e (= Bf), then  dec + w (dec * scale + shift)
+            lin(I['sc1'], Bf, 256, 0, am[2], A, bias=I['bsc1'], post=1, amax_out=am[3])
+            lin(I['sc2'], A, 256, 0, am[3], C, bias=I['bsc2'])
+            lin(I['sh1'], Bf, 256, 0, am[2], A, bias=I['bsh1'], post=1, amax_out=am[4])
+            lin(I['sh2'], A, 256, 0, am[4], o2, ld_y=o2.shape[-1], off_y=out_off, bias=I['bsh2'], r1=x, r1_ld=ld, r1_off=b_off, r2=C, post=2)
+        return out[..., out_off:out_off + 256]
 
 
 def local_features_from_maps(local_data_batch, n_freqs=7):
@@ -141,7 +257,7 @@ def local_features_from_maps(local_data_batch, n_freqs=7):
         enc_in[..., C] = vis.reshape(B, H * W, 1).expand(B, H * W, S).reshape(B, N)
     width = 3 * (2 * n_freqs + 1)
     feats = torch.empty((B, N, C + width), device=pts.device, dtype=torch.float32)
-    feats[..., :C] = fuse.fuse(enc_in, dec)
+    fuse.fuse(enc_in, dec, out=feats, out_off=0)
     pos_encoding(pts, n_freqs, out=feats.reshape(B * N, C + width), col_off=C)
     return feats.reshape(B, H, W, S, C + width), in_img.reshape(B, H, W, S, 1)
 

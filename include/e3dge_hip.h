@@ -520,6 +520,22 @@ int64_t e3dge_ws_image_bytes(int n_layers);
 int e3dge_ws_pack(void* wimg, const float* weights, int n_layers, e3dge_stream_t stream);
 int e3dge_ws_chain(const void* wimg, const float* film, const float* x, float* y, int n_layers, int n_points, int grid,
                    long long* cycles, e3dge_stream_t stream);
+/* One 256 x 256 linear layer over the rows of a matrix, weight-stationary split-f16 (the layers of Fuse_sft_MLP,
+ * project/models/helper_modules/sft.py:84-109 and resnetfc.py:49-58 -- local_query.py chains nine of these):
+ *   y[row, off_y + f] = post( sum_k W[f][k] pre(x[row, off_x + k]) + bias[f] + colw[f] pre(m[row, off_m]) + r1[row, off_r1 + f] + r2[row, off_r2 + f] )
+ * pre = relu (pre_relu != 0) or identity; post: 0 identity, 1 leaky relu (slope), 2 the SFT fuse  D + w_fuse (D S + v)  with
+ * D = r1, S = r2 and v the bracket without r1, r2.  wimg = e3dge_ws_pack(W, 1).  amax_in: amax buffer (E3DGE_AMAX_FLOATS) holding
+ * max |x| over the tensor x comes from (operand scale; NULL: values of order 1), amax_out: NULL or the buffer that receives max |y|
+ * (zero it first).  Pointers other than wimg, x, y may be NULL (colw and m together); row pitches in floats, any alignment. */
+typedef struct E3dgeWsLinear {
+    const void* wimg; const float* x; const float* amax_in; const float* bias; const float* colw; const float* m;
+    const float* r1; const float* r2; float* y; float* amax_out;
+    int64_t n_rows;
+    int32_t ld_x, off_x, ld_m, off_m, ld_r1, off_r1, ld_r2, off_r2, ld_y, off_y;
+    int32_t pre_relu, post;
+    float slope, w_fuse;
+} E3dgeWsLinear;
+int e3dge_ws_linear(const E3dgeWsLinear* args, e3dge_stream_t stream);
 /* Accuracy self-test of the kernel's sine: y[i] = sin(x[i]) with the device routine the SIREN layers use. */
 int e3dge_selftest_sin(float* y, const float* x, int n, e3dge_stream_t stream);
 /* The alternative 13-op polynomial sine (kernels built with -DE3DGE_POLY_SINE use it). */

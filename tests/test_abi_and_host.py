@@ -150,6 +150,34 @@ int main(void) {
     assert lib.e3dge_hitprob_points(None, None, None, None, None, None, None, None, 1, 4, 4, 1, None) == -1
 
 
+def test_ws_linear_struct_layout_matches_c_and_arguments_are_checked():
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "e3dge_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(E3dgeWsLinear), offsetof(E3dgeWsLinear, n_rows), offsetof(E3dgeWsLinear, ld_x),
+         offsetof(E3dgeWsLinear, off_y), offsetof(E3dgeWsLinear, post), offsetof(E3dgeWsLinear, w_fuse));
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), c, "-o", exe], check=True)
+        got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    W = _lib.WsLinear
+    assert got == [ctypes.sizeof(W), W.n_rows.offset, W.ld_x.offset, W.off_y.offset, W.post.offset, W.w_fuse.offset]
+    lib = _lib.load()
+    assert lib.e3dge_ws_image_bytes(1) == 8 * 8 * 2 * 2 * 64 * 16 and lib.e3dge_ws_image_bytes(8) == 8 * 262144
+    assert lib.e3dge_ws_linear(None, None) == -1
+    one = ctypes.c_void_p(16)                                   # (never dereferenced: validation fails first)
+    assert lib.e3dge_ws_linear(ctypes.byref(W(wimg=one, x=one, y=one, n_rows=4, ld_x=255, ld_y=256)), None) == -1      # 256 columns do not fit
+    assert lib.e3dge_ws_linear(ctypes.byref(W(wimg=one, x=one, y=one, n_rows=4, ld_x=256, ld_y=256, post=2)), None) == -1  # fuse without D, S
+    assert lib.e3dge_ws_linear(ctypes.byref(W(wimg=one, x=one, y=one, n_rows=4, ld_x=256, ld_y=256, colw=one)), None) == -1  # colw without m
+    assert lib.e3dge_ws_linear(ctypes.byref(W(wimg=one, x=one, y=one, n_rows=0, ld_x=256, ld_y=256)), None) == 0          # nothing to do
+    assert lib.e3dge_ws_pack(None, None, 1, None) == -1 and lib.e3dge_ws_chain(None, None, None, None, 1, 128, 0, None, None) == -1
+
+
 def test_host_helpers_that_need_no_gpu(lib):
     assert lib.e3dge_upfirdn2d_out_size(129, 1, 1, 1, 1, 4) == 128     # Blur after the 64->129 transposed conv
     assert lib.e3dge_upfirdn2d_out_size(64, 2, 1, 2, 1, 4) == 128      # skip Upsample

@@ -227,3 +227,47 @@ def test_stale_render_event_is_dropped():
         o = r(p, f, n, fa, styles=wr, return_eikonal=True, return_surface_eikonal=True)
     assert getattr(r, '_render_done', None) is None and torch.isfinite(o['surface_eikonal_term']).all()
     copy.deepcopy(r)
+
+
+def _fuse_module(in_ch, seed):
+    from e3dge_amd.local_query import Fuse_sft_MLP
+    torch.manual_seed(seed)
+    m = Fuse_sft_MLP(in_ch=in_ch, out_ch=256)
+    with torch.no_grad():
+        for p in m.parameters():                                   # (the reference zero-initialises fc_1.weight and the biases)
+            p.copy_(torch.randn_like(p) * (0.3 if p.ndim == 1 else 1.5 / p.shape[1] ** 0.5))
+    return m
+
+
+@pytest.mark.parametrize("in_ch,n_pts,mag", [(257, 1000, 1.0), (257, 64, 300.0), (256, 333, 1e-3), (257, 4096, 1.0)])
+def test_fuse_sft_mlp_native_against_float64(in_ch, n_pts, mag, monkeypatch):
+    """Fuse_sft_MLP (sft.py:84-109, resnetfc.py:49-58) as nine e3dge_ws_linear launches vs the same module in float64 on the CPU;
+    tolerance 3 x what the fp32 torch modules deviate (+ 1e-6 of the output's maximum), ragged row counts, both input widths,
+    large / small magnitudes (the operand scale comes from the tensors' amax), writing into a column slice of a wider buffer."""
+    import copy
+    m = _fuse_module(in_ch, seed=in_ch + n_pts)
+    m64 = copy.deepcopy(m).double()
+    torch.manual_seed(1)
+    enc_in = mag * torch.randn(2, n_pts, in_ch + 256)
+    if in_ch == 257:
+        enc_in[..., 256] = (torch.rand(2, n_pts) > 0.4).float()
+    dec = enc_in[..., in_ch:]
+    with torch.no_grad():
+        ref = m64.fuse(enc_in.double(), dec.double(), w=0.7)
+        r32 = m.fuse(enc_in, dec, w=0.7)
+        mg = m.to(DEV)
+        xg = enc_in.to(DEV)
+        wide = torch.full((2, n_pts, 301), 7.0, device=DEV)
+        got = mg.fuse(xg, xg[..., in_ch:], w=0.7, out=wide, out_off=0)
+        monkeypatch.setenv("E3DGE_FUSE", "torch")
+        lib = mg.fuse(xg, xg[..., in_ch:], w=0.7)
+        monkeypatch.delenv("E3DGE_FUSE")
+    scale = float(ref.abs().max())
+    err, e32, elib = (float((t.cpu().double() - ref).abs().max()) for t in (got, r32, lib))
+    record("fuse_sft_mlp", in_ch=in_ch, n=n_pts, mag=mag, err=err, fp32_cpu=e32, torch_gpu=elib, out_max=scale)
+    assert err <= 3 * e32 + 1e-6 * scale, (err, e32, scale)
+    assert float((wide[..., 256:] - 7.0).abs().max()) == 0.0                  # columns beyond the slice untouched
+    with torch.enable_grad():                                                  # a graph is needed: the torch modules run
+        xg2 = xg.clone().requires_grad_(True)
+        y = mg.fuse(xg2, xg2[..., in_ch:], w=0.7)
+        assert y.requires_grad
