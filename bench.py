@@ -415,12 +415,21 @@ def main():
         head = rr.network.netLocal.local_feat_to_tex_modulations_linear
         tex = head.tex_modulations(feats)
         n_pts = RES * RES * N_SAMPLES
-        rows = [row("render pass #1 (siren16_kernel)", ev_ms(lambda: rr.render_with_film(film, f1, p1, n1, fa1)),
-                    flops=FLOP_PER_RAY * RES * RES, nbytes=BYTES_PER_RAY * RES * RES),
+        reuse = rr._reuse_enabled(None)
+        key = rr._reuse_key(w_r, f1, p1, n1, fa1) if reuse else None
+        view_flop = 2.0 * (259 * 256 + 3 * 256) * N_SAMPLES          # view layer + rgb head per ray
+        rows = [row("render pass #1 (siren16_kernel" + (", + layer-7 record for pass #2)" if reuse else ")"),
+                    ev_ms(lambda: rr.render_with_film(film, f1, p1, n1, fa1, reuse_key=key)),
+                    flops=FLOP_PER_RAY * RES * RES, nbytes=(BYTES_PER_RAY + (1024 * N_SAMPLES if reuse else 0)) * RES * RES),
                 row("texture head (resblock_kernel, 301 -> 512)", ev_ms(lambda: head.tex_modulations(feats)),
-                    flops=2 * 398825 * n_pts, nbytes=n_pts * (301 + 512) * 4),
-                row("render pass #2 with texture FiLM", ev_ms(lambda: rr.render_with_film(film, f1, p1, n1, fa1, tex_conditions=tex)),
-                    flops=FLOP_PER_RAY * RES * RES, nbytes=(BYTES_PER_RAY + 2 * 256 * 4 * N_SAMPLES) * RES * RES)]
+                    flops=2 * 398825 * n_pts, nbytes=n_pts * (301 + 512) * 4)]
+        if reuse:       # (the record written by the timed pass-#1 launches above is the one these read)
+            rows.append(row("render pass #2: texture FiLM + view layer + compositing on pass #1's layer-7 record",
+                            ev_ms(lambda: rr.render_with_film(film, f1, p1, n1, fa1, tex_conditions=tex, reuse_key=key)),
+                            flops=view_flop * RES * RES, nbytes=(BYTES_PER_RAY + (1024 + 4 + 2 * 256 * 4) * N_SAMPLES) * RES * RES))
+        rows.append(row("render pass #2 as a full launch (E3DGE_REUSE_BACKBONE=0" + ("; not part of the forward)" if reuse else ")"),
+                        ev_ms(lambda: rr.render_with_film(film, f1, p1, n1, fa1, tex_conditions=tex)),
+                        flops=FLOP_PER_RAY * RES * RES, nbytes=(BYTES_PER_RAY + 2 * 256 * 4 * N_SAMPLES) * RES * RES))
         dec = gl_.decoder
         latent, noise = dec.styles_and_noise_forward([w_d], None, input_is_latent=True, randomize_noise=False)
         fmap = out2['features'].contiguous()
@@ -485,7 +494,22 @@ def main():
                             "mean_ssim": float(table[:, 6].mean()),
                             "note": "BASELINE configs[2]: per image pass #1 render + texture head on (64,64,24,301) local features + "
                                     "pass #2 render + decoder 64^2->1024^2 (cm=2) + 8 metric scalars (ArcFace / LPIPS terms need "
-                                    "pretrained nets: reported as 0); images i -> rank i mod W, one all_gather of the (n,8) rows"}
+                                    "pretrained nets: reported as 0); images i -> rank i mod W, one all_gather of the (n,8) rows.  "
+                                    "Pass #2 reads pass #1's layer-7 record (same styles and poses; see inversion_fwd_note); "
+                                    "no_reuse = the same evaluation with pass #2 as a full render launch (E3DGE_REUSE_BACKBONE=0)"}
+            if os.environ.get("E3DGE_REUSE_BACKBONE", "1") != "0":
+                os.environ["E3DGE_REUSE_BACKBONE"] = "0"
+                try:
+                    with torch.no_grad():
+                        barrier()
+                        t0 = time.perf_counter()
+                        table0 = sharded_eval.evaluate_sharded(unit, n_units, rank, world, device=dev)
+                        barrier()
+                        e30 = max_over_ranks(time.perf_counter() - t0)
+                    result["c3"]["no_reuse"] = {"images_per_s": n_units / e30, "wall_s": e30, "ms_per_image_per_gpu": 1e3 * e30 / c3_per_rank,
+                                                "tables_identical": bool(torch.equal(table0, table))}
+                finally:
+                    os.environ.pop("E3DGE_REUSE_BACKBONE", None)
         except Exception as exc:  # the headline metric must still be printed
             result["c3"] = {"failed": f"{type(exc).__name__}: {exc}"}
 
@@ -553,9 +577,27 @@ def main():
                     o = inversion(w1, d1)
                 torch.cuda.synchronize()
                 result["inversion_fwd_ms"] = 1e3 * (time.perf_counter() - t1) / n_inv
+                if os.environ.get("E3DGE_REUSE_BACKBONE", "1") != "0":
+                    # the same forward with pass #2 as a full render launch (what rounds 1-2 measured)
+                    os.environ["E3DGE_REUSE_BACKBONE"] = "0"
+                    try:
+                        for _ in range(3):
+                            inversion(w1, d1)
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for _ in range(n_inv):
+                            inversion(w1, d1)
+                        torch.cuda.synchronize()
+                        result["inversion_fwd_no_reuse_ms"] = 1e3 * (time.perf_counter() - t1) / n_inv
+                    finally:
+                        os.environ.pop("E3DGE_REUSE_BACKBONE", None)
                 result["inversion_fwd_note"] = ("pass#1 render + texture head on (64,64,24,301) local features + pass#2 render with the "
                                                 "resulting texture FiLM + decoder 64^2->1024^2; encoder and the local branch's image "
-                                                "filters excluded (out of scope)")
+                                                "filters excluded (out of scope).  Pass #2 sees the same styles and poses as pass #1, and the "
+                                                "texture FiLM enters behind the sdf head: it reads pass #1's layer-7 record instead of "
+                                                "recomputing layers 0..7 + sdf head + transmittance scan (bit-identical outputs, "
+                                                "tests/test_gpu_texhead.py); inversion_fwd_no_reuse_ms is the same forward with pass #2 as a "
+                                                "full launch (E3DGE_REUSE_BACKBONE=0)")
                 assert tuple(o['gen_imgs'].shape) == (1, 3, 1024, 1024)
                 ref_img = o['gen_imgs'].clone()
                 result["inversion"] = {"kernels": inversion_kernel_table(gl, w1, d1, o), "note": (

@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E3DGE_LIB_PATH") or os.path.join(_HERE, "lib", "libe3dge_hip.so")   # override: kernel A/B variants
-ABI_VERSION = 9
+ABI_VERSION = 10
 PREC_F32, PREC_F16X3, PREC_F16X3_V1, PREC_F16X3_G2 = 0, 1, 2, 3
 AMAX_FLOATS = 64 * 32           # E3DGE_AMAX_FLOATS: one amax buffer (include/e3dge_hip.h)
 
@@ -27,6 +27,7 @@ class RenderArgs(ctypes.Structure):
         ("res", _i32), ("force_background", _i32), ("precision", _i32),
         ("rgb", _vp), ("features", _vp), ("xyz", _vp), ("depth", _vp), ("mask", _vp), ("sdf", _vp),
         ("weights", _vp), ("points", _vp), ("rays_d", _vp), ("viewdirs", _vp), ("dists", _vp), ("save_args", _vp),
+        ("backbone_out", _vp), ("backbone_in", _vp), ("weights_in", _vp),
     ]
 
 
@@ -121,6 +122,7 @@ SIGNATURES = {
     "e3dge_siren_pack_weights": (_i32, [_vp] * 11 + [_vp]),
     "e3dge_film_params": (_i32, [_vp] * 6 + [_i32, _vp]),
     "e3dge_siren_render_fwd": (_i32, [ctypes.POINTER(RenderArgs), _vp]),
+    "e3dge_siren_backbone_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "e3dge_siren_points_fwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _i64, _vp, _vp, _vp, _i32, _vp]),
     "e3dge_siren_bwd_partial_floats": (_i64, [_i32, _i64]),
     "e3dge_siren_bwd": (_i32, [ctypes.POINTER(SirenBwdArgs), _vp]),

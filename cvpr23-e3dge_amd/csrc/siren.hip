@@ -951,7 +951,11 @@ static int launch_siren(const SirenK& k, int precision, int64_t grid, hipStream_
     if (precision == E3DGE_PREC_F16X3) {
         // second-generation split-f16 kernel: 8 waves x 16 points, v_mfma_f32_16x16x32_f16 (siren16.h)
         static const KernelFn fns16[2] = {&siren16_kernel<MODE, false>, &siren16_kernel<MODE, true>};
-        const KernelFn fn = fns16[save];
+        KernelFn fn = fns16[save];
+        if constexpr (MODE == 0) {
+            if (k.bb_out) fn = &siren16_kernel<0, false, 1>;
+            else if (k.bb_in) fn = &siren16_kernel<0, false, 2>;
+        }
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, k16LdsBytes);
         if (e != hipSuccess)
             return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d): %s", k16LdsBytes, hipGetErrorString(e));
@@ -1049,9 +1053,28 @@ extern "C" int e3dge_siren_render_fwd(const E3dgeRenderArgs* r, e3dge_stream_t s
     const int64_t grid = (int64_t)k.tiles_per_img * r->batch;
     E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_render_fwd: grid too large");
     k.save_args = r->save_args;
+    if (r->backbone_out || r->backbone_in) {
+        E3DGE_REQUIRE(r->precision == E3DGE_PREC_F16X3 && !r->save_args, "siren_render_fwd: the backbone hand-over needs precision f16x3 and no save_args");
+        E3DGE_REQUIRE(!(r->backbone_out && r->backbone_in), "siren_render_fwd: backbone_out and backbone_in are exclusive");
+        E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(r->backbone_out) | reinterpret_cast<uintptr_t>(r->backbone_in)) & 15) == 0, "siren_render_fwd: backbone record must be 16-B aligned");
+        if (r->backbone_in)
+            E3DGE_REQUIRE(r->weights_in && !r->sdf && !r->weights && !r->xyz && !r->depth && !r->mask,
+                          "siren_render_fwd: a launch that reads the backbone record needs weights_in and produces only rgb / features (and the ray geometry)");
+        k.bb_out = r->backbone_out; k.bb_in = r->backbone_in; k.weights_in = r->weights_in;
+        k.bb_subs = (k.R * r->n_samples + kTilePts - 1) / kTilePts;
+    }
     int rc = launch_siren<0>(k, r->precision, grid, as_stream(stream));
     if (rc) return rc;
     return check_launch("siren_render_fwd");
+}
+
+extern "C" int64_t e3dge_siren_backbone_bytes(int batch, int height, int width, int n_samples) {
+    if (batch <= 0 || height <= 0 || width <= 0 || n_samples < kMinSamples) return 0;
+    const int64_t HW = (int64_t)height * width;
+    int R = pick_rays_per_wg(n_samples, HW * batch);
+    if (R > HW) R = (int)HW;
+    const int64_t grid = ((HW + R - 1) / R) * batch, subs = (R * (int64_t)n_samples + kTilePts - 1) / kTilePts;
+    return grid * subs * 8 * k16SlabWords * 16;
 }
 
 extern "C" int e3dge_siren_points_fwd(const float* packed, const float* film, const float* pts,

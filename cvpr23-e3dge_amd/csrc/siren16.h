@@ -34,7 +34,8 @@ constexpr int k16Chunks = kBigLayers * k16Tiles; // 128 chunks per 128-point sub
 #define E3DGE_16_SPLIT 0     // 1 = hidden layers with the two waves of a SIMD in opposite phases (measured 5 % SLOWER)
 #endif
 #ifndef E3DGE_16_ABL
-#define E3DGE_16_ABL 0      // timing ablation (wrong results): 4 = no workgroup barrier in the weight pipe
+#define E3DGE_16_ABL 0      // timing ablations (wrong results): 4 = no workgroup barrier in the weight pipe, 8 = no
+                            // transmittance scan, 16 = no colour compositing scan, 32 = no ordered merge of the feature partials
 #endif
 constexpr int k16NBuf = 4;                       // LDS weight buffers
 constexpr int k16Slots = 2;                      // rays a 16-point slab can touch when S >= 16
@@ -214,8 +215,16 @@ __device__ __forceinline__ void tile16(ChunkPipe16& pipe, int lane, const u32x4 
 #define PHASE16(i) do { } while (0)
 #endif
 
-template <int MODE, bool SAVE>
+// CACHE (render mode without SAVE only): 1 = also write the backbone output (layer 7, packed hi / lo) to a.bb_out, one 16-KiB
+// record per wave slab in register order; 2 = read it (and the composite weights a.weights_in) back instead of running layers
+// 0..7, the sdf head, alpha and the transmittance scan: the second pass of an evaluated image differs from the first only
+// behind the sdf head (texture FiLM -> view layer -> colour / feature compositing).  Geometry, launch shape and the point ->
+// (workgroup, sub-tile, wave, lane) mapping are those of the launch that wrote the record.
+constexpr int64_t k16SlabWords = 8 * 2 * 64;      // u32x4 per slab record: [g][hi | lo][lane]
+
+template <int MODE, bool SAVE, int CACHE = 0>
 __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
+    static_assert(CACHE == 0 || (MODE == 0 && !SAVE), "the backbone hand-over exists for inference renders only");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wbuf = smem + k16LdsW;
     float* const film_s = smem + k16LdsFilm;
@@ -261,7 +270,8 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
     const float* __restrict__ film_g = a.film + (int64_t)b * 9 * 2 * kWidth;
     // first weight chunks on their way (L2 -> LDS by DMA) while the tables below are built
     ChunkPipe16 pipe;
-    pipe.init(wbuf, packed + kOffBig16b, tid_k >> 6, tid_k & 63);
+    if (CACHE == 2) pipe.init(wbuf, packed + kOffBig16b + (int64_t)(kBigLayers - 1) * k16Tiles * k16ChunkFloats, tid_k >> 6, tid_k & 63, k16Tiles);
+    else pipe.init(wbuf, packed + kOffBig16b, tid_k >> 6, tid_k & 63);
     pipe.prime();
     // FiLM block with the layer bias folded into the offset and the weights' factor 128 divided out of gamma (layers >= 1)
     for (int i = tid_k; i < 9 * kWidth; i += k16Threads) {
@@ -389,7 +399,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
         // =====================================================================================
         // 2. layer 0 (3 -> 256) in the VALU: every lane its 4 features of each tile
         // =====================================================================================
-        {
+        if (CACHE != 2) {
             const float xs = __fmul_rn(px, a.box_scale), ys = __fmul_rn(py, a.box_scale), zs = __fmul_rn(pz, a.box_scale);
 #pragma unroll
             for (int t = 0; t < k16Tiles; ++t) {
@@ -491,7 +501,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
         }
 #else
 #pragma unroll 1
-        for (int L = 1; L < E3DGE_SIREN_DEPTH; ++L) {
+        for (int L = 1; L < ((CACHE == 2) ? 0 : E3DGE_SIREN_DEPTH); ++L) {
             const float* __restrict__ film_l = film + L * 2 * kWidth;
             f32x4v prev = zero4();
             auto finish = [&](int tp, const f32x4v& pv) {      // whole epilogue of tile tp (used for the layer's last tile)
@@ -552,13 +562,27 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
         }
 
 #endif
+        if (CACHE != 0) {
+            const int64_t rec = (((int64_t)blockIdx.x * a.bb_subs + sub) * 8 + wave) * k16SlabWords + lane;
+            if (CACHE == 1) {
+                u32x4* __restrict__ dst = reinterpret_cast<u32x4*>(a.bb_out) + rec;
+#pragma unroll
+                for (int g = 0; g < k16Steps; ++g) { dst[(g * 2 + 0) * 64] = inH[g]; dst[(g * 2 + 1) * 64] = inL[g]; }
+            } else {
+                const u32x4* __restrict__ src = reinterpret_cast<const u32x4*>(a.bb_in) + rec;
+#pragma unroll
+                for (int g = 0; g < k16Steps; ++g) { inH[g] = src[(g * 2 + 0) * 64]; inL[g] = src[(g * 2 + 1) * 64]; }
+            }
+        }
 
         PHASE16(2);
         // =====================================================================================
         // 4. sdf head on the backbone output (features on registers): 64 features per lane, then over the 4 lane groups
         // =====================================================================================
-        float sdf;
-        {
+        float sdf = 0.0f;
+        if (CACHE == 2) {
+            if (q == 0) wgt_s[p_sub] = valid ? a.weights_in[gpt] : 0.0f;      // (read back by this wave's own lanes and, after the
+        } else {                                                                //  barrier behind rgb_s, by the compositing threads)
             float acc = 0.0f;
 #pragma unroll
             for (int t = 0; t < k16Tiles; ++t) {
@@ -574,7 +598,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             sdf = acc + head_s[4 * kWidth];
         }
 
-        if (MODE == 0) {
+        if (MODE == 0 && CACHE != 2) {
             const float sg = __fdiv_rn(sigmoid_f32(__fdiv_rn(-sdf, a.sigmoid_beta)), a.sigmoid_beta);
             const float alpha = __fsub_rn(1.0f, expf(-__fmul_rn(sg, dist)));
             if (q == 0) {
@@ -588,7 +612,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             const int sub_lo = sub * kTilePts;
             const int sub_hi = min(sub_lo + kTilePts, npts);
             const int r_first = sub_lo / S, r_last = (sub_hi - 1) / S;
-            for (int i = tid; i <= r_last - r_first; i += k16Threads) {
+            for (int i = tid; i <= ((E3DGE_16_ABL & 8) ? -1 : r_last - r_first); i += k16Threads) {
                 const int rl = r_first + i;
                 const int s_lo = max(0, sub_lo - rl * S), s_hi = min(S, sub_hi - rl * S);
                 float* st = state + rl * kStateStride;
@@ -758,7 +782,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             const int sub_lo = sub * kTilePts;
             const int sub_hi = min(sub_lo + kTilePts, npts);
             const int r_first = sub_lo / S, r_last = (sub_hi - 1) / S;
-            for (int i = tid; i <= r_last - r_first; i += k16Threads) {
+            for (int i = tid; i <= ((E3DGE_16_ABL & 16) ? -1 : r_last - r_first); i += k16Threads) {
                 const int rl = r_first + i;
                 const int s_lo = max(0, sub_lo - rl * S), s_hi = min(S, sub_hi - rl * S);
                 float* st = state + rl * kStateStride;
@@ -781,7 +805,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
                 }
                 st[6] = c0; st[7] = c1; st[8] = c2;
             }
-            if (tid < kWidth) {   // ordered merge of the feature partials: slab by slab, ray slot by ray slot
+            if (tid < kWidth && !(E3DGE_16_ABL & 32)) {   // ordered merge of the feature partials: slab by slab, ray slot by ray slot
                 const int n = tid;
                 for (int wv = 0; wv < 8; ++wv) {
                     const int slab_lo = sub_lo + 16 * wv;

@@ -108,6 +108,10 @@ struct SirenK {
     const float* pts; const float* vdirs; long long n_pts; int subtiles_per_wg, wgs_per_img;
     float* raw;
     float* save_args;          // training: (points, 9, 256) pre-sine arguments of every layer, or null
+    // backbone hand-over between the two passes of one evaluated image (siren16_kernel<0, false, CACHE>): pass #1 writes the packed
+    // (hi, lo) output of layer 7 per 16-point slab, pass #2 (texture FiLM) reads it and the composite weights instead of
+    // recomputing layers 0..7, the sdf head and the transmittance scan -- they do not depend on the texture conditions
+    void* bb_out; const void* bb_in; const float* weights_in; int bb_subs;
 };
 
 // ---------------------------------------------------------------------------------------------

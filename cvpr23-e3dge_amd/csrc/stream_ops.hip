@@ -227,7 +227,7 @@ modconv_weights_kernel(float* __restrict__ out, const float* __restrict__ weight
 
 using namespace e3dge;
 
-extern "C" int e3dge_abi_version(void) { return 9; }
+extern "C" int e3dge_abi_version(void) { return 10; }
 extern "C" const char* e3dge_last_error(void) { return err_buf(); }
 
 extern "C" int e3dge_fused_bias_act(float* y, const float* x, const float* bias, const float* ref,

@@ -339,6 +339,16 @@ typedef struct E3dgeRenderArgs {
     float* dists;          /* (batch, H, W, S)    (:826-837)                                        */
     float* save_args;      /* training only, else NULL: (batch, H, W, S, 9, 256) pre-sine arguments of the 9 FiLM
                               layers, consumed by e3dge_siren_bwd                                        */
+    /* ---- backbone hand-over between the two renders of one evaluated image (precision f16x3, inference; all NULL otherwise) ----
+     * que_render_given_ref (e3dge_full_runner.py:185-317) renders the same rays twice: without and with the texture FiLM, which
+     * enters behind the sdf head (volume_renderer.py:217-220).  Layers 0..7, the sdf head, alpha and the transmittance scan are
+     * identical in both.  backbone_out: the first launch also writes its layer-7 output (e3dge_siren_backbone_bytes bytes).
+     * backbone_in + weights_in (that launch's `weights` output): the second launch, same sizes / poses / film, reads them and
+     * runs only texture FiLM -> view layer -> compositing; it produces rgb and features (+ ray geometry): sdf, weights, xyz,
+     * depth, mask must be NULL there (the first launch's are the values).  Results are bit-identical to a full launch. */
+    void* backbone_out;
+    const void* backbone_in;
+    const float* weights_in;
 } E3dgeRenderArgs;
 
 /*
@@ -350,6 +360,8 @@ typedef struct E3dgeRenderArgs {
  * Requires n_samples >= 16 (or use e3dge_siren_points_fwd for un-composited queries).
  */
 int e3dge_siren_render_fwd(const E3dgeRenderArgs* args, e3dge_stream_t stream);
+/* bytes of the backbone record of a render launch with these sizes (0 if the sizes are not renderable) */
+int64_t e3dge_siren_backbone_bytes(int batch, int height, int width, int n_samples);
 
 /*
  * Replaces VolumeFeatureRenderer.run_network on an arbitrary point set

@@ -4,6 +4,8 @@ from the reference's ResnetBlockFC and against the oracle on other sizes; then t
 Stated fp32 tolerance: outputs are O(10); the reference's own fp32 result is 9e-6 (abs) from the float64 evaluation on
 the fixture.  Bound: |hip - reference| <= 2e-5 * max(1, max|out|/10) (measured 4-9e-6) and |hip - f64| <= 3x the fp32 oracle's own
 distance (+1e-5)."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -160,3 +162,72 @@ def test_second_pass_from_local_feats():
     record("second_pass_from_local_feats", **e)
     assert e['tex_effect'] > 1e-2                        # the modulation does something
     assert e['features'] <= 1e-4 and e['rgb'] <= 5e-6 and e['sdf'] <= 1e-5, e
+
+
+@pytest.mark.parametrize("res,S,B", [(8, 24, 1), (16, 18, 2), (16, 48, 1), (64, 24, 1)])
+def test_second_pass_reads_the_first_passs_backbone(res, S, B, monkeypatch):
+    """The second pass of an evaluated image (same styles / poses, texture FiLM behind the sdf head) reads the layer-7 record
+    and the composite weights the first pass left behind (e3dge_siren_render_fwd backbone_out / backbone_in) instead of
+    recomputing layers 0..7 + sdf head + transmittance scan: every output must be BIT-identical to a full second pass; a
+    changed latent / pose / weight, grad mode, or E3DGE_REUSE_BACKBONE=0 must fall back to the full launch."""
+    from e3dge_amd import volume_renderer as vr
+    g, sd = full_state_dict(res=res, n_samples=S)
+    r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S, enable_local_model=True, L_pred_tex_modulations=True),
+                              out_im_res=res, mode='test')
+    own = {k: (syn.synthetic_tensor('renderer.' + k, v.shape) * 0.05 if 'netLocal' in k else
+               sd['renderer.' + k.replace('network.netGlobal.', 'network.')]) for k, v in r.state_dict().items()}
+    r.load_state_dict(own)
+    r = r.to(DEV).eval()
+    wr, _ = syn.synthetic_inputs(B, seed=4, device=DEV)
+    poses, focal, near, far, _ = generate_camera_params(res, DEV, locations=0.2 * torch.randn(B, 2, device=DEV))
+    feats = syn.synthetic_local_feats(B, res, S, device=DEV)
+    launches = []
+    orig = r.render_with_film
+
+    def spy(*a, **k):
+        rec = vr._BACKBONE.get(r)
+        launches.append((a[5] is not None if len(a) > 5 else k.get('tex_conditions') is not None,
+                         rec is not None and k.get('reuse_key') is not None and rec['key'] == k['reuse_key']))
+        return orig(*a, **k)
+    monkeypatch.setattr(r, "render_with_film", spy)
+    keys = ('features', 'gen_thumb_imgs', 'sdf', 'hit_prob', 'xyz', 'depth', 'mask', 'points', 'dists', 'rays_d', 'viewdirs')
+    with torch.no_grad():
+        monkeypatch.setenv("E3DGE_REUSE_BACKBONE", "0")
+        r(poses, focal, near, far, styles=wr)
+        full = r(poses, focal, near, far, styles=wr, local_data_batch={'feats': feats})
+        assert vr._BACKBONE.get(r) is None
+        monkeypatch.setenv("E3DGE_REUSE_BACKBONE", "1")
+        launches.clear()
+        p1 = r(poses, focal, near, far, styles=wr)
+        fast = r(poses, focal, near, far, styles=wr, local_data_batch={'feats': feats})
+        again = r(poses, focal, near, far, styles=wr, local_data_batch={'feats': 0.5 * feats})     # the record serves any number of second passes
+        assert launches == [(False, False), (True, True), (True, True)], launches
+        for k in keys:
+            assert torch.equal(fast[k], full[k]), k
+        assert not torch.equal(again['features'], fast['features']) and torch.equal(again['sdf'], full['sdf'])
+        assert torch.equal(p1['sdf'], full['sdf'])
+        # misses: another latent (new tensor), the same tensor edited in place, another pose
+        launches.clear()
+        wr2 = wr.clone()
+        miss1 = r(poses, focal, near, far, styles=wr2, local_data_batch={'feats': feats})
+        wr.mul_(1.0)
+        miss2 = r(poses, focal, near, far, styles=wr, local_data_batch={'feats': feats})
+        assert [l[1] for l in launches] == [False, False], launches
+        for k in keys:
+            assert torch.equal(miss1[k], full[k]) and torch.equal(miss2[k], full[k]), k
+        r(poses, focal, near, far, styles=wr)
+        poses2 = poses.clone()
+        poses2[:, 0, 3] += 0.05
+        launches.clear()
+        other = r(poses2, focal, near, far, styles=wr, local_data_batch={'feats': feats})
+        assert launches == [(True, False)] and not torch.equal(other['xyz'], full['xyz'])
+    # the C entry refuses inconsistent requests
+    from e3dge_amd import _lib
+    lib = _lib.load()
+    one = 16
+    bad = _lib.RenderArgs(packed=one, film=one, c2w=one, focal=one, near=one, far=one, t_vals=one, sigmoid_beta=1.0, batch=1, height=8, width=8,
+                          n_samples=24, res=8, precision=_lib.PREC_F32, backbone_out=one)
+    assert lib.e3dge_siren_render_fwd(ctypes.byref(bad), None) == -1                      # only the f16x3 kernel has the hand-over
+    bad.precision, bad.backbone_out, bad.backbone_in = _lib.PREC_F16X3, None, one
+    assert lib.e3dge_siren_render_fwd(ctypes.byref(bad), None) == -1                      # backbone_in without weights_in
+    assert lib.e3dge_siren_backbone_bytes(1, 64, 64, 24) == 256 * 3 * 8 * 16384 and lib.e3dge_siren_backbone_bytes(1, 8, 8, 4) == 0
