@@ -61,6 +61,9 @@ summ "$OUT/trace_decoder" "$OUT/r3_decoder_pass_kernel_stats.txt" "rocprofv3 --k
 echo "== (c) training step"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_train" -o t -- python $REPO/tools/c5_step.py > "$OUT/trace_train.log" 2>&1
 summ "$OUT/trace_train" "$OUT/r3_train_step_kernel_stats.txt" "rocprofv3 --kernel-trace --stats -- python tools/c5_step.py"
+echo "== (d) evaluated images (two render passes with the backbone hand-over, texture head, decoder, metrics)"
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c3" -o t -- python $REPO/tools/time_c3.py 128 > "$OUT/trace_c3.log" 2>&1
+summ "$OUT/trace_c3" "$OUT/r3_c3_images_kernel_stats.txt" "rocprofv3 --kernel-trace --stats -- python tools/time_c3.py 128   (6 timed loops of 128 evaluated images, some on 2-3 streams)"
 echo "== PMC"
 pmc dec_issue "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY" python $REPO/tools/decoder_bench.py
 pmc dec_lds "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SALU GRBM_GUI_ACTIVE" python $REPO/tools/decoder_bench.py
