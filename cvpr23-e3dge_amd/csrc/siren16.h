@@ -93,6 +93,31 @@ __device__ __forceinline__ float row_sum16(float x) {
     return x;
 }
 
+// Wave-wide inclusive scans in the VALU (DPP; gfx9 controls row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143,
+// wave_shr:1 = 0x138): four shifted steps inside every 16-lane row, then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into
+// rows 2 and 3.  Lanes a step does not reach combine with the identity.  Lane 63 ends up with the reduction over the wave.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_or(float ident, float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, ident), __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_incl_prod(float x) {
+    x = __fmul_rn(x, dpp_or<0x111, 0xf>(1.0f, x));
+    x = __fmul_rn(x, dpp_or<0x112, 0xf>(1.0f, x));
+    x = __fmul_rn(x, dpp_or<0x114, 0xf>(1.0f, x));
+    x = __fmul_rn(x, dpp_or<0x118, 0xf>(1.0f, x));
+    x = __fmul_rn(x, dpp_or<0x142, 0xa>(1.0f, x));
+    x = __fmul_rn(x, dpp_or<0x143, 0xc>(1.0f, x));
+    return x;
+}
+__device__ __forceinline__ float wave_sum_last(float x) {      // the sum over the wave, valid in lane 63 (broadcast below)
+    x = __fadd_rn(x, dpp_or<0x111, 0xf>(0.0f, x));
+    x = __fadd_rn(x, dpp_or<0x112, 0xf>(0.0f, x));
+    x = __fadd_rn(x, dpp_or<0x114, 0xf>(0.0f, x));
+    x = __fadd_rn(x, dpp_or<0x118, 0xf>(0.0f, x));
+    x = __fadd_rn(x, dpp_or<0x142, 0xa>(0.0f, x));
+    x = __fadd_rn(x, dpp_or<0x143, 0xc>(0.0f, x));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
+}
+
 // 16-KiB weight chunks through k16NBuf LDS buffers; every wave moves a 2-KiB slice (two LDS-DMA pieces) of each chunk.
 //   tile g: sync() -> wait for everything but the chunk issued one tile ago, barrier (publishes chunk g+2, proves tile g-1 is
 //   finished) -> issue chunk g+3 into the buffer tile g-1 used: two tile times to arrive.
@@ -608,42 +633,44 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
                 if (valid && a.sdf) a.sdf[gpt] = sdf;
             }
             __syncthreads();
-            // transmittance scan (:869-886): one thread per ray touching this sub-tile, front to back
+            // transmittance scan (:869-886) as a wavefront prefix product: a wave per ray touching this sub-tile, a lane per sample
+            // (64 at a time, front to back): T_s = T_in * prod_{j < s} (1 - alpha_j + 1e-10) from one inclusive DPP scan shifted by a
+            // lane, the weight sum in front of the last sample and the weighted depth / position sums as DPP reductions.
+            // (Same terms as the reference's cumprod / sum; the association order is the scan tree's.)
             const int sub_lo = sub * kTilePts;
             const int sub_hi = min(sub_lo + kTilePts, npts);
             const int r_first = sub_lo / S, r_last = (sub_hi - 1) / S;
-            for (int i = tid; i <= ((E3DGE_16_ABL & 8) ? -1 : r_last - r_first); i += k16Threads) {
+            for (int i = __builtin_amdgcn_readfirstlane(wave); i <= ((E3DGE_16_ABL & 8) ? -1 : r_last - r_first); i += 8) {
                 const int rl = r_first + i;
                 const int s_lo = max(0, sub_lo - rl * S), s_hi = min(S, sub_hi - rl * S);
                 float* st = state + rl * kStateStride;
-                float T = (s_lo == 0) ? 1.0f : st[0];
+                float T_in = (s_lo == 0) ? 1.0f : st[0];
                 float wsum = (s_lo == 0) ? 0.0f : st[1];
-                float dep = st[2], x0 = st[3], x1 = st[4], x2 = st[5];
-                for (int s0 = s_lo; s0 < s_hi; s0 += 4) {
-                    float al[4], zz[4], p0[4], p1[4], p2[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int ps = min(rl * S + s0 + u, sub_hi - 1) - sub_lo;
-                        al[u] = alpha_s[ps]; zz[u] = z_s[ps];
-                        p0[u] = pts_s[ps * 3 + 0]; p1[u] = pts_s[ps * 3 + 1]; p2[u] = pts_s[ps * 3 + 2];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int s = s0 + u;
-                        if (s < s_hi) {
-                            float w = __fmul_rn(al[u], T);
-                            if (a.force_bg && s == S - 1) w = __fsub_rn(1.0f, wsum);
-                            else wsum = __fadd_rn(wsum, w);
-                            T = __fmul_rn(T, __fadd_rn(__fsub_rn(1.0f, al[u]), 1e-10f));
-                            wgt_s[rl * S + s - sub_lo] = w;
-                            dep = __fadd_rn(dep, __fmul_rn(w, zz[u]));
-                            x0 = __fadd_rn(x0, __fmul_rn(w, p0[u]));
-                            x1 = __fadd_rn(x1, __fmul_rn(w, p1[u]));
-                            x2 = __fadd_rn(x2, __fmul_rn(w, p2[u]));
-                        }
-                    }
+                float dep = 0.0f, x0 = 0.0f, x1 = 0.0f, x2 = 0.0f;
+                for (int c0 = s_lo; c0 < s_hi; c0 += 64) {
+                    const int s = c0 + lane;
+                    const bool act = s < s_hi;
+                    const int ps = rl * S + min(s, s_hi - 1) - sub_lo;
+                    const float al = act ? alpha_s[ps] : 0.0f;
+                    const float zz = z_s[ps], p0 = pts_s[ps * 3 + 0], p1 = pts_s[ps * 3 + 1], p2 = pts_s[ps * 3 + 2];
+                    const float incl = wave_incl_prod(act ? __fadd_rn(__fsub_rn(1.0f, al), 1e-10f) : 1.0f);
+                    const float T = __fmul_rn(T_in, dpp_or<0x138, 0xf>(1.0f, incl));
+                    float w = __fmul_rn(al, T);
+                    const bool last = a.force_bg && act && s == S - 1;
+                    const float wfront = wave_sum_last(last ? 0.0f : w);
+                    if (last) w = __fsub_rn(1.0f, __fadd_rn(wsum, wfront));
+                    wsum = __fadd_rn(wsum, wfront);
+                    if (act) wgt_s[ps] = w;
+                    dep = __fadd_rn(dep, wave_sum_last(__fmul_rn(w, zz)));
+                    x0 = __fadd_rn(x0, wave_sum_last(__fmul_rn(w, p0)));
+                    x1 = __fadd_rn(x1, wave_sum_last(__fmul_rn(w, p1)));
+                    x2 = __fadd_rn(x2, wave_sum_last(__fmul_rn(w, p2)));
+                    T_in = __fmul_rn(T_in, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, incl), 63)));
                 }
-                st[0] = T; st[1] = wsum; st[2] = dep; st[3] = x0; st[4] = x1; st[5] = x2;
+                if (lane == 0) {
+                    st[0] = T_in; st[1] = wsum;
+                    st[2] = __fadd_rn(st[2], dep); st[3] = __fadd_rn(st[3], x0); st[4] = __fadd_rn(st[4], x1); st[5] = __fadd_rn(st[5], x2);
+                }
             }
             __syncthreads();
             if (valid && q == 0 && a.weights) a.weights[gpt] = wgt_s[p_sub];
@@ -782,40 +809,50 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             const int sub_lo = sub * kTilePts;
             const int sub_hi = min(sub_lo + kTilePts, npts);
             const int r_first = sub_lo / S, r_last = (sub_hi - 1) / S;
-            for (int i = tid; i <= ((E3DGE_16_ABL & 16) ? -1 : r_last - r_first); i += k16Threads) {
+            for (int i = __builtin_amdgcn_readfirstlane(wave); i <= ((E3DGE_16_ABL & 16) ? -1 : r_last - r_first); i += 8) {   // a wave per ray, a lane per sample
                 const int rl = r_first + i;
                 const int s_lo = max(0, sub_lo - rl * S), s_hi = min(S, sub_hi - rl * S);
-                float* st = state + rl * kStateStride;
-                float c0 = st[6], c1 = st[7], c2 = st[8];
-                for (int s0 = s_lo; s0 < s_hi; s0 += 4) {
-                    float ww[4], g0[4], g1[4], g2[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int ps = min(rl * S + s0 + u, sub_hi - 1) - sub_lo;
-                        ww[u] = (s0 + u < s_hi) ? wgt_s[ps] : 0.0f;
-                        g0[u] = rgb_s[ps * 3 + 0]; g1[u] = rgb_s[ps * 3 + 1]; g2[u] = rgb_s[ps * 3 + 2];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (s0 + u < s_hi) {
-                            c0 = __fadd_rn(c0, __fmul_rn(ww[u], g0[u]));
-                            c1 = __fadd_rn(c1, __fmul_rn(ww[u], g1[u]));
-                            c2 = __fadd_rn(c2, __fmul_rn(ww[u], g2[u]));
-                        }
+                float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f;
+                for (int b0 = s_lo; b0 < s_hi; b0 += 64) {
+                    const int s = b0 + lane;
+                    const int ps = rl * S + min(s, s_hi - 1) - sub_lo;
+                    const float ww = (s < s_hi) ? wgt_s[ps] : 0.0f;
+                    c0 = __fadd_rn(c0, wave_sum_last(__fmul_rn(ww, rgb_s[ps * 3 + 0])));
+                    c1 = __fadd_rn(c1, wave_sum_last(__fmul_rn(ww, rgb_s[ps * 3 + 1])));
+                    c2 = __fadd_rn(c2, wave_sum_last(__fmul_rn(ww, rgb_s[ps * 3 + 2])));
                 }
-                st[6] = c0; st[7] = c1; st[8] = c2;
+                if (lane == 0) {
+                    float* st = state + rl * kStateStride;
+                    st[6] = __fadd_rn(st[6], c0); st[7] = __fadd_rn(st[7], c1); st[8] = __fadd_rn(st[8], c2);
+                }
             }
             if (tid < kWidth && !(E3DGE_16_ABL & 32)) {   // ordered merge of the feature partials: slab by slab, ray slot by ray slot
                 const int n = tid;
+                float pv[8 * k16Slots];                      // (all sixteen loads in flight at once; unused slots are never added)
+#pragma unroll
+                for (int j = 0; j < 8 * k16Slots; ++j) pv[j] = part[j * kWidth + n];
+                int cur = -1;
+                float run = 0.0f;
+#pragma unroll
                 for (int wv = 0; wv < 8; ++wv) {
                     const int slab_lo = sub_lo + 16 * wv;
                     const int slab_hi2 = min(slab_lo + 16, npts);
-                    if (slab_hi2 <= slab_lo) break;
-                    const int fr = slab_lo / S;
-                    const int ns = (slab_hi2 - 1) / S - fr + 1;
-                    for (int sl = 0; sl < ns; ++sl)
-                        feat_acc[(fr + sl) * kFPitch + n] += part[(wv * k16Slots + sl) * kWidth + n];
+                    if (slab_hi2 > slab_lo) {
+                        const int fr = slab_lo / S;
+                        const int ns = (slab_hi2 - 1) / S - fr + 1;
+#pragma unroll
+                        for (int sl = 0; sl < k16Slots; ++sl)
+                            if (sl < ns) {
+                                if (fr + sl != cur) {
+                                    if (cur >= 0) feat_acc[cur * kFPitch + n] += run;
+                                    cur = fr + sl;
+                                    run = 0.0f;
+                                }
+                                run += pv[wv * k16Slots + sl];
+                            }
+                    }
                 }
+                if (cur >= 0) feat_acc[cur * kFPitch + n] += run;
             }
             __syncthreads();
         } else {
