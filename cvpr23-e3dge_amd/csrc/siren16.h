@@ -93,6 +93,19 @@ __device__ __forceinline__ float row_sum16(float x) {
     return x;
 }
 
+// x[l] + x[l ^ 16] + x[l ^ 32] + x[l ^ 48] in every lane (the sum over the four 16-lane groups q), in the VALU: v_permlane16_swap
+// exchanges the odd rows of its first operand with the even rows of the second, v_permlane32_swap the upper half of the first
+// with the lower half of the second -- fed the same register twice, the two results add up to the pairwise sums.  (The same
+// tree as two __shfl_xor steps, without their ds_bpermute round trips through the LDS crossbar.)
+__device__ __forceinline__ float sum_over_q(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float y = __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+    const unsigned v = __builtin_bit_cast(unsigned, y);
+    const auto t = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return __builtin_bit_cast(float, (unsigned)t[0]) + __builtin_bit_cast(float, (unsigned)t[1]);
+}
+
 // Wave-wide inclusive scans in the VALU (DPP; gfx9 controls row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143,
 // wave_shr:1 = 0x138): four shifted steps inside every 16-lane row, then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into
 // rows 2 and 3.  Lanes a step does not reach combine with the identity.  Lane 63 ends up with the reduction over the wave.
@@ -618,9 +631,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
                 acc = fma_mix_h<0>(inH[g][w0i + 1], w4[2], acc); acc = fma_mix_h<0>(inL[g][w0i + 1], w4[2], acc);
                 acc = fma_mix_h<1>(inH[g][w0i + 1], w4[3], acc); acc = fma_mix_h<1>(inL[g][w0i + 1], w4[3], acc);
             }
-            acc += __shfl_xor(acc, 16, kWave);
-            acc += __shfl_xor(acc, 32, kWave);
-            sdf = acc + head_s[4 * kWidth];
+            sdf = sum_over_q(acc) + head_s[4 * kWidth];
         }
 
         if (MODE == 0 && CACHE != 2) {
@@ -752,8 +763,8 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             };
             auto epi_end = [&]() {
                 if (MODE == 0) {
-                    fa0 += __shfl_xor(fa0, 16, kWave); fa0 += __shfl_xor(fa0, 32, kWave);
-                    fa1 += __shfl_xor(fa1, 16, kWave); fa1 += __shfl_xor(fa1, 32, kWave);
+                    fa0 = sum_over_q(fa0);
+                    fa1 = sum_over_q(fa1);
                     if (q == 0) {
                         float* pp = part + (wave * k16Slots) * kWidth + e_n;
                         if (slab_nslots > 0) pp[0] = fa0;
