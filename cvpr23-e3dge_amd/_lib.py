@@ -98,6 +98,7 @@ class WsLinear(ctypes.Structure):
 SIGNATURES = {
     "e3dge_abi_version": (_i32, []),
     "e3dge_last_error": (ctypes.c_char_p, []),
+    "e3dge_stream_capture_id": (_i64, [_vp]),
     "e3dge_fused_bias_act": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _i64, _i64, _i64, _vp]),
     "e3dge_noise_bias_act": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i64, _i64, _i64, _vp]),
     "e3dge_upfirdn2d": (_i32, [_vp, _vp, _vp, _i64] + [_i32] * 12 + [_vp]),

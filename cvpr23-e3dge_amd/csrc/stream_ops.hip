@@ -230,6 +230,13 @@ using namespace e3dge;
 extern "C" int e3dge_abi_version(void) { return 10; }
 extern "C" const char* e3dge_last_error(void) { return err_buf(); }
 
+extern "C" int64_t e3dge_stream_capture_id(e3dge_stream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo(as_stream(stream), &st, &id) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return st == hipStreamCaptureStatusActive ? (int64_t)id + 1 : 0;
+}
+
 extern "C" int e3dge_fused_bias_act(float* y, const float* x, const float* bias, const float* ref,
                                     int act, int grad, float alpha, float scale, int64_t n,
                                     int64_t step_b, int64_t size_b, e3dge_stream_t stream) {

@@ -888,6 +888,9 @@ class VolumeFeatureRenderer(nn.Module):
         f32 = dict(device=dev, dtype=torch.float32)
         use = bb_out = None
         if reuse_key is not None and B > 0 and self._reuse_enabled(save_args):
+            # producer and consumer of a record must be both eager or both inside the same graph capture (a graph holding only the
+            # second pass would replay against whatever the record held at capture time)
+            reuse_key = reuse_key + (_lib.load().e3dge_stream_capture_id(_lib.stream_of(c2w)),)
             rec = _BACKBONE.get(self)
             if tex_conditions is None:                       # first pass: leave a record behind
                 n_bytes = _lib.load().e3dge_siren_backbone_bytes(B, H, Wd, S)

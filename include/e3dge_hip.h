@@ -29,6 +29,10 @@ enum {
 
 /* ABI version; bumped whenever a signature below changes. */
 int e3dge_abi_version(void);
+/* 0 when `stream` is not being captured into a HIP graph, otherwise a positive id unique to the capture session (-1: query failed).
+ * Host-side caches that hand device buffers from one launch to a later one (the backbone record of E3dgeRenderArgs) use it to
+ * keep producer and consumer inside the same capture -- a graph that holds only the consumer would replay against a stale buffer. */
+int64_t e3dge_stream_capture_id(e3dge_stream_t stream);
 /* Thread-local message of the most recent failing call on this thread ("" if none). */
 const char* e3dge_last_error(void);
 

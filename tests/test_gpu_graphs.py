@@ -37,3 +37,48 @@ def test_generator_forward_replays_bit_identically_with_new_inputs():
         gc(codes[0][0])
     with pytest.raises(RuntimeError):
         GraphedCall(fwd, torch.zeros(3))
+
+
+def test_backbone_record_never_crosses_a_capture_boundary():
+    """The second render pass may read the first pass's layer-7 record only when both are eager or both inside the SAME capture:
+    a graph that holds only the second pass must contain a full render (it would otherwise replay against a stale record);
+    a graph that holds both passes replays them together and stays bit-identical to eager for new latents."""
+    from e3dge_amd import volume_renderer as vr
+    from e3dge_amd.volume_renderer import VolumeFeatureRenderer
+    res, S = 16, 24
+    g, sd = full_state_dict(res=res, n_samples=S)
+    r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S, enable_local_model=True, L_pred_tex_modulations=True), out_im_res=res, mode='test')
+    r.load_state_dict({k: (syn.synthetic_tensor('renderer.' + k, v.shape) * 0.05 if 'netLocal' in k else
+                           sd['renderer.' + k.replace('network.netGlobal.', 'network.')]) for k, v in r.state_dict().items()})
+    r = r.to(DEV).eval()
+    poses, focal, near, far, _ = generate_camera_params(res, DEV, locations=torch.zeros(1, 2, device=DEV))
+    feats = syn.synthetic_local_feats(1, res, S, device=DEV)
+    w1, w2 = (syn.synthetic_inputs(1, seed=s, device=DEV)[0] for s in (5, 6))
+    hits = []
+    orig = r.render_with_film
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        rec = vr._BACKBONE.get(r)
+        hits.append(len(a) > 5 and a[5] is not None and out['sdf'] is (rec['out']['sdf'] if rec else None))
+        return out
+    r.render_with_film = spy
+
+    def both(w):
+        r(poses, focal, near, far, styles=w)
+        return r(poses, focal, near, far, styles=w, local_data_batch={'feats': feats})['features']
+
+    def second_only(w):
+        return r(poses, focal, near, far, styles=w, local_data_batch={'feats': feats})['features']
+    with torch.no_grad():
+        e1, e2 = both(w1).clone(), both(w2).clone()
+        assert hits == [False, True, False, True]                     # eager: the second pass of each pair starts from the record
+        g_both = GraphedCall(both, w1)
+        hits.clear()
+        r(poses, focal, near, far, styles=w1)                          # an eager first pass leaves a record for exactly these tensors ...
+        g_second = GraphedCall(second_only, w1)                        # ... which the capture of a lone second pass must not pick up
+        assert hits[-1] is False
+        for w, want in ((w2, e2), (w1, e1), (w2, e2)):
+            assert torch.equal(g_both(w)[...], want)
+            assert torch.equal(g_second(w)[...], want)
+    assert not torch.equal(e1, e2)
