@@ -961,6 +961,7 @@ class VolumeFeatureRenderer(nn.Module):
         EMA accumulate(), utils/training_utils.py:45); optimizer steps, load_state_dict, .to() and train()/eval() are
         detected without it."""
         self._sb_key = None
+        _BACKBONE.pop(self, None)                             # (the first pass's layer-7 record was computed from the old values)
         for m in self.modules():
             if m is not self and hasattr(m, 'invalidate'):
                 m.invalidate()

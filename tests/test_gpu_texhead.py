@@ -217,6 +217,11 @@ def test_second_pass_reads_the_first_passs_backbone(res, S, B, monkeypatch):
         for k in keys:
             assert torch.equal(miss1[k], full[k]) and torch.equal(miss2[k], full[k]), k
         r(poses, focal, near, far, styles=wr)
+        r.invalidate()                                     # (what a caller does after editing weights / inputs through .data)
+        launches.clear()
+        miss3 = r(poses, focal, near, far, styles=wr, local_data_batch={'feats': feats})
+        assert launches == [(True, False)] and torch.equal(miss3['features'], full['features'])
+        r(poses, focal, near, far, styles=wr)
         poses2 = poses.clone()
         poses2[:, 0, 3] += 0.05
         launches.clear()
