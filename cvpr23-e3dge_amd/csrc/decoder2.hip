@@ -1529,10 +1529,17 @@ extern "C" int e3dge_dec2_forward(const E3dgeDec2Plan* P, e3dge_stream_t stream)
     hipEvent_t ev[8 + 4 * E3DGE_DEC2_MAX_UP];
     bool fused_away[8 + 4 * E3DGE_DEC2_MAX_UP] = {};
     int n_ev = 0;
-    auto mark = [&](bool fused = false) { if (timing) { hipEventCreate(&ev[n_ev]); hipEventRecord(ev[n_ev], st); fused_away[n_ev] = fused; ++n_ev; } };
+    bool ev_failed = false;
+    auto mark = [&](bool fused = false) {
+        if (!timing || ev_failed) return;
+        if (hipEventCreate(&ev[n_ev]) != hipSuccess) { ev_failed = true; return; }
+        fused_away[n_ev] = fused;
+        if (hipEventRecord(ev[n_ev++], st) != hipSuccess) ev_failed = true;
+    };
     auto finish = [&](int code) {
         if (timing) {
-            if (code == 0) {
+            if (code == 0 && ev_failed) code = fail(E3DGE_ERR_LAUNCH, "dec2_forward: HIP event create / record failed (kernel_ms)");
+            if (code == 0 && n_ev > 0) {
                 hipEventSynchronize(ev[n_ev - 1]);
                 for (int i = 0; i + 1 < n_ev; ++i) {
                     hipEventElapsedTime(&P->kernel_ms[i], ev[i], ev[i + 1]);
@@ -1633,13 +1640,13 @@ extern "C" int e3dge_dec2_forward(const E3dgeDec2Plan* P, e3dge_stream_t stream)
             if (shape_override("E3DGE_DEC2_BLUR") == 1) {
                 pk_blur_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(k);
             } else {
-                E3DGE_REQUIRE(cu.co <= 1024 && blocks < ((int64_t)1 << 30), "dec2 blur: too many channels / tiles");
+                if (!(cu.co <= 1024 && blocks < ((int64_t)1 << 30))) return finish(fail(E3DGE_ERR_INVALID_ARG, "dec2 blur: too many channels / tiles"));
                 auto fn = &pk_blur2_kernel;
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kPb2Lds);
                 if (e != hipSuccess) return finish(fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(dec2 blur): %s", hipGetErrorString(e)));
                 const int tiles_y2 = (res + kPb2Rows - 1) / kPb2Rows;
                 const int64_t tiles2 = (int64_t)k.tiles_x * tiles_y2 * (cu.co / 8) * B;
-                E3DGE_REQUIRE(tiles2 < ((int64_t)1 << 30), "dec2 blur: too many tiles");
+                if (!(tiles2 < ((int64_t)1 << 30))) return finish(fail(E3DGE_ERR_INVALID_ARG, "dec2 blur: too many tiles"));
                 const int grid = tiles2 < 512 ? (int)tiles2 : 512;        // two 70-KB workgroups per CU
                 fn<<<dim3((unsigned)grid), dim3(kPb2Threads), kPb2Lds, st>>>(k, (int)tiles2, tiles_y2);
             }

@@ -556,6 +556,8 @@ class Decoder(nn.Module):
             return False
         if features.device.type != "cuda" or features.dtype != torch.float32 or latent.dtype != torch.float32:
             return False
+        if latent.device != features.device:
+            return False
         if features.ndim != 4 or features.shape[2] != features.shape[3] or features.shape[2] < 4 or features.shape[2] % 2:
             return False
         if len(self.to_rgbs) > _lib.DEC2_MAX_UP or features.shape[0] < 1:
@@ -576,18 +578,26 @@ class Decoder(nn.Module):
         return all(n is None or (n.device == features.device and n.dtype == torch.float32) for n in noise)
 
     def _noise_amax(self, nz):
-        """amax buffer with max|noise| (the packed producers need it for their operand-scale bound); cached per tensor version."""
+        """amax buffer with max|noise| (the packed producers need it for their operand-scale bound).  Cached only for the
+        module's own registered `noises.noise_i` buffers, and the entry keeps the tensor it was measured on: a (data_ptr,
+        version) key alone is recycled by the caching allocator (every fresh `normal_()` tensor has version 1 and lands on
+        the block the previous call freed), which would hand a caller-supplied noise the maximum of an older tensor -- and
+        with it an operand-scale bound that is too small.  Ad-hoc / random noise is measured on every call (one launch)."""
+        own = any(nz is b for b in self.noises.buffers())
         cache = _DEC2_NOISE_AMAX.setdefault(self, {})
-        key = (nz.data_ptr(), nz._version, tuple(nz.shape), str(nz.device))
-        hit = cache.get(key)
-        if hit is None:
-            hit = torch.zeros(_lib.AMAX_FLOATS, device=nz.device, dtype=torch.float32)
-            with torch.cuda.device(nz.device):
-                _lib.check(_lib.load().e3dge_amax(_lib.ptr(hit), _lib.ptr(nz), nz.numel(), _lib.stream_of(nz)), "e3dge_amax")
+        key = (nz.data_ptr(), tuple(nz.shape), str(nz.device))
+        if own:
+            hit = cache.get(key)
+            if hit is not None and hit[0] is nz and hit[1] == nz._version:
+                return hit[2]
+        am = torch.zeros(_lib.AMAX_FLOATS, device=nz.device, dtype=torch.float32)
+        with torch.cuda.device(nz.device):
+            _lib.check(_lib.load().e3dge_amax(_lib.ptr(am), _lib.ptr(nz), nz.numel(), _lib.stream_of(nz)), "e3dge_amax")
+        if own:
             if len(cache) >= 64:
                 cache.pop(next(iter(cache)))
-            cache[key] = hit
-        return hit
+            cache[key] = (nz, nz._version, am)
+        return am
 
     def _dec2_state(self, B, res, device):
         """Workspace + plan of the packed pipeline for one (batch, input resolution, device, stream): packed activation

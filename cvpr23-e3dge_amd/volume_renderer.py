@@ -36,6 +36,32 @@ def _reuse_backbone():                                                 # second 
     return os.environ.get("E3DGE_REUSE_BACKBONE", "1") != "0"
 
 
+class _ReuseKey:
+    """Key of a backbone record: strong references to the tensors + their version counters + plain scalars."""
+    __slots__ = ('tensors', 'sig', 'scalars')
+
+    def __init__(self, tensors, scalars):
+        self.tensors = tuple(tensors)
+        self.sig = tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride())) if torch.is_tensor(t) else t
+                         for t in self.tensors)
+        self.scalars = tuple(scalars)
+
+    def extended(self, *more):
+        k = _ReuseKey.__new__(_ReuseKey)
+        k.tensors, k.sig, k.scalars = self.tensors, self.sig, self.scalars + tuple(more)
+        return k
+
+    def matches(self, rec_key):
+        """`self` describes the current call, `rec_key` the recorded one (whose tensors are alive by construction)."""
+        if rec_key is None or self.scalars != rec_key.scalars or self.sig != rec_key.sig:
+            return False
+        # the packed weight image is compared by identity (it is rebuilt, not edited); the recorded tensors must not have
+        # been edited in place since (their version is part of sig: re-read it from the LIVE recorded tensors)
+        if self.tensors[-1] is not rec_key.tensors[-1]:
+            return False
+        return all((t._version == s[1]) for t, s in zip(rec_key.tensors, rec_key.sig) if torch.is_tensor(t))
+
+
 _BACKBONE = weakref.WeakKeyDictionary()                                # renderer -> {key, buf (record), out (first pass's tensors)}
 _SIDE_STREAMS = {}                                                     # per device (module level: modules stay deep-copyable)
 
@@ -850,14 +876,15 @@ class VolumeFeatureRenderer(nn.Module):
 
     # ---- backbone hand-over between the two renders of an evaluated image -------------------------------------------------
     def _reuse_key(self, styles, focal, c2w, near, far):
-        """Identity of everything layers 0..7, the sdf head and the scan depend on (tensor storage + version counters: an
-        in-place edit through autograd-visible ops changes it; edits through `.data` need invalidate(), as for the weights)."""
-        def tk(t):
-            return (t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride())) if torch.is_tensor(t) else t
+        """Identity of everything layers 0..7, the sdf head and the scan depend on.  The key HOLDS the tensors it names (and
+        the packed weight image): as long as a record exists their storage cannot be freed and handed to another tensor, so
+        equal (data_ptr, shape, stride, version) means the same live memory with the same autograd-visible contents -- a
+        freed latent and a new one the caching allocator places at the same address can no longer alias (round-3 ABA).
+        Edits through `.data` / graph replays into the same buffers still need invalidate(), as for the weights."""
         dev = c2w.device
-        return (tk(styles), tk(focal), tk(c2w), tk(near), tk(far), self.N_samples, self.out_im_res, str(dev),
-                torch.cuda.current_stream(dev).cuda_stream, id(self.siren.device_image()[0]), self.siren.mfma_mode,
-                tk(self.sigmoid_beta), bool(self.force_background), float(self.box_scale))
+        return _ReuseKey((styles, focal, c2w, near, far, self.sigmoid_beta, self.siren.device_image()[0]),
+                         (self.N_samples, self.out_im_res, str(dev), torch.cuda.current_stream(dev).cuda_stream,
+                          self.siren.mfma_mode, bool(self.force_background), float(self.box_scale)))
 
     def _reuse_enabled(self, save_args):
         return (_reuse_backbone() and save_args is None and not torch.is_grad_enabled() and self.enable_local_model
@@ -890,7 +917,7 @@ class VolumeFeatureRenderer(nn.Module):
         if reuse_key is not None and B > 0 and self._reuse_enabled(save_args):
             # producer and consumer of a record must be both eager or both inside the same graph capture (a graph holding only the
             # second pass would replay against whatever the record held at capture time)
-            reuse_key = reuse_key + (_lib.load().e3dge_stream_capture_id(_lib.stream_of(c2w)),)
+            reuse_key = reuse_key.extended(_lib.load().e3dge_stream_capture_id(_lib.stream_of(c2w)))
             rec = _BACKBONE.get(self)
             if tex_conditions is None:                       # first pass: leave a record behind
                 n_bytes = _lib.load().e3dge_siren_backbone_bytes(B, H, Wd, S)
@@ -898,8 +925,11 @@ class VolumeFeatureRenderer(nn.Module):
                     torch.empty(n_bytes, device=dev, dtype=torch.uint8)
                 bb_out = buf
                 _BACKBONE[self] = None                        # (not valid until the launch below is queued)
-            elif rec is not None and rec['key'] == reuse_key:
-                use = rec
+            elif rec is not None and reuse_key.matches(rec['key']) and \
+                    all(t._version == v for t, v in zip(rec['out'].values(), rec['out_versions'])):
+                use = rec                                     # (a first-pass output edited in place since is a miss, not a stale read)
+        elif tex_conditions is None:
+            _BACKBONE.pop(self, None)                         # a plain render that leaves no record must not leave an older one valid
         if use is not None:
             o1 = use['out']
             out = dict(o1, rgb=torch.empty((B, 3, H, Wd), **f32), features=torch.empty((B, 256, H, Wd), **f32))
@@ -931,7 +961,9 @@ class VolumeFeatureRenderer(nn.Module):
             rc = _lib.load().e3dge_siren_render_fwd(ctypes.byref(args), _lib.stream_of(c2w))
         _lib.check(rc, "e3dge_siren_render_fwd")
         if bb_out is not None:
-            _BACKBONE[self] = dict(key=reuse_key, buf=bb_out, out=out)
+            # the record keeps the geometry tensors a second pass returns (a few MB), not the first pass's rgb / features
+            geo = {k: v for k, v in out.items() if k not in ('rgb', 'features')}
+            _BACKBONE[self] = dict(key=reuse_key, buf=bb_out, out=geo, out_versions=[t._version for t in geo.values()])
         return self._render_dict({'rays_d': out['rays_d'], 'dists': out['dists'], 'hit_prob': out['weights'],
                                   'points': out['points'], 'sdf': out['sdf'], 'gen_thumb_imgs': out['rgb'],
                                   'features': out['features'], 'mask': out['mask'], 'xyz': out['xyz'],
@@ -1105,9 +1137,14 @@ class VolumeFeatureRenderer(nn.Module):
         poses = ref_img_info['cam_settings']['poses']                       # (B,3,4) c2w
         extr = ref_img_info['cam_settings']['extrinsics']                   # (B,3,4) w2c
         styles = ref_img_info['pred_latents'][0]
+        dev = wd_space_pts.device
+        for name, t in (("cam_settings.poses", poses), ("cam_settings.extrinsics", extr), ("global_render_out.near", ro['near']),
+                        ("global_render_out.far", ro['far']), ("pred_latents[0]", styles)):
+            if not torch.is_tensor(t) or t.device != dev:      # raw pointers go to the kernels: a CPU / other-device tensor must raise here
+                raise RuntimeError(f"query_hitting_probability_fixed_interval: {name} must be a tensor on {dev} "
+                                   f"(got {getattr(t, 'device', type(t))})")
         with torch.no_grad():
             lib = _lib.load()
-            dev = wd_space_pts.device
             N = H * W
             near = ro['near'].reshape(B, N).contiguous().float()
             far = ro['far'].reshape(B, N).contiguous().float()

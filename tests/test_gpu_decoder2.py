@@ -158,6 +158,32 @@ def test_input_magnitude_does_not_matter(gen256):
     assert max(out.values()) <= 2e-5
 
 
+def test_fresh_caller_noise_is_measured_every_call(gen256):
+    """Advisor finding (round 3): max|noise| was cached by (data_ptr, version); fresh caller tensors of one size are recycled by
+    the caching allocator with the same version, so a LARGE noise could inherit the maximum of an earlier small one and the
+    operand-scale bound (|noise_w| amax_noise + ...) came out too small -- inf / garbage without an error.  Ad-hoc noise is
+    now measured on every call; only the module's own `noises.noise_i` buffers are cached."""
+    g, sd = gen256
+    dec = g.decoder
+    _, wd = syn.synthetic_inputs(1, seed=2, device=DEV)
+    wd = wd[:, :dec.n_latent].contiguous()
+    feats = torch.randn(1, 256, 64, 64, device=DEV, generator=torch.Generator(DEV).manual_seed(5)).contiguous()
+    shapes = [tuple(getattr(dec.noises, f"noise_{i}").shape) for i in range(dec.num_layers)]
+    gen = torch.Generator(DEV).manual_seed(6)
+    worst, ptrs = 0.0, []
+    with torch.no_grad():
+        for mag in (1.0, 3e3, 1.0, 1e4):                    # small, LARGE on the recycled blocks, small, larger
+            noise = [(torch.randn(s, device=DEV, generator=gen) * mag).contiguous() for s in shapes]
+            ptrs.append(noise[-1].data_ptr())
+            img, _ = dec(feats, [wd], input_is_latent=True, noise=noise, randomize_noise=False)
+            ref = _planar(dec, feats, wd, noise)
+            assert torch.isfinite(img).all()
+            worst = max(worst, maxerr(img, ref) / float(ref.abs().max()))
+            del noise, img, ref
+    record("dec2_fresh_noise", rel=worst, blocks_recycled=len(set(ptrs)) < len(ptrs))
+    assert worst <= 2e-5
+
+
 def test_falls_back_when_a_graph_is_needed():
     """A latent that requires grad must not take the packed (graph-less) path: the gradient w.r.t. the decoder latent exists
     and matches the library path (fused kernels silently dropped dL/d(style))."""

@@ -237,3 +237,84 @@ def test_second_pass_reads_the_first_passs_backbone(res, S, B, monkeypatch):
     bad.precision, bad.backbone_out, bad.backbone_in = _lib.PREC_F16X3, None, one
     assert lib.e3dge_siren_render_fwd(ctypes.byref(bad), None) == -1                      # backbone_in without weights_in
     assert lib.e3dge_siren_backbone_bytes(1, 64, 64, 24) == 256 * 3 * 8 * 16384 and lib.e3dge_siren_backbone_bytes(1, 8, 8, 4) == 0
+
+
+def _local_renderer(res, S):
+    g, sd = full_state_dict(res=res, n_samples=S)
+    r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S, enable_local_model=True, L_pred_tex_modulations=True),
+                              out_im_res=res, mode='test')
+    r.load_state_dict({k: (syn.synthetic_tensor('renderer.' + k, v.shape) * 0.05 if 'netLocal' in k else
+                           sd['renderer.' + k.replace('network.netGlobal.', 'network.')]) for k, v in r.state_dict().items()})
+    return r.to(DEV).eval()
+
+
+def test_backbone_record_does_not_alias_a_recycled_latent(monkeypatch):
+    """ABA guard (round-3 review): a latent that is freed and a NEW latent of the same size that the caching allocator
+    places at the same address (both with version 0) must not be mistaken for each other.  The record holds the tensors
+    it was keyed on, so their storage cannot be recycled while the record is alive; once the record is gone (a plain
+    render that leaves none, or invalidate()) a second pass without its own first pass must be a full launch."""
+    from e3dge_amd import volume_renderer as vr
+    res, S = 16, 24
+    r = _local_renderer(res, S)
+    poses, focal, near, far, _ = generate_camera_params(res, DEV, locations=torch.zeros(1, 2, device=DEV))
+    feats = syn.synthetic_local_feats(1, res, S, device=DEV)
+    launches = []
+    orig = r.render_with_film
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        rec = vr._BACKBONE.get(r)
+        tex = (a[5] if len(a) > 5 else k.get('tex_conditions')) is not None
+        launches.append(bool(tex and rec is not None and out['sdf'] is rec['out']['sdf']))
+        return out
+    monkeypatch.setattr(r, "render_with_film", spy)
+    w_b_host = syn.synthetic_inputs(1, seed=12, device='cpu')[0]
+    with torch.no_grad():
+        w_a = syn.synthetic_inputs(1, seed=11, device=DEV)[0].clone()
+        r(poses, focal, near, far, styles=w_a)
+        ptr_a = w_a.data_ptr()
+        del w_a                                                        # the record still holds it: the block is NOT returned
+        w_b = torch.empty_like(w_b_host, device=DEV).copy_(w_b_host)
+        assert w_b.data_ptr() != ptr_a, "the record must keep the latent's storage alive"
+        got = r(poses, focal, near, far, styles=w_b, local_data_batch={'feats': feats})
+        assert launches[-1] is False
+        # the ABA shape proper: no record alive, latent freed, a new one lands on its address, tex pass without a pass #1
+        r.invalidate()
+        w_c = syn.synthetic_inputs(1, seed=11, device=DEV)[0].clone()
+        r(poses, focal, near, far, styles=w_c)
+        ptr_c = w_c.data_ptr()
+        r(poses, focal, near, far, styles=w_c, return_eikonal=True)    # a plain render that cannot leave a record drops the old one
+        assert vr._BACKBONE.get(r) is None
+        del w_c
+        w_d = torch.empty_like(w_b_host, device=DEV).copy_(w_b_host)
+        recycled = w_d.data_ptr() == ptr_c
+        launches.clear()
+        got2 = r(poses, focal, near, far, styles=w_d, local_data_batch={'feats': feats})
+        assert launches == [False]
+        monkeypatch.setenv("E3DGE_REUSE_BACKBONE", "0")
+        want = r(poses, focal, near, far, styles=w_d, local_data_batch={'feats': feats})
+        for k in ('features', 'gen_thumb_imgs', 'sdf', 'hit_prob', 'xyz', 'depth'):
+            assert torch.equal(got2[k], want[k]) and torch.equal(got[k], want[k]), k
+    record("backbone_aba_guard", allocator_recycled_the_block=bool(recycled))
+
+
+def test_backbone_record_notices_an_edited_first_pass_output():
+    """The hit path hands the first pass's geometry tensors (and `weights_in`) to the second pass: an in-place edit of one
+    of them in between must turn the hit into a full launch, not into a composite over edited weights.  The record does not
+    keep the first pass's rgb / features alive."""
+    from e3dge_amd import volume_renderer as vr
+    res, S = 8, 24
+    r = _local_renderer(res, S)
+    poses, focal, near, far, _ = generate_camera_params(res, DEV, locations=torch.zeros(1, 2, device=DEV))
+    feats = syn.synthetic_local_feats(1, res, S, device=DEV)
+    wr = syn.synthetic_inputs(1, seed=3, device=DEV)[0]
+    with torch.no_grad():
+        p1 = r(poses, focal, near, far, styles=wr)
+        assert set(vr._BACKBONE[r]['out']).isdisjoint({'rgb', 'features'})
+        ok = r(poses, focal, near, far, styles=wr, local_data_batch={'feats': feats})
+        assert ok['sdf'] is p1['sdf']                                  # hit: geometry tensors are the first pass's
+        keep = ok['features'].clone()
+        p1['hit_prob'].mul_(0.5)                                       # the caller scribbles over the weights
+        again = r(poses, focal, near, far, styles=wr, local_data_batch={'feats': feats})
+        assert again['sdf'] is not p1['sdf']                           # full launch
+        assert torch.equal(again['features'], keep)
