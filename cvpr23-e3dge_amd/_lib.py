@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E3DGE_LIB_PATH") or os.path.join(_HERE, "lib", "libe3dge_hip.so")   # override: kernel A/B variants
-ABI_VERSION = 10
+ABI_VERSION = 11
 PREC_F32, PREC_F16X3, PREC_F16X3_V1, PREC_F16X3_G2 = 0, 1, 2, 3
 AMAX_FLOATS = 64 * 32           # E3DGE_AMAX_FLOATS: one amax buffer (include/e3dge_hip.h)
 
@@ -84,7 +84,8 @@ class Dec2Plan(ctypes.Structure):
                 ("up", Dec2Conv * DEC2_MAX_UP), ("conv", Dec2Conv * DEC2_MAX_UP), ("rgb", Dec2Rgb * DEC2_MAX_UP),
                 ("act", _vp * (2 * DEC2_MAX_UP + 2)), ("tbuf", _vp * DEC2_MAX_UP), ("amax", _vp), ("meta", _vp),
                 ("fir_blur", _vp), ("fir_up", _vp), ("negative_slope", _f32), ("act_scale", _f32),
-                ("kernel_ms", ctypes.POINTER(ctypes.c_float)), ("n_kernel_ms", _i32), ("reserved1", _i32)]
+                ("kernel_ms", ctypes.POINTER(ctypes.c_float)), ("n_kernel_ms", _i32), ("reserved1", _i32),
+                ("fir_blur_1d", _f32 * 4), ("fir_blur_separable", _i32), ("reserved2", _i32)]
 
 
 class WsLinear(ctypes.Structure):

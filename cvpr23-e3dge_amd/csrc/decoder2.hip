@@ -60,6 +60,13 @@ __device__ __forceinline__ int div_small(int q, int d, float rcp) {
     return i;
 }
 __device__ __forceinline__ float pow2_bits(unsigned biased) { return __uint_as_float(biased << 23); }
+// value of the lane one below / one above in the wavefront (DPP wave_shr:1 / wave_shl:1; the end lanes read 0)
+__device__ __forceinline__ float dpp_wave_shr1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_wave_shl1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // fp32 (B, C, R, R) <-> packed
@@ -926,6 +933,283 @@ __global__ void __launch_bounds__(512) pkconv_upblur_kernel(const PkConvK a, con
     PK_T_DONE(NW);
 }
 
+// ---- the same layer, second generation (round 4): separable FIR, horizontal pass in registers, prefetch under the epilogue ----
+// What round 3's counters said about pkconv_upblur_kernel (profiles/r3_decoder_pmc.txt): 7 VALU per MFMA (the 4x4 FIR: ~1,100
+// VALU per thread and round of eight channels), 36 % of the LDS cycles bank conflicts, 20 % matrix-pipe busy, and the first
+// chunk of every tile waited for in the open (the T patch aliased BOTH staging buffers).  Here:
+//  * the FIR is applied as its two 1-D factors (Blur's kernel is make_kernel([1,3,3,1]): rank one; the host checks and passes
+//    the factor, anything else takes the first-generation kernel).  The HORIZONTAL pass runs on the accumulators themselves:
+//    a lane holds position column j of its row, its neighbours j-1 / j+1 are the adjacent lanes (v_mov_dpp wave_shr / wave_shl;
+//    the lanes at the ends of a 32-column tile are the halo columns whose results are never stored), 8 FMAs + 3 DPP moves per
+//    (row, channel) for the two output columns 2j, 2j+1 -- no LDS traffic, no 7-column windows;
+//  * what goes through LDS is H, laid out [channel half][T row][output column] in 16-byte elements (four channels): writers
+//    (lane = position column, two adjacent elements) and readers (lane = output column, one element) are both lane-linear --
+//    conflict-free by construction for ds_write_b128 / ds_read_b128 (MI355X_MICROARCH, LDS table);
+//  * the VERTICAL pass: a wave owns 4 output rows x 64 output columns x 8 channels, reads 7 H rows (2 x ds_read_b128 each),
+//    4 FMAs per output, then StyledConv's tail, the f16 split and fully coalesced stores (64 consecutive 16-byte entries per
+//    instruction -- the first generation's threads held four adjacent pixels each and left 48-byte gaps between lanes);
+//  * the H buffer lives behind staging buffer 0, so the NEXT tile's first chunk is fetched during the epilogue.
+// Per thread and round: ~180 VALU (horizontal) + ~360 (vertical + tail + split, 7 of 8 waves) instead of ~1,100.
+template <int NPT, int NW, int TC>
+__global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) pkconv_upblur2_kernel(const PkConvK a, const float g0, const float g1) {
+    // TC = position columns of one MFMA column tile: 32 (one position row per tile) or 16 (two rows x 16 columns: square-ish
+    // workgroup tiles -- a 65-wide level needs five 14-column tiles = 80 computed columns instead of three 30-column tiles = 96)
+    static_assert(TC == 32 || TC == 16, "MFMA column tile = 1 x 32 or 2 x 16 positions");
+    constexpr int SR = 32 / TC, PRW = NW * NPT * SR;                         // position rows per MFMA tile / per workgroup tile
+    constexpr int kUbTH = PRW - 2, kUbTW = TC - 2, kUbPR = PRW + 1, kUbPC = TC + 1, kUbNpix = kUbPR * kUbPC;
+    constexpr int TLR = 2 * PRW, ORows = 2 * kUbTH, OX = 2 * TC;                // T rows of a tile / output rows / output columns incl. halo
+    constexpr int NG = NW * (64 / OX);                                       // vertical pass: row groups (a wave holds 64 / OX of them)
+    constexpr int RPW = (ORows + NG - 1) / NG, NVW = ORows / RPW;            // output rows per group, groups taking part
+    static_assert(NVW * RPW == ORows && NVW <= NG, "vertical-pass split");
+    constexpr int NT = 64 * NW, XPLANE = kUbNpix * 16, XST = 4 * XPLANE, WST = kPkSlab, STAGE = XST + WST;
+    constexpr int NWP = 18, NPP = (kUbNpix + 63) / 64, NPIECE = NWP + 4 * NPP, NPW = (NPIECE + NW - 1) / NW, PPT = (NPW + 5) / 6;
+    constexpr int HB = 2 * TLR * OX * 16;                                    // H buffer: [half][T row][OX columns] x 16 B
+    constexpr int HOFF = STAGE, BOFF = (2 * STAGE > STAGE + HB ? 2 * STAGE : STAGE + HB);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pk[];
+    unsigned char* const hl = smem_pk + HOFF;                                // aliases staging buffer 1 (and beyond), never buffer 0
+    float* const bias_s = reinterpret_cast<float*>(smem_pk + BOFF);
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & (TC - 1), srow = (lane & 31) / TC;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int my_tiles = (a.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (my_tiles <= 0) return;
+    const int HP = a.H + 2, WP = a.W + 2, G = a.Ci >> 3, GO = a.Co >> 3, R = 2 * a.H;
+    const int64_t plane_b = (int64_t)HP * WP * 16, oplane = (int64_t)(R + 2) * (R + 2);
+    const float oscale = pow2_bits((unsigned)a.in_meta[0] - 21u);
+    const float nw = a.noise ? a.noise_w[0] : 0.0f;
+    const float nza = a.noise ? fabsf(nw) * amax_read(a.noise_amax, lane) : 0.0f;
+    const float bound = a.act_scale * (amax_read(a.in_amax, lane) * a.knorm * 1.002f + nza + a.bias_amax) * 1.001f;   // knorm = sqrt(4 ci)
+    const unsigned eb_out = (unsigned)__builtin_amdgcn_readfirstlane((int)scale_exponent(bound));     // (wave-uniform: keep it, kmul and kinv in SGPRs)
+    const float kmul = a.act_scale * pow2_bits(268u - eb_out), kinv = pow2_bits(eb_out - 14u);      // 2^-(141 - eb)
+    if (blockIdx.x == 0 && tid == 0) a.out_meta[0] = (int)eb_out;
+    for (int i = tid; i < a.Co; i += NT) bias_s[i] = a.bias[i];
+    // The 1-D factor is SYMMETRIC (g0, g1, g1, g0: the host checks; make_kernel([1,3,3,1]) is), so flipping it (upfirdn2d correlates
+    // with the flipped kernel) is the identity and two constants per pass do -- four register pairs of packed taps fewer, which is
+    // what kept the 2 x 16 form from fitting 256 registers.  The accumulators' power-of-two scale rides on the horizontal taps (exact).
+    const float fx0 = g0 * oscale, fx1 = g1 * oscale;
+    const float fy0 = g0, fy1 = g1;
+    float amax_l = 0.0f;
+    PK_T_INIT;
+    const int nsteps = my_tiles;
+
+    struct Tile { int b, cb, i0, j0; };
+    auto decode = [&](int k) {
+        int L = xcd_logical((int)blockIdx.x + k * (int)gridDim.x, a.n_tiles);
+        Tile t;
+        t.cb = L % a.co_blocks; L /= a.co_blocks;
+        const int txi = L % a.tiles_x; L /= a.tiles_x;
+        const int tyi = L % a.tiles_y;
+        t.b = L / a.tiles_y;
+        t.i0 = tyi * kUbTH; t.j0 = txi * kUbTW;                            // first position whose outputs this tile stores
+        return t;
+    };
+    // Patch pieces: piece p of a wave covers 64 consecutive entries of the (kUbPR x kUbPC) patch; which entry a lane fetches is a
+    // kernel constant, kept PACKED (row << 8 | column, one register per piece).  The source address is rebuilt per chunk from it
+    // (six VALU per piece, in the shadow of the MFMAs): left to LICM, row, column and offset of every piece stay live across the
+    // K loop and the epilogue -- three registers each, which is what spilled in the 2 x 16 form.
+    constexpr int JP0 = (NWP - (NW - 1) + NW - 1) / NW > 0 ? (NWP - (NW - 1) + NW - 1) / NW : 0;   // pieces j < JP0 are weight pieces for every wave
+    uint32_t pkv[NPW];
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+        if (j < JP0) { pkv[j] = 0xffffffffu; continue; }
+        const int i = wave + j * NW;
+        const int p = max(i - NWP, 0), pp = p % NPP;
+        const int e = pp * 64 + lane;
+        const int prow = e / kUbPC, pcol = e - prow * kUbPC;
+        pkv[j] = e < kUbNpix ? (uint32_t)(prow << 8 | pcol) : 0xffffffffu;
+        asm volatile("" : "+v"(pkv[j]));
+    }
+    auto issue = [&](const Tile& t, int c, int stage, int j_lo, int j_hi) {
+        const uint32_t xl = lds_u32(smem_pk + stage * STAGE), wl = xl + XST;
+        const unsigned char* wsrc = a.wimg + (int64_t)t.b * a.wimg_bytes + ((int64_t)t.cb * a.n_chunks + c) * kPkSlab;
+        const unsigned char* xsrc = a.x + ((int64_t)(t.b * G + 2 * c) * 2) * plane_b;
+        int im = t.i0 - 1, jm = t.j0 - 1;
+        asm volatile("" : "+s"(im), "+s"(jm));          // (not loop-invariant as far as the compiler can tell: see pkv)
+#pragma unroll
+        for (int j = j_lo; j < j_hi; ++j) {
+            const int i = wave + j * NW;
+            if (i >= NPIECE) break;
+            if (i < NWP) {
+                dma_piece(wsrc + i * 1024, (uint32_t)lane * 16u, wl + i * 1024);
+            } else {
+                const int p = i - NWP, pl = p / NPP, pp = p - pl * NPP;
+                const uint32_t pk = pkv[j];
+                if (pk != 0xffffffffu) {
+                    // padded input rows i0 - 1 + prow, clamped into the buffer: everything outside the image lands on the
+                    // zero border, so positions outside the image come out as T = 0 (= the blur's padding) by themselves
+                    const int gy = min(max(im + (int)(pk >> 8), 0), HP - 1), gx_ = min(max(jm + (int)(pk & 255u), 0), WP - 1);
+                    dma_piece(xsrc + pl * plane_b, (uint32_t)(gy * WP + gx_) * 16u, xl + pl * XPLANE + pp * 1024);
+                }
+            }
+        }
+    };
+
+    Tile cur = decode(0);
+    issue(cur, 0, 0, 0, NPW);
+    for (int k = 0; k < my_tiles; ++k) {
+        const bool more = k + 1 < my_tiles;
+        Tile nxt = cur;
+        if (more) nxt = decode(k + 1);
+        // the vertical-pass role of this thread: row group vg (output rows RPW vg .. + RPW - 1 of the tile), output column 2 j0 - 2 + vx
+        int l3 = lane;
+        asm volatile("" : "+v"(l3));                 // (re-derived per tile: as kernel-lifetime constants these cost two more registers than the 2 x 16 form has)
+        const int vx = l3 & (OX - 1), vg = wave * (64 / OX) + l3 / OX;
+        const int ox = 2 * cur.j0 - 2 + vx, oy0 = 2 * cur.i0 + RPW * vg;
+        const bool lane_ok = vx >= 2 && vx < OX - 2 && ox < R && vg < NVW;
+        float nzv[RPW];
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) nzv[rr] = 0.0f;
+        if (a.noise && vg < NVW) {
+            const float* __restrict__ nb = a.noise + (int64_t)(a.noise_batch > 1 ? cur.b : 0) * R * R + min(max(ox, 0), R - 1);
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) nzv[rr] = nb[(int64_t)min(oy0 + rr, R - 1) * R];
+        }
+
+        f32x16 acc[4][NPT];
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt) acc[ph][pt] = zero16();
+        for (int c = 0; c < a.n_chunks; ++c) {
+            const int cs = c & 1;
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            PK_T(0);
+            const bool has_next = c + 1 < a.n_chunks;
+            const unsigned char* xb = smem_pk + cs * STAGE + (size_t)(half * 2) * XPLANE;
+            const unsigned char* wb = smem_pk + cs * STAGE + XST + lane * 16;
+            u32x4 bh[NPT][4], bl[NPT][4];       // shift s = 2 a + b: input rows i - 1 + a, columns j - 1 + b
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+                for (int sft = 0; sft < 4; ++sft) {
+                    const int pix = ((wave * NPT + pt) * SR + srow + (sft >> 1)) * kUbPC + col + (sft & 1);
+                    bh[pt][sft] = *reinterpret_cast<const u32x4*>(xb + pix * 16);
+                    bl[pt][sft] = *reinterpret_cast<const u32x4*>(xb + XPLANE + pix * 16);
+                }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const int sft = (ky == 2 ? 0 : 2) + (kx == 2 ? 0 : 1), ph = (ky & 1) * 2 + (kx & 1);
+                const u32x4 ah = *reinterpret_cast<const u32x4*>(wb + (tap * 2 + 0) * 1024);
+                const u32x4 al = *reinterpret_cast<const u32x4*>(wb + (tap * 2 + 1) * 1024);
+                // product-major: consecutive MFMAs go to DIFFERENT accumulators.  Tile-major (three dependent MFMAs in a row) is
+                // free while two waves share the SIMD, but a wave that has its SIMD to itself (<= 256 tiles: one workgroup per CU)
+                // then runs at the dependent-accumulator latency -- measured 61 cycles per MFMA at the 64^2 level instead of 32.
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[ph][pt] = mfma16(ah, bh[pt][sft], acc[ph][pt]);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[ph][pt] = mfma16(al, bh[pt][sft], acc[ph][pt]);
+#pragma unroll
+                for (int pt = 0; pt < NPT; ++pt) acc[ph][pt] = mfma16(ah, bl[pt][sft], acc[ph][pt]);
+                if (has_next && tap * PPT < NPW) issue(cur, c + 1, cs ^ 1, tap * PPT, min((tap + 1) * PPT, NPW));
+                if (tap % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+            }
+            PK_T(1);
+        }
+        // ---- epilogue: four rounds of eight output channels ----
+        // (pin the noise values here: the compiler then waits for ITS loads now, while nothing else is in flight.  Left to itself it
+        // puts s_waitcnt vmcnt(n) in front of their first use -- behind the prefetch pieces and the stores, which the in-order
+        // counter would then drain in the middle of the vertical pass)
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) asm volatile("" : "+v"(nzv[rr]));
+        const float slope = a.slope;
+        const f32x2 kx0 = f32x2{fx0, fx0}, kx1 = f32x2{fx1, fx1};
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            // horizontal pass on the accumulators (registers only): output columns 2 j (h0) and 2 j + 1 (h1) of every T row
+            f32x4 h0[NPT][2], h1[NPT][2];
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {            // two channels per instruction (v_pk_fma_f32; the DPP moves stay per register)
+                        const f32x2 p0 = f32x2{acc[2 * py][pt][4 * g4 + r], acc[2 * py][pt][4 * g4 + r + 1]};
+                        const f32x2 p1 = f32x2{acc[2 * py + 1][pt][4 * g4 + r], acc[2 * py + 1][pt][4 * g4 + r + 1]};
+                        const f32x2 p1m = f32x2{dpp_wave_shr1(p1[0]), dpp_wave_shr1(p1[1])};
+                        const f32x2 p0p = f32x2{dpp_wave_shl1(p0[0]), dpp_wave_shl1(p0[1])};
+                        const f32x2 p1p = f32x2{dpp_wave_shl1(p1[0]), dpp_wave_shl1(p1[1])};
+                        f32x2 u = p1m * kx0;                    // T columns 2j-1, 2j, 2j+1, 2j+2
+                        u = __builtin_elementwise_fma(p0, kx1, u); u = __builtin_elementwise_fma(p1, kx1, u); u = __builtin_elementwise_fma(p0p, kx0, u);
+                        f32x2 v = p0 * kx0;                     // T columns 2j, 2j+1, 2j+2, 2j+3
+                        v = __builtin_elementwise_fma(p1, kx1, v); v = __builtin_elementwise_fma(p0p, kx1, v); v = __builtin_elementwise_fma(p1p, kx0, v);
+                        h0[pt][py][r] = u[0]; h0[pt][py][r + 1] = u[1];
+                        h1[pt][py][r] = v[0]; h1[pt][py][r + 1] = v[1];
+                    }
+            __syncthreads();            // round 0: every wave has left the K loop (staging buffer 1 is free); later: the previous round's readers are done
+            if (g4 == 0 && more) issue(nxt, 0, 0, 0, NPW);          // the next tile's first chunk lands in buffer 0 during this epilogue
+#pragma unroll
+            for (int pt = 0; pt < NPT; ++pt)
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+                    const int trow = 2 * ((wave * NPT + pt) * SR + srow) + py;
+                    f32x4* dst = reinterpret_cast<f32x4*>(hl + ((size_t)(half * TLR + trow) * OX + 2 * col) * 16);
+                    dst[0] = h0[pt][py];
+                    dst[1] = h1[pt][py];
+                }
+            __syncthreads();
+            PK_T(2);
+            if (vg < NVW) {
+                const int gout = cur.cb * 4 + g4;
+                // vertical pass: output row rr of the group needs T rows RPW vg + rr + 1 .. + 4 (tile row t <-> y = 2 i0 - 2 + t)
+                auto load_row = [&](f32x2 (&w)[4], int t) {        // H row RPW vg + 1 + t of this thread's column: [channel pair]
+                    const int trow = RPW * vg + 1 + t;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const f32x4 q = *reinterpret_cast<const f32x4*>(hl + ((size_t)(hh * TLR + trow) * OX + vx) * 16);
+                        w[2 * hh] = f32x2{q[0], q[1]};
+                        w[2 * hh + 1] = f32x2{q[2], q[3]};
+                    }
+                };
+                f32x2 win[4][4];                                   // sliding window of four H rows (a full RPW + 3 row block costs 24 more registers)
+                load_row(win[0], 0); load_row(win[1], 1); load_row(win[2], 2);
+                f32x2 bv[4];
+#pragma unroll
+                for (int cp = 0; cp < 4; ++cp) bv[cp] = *reinterpret_cast<const f32x2*>(bias_s + gout * 8 + 2 * cp);
+                const f32x2 sl = f32x2{slope, slope}, km = f32x2{kmul, kmul};
+                const f32x2 k0 = f32x2{fy0, fy0}, k1 = f32x2{fy1, fy1};
+#pragma unroll
+                for (int rr = 0; rr < RPW; ++rr) {
+                    const float nzr = a.noise ? __fmul_rn(nw, nzv[rr]) : 0.0f;
+                    const f32x2 nz2 = f32x2{nzr, nzr};
+                    u32x4 hi, lo;
+                    float m = 0.0f;
+                    load_row(win[(rr + 3) & 3], rr + 3);
+#pragma unroll
+                    for (int cp = 0; cp < 4; ++cp) {
+                        f32x2 o = win[rr & 3][cp] * k0;
+                        o = __builtin_elementwise_fma(win[(rr + 1) & 3][cp], k1, o);
+                        o = __builtin_elementwise_fma(win[(rr + 2) & 3][cp], k1, o);
+                        o = __builtin_elementwise_fma(win[(rr + 3) & 3][cp], k0, o);
+                        f32x2 tv = (o + nz2) + bv[cp];                       // (conv + noise) + bias, as the unfused kernels round it
+                        const f32x2 ls = tv * sl;
+                        tv = f32x2{fmaxf(tv[0], ls[0]), fmaxf(tv[1], ls[1])} * km;     // lrelu (0 <= slope <= 1) * act_scale * 2^k
+                        m = fmaxf(m, fmaxf(fabsf(tv[0]), fabsf(tv[1])));
+                        SPLIT2_TO(tv[0], tv[1], hi[cp], lo[cp]);
+                    }
+                    const int oy = oy0 + rr;
+                    if (lane_ok && oy < R) {
+                        amax_l = fmaxf(amax_l, m);
+                        u32x4* __restrict__ dst = reinterpret_cast<u32x4*>(a.y) + ((int64_t)(cur.b * GO + gout) * 2) * oplane + (int64_t)(oy + 1) * (R + 2) + ox + 1;
+                        dst[0] = hi;
+                        dst[oplane] = lo;
+                    }
+                }
+            }
+            PK_T(3);
+        }
+        cur = nxt;
+    }
+    if (a.out_amax) {
+        int l2 = lane;
+        asm volatile("" : "+v"(l2));          // (fresh permute addresses: sharing them with the prologue's amax_read keeps five registers alive across the kernel)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            amax_l = fmaxf(amax_l, __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((l2 ^ off) << 2, __builtin_bit_cast(int, amax_l))));
+        if (l2 == 0) atomic_max_nonneg(a.out_amax + (((int)blockIdx.x * NW + wave) & (kAmaxSlots - 1)) * kAmaxStride, amax_l * kinv);
+    }
+    PK_T_DONE(NW);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Blur of an up-sampling layer + StyledConv's tail, T (fp32, zero-bordered) -> packed:  u = lrelu(upfirdn2d(T, k, pad (1, 1))
 // + noise_w noise + bias) * act_scale  (stylesdf_model.py:346, :459-466, :500-507).  Workgroup = 8 channels (one packed entry
@@ -1374,8 +1658,62 @@ static int launch_upblur_t(PkConvK k, const float* fir, hipStream_t st) {
     return check_launch("dec2 convT+blur");
 }
 static int shape_override(const char* name);
-static int launch_upblur(PkConvK k, const float* fir, hipStream_t st) {
+template <int NPT, int NW, int TC>
+static int launch_upblur2_t(PkConvK k, const float* g, hipStream_t st) {
+    constexpr int PRW = NW * NPT * (32 / TC), TH = PRW - 2, TW = TC - 2;
+    constexpr int STAGE = 4 * (PRW + 1) * (TC + 1) * 16 + kPkSlab, HB = 2 * 2 * PRW * 2 * TC * 16;
+    constexpr int lds = (2 * STAGE > STAGE + HB ? 2 * STAGE : STAGE + HB) + 4096;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    k.co_blocks = k.Co / 32;
+    k.tiles_y = (k.H + TH - 1) / TH;
+    k.tiles_x = (k.W + TW - 1) / TW;
+    const int64_t n_tiles = (int64_t)k.B * k.co_blocks * k.tiles_y * k.tiles_x;
+    E3DGE_REQUIRE(n_tiles < ((int64_t)1 << 30), "dec2 convT+blur: too many tiles");
+    k.n_tiles = (int)n_tiles;
+    auto fn = &pkconv_upblur2_kernel<NPT, NW, TC>;
+    const int wgs = (NW == 4 && (160 * 1024) / lds >= 2) ? 512 : 256;      // (eight-wave forms: 143+ registers, one workgroup per CU)
+    const int grid = k.n_tiles < wgs ? k.n_tiles : wgs;
+    // Two 77-KB workgroups fit a CU and the dispatcher PACKS them (measured: 264 tiles of the 64^2 level ran two per CU on 132 CUs,
+    // each at half the matrix-pipe rate, while 124 CUs idled).  With at most one tile per CU to hand out, ask for more than half
+    // of the LDS so that every workgroup gets a CU of its own.
+    const int lds_req = ((160 * 1024) / lds >= 2 && grid <= 256 && shape_override("E3DGE_DEC2_UPBLUR_SPREAD") != 0) ? 81 * 1024 : lds;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_req);
+    if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(dec2 convT+blur v2): %s", hipGetErrorString(e));
+    fn<<<dim3((unsigned)grid), dim3(64 * NW), lds_req, st>>>(k, g[0], g[1]);
+    return check_launch("dec2 convT+blur v2");
+}
+// how many rounds of `slots` concurrently resident workgroups a tiling needs (ceil), per (stored rows, stored columns) of a tile
+static int upblur_rounds(const PkConvK& k, int th, int tw, int slots) {
+    const int64_t n = (int64_t)k.B * (k.Co / 32) * ((k.H + th - 1) / th) * ((k.W + tw - 1) / tw);
+    return (int)((n + slots - 1) / slots);
+}
+static int shape_override(const char* name);
+// fir1d: the 1-D factor of the blur kernel when the plan says it is rank one (second-generation kernel), else NULL
+static int launch_upblur(PkConvK k, const float* fir, const float* fir1d, hipStream_t st) {
     E3DGE_REQUIRE(k.Co % 32 == 0 && k.Co <= 1024 && k.y && k.out_meta, "dec2 convT+blur: bad arguments");
+    if (fir1d && shape_override("E3DGE_DEC2_UPBLUR_GEN") != 1) {
+        // tile shapes: 0 = eight waves x 2 position rows (14 x 30 stored positions, one workgroup per CU), 1 = eight waves x 1 row
+        // (6 x 30), 2 = FOUR waves x 2 rows (6 x 30, 77 KB of LDS: two workgroups per CU, whose barriers and operand fetches
+        // interleave), 3 = four waves x 2 MFMA tiles of 2 x 16 positions (14 x 14 stored, same LDS).  Automatic: 2 or 3, whichever
+        // needs fewer rounds of 512 resident workgroups (64^2: 200 instead of 264 tiles -- one per CU; 512^2: 1,369 instead of
+        // 1,548 -- three rounds instead of four), 3 on a tie (9 % fewer halo positions).
+        // 4 = EIGHT waves x 1 MFMA tile of 2 x 16 (the same 14 x 14 tile, one workgroup per CU): when there are no more tiles than
+        // CUs a four-wave workgroup has its SIMDs to itself and its LDS-DMA issue (10 pieces per wave and chunk, ~150 cycles each)
+        // is no longer covered by a partner's MFMAs -- 61 cycles per MFMA measured at the 64^2 level; with two waves of the SAME
+        // workgroup per SIMD it is (59.6 vs 70.0 us there, same box).
+        int v = shape_override("E3DGE_DEC2_UPBLUR_SHAPE");
+        if (v < 0) {
+            if (upblur_rounds(k, 14, 14, 256) <= 1) v = 4;
+            else v = upblur_rounds(k, 14, 14, 512) <= upblur_rounds(k, 6, 30, 512) ? 3 : 2;
+        }
+        switch (v) {
+            case 0: return launch_upblur2_t<2, 8, 32>(k, fir1d, st);
+            case 1: return launch_upblur2_t<1, 8, 32>(k, fir1d, st);
+            case 2: return launch_upblur2_t<2, 4, 32>(k, fir1d, st);
+            case 4: return launch_upblur2_t<1, 8, 16>(k, fir1d, st);
+            default: return launch_upblur2_t<2, 4, 16>(k, fir1d, st);
+        }
+    }
     // tiles of 14 x 30 positions (two position rows per wave).  The 6 x 30 form (E3DGE_DEC2_UPBLUR_NPT=1) gives the 64^2 level 264
     // tiles instead of 120 for the 256 CUs but re-streams every weight slab twice as often: 115 vs 96 us there, slower everywhere.
     return shape_override("E3DGE_DEC2_UPBLUR_NPT") == 1 ? launch_upblur_t<1>(k, fir, st) : launch_upblur_t<2>(k, fir, st);
@@ -1615,7 +1953,7 @@ extern "C" int e3dge_dec2_forward(const E3dgeDec2Plan* P, e3dge_stream_t stream)
             k.x = reinterpret_cast<const unsigned char*>(P->act[prev_act]); k.in_meta = P->meta + prev_act;
             k.in_amax = P->amax + (int64_t)E3DGE_AMAX_FLOATS * (prev_act == 1 ? 1 : 4 + 3 * (u - 1));
             k.y = reinterpret_cast<unsigned char*>(P->act[2 + 2 * u]); k.out_meta = P->meta + 2 + 2 * u; k.out_amax = am_u;
-            DEC2_STEP(launch_upblur(k, P->fir_blur, st));
+            DEC2_STEP(launch_upblur(k, P->fir_blur, P->fir_blur_separable ? P->fir_blur_1d : nullptr, st));
             mark(true);                   // (keeps the kernel_ms slots aligned: this level's blur entry reads 0)
             res *= 2;
         } else {

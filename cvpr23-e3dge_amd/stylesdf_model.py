@@ -673,6 +673,18 @@ class Decoder(nn.Module):
         fir_up = (self.to_rgbs[0].upsample.kernel if n_up else fir_blur).detach().contiguous()
         keep += [amax, meta, fir_blur, fir_up]
         plan.amax, plan.meta, plan.fir_blur, plan.fir_up = _lib.ptr(amax), _lib.ptr(meta), _lib.ptr(fir_blur), _lib.ptr(fir_up)
+        # the blur kernel is make_kernel(1-D list) * 4 = outer(g, g): hand the kernel its 1-D factor when that holds exactly
+        # enough (fp32 round-off of the outer product), otherwise the 4x4 form is applied as it is
+        k2 = fir_blur.detach().double().cpu()
+        tot = float(k2.sum())
+        if tuple(k2.shape) == (4, 4) and tot > 0:
+            g1 = k2.sum(1) / tot ** 0.5
+            if float((torch.outer(g1, g1) - k2).abs().max()) <= 1e-6 * float(k2.abs().max()) and \
+                    float((k2 - k2.t()).abs().max()) <= 1e-6 * float(k2.abs().max()) and \
+                    float((g1 - g1.flip(0)).abs().max()) <= 1e-7 * float(g1.abs().max()):      # symmetric factor (g0, g1, g1, g0)
+                for i in range(4):
+                    plan.fir_blur_1d[i] = float(g1[i])
+                plan.fir_blur_separable = 1
         st = dict(key=pkey, plan=plan, keep=keep, acts=acts, outs=outs, meta=meta, amax=amax, n_launch=lib.e3dge_dec2_num_launches(n_up))
         states.pop(slot, None)
         while len(states) >= 4:

@@ -232,6 +232,11 @@ typedef struct E3dgeDec2Plan {
     float negative_slope, act_scale;
     float* kernel_ms;                              /* host array, n_kernel_ms floats, or NULL: HIP-event time of every launch (makes the call synchronous) */
     int32_t n_kernel_ms, reserved1;
+    /* ABI 11: when the blur kernel is rank one with a SYMMETRIC factor (make_kernel([1,3,3,1]) is), fir_blur = outer(fir_blur_1d,
+     * fir_blur_1d), fir_blur_1d = (g0, g1, g1, g0) and fir_blur_separable != 0: the fused up-sampling kernel then applies the two 1-D passes (horizontal in registers,
+     * vertical through LDS).  With fir_blur_separable == 0 the 4x4 taps are applied as they are (first-generation kernel). */
+    float fir_blur_1d[4];
+    int32_t fir_blur_separable, reserved2;
 } E3dgeDec2Plan;
 /* 32-bit words of a packed tensor / floats of a T buffer / floats of a wpre image */
 int64_t e3dge_dec2_act_words(int batch, int channels, int res);

@@ -128,9 +128,9 @@ def test_dec2_structs_layout_matches_c():
 #include "e3dge_hip.h"
 int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(E3dgeDec2Conv), offsetof(E3dgeDec2Conv, bias_amax), offsetof(E3dgeDec2Conv, noise_batch), sizeof(E3dgeDec2Rgb));
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %d\n", sizeof(E3dgeDec2Plan), offsetof(E3dgeDec2Plan, conv1), offsetof(E3dgeDec2Plan, up),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %d %zu %zu\n", sizeof(E3dgeDec2Plan), offsetof(E3dgeDec2Plan, conv1), offsetof(E3dgeDec2Plan, up),
          offsetof(E3dgeDec2Plan, rgb), offsetof(E3dgeDec2Plan, act), offsetof(E3dgeDec2Plan, amax), offsetof(E3dgeDec2Plan, negative_slope),
-         offsetof(E3dgeDec2Plan, kernel_ms), E3DGE_DEC2_MAX_UP);
+         offsetof(E3dgeDec2Plan, kernel_ms), E3DGE_DEC2_MAX_UP, offsetof(E3dgeDec2Plan, fir_blur_1d), offsetof(E3dgeDec2Plan, fir_blur_separable));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
@@ -140,7 +140,8 @@ int main(void) {
         got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
     C, R, P = _lib.Dec2Conv, _lib.Dec2Rgb, _lib.Dec2Plan
     assert got == [ctypes.sizeof(C), C.bias_amax.offset, C.noise_batch.offset, ctypes.sizeof(R), ctypes.sizeof(P), P.conv1.offset, P.up.offset,
-                   P.rgb.offset, P.act.offset, P.amax.offset, P.negative_slope.offset, P.kernel_ms.offset, _lib.DEC2_MAX_UP]
+                   P.rgb.offset, P.act.offset, P.amax.offset, P.negative_slope.offset, P.kernel_ms.offset, _lib.DEC2_MAX_UP,
+                   P.fir_blur_1d.offset, P.fir_blur_separable.offset]
     lib = _lib.load()
     assert lib.e3dge_dec2_forward(None, None) == -1
     assert lib.e3dge_dec2_forward(ctypes.byref(P(batch=1, n_up=7, in_res=64, in_ch=256)), None) == -1       # more levels than the plan holds

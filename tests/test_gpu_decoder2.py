@@ -63,10 +63,25 @@ def gen256():
     return g.to(DEV).eval(), sd
 
 
-@pytest.mark.parametrize("upblur", ["1", "0"])
-def test_every_stage_against_the_planar_kernels(gen256, upblur, monkeypatch):
-    """upblur = 1 (default): transposed conv + blur in one kernel (T stays in LDS); 0: two kernels with T in HBM."""
+UPBLUR_FORMS = {                    # name -> (E3DGE_DEC2_UPBLUR, E3DGE_DEC2_UPBLUR_GEN, E3DGE_DEC2_UPBLUR_SHAPE)
+    "auto": ("1", None, None),      # second generation, tile shape picked per level
+    "gen2_8w_14x30": ("1", None, "0"), "gen2_8w_6x30": ("1", None, "1"), "gen2_4w_6x30": ("1", None, "2"), "gen2_4w_14x14": ("1", None, "3"),
+    "gen2_8w_14x14": ("1", None, "4"),
+    "gen1": ("1", "1", None),       # first generation (4x4 FIR from the LDS patch); also what a non-separable kernel takes
+    "two_kernels": ("0", None, None),
+}
+
+
+@pytest.mark.parametrize("form", list(UPBLUR_FORMS))
+def test_every_stage_against_the_planar_kernels(gen256, form, monkeypatch):
+    """Up-sampling layer forms: transposed conv + blur in one kernel (T / H stay in LDS) in both generations and every tile
+    shape of the second, and the two-kernel form with T in HBM."""
+    upblur, gen, shape = UPBLUR_FORMS[form]
     monkeypatch.setenv("E3DGE_DEC2_UPBLUR", upblur)
+    if gen is not None:
+        monkeypatch.setenv("E3DGE_DEC2_UPBLUR_GEN", gen)
+    if shape is not None:
+        monkeypatch.setenv("E3DGE_DEC2_UPBLUR_SHAPE", shape)
     g, sd = gen256
     dec = g.decoder
     _, wd = syn.synthetic_inputs(1, seed=1, device=DEV)
@@ -102,7 +117,7 @@ def test_every_stage_against_the_planar_kernels(gen256, upblur, monkeypatch):
         os.environ.pop("E3DGE_DEC2_FUSE_RGB")
         img_fused = dec._forward_packed(feats, wd, noise)
         errs["img_fused_rgb"] = maxerr(img_fused, ref_img)
-    record(f"dec2_stages_256_upblur{upblur}", **errs)
+    record(f"dec2_stages_256_{form}", **errs)
     for k, v in errs.items():
         assert v <= (IMG_ATOL if k.startswith("img") else 2e-5), (k, v)
     # the default Decoder.forward takes the packed path and returns the same tensor values

@@ -112,7 +112,7 @@ def main():
             am = st['amax'].cpu()
             rows = {"conv1": 1}
             for u in range(len(dec.to_rgbs)):
-                rows[f"L{u}.upblur(per TILE: wait, taps, T->LDS + barriers, blur + store)"] = 3 + 3 * u
+                rows[f"L{u}.upblur(per TILE: wait, taps, H pass + LDS + barriers [gen 1: T->LDS], V pass + store [gen 1: blur + store])"] = 3 + 3 * u
                 rows[f"L{u}.convT"] = 2 + 3 * u
                 rows[f"L{u}.conv"] = 4 + 3 * u
             for name, r in rows.items():
