@@ -421,10 +421,22 @@ def main():
         rows = [row("render pass #1 (siren16_kernel" + (", + layer-7 record for pass #2)" if reuse else ")"),
                     ev_ms(lambda: rr.render_with_film(film, f1, p1, n1, fa1, reuse_key=key)),
                     flops=FLOP_PER_RAY * RES * RES, nbytes=(BYTES_PER_RAY + (1024 * N_SAMPLES if reuse else 0)) * RES * RES),
-                row("texture head (resblock_kernel, 301 -> 512)", ev_ms(lambda: head.tex_modulations(feats)),
+                row("texture head alone (resblock_kernel, 301 -> 512, (alpha, beta) to HBM)", ev_ms(lambda: head.tex_modulations(feats)),
                     flops=2 * 398825 * n_pts, nbytes=n_pts * (301 + 512) * 4)]
         if reuse:       # (the record written by the timed pass-#1 launches above is the one these read)
-            rows.append(row("render pass #2: texture FiLM + view layer + compositing on pass #1's layer-7 record",
+            from e3dge_amd import volume_renderer as _vr
+            fused = _vr._fuse_texfilm() and rr._lazy_tex_ok(feats, head)
+            if fused:   # what the forward runs: head + FiLM in one launch (FiLM-ed record out), then the short pass #2 on that record
+                rec = _vr._BACKBONE.get(rr)
+                tbuf = torch.zeros_like(rec['buf'])
+                rows.append(row("texture head + FiLM (resblock_kernel<FILM>: 301 -> 512, h' = (alpha+1) h8 + beta -> record; (alpha, beta) stay on chip)",
+                                ev_ms(lambda: head.tex_film(feats, rec['buf'], tbuf, 1, RES, RES, N_SAMPLES)),
+                                flops=2 * 398825 * n_pts, nbytes=n_pts * (301 * 4 + 1024 + 1024)))
+                rows.append(row("render pass #2: view layer + compositing on the FiLM-ed layer-7 record",
+                                ev_ms(lambda: rr.render_with_film(film, f1, p1, n1, fa1, tex_conditions=_vr._LazyTex(head, feats), reuse_key=key)) - rows[-1]["ms"],
+                                flops=view_flop * RES * RES, nbytes=(BYTES_PER_RAY + (1024 + 4) * N_SAMPLES) * RES * RES))
+                rows[-1]["note"] = "timed as (head + FiLM + pass #2) minus the head + FiLM row"
+            rows.append(row("render pass #2 on record + (alpha, beta) from HBM (E3DGE_FUSE_TEXFILM=0" + ("; not part of the forward)" if fused else ")"),
                             ev_ms(lambda: rr.render_with_film(film, f1, p1, n1, fa1, tex_conditions=tex, reuse_key=key)),
                             flops=view_flop * RES * RES, nbytes=(BYTES_PER_RAY + (1024 + 4 + 2 * 256 * 4) * N_SAMPLES) * RES * RES))
         rows.append(row("render pass #2 as a full launch (E3DGE_REUSE_BACKBONE=0" + ("; not part of the forward)" if reuse else ")"),

@@ -15,6 +15,7 @@
 // the (P, 301) hidden activations nor r ever touch memory; the output goes straight to (alpha, beta).  DESIGN.md 4.7 has the
 // measurements behind every choice here (tools/rb_trace.py, profiles/r2_pmc_issue_texhead.txt).
 #include "siren_common.h"
+#include <type_traits>
 
 namespace e3dge {
 
@@ -47,6 +48,13 @@ constexpr int kRbLdsB = kRbLdsW + kRbNBuf * kRbChunkFloats;           // b_0 [32
 constexpr int kRbLdsFloats = kRbLdsB + kRbKin + kRbOut;
 constexpr int kRbLdsBytes = kRbLdsFloats * 4;
 static_assert(kRbLdsBytes <= 160 * 1024, "LDS budget");
+// FILM form (the head writes h' = (alpha + 1) h8 + beta straight into a layer-7 record, see resblock_kernel): per wave a 4-KiB stash of
+// the alpha tile ([q][lane] x 16 B) and two 4-KiB buffers of the h8 entries of the current / next feature block ([hl][s][lane] x 16 B)
+constexpr int kRbLdsStash = ((kRbLdsFloats + 3) / 4) * 4;
+constexpr int kRbLdsH8 = kRbLdsStash + 4 * 1024;                      // floats: 4 waves x 4 KiB
+constexpr int kRbLdsFilmFloats = kRbLdsH8 + 4 * 2 * 1024;             // 4 waves x 2 buffers x 4 KiB
+constexpr int kRbLdsFilmBytes = kRbLdsFilmFloats * 4;
+static_assert(kRbLdsFilmBytes <= 160 * 1024, "LDS budget (FILM)");
 static_assert(kRbNBuf >= 3 && kRbPieces == 5, "chunk pipeline shape");
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -74,7 +82,10 @@ resblock_pack_kernel(float* __restrict__ packed, const float* __restrict__ w0, c
             const int g = (int)(r - (int64_t)chunk * kRbCSteps);
             int t, kc, which;                         // which: 0 = W_0, 1 = W_s, 2 = W_1
             if (chunk < kRbChunksG1) { t = chunk >> 1; kc = chunk & 1; which = 0; }
-            else { const int c2 = chunk - kRbChunksG1; t = c2 >> 2; kc = c2 & 1; which = 1 + ((c2 >> 1) & 1); }
+            else {      // output tiles are streamed alpha_0, beta_0, alpha_1, beta_1, ...: stream position t' -> row tile 8 (t' & 1) + (t' >> 1)
+                const int c2 = chunk - kRbChunksG1, tp = c2 >> 2;
+                t = 8 * (tp & 1) + (tp >> 1); kc = c2 & 1; which = 1 + ((c2 >> 1) & 1);
+            }
             const int n = 32 * t + (lane & 31);
             unsigned word = 0;
             for (int e2 = 0; e2 < 2; ++e2) {
@@ -225,6 +236,9 @@ struct ResblockK {
     float* beta;            // (n_pts, 256)
     long long n_pts;
     int cin, subtiles_per_wg;
+    // FILM form: the render launch's layer-7 record (siren16.h, CACHE = 1) in, the FiLM-ed record out, and the render's tiling
+    const unsigned char* bb_in; unsigned char* bb_out;
+    int S, R, HW, tiles_per_img, bb_subs;
 };
 
 // relu on a packed (hi, lo) pair of two f16 values each: both halves are cleared where hi is negative.  Three VALU ops a
@@ -264,6 +278,16 @@ __device__ unsigned long long g_rb_trace[640];
 
 struct __attribute__((packed, aligned(4))) F4u { float v[4]; };        // 16-byte load at 4-byte alignment
 
+// FILM = false: (alpha, beta) -> global memory.  FILM = true (inference, second pass of an evaluated image): the head also applies
+// them -- h' = (alpha + 1) h8 + beta on the layer-7 output h8 that render pass #1 left in its record (same operation order and
+// rounding as siren16_kernel's FiLM step, volume_renderer.py:217-220) -- and writes h' as a record of the same layout, which pass #2
+// reads INSTEAD of record + alpha + beta: (alpha, beta) never reach HBM (2 KiB of the 3 KiB per point that made pass #2 HBM-bound).
+// Output tiles are streamed alpha_i, beta_i, ...: the alpha tile waits in LDS (each lane's own 4 x 16 B) for its beta tile; the
+// h8 entries of feature block i (four 16-byte entries per lane: [hi | lo] x [two lane groups of the 16x16x32 B-operand layout]) come
+// in by LDS-DMA two tiles ahead -- a plain global load inside the tile loop would put an in-order vmcnt wait in front of its
+// use and drain the weight pipe; DMA pieces are covered by the pipe's own counted wait, which runs at least three
+// chunks behind their issue.
+template <bool FILM>
 __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wbuf = smem + kRbLdsW;
@@ -320,6 +344,21 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
         // output position as a 32-bit offset from the workgroup's first row: a 64-bit per-lane address held across the
         // tile loop gets spilled, and its reload waits for every weight DMA in flight
         const unsigned out_off = (unsigned)pc * kWidth + 4u * half;
+        // FILM: byte offset of this lane's first record entry (feature block 0, hi, lane group s = 0): the render kernel's point
+        // order is [image][tile of R rays][sample], a tile's points in sub-tiles of 128 = 8 slabs of 16 (siren16.h)
+        unsigned rec_b = 0;
+        uint32_t h8_lds = 0;
+        f32x4* stash = nullptr;
+        if (FILM) {
+            const unsigned gp = (unsigned)gpt, per_img = (unsigned)a.HW * (unsigned)a.S;
+            const unsigned b = gp / per_img, in_img = gp - b * per_img;
+            const unsigned ray = in_img / (unsigned)a.S, tile = ray / (unsigned)a.R;
+            const unsigned pin = in_img - tile * (unsigned)a.R * (unsigned)a.S;
+            const unsigned slab = ((b * (unsigned)a.tiles_per_img + tile) * (unsigned)a.bb_subs + (pin >> 7)) * 8u + ((pin >> 4) & 7u);
+            rec_b = (slab * 1024u + (pin & 15u) + 16u * (unsigned)half) * 16u;
+            h8_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) float*)(smem + kRbLdsH8) + (uint32_t)wave * 8192u;
+            stash = reinterpret_cast<f32x4*>(smem + kRbLdsStash + wave * 1024) + lane;
+        }
 
 #ifdef E3DGE_RB_TRACE
         tr_sub = blockIdx.x == 7 && (tid_k >> 6) == 0 && sub == 1;
@@ -488,28 +527,55 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
             // W_s x accumulates in P, W_1 r in Q.  P is folded into `px` in front of k-steps 20..23 (while Q runs); Q is folded,
             // biased and stored in front of k-steps 1..4 of the NEXT tile (while P runs): no k-step waits for an epilogue.
             f32x16 px;
-            auto out_slice = [&](int tp, int q) {                           // registers 4q..4q+3 of output tile tp
-                float* __restrict__ dst = (tp < 8 ? out_a : out_b) + (out_off + 32u * (tp & 7));
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(b1_s + 32 * tp + 8 * q + 4 * half);
+            // registers 4q..4q+3 of stream tile tp = (tp & 1 ? beta : alpha) of feature block tp >> 1 (PAR = tp & 1, compile time)
+            auto out_slice = [&](auto par, int tp, int q) {
+                constexpr int PAR = decltype(par)::value;
+                const int blk = tp >> 1, rt = 8 * PAR + blk;                 // row tile of W_s / W_1 / b_1
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(b1_s + 32 * rt + 8 * q + 4 * half);
                 f32x4 o4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o4[j] = px[4 * q + j] + (Q0[4 * q + j] + Q1[4 * q + j]) * inv_r + b4[j];
-                if (valid) *reinterpret_cast<f32x4*>(dst + 8 * q) = o4;
-            };
-#pragma unroll 1
-            for (int t = 0; t < kRbTilesOut; ++t) {
-#if defined(E3DGE_RB_TRACE) && E3DGE_RB_TRACE > 1
-                tr_on = tr_sub && t == E3DGE_RB_TRACE_T3;
-#endif
-                auto hook = [&](int g) {
-                    kstep(g);
-                    if (g >= 1 && g <= 4 && t > 0) out_slice(t - 1, g - 1);
-                    if (g >= 20 && g <= 23) {
-                        const int q = g - 20;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) px[4 * q + j] = (P0[4 * q + j] + P1[4 * q + j]) * inv_x;
+                if (!FILM) {
+                    float* __restrict__ dst = (PAR ? out_b : out_a) + (out_off + 32u * blk);
+                    if (valid) *reinterpret_cast<f32x4*>(dst + 8 * q) = o4;
+                } else if (!PAR) {
+                    stash[q * 64] = o4;                                      // alpha waits for its beta tile (this lane's own slot)
+                } else {
+                    const f32x4 al = stash[q * 64];
+                    // h8 of features 32 blk + 8 q + 4 half + (0..3): entry (g = blk, hl, lane group s = q & 1), words 2 (q >> 1), + 1
+                    const unsigned char* hb = reinterpret_cast<const unsigned char*>(smem + kRbLdsH8) + wave * 8192 + (blk & 1) * 4096 + lane * 16 + 8 * (q >> 1);
+                    const uint2 wh = *reinterpret_cast<const uint2*>(hb + (0 * 2 + (q & 1)) * 1024);
+                    const uint2 wl = *reinterpret_cast<const uint2*>(hb + (1 * 2 + (q & 1)) * 1024);
+                    const float h0 = f16lo(wh.x) + f16lo(wl.x), h1 = f16hi(wh.x) + f16hi(wl.x);
+                    const float h2 = f16lo(wh.y) + f16lo(wl.y), h3 = f16hi(wh.y) + f16hi(wl.y);
+                    // the operation order of siren16_kernel's FiLM step: ((alpha + 1) h) + beta, every step rounded
+                    const float y0 = __fadd_rn(__fmul_rn(__fadd_rn(al[0], 1.0f), h0), o4[0]), y1 = __fadd_rn(__fmul_rn(__fadd_rn(al[1], 1.0f), h1), o4[1]);
+                    const float y2 = __fadd_rn(__fmul_rn(__fadd_rn(al[2], 1.0f), h2), o4[2]), y3 = __fadd_rn(__fmul_rn(__fadd_rn(al[3], 1.0f), h3), o4[3]);
+                    uint2 oh, ol;
+                    SPLIT2_TO(y0, y1, oh.x, ol.x);
+                    SPLIT2_TO(y2, y3, oh.y, ol.y);
+                    if (valid) {
+                        unsigned char* ob = a.bb_out + (rec_b + (unsigned)(((blk * 2) * 64 + 32 * (q & 1)) * 16 + 8 * (q >> 1)));
+                        *reinterpret_cast<uint2*>(ob) = oh;
+                        *reinterpret_cast<uint2*>(ob + 64 * 16) = ol;
                     }
-                };
+                }
+            };
+            // FILM: the four h8 entries per lane of feature block blk, by LDS-DMA into buffer blk & 1: piece i = (hl = i >> 1, s = i & 1)
+            auto h8_piece = [&](int blk, int i) {
+                const uint32_t dst = h8_lds + (uint32_t)((blk & 1) * 4096 + i * 1024);
+                glds16_saddr<0>(a.bb_in, rec_b + (unsigned)(((blk * 2 + (i >> 1)) * 64 + 32 * (i & 1)) * 16), (uint32_t)__builtin_amdgcn_readfirstlane((int)dst));
+            };
+            using ParA = std::integral_constant<int, 0>;
+            using ParB = std::integral_constant<int, 1>;
+            auto fold_px = [&](int g) {
+                if (g >= 20 && g <= 23) {
+                    const int q = g - 20;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) px[4 * q + j] = (P0[4 * q + j] + P1[4 * q + j]) * inv_x;
+                }
+            };
+            auto run_tile = [&](auto&& hook) {
                 P0 = zero16(); P1 = zero16();
                 rb_tile<kRbCSteps, kSyncStep16, 0>(pipe.wcur, pipe.wnxt, lane, P0, P1, ringH, ringL,
                     [&](int g, u32x4& H, u32x4& L) { H = xH[g]; L = xL[g]; }, chunk_sync, issue_piece, hook);
@@ -526,9 +592,32 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
                     [&](int g, u32x4& H, u32x4& L) { H = rH[kRbCSteps + g]; L = rL[kRbCSteps + g]; }, chunk_sync, issue_piece, hook);
                 pipe.advance();
                 RB_STAMP(700);
+            };
+            // W_s x accumulates in P, W_1 r in Q.  P is folded into `px` in front of k-steps 20..23 (while Q runs); Q is folded,
+            // biased and stored / stashed / FiLM-ed in front of k-steps 1..4 of the NEXT tile (while P runs): no k-step waits for
+            // an epilogue.  The tile loop runs over feature blocks (alpha tile, beta tile) so that a slice's kind is a compile-time fact.
+#pragma unroll 1
+            for (int blk = 0; blk < kRbTilesOut / 2; ++blk) {
+#if defined(E3DGE_RB_TRACE) && E3DGE_RB_TRACE > 1
+                tr_on = tr_sub && 2 * blk == E3DGE_RB_TRACE_T3;
+#endif
+                run_tile([&](int g) {                   // alpha tile of block blk; finishes the beta tile of block blk - 1
+                    kstep(g);
+                    if (g >= 1 && g <= 4 && blk > 0) out_slice(ParB{}, 2 * blk - 1, g - 1);
+                    if (FILM && g >= 11 && g <= 14) h8_piece(blk, g - 11);
+                    fold_px(g);
+                });
+#if defined(E3DGE_RB_TRACE) && E3DGE_RB_TRACE > 1
+                tr_on = tr_sub && 2 * blk + 1 == E3DGE_RB_TRACE_T3;
+#endif
+                run_tile([&](int g) {                   // beta tile of block blk; finishes its alpha tile
+                    kstep(g);
+                    if (g >= 1 && g <= 4) out_slice(ParA{}, 2 * blk, g - 1);
+                    fold_px(g);
+                });
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) out_slice(kRbTilesOut - 1, q);
+            for (int q = 0; q < 4; ++q) out_slice(ParB{}, kRbTilesOut - 1, q);
             RB_STAMP(800);
         }
 #ifdef E3DGE_RB_TRACE
@@ -562,6 +651,23 @@ extern "C" int e3dge_resblock_pack_weights(float* packed, const float* w0, const
     return check_launch("resblock_pack_weights(norms)");
 }
 
+static int launch_resblock(ResblockK k, bool film, hipStream_t st, const char* what) {
+    const int lds = film ? kRbLdsFilmBytes : kRbLdsBytes;
+    const void* fn = film ? reinterpret_cast<const void*>(&resblock_kernel<true>) : reinterpret_cast<const void*>(&resblock_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);       // per device, cheap: set on every launch
+    if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(resblock): %s", hipGetErrorString(e));
+    const int64_t tiles = (k.n_pts + kTilePts - 1) / kTilePts;
+    int spw = (int)((tiles + 255) / 256);
+    if (spw < 1) spw = 1;
+    if (spw > 8) spw = 8;
+    k.subtiles_per_wg = spw;
+    const int64_t grid = (tiles + spw - 1) / spw;
+    E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "%s: grid too large", what);
+    if (film) resblock_kernel<true><<<dim3((unsigned)grid), dim3(kThreads), lds, st>>>(k);
+    else resblock_kernel<false><<<dim3((unsigned)grid), dim3(kThreads), lds, st>>>(k);
+    return check_launch(what);
+}
+
 extern "C" int e3dge_tex_modulations_fwd(const float* packed, const float* feats, int cin, int64_t n_pts,
                                          float* alpha, float* beta, e3dge_stream_t stream) {
     E3DGE_REQUIRE(n_pts >= 0, "tex_modulations_fwd: bad size");
@@ -570,20 +676,27 @@ extern "C" int e3dge_tex_modulations_fwd(const float* packed, const float* feats
     E3DGE_REQUIRE(cin >= 1 && cin <= kRbKin, "tex_modulations_fwd: cin=%d outside [1, %d]", cin, kRbKin);
     E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(alpha) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0,
                   "tex_modulations_fwd: packed/alpha/beta must be 16-B aligned");
-    {   // per device, cheap: set on every launch
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kRbLdsBytes);
-        if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(resblock): %s", hipGetErrorString(e));
-    }
     ResblockK k{};
     k.packed = packed; k.feats = feats; k.alpha = alpha; k.beta = beta; k.n_pts = n_pts; k.cin = cin;
-    const int64_t tiles = (n_pts + kTilePts - 1) / kTilePts;
-    int spw = (int)((tiles + 255) / 256);
-    if (spw < 1) spw = 1;
-    if (spw > 8) spw = 8;
-    k.subtiles_per_wg = spw;
-    const int64_t grid = (tiles + spw - 1) / spw;
-    E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "tex_modulations_fwd: grid too large");
-    resblock_kernel<<<dim3((unsigned)grid), dim3(kThreads), kRbLdsBytes, as_stream(stream)>>>(k);
-    return check_launch("tex_modulations_fwd");
+    return launch_resblock(k, false, as_stream(stream), "tex_modulations_fwd");
+}
+
+extern "C" int e3dge_tex_film_fwd(const float* packed, const float* feats, int cin, int batch, int height, int width, int n_samples,
+                                  const void* backbone_in, void* backbone_out, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(batch >= 0 && height > 0 && width > 0 && n_samples > 0, "tex_film_fwd: bad sizes");
+    if (batch == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(packed && feats && backbone_in && backbone_out && backbone_in != backbone_out, "tex_film_fwd: null / aliased pointer");
+    E3DGE_REQUIRE(cin >= 1 && cin <= kRbKin, "tex_film_fwd: cin=%d outside [1, %d]", cin, kRbKin);
+    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(backbone_in) | reinterpret_cast<uintptr_t>(backbone_out)) & 15) == 0,
+                  "tex_film_fwd: packed / records must be 16-B aligned");
+    const int64_t bytes = e3dge_siren_backbone_bytes(batch, height, width, n_samples);
+    const int64_t n_pts = (int64_t)batch * height * width * n_samples;
+    E3DGE_REQUIRE(bytes > 0 && bytes < ((int64_t)1 << 32) && n_pts < ((int64_t)1 << 31),
+                  "tex_film_fwd: record of %lld bytes (needs 0 < bytes < 4 GiB: 32-bit offsets)", (long long)bytes);
+    ResblockK k{};
+    k.packed = packed; k.feats = feats; k.n_pts = n_pts; k.cin = cin;
+    k.bb_in = static_cast<const unsigned char*>(backbone_in); k.bb_out = static_cast<unsigned char*>(backbone_out);
+    k.S = n_samples; k.HW = height * width;
+    siren_record_layout(batch, height, width, n_samples, &k.R, &k.tiles_per_img, &k.bb_subs);
+    return launch_resblock(k, true, as_stream(stream), "tex_film_fwd");
 }

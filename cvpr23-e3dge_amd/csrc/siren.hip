@@ -1068,6 +1068,17 @@ extern "C" int e3dge_siren_render_fwd(const E3dgeRenderArgs* r, e3dge_stream_t s
     return check_launch("siren_render_fwd");
 }
 
+// tiling of a render launch (rays per workgroup, workgroups per image, 128-point sub-tiles per workgroup): what the layer-7 record's
+// slab index is made of; shared with the texture head's FILM form (resblock.hip)
+void e3dge::siren_record_layout(int batch, int height, int width, int n_samples, int* R, int* tiles_per_img, int* subs) {
+    const int64_t HW = (int64_t)height * width;
+    int r = pick_rays_per_wg(n_samples, HW * batch);
+    if (r > HW) r = (int)HW;
+    *R = r;
+    *tiles_per_img = (int)((HW + r - 1) / r);
+    *subs = (r * n_samples + kTilePts - 1) / kTilePts;
+}
+
 extern "C" int64_t e3dge_siren_backbone_bytes(int batch, int height, int width, int n_samples) {
     if (batch <= 0 || height <= 0 || width <= 0 || n_samples < kMinSamples) return 0;
     const int64_t HW = (int64_t)height * width;

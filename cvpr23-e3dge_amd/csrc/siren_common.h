@@ -114,6 +114,8 @@ struct SirenK {
     void* bb_out; const void* bb_in; const float* weights_in; int bb_subs;
 };
 
+void siren_record_layout(int batch, int height, int width, int n_samples, int* R, int* tiles_per_img, int* subs);   // siren.hip
+
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------

@@ -266,4 +266,8 @@ def tex_modulations_from_maps(local_head, renderer, cam_poses, focal, near, far,
     """(alpha, beta), each (B,H,W,S,256), for the renderer's second pass (called by VolumeFeatureRenderer.forward)."""
     feats, in_img = local_features_from_maps(local_data_batch)
     local_data_batch['in_img_mask'] = in_img
-    return local_head.local_feat_to_tex_modulations_linear.tex_modulations(feats)
+    head = local_head.local_feat_to_tex_modulations_linear
+    if not torch.is_grad_enabled():
+        from .volume_renderer import _LazyTex            # the renderer decides: fused head + FiLM launch on the record path, or (alpha, beta)
+        return _LazyTex(head, feats)
+    return head.tex_modulations(feats)

@@ -32,6 +32,25 @@ from . import _lib
 
 MFMA_MODES = {"f32": _lib.PREC_F32, "f16x3": _lib.PREC_F16X3, "f16x3_v1": _lib.PREC_F16X3_V1}
 _SIDE_STREAM = os.environ.get("E3DGE_SIDE_STREAM", "1") != "0"     # surface-normal query beside the sdf chain (forward())
+def _fuse_texfilm():                                                   # texture head writes the FiLM-ed layer-7 record itself
+    return os.environ.get("E3DGE_FUSE_TEXFILM", "1") != "0"
+
+
+class _LazyTex:
+    """The texture FiLM of a second pass, not yet evaluated: the head and its (B,H,W,S,C) input.  When the pass starts from the
+    first pass's layer-7 record, head + FiLM run as ONE launch that writes the FiLM-ed record (e3dge_tex_film_fwd: (alpha, beta)
+    never reach HBM); otherwise `materialize()` gives the (alpha, beta) pair every other path consumes."""
+    __slots__ = ('head', 'feats', '_ab')
+
+    def __init__(self, head, feats):
+        self.head, self.feats, self._ab = head, feats, None
+
+    def materialize(self):
+        if self._ab is None:
+            self._ab = self.head.tex_modulations(self.feats)
+        return self._ab
+
+
 def _reuse_backbone():                                                 # second pass of an image reads the first pass's layer-7 output
     return os.environ.get("E3DGE_REUSE_BACKBONE", "1") != "0"
 
@@ -690,6 +709,20 @@ class ResnetBlockFC(nn.Module):
         _lib.check(rc, "e3dge_tex_modulations_fwd")
         return alpha, beta
 
+    def tex_film(self, feats, record_in, record_out, B, H, W, S):
+        """feats (B,H,W,S,size_in) + the first render pass's layer-7 record -> `record_out` = the record of (alpha + 1) h8 + beta,
+        in one launch (inference only; bit-identical to tex_modulations + the FiLM step inside the render kernel)."""
+        _lib.require_gpu(feats, "feats")
+        f = feats.reshape(-1, self.size_in).contiguous()
+        if f.shape[0] != B * H * W * S:
+            raise RuntimeError(f"local features {tuple(feats.shape)} do not match the render ({B},{H},{W},{S},{self.size_in})")
+        packed = self.device_image()
+        with torch.cuda.device(f.device):
+            rc = _lib.load().e3dge_tex_film_fwd(_lib.ptr(packed), _lib.ptr(f), self.size_in, B, H, W, S, _lib.ptr(record_in),
+                                                _lib.ptr(record_out), _lib.stream_of(f))
+        _lib.check(rc, "e3dge_tex_film_fwd")
+        return record_out
+
     def tex_modulations(self, feats):
         """feats (.., size_in) -> (alpha, beta), each (.., 256): the split the renderer's second pass consumes.
         Differentiable (features and the five parameters) when anything requires grad: the backward recomputes the hidden
@@ -852,7 +885,9 @@ class VolumeFeatureRenderer(nn.Module):
         if not self.test and (self.perturb or self.raw_noise_std):
             raise NotImplementedError("stratified perturbation / raw noise (train-mode sampling) is not covered by "
                                       "the fused kernel; construct with mode='test' or perturb=0")
-        tex_grad = tex_conditions is not None and (tex_conditions[0].requires_grad or tex_conditions[1].requires_grad)
+        if isinstance(tex_conditions, _LazyTex) and (torch.is_grad_enabled() or return_eikonal or not self._reuse_enabled(None)):
+            tex_conditions = tex_conditions.materialize()          # (only the record path can use the fused head + FiLM launch)
+        tex_grad = tex_conditions is not None and not isinstance(tex_conditions, _LazyTex) and (tex_conditions[0].requires_grad or tex_conditions[1].requires_grad)
         if torch.is_grad_enabled() and (styles.requires_grad or tex_grad) and c2w.shape[0]:
             self.siren.require_frozen("VolumeFeatureRenderer.render")
             if self.sigmoid_beta.requires_grad:
@@ -886,6 +921,11 @@ class VolumeFeatureRenderer(nn.Module):
                          (self.N_samples, self.out_im_res, str(dev), torch.cuda.current_stream(dev).cuda_stream,
                           self.siren.mfma_mode, bool(self.force_background), float(self.box_scale)))
 
+    def _lazy_tex_ok(self, feats, head):
+        """May the texture head be deferred into the record path (no autograd graph wanted anywhere near it)?"""
+        return (not torch.is_grad_enabled() and self._reuse_enabled(None) and _fuse_texfilm() and torch.is_tensor(feats)
+                and feats.ndim == 5 and feats.shape[-1] == head.size_in and feats.dtype == torch.float32 and feats.device.type == "cuda")
+
     def _reuse_enabled(self, save_args):
         return (_reuse_backbone() and save_args is None and not torch.is_grad_enabled() and self.enable_local_model
                 and self.siren.check_mode(self.siren.mfma_mode) == _lib.PREC_F16X3)
@@ -906,7 +946,8 @@ class VolumeFeatureRenderer(nn.Module):
         near_c = near.reshape(B).contiguous()
         far_c = far.reshape(B).contiguous()
         ta = tb = None
-        if tex_conditions is not None:
+        lazy = tex_conditions if isinstance(tex_conditions, _LazyTex) else None
+        if tex_conditions is not None and lazy is None:
             ta, tb = tex_conditions
             _lib.require_gpu(ta, "tex alpha"); _lib.require_gpu(tb, "tex beta")
             if tuple(ta.shape) != (B, H, Wd, S, 256) or tuple(tb.shape) != (B, H, Wd, S, 256):
@@ -930,6 +971,21 @@ class VolumeFeatureRenderer(nn.Module):
                 use = rec                                     # (a first-pass output edited in place since is a miss, not a stale read)
         elif tex_conditions is None:
             _BACKBONE.pop(self, None)                         # a plain render that leaves no record must not leave an older one valid
+        bb_in = use['buf'] if use is not None else None
+        if lazy is not None:
+            n_rec = use['buf'].numel() if use is not None else 0
+            if (use is not None and _fuse_texfilm() and lazy.feats.dtype == torch.float32 and lazy.feats.device == dev
+                    and tuple(lazy.feats.shape[:4]) == (B, H, Wd, S) and 0 < n_rec < 2 ** 32 and B * H * Wd * S < 2 ** 31):
+                tb_ = use.get('tex_buf')
+                if tb_ is None or tb_.numel() != n_rec or tb_.device != dev:
+                    tb_ = use['tex_buf'] = torch.zeros(n_rec, device=dev, dtype=torch.uint8)     # (padding slabs stay zero)
+                bb_in = lazy.head.tex_film(lazy.feats, use['buf'], tb_, B, H, Wd, S)
+            else:
+                ta, tb = lazy.materialize()
+                _lib.require_gpu(ta, "tex alpha"); _lib.require_gpu(tb, "tex beta")
+                if tuple(ta.shape) != (B, H, Wd, S, 256) or tuple(tb.shape) != (B, H, Wd, S, 256):
+                    raise RuntimeError(f"tex conditions must be (B,H,W,S,256) = {(B, H, Wd, S, 256)}; got {tuple(ta.shape)}")
+                ta, tb = ta.contiguous(), tb.contiguous()
         if use is not None:
             o1 = use['out']
             out = dict(o1, rgb=torch.empty((B, 3, H, Wd), **f32), features=torch.empty((B, 256, H, Wd), **f32))
@@ -955,7 +1011,7 @@ class VolumeFeatureRenderer(nn.Module):
             rgb=op['rgb'], features=op['features'], xyz=op['xyz'], depth=op['depth'], mask=op['mask'], sdf=op['sdf'],
             weights=op['weights'], points=op['points'], rays_d=op['rays_d'], viewdirs=op['viewdirs'], dists=op['dists'],
             save_args=_lib.ptr(save_args), backbone_out=_lib.ptr(bb_out),
-            backbone_in=_lib.ptr(use['buf']) if use is not None else None,
+            backbone_in=_lib.ptr(bb_in) if use is not None else None,
             weights_in=_lib.ptr(use['out']['weights']) if use is not None else None)
         with torch.cuda.device(dev):
             rc = _lib.load().e3dge_siren_render_fwd(ctypes.byref(args), _lib.stream_of(c2w))
@@ -1022,11 +1078,15 @@ class VolumeFeatureRenderer(nn.Module):
                 tex = local_data_batch['tex']
             elif local_data_batch.get('feats', None) is not None and self.network.netLocal is not None:
                 # already-queried local features (forward_local :434-437) -> texture FiLM (:327-336), fused head
-                tex = self.network.netLocal.local_feat_to_tex_modulations_linear.tex_modulations(local_data_batch['feats'])
+                head = self.network.netLocal.local_feat_to_tex_modulations_linear
+                tex = _LazyTex(head, local_data_batch['feats']) if self._lazy_tex_ok(local_data_batch['feats'], head) \
+                    else head.tex_modulations(local_data_batch['feats'])
             elif local_data_batch.get('feature_maps', None) is not None and self.network.netLocal is not None:
                 # feature maps of the local branch: the per-point query (projection + bilinear gather + positional
                 # encoding, e3dge_full_runner.py:185-317) runs in HIP and feeds the texture head directly
                 tex = self.network.netLocal.tex_modulations_from_maps(self, cam_poses, focal, near, far, local_data_batch)
+                if isinstance(tex, _LazyTex) and not self._lazy_tex_ok(tex.feats, tex.head):
+                    tex = tex.materialize()
             else:
                 raise NotImplementedError(
                     "local_data_batch must carry the local features 'feats' (B,H,W,S,C) [with L_pred_tex_modulations], the "

@@ -475,6 +475,14 @@ int e3dge_resblock_pack_weights(float* packed, const float* w0, const float* b0,
                                 const float* ws, int cin, e3dge_stream_t stream);
 int e3dge_tex_modulations_fwd(const float* packed, const float* feats, int cin, int64_t n_pts,
                               float* alpha, float* beta, e3dge_stream_t stream);
+/* The head INSIDE the second render pass's data flow (ABI 11; SURVEY.md 8 f1 as specified: (alpha, beta) never materialise):
+ * feats (batch, height, width, n_samples, cin) -> h' = (alpha + 1) h8 + beta, where h8 is the layer-7 output that render
+ * pass #1 left in `backbone_in` (e3dge_siren_render_fwd backbone_out, e3dge_siren_backbone_bytes bytes) -- the FiLM step of
+ * volume_renderer.py:217-220 in siren16_kernel's operation order, bit-identical to applying tex_alpha / tex_beta there.
+ * `backbone_out` (same size and layout, zero-filled once by the caller: padding slabs are never written) is what pass #2 then
+ * takes as its backbone_in, WITHOUT tex_alpha / tex_beta.  Records are limited to 4 GiB (32-bit offsets). */
+int e3dge_tex_film_fwd(const float* packed, const float* feats, int cin, int batch, int height, int width, int n_samples,
+                       const void* backbone_in, void* backbone_out, e3dge_stream_t stream);
 
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -318,3 +318,47 @@ def test_backbone_record_notices_an_edited_first_pass_output():
         again = r(poses, focal, near, far, styles=wr, local_data_batch={'feats': feats})
         assert again['sdf'] is not p1['sdf']                           # full launch
         assert torch.equal(again['features'], keep)
+
+
+@pytest.mark.parametrize("res,S,B", [(8, 24, 1), (16, 18, 2), (16, 21, 1), (64, 24, 1)])
+def test_head_and_film_in_one_launch_is_bit_identical(res, S, B, monkeypatch):
+    """SURVEY 8 f1 as specified: on the record path the texture head applies (alpha + 1) h8 + beta itself and hands pass #2 the
+    FiLM-ed layer-7 record (e3dge_tex_film_fwd) -- (alpha, beta) never reach HBM.  Every output must equal, bit for bit, the
+    two-launch form (head -> (alpha, beta) -> FiLM inside the render kernel) and the full second pass; sizes include tiles
+    whose point count is not a multiple of the 128-point sub-tile (S = 18, 21) and a batch of two."""
+    r = _local_renderer(res, S)
+    head = r.network.netLocal.local_feat_to_tex_modulations_linear
+    wr, _ = syn.synthetic_inputs(B, seed=7, device=DEV)
+    poses, focal, near, far, _ = generate_camera_params(res, DEV, locations=0.2 * torch.randn(B, 2, device=DEV))
+    feats = syn.synthetic_local_feats(B, res, S, device=DEV)
+    calls = []
+    orig = head.tex_film
+    monkeypatch.setattr(head, "tex_film", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    keys = ('features', 'gen_thumb_imgs', 'sdf', 'hit_prob', 'xyz', 'depth', 'mask')
+    with torch.no_grad():
+        monkeypatch.setenv("E3DGE_REUSE_BACKBONE", "0")
+        full = r(poses, focal, near, far, styles=wr, local_data_batch={'feats': feats})
+        monkeypatch.setenv("E3DGE_REUSE_BACKBONE", "1")
+        monkeypatch.setenv("E3DGE_FUSE_TEXFILM", "0")
+        r(poses, focal, near, far, styles=wr)
+        two = r(poses, focal, near, far, styles=wr, local_data_batch={'feats': feats})
+        assert not calls
+        monkeypatch.setenv("E3DGE_FUSE_TEXFILM", "1")
+        r(poses, focal, near, far, styles=wr)
+        one = r(poses, focal, near, far, styles=wr, local_data_batch={'feats': feats})
+        again = r(poses, focal, near, far, styles=wr, local_data_batch={'feats': feats.clone()})
+        assert len(calls) == 2
+        for k in keys:
+            assert torch.equal(one[k], two[k]) and torch.equal(one[k], full[k]) and torch.equal(again[k], full[k]), k
+        # a second pass without a record (another latent) falls back to (alpha, beta)
+        calls.clear()
+        wr2 = wr.clone()
+        miss = r(poses, focal, near, far, styles=wr2, local_data_batch={'feats': feats})
+        assert not calls and torch.equal(miss['features'], full['features'])
+    # with a graph wanted, the head stays differentiable
+    f2 = feats.clone().requires_grad_(True)
+    for p_ in r.parameters():
+        p_.requires_grad_(False)
+    out = r(poses, focal, near, far, styles=wr, local_data_batch={'feats': f2})
+    out['features'].square().mean().backward()
+    assert f2.grad is not None and torch.isfinite(f2.grad).all() and float(f2.grad.abs().max()) > 0
