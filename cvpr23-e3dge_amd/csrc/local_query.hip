@@ -84,6 +84,96 @@ __global__ void __launch_bounds__(256) local_query_kernel(const LocalQueryK a) {
     }
 }
 
+// Backward of the gather (reference: project/models/op/grid_sample_gradfix.py:52-89 -- grid_sampler_2d_backward for the feature map
+// AND the grid -- behind HGPIFuNetGAN.query's index(), vendor/pifu/lib/model/HGPIFuGANNet.py:85-151; stage-2 training
+// back-propagates into the hourglass filters' maps through it, e3dge_full_runner.py:185-317).  One wave per point, as forward:
+//   d_fmap[corner] += w_corner * d_out          (atomic adds into the channel-last map: four contiguous C-float rows per point)
+//   d_fx = sum_c d_out_c ((1-ty)(f01 - f00) + ty (f11 - f10)),  d_fy = sum_c d_out_c ((1-tx)(f10 - f00) + tx (f11 - f01))
+//   (corners outside the map count as zeros, like grid_sample's zeros padding), then through the pixel mapping, the flip of y,
+//   the perspective division and the calibration rows to d_pts.
+struct LocalQueryBwdK {
+    const float* pts; const float* calibs; const float* fmap;      // as forward
+    const float* d_out;     // (B, N, ld): gradient of the features, columns [col_off, col_off + C)
+    float* d_fmap;          // (B, h, w, C) channel-last, zero-filled by the caller, or null
+    float* d_pts;           // (B, N, 3) or null
+    long long N;
+    int B, C, h, w, ld, col_off;
+};
+
+__global__ void __launch_bounds__(256) local_query_bwd_kernel(const LocalQueryBwdK a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float zsign;
+    {
+        const float* c = a.calibs;
+        const float* p = a.pts;
+        const float hz = fmaf(c[8], p[0], fmaf(c[9], p[1], fmaf(c[10], p[2], c[11])));
+        zsign = hz < 0.0f ? -1.0f : 1.0f;
+    }
+    const long long total = (long long)a.B * a.N;
+    for (long long pt = (long long)blockIdx.x * 4 + wave; pt < total; pt += (long long)gridDim.x * 4) {
+        const int b = (int)(pt / a.N);
+        const float* c = a.calibs + (size_t)b * 12;
+        const float* p = a.pts + (size_t)pt * 3;
+        const float px = p[0], py = p[1], pz = p[2];
+        const float hx = c[3] + (c[0] * px + c[1] * py + c[2] * pz);
+        const float hy = c[7] + (c[4] * px + c[5] * py + c[6] * pz);
+        const float hz = c[11] + (c[8] * px + c[9] * py + c[10] * pz);
+        const float z = zsign * hz;
+        const float x = hx / z, y = -(hy / z);
+        const float fx = ((x + 1.0f) * (float)a.w - 1.0f) * 0.5f, fy = ((y + 1.0f) * (float)a.h - 1.0f) * 0.5f;
+        const float x0f = floorf(fx), y0f = floorf(fy);
+        const float tx = fx - x0f, ty = fy - y0f;
+        const bool finite = fx > -2.0f && fx < (float)a.w + 1.0f && fy > -2.0f && fy < (float)a.h + 1.0f;
+        const int x0 = finite ? (int)x0f : -5, y0 = finite ? (int)y0f : -5;
+        const float w00 = (1.0f - tx) * (1.0f - ty), w01 = tx * (1.0f - ty), w10 = (1.0f - tx) * ty, w11 = tx * ty;
+        const bool vx0 = x0 >= 0 && x0 < a.w, vx1 = x0 + 1 >= 0 && x0 + 1 < a.w;
+        const bool vy0 = y0 >= 0 && y0 < a.h, vy1 = y0 + 1 >= 0 && y0 + 1 < a.h;
+        const size_t moff = (size_t)b * a.h * a.w * a.C;
+        const size_t o00 = moff + ((size_t)y0 * a.w + x0) * a.C, o01 = o00 + a.C, o10 = o00 + (size_t)a.w * a.C, o11 = o10 + a.C;
+        const float* g = a.d_out + (size_t)pt * a.ld + a.col_off;
+        float gx = 0.0f, gy = 0.0f;
+        for (int ch = lane * 4; ch < a.C; ch += 256) {
+            lq_f4 d;
+            if ((a.ld & 3) == 0 && (a.col_off & 3) == 0) d = *reinterpret_cast<const lq_f4*>(g + ch);
+            else { d[0] = g[ch]; d[1] = g[ch + 1]; d[2] = g[ch + 2]; d[3] = g[ch + 3]; }
+            if (a.d_fmap) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (vy0 && vx0) atomicAdd(a.d_fmap + o00 + ch + j, w00 * d[j]);
+                    if (vy0 && vx1) atomicAdd(a.d_fmap + o01 + ch + j, w01 * d[j]);
+                    if (vy1 && vx0) atomicAdd(a.d_fmap + o10 + ch + j, w10 * d[j]);
+                    if (vy1 && vx1) atomicAdd(a.d_fmap + o11 + ch + j, w11 * d[j]);
+                }
+            }
+            if (a.d_pts) {
+                const lq_f4 zero = {0.f, 0.f, 0.f, 0.f};
+                const lq_f4 f00 = (vy0 && vx0) ? *reinterpret_cast<const lq_f4*>(a.fmap + o00 + ch) : zero;
+                const lq_f4 f01 = (vy0 && vx1) ? *reinterpret_cast<const lq_f4*>(a.fmap + o01 + ch) : zero;
+                const lq_f4 f10 = (vy1 && vx0) ? *reinterpret_cast<const lq_f4*>(a.fmap + o10 + ch) : zero;
+                const lq_f4 f11 = (vy1 && vx1) ? *reinterpret_cast<const lq_f4*>(a.fmap + o11 + ch) : zero;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    gx = fmaf(d[j], (1.0f - ty) * (f01[j] - f00[j]) + ty * (f11[j] - f10[j]), gx);
+                    gy = fmaf(d[j], (1.0f - tx) * (f10[j] - f00[j]) + tx * (f11[j] - f01[j]), gy);
+                }
+            }
+        }
+        if (a.d_pts) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { gx += __shfl_xor(gx, off, kWave); gy += __shfl_xor(gy, off, kWave); }
+            if (lane == 0) {
+                const float dx = gx * (0.5f * (float)a.w), dy = gy * (0.5f * (float)a.h);     // d fx / d x = w / 2
+                // x = hx / z, y = -hy / z, z = zsign hz
+                const float dhx = dx / z, dhy = -dy / z, dhz = zsign * (-(dx * x + dy * y) / z);
+                float* q = a.d_pts + (size_t)pt * 3;
+                q[0] = c[0] * dhx + c[4] * dhy + c[8] * dhz;
+                q[1] = c[1] * dhx + c[5] * dhy + c[9] * dhz;
+                q[2] = c[2] * dhx + c[6] * dhy + c[10] * dhz;
+            }
+        }
+    }
+}
+
 // out[m, col_off + ...] = [x(3), sin(f_0 x)(3), cos(f_0 x)(3), sin(f_1 x)(3), ...], f_k = 2^k
 __global__ void __launch_bounds__(256)
 pos_encoding_kernel(float* __restrict__ out, const float* __restrict__ pts, long long M, int n_freqs, int ld, int col_off) {
@@ -126,6 +216,24 @@ extern "C" int e3dge_local_query(float* out, int ld, int col_off, float* in_img,
     if (blocks > 256 * 32) blocks = 256 * 32;
     local_query_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(k);
     return check_launch("local_query");
+}
+
+extern "C" int e3dge_local_query_bwd(float* d_fmap_nhwc, float* d_pts, const float* d_out, int ld, int col_off, const float* pts,
+                                     const float* calibs, const float* fmap_nhwc, int batch, int64_t n_pts, int channels, int fh, int fw,
+                                     e3dge_stream_t stream) {
+    E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "local_query_bwd: bad sizes");
+    if (batch == 0 || n_pts == 0 || (!d_fmap_nhwc && !d_pts)) return E3DGE_OK;
+    E3DGE_REQUIRE(pts && calibs && d_out && fmap_nhwc, "local_query_bwd: null pointer");
+    E3DGE_REQUIRE(channels >= 4 && channels % 4 == 0 && fh >= 1 && fw >= 1, "local_query_bwd: feature map needs C %% 4 == 0");
+    E3DGE_REQUIRE(ld >= col_off + channels && col_off >= 0, "local_query_bwd: gradient slice [%d, %d) outside ld=%d", col_off, col_off + channels, ld);
+    E3DGE_REQUIRE((reinterpret_cast<uintptr_t>(fmap_nhwc) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0, "local_query_bwd: fmap / d_out must be 16-B aligned");
+    LocalQueryBwdK k{};
+    k.pts = pts; k.calibs = calibs; k.fmap = fmap_nhwc; k.d_out = d_out; k.d_fmap = d_fmap_nhwc; k.d_pts = d_pts; k.N = n_pts; k.B = batch;
+    k.C = channels; k.h = fh; k.w = fw; k.ld = ld; k.col_off = col_off;
+    int64_t blocks = ((int64_t)batch * n_pts + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    local_query_bwd_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(k);
+    return check_launch("local_query_bwd");
 }
 
 extern "C" int e3dge_pos_encoding(float* out, int ld, int col_off, const float* pts, int64_t n_pts, int n_freqs,

@@ -42,10 +42,13 @@ def query_feature_map(pts, calibs, fmap=None, out=None, col_off=0, mask_out=None
     _lib.require_gpu(pts, "pts")
     _lib.require_gpu(calibs, "calibs")
     if torch.is_grad_enabled() and (pts.requires_grad or (fmap is not None and fmap.requires_grad)):
-        # the reference's index() is grid_sample_gradfix: differentiable w.r.t. the feature map (stage-2 training trains the
-        # hourglass filters through it).  The gather kernel has no backward yet -- refuse rather than drop the gradient.
-        raise NotImplementedError("e3dge_local_query has no backward: detach the feature map / points (the hourglass filters "
-                                  "that produce them are outside this build) or run under torch.no_grad()")
+        # the reference's index() is grid_sample_gradfix: differentiable w.r.t. the feature map AND the sampling position (stage-2
+        # training trains the hourglass filters through it).  The differentiable form returns its own (B,N,C) tensor:
+        if fmap is None or want_proj or out is not None or mask_out is not None:
+            raise NotImplementedError("the differentiable gather (e3dge_local_query_bwd) covers the features only: call without "
+                                      "`out` / `mask_out` / want_proj, or detach the points (projection and mask carry no gradient here)")
+        feats, mask = _GatherFn.apply(pts, calibs, fmap)
+        return feats, mask, None
     B, N, _ = pts.shape
     dev = pts.device
     p = pts.contiguous()
@@ -74,6 +77,40 @@ def query_feature_map(pts, calibs, fmap=None, out=None, col_off=0, mask_out=None
     _lib.check(rc, "e3dge_local_query")
     feats = None if fmap is None else out[..., col_off:col_off + C]
     return feats, mask, proj
+
+
+class _GatherFn(torch.autograd.Function):
+    """e3dge_local_query with a backward (e3dge_local_query_bwd): bilinear scatter of d feats into the channel-last map (atomic
+    adds) and the gradient through the sampling position; the in-image mask is returned as a non-differentiable output.
+    Reference: project/models/op/grid_sample_gradfix.py:52-89."""
+
+    @staticmethod
+    def forward(ctx, pts, calibs, fmap):
+        with torch.no_grad():
+            feats, mask, _ = query_feature_map(pts.detach(), calibs.detach(), fmap.detach())
+        ctx.save_for_backward(pts, calibs, fmap)
+        ctx.mark_non_differentiable(mask)
+        return feats, mask
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_feats, _d_mask):
+        pts, calibs, fmap = ctx.saved_tensors
+        B, N, _ = pts.shape
+        C, h, w = fmap.shape[1:]
+        dev = pts.device
+        need_p, _, need_f = ctx.needs_input_grad
+        g = d_feats.contiguous().float()
+        fm = fmap.detach().permute(0, 2, 3, 1).contiguous()
+        d_fm = torch.zeros((B, h, w, C), device=dev, dtype=torch.float32) if need_f else None
+        d_p = torch.empty((B, N, 3), device=dev, dtype=torch.float32) if need_p else None
+        p = pts.detach().contiguous()
+        c = calibs.detach()[:, :3, :4].contiguous()
+        with torch.cuda.device(dev):
+            rc = _lib.load().e3dge_local_query_bwd(_lib.ptr(d_fm), _lib.ptr(d_p), _lib.ptr(g), C, 0, _lib.ptr(p), _lib.ptr(c), _lib.ptr(fm),
+                                                   B, N, C, h, w, _lib.stream_of(g))
+        _lib.check(rc, "e3dge_local_query_bwd")
+        return d_p, None, (d_fm.permute(0, 3, 1, 2) if need_f else None)
 
 
 def pos_encoding(pts, n_freqs=7, out=None, col_off=0):
@@ -248,6 +285,24 @@ def local_features_from_maps(local_data_batch, n_freqs=7):
     add_mask = bool(local_data_batch.get('add_vis_mask', True))
     C = maps['ref'].shape[1]
     n_enc = C + (1 if add_mask else 0)
+    if torch.is_grad_enabled() and (maps['ref'].requires_grad or maps['que'].requires_grad or pts.requires_grad or
+                                    any(p_.requires_grad for p_ in fuse.parameters())):
+        # training form (stage 2 trains the hourglass filters and Fuse_sft_MLP through this, e3dge_full_runner.py:185-317): the
+        # same values assembled from differentiable pieces -- gathers with the HIP backward, Fuse_sft_MLP as torch modules
+        a, _, _ = query_feature_map(pts, local_data_batch['que_calibs'], maps['que'])
+        dec, in_img, _ = query_feature_map(pts, local_data_batch['ref_calibs'], maps['ref'])
+        cols = [a]
+        if add_mask:
+            with torch.no_grad():
+                surf = local_data_batch['xyz'].detach().reshape(B, 3, H * W).permute(0, 2, 1)
+                _, vis, _ = query_feature_map(surf, local_data_batch['ref_calibs'])
+            cols.append(vis.reshape(B, H * W, 1).expand(B, H * W, S).reshape(B, N, 1))
+        cols.append(dec)
+        fused = fuse.fuse(torch.cat(cols, -1), dec)
+        with torch.no_grad():
+            enc_p = pos_encoding(pts.detach(), n_freqs)
+        feats = torch.cat([fused, enc_p], -1)
+        return feats.reshape(B, H, W, S, feats.shape[-1]), in_img.reshape(B, H, W, S, 1)
     enc_in = torch.empty((B, N, n_enc + C), device=pts.device, dtype=torch.float32)       # [2D-aligned | vis mask | 3D-projected]
     query_feature_map(pts, local_data_batch['que_calibs'], maps['que'], out=enc_in, col_off=0)
     dec, in_img, _ = query_feature_map(pts, local_data_batch['ref_calibs'], maps['ref'], out=enc_in, col_off=n_enc)

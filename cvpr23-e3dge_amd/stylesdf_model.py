@@ -138,6 +138,52 @@ def decoder_backend():
     return v
 
 
+def decoder_autograd_backend():
+    """What Decoder.forward does when an autograd graph is wanted through it (features / latent / parameters require grad):
+    'packed' = the packed forward (e3dge_dec2_forward) wrapped in an autograd.Function whose backward recomputes the planar
+    library path (weight modulation + MIOpen) under enable_grad and differentiates that; 'library' = the library path for both
+    directions.  Forward-only cost 0.70 vs 1.0 ms at 1024^2; a full forward + backward is cheaper on the library path (no
+    recomputation) until the packed kernels get their own backward -- so 'library' is the default and E3DGE_DECODER_AUTOGRAD=packed
+    opts in (validation passes that run with grad enabled but never call backward)."""
+    v = os.environ.get("E3DGE_DECODER_AUTOGRAD", "library")
+    if v not in ("packed", "library"):
+        raise RuntimeError(f"E3DGE_DECODER_AUTOGRAD must be 'packed' or 'library', got {v!r}")
+    return v
+
+
+class _PackedDecoderFn(torch.autograd.Function):
+    """Decoder.forward as one native call (packed pipeline) that stays inside an autograd graph.  backward: the same forward is
+    re-run on the library path (every op differentiable) with the saved inputs and the SAME noise, and `torch.autograd.grad` of that
+    graph gives d features, d latent and the parameter gradients.  First-order only (reference: stylesdf_model.py:317-362, 741-797)."""
+
+    @staticmethod
+    def forward(ctx, dec, noise, features, latent, *params):
+        ctx.dec, ctx.noise, ctx.n_params = dec, noise, len(params)
+        ctx.save_for_backward(features, latent)
+        with torch.no_grad():
+            return dec._forward_packed(features, latent, noise)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_img):
+        features, latent = ctx.saved_tensors
+        dec = ctx.dec
+        need = ctx.needs_input_grad
+        params = [p for p in dec.parameters()]
+        with torch.enable_grad():
+            f_ = features.detach().requires_grad_(need[2])
+            l_ = latent.detach().requires_grad_(need[3])
+            img = dec._forward_layers(f_, l_, ctx.noise, None)
+            wrt = [t for t in (f_, l_) if t.requires_grad] + [p for p, n in zip(params, need[4:]) if n]
+            grads = list(torch.autograd.grad(img, wrt, d_img.contiguous(), allow_unused=True)) if wrt else []
+        out = [None, None]
+        out.append(grads.pop(0) if need[2] else None)
+        out.append(grads.pop(0) if need[3] else None)
+        for n in need[4:]:
+            out.append(grads.pop(0) if n else None)
+        return tuple(out)
+
+
 def modconv_backend():
     """'hip' (default): 3x3 modulated convolutions run on the fused implicit-GEMM kernel e3dge_modconv3x3.
     E3DGE_MODCONV=library keeps the previous path (e3dge_modconv_weights + MIOpen convolution through torch)."""
@@ -562,8 +608,8 @@ class Decoder(nn.Module):
             return False
         if len(self.to_rgbs) > _lib.DEC2_MAX_UP or features.shape[0] < 1:
             return False
-        if torch.is_grad_enabled() and (features.requires_grad or latent.requires_grad or
-                                        any(p.requires_grad for p in self.parameters())):
+        if self._needs_graph(features, latent) and (decoder_autograd_backend() != "packed" or
+                                                     any(n is not None and n.requires_grad for n in noise)):
             return False
         for m, _ in self._mod_layers():
             if m.kernel_size == 3 and (m.in_channel % 16 or m.out_channel % 32 or not m.demodulate or m.in_channel > 1024):
@@ -576,6 +622,10 @@ class Decoder(nn.Module):
         if B * max(self.channels.get(top, 16), 16) * (top + 4) * (top + 4) * 4 >= 2 ** 31:
             return False
         return all(n is None or (n.device == features.device and n.dtype == torch.float32) for n in noise)
+
+    def _needs_graph(self, features, latent):
+        return torch.is_grad_enabled() and (features.requires_grad or latent.requires_grad or
+                                            any(p.requires_grad for p in self.parameters()))
 
     def _noise_amax(self, nz):
         """amax buffer with max|noise| (the packed producers need it for their operand-scale bound).  Cached only for the
@@ -791,7 +841,22 @@ class Decoder(nn.Module):
         latent, noise = self.styles_and_noise_forward(styles, noise, inject_index, truncation, truncation_latent,
                                                       input_is_latent, randomize_noise)
         if self._dec2_ok(features, latent, noise, rgbd_in):
-            return self._forward_packed(features, latent, noise), (latent if return_latents else None)
+            if not self._needs_graph(features, latent):
+                return self._forward_packed(features, latent, noise), (latent if return_latents else None)
+            # a graph is wanted and E3DGE_DECODER_AUTOGRAD=packed: packed forward, library backward on recomputed activations.
+            # NoiseInjection's own noise is drawn HERE so that the backward's recomputation sees the same values.
+            r, nz = features.shape[2], []
+            for i, n in enumerate(noise):
+                if i >= 1 and i % 2 == 1:
+                    r *= 2
+                nz.append(n if n is not None else torch.empty((features.shape[0], 1, r, r), device=features.device, dtype=torch.float32).normal_())
+            img = _PackedDecoderFn.apply(self, nz, features, latent, *self.parameters())
+            return img, (latent if return_latents else None)
+        return self._forward_layers(features, latent, noise, rgbd_in), (latent if return_latents else None)
+
+    def _forward_layers(self, features, latent, noise, rgbd_in):
+        """The layer-by-layer forward (reference :764-792): fused planar kernels without a graph, weight modulation + library
+        convolutions (differentiable) with one."""
         # amax buffers (one row per activation): every fused layer leaves max|output| for the next one's operand scaling
         track = features.device.type == "cuda" and modconv_backend() == "hip" and not torch.is_grad_enabled()
         amax = torch.zeros((self.num_layers + 1, _lib.AMAX_FLOATS), device=features.device, dtype=torch.float32) if track else None
@@ -808,7 +873,7 @@ class Decoder(nn.Module):
             skip = to_rgb(out, latent[:, i + 2], skip=skip, pre=pre(j + 2))
             i += 2
             j += 3
-        return skip, (latent if return_latents else None)
+        return skip
 
 
 class Generator(nn.Module):

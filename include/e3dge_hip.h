@@ -501,6 +501,12 @@ int e3dge_tex_film_fwd(const float* packed, const float* feats, int cin, int bat
 int e3dge_local_query(float* out, int ld, int col_off, float* in_img, int mask_ld, int mask_off, float* proj,
                       const float* pts, const float* calibs, const float* fmap_nhwc, int batch, int64_t n_pts, int channels,
                       int fh, int fw, e3dge_stream_t stream);
+/* Backward of the gather (ABI 11; reference: project/models/op/grid_sample_gradfix.py:52-89 behind HGPIFuNetGAN.query's index()):
+ * d_fmap_nhwc (batch, fh, fw, channels), ZERO-FILLED by the caller, receives the bilinear scatter of d_out[..., col_off:col_off+C]
+ * (atomic adds); d_pts (batch, n_pts, 3) the gradient through the sampling position (projection included).  Either may be NULL. */
+int e3dge_local_query_bwd(float* d_fmap_nhwc, float* d_pts, const float* d_out, int ld, int col_off, const float* pts,
+                          const float* calibs, const float* fmap_nhwc, int batch, int64_t n_pts, int channels, int fh, int fw,
+                          e3dge_stream_t stream);
 int e3dge_pos_encoding(float* out, int ld, int col_off, const float* pts, int64_t n_pts, int n_freqs, e3dge_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -129,3 +129,72 @@ def test_second_pass_from_feature_maps():
              tex_effect=maxerr(ref['features'], c(p1['features'])))
     record("second_pass_from_feature_maps", **e)
     assert e['tex_effect'] > 1e-2 and e['features'] <= 1e-4 and e['rgb'] <= 5e-6, e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,h,w,N", [(8, 5, 7, 300), (256, 32, 32, 2000)])
+def test_gather_backward_against_float64_grid_sample(C, h, w, N):
+    """e3dge_local_query_bwd (the reference's grid_sample_gradfix backward, project/models/op/grid_sample_gradfix.py:52-89, behind
+    HGPIFuNetGAN.query, vendor/pifu/lib/model/HGPIFuGANNet.py:85-151): d feature map and d points against float64 autograd of
+    perspective + F.grid_sample(bilinear, zeros padding, align_corners=False) on the same inputs, incl. points that project
+    outside the map (zero padding on some corners) and far outside (no gradient at all).
+    Tolerance: 2e-5 of the gradient's maximum (fp32 atomics in arbitrary order; measured ~1e-6)."""
+    import torch.nn.functional as F
+    from e3dge_amd.local_query import query_feature_map
+    DEV = "cuda:0"
+    gen = torch.Generator("cpu").manual_seed(5)
+    B = 2
+    pts = (torch.rand(B, N, 3, generator=gen) - 0.5) * 0.5
+    pts[:, :N // 8] *= 6.0                                          # some project outside the image plane
+    calib = torch.tensor([[[2.2, 0.1, 0.0, 0.03], [0.05, 2.1, 0.1, -0.02], [0.0, 0.1, 1.0, 2.0]],
+                          [[1.9, -0.2, 0.1, 0.0], [0.1, 2.3, 0.0, 0.05], [0.1, 0.0, 1.0, 1.7]]])
+    fmap = torch.randn(B, C, h, w, generator=gen)
+    g_out = torch.randn(B, N, C, generator=gen)
+
+    def ref(p, fm):
+        homo = torch.einsum('bij,bnj->bni', calib.double()[:, :, :3], p) + calib.double()[:, None, :, 3]
+        hz0 = float(homo[0, 0, 2])
+        z = -homo[..., 2] if hz0 < 0 else homo[..., 2]
+        xy = homo[..., :2] / z[..., None]
+        uv = torch.stack([xy[..., 0], -xy[..., 1]], -1)
+        return F.grid_sample(fm, uv[:, :, None, :], mode='bilinear', padding_mode='zeros', align_corners=False)[..., 0].permute(0, 2, 1)
+    p64 = pts.double().requires_grad_(True)
+    f64 = fmap.double().requires_grad_(True)
+    out64 = ref(p64, f64)
+    (out64 * g_out.double()).sum().backward()
+    p32 = pts.to(DEV).requires_grad_(True)
+    f32 = fmap.to(DEV).requires_grad_(True)
+    out, mask, _ = query_feature_map(p32, calib.to(DEV), f32)
+    (out * g_out.to(DEV)).sum().backward()
+    e = dict(fwd=float((out.detach().cpu().double() - out64.detach()).abs().max()),
+             d_fmap=float((f32.grad.cpu().double() - f64.grad).abs().max() / f64.grad.abs().max()),
+             d_pts=float((p32.grad.cpu().double() - p64.grad).abs().max() / p64.grad.abs().max()))
+    from conftest import record
+    record("local_query_backward", C=C, h=h, w=w, N=N, **e)
+    assert e['fwd'] <= 2e-5 and e['d_fmap'] <= 2e-5 and e['d_pts'] <= 1e-4, e
+
+
+@pytest.mark.gpu
+def test_training_form_of_the_local_features_matches_the_inference_form():
+    """With a feature map that requires grad, local_features_from_maps assembles the same (B,H,W,S,301) features from
+    differentiable pieces (gathers with the HIP backward + Fuse_sft_MLP as torch modules): values equal the inference form
+    (native Fuse_sft_MLP) to 1e-4, and the gradient reaches both maps and the fuse block's parameters."""
+    from e3dge_amd.local_query import Fuse_sft_MLP, local_features_from_maps
+    DEV = "cuda:0"
+    torch.manual_seed(3)
+    B, H, S, C = 1, 8, 6, 256
+    fuse = Fuse_sft_MLP(C + 1, C).to(DEV)
+    for p_ in fuse.parameters():
+        torch.nn.init.normal_(p_, std=0.05)
+    maps = {'ref': torch.randn(B, C, 16, 16, device=DEV), 'que': torch.randn(B, C, 16, 16, device=DEV)}
+    calib = torch.tensor([[[2.0, 0.0, 0.0, 0.0], [0.0, 2.0, 0.0, 0.0], [0.0, 0.0, 1.0, 2.0]]], device=DEV)
+    batch = dict(feature_maps=maps, ref_calibs=calib, que_calibs=calib.clone(), points=(torch.rand(B, H, H, S, 3, device=DEV) - 0.5),
+                 xyz=(torch.rand(B, 3, H, H, device=DEV) - 0.5), fuse_sft_block=fuse)
+    with torch.no_grad():
+        want, _ = local_features_from_maps(batch)
+    maps['ref'].requires_grad_(True); maps['que'].requires_grad_(True)
+    got, _ = local_features_from_maps(batch)
+    assert got.requires_grad and float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+    got.square().mean().backward()
+    assert all(m.grad is not None and torch.isfinite(m.grad).all() and float(m.grad.abs().max()) > 0 for m in maps.values())
+    assert all(p_.grad is not None for p_ in fuse.parameters())
