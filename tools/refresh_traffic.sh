@@ -18,6 +18,15 @@ for mode in f16x3 f32; do
     echo "$mode $ctr rc=$?"
   done
 done
+# matrix-pipe occupancy and the achieved shader clock of the headline kernel: one more pass, SQ + GRBM counters only
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d "$OUT/f16x3_busy" -o pmc -- \
+  python $REPO/bench.py --steps 20 --warmup 3 --headline-only > "$OUT/f16x3_busy.log" 2>&1
+echo "f16x3 busy rc=$?"
+# HBM traffic of one stage-1 step (all its kernels), 23 steps per run of tools/c5_step.py
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$OUT/train_$ctr" -o pmc -- python $REPO/tools/c5_step.py 20 > "$OUT/train_$ctr.log" 2>&1
+  echo "train $ctr rc=$?"
+done
 cd "$REPO"
 python - "$OUT" "$GIT" <<'PY'
 import collections, csv, glob, json, os, sys
@@ -42,6 +51,36 @@ for mode in ("f16x3", "f32"):
             ent[ctr + "_launches"] = n
     if len(ent) >= 4:
         res[mode] = ent
+# headline kernel: SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1,024 SIMDs; GRBM_GUI_ACTIVE = shader cycles of the dispatch;
+# the kernel-trace of the same run gives its duration
+c = glob.glob(os.path.join(out, "f16x3_busy", "**", "*counter_collection.csv"), recursive=True)
+if c and "f16x3" in res:
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    dur = [0.0, 0]
+    for r in csv.DictReader(open(c[0])):
+        k = r.get("Kernel_Name", r.get("Kernel Name", ""))
+        if "siren16_kernel<0" in k:
+            a = agg[r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"]); a[1] += 1
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                dur[0] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"]); dur[1] += 1
+    m = {k: v[0] / max(v[1], 1) for k, v in agg.items()}
+    if m.get("GRBM_GUI_ACTIVE"):
+        e = res["f16x3"]
+        e["SQ_INSTS_MFMA"] = m.get("SQ_INSTS_MFMA")
+        e["mfma_busy_frac"] = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * m["GRBM_GUI_ACTIVE"])
+        if dur[1]:
+            e["shader_clock_ghz"] = m["GRBM_GUI_ACTIVE"] / (dur[0] / dur[1])
+            e["profiled_kernel_us"] = dur[0] / dur[1] / 1e3
+ent = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    c = glob.glob(os.path.join(out, f"train_{ctr}", "**", "*counter_collection.csv"), recursive=True)
+    if c:
+        tot = sum(float(r["Counter_Value"]) for r in csv.DictReader(open(c[0])) if r["Counter_Name"] == ctr)
+        ent[ctr + "_KB"] = tot / 23.0          # tools/c5_step.py 20: 3 warm-up + 20 timed steps
+if len(ent) == 2:
+    ent["note"] = "all kernels of tools/c5_step.py 20 (23 stage-1 steps 64x64x18), per step"
+    res["train_step"] = ent
 json.dump(res, open(os.path.join(out, "traffic_pmc.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
