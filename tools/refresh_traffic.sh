@@ -68,9 +68,10 @@ if c and "f16x3" in res:
     if m.get("GRBM_GUI_ACTIVE"):
         e = res["f16x3"]
         e["SQ_INSTS_MFMA"] = m.get("SQ_INSTS_MFMA")
-        e["mfma_busy_frac"] = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * m["GRBM_GUI_ACTIVE"])
+        cyc = m["GRBM_GUI_ACTIVE"] / 8.0          # the counter comes back summed over the 8 XCDs (decoder PMC: 1.19e6 for a 64.5 us dispatch)
+        e["mfma_busy_frac"] = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * cyc)
         if dur[1]:
-            e["shader_clock_ghz"] = m["GRBM_GUI_ACTIVE"] / (dur[0] / dur[1])
+            e["shader_clock_ghz"] = cyc / (dur[0] / dur[1])
             e["profiled_kernel_us"] = dur[0] / dur[1] / 1e3
 ent = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
