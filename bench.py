@@ -112,7 +112,7 @@ def finalize(result):
                "inversion_fwd_ms": r.get("inversion_fwd_ms"), "inversion_fwd_graph_ms": r.get("inversion_fwd_graph_ms"),
                "inversion_fwd_no_reuse_ms": r.get("inversion_fwd_no_reuse_ms"), "c3_images_per_s": g("c3", "images_per_s"),
                "c4_ms_per_pose": g("c4", "sequential", "ms_per_pose"), "train_step_ms": r.get("train_step_ms"),
-               "train_step_mfma_frac": g("train_step", "roofline", "frac"), "cpu_rays_per_s": g("cpu_baseline", "value")}
+               "train_step_mfma_frac": g("train_step", "roofline", "frac"), "train_step_f32_fallback_ms": r.get("train_step_f32_fallback_ms"), "cpu_rays_per_s": g("cpu_baseline", "value")}
     if isinstance(inv, dict) and isinstance(inv.get("kernels"), list):
         dec = sum(k[1] for k in inv["kernels"] if k[0].startswith("decoder:"))
         summary["decoder_ms_sum_of_launches"] = round(dec, 4)
@@ -811,6 +811,20 @@ def main():
             n_tr = 10
             ms = wall_ms(train_step, n_tr)
             assert torch.isfinite(gr).all()
+            # the fp32 fallback of the same step (what a checkpoint with |w| >= 256 takes): two of its kernels still spill (20 / 60 B
+            # of scratch, tools/scratch_report.sh) -- its cost goes on the line instead of being implied
+            try:
+                m0, b0 = r5.siren.mfma_mode, r5.siren.bwd_mode
+                r5.siren.mfma_mode = r5.siren.bwd_mode = "f32"
+                for _ in range(2):
+                    train_step()
+                ms_f32 = wall_ms(train_step, 5)
+                r5.siren.mfma_mode, r5.siren.bwd_mode = m0, b0
+                if isinstance(result.get("modes"), dict) and "f32" in result["modes"]:
+                    result["modes"]["f32"]["train_step_ms"] = ms_f32
+                result["train_step_f32_fallback_ms"] = ms_f32
+            except Exception as exc:
+                result["train_step_f32_fallback_ms"] = f"failed: {type(exc).__name__}: {exc}"[:120]
             result["train_step_ms"] = ms
             result["train_step_rays_per_sec"] = world * RES * RES / ms * 1e3
             result["train_step_note"] = ("C5 renderer part, 1 image 64x64x18 per GPU: forward saving arguments + eikonal term (sdf chain) + "

@@ -95,6 +95,15 @@ class WsLinear(ctypes.Structure):
         ("slope", _f32), ("w_fuse", _f32)]
 
 
+# include/e3dge_hip_experimental.h: present only in -DE3DGE_EXPERIMENTAL builds (tools/build_variant.sh)
+EXPERIMENTAL_SIGNATURES = {"e3dge_ws_chain": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp])}
+
+
+def has_experimental():
+    """Was the loaded library built with -DE3DGE_EXPERIMENTAL (modes f16x3_v1 / f16x3_g2, e3dge_ws_chain)?"""
+    return hasattr(load(), "e3dge_ws_chain")
+
+
 # name -> (restype, argtypes); every symbol include/e3dge_hip.h declares.
 SIGNATURES = {
     "e3dge_abi_version": (_i32, []),
@@ -149,7 +158,6 @@ SIGNATURES = {
     "e3dge_selftest_mfma16x16": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "e3dge_ws_image_bytes": (_i64, [_i32]),
     "e3dge_ws_pack": (_i32, [_vp, _vp, _i32, _vp]),
-    "e3dge_ws_chain": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "e3dge_ws_linear": (_i32, [ctypes.POINTER(WsLinear), _vp]),
     "e3dge_selftest_sin": (_i32, [_vp, _vp, _i32, _vp]),
     "e3dge_selftest_sin_poly": (_i32, [_vp, _vp, _i32, _vp]),
@@ -191,6 +199,10 @@ def load():
             fn = getattr(lib, name)     # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in EXPERIMENTAL_SIGNATURES.items():      # -DE3DGE_EXPERIMENTAL builds only
+            fn = getattr(lib, name, None)
+            if fn is not None:
+                fn.restype, fn.argtypes = res, args
         got = lib.e3dge_abi_version()
         if got != ABI_VERSION:
             raise RuntimeError(f"libe3dge_hip.so ABI {got} != expected {ABI_VERSION}; rebuild")

@@ -645,8 +645,9 @@ extern "C" int e3dge_modconv3x3(const E3dgeModconvArgs* r, e3dge_stream_t stream
     if (!r->upsample) {
         if (r->co % 64 != 0) return launch_modconv<false, 8, 2, 1, 1, E3DGE_MC_AH_D>(k, st, "modconv3x3<8x64,32co>");
         if (px <= 64 * 64) return launch_modconv<false, 4, 1, 2, 1, E3DGE_MC_AH_A>(k, st, "modconv3x3<4x32,64co>");
-        if (px <= 128 * 128) return launch_modconv<false, 4, 2, 2, 1, E3DGE_MC_AH_B>(k, st, "modconv3x3<4x64,64co>");
-        return launch_modconv<false, 8, 2, 1, 2, E3DGE_MC_AH_C>(k, st, "modconv3x3<8x64,64co>");
+        // (above 128^2 an 8 x 64 tile with two co-tiles per wave measured a few % faster in round 2, but its instantiation spills 60 B;
+        // this planar path is the fallback of the packed pipeline now, so the 4 x 64 shape serves every larger size: no scratch anywhere)
+        return launch_modconv<false, 4, 2, 2, 1, E3DGE_MC_AH_B>(k, st, "modconv3x3<4x64,64co>");
     }
     if (r->co % 64 == 0) return launch_modconv<true, 4, 1, 2, 1, E3DGE_MC_AH_TA>(k, st, "modconv3x3T<4x32,64co>");
     return launch_modconv<true, 8, 1, 1, 1, E3DGE_MC_AH_TD>(k, st, "modconv3x3T<8x32,32co>");

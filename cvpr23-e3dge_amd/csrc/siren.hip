@@ -962,9 +962,16 @@ static int launch_siren(const SirenK& k, int precision, int64_t grid, hipStream_
         fn<<<dim3((unsigned)grid), dim3(k16Threads), k16LdsBytes, st>>>(k);
         return E3DGE_OK;
     }
+#ifdef E3DGE_EXPERIMENTAL   // the first-generation split-f16 forward (4 waves x 32 points; 48-52 B of scratch): A/B builds only
     static const KernelFn fns[4] = {&siren_kernel<MODE, 0, false>, &siren_kernel<MODE, 0, true>,
                                     &siren_kernel<MODE, 1, false>, &siren_kernel<MODE, 1, true>};
     const KernelFn fn = fns[2 * (precision == E3DGE_PREC_F16X3_V1) + save];
+#else
+    static const KernelFn fns[2] = {&siren_kernel<MODE, 0, false>, &siren_kernel<MODE, 0, true>};
+    if (precision == E3DGE_PREC_F16X3_V1)
+        return fail(E3DGE_ERR_INVALID_ARG, "precision f16x3_v1 (first-generation split-f16 forward) is only in -DE3DGE_EXPERIMENTAL builds");
+    const KernelFn fn = fns[save];
+#endif
     // the attribute is per device; setting it on every launch is cheap and keeps multi-GPU processes correct
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e != hipSuccess)

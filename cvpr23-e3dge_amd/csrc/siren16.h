@@ -30,9 +30,6 @@ constexpr int k16ChunkFloats = 16 * kWidth;      // one tile x K = 256: 16 KiB
 constexpr int k16Chunks = kBigLayers * k16Tiles; // 128 chunks per 128-point sub-tile
 // One workgroup barrier per tile.  (Per two tiles with a fifth LDS buffer measured the same, 0.3140 vs 0.3145 ms: the wait at
 // the barrier is where the two waves of a SIMD queue for the matrix pipe, not a cost of the barrier -- removed)
-#ifndef E3DGE_16_SPLIT
-#define E3DGE_16_SPLIT 0     // 1 = hidden layers with the two waves of a SIMD in opposite phases (measured 5 % SLOWER)
-#endif
 #ifndef E3DGE_16_ABL
 #define E3DGE_16_ABL 0      // timing ablations (wrong results): 4 = no workgroup barrier in the weight pipe, 8 = no
                             // transmittance scan, 16 = no colour compositing scan, 32 = no ordered merge of the feature partials
@@ -462,82 +459,8 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
         // =====================================================================================
         // 3. layers 1..7: 112 tiles; the FiLM + sine epilogue of tile t-1 issues inside tile t's MFMA stream
         // =====================================================================================
-#if E3DGE_16_SPLIT
-        // Role split (MI355X_MICROARCH, "Two waves per SIMD"): the two waves of a SIMD take turns on the matrix pipe.  Per tile a
-        // wave runs a GEMM segment G (8 k-steps: 24 MFMAs + the fragment reads, nothing else) and an epilogue segment E (FiLM +
-        // sine + hi/lo split of the tile's four values, argument stores, first fragment pair of its next tile); waves 4-7 run
-        // half a tile behind waves 0-3, a workgroup barrier after every segment keeps one group in G while the other is in E:
-        //     half-step h of a layer:   waves 0-3: h even G(h/2), h odd E(h/2)      waves 4-7: h even E(h/2 - 1), h odd G(h/2)
-        // Weight chunks: after every even half-step (all of chunk t's readers of waves 0-3 done, waves 4-7 about to start it)
-        // everything in flight is waited for, which publishes chunk t+2 one tile after its issue, and chunk t+3 is issued into
-        // the buffer chunk t-1 left (its last readers, waves 4-7, finished it one barrier earlier).
-        {
-            const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
-            f32x4v acc = zero4(), accb = zero4();
-            auto gemm_seg = [&](int t) {                  // on entry the ring holds k-step 0 of chunk t (buffer t % 4)
-                const u32x4* __restrict__ wp = reinterpret_cast<const u32x4*>(pipe.wbuf + (t % k16NBuf) * k16ChunkFloats) + lane;
-                acc = zero4(); accb = zero4();
-#pragma unroll
-                for (int g = 0; g < k16Steps; ++g) {
-                    if (g + k16Ring - 1 < k16Steps) {
-                        ringH[(g + k16Ring - 1) % k16Ring] = wp[((g + k16Ring - 1) * 2 + 0) * 64];
-                        ringL[(g + k16Ring - 1) % k16Ring] = wp[((g + k16Ring - 1) * 2 + 1) * 64];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    const u32x4 wh = ringH[g % k16Ring], wl = ringL[g % k16Ring];
-                    f32x4v& x0 = (g & 1) ? accb : acc;
-                    f32x4v& x1 = (g & 1) ? acc : accb;
-                    x0 = mfma16x16(wh, inH[g], x0);
-                    x1 = mfma16x16(wl, inH[g], x1);
-                    x0 = mfma16x16(wh, inL[g], x0);
-                }
-            };
-            auto epi_seg = [&](int Le, int t) {           // epilogue of tile t of layer Le from acc / accb; then k-step 0 of the next chunk
-                const float* __restrict__ film_e = film + Le * 2 * kWidth;
-                const int o = 16 * t + 4 * q;
-                const f32x4v g4 = *reinterpret_cast<const f32x4v*>(film_e + o), b4 = *reinterpret_cast<const f32x4v*>(film_e + kWidth + o);
-                const u32x4* __restrict__ wn = reinterpret_cast<const u32x4*>(pipe.wbuf + ((t + 1) % k16NBuf) * k16ChunkFloats) + lane;
-#pragma unroll
-                for (int g = 0; g < k16Ring - 1; ++g) { ringH[g] = wn[(g * 2 + 0) * 64]; ringL[g] = wn[(g * 2 + 1) * 64]; }
-                const f32x4v pv = acc + accb;
-                f32x4v arg, v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { arg[r] = fmaf(g4[r], pv[r], b4[r]); v[r] = sin_f32(arg[r]); }
-                if (SAVE && sv) *reinterpret_cast<f32x4v*>(sv + Le * kWidth + o) = arg;
-                SPLIT2_TO(v[0], v[1], outH[t >> 1][2 * (t & 1)], outL[t >> 1][2 * (t & 1)]);
-                SPLIT2_TO(v[2], v[3], outH[t >> 1][2 * (t & 1) + 1], outL[t >> 1][2 * (t & 1) + 1]);
-                if (t == k16Tiles - 1) {
-#pragma unroll
-                    for (int g = 0; g < k16Steps; ++g) { inH[g] = outH[g]; inL[g] = outL[g]; }
-                }
-            };
-            static_assert(k16Steps % k16Ring == 0 && k16NBuf == 4 && k16Tiles % k16NBuf == 0, "role-split schedule");
-#pragma unroll 1
-            for (int L = 1; L < E3DGE_SIREN_DEPTH; ++L) {
-#pragma unroll
-                for (int h = 0; h < 2 * k16Tiles; ++h) {
-                    if (grp == 0) {
-                        if ((h & 1) == 0) gemm_seg(h >> 1);
-                        else epi_seg(L, h >> 1);
-                    } else {
-                        if (h & 1) gemm_seg(h >> 1);
-                        else if (h > 0) epi_seg(L, (h >> 1) - 1);
-                        else if (L > 1) epi_seg(L - 1, k16Tiles - 1);
-                    }
-                    if ((h & 1) == 0) {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __syncthreads();
-                        pipe.issue_chunk();
-                        pipe.advance();
-                    } else {
-                        __syncthreads();
-                    }
-                }
-            }
-            if (grp != 0) epi_seg(E3DGE_SIREN_DEPTH - 1, k16Tiles - 1);
-            __syncthreads();
-        }
-#else
+        // (A role split of the two waves of a SIMD -- GEMM segment / epilogue segment in opposite phases, two barriers per tile -- was
+        // built and measured 5 % slower; the code is in the history at da20f64.)
 #pragma unroll 1
         for (int L = 1; L < ((CACHE == 2) ? 0 : E3DGE_SIREN_DEPTH); ++L) {
             const float* __restrict__ film_l = film + L * 2 * kWidth;
@@ -599,7 +522,6 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
             for (int g = 0; g < k16Steps; ++g) { inH[g] = outH[g]; inL[g] = outL[g]; }
         }
 
-#endif
         if (CACHE != 0) {
             const int64_t rec = (((int64_t)blockIdx.x * a.bb_subs + sub) * 8 + wave) * k16SlabWords + lane;
             if (CACHE == 1) {

@@ -225,8 +225,11 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
 #define BT_NOW() 0ull
 #endif
 
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     for (int sub = 0; sub < n_sub; ++sub) {
         [[maybe_unused]] const unsigned long long tp0 = BT_NOW();
+        const int lane = lane_id_fresh(), half = lane >> 5, col = lane & 31;      // (per sub-tile: see lane_id_fresh)
+        const int wave = wave_s;
         const int p = sub * kTilePts + 32 * wave + col;
         const bool valid = p < npts;
         const int pc = valid ? p : (npts - 1);
@@ -690,7 +693,10 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
         }
     };
 
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     for (int sub = 0; sub < n_sub; ++sub) {
+        const int lane = lane_id_fresh(), half = lane >> 5, col = lane & 31;      // (per sub-tile: see lane_id_fresh)
+        const int wave = wave_s;
         const int p = sub * kTilePts + 32 * wave + col;
         const bool valid = p < npts;
         const int pc = valid ? p : (npts - 1);
@@ -1034,7 +1040,9 @@ film_bwd_kernel(float* __restrict__ dstyles, const float* __restrict__ dfilm, co
 
 }  // namespace e3dge
 
+#ifdef E3DGE_EXPERIMENTAL      // the 8-wave backward / chain kernels (mode f16x3_g2): slower than the default and 16-196 B of scratch -- A/B builds only
 #include "siren16_bwd.h"
+#endif
 
 using namespace e3dge;
 
@@ -1080,17 +1088,23 @@ static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfil
         &siren_bwd_kernel<true, false, false, true>, &siren_bwd_kernel<true, true, false, true>,
         &siren_bwd_kernel<false, false, true, false>, &siren_bwd_kernel<false, true, true, false>};
     E3DGE_REQUIRE(!(tex && k.d_pts), "siren_bwd: d_pts is not available on the tex-FiLM pass");
+    const int f16 = k.precision != E3DGE_PREC_F32;
+#ifdef E3DGE_EXPERIMENTAL
     // second generation (8 waves x 16 points): [dpts][eik], then the tex variant
     static const KernelFn fns16[5] = {
         &siren16_bwd_kernel<false, false, false>, &siren16_bwd_kernel<true, false, false>,
         &siren16_bwd_kernel<false, false, true>, &siren16_bwd_kernel<true, false, true>,
         &siren16_bwd_kernel<false, true, false>};
     const bool gen2 = k.precision == E3DGE_PREC_F16X3_G2;
-    const int f16 = k.precision != E3DGE_PREC_F32;
     const KernelFn fn = gen2 ? fns16[tex ? 4 : 2 * (k.d_pts != nullptr) + (k.tang != nullptr)]
                              : fns[tex ? 8 + f16 : 4 * (k.d_pts != nullptr) + 2 * (k.tang != nullptr) + f16];
-    k.precision = f16 ? E3DGE_PREC_F16X3 : E3DGE_PREC_F32;
     const int lds_bytes = gen2 ? kB16LdsBytes : kBwdLdsBytes;
+#else
+    E3DGE_REQUIRE(k.precision != E3DGE_PREC_F16X3_G2, "siren_bwd: precision f16x3_g2 is only in -DE3DGE_EXPERIMENTAL builds");
+    const KernelFn fn = fns[tex ? 8 + f16 : 4 * (k.d_pts != nullptr) + 2 * (k.tang != nullptr) + f16];
+    const int lds_bytes = kBwdLdsBytes;
+#endif
+    k.precision = f16 ? E3DGE_PREC_F16X3 : E3DGE_PREC_F32;
     {   // the attribute is per device (and cheap): set it on the launch's device every time
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(siren_bwd): %s", hipGetErrorString(e));
@@ -1099,7 +1113,11 @@ static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfil
     if (n_pts > 0) {
         const int64_t grid = (int64_t)k.wgs_per_img * batch;
         E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_bwd: grid too large");
+#ifdef E3DGE_EXPERIMENTAL
         fn<<<dim3((unsigned)grid), dim3(gen2 ? k16Threads : kThreads), lds_bytes, st>>>(k);
+#else
+        fn<<<dim3((unsigned)grid), dim3(kThreads), lds_bytes, st>>>(k);
+#endif
         int rc = check_launch("siren_bwd");
         if (rc) return rc;
     }
@@ -1169,12 +1187,20 @@ static int launch_chain(const float* packed, const float* film, const float* arg
     E3DGE_REQUIRE(packed && film && args && save && (TANGENT ? seed != nullptr : eik != nullptr), "%s: null pointer", what);
     E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(args) | reinterpret_cast<uintptr_t>(save)) & 15) == 0,
                   "%s: packed/args/save must be 16-B aligned", what);
+#ifdef E3DGE_EXPERIMENTAL
     const bool gen2 = precision == E3DGE_PREC_F16X3_G2;
+#else
+    constexpr bool gen2 = false;
+    E3DGE_REQUIRE(precision != E3DGE_PREC_F16X3_G2, "%s: precision f16x3_g2 is only in -DE3DGE_EXPERIMENTAL builds", what);
+#endif
     {   // per device, cheap: set on every launch
-        const void* fn = gen2 ? reinterpret_cast<const void*>(&siren16_chain_kernel<TANGENT>)
-                       : (precision != E3DGE_PREC_F32) ? reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, true>)
-                                                             : reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, false>);
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, gen2 ? kC16LdsBytes : kChLdsBytes);
+        const void* fn = (precision != E3DGE_PREC_F32) ? reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, true>)
+                                                       : reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, false>);
+        int lds_bytes = kChLdsBytes;
+#ifdef E3DGE_EXPERIMENTAL
+        if (gen2) { fn = reinterpret_cast<const void*>(&siren16_chain_kernel<TANGENT>); lds_bytes = kC16LdsBytes; }
+#endif
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
     }
     SirenChainK k{};
@@ -1183,8 +1209,10 @@ static int launch_chain(const float* packed, const float* film, const float* arg
     bwd_geometry(batch, n_pts, &k.subtiles_per_wg, &k.wgs_per_img);
     const int64_t grid = (int64_t)k.wgs_per_img * batch;
     E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "%s: grid too large", what);
-    if (gen2) siren16_chain_kernel<TANGENT><<<dim3((unsigned)grid), dim3(k16Threads), kC16LdsBytes, st>>>(k);
-    else if (precision != E3DGE_PREC_F32) siren_chain_kernel<TANGENT, true><<<dim3((unsigned)grid), dim3(kThreads), kChLdsBytes, st>>>(k);
+#ifdef E3DGE_EXPERIMENTAL
+    if (gen2) { siren16_chain_kernel<TANGENT><<<dim3((unsigned)grid), dim3(k16Threads), kC16LdsBytes, st>>>(k); return check_launch(what); }
+#endif
+    if (precision != E3DGE_PREC_F32) siren_chain_kernel<TANGENT, true><<<dim3((unsigned)grid), dim3(kThreads), kChLdsBytes, st>>>(k);
     else siren_chain_kernel<TANGENT, false><<<dim3((unsigned)grid), dim3(kThreads), kChLdsBytes, st>>>(k);
     return check_launch(what);
 }

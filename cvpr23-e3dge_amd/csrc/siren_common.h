@@ -284,6 +284,13 @@ __device__ __forceinline__ float sin_f32(float x) {
 __device__ __forceinline__ float sigmoid_f32(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
 
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, kWave); }
+// lane index of the wavefront, re-derived on the spot (two VALU ops, not hoistable): a kernel-lifetime copy of threadIdx.x costs
+// a register across the register-saturated tile loops -- where it is the value the allocator picks to spill
+__device__ __forceinline__ int lane_id_fresh() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 
 // K=256 contraction of one 32-feature output tile against the wave's register-resident activations.
 //   TRANSPOSED=false: D[feature][point]  (weights = A operand, activations = B operand)

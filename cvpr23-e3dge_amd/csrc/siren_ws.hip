@@ -185,6 +185,7 @@ __device__ __forceinline__ void ws_carry(WsCarry& C, const char* xm, const float
     }
 }
 
+#ifdef E3DGE_EXPERIMENTAL     // the chain study of DESIGN.md 4.1d (include/e3dge_hip_experimental.h); e3dge_ws_linear below is the product use
 // y = layer_{n-1}(... layer_0(x)), layer(x) = sin(gamma * (W x) + beta); film = [layer][gamma | beta][256] with the weights'
 // factor 128 already divided out of gamma.  One workgroup per CU, groups of 128 points.
 __global__ void __launch_bounds__(kWsThreads)
@@ -271,6 +272,7 @@ ws_chain_kernel(const u32x4* __restrict__ wimg, const float* __restrict__ film, 
         WS_SYNC();
     }
 }
+#endif  // E3DGE_EXPERIMENTAL
 
 }  // namespace e3dge
 
@@ -457,6 +459,7 @@ extern "C" int e3dge_ws_pack(void* wimg, const float* weights, int n_layers, e3d
     return check_launch("ws_pack");
 }
 
+#ifdef E3DGE_EXPERIMENTAL
 extern "C" int e3dge_ws_chain(const void* wimg, const float* film, const float* x0, float* y, int n_layers, int n_points, int grid,
                               long long* dbg, e3dge_stream_t stream) {
     using namespace e3dge;
@@ -470,6 +473,7 @@ extern "C" int e3dge_ws_chain(const void* wimg, const float* film, const float* 
                                                                              n_points / 128, dbg);
     return check_launch("ws_chain");
 }
+#endif
 
 static_assert(sizeof(E3dgeWsLinear) == sizeof(e3dge::WsLinK), "E3dgeWsLinear mirrors WsLinK");
 

@@ -543,18 +543,11 @@ int e3dge_selftest_mfma(float* c, const float* a, const float* b, int k, e3dge_s
 int e3dge_selftest_mfma16(float* c, const float* a, const float* b, int k, e3dge_stream_t stream);
 /* The same for v_mfma_f32_16x16x32_f16 (c: 16x16, a, b: (16, k) row-major, k multiple of 32). */
 int e3dge_selftest_mfma16x16(float* c, const float* a, const float* b, int k, e3dge_stream_t stream);
-/* Round-3 study kernel (not on a product path yet): a WEIGHT-STATIONARY split-f16 chain of n_layers (<= 8)
- * 256 x 256 layers  x <- sin(gamma * (W x) + beta)  over n_points (a multiple of 128) points -- the hidden-layer core of the
- * renderer with the operand roles swapped (weights in registers, activations in LDS).
+/* Weight-stationary split-f16 layers (csrc/siren_ws.hip): the weights of a 256 x 256 layer live in registers, activations in LDS.
  *   wimg   : e3dge_ws_image_bytes(n_layers) bytes, written by e3dge_ws_pack from fp32 weights (n_layers, 256, 256) [out][in]
- *   film   : (n_layers, 2, 256) fp32: gamma / 128 (the image carries the factor 128), beta
- *   x, y   : (n_points, 256) fp32
- *   grid   : workgroups (<= 0: 256, one per CU);  cycles: NULL or 512 int64 -- per workgroup shader cycles / 100-MHz ticks
- *            of layers 1.. of its first 128-point group (tools/ws_proto.py) */
+ * (The round-3 study chain e3dge_ws_chain -- DESIGN.md 4.1d -- is only in -DE3DGE_EXPERIMENTAL builds: include/e3dge_hip_experimental.h.) */
 int64_t e3dge_ws_image_bytes(int n_layers);
 int e3dge_ws_pack(void* wimg, const float* weights, int n_layers, e3dge_stream_t stream);
-int e3dge_ws_chain(const void* wimg, const float* film, const float* x, float* y, int n_layers, int n_points, int grid,
-                   long long* cycles, e3dge_stream_t stream);
 /* One 256 x 256 linear layer over the rows of a matrix, weight-stationary split-f16 (the layers of Fuse_sft_MLP,
  * project/models/helper_modules/sft.py:84-109 and resnetfc.py:49-58 -- local_query.py chains nine of these):
  *   y[row, off_y + f] = post( sum_k W[f][k] pre(x[row, off_x + k]) + bias[f] + colw[f] pre(m[row, off_m]) + r1[row, off_r1 + f] + r2[row, off_r2 + f] )

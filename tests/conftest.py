@@ -73,3 +73,16 @@ def maxerr(a, b):
     if a.numel() == 0:
         return 0.0
     return float((a - b).abs().max())
+
+
+def contraction_modes(*modes):
+    """Contraction modes to parametrize over: the experimental ones (first-generation split-f16 forward 'f16x3_v1', the 8-wave
+    backward kernels 'f16x3_g2') exist only in -DE3DGE_EXPERIMENTAL builds of the library (include/e3dge_hip_experimental.h) and
+    are dropped when the loaded library does not have them."""
+    import e3dge_amd  # noqa: F401
+    from e3dge_amd import _lib
+    try:
+        exp = _lib.has_experimental()
+    except Exception:
+        exp = False
+    return [m for m in modes if exp or m not in ("f16x3_v1", "f16x3_g2")]

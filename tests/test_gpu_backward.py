@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import full_state_dict, record
+from conftest import contraction_modes, full_state_dict, record
 from oracle import renderer_ref
 
 import e3dge_amd  # noqa: F401
@@ -39,7 +39,7 @@ def rel_err(a, truth):
     return float((a.detach().double().cpu() - truth).abs().max() / truth.abs().max())
 
 
-@pytest.mark.parametrize("mode", ["f16x3", "f32", "f16x3_g2"])
+@pytest.mark.parametrize("mode", contraction_modes("f16x3", "f32", "f16x3_g2"))
 @pytest.mark.parametrize("n_pts,batch", [(1, 1), (130, 2), (1000, 1), (4096, 2)])
 def test_points_backward_vs_oracle_autograd(sd, mode, n_pts, batch):
     r = make_renderer(sd, 8, 18, mfma_mode=mode)
@@ -231,7 +231,7 @@ def oracle_points_with_eikonal(sd, pts, styles, dtype):
     return raw, eik
 
 
-@pytest.mark.parametrize("mode", ["f16x3", "f32", "f16x3_g2"])
+@pytest.mark.parametrize("mode", contraction_modes("f16x3", "f32", "f16x3_g2"))
 @pytest.mark.parametrize("n_pts,batch", [(1, 1), (200, 2), (1500, 1)])
 def test_eikonal_term_value_and_double_backward(sd, mode, n_pts, batch):
     r = make_renderer(sd, 8, 18, mfma_mode=mode)
@@ -389,7 +389,7 @@ def test_c5_step_against_reference_golden_gradients(mode):
     assert e['surf_only_vs_f64'] <= REL_TOL and e['surf_only_if_xyz_were_detached'] > 0.1, e   # the xyz path is really there
 
 
-@pytest.mark.parametrize("mode", ["f16x3", "f32", "f16x3_g2"])
+@pytest.mark.parametrize("mode", contraction_modes("f16x3", "f32", "f16x3_g2"))
 def test_point_gradient_of_queries(sd, mode):
     """d(loss)/d(pts) of a point query (first-order through sdf / raw, and the Hessian-vector product through the eikonal
     term) against float64 autograd of the oracle."""
@@ -427,7 +427,7 @@ def test_point_gradient_of_queries(sd, mode):
     assert x.grad is not None and torch.isfinite(x.grad).all()
 
 
-@pytest.mark.parametrize("mode", ["f16x3", "f32", "f16x3_g2"])
+@pytest.mark.parametrize("mode", contraction_modes("f16x3", "f32", "f16x3_g2"))
 def test_tex_pass_backward_vs_oracle_autograd(sd, mode):
     """Second (texture-FiLM) pass under grad: gradients w.r.t. the styles and the per-point (alpha, beta) against float64
     autograd of the oracle (stage-2 training differentiates this pass, e3dge_full_runner.py:185-317)."""

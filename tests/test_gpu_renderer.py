@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import full_state_dict, load_golden, maxerr, record
+from conftest import contraction_modes, full_state_dict, load_golden, maxerr, record
 from oracle import renderer_ref
 
 import e3dge_amd  # noqa: F401
@@ -34,7 +34,7 @@ def sd():
     return full_state_dict()[1]
 
 
-MODES = ["f16x3", "f32", "f16x3_v1"]     # every contraction kernel must meet the same bounds
+MODES = contraction_modes("f16x3", "f32", "f16x3_v1")     # every contraction kernel must meet the same bounds
 
 
 def make_renderer(sd, res, S, mfma_mode=None, **over):
