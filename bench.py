@@ -66,7 +66,7 @@ SHORT_NOTES = {      # the prose lives in DESIGN.md section 5 ("fields of the be
     "local_features/note": "que_render_given_ref's per-point features: 3 gathers + Fuse_sft_MLP (9 launches) + positional encoding",
     "inversion_fwd_note": "pass #1 + texture head/FiLM + pass #2 on the layer-7 record + decoder 64^2->1024^2; encoder / image filters excluded",
     "inversion/note": "HIP-event ms per launch group (median of 10); frac = max(flops / (f16 peak / 3), bytes / 8 TB/s) / measured time",
-    "c4/note": "configs[3]: 120 poses of one latent, 128x128 rays x 48 samples, sequential and in batches of 8",
+    "c4/note": "configs[3]: 120 poses of one latent, 128x128 rays x 48 samples, one launch per pose, pose k -> rank k mod W",
     "surface/note": "surf_extraction generator: 128x128 rays x 128 samples + align_volume onto the 128^3 grid",
     "train_step_note": "C5 renderer part, 64x64x18 per GPU: forward + eikonal + surface normals, backward to the styles incl. double backward",
     "train_step/roofline/note": "bound = the 30 GEMM chains of the step on f16 MFMA / 3; saved-state bytes are a design cost, not algorithmic",
@@ -725,7 +725,9 @@ def main():
             c4 = {}
             spin(args.prewarm_ms / 2)
             with torch.no_grad():
-                for label, bsz in (("sequential", 1), ("batched8", 8)):
+                # (a batch-of-8 leg used to run beside this: 2.340 vs 2.293 ms per pose in round 3 -- one 128x128x48 pose is 6,144
+                # sub-tiles, 24 per CU, so batching poses buys nothing; dropped, SURVEY's "B = 8" variant is covered by the parity tests)
+                for label, bsz in (("sequential", 1),):
                     sweep(bsz)
                     barrier()
                     t0 = time.perf_counter()
