@@ -27,6 +27,9 @@ constexpr int kPkSlab = 9 * 2 * 1024;            // bytes of one weight slab: (3
 #ifndef E3DGE_PK_OVL
 #define E3DGE_PK_OVL 0
 #endif
+#ifndef E3DGE_PK_S1_PM
+#define E3DGE_PK_S1_PM 1         // stride-1 conv: product-major MFMA order (0 = three dependent MFMAs per accumulator in a row)
+#endif
 #ifndef E3DGE_PK_EPI_VALU
 #define E3DGE_PK_EPI_VALU 8      // VALU instructions of a finished tile's epilogue scheduled behind each MFMA of the next tile
 #endif
@@ -466,6 +469,20 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
                         bh[py * NPX + px] = *reinterpret_cast<const u32x4*>(xb + pix * 16);
                         bl[py * NPX + px] = *reinterpret_cast<const u32x4*>(xb + XPLANE + pix * 16);
                     }
+#if E3DGE_PK_S1_PM        // product-major: consecutive MFMAs go to different accumulators (cf. pkconv_upblur2_kernel)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt) acc[ct][pt] = mfma16(ah[ct], bh[pt], acc[ct][pt]);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt) acc[ct][pt] = mfma16(al[ct], bh[pt], acc[ct][pt]);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < NPT; ++pt) acc[ct][pt] = mfma16(ah[ct], bl[pt], acc[ct][pt]);
+#else
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -475,6 +492,7 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
                         d = mfma16(al[ct], bh[pt], d);
                         d = mfma16(ah[ct], bl[pt], d);
                     }
+#endif
                 if (EPI) {                               // this tap's slices of the finished tile, threaded between its MFMAs
 #pragma unroll
                     for (int h = 0; h < NH; ++h)
