@@ -110,6 +110,8 @@ SIGNATURES = {
     "e3dge_last_error": (ctypes.c_char_p, []),
     "e3dge_stream_capture_id": (_i64, [_vp]),
     "e3dge_fused_bias_act": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _i64, _i64, _i64, _vp]),
+    "e3dge_fused_bias_act_f16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _i64, _i64, _i64, _vp]),
+    "e3dge_upfirdn2d_f16": (_i32, [_vp, _vp, _vp, _i64] + [_i32] * 12 + [_vp]),
     "e3dge_noise_bias_act": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i64, _i64, _i64, _vp]),
     "e3dge_upfirdn2d": (_i32, [_vp, _vp, _vp, _i64] + [_i32] * 12 + [_vp]),
     "e3dge_upfirdn2d_out_size": (_i32, [_i32] * 6),
@@ -227,10 +229,11 @@ def stream_of(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def require_gpu(t, name):
+def require_gpu(t, name, half_ok=False):
+    """`half_ok`: the two stream ops (fused_bias_act, upfirdn2d) also take float16, as the reference's do."""
     import torch
     if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
         raise RuntimeError(f"{name} must be a GPU (HIP) tensor; this build has no CPU path "
                            f"(got {getattr(t, 'device', type(t))})")
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
+    if t.dtype != torch.float32 and not (half_ok and t.dtype == torch.float16):
+        raise RuntimeError(f"{name} must be float32{' or float16' if half_ok else ''} (got {t.dtype})")

@@ -36,6 +36,48 @@ constexpr int kActThreads = 256;
 constexpr int kActVecPerThread = 4;                                  // float4s per thread
 constexpr int kActChunk = kActThreads * kActVecPerThread * 4;        // floats per workgroup
 
+// Storage type T: float, or _Float16 for e3dge_fused_bias_act_f16 (the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+// fused_bias_act_kernel.cu:79).  Arithmetic is fp32 either way; a half tensor is widened on load and rounded once (RNE) on store.
+// One 16-byte vector = 4 floats or 8 halves; the row kernel below keeps its float4 form for T = float and has a twin for halves.
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+
+template <int MODE, bool HAS_BIAS, bool HAS_REF>
+__global__ void __launch_bounds__(kActThreads)
+bias_act_rows_f16_kernel(_Float16* __restrict__ y, const _Float16* __restrict__ x, const _Float16* __restrict__ bias,
+                         const _Float16* __restrict__ ref, float alpha, float scale, int step_b, int size_b, int chunks_per_row) {
+    const int row = blockIdx.x / chunks_per_row;
+    const int chunk = blockIdx.x - row * chunks_per_row;
+    const float b = HAS_BIAS ? (float)bias[row % size_b] : 0.0f;
+    const int64_t base = (int64_t)row * step_b;
+    const int nvec = step_b >> 3;
+    const half8v* x8 = reinterpret_cast<const half8v*>(x + base);
+    const half8v* r8 = HAS_REF ? reinterpret_cast<const half8v*>(ref + base) : nullptr;
+    half8v* y8 = reinterpret_cast<half8v*>(y + base);
+    const int v0 = chunk * (kActThreads * kActVecPerThread) + threadIdx.x;
+    half8v xv[kActVecPerThread], rv[kActVecPerThread];
+#pragma unroll
+    for (int j = 0; j < kActVecPerThread; ++j) {
+        const int v = v0 + j * kActThreads;
+        if (v < nvec) {
+            xv[j] = x8[v];
+            if (HAS_REF) rv[j] = r8[v];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kActVecPerThread; ++j) {
+        const int v = v0 + j * kActThreads;
+        if (v < nvec) {
+            half8v o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xe = (float)xv[j][e];
+                o[e] = (_Float16)act_one<MODE>(HAS_BIAS ? xe + b : xe, HAS_REF ? (float)rv[j][e] : 0.0f, alpha, scale);
+            }
+            y8[v] = o;
+        }
+    }
+}
+
 // Row kernel: x viewed as (rows, step_b) with one bias value per row; step_b % 4 == 0.
 template <int MODE, bool HAS_BIAS, bool HAS_REF>
 __global__ void __launch_bounds__(kActThreads)
@@ -75,54 +117,61 @@ bias_act_rows_kernel(float* __restrict__ y, const float* __restrict__ x,
 }
 
 // Generic element kernel (any step_b, e.g. the (B, C) outputs of MappingLinear / EqualLinear).
-template <int MODE, bool HAS_BIAS, bool HAS_REF>
+template <int MODE, bool HAS_BIAS, bool HAS_REF, typename T>
 __global__ void __launch_bounds__(kActThreads)
-bias_act_elem_kernel(float* __restrict__ y, const float* __restrict__ x,
-                     const float* __restrict__ bias, const float* __restrict__ ref, float alpha,
+bias_act_elem_kernel(T* __restrict__ y, const T* __restrict__ x,
+                     const T* __restrict__ bias, const T* __restrict__ ref, float alpha,
                      float scale, int n, int step_b, int size_b) {
     for (int i = blockIdx.x * kActThreads + threadIdx.x; i < n; i += gridDim.x * kActThreads) {
-        float v = x[i];
-        if (HAS_BIAS) v += bias[(i / step_b) % size_b];
-        y[i] = act_one<MODE>(v, HAS_REF ? ref[i] : 0.0f, alpha, scale);
+        float v = (float)x[i];
+        if (HAS_BIAS) v += (float)bias[(i / step_b) % size_b];
+        y[i] = (T)act_one<MODE>(v, HAS_REF ? (float)ref[i] : 0.0f, alpha, scale);
     }
 }
 
-template <int MODE, bool HAS_BIAS, bool HAS_REF>
-static int launch_bias_act(float* y, const float* x, const float* bias, const float* ref,
+template <int MODE, bool HAS_BIAS, bool HAS_REF, typename T>
+static int launch_bias_act(T* y, const T* x, const T* bias, const T* ref,
                            float alpha, float scale, int64_t n, int64_t step_b, int64_t size_b,
                            hipStream_t st) {
+    constexpr int EPV = 16 / (int)sizeof(T);                 // elements per 16-byte vector
     const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
                            (HAS_REF ? reinterpret_cast<uintptr_t>(ref) : 0)) & 15) == 0;
     // Without a bias the whole tensor is one "row"; keep rows < 2^31 elements.
     int64_t row_len = HAS_BIAS ? step_b : n;
-    if (aligned && row_len >= 4 && (row_len % 4) == 0 && (n % row_len) == 0) {
+    if (aligned && row_len >= EPV && (row_len % EPV) == 0 && (n % row_len) == 0) {
         const int64_t rows = n / row_len;
-        const int64_t cpr = (row_len + kActChunk - 1) / kActChunk;
+        const int64_t chunk = (int64_t)kActThreads * kActVecPerThread * EPV;
+        const int64_t cpr = (row_len + chunk - 1) / chunk;
         const int64_t blocks = rows * cpr;
         if (blocks < (int64_t)1 << 31) {
-            bias_act_rows_kernel<MODE, HAS_BIAS, HAS_REF>
-                <<<dim3((unsigned)blocks), dim3(kActThreads), 0, st>>>(
-                    y, x, bias, ref, alpha, scale, (int)row_len, HAS_BIAS ? (int)size_b : 1, (int)cpr);
+            if constexpr (sizeof(T) == 4)
+                bias_act_rows_kernel<MODE, HAS_BIAS, HAS_REF>
+                    <<<dim3((unsigned)blocks), dim3(kActThreads), 0, st>>>(
+                        y, x, bias, ref, alpha, scale, (int)row_len, HAS_BIAS ? (int)size_b : 1, (int)cpr);
+            else
+                bias_act_rows_f16_kernel<MODE, HAS_BIAS, HAS_REF>
+                    <<<dim3((unsigned)blocks), dim3(kActThreads), 0, st>>>(
+                        y, x, bias, ref, alpha, scale, (int)row_len, HAS_BIAS ? (int)size_b : 1, (int)cpr);
             return check_launch("fused_bias_act(rows)");
         }
     }
     int64_t blocks = (n + kActThreads - 1) / kActThreads;
     if (blocks > 8192) blocks = 8192;
-    bias_act_elem_kernel<MODE, HAS_BIAS, HAS_REF><<<dim3((unsigned)blocks), dim3(kActThreads), 0, st>>>(
+    bias_act_elem_kernel<MODE, HAS_BIAS, HAS_REF, T><<<dim3((unsigned)blocks), dim3(kActThreads), 0, st>>>(
         y, x, bias, ref, alpha, scale, (int)n, HAS_BIAS ? (int)step_b : 1, HAS_BIAS ? (int)size_b : 1);
     return check_launch("fused_bias_act(elem)");
 }
 
-template <int MODE>
-static int dispatch_bias_act(float* y, const float* x, const float* bias, const float* ref,
+template <int MODE, typename T>
+static int dispatch_bias_act(T* y, const T* x, const T* bias, const T* ref,
                              float alpha, float scale, int64_t n, int64_t step_b, int64_t size_b,
                              hipStream_t st) {
     const bool hb = bias != nullptr && size_b > 0;
     const bool hr = (MODE == kLreluGrad) && ref != nullptr;
-    if (hb && hr) return launch_bias_act<MODE, true, true>(y, x, bias, ref, alpha, scale, n, step_b, size_b, st);
-    if (hb) return launch_bias_act<MODE, true, false>(y, x, bias, ref, alpha, scale, n, step_b, size_b, st);
-    if (hr) return launch_bias_act<MODE, false, true>(y, x, bias, ref, alpha, scale, n, step_b, size_b, st);
-    return launch_bias_act<MODE, false, false>(y, x, bias, ref, alpha, scale, n, step_b, size_b, st);
+    if (hb && hr) return launch_bias_act<MODE, true, true, T>(y, x, bias, ref, alpha, scale, n, step_b, size_b, st);
+    if (hb) return launch_bias_act<MODE, true, false, T>(y, x, bias, ref, alpha, scale, n, step_b, size_b, st);
+    if (hr) return launch_bias_act<MODE, false, true, T>(y, x, bias, ref, alpha, scale, n, step_b, size_b, st);
+    return launch_bias_act<MODE, false, false, T>(y, x, bias, ref, alpha, scale, n, step_b, size_b, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -237,9 +286,9 @@ extern "C" int64_t e3dge_stream_capture_id(e3dge_stream_t stream) {
     return st == hipStreamCaptureStatusActive ? (int64_t)id + 1 : 0;
 }
 
-extern "C" int e3dge_fused_bias_act(float* y, const float* x, const float* bias, const float* ref,
-                                    int act, int grad, float alpha, float scale, int64_t n,
-                                    int64_t step_b, int64_t size_b, e3dge_stream_t stream) {
+template <typename T>
+static int fused_bias_act_any(T* y, const T* x, const T* bias, const T* ref, int act, int grad, float alpha, float scale, int64_t n,
+                              int64_t step_b, int64_t size_b, e3dge_stream_t stream) {
     E3DGE_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "fused_bias_act: n=%lld outside int32 range", (long long)n);
     if (n == 0) return E3DGE_OK;
     E3DGE_REQUIRE(x && y, "fused_bias_act: null x/y");
@@ -250,14 +299,27 @@ extern "C" int e3dge_fused_bias_act(float* y, const float* x, const float* bias,
     const int code = act * 10 + grad;
     switch (code) {
         case 12: case 32:
-            return dispatch_bias_act<kZero>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
+            return dispatch_bias_act<kZero, T>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
         case 30:
-            return dispatch_bias_act<kLrelu>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
+            return dispatch_bias_act<kLrelu, T>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
         case 31:
-            return dispatch_bias_act<kLreluGrad>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
+            return dispatch_bias_act<kLreluGrad, T>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
         default:
-            return dispatch_bias_act<kLinear>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
+            return dispatch_bias_act<kLinear, T>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
     }
+}
+
+extern "C" int e3dge_fused_bias_act(float* y, const float* x, const float* bias, const float* ref,
+                                    int act, int grad, float alpha, float scale, int64_t n,
+                                    int64_t step_b, int64_t size_b, e3dge_stream_t stream) {
+    return fused_bias_act_any<float>(y, x, bias, ref, act, grad, alpha, scale, n, step_b, size_b, stream);
+}
+
+extern "C" int e3dge_fused_bias_act_f16(void* y, const void* x, const void* bias, const void* ref,
+                                        int act, int grad, float alpha, float scale, int64_t n,
+                                        int64_t step_b, int64_t size_b, e3dge_stream_t stream) {
+    return fused_bias_act_any<_Float16>(static_cast<_Float16*>(y), static_cast<const _Float16*>(x), static_cast<const _Float16*>(bias),
+                                        static_cast<const _Float16*>(ref), act, grad, alpha, scale, n, step_b, size_b, stream);
 }
 
 extern "C" int e3dge_noise_bias_act(float* y, const float* x, const float* noise,

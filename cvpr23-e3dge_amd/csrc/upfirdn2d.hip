@@ -24,6 +24,24 @@ struct UpfirdnGeom {
     int kh, kw;
 };
 
+// Storage type T of x / y: float, or _Float16 for the half entry points (the reference dispatches
+// AT_DISPATCH_FLOATING_TYPES_AND_HALF, upfirdn2d_kernel.cu:311).  Arithmetic is fp32 either way: a half tensor is widened on
+// load and rounded ONCE (RNE) on store -- at least as accurate as the reference's scalar_t = half accumulation.
+template <typename T> __device__ __forceinline__ void store4(T* dst, const float (&v)[4], bool vec, int n_ok) {
+    if (vec && n_ok >= 4) {
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<h4*>(dst) = h4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < n_ok) dst[j] = (T)v[j];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Tiled kernel: square up factor UP, square decimation DN, KHxKW taps; tile 32 x 64 outputs.
 // ---------------------------------------------------------------------------------------------
@@ -41,9 +59,9 @@ struct UpfirdnEpi {
     int channels, noise_batch;
 };
 
-template <int UP, int DN, int KH, int KW, bool EPI = false>
+template <int UP, int DN, int KH, int KW, bool EPI = false, typename T = float>
 __global__ void __launch_bounds__(kUpThreads)
-upfirdn2d_tiled_kernel(float* __restrict__ y, const float* __restrict__ x,
+upfirdn2d_tiled_kernel(T* __restrict__ y, const T* __restrict__ x,
                        const float* __restrict__ k, UpfirdnGeom g, int tiles_x, int tiles_y, UpfirdnEpi ep = UpfirdnEpi{}) {
     constexpr int UH = (kTileH - 1) * DN + KH;           // rows of U needed by the tile
     constexpr int UW = (kTileW - 1) * DN + KW;
@@ -55,7 +73,7 @@ upfirdn2d_tiled_kernel(float* __restrict__ y, const float* __restrict__ x,
     const int ty_i = bid % tiles_y; bid /= tiles_y;
     const int64_t plane = bid;
     const int oy0 = ty_i * kTileH, ox0 = tx_i * kTileW;
-    const float* xp = x + plane * (int64_t)g.in_h * g.in_w;
+    const T* xp = x + plane * (int64_t)g.in_h * g.in_w;
 
     // ---- stage U (zero-inserted, padded) ----
     const int gy0 = oy0 * DN - g.pad_y0, gx0 = ox0 * DN - g.pad_x0;   // U-tile origin in up-sampled coords
@@ -77,7 +95,7 @@ upfirdn2d_tiled_kernel(float* __restrict__ y, const float* __restrict__ x,
                     iy = sy / UP; ix = sx / UP;
                     ok = (iy * UP == sy) && (ix * UP == sx);
                 }
-                if (ok && iy < g.in_h && ix < g.in_w) v = xp[(int64_t)iy * g.in_w + ix];
+                if (ok && iy < g.in_h && ix < g.in_w) v = (float)xp[(int64_t)iy * g.in_w + ix];
             }
         }
         sv[it] = v;
@@ -97,8 +115,8 @@ upfirdn2d_tiled_kernel(float* __restrict__ y, const float* __restrict__ x,
 
     // ---- compute: lane -> 4 adjacent outputs in x, rows ty and ty+16 ----
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    float* yp = y + plane * (int64_t)g.out_h * g.out_w;
-    const bool vec_ok = (g.out_w & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+    T* yp = y + plane * (int64_t)g.out_h * g.out_w;
+    const bool vec_ok = (g.out_w & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) & (4 * sizeof(T) - 1)) == 0);
     float amax_l = 0.0f;
     [[maybe_unused]] const float e_nw = (EPI && ep.noise) ? ep.noise_w[0] : 0.0f;
     [[maybe_unused]] const float e_b = (EPI && ep.bias) ? ep.bias[(int)(plane % ep.channels)] : 0.0f;
@@ -128,7 +146,7 @@ upfirdn2d_tiled_kernel(float* __restrict__ y, const float* __restrict__ x,
         }
         if (oy < g.out_h) {
             const int ox = ox0 + tx * 4;
-            float* dst = yp + (int64_t)oy * g.out_w + ox;
+            T* dst = yp + (int64_t)oy * g.out_w + ox;
             if (EPI) {
                 float nzv[4] = {0.f, 0.f, 0.f, 0.f};
                 if (e_nz) {
@@ -153,13 +171,7 @@ upfirdn2d_tiled_kernel(float* __restrict__ y, const float* __restrict__ x,
                     }
                 }
             }
-            if (vec_ok && ox + 3 < g.out_w) {
-                *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (ox + j < g.out_w) dst[j] = acc[j];
-            }
+            store4<T>(dst, acc, vec_ok, g.out_w - ox);
         }
     }
     if (EPI && ep.out_amax) {                           // one atomic per block, spread over the buffer's slots
@@ -186,9 +198,9 @@ upfirdn2d_tiled_kernel(float* __restrict__ y, const float* __restrict__ x,
 // ---------------------------------------------------------------------------------------------
 constexpr int kBlTile = 64, kBlU = kBlTile + 3, kBlPitch = 68, kBlGroups = kBlPitch / 4;   // 67 rows x 17 groups of 4
 
-template <bool EPI>
+template <bool EPI, typename T = float>
 __global__ void __launch_bounds__(kUpThreads)
-blur44_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ k, UpfirdnGeom g, int tiles_x,
+blur44_kernel(T* __restrict__ y, const T* __restrict__ x, const float* __restrict__ k, UpfirdnGeom g, int tiles_x,
               int tiles_y, UpfirdnEpi ep) {
     __shared__ __attribute__((aligned(16))) float u[kBlU * kBlPitch];
     int bid = blockIdx.x;
@@ -196,7 +208,7 @@ blur44_kernel(float* __restrict__ y, const float* __restrict__ x, const float* _
     const int ty_i = bid % tiles_y; bid /= tiles_y;
     const int64_t plane = bid;
     const int oy0 = ty_i * kBlTile, ox0 = tx_i * kBlTile;
-    const float* __restrict__ xp = x + plane * (int64_t)g.in_h * g.in_w;
+    const T* __restrict__ xp = x + plane * (int64_t)g.in_h * g.in_w;
     const int gy0 = oy0 - g.pad_y0, gx0 = ox0 - g.pad_x0;
 
     // ---- stage the patch: all loads of a thread first (in flight together), then the LDS stores ----
@@ -209,10 +221,10 @@ blur44_kernel(float* __restrict__ y, const float* __restrict__ x, const float* _
         const int sy = gy0 + r, sx = gx0 + 4 * cg;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (gi < NG && sy >= 0 && sy < g.in_h) {
-            const float* __restrict__ row = xp + (int64_t)sy * g.in_w;
+            const T* __restrict__ row = xp + (int64_t)sy * g.in_w;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (sx + j >= 0 && sx + j < g.in_w) v[j] = row[sx + j];
+                if (sx + j >= 0 && sx + j < g.in_w) v[j] = (float)row[sx + j];
         }
         sv[it] = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -251,8 +263,8 @@ blur44_kernel(float* __restrict__ y, const float* __restrict__ x, const float* _
             }
         }
     }
-    float* __restrict__ yp = y + plane * (int64_t)g.out_h * g.out_w;
-    const bool vec_ok = (g.out_w & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+    T* __restrict__ yp = y + plane * (int64_t)g.out_h * g.out_w;
+    const bool vec_ok = (g.out_w & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) & (4 * sizeof(T) - 1)) == 0);
     float amax_l = 0.0f;
     [[maybe_unused]] const float e_nw = (EPI && ep.noise) ? ep.noise_w[0] : 0.0f;
     [[maybe_unused]] const float e_b = (EPI && ep.bias) ? ep.bias[(int)(plane % ep.channels)] : 0.0f;
@@ -262,7 +274,7 @@ blur44_kernel(float* __restrict__ y, const float* __restrict__ x, const float* _
     for (int rr = 0; rr < 4; ++rr) {
         const int oy = oy0 + 4 * ty + rr;
         if (oy >= g.out_h) continue;
-        float* dst = yp + (int64_t)oy * g.out_w + ox;
+        T* dst = yp + (int64_t)oy * g.out_w + ox;
         if (EPI) {
             float nzv[4] = {0.f, 0.f, 0.f, 0.f};
             if (e_nz) {
@@ -287,13 +299,7 @@ blur44_kernel(float* __restrict__ y, const float* __restrict__ x, const float* _
                 }
             }
         }
-        if (vec_ok && ox + 3 < g.out_w) {
-            *reinterpret_cast<float4*>(dst) = make_float4(acc[rr][0], acc[rr][1], acc[rr][2], acc[rr][3]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (ox + j < g.out_w) dst[j] = acc[rr][j];
-        }
+        store4<T>(dst, acc[rr], vec_ok, g.out_w - ox);
     }
     if (EPI && ep.out_amax) {                           // one atomic per block, spread over the buffer's slots
         __shared__ float part[kUpThreads / 64];
@@ -307,21 +313,22 @@ blur44_kernel(float* __restrict__ y, const float* __restrict__ x, const float* _
     }
 }
 
-template <bool EPI>
-static int launch_blur44(float* y, const float* x, const float* k, const UpfirdnGeom& g, int64_t planes, const UpfirdnEpi& ep,
+template <bool EPI, typename T = float>
+static int launch_blur44(T* y, const T* x, const float* k, const UpfirdnGeom& g, int64_t planes, const UpfirdnEpi& ep,
                          hipStream_t st, const char* what) {
     const int tiles_x = (g.out_w + kBlTile - 1) / kBlTile, tiles_y = (g.out_h + kBlTile - 1) / kBlTile;
     const int64_t blocks = (int64_t)tiles_x * tiles_y * planes;
     if (blocks >= ((int64_t)1 << 31)) return fail(E3DGE_ERR_INVALID_ARG, "%s: grid too large", what);
-    blur44_kernel<EPI><<<dim3((unsigned)blocks), dim3(kUpThreads), 0, st>>>(y, x, k, g, tiles_x, tiles_y, ep);
+    blur44_kernel<EPI, T><<<dim3((unsigned)blocks), dim3(kUpThreads), 0, st>>>(y, x, k, g, tiles_x, tiles_y, ep);
     return check_launch(what);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Generic kernel: one output per thread, direct gather (any up/down/pad/kernel <= 32x32).
 // ---------------------------------------------------------------------------------------------
+template <typename T>
 __global__ void __launch_bounds__(kUpThreads)
-upfirdn2d_generic_kernel(float* __restrict__ y, const float* __restrict__ x,
+upfirdn2d_generic_kernel(T* __restrict__ y, const T* __restrict__ x,
                          const float* __restrict__ k, UpfirdnGeom g, int64_t total) {
     for (int64_t o = (int64_t)blockIdx.x * kUpThreads + threadIdx.x; o < total;
          o += (int64_t)gridDim.x * kUpThreads) {
@@ -329,7 +336,7 @@ upfirdn2d_generic_kernel(float* __restrict__ y, const float* __restrict__ x,
         const int64_t t = o / g.out_w;
         const int oy = (int)(t % g.out_h);
         const int64_t plane = t / g.out_h;
-        const float* xp = x + plane * (int64_t)g.in_h * g.in_w;
+        const T* xp = x + plane * (int64_t)g.in_h * g.in_w;
         const int by = oy * g.down_y - g.pad_y0, bx = ox * g.down_x - g.pad_x0;
         float acc = 0.0f;
         for (int ky = 0; ky < g.kh; ++ky) {
@@ -342,20 +349,20 @@ upfirdn2d_generic_kernel(float* __restrict__ y, const float* __restrict__ x,
                 if (sx < 0) continue;
                 const int ix = sx / g.up_x;
                 if (ix * g.up_x != sx || ix >= g.in_w) continue;
-                acc = fmaf(xp[(int64_t)iy * g.in_w + ix], k[(g.kh - 1 - ky) * g.kw + (g.kw - 1 - kx)], acc);
+                acc = fmaf((float)xp[(int64_t)iy * g.in_w + ix], k[(g.kh - 1 - ky) * g.kw + (g.kw - 1 - kx)], acc);
             }
         }
-        y[o] = acc;
+        y[o] = (T)acc;
     }
 }
 
-template <int UP, int DN, int KH, int KW>
-static int launch_tiled(float* y, const float* x, const float* k, const UpfirdnGeom& g,
+template <int UP, int DN, int KH, int KW, typename T = float>
+static int launch_tiled(T* y, const T* x, const float* k, const UpfirdnGeom& g,
                         int64_t major, hipStream_t st) {
     const int tiles_x = (g.out_w + kTileW - 1) / kTileW, tiles_y = (g.out_h + kTileH - 1) / kTileH;
     const int64_t blocks = (int64_t)tiles_x * tiles_y * major;
     if (blocks >= ((int64_t)1 << 31)) return fail(E3DGE_ERR_INVALID_ARG, "upfirdn2d: grid too large");
-    upfirdn2d_tiled_kernel<UP, DN, KH, KW><<<dim3((unsigned)blocks), dim3(kUpThreads), 0, st>>>(
+    upfirdn2d_tiled_kernel<UP, DN, KH, KW, false, T><<<dim3((unsigned)blocks), dim3(kUpThreads), 0, st>>>(
         y, x, k, g, tiles_x, tiles_y);
     return check_launch("upfirdn2d(tiled)");
 }
@@ -372,9 +379,9 @@ extern "C" int e3dge_upfirdn2d_out_size(int in, int up, int down, int pad0, int 
     return out > 0 ? out : -1;
 }
 
-extern "C" int e3dge_upfirdn2d(float* y, const float* x, const float* k, int64_t major, int in_h,
-                               int in_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
-                               int pad_x0, int pad_x1, int pad_y0, int pad_y1, e3dge_stream_t stream) {
+template <typename T>
+static int upfirdn2d_any(T* y, const T* x, const float* k, int64_t major, int in_h, int in_w, int kh, int kw, int up_x, int up_y,
+                         int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, e3dge_stream_t stream) {
     E3DGE_REQUIRE(up_x >= 1 && up_y >= 1 && down_x >= 1 && down_y >= 1, "upfirdn2d: up/down must be >= 1");
     E3DGE_REQUIRE(kh >= 1 && kw >= 1 && kh <= 32 && kw <= 32, "upfirdn2d: kernel %dx%d outside 1..32", kh, kw);
     E3DGE_REQUIRE(major >= 0 && in_h >= 1 && in_w >= 1, "upfirdn2d: bad input extent");
@@ -387,14 +394,27 @@ extern "C" int e3dge_upfirdn2d(float* y, const float* x, const float* k, int64_t
     UpfirdnGeom g{in_h, in_w, out_h, out_w, up_x, up_y, down_x, down_y, pad_x0, pad_y0, kh, kw};
     hipStream_t st = as_stream(stream);
     const bool sq = (up_x == up_y) && (down_x == down_y) && kh == 4 && kw == 4;
-    if (sq && up_x == 1 && down_x == 1) return launch_blur44<false>(y, x, k, g, major, UpfirdnEpi{}, st, "upfirdn2d(blur)");   // Blur
-    if (sq && up_x == 2 && down_x == 1) return launch_tiled<2, 1, 4, 4>(y, x, k, g, major, st);   // Upsample
-    if (sq && up_x == 1 && down_x == 2) return launch_tiled<1, 2, 4, 4>(y, x, k, g, major, st);   // its gradient / Downsample
+    if (sq && up_x == 1 && down_x == 1) return launch_blur44<false, T>(y, x, k, g, major, UpfirdnEpi{}, st, "upfirdn2d(blur)");   // Blur
+    if (sq && up_x == 2 && down_x == 1) return launch_tiled<2, 1, 4, 4, T>(y, x, k, g, major, st);   // Upsample
+    if (sq && up_x == 1 && down_x == 2) return launch_tiled<1, 2, 4, 4, T>(y, x, k, g, major, st);   // its gradient / Downsample
     const int64_t total = major * (int64_t)out_h * out_w;
     int64_t blocks = (total + kUpThreads - 1) / kUpThreads;
     if (blocks > 16384) blocks = 16384;
-    upfirdn2d_generic_kernel<<<dim3((unsigned)blocks), dim3(kUpThreads), 0, st>>>(y, x, k, g, total);
+    upfirdn2d_generic_kernel<T><<<dim3((unsigned)blocks), dim3(kUpThreads), 0, st>>>(y, x, k, g, total);
     return check_launch("upfirdn2d(generic)");
+}
+
+extern "C" int e3dge_upfirdn2d(float* y, const float* x, const float* k, int64_t major, int in_h,
+                               int in_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                               int pad_x0, int pad_x1, int pad_y0, int pad_y1, e3dge_stream_t stream) {
+    return upfirdn2d_any<float>(y, x, k, major, in_h, in_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, stream);
+}
+
+extern "C" int e3dge_upfirdn2d_f16(void* y, const void* x, const float* k, int64_t major, int in_h,
+                                   int in_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                                   int pad_x0, int pad_x1, int pad_y0, int pad_y1, e3dge_stream_t stream) {
+    return upfirdn2d_any<_Float16>(static_cast<_Float16*>(y), static_cast<const _Float16*>(x), k, major, in_h, in_w, kh, kw, up_x, up_y,
+                                   down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, stream);
 }
 
 extern "C" int e3dge_blur_noise_bias_act(float* y, const float* x, const float* k, const float* noise, const float* noise_weight,

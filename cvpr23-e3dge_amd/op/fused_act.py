@@ -23,24 +23,25 @@ from .. import _lib
 def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
     """y = act(x + bias[(i / prod(shape[2:])) % len(bias)]) * scale (see include/e3dge_hip.h).
     `bias` / `refer` may be None or empty tensors, as the reference passes `empty`."""
-    _lib.require_gpu(input, "input")
+    _lib.require_gpu(input, "input", half_ok=True)
     x = input.contiguous()
-    b = bias.contiguous() if bias is not None and bias.numel() else None
-    r = refer.contiguous() if refer is not None and refer.numel() else None
+    half = x.dtype == torch.float16          # the reference dispatches on the input's type (fused_bias_act_kernel.cu:79)
+    b = bias.contiguous().to(x.dtype) if bias is not None and bias.numel() else None
+    r = refer.contiguous().to(x.dtype) if refer is not None and refer.numel() else None
     if b is not None:
-        _lib.require_gpu(b, "bias")
+        _lib.require_gpu(b, "bias", half_ok=True)
     if r is not None:
-        _lib.require_gpu(r, "refer")
+        _lib.require_gpu(r, "refer", half_ok=True)
         if r.numel() != x.numel():
             raise RuntimeError("refer must have as many elements as input")
     step_b = 1
     for d in x.shape[2:]:
         step_b *= d
     y = torch.empty_like(x)
+    fn = _lib.load().e3dge_fused_bias_act_f16 if half else _lib.load().e3dge_fused_bias_act
     with torch.cuda.device(x.device):
-        rc = _lib.load().e3dge_fused_bias_act(
-            _lib.ptr(y), _lib.ptr(x), _lib.ptr(b), _lib.ptr(r), int(act), int(grad), float(alpha), float(scale),
-            x.numel(), step_b, 0 if b is None else b.numel(), _lib.stream_of(x))
+        rc = fn(_lib.ptr(y), _lib.ptr(x), _lib.ptr(b), _lib.ptr(r), int(act), int(grad), float(alpha), float(scale),
+                x.numel(), step_b, 0 if b is None else b.numel(), _lib.stream_of(x))
     _lib.check(rc, "e3dge_fused_bias_act")
     return y
 
@@ -89,7 +90,7 @@ def _fused_leaky_relu_cpu(input, bias, negative_slope, scale):
 def fused_leaky_relu(input, bias=None, negative_slope=0.2, scale=2 ** 0.5):
     if isinstance(input, torch.Tensor) and input.device.type == "cpu":
         return _fused_leaky_relu_cpu(input, bias, negative_slope, scale)
-    _lib.require_gpu(input, "input")
+    _lib.require_gpu(input, "input", half_ok=True)
     return _BiasLrelu.apply(input, bias, negative_slope, scale)
 
 

@@ -44,8 +44,10 @@ class Geometry(NamedTuple):
 
 
 def _launch(planes, kernel, geo):
-    """planes (major, in_h, in_w) contiguous fp32 on the GPU -> (major, out_h, out_w)."""
+    """planes (major, in_h, in_w) contiguous fp32 or fp16 on the GPU -> (major, out_h, out_w), same dtype.  The FIR taps go
+    to the kernel as fp32 either way (the half form computes in fp32 and rounds once on store)."""
     major, in_h, in_w = planes.shape
+    kernel = kernel.float()
     kh, kw = kernel.shape
     (ux, uy), (dx, dy), (px0, px1, py0, py1) = geo.up, geo.down, geo.pad
     lib = _lib.load()
@@ -55,9 +57,10 @@ def _launch(planes, kernel, geo):
         raise RuntimeError(f"upfirdn2d: empty output for input {in_h}x{in_w}, up {geo.up}, down {geo.down}, "
                            f"pad {geo.pad}, kernel {kh}x{kw}")
     y = planes.new_empty((major, out_h, out_w))
+    fn = lib.e3dge_upfirdn2d_f16 if planes.dtype == torch.float16 else lib.e3dge_upfirdn2d
     with torch.cuda.device(planes.device):
-        rc = lib.e3dge_upfirdn2d(_lib.ptr(y), _lib.ptr(planes), _lib.ptr(kernel), major, in_h, in_w, kh, kw,
-                                 ux, uy, dx, dy, px0, px1, py0, py1, _lib.stream_of(planes))
+        rc = fn(_lib.ptr(y), _lib.ptr(planes), _lib.ptr(kernel), major, in_h, in_w, kh, kw,
+                ux, uy, dx, dy, px0, px1, py0, py1, _lib.stream_of(planes))
     _lib.check(rc, "e3dge_upfirdn2d")
     return y
 
@@ -65,8 +68,8 @@ def _launch(planes, kernel, geo):
 def upfirdn2d_raw(input, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
     """input (major, in_h, in_w, 1) -> (major, out_h, out_w, 1); minor_dim must be 1 (as every reference
     caller passes it, upfirdn2d.py:27,78,96)."""
-    _lib.require_gpu(input, "input")
-    _lib.require_gpu(kernel, "kernel")
+    _lib.require_gpu(input, "input", half_ok=True)
+    _lib.require_gpu(kernel, "kernel", half_ok=True)
     if input.ndim != 4 or input.shape[3] != 1:
         raise RuntimeError("upfirdn2d_raw expects a (major, in_h, in_w, 1) tensor")
     geo = Geometry((up_x, up_y), (down_x, down_y), (pad_x0, pad_x1, pad_y0, pad_y1))
@@ -115,8 +118,8 @@ def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
         if input.ndim != 4 or kernel.ndim != 2:
             raise RuntimeError("upfirdn2d expects input (B, C, H, W) and a 2-D FIR kernel")
         return _upfirdn2d_cpu(input, kernel, Geometry((up, up), (down, down), (pad[0], pad[1], pad[0], pad[1])))
-    _lib.require_gpu(input, "input")
-    _lib.require_gpu(kernel, "kernel")
+    _lib.require_gpu(input, "input", half_ok=True)
+    _lib.require_gpu(kernel, "kernel", half_ok=True)
     if input.ndim != 4 or kernel.ndim != 2:
         raise RuntimeError("upfirdn2d expects input (B, C, H, W) and a 2-D FIR kernel")
     geo = Geometry((up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))

@@ -76,6 +76,14 @@ int e3dge_noise_bias_act(float* y, const float* x, const float* noise, const flo
 int e3dge_upfirdn2d(float* y, const float* x, const float* k, int64_t major, int in_h, int in_w,
                     int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
                     int pad_x1, int pad_y0, int pad_y1, e3dge_stream_t stream);
+/* Half-precision forms of the two ops (ABI 11; the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF:
+ * fused_bias_act_kernel.cu:79, upfirdn2d_kernel.cu:311).  x, y, bias, ref are IEEE fp16 tensors; the FIR taps stay fp32.  Arithmetic
+ * is fp32 with ONE rounding (RNE) on store -- at least as accurate as the reference's scalar_t = half arithmetic, which rounds after
+ * every operation; parity is stated against the fp32 op on the widened inputs, rounded to fp16 (tests/test_gpu_selftest_and_ops.py). */
+int e3dge_fused_bias_act_f16(void* y, const void* x, const void* bias, const void* ref, int act, int grad, float alpha, float scale,
+                             int64_t n, int64_t step_b, int64_t size_b, e3dge_stream_t stream);
+int e3dge_upfirdn2d_f16(void* y, const void* x, const float* k, int64_t major, int in_h, int in_w, int kh, int kw, int up_x, int up_y,
+                        int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, e3dge_stream_t stream);
 /* Output extent helper (same formula as above); returns <0 if the result would be empty. */
 int e3dge_upfirdn2d_out_size(int in, int up, int down, int pad0, int pad1, int k);
 
