@@ -81,6 +81,7 @@ class _ReuseKey:
         return all((t._version == s[1]) for t, s in zip(rec_key.tensors, rec_key.sig) if torch.is_tensor(t))
 
 
+_FILM_RECORD = weakref.WeakKeyDictionary()                             # renderer -> FiLM-ed layer-7 record (e3dge_tex_film_fwd output)
 _BACKBONE = weakref.WeakKeyDictionary()                                # renderer -> {key, buf (record), out (first pass's tensors)}
 _SIDE_STREAMS = {}                                                     # per device (module level: modules stay deep-copyable)
 
@@ -976,9 +977,12 @@ class VolumeFeatureRenderer(nn.Module):
             n_rec = use['buf'].numel() if use is not None else 0
             if (use is not None and _fuse_texfilm() and lazy.feats.dtype == torch.float32 and lazy.feats.device == dev
                     and tuple(lazy.feats.shape[:4]) == (B, H, Wd, S) and 0 < n_rec < 2 ** 32 and B * H * Wd * S < 2 ** 31):
-                tb_ = use.get('tex_buf')
+                # the FiLM-ed record outlives the layer-7 records it is computed from (one buffer per renderer, zero-filled ONCE:
+                # padding slabs are never written): allocating it per record put a 100-MB fill into every captured forward
+                tb_ = _FILM_RECORD.get(self)
                 if tb_ is None or tb_.numel() != n_rec or tb_.device != dev:
-                    tb_ = use['tex_buf'] = torch.zeros(n_rec, device=dev, dtype=torch.uint8)     # (padding slabs stay zero)
+                    tb_ = _FILM_RECORD[self] = torch.zeros(n_rec, device=dev, dtype=torch.uint8)
+                use['tex_buf'] = tb_
                 bb_in = lazy.head.tex_film(lazy.feats, use['buf'], tb_, B, H, Wd, S)
             else:
                 ta, tb = lazy.materialize()
@@ -1050,6 +1054,7 @@ class VolumeFeatureRenderer(nn.Module):
         detected without it."""
         self._sb_key = None
         _BACKBONE.pop(self, None)                             # (the first pass's layer-7 record was computed from the old values)
+        _FILM_RECORD.pop(self, None)
         for m in self.modules():
             if m is not self and hasattr(m, 'invalidate'):
                 m.invalidate()
