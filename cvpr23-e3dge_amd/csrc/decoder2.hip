@@ -203,6 +203,7 @@ struct PkConvK {
     float* out_amax;
     // fused ToRGB of the last convolution (RGB variants): (B, 3, Co) table, (3) bias, skip (B, 3, H/2, W/2) or null, 4x4 FIR, out (B, 3, H, W)
     const float* rgb_wm; const float* rgb_bias; const float* rgb_skip; const float* rgb_fir; float* rgb_out;
+    int rgb_store;                 // with rgb_out: 1 = also store the packed activation (a level that is not the last)
     float bias_amax, knorm, slope, act_scale;
     int B, Ci, Co, H, W;
     int n_chunks, noise_batch;
@@ -233,7 +234,9 @@ __device__ __forceinline__ int xcd_logical(int t, int n_tiles) {
 // the patch row-major (the source address is per lane, the LDS side is linear); weight slabs are 18 pieces each.
 // RGB = true (last convolution of the decoder, tile covers all output channels): ToRGB (:531-541) happens in the epilogue --
 // the activation is reduced against the 3 x Co table (scale W) s from LDS, + bias + FIR-up-sampled skip -- and is never stored.
-template <int NCT, int NPY, int NPX, int WCO, int WY, int WX, bool RGB>
+// RGB = 2 (round 4: a 64-channel level that is NOT the last): the same ToRGB in the epilogue AND the packed activation stored -- the
+// stand-alone ToRGB launch re-read the whole activation (67 MB at 512^2) for three output channels.
+template <int NCT, int NPY, int NPX, int WCO, int WY, int WX, int RGB>
 __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkConvK a) {
     static_assert(!RGB || WCO == 1, "fused ToRGB needs every output channel of a pixel in one wave");
     constexpr int NW = WCO * WY * WX, NT = 64 * NW;
@@ -256,7 +259,7 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
     const float oscale = pow2_bits(eb_in - 21u);                     // 1 / (128 * 2^(141 - eb_in))
     const float nw = a.noise ? a.noise_w[0] : 0.0f;
     float sc_out = 1.0f;
-    if (!RGB) {
+    if (RGB != 1) {
         const float nza = a.noise ? fabsf(nw) * amax_read(a.noise_amax, lane) : 0.0f;
         const float bound = a.act_scale * (amax_read(a.in_amax, lane) * a.knorm * 1.002f + nza + a.bias_amax) * 1.001f;
         const unsigned eb_out = scale_exponent(bound);
@@ -280,11 +283,28 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
     // the pieces of step + 1 are dealt out behind the MFMAs of the first taps: a dedicated issue phase had all eight waves
     // stalled on the CU's one vector-memory path at the same time (2.2-3.5 k cycles of a 12 k-cycle step, E3DGE_PK_TIMING).
     constexpr int NPW = (NPIECE + NW - 1) / NW, PPT = (NPW + 5) / 6;
+    // which patch entry a lane fetches in piece j is a kernel constant, kept PACKED (row << 8 | column, one register per piece) and
+    // turned into an address per step (cf. pkconv_upblur2_kernel: left to LICM, row / column / offset of every piece stay live
+    // across the tap loop -- the store + ToRGB form spilled 100 B of them into its MFMA stream)
+    constexpr int JP0 = (NWP - (NW - 1) + NW - 1) / NW > 0 ? (NWP - (NW - 1) + NW - 1) / NW : 0;
+    uint32_t pkv[NPW];
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) {
+        if (j < JP0) { pkv[j] = 0xffffffffu; continue; }
+        const int i = wave + j * NW;
+        const int p = max(i - NWP, 0), pp = p % NPP;
+        const int e = pp * 64 + lane;
+        const int prow = e / PW, pcol = e - prow * PW;
+        pkv[j] = e < NPIX ? (uint32_t)(prow << 8 | pcol) : 0xffffffffu;
+        asm volatile("" : "+v"(pkv[j]));
+    }
     auto issue = [&](const Pos& ps, int stage, int j_lo, int j_hi) {
         const uint32_t xl = lds_u32(smem_pk + stage * STAGE), wl = xl + XST;
         const unsigned char* wsrc = a.wimg + (int64_t)ps.b * a.wimg_bytes + ((int64_t)(ps.cb * NCTB) * a.n_chunks + ps.c) * kPkSlab;
         const unsigned char* xsrc = a.x + ((int64_t)(ps.b * G + 2 * ps.c) * 2) * plane_b;
-        const int gy0 = ps.ty * TH, gx0 = ps.tx * TW;
+        int gy0 = ps.ty * TH, gx0 = ps.tx * TW;
+        asm volatile("" : "+s"(gy0), "+s"(gx0));          // (not loop-invariant as far as the compiler can tell: see pkv)
+#pragma unroll
         for (int j = j_lo; j < j_hi; ++j) {
             const int i = wave + j * NW;
             if (i >= NPIECE) break;
@@ -293,11 +313,10 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
                 dma_piece(wsrc + (int64_t)ct * a.n_chunks * kPkSlab + pc * 1024, (uint32_t)lane * 16u, wl + ct * kPkSlab + pc * 1024);
             } else {
                 const int p = i - NWP, pl = p / NPP, pp = p - pl * NPP;
-                const int e = pp * 64 + lane;
-                if (e < NPIX) {
-                    const int prow = e / PW, pcol = e - prow * PW;
+                const uint32_t pk = pkv[j];
+                if (pk != 0xffffffffu) {
                     // clamped into the padded image: tiles that overhang a small image read (and compute) garbage that is never stored
-                    const int gy = min(gy0 + prow, HP - 1), gx = min(gx0 + pcol, WP - 1);
+                    const int gy = min(gy0 + (int)(pk >> 8), HP - 1), gx = min(gx0 + (int)(pk & 255u), WP - 1);
                     dma_piece(xsrc + pl * plane_b, (uint32_t)(gy * WP + gx) * 16u, xl + pl * XPLANE + pp * 1024);
                 }
             }
@@ -318,8 +337,8 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
     bool pending = false;
     float amax_l = 0.0f;
     const int prow0 = wy * NPY, pcol0 = wx * NPX * 32 + col;
-    const float kmul = RGB ? a.act_scale : a.act_scale * sc_out;      // lrelu(t) * act_scale * 2^k == (lrelu(t) * act_scale) * 2^k exactly
-    const float kinv = RGB ? 1.0f : 1.0f / sc_out;
+    const float kmul = RGB == 1 ? a.act_scale : a.act_scale * sc_out;      // lrelu(t) * act_scale * 2^k == (lrelu(t) * act_scale) * 2^k exactly
+    const float kinv = RGB == 1 ? 1.0f : 1.0f / sc_out;                    // (RGB = 2: the ToRGB sums carry 2^k too and shed it, exactly, at the end)
     PK_T_INIT;
 
     // One slice of a finished tile's epilogue: pixel tile pt, co-tile ct, channel group g4 = 2 gp + e (four values per lane):
@@ -364,10 +383,10 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
                 if (ok && half == 0) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
-                        a.rgb_out[((int64_t)b * 3 + c) * a.H * a.W + (int64_t)oy * a.W + ox] = (rgbp[pt][c] + a.rgb_bias[c]) + skf[pt][c];
+                        a.rgb_out[((int64_t)b * 3 + c) * a.H * a.W + (int64_t)oy * a.W + ox] = (rgbp[pt][c] * kinv + a.rgb_bias[c]) + skf[pt][c];
                 }
             }
-            return;
+            if (RGB == 1) return;
         }
         unsigned h0, l0, h1, l1;
         SPLIT2_TO(v[0], v[1], h0, l0);
@@ -408,7 +427,8 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
         // previous sample's table for the finished tile's epilogue; the host requires n_chunks >= 2, so a barrier lies before its readers.
         if (RGB && p_cur.c == 1 && p_cur.b != b_tab) {
             b_tab = p_cur.b;
-            for (int i = tid; i < 3 * a.Co; i += NT) tab[a.Co + i] = a.rgb_wm[(size_t)b_tab * 3 * a.Co + i];
+            const int t2 = (int)__builtin_amdgcn_readfirstlane(tid >> 6) * 64 + lane_id_fresh();     // (a kernel-lifetime copy of tid was the value spilled here)
+            for (int i = t2; i < 3 * a.Co; i += NT) tab[a.Co + i] = a.rgb_wm[(size_t)b_tab * 3 * a.Co + i];
         }
         // The epilogue's per-pixel inputs are requested here, while nothing else is in flight, and waited for behind tap 0 -- before
         // this step's DMA pieces go out: a wait inside the epilogue would also wait for every DMA piece issued since (vmcnt is in order).
@@ -553,10 +573,13 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
 #pragma unroll
         for (int h = 0; h < NH; ++h) epi_slice(h);
     }
-    if (!RGB && a.out_amax) {
+    if (RGB != 1 && a.out_amax) {
+        int l2 = lane;
+        asm volatile("" : "+v"(l2));          // (fresh permute addresses: sharing them with the prologue's amax_read keeps five registers alive across the kernel)
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) amax_l = fmaxf(amax_l, __shfl_xor(amax_l, off, kWave));
-        if (lane == 0) atomic_max_nonneg(a.out_amax + (((int)blockIdx.x * NW + wave) & (kAmaxSlots - 1)) * kAmaxStride, amax_l * kinv);
+        for (int off = 32; off > 0; off >>= 1)
+            amax_l = fmaxf(amax_l, __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((l2 ^ off) << 2, __builtin_bit_cast(int, amax_l))));
+        if (l2 == 0) atomic_max_nonneg(a.out_amax + (((int)blockIdx.x * NW + wave) & (kAmaxSlots - 1)) * kAmaxStride, amax_l * kinv);
     }
     PK_T_DONE(NW);
 }
@@ -1603,7 +1626,7 @@ pk_torgb_kernel(float* __restrict__ y, const unsigned char* __restrict__ x, cons
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NCT, int NPY, int NPX, int WCO, int WY, int WX, bool RGB = false>
+template <int NCT, int NPY, int NPX, int WCO, int WY, int WX, int RGB = 0>
 static int launch_s1(PkConvK k, hipStream_t st, const char* what) {
     constexpr int TH = NPY * WY, TW = 32 * NPX * WX, NPIX = (TH + 2) * (TW + 2), NCTB = NCT * WCO;
     constexpr int lds_stages = 2 * (4 * NPIX * 16 + NCTB * kPkSlab);
@@ -1615,6 +1638,7 @@ static int launch_s1(PkConvK k, hipStream_t st, const char* what) {
     k.tiles_x = (k.W + TW - 1) / TW;
     k.co_blocks = k.Co / (32 * NCTB);
     E3DGE_REQUIRE(!RGB || (k.co_blocks == 1 && k.n_chunks >= 2 && k.rgb_wm && k.rgb_bias && k.rgb_out), "%s: fused ToRGB needs one co-block and >= 32 input channels", what);
+    E3DGE_REQUIRE(RGB != 2 || (k.y && k.out_meta), "%s: the store + ToRGB form needs the output activation", what);
     const int64_t n_tiles = (int64_t)k.B * k.co_blocks * k.tiles_y * k.tiles_x;
     E3DGE_REQUIRE(n_tiles < ((int64_t)1 << 30), "%s: too many tiles", what);
     k.n_tiles = (int)n_tiles;
@@ -1763,9 +1787,13 @@ static bool s1_can_fuse_rgb(int co, int ci) {
 }
 
 static int conv_s1(PkConvK k, hipStream_t st) {
+    if (k.rgb_out && k.rgb_store) {
+        if (k.Co == 32) return launch_s1<1, 1, 2, 1, 8, 1, 2>(k, st, "dec2 conv+store+rgb<32co,8x64>");
+        return launch_s1<2, 1, 2, 1, 8, 1, 2>(k, st, "dec2 conv+store+rgb<64co,8x64>");
+    }
     if (k.rgb_out) {
-        if (k.Co == 32) return launch_s1<1, 1, 2, 1, 8, 1, true>(k, st, "dec2 conv+rgb<32co,8x64>");
-        return launch_s1<2, 1, 2, 1, 8, 1, true>(k, st, "dec2 conv+rgb<64co,8x64>");
+        if (k.Co == 32) return launch_s1<1, 1, 2, 1, 8, 1, 1>(k, st, "dec2 conv+rgb<32co,8x64>");
+        return launch_s1<2, 1, 2, 1, 8, 1, 1>(k, st, "dec2 conv+rgb<64co,8x64>");
     }
     int v = shape_override("E3DGE_DEC2_S1");
     const int64_t px = (int64_t)k.H * k.W;
@@ -2022,13 +2050,17 @@ extern "C" int e3dge_dec2_forward(const E3dgeDec2Plan* P, e3dge_stream_t stream)
             DEC2_STEP(check_launch("dec2 blur"));
         }
         }
-        const bool fuse_rgb = u == P->n_up - 1 && s1_can_fuse_rgb(cc.co, cc.ci);   // the last activation is never stored
+        // ToRGB in the convolution's epilogue whenever one tile covers every output channel (32 / 64): at the last level the activation
+        // is then never stored; at an earlier level (round 4) it is stored AND reduced -- the stand-alone ToRGB re-read all of it
+        const bool last_level = u == P->n_up - 1;
+        const bool fuse_rgb = s1_can_fuse_rgb(cc.co, cc.ci) && (last_level || shape_override("E3DGE_DEC2_FUSE_RGB_MID") != 0);
         {   // stride-1 conv
             PkConvK k = conv_args(cc, res);
             k.x = reinterpret_cast<const unsigned char*>(P->act[2 + 2 * u]); k.in_meta = P->meta + 2 + 2 * u; k.in_amax = am_u;
             k.y = reinterpret_cast<unsigned char*>(P->act[3 + 2 * u]); k.out_meta = P->meta + 3 + 2 * u; k.out_amax = am_v;
             if (fuse_rgb) {
                 k.rgb_wm = P->rgb[u].wm; k.rgb_bias = P->rgb[u].bias; k.rgb_skip = skip; k.rgb_fir = P->fir_up; k.rgb_out = P->rgb[u].out;
+                k.rgb_store = last_level ? 0 : 1;
             }
             DEC2_STEP(conv_s1(k, st));
         }
