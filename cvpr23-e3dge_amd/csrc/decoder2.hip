@@ -279,60 +279,89 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
     };
     auto advance = [&](Pos& p) { if (++p.c == a.n_chunks) { p.c = 0; ++p.k; tile_of(p); } };
 
-    // this wave's DMA pieces j_lo <= j < j_hi of step `ps` (piece index wave + j NW) into LDS stage `stage`.  Inside the main loop
-    // the pieces of step + 1 are dealt out behind the MFMAs of the first taps: a dedicated issue phase had all eight waves
-    // stalled on the CU's one vector-memory path at the same time (2.2-3.5 k cycles of a 12 k-cycle step, E3DGE_PK_TIMING).
-    constexpr int NPW = (NPIECE + NW - 1) / NW, PPT = (NPW + 5) / 6;
-    // which patch entry a lane fetches in piece j is a kernel constant, kept PACKED (row << 8 | column, one register per piece) and
-    // turned into an address per step (cf. pkconv_upblur2_kernel: left to LICM, row / column / offset of every piece stay live
-    // across the tap loop -- the store + ToRGB form spilled 100 B of them into its MFMA stream)
-    constexpr int JP0 = (NWP - (NW - 1) + NW - 1) / NW > 0 ? (NWP - (NW - 1) + NW - 1) / NW : 0;
-    uint32_t pkv[NPW];
+    // The LDS-DMA pieces of a step, dealt out in STATIC slots (round 4).  Inside the main loop the pieces of step + 1 go out behind the
+    // MFMAs of the first six taps: a dedicated issue phase had all eight waves stalled on the CU's one vector-memory path at the
+    // same time (2.2-3.5 k cycles of a 12 k-cycle step, E3DGE_PK_TIMING).  Until round 4 piece i = wave + j NW was "a weight piece if
+    // i < NWP, else patch piece i - NWP": what a slot j held depended on the wave index, so every slot carried both forms, their
+    // 64-bit source bases were recomputed from (b, cb, c, ty, tx) behind every tap, and the kernel-lifetime scalars this kept alive
+    // were spilled to VGPR lanes -- ~170 instructions per tap for two pieces, ~1,000 of the ~2,800 a wave issued per step
+    // (54 of them MFMAs; the step was instruction-issue bound: 11-12 k cycles, both waves of a SIMD alike).  Now:
+    //   weight slot j < NWS:   piece i = wave + j NW of the NCTB slabs (18 pieces each), source offset in a per-lane register
+    //   patch slot (pl, r):    plane pl (static), piece pp = (wave + pl ROT) % NW + r NW of its NPP (the rotation spreads the
+    //                          planes' leftover pieces over the waves), lane's patch entry packed (row << 8 | column) in a register
+    // and the sources of step + 1 are computed ONCE at the top of a step (Src, pinned in scalar registers).
+    constexpr int NWS = (NWP + NW - 1) / NW, PR = (NPP + NW - 1) / NW, ROT = NW >= 4 ? NW / 4 : 1;
+    constexpr int NSLOT = NWS + 4 * PR, PPT = (NSLOT + 5) / 6;
+    uint32_t wvo[NWS];
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) {
-        if (j < JP0) { pkv[j] = 0xffffffffu; continue; }
-        const int i = wave + j * NW;
-        const int p = max(i - NWP, 0), pp = p % NPP;
-        const int e = pp * 64 + lane;
-        const int prow = e / PW, pcol = e - prow * PW;
-        pkv[j] = e < NPIX ? (uint32_t)(prow << 8 | pcol) : 0xffffffffu;
-        asm volatile("" : "+v"(pkv[j]));
+    for (int j = 0; j < NWS; ++j) {
+        const int i = wave + j * NW, ct = i / 18, pc = i - ct * 18;
+        wvo[j] = (uint32_t)lane * 16u + (uint32_t)((ct * a.n_chunks * 18 + pc) * 1024);
+        asm volatile("" : "+v"(wvo[j]));
     }
-    auto issue = [&](const Pos& ps, int stage, int j_lo, int j_hi) {
-        const uint32_t xl = lds_u32(smem_pk + stage * STAGE), wl = xl + XST;
-        const unsigned char* wsrc = a.wimg + (int64_t)ps.b * a.wimg_bytes + ((int64_t)(ps.cb * NCTB) * a.n_chunks + ps.c) * kPkSlab;
-        const unsigned char* xsrc = a.x + ((int64_t)(ps.b * G + 2 * ps.c) * 2) * plane_b;
-        int gy0 = ps.ty * TH, gx0 = ps.tx * TW;
-        asm volatile("" : "+s"(gy0), "+s"(gx0));          // (not loop-invariant as far as the compiler can tell: see pkv)
+    uint32_t pkv[4][PR];
+    int rws[4];
 #pragma unroll
-        for (int j = j_lo; j < j_hi; ++j) {
-            const int i = wave + j * NW;
-            if (i >= NPIECE) break;
-            if (i < NWP) {
-                const int ct = i / 18, pc = i - ct * 18;
-                dma_piece(wsrc + (int64_t)ct * a.n_chunks * kPkSlab + pc * 1024, (uint32_t)lane * 16u, wl + ct * kPkSlab + pc * 1024);
+    for (int pl = 0; pl < 4; ++pl) {
+        const int pp0 = (wave + pl * ROT) % NW;
+        rws[pl] = pl * XPLANE + pp0 * 1024;
+        asm volatile("" : "+s"(rws[pl]));
+#pragma unroll
+        for (int r = 0; r < PR; ++r) {
+            const int pp = pp0 + r * NW, e = pp * 64 + lane;
+            const int prow = e / PW, pcol = e - prow * PW;
+            pkv[pl][r] = (pp < NPP && e < NPIX) ? (uint32_t)(prow << 8 | pcol) : 0xffffffffu;
+            asm volatile("" : "+v"(pkv[pl][r]));
+        }
+    }
+    const uint32_t plb = (uint32_t)plane_b;
+    struct Src { uint32_t wlo, whi, xlo, xhi; int gy0, gx0; };
+    auto src_of = [&](const Pos& ps) {
+        const uint64_t w = reinterpret_cast<uint64_t>(a.wimg + (int64_t)ps.b * a.wimg_bytes + ((int64_t)(ps.cb * NCTB) * a.n_chunks + ps.c) * kPkSlab);
+        const uint64_t x = reinterpret_cast<uint64_t>(a.x + ((int64_t)(ps.b * G + 2 * ps.c) * 2) * plane_b);
+        Src sc;
+        sc.wlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w); sc.whi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 32));
+        sc.xlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x); sc.xhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32));
+        sc.gy0 = ps.ty * TH; sc.gx0 = ps.tx * TW;
+        asm volatile("" : "+s"(sc.wlo), "+s"(sc.whi), "+s"(sc.xlo), "+s"(sc.xhi), "+s"(sc.gy0), "+s"(sc.gx0));      // (computed here, not re-derived at every use)
+        return sc;
+    };
+    auto issue = [&](const Src& sc, uint32_t xl, int s_lo, int s_hi) {         // xl: LDS address of the target stage
+        const void* wsrc = reinterpret_cast<const void*>((uint64_t)sc.whi << 32 | sc.wlo);
+        const void* xsrc = reinterpret_cast<const void*>((uint64_t)sc.xhi << 32 | sc.xlo);
+#pragma unroll
+        for (int sl = s_lo; sl < s_hi; ++sl) {
+            if (sl < NWS) {
+                if ((sl + 1) * NW <= NWP || wave + sl * NW < NWP)
+                    glds16_saddr<0>(wsrc, wvo[sl], xl + (uint32_t)(XST + (wave + sl * NW) * 1024));
             } else {
-                const int p = i - NWP, pl = p / NPP, pp = p - pl * NPP;
-                const uint32_t pk = pkv[j];
+                const int q = sl - NWS, pl = q & 3, r = q >> 2;
+                const uint32_t pk = pkv[pl][r];
                 if (pk != 0xffffffffu) {
                     // clamped into the padded image: tiles that overhang a small image read (and compute) garbage that is never stored
-                    const int gy = min(gy0 + (int)(pk >> 8), HP - 1), gx = min(gx0 + (int)(pk & 255u), WP - 1);
-                    dma_piece(xsrc + pl * plane_b, (uint32_t)(gy * WP + gx) * 16u, xl + pl * XPLANE + pp * 1024);
+                    const int gy = min(sc.gy0 + (int)(pk >> 8), HP - 1), gx = min(sc.gx0 + (int)(pk & 255u), WP - 1);
+                    glds16_saddr<0>(xsrc, (uint32_t)(gy * WP + gx) * 16u + (uint32_t)pl * plb, xl + (uint32_t)(rws[pl] + r * NW * 1024));
                 }
             }
         }
+    };
+    auto stage_lds = [&](int stage) {
+        uint32_t xl = lds_u32(smem_pk) + (uint32_t)(stage * STAGE);
+        asm volatile("" : "+s"(xl));
+        return xl;
     };
 
     Pos p_cur{0, 0, 0, 0, 0, 0};
     tile_of(p_cur);
     Pos p_nx1 = p_cur; advance(p_nx1);
-    issue(p_cur, 0, 0, NPW);
+    issue(src_of(p_cur), stage_lds(0), 0, NSLOT);
 
     f32x16 acc[NCT][NPT];                                // the tile being accumulated
     f32x16 fin[NCT][NPT];                                // the finished tile: its epilogue runs under the NEXT tile's first MFMAs
     float nzr[NPT], nzf[NPT];                            // noise of the tile's pixels (being fetched / of the finished tile)
     float skr[RGB ? NPT : 1][3], skf[RGB ? NPT : 1][3];  // (RGB) the FIR-up-sampled skip image at the tile's pixels, idem
     float rgbp[RGB ? NPT : 1][3];                        // (RGB) partial channel sums of the finished tile
+    float svr[RGB ? NPT : 1][3][4], fwr[RGB ? NPT : 1][4];   // (RGB) the four skip-image taps of each pixel and their FIR weights, as loaded
     Pos p_fin{0, 0, 0, 0, 0, 0};
     bool pending = false;
     float amax_l = 0.0f;
@@ -410,12 +439,37 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
         }
     };
 
+    // (RGB) FIR-up-sampled skip image at pixel tile pt of the CURRENT tile from its four loaded taps.  DEFER: called behind tap 0 -- in
+    // the step's prelude it put the loads' s_waitcnt, a full memory round trip (~4 k cycles per tile at the 1024^2 level,
+    // E3DGE_PK_TIMING), in front of the step's MFMAs.  Not for the 64-channel store + ToRGB form: the 32 registers of raw taps
+    // that stay live through tap 0 spill 108 B there.
+    constexpr bool DEFER = !(RGB == 2 && NCT * NPT > 2);
+    auto skip_combine = [&](int pt) {
+        const int oy = p_cur.ty * TH + prow0 + pt / NPX, ox = p_cur.tx * TW + pcol0 + 32 * (pt % NPX);
+        const int oyc = min(oy, a.H - 1), oxc = min(ox, a.W - 1), h2 = a.H >> 1, w2 = a.W >> 1;
+        float fw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ky = (oyc & 1) + 2 * (q >> 1), iy = (oyc + ky - 2) >> 1, kx = (oxc & 1) + 2 * (q & 1), ix = (oxc + kx - 2) >> 1;
+            fw[q] = (iy >= 0 && iy < h2 && ix >= 0 && ix < w2) ? fwr[pt][q] : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float uacc = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) uacc = fmaf(svr[pt][c][q], fw[q], uacc);     // (a tap with weight 0 leaves the chain's value unchanged)
+            skr[pt][c] = uacc;
+        }
+    };
+
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
         // my pieces of this step have landed; after the barrier everybody's have, and nobody still reads the other stage
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         PK_T(0);
         const bool has_next = step + 1 < nsteps, last_chunk = p_cur.c == a.n_chunks - 1;
+        const Src src_nx = src_of(p_nx1);                // (past the last step: unused)
+        const uint32_t xl_nx = stage_lds(cur ^ 1);
         const bool do_epi = pending;                     // (a tile's epilogue runs in the step after its last chunk)
         if (p_cur.c == 0) {
 #pragma unroll
@@ -441,30 +495,22 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
                 const int oyc = min(oy, a.H - 1), oxc = min(ox, a.W - 1);
                 nzr[pt] = a.noise ? a.noise[(int64_t)(a.noise_batch > 1 ? p_cur.b : 0) * a.H * a.W + (int64_t)oyc * a.W + oxc] : 0.0f;
                 if (RGB) {
+                    // raw taps (skip_combine above)
                     const int h2 = a.H >> 1, w2 = a.W >> 1;
-                    float sv[3][4], fw[4];
 #pragma unroll
                     for (int p2 = 0; p2 < 2; ++p2) {        // upfirdn2d(skip, fir, up=2, pad=(2,1)): taps and order of e3dge_upfirdn2d
                         const int ky = (oyc & 1) + 2 * p2, iy = (oyc + ky - 2) >> 1;
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             const int kx = (oxc & 1) + 2 * e, ix = (oxc + kx - 2) >> 1;
-                            const bool in = iy >= 0 && iy < h2 && ix >= 0 && ix < w2;
                             const int off = min(max(iy, 0), h2 - 1) * w2 + min(max(ix, 0), w2 - 1);
-                            const float f = a.rgb_skip ? a.rgb_fir[(3 - ky) * 4 + (3 - kx)] : 0.0f;
-                            fw[2 * p2 + e] = in ? f : 0.0f;
+                            fwr[pt][2 * p2 + e] = a.rgb_skip ? a.rgb_fir[(3 - ky) * 4 + (3 - kx)] : 0.0f;
 #pragma unroll
                             for (int c = 0; c < 3; ++c)
-                                sv[c][2 * p2 + e] = a.rgb_skip ? a.rgb_skip[((int64_t)p_cur.b * 3 + c) * h2 * w2 + off] : 0.0f;
+                                svr[pt][c][2 * p2 + e] = a.rgb_skip ? a.rgb_skip[((int64_t)p_cur.b * 3 + c) * h2 * w2 + off] : 0.0f;
                         }
                     }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        float uacc = 0.0f;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) uacc = fmaf(sv[c][q], fw[q], uacc);     // (a tap with weight 0 leaves the chain's value unchanged)
-                        skr[pt][c] = uacc;
-                    }
+                    if (!DEFER) skip_combine(pt);
                 }
             }
         }
@@ -533,10 +579,11 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
 #pragma unroll
                     for (int pt = 0; pt < NPT; ++pt) {
                         asm volatile("" : "+v"(nzr[pt]));      // the compiler's vmcnt wait lands here
-                        if (RGB) asm volatile("" : "+v"(skr[pt][0]), "+v"(skr[pt][1]), "+v"(skr[pt][2]));
+                        if (RGB && DEFER) skip_combine(pt);
+                        if (RGB && !DEFER) asm volatile("" : "+v"(skr[pt][0]), "+v"(skr[pt][1]), "+v"(skr[pt][2]));
                     }
                 }
-                if (has_next && tap * PPT < NPW) issue(p_nx1, cur ^ 1, tap * PPT, min((tap + 1) * PPT, NPW));
+                if (has_next && tap * PPT < NSLOT) issue(src_nx, xl_nx, tap * PPT, min((tap + 1) * PPT, NSLOT));
                 if (tap % 3 == 2 || EPI) __builtin_amdgcn_sched_barrier(0);      // keep the fragment reads of later taps from piling up
 #ifdef E3DGE_PK_TIMING
                 if (tap == 0 || tap == 8) { const unsigned long long n2_ = __builtin_readcyclecounter();
@@ -1792,6 +1839,7 @@ static int conv_s1(PkConvK k, hipStream_t st) {
         return launch_s1<2, 1, 2, 1, 8, 1, 2>(k, st, "dec2 conv+store+rgb<64co,8x64>");
     }
     if (k.rgb_out) {
+        if (k.Co == 32 && shape_override("E3DGE_DEC2_S1_RGB32") == 1) return launch_s1<1, 2, 1, 1, 4, 1, 1>(k, st, "dec2 conv+rgb<32co,8x32,4w>");
         if (k.Co == 32) return launch_s1<1, 1, 2, 1, 8, 1, 1>(k, st, "dec2 conv+rgb<32co,8x64>");
         return launch_s1<2, 1, 2, 1, 8, 1, 1>(k, st, "dec2 conv+rgb<64co,8x64>");
     }
