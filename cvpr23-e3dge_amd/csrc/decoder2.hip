@@ -30,6 +30,9 @@ constexpr int kPkSlab = 9 * 2 * 1024;            // bytes of one weight slab: (3
 #ifndef E3DGE_PK_S1_PM
 #define E3DGE_PK_S1_PM 1         // stride-1 conv: product-major MFMA order (0 = three dependent MFMAs per accumulator in a row)
 #endif
+#ifndef E3DGE_PK_ISSUE_TAPS
+#define E3DGE_PK_ISSUE_TAPS 6    // the LDS-DMA pieces of the next step go out behind the MFMAs of this many taps (stride-1 and fused up-sampling kernels)
+#endif
 #ifndef E3DGE_PK_EPI_VALU
 #define E3DGE_PK_EPI_VALU 8      // VALU instructions of a finished tile's epilogue scheduled behind each MFMA of the next tile
 #endif
@@ -291,7 +294,7 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
     //                          planes' leftover pieces over the waves), lane's patch entry packed (row << 8 | column) in a register
     // and the sources of step + 1 are computed ONCE at the top of a step (Src, pinned in scalar registers).
     constexpr int NWS = (NWP + NW - 1) / NW, PR = (NPP + NW - 1) / NW, ROT = NW >= 4 ? NW / 4 : 1;
-    constexpr int NSLOT = NWS + 4 * PR, PPT = (NSLOT + 5) / 6;
+    constexpr int NSLOT = NWS + 4 * PR, PPT = (NSLOT + E3DGE_PK_ISSUE_TAPS - 1) / E3DGE_PK_ISSUE_TAPS;
     uint32_t wvo[NWS];
 #pragma unroll
     for (int j = 0; j < NWS; ++j) {
@@ -299,21 +302,23 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
         wvo[j] = (uint32_t)lane * 16u + (uint32_t)((ct * a.n_chunks * 18 + pc) * 1024);
         asm volatile("" : "+v"(wvo[j]));
     }
-    uint32_t pkv[4][PR];
+    // (one register per plane: the entry of round r > 0 lies r NW 64 entries further on and is derived from round 0's when it is issued)
+    uint32_t pkv[4];
     int rws[4];
+    unsigned vmask = 0;                                  // bit pl PR + r: this wave has a piece in round r of plane pl
 #pragma unroll
     for (int pl = 0; pl < 4; ++pl) {
         const int pp0 = (wave + pl * ROT) % NW;
         rws[pl] = pl * XPLANE + pp0 * 1024;
         asm volatile("" : "+s"(rws[pl]));
+        const int e = pp0 * 64 + lane, prow = e / PW, pcol = e - prow * PW;
+        pkv[pl] = (pp0 < NPP && e < NPIX) ? (uint32_t)(prow << 8 | pcol) : 0xffffffffu;
+        asm volatile("" : "+v"(pkv[pl]));
 #pragma unroll
-        for (int r = 0; r < PR; ++r) {
-            const int pp = pp0 + r * NW, e = pp * 64 + lane;
-            const int prow = e / PW, pcol = e - prow * PW;
-            pkv[pl][r] = (pp < NPP && e < NPIX) ? (uint32_t)(prow << 8 | pcol) : 0xffffffffu;
-            asm volatile("" : "+v"(pkv[pl][r]));
-        }
+        for (int r = 0; r < PR; ++r) vmask |= (pp0 + r * NW < NPP ? 1u : 0u) << (pl * PR + r);
     }
+    vmask = (unsigned)__builtin_amdgcn_readfirstlane((int)vmask);
+    asm volatile("" : "+s"(vmask));
     const uint32_t plb = (uint32_t)plane_b;
     struct Src { uint32_t wlo, whi, xlo, xhi; int gy0, gx0; };
     auto src_of = [&](const Pos& ps) {
@@ -336,10 +341,19 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
                     glds16_saddr<0>(wsrc, wvo[sl], xl + (uint32_t)(XST + (wave + sl * NW) * 1024));
             } else {
                 const int q = sl - NWS, pl = q & 3, r = q >> 2;
-                const uint32_t pk = pkv[pl][r];
-                if (pk != 0xffffffffu) {
+                constexpr int DQ = (NW * 64) / PW, DR = (NW * 64) % PW;
+                uint32_t pk = pkv[pl];
+                if (r > 0) asm volatile("" : "+v"(pk));     // (a fresh copy: derived entries hoisted out of the loop would cost the registers this saves)
+                uint32_t prow = pk >> 8, pcol = pk & 255u;
+#pragma unroll
+                for (int i = 0; i < r; ++i) {
+                    pcol += DR; prow += DQ;
+                    const bool cy = pcol >= (uint32_t)PW;
+                    pcol = cy ? pcol - PW : pcol; prow += cy ? 1u : 0u;
+                }
+                if (((vmask >> (pl * PR + r)) & 1u) && prow < (uint32_t)PH) {
                     // clamped into the padded image: tiles that overhang a small image read (and compute) garbage that is never stored
-                    const int gy = min(sc.gy0 + (int)(pk >> 8), HP - 1), gx = min(sc.gx0 + (int)(pk & 255u), WP - 1);
+                    const int gy = min(sc.gy0 + (int)prow, HP - 1), gx = min(sc.gx0 + (int)pcol, WP - 1);
                     glds16_saddr<0>(xsrc, (uint32_t)(gy * WP + gx) * 16u + (uint32_t)pl * plb, xl + (uint32_t)(rws[pl] + r * NW * 1024));
                 }
             }
@@ -1055,7 +1069,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) pkconv_upblur2_kerne
     constexpr int RPW = (ORows + NG - 1) / NG, NVW = ORows / RPW;            // output rows per group, groups taking part
     static_assert(NVW * RPW == ORows && NVW <= NG, "vertical-pass split");
     constexpr int NT = 64 * NW, XPLANE = kUbNpix * 16, XST = 4 * XPLANE, WST = kPkSlab, STAGE = XST + WST;
-    constexpr int NWP = 18, NPP = (kUbNpix + 63) / 64, NPIECE = NWP + 4 * NPP, NPW = (NPIECE + NW - 1) / NW, PPT = (NPW + 5) / 6;
+    constexpr int NWP = 18, NPP = (kUbNpix + 63) / 64;
     constexpr int HB = 2 * TLR * OX * 16;                                    // H buffer: [half][T row][OX columns] x 16 B
     constexpr int HOFF = STAGE, BOFF = (2 * STAGE > STAGE + HB ? 2 * STAGE : STAGE + HB);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pk[];
@@ -1095,49 +1109,76 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) pkconv_upblur2_kerne
         t.i0 = tyi * kUbTH; t.j0 = txi * kUbTW;                            // first position whose outputs this tile stores
         return t;
     };
-    // Patch pieces: piece p of a wave covers 64 consecutive entries of the (kUbPR x kUbPC) patch; which entry a lane fetches is a
-    // kernel constant, kept PACKED (row << 8 | column, one register per piece).  The source address is rebuilt per chunk from it
-    // (six VALU per piece, in the shadow of the MFMAs): left to LICM, row, column and offset of every piece stay live across the
-    // K loop and the epilogue -- three registers each, which is what spilled in the 2 x 16 form.
-    constexpr int JP0 = (NWP - (NW - 1) + NW - 1) / NW > 0 ? (NWP - (NW - 1) + NW - 1) / NW : 0;   // pieces j < JP0 are weight pieces for every wave
-    uint32_t pkv[NPW];
+    // LDS-DMA pieces in static slots, as in pkconv_s1_kernel: weight slot j = piece wave + j NW of the slab's 18; patch slot (pl, r) =
+    // piece (wave + pl ROT) % NW + r NW of plane pl.  Which entry of the (kUbPR x kUbPC) patch a lane fetches is a kernel constant,
+    // kept PACKED (row << 8 | column, one register per slot); the source address is rebuilt per chunk from it (six VALU per piece,
+    // in the shadow of the MFMAs): left to LICM, row, column and offset of every piece stay live across the K loop and the
+    // epilogue -- three registers each, which is what spilled in the 2 x 16 form.  The 64-bit sources of a chunk are computed once
+    // (Src), not behind every tap.
+    constexpr int NWS = (NWP + NW - 1) / NW, PR = (NPP + NW - 1) / NW, ROT = NW / 4;
+    constexpr int NSLOT = NWS + 4 * PR, PPT = (NSLOT + E3DGE_PK_ISSUE_TAPS - 1) / E3DGE_PK_ISSUE_TAPS;
+    uint32_t pkv[4];                                     // (round 0; later rounds are derived from it when they are issued)
+    int rws[4];
+    unsigned vmask = 0;
 #pragma unroll
-    for (int j = 0; j < NPW; ++j) {
-        if (j < JP0) { pkv[j] = 0xffffffffu; continue; }
-        const int i = wave + j * NW;
-        const int p = max(i - NWP, 0), pp = p % NPP;
-        const int e = pp * 64 + lane;
-        const int prow = e / kUbPC, pcol = e - prow * kUbPC;
-        pkv[j] = e < kUbNpix ? (uint32_t)(prow << 8 | pcol) : 0xffffffffu;
-        asm volatile("" : "+v"(pkv[j]));
+    for (int pl = 0; pl < 4; ++pl) {
+        const int pp0 = (wave + pl * ROT) % NW;
+        rws[pl] = pl * XPLANE + pp0 * 1024;
+        asm volatile("" : "+s"(rws[pl]));
+        const int e = pp0 * 64 + lane, prow = e / kUbPC, pcol = e - prow * kUbPC;
+        pkv[pl] = (pp0 < NPP && e < kUbNpix) ? (uint32_t)(prow << 8 | pcol) : 0xffffffffu;
+        asm volatile("" : "+v"(pkv[pl]));
+#pragma unroll
+        for (int r = 0; r < PR; ++r) vmask |= (pp0 + r * NW < NPP ? 1u : 0u) << (pl * PR + r);
     }
-    auto issue = [&](const Tile& t, int c, int stage, int j_lo, int j_hi) {
-        const uint32_t xl = lds_u32(smem_pk + stage * STAGE), wl = xl + XST;
-        const unsigned char* wsrc = a.wimg + (int64_t)t.b * a.wimg_bytes + ((int64_t)t.cb * a.n_chunks + c) * kPkSlab;
-        const unsigned char* xsrc = a.x + ((int64_t)(t.b * G + 2 * c) * 2) * plane_b;
-        int im = t.i0 - 1, jm = t.j0 - 1;
-        asm volatile("" : "+s"(im), "+s"(jm));          // (not loop-invariant as far as the compiler can tell: see pkv)
+    vmask = (unsigned)__builtin_amdgcn_readfirstlane((int)vmask);
+    asm volatile("" : "+s"(vmask));
+    const uint32_t plb = (uint32_t)plane_b;
+    struct Src { uint32_t wlo, whi, xlo, xhi; int im, jm; };
+    auto src_of = [&](const Tile& t, int c) {
+        const uint64_t w = reinterpret_cast<uint64_t>(a.wimg + (int64_t)t.b * a.wimg_bytes + ((int64_t)t.cb * a.n_chunks + c) * kPkSlab);
+        const uint64_t x = reinterpret_cast<uint64_t>(a.x + ((int64_t)(t.b * G + 2 * c) * 2) * plane_b);
+        Src sc;
+        sc.wlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w); sc.whi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 32));
+        sc.xlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x); sc.xhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32));
+        sc.im = t.i0 - 1; sc.jm = t.j0 - 1;
+        asm volatile("" : "+s"(sc.wlo), "+s"(sc.whi), "+s"(sc.xlo), "+s"(sc.xhi), "+s"(sc.im), "+s"(sc.jm));
+        return sc;
+    };
+    auto issue = [&](const Src& sc, int stage, int s_lo, int s_hi) {
+        uint32_t xl = lds_u32(smem_pk) + (uint32_t)(stage * STAGE);
+        asm volatile("" : "+s"(xl));
+        const void* wsrc = reinterpret_cast<const void*>((uint64_t)sc.whi << 32 | sc.wlo);
+        const void* xsrc = reinterpret_cast<const void*>((uint64_t)sc.xhi << 32 | sc.xlo);
 #pragma unroll
-        for (int j = j_lo; j < j_hi; ++j) {
-            const int i = wave + j * NW;
-            if (i >= NPIECE) break;
-            if (i < NWP) {
-                dma_piece(wsrc + i * 1024, (uint32_t)lane * 16u, wl + i * 1024);
+        for (int sl = s_lo; sl < s_hi; ++sl) {
+            if (sl < NWS) {
+                if ((sl + 1) * NW <= NWP || wave + sl * NW < NWP)
+                    glds16_saddr<0>(wsrc, (uint32_t)lane * 16u + (uint32_t)((wave + sl * NW) * 1024), xl + (uint32_t)(XST + (wave + sl * NW) * 1024));
             } else {
-                const int p = i - NWP, pl = p / NPP, pp = p - pl * NPP;
-                const uint32_t pk = pkv[j];
-                if (pk != 0xffffffffu) {
+                const int q = sl - NWS, pl = q & 3, r = q >> 2;
+                constexpr int DQ = (NW * 64) / kUbPC, DR = (NW * 64) % kUbPC;
+                uint32_t pk = pkv[pl];
+                if (r > 0) asm volatile("" : "+v"(pk));     // (a fresh copy: derived entries hoisted out of the loop would cost the registers this saves)
+                uint32_t prow = pk >> 8, pcol = pk & 255u;
+#pragma unroll
+                for (int i = 0; i < r; ++i) {
+                    pcol += DR; prow += DQ;
+                    const bool cy = pcol >= (uint32_t)kUbPC;
+                    pcol = cy ? pcol - kUbPC : pcol; prow += cy ? 1u : 0u;
+                }
+                if (((vmask >> (pl * PR + r)) & 1u) && prow < (uint32_t)kUbPR) {
                     // padded input rows i0 - 1 + prow, clamped into the buffer: everything outside the image lands on the
                     // zero border, so positions outside the image come out as T = 0 (= the blur's padding) by themselves
-                    const int gy = min(max(im + (int)(pk >> 8), 0), HP - 1), gx_ = min(max(jm + (int)(pk & 255u), 0), WP - 1);
-                    dma_piece(xsrc + pl * plane_b, (uint32_t)(gy * WP + gx_) * 16u, xl + pl * XPLANE + pp * 1024);
+                    const int gy = min(max(sc.im + (int)prow, 0), HP - 1), gx_ = min(max(sc.jm + (int)pcol, 0), WP - 1);
+                    glds16_saddr<0>(xsrc, (uint32_t)(gy * WP + gx_) * 16u + (uint32_t)pl * plb, xl + (uint32_t)(rws[pl] + r * NW * 1024));
                 }
             }
         }
     };
 
     Tile cur = decode(0);
-    issue(cur, 0, 0, 0, NPW);
+    issue(src_of(cur, 0), 0, 0, NSLOT);
     for (int k = 0; k < my_tiles; ++k) {
         const bool more = k + 1 < my_tiles;
         Tile nxt = cur;
@@ -1167,6 +1208,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) pkconv_upblur2_kerne
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             PK_T(0);
             const bool has_next = c + 1 < a.n_chunks;
+            const Src src_nx = src_of(cur, c + 1);           // (past the last chunk: unused)
             const unsigned char* xb = smem_pk + cs * STAGE + (size_t)(half * 2) * XPLANE;
             const unsigned char* wb = smem_pk + cs * STAGE + XST + lane * 16;
             u32x4 bh[NPT][4], bl[NPT][4];       // shift s = 2 a + b: input rows i - 1 + a, columns j - 1 + b
@@ -1193,7 +1235,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) pkconv_upblur2_kerne
                 for (int pt = 0; pt < NPT; ++pt) acc[ph][pt] = mfma16(al, bh[pt][sft], acc[ph][pt]);
 #pragma unroll
                 for (int pt = 0; pt < NPT; ++pt) acc[ph][pt] = mfma16(ah, bl[pt][sft], acc[ph][pt]);
-                if (has_next && tap * PPT < NPW) issue(cur, c + 1, cs ^ 1, tap * PPT, min((tap + 1) * PPT, NPW));
+                if (has_next && tap * PPT < NSLOT) issue(src_nx, cs ^ 1, tap * PPT, min((tap + 1) * PPT, NSLOT));
                 if (tap % 3 == 2) __builtin_amdgcn_sched_barrier(0);
             }
             PK_T(1);
@@ -1229,7 +1271,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) pkconv_upblur2_kerne
                         h1[pt][py][r] = v[0]; h1[pt][py][r + 1] = v[1];
                     }
             __syncthreads();            // round 0: every wave has left the K loop (staging buffer 1 is free); later: the previous round's readers are done
-            if (g4 == 0 && more) issue(nxt, 0, 0, 0, NPW);          // the next tile's first chunk lands in buffer 0 during this epilogue
+            if (g4 == 0 && more) issue(src_of(nxt, 0), 0, 0, NSLOT);          // the next tile's first chunk lands in buffer 0 during this epilogue
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt)
 #pragma unroll
