@@ -841,13 +841,14 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
 #ifdef E3DGE_PHASE_TIMING
         // profiling build: the first floats of `dists` carry thread 0's per-phase cycle counts (tools/phase_timing.py)
         __syncthreads();
-        if (blockIdx.x == 0 && tid == 0 && a.dists) {
+        float* const td = a.dists ? a.dists : a.rgb;       // (the launch on the layer-7 record has no `dists`: its counts overwrite rgb[0..22])
+        if (blockIdx.x == 0 && tid == 0 && td) {
             for (int i = 0; i < 18; ++i)
-                a.dists[i] = (i % 6 == 0) ? (float)(i / 6 ? tstamp[i] - tstamp[i - 1] : 0) : (float)(tstamp[i] - tstamp[i - 1]);
-            a.dists[18] = (float)pipe.t_vm; a.dists[19] = (float)pipe.t_bar;
-            a.dists[20] = (float)(t_loop0 - t_entry);                            // prologue: LDS tables, first weight chunks
-            a.dists[21] = (float)(t_loop1 - t_loop0);                            // all sub-tiles
-            a.dists[22] = (float)(__builtin_readcyclecounter() - t_loop1);       // per-ray outputs (up to this thread's last store)
+                td[i] = (i % 6 == 0) ? (float)(i / 6 ? tstamp[i] - tstamp[i - 1] : 0) : (float)(tstamp[i] - tstamp[i - 1]);
+            td[18] = (float)pipe.t_vm; td[19] = (float)pipe.t_bar;
+            td[20] = (float)(t_loop0 - t_entry);                            // prologue: LDS tables, first weight chunks
+            td[21] = (float)(t_loop1 - t_loop0);                            // all sub-tiles
+            td[22] = (float)(__builtin_readcyclecounter() - t_loop1);       // per-ray outputs (up to this thread's last store)
         }
 #endif
     }
