@@ -26,6 +26,15 @@ from . import _lib
 _FUSE_IMAGES = weakref.WeakKeyDictionary()          # Fuse_sft_MLP -> packed weight images of its nine 256 x 256 blocks
 
 
+def fuse_autograd_backend():
+    """'hip' (default): Fuse_sft_MLP under autograd runs its forward as the nine e3dge_ws_linear launches (_FuseFn);
+    E3DGE_FUSE_AUTOGRAD=torch keeps the torch modules there (A/B, tests)."""
+    v = os.environ.get("E3DGE_FUSE_AUTOGRAD", "hip")
+    if v not in ("hip", "torch"):
+        raise RuntimeError(f"E3DGE_FUSE_AUTOGRAD must be 'hip' or 'torch', got {v!r}")
+    return v
+
+
 def native_fuse_backend():
     """'hip' (default): Fuse_sft_MLP without an autograd graph runs as nine e3dge_ws_linear launches; E3DGE_FUSE=torch keeps
     the library-GEMM modules (A/B, tests)."""
@@ -168,10 +177,15 @@ class Fuse_sft_MLP(nn.Module):
     def fuse(self, enc_in, dec_feat, w=1, out=None, out_off=0):
         """enc_in = cat(enc_feat, dec_feat) already laid out in one buffer (the query kernels write it that way).  With `out`
         (..., ld) the result goes to out[..., out_off:out_off + out_ch] (and that view is returned).
-        GPU, fp32, no autograd graph: nine launches of e3dge_ws_linear (weight-stationary split-f16, csrc/siren_ws.hip); otherwise
-        the torch modules (library GEMMs) -- that is the training path."""
+        GPU, fp32: nine launches of e3dge_ws_linear (weight-stationary split-f16, csrc/siren_ws.hip) -- under autograd as the forward
+        of _FuseFn (E3DGE_FUSE_AUTOGRAD=torch, a non-GPU tensor or an `out` buffer under autograd: the torch modules)."""
         if self._native_ok(enc_in):
-            return self._fuse_native(enc_in, float(w), out, out_off)
+            if not self._wants_grad(enc_in):
+                return self._fuse_native(enc_in, float(w), out, out_off)
+            if out is None and fuse_autograd_backend() == "hip":
+                # training (round 4): the same nine launches as the forward of an autograd node; its backward is library GEMMs on
+                # the intermediates the launches left behind (the 3D-projected block of enc_in IS dec_feat, as on the inference path)
+                return _FuseFn.apply(self, enc_in, float(w), *self._param_list())
         e = self.encode_enc(enc_in)
         res = dec_feat + w * (dec_feat * self.scale(e) + self.shift(e))
         if out is None:
@@ -188,9 +202,17 @@ class Fuse_sft_MLP(nn.Module):
             return False
         if enc_in.shape[-1] != fc0.in_features or self.encode_enc.shortcut is None:
             return False
-        if torch.is_grad_enabled() and (enc_in.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return False
         return all(p.device == enc_in.device and p.dtype == torch.float32 for p in self.parameters())
+
+    def _wants_grad(self, enc_in):
+        return torch.is_grad_enabled() and (enc_in.requires_grad or any(p.requires_grad for p in self.parameters()))
+
+    def _param_list(self):
+        """The thirteen parameters in the order _FuseFn.backward returns their gradients."""
+        e = self.encode_enc
+        return [e.fc_0.weight, e.fc_0.bias, e.fc_1.weight, e.fc_1.bias, e.shortcut.weight,
+                self.scale[0].weight, self.scale[0].bias, self.scale[2].weight, self.scale[2].bias,
+                self.shift[0].weight, self.shift[0].bias, self.shift[2].weight, self.shift[2].bias]
 
     def _images(self, device):
         """Packed weight images (e3dge_ws_pack) of the nine 256 x 256 blocks, bias / mask-column vectors; rebuilt when a
@@ -222,7 +244,9 @@ class Fuse_sft_MLP(nn.Module):
         _FUSE_IMAGES[self] = hit
         return hit
 
-    def _fuse_native(self, enc_in, w, out, out_off):
+    def _fuse_native(self, enc_in, w, out, out_off, keep=None):
+        """`keep` (a dict): every intermediate gets a buffer of its own and is left there for _FuseFn.backward --
+        net (fc_0's output), e (the block's output), s1 / t1 (the SFT branches' hidden activations), scale (the scale branch)."""
         lead = enc_in.shape[:-1]
         x = enc_in.reshape(-1, enc_in.shape[-1])
         if not x.is_contiguous():
@@ -240,6 +264,10 @@ class Fuse_sft_MLP(nn.Module):
             return out[..., out_off:out_off + 256]
         lib = _lib.load()
         A, Bf, C = (torch.empty((N, 256), device=dev, dtype=torch.float32) for _ in range(3))
+        if keep is not None:
+            NET, E, S1, T1 = (torch.empty((N, 256), device=dev, dtype=torch.float32) for _ in range(4))
+        else:
+            NET, E, S1, T1 = Bf, Bf, A, A
         am = torch.zeros((5, _lib.AMAX_FLOATS), device=dev, dtype=torch.float32)       # x, net, e, h1, h2
         st = _lib.stream_of(x)
         b_off = I['b_off']
@@ -259,16 +287,73 @@ class Fuse_sft_MLP(nn.Module):
             _lib.check(lib.e3dge_amax(_lib.ptr(am[0]), _lib.ptr(x), x.numel(), st), "e3dge_amax")
             # ResnetBlockFC: net = fc_0(relu(x)), dx = fc_1(relu(net)), e = shortcut(x) + dx  (K = 513 as two 256-blocks + the mask column)
             lin(I['f0a'], x, ld, 0, am[0], A, pre_relu=True)
-            lin(I['f0b'], x, ld, b_off, am[0], Bf, bias=I['b0'], col=I['f0col'], r1=A, pre_relu=True, amax_out=am[1])
-            lin(I['f1'], Bf, 256, 0, am[1], A, bias=I['b1'], pre_relu=True)
+            lin(I['f0b'], x, ld, b_off, am[0], NET, bias=I['b0'], col=I['f0col'], r1=A, pre_relu=True, amax_out=am[1])
+            lin(I['f1'], NET, 256, 0, am[1], A, bias=I['b1'], pre_relu=True)
             lin(I['sa'], x, ld, 0, am[0], C)
-            lin(I['sb'], x, ld, b_off, am[0], Bf, col=I['scol'], r1=C, r2=A, amax_out=am[2])
-            # SFT branches on e (= Bf), then  dec + w (dec * scale + shift)
-            lin(I['sc1'], Bf, 256, 0, am[2], A, bias=I['bsc1'], post=1, amax_out=am[3])
-            lin(I['sc2'], A, 256, 0, am[3], C, bias=I['bsc2'])
-            lin(I['sh1'], Bf, 256, 0, am[2], A, bias=I['bsh1'], post=1, amax_out=am[4])
-            lin(I['sh2'], A, 256, 0, am[4], o2, ld_y=o2.shape[-1], off_y=out_off, bias=I['bsh2'], r1=x, r1_ld=ld, r1_off=b_off, r2=C, post=2)
+            lin(I['sb'], x, ld, b_off, am[0], E, col=I['scol'], r1=C, r2=A, amax_out=am[2])
+            # SFT branches on e, then  dec + w (dec * scale + shift)
+            lin(I['sc1'], E, 256, 0, am[2], S1, bias=I['bsc1'], post=1, amax_out=am[3])
+            lin(I['sc2'], S1, 256, 0, am[3], C, bias=I['bsc2'])
+            lin(I['sh1'], E, 256, 0, am[2], T1, bias=I['bsh1'], post=1, amax_out=am[4])
+            lin(I['sh2'], T1, 256, 0, am[4], o2, ld_y=o2.shape[-1], off_y=out_off, bias=I['bsh2'], r1=x, r1_ld=ld, r1_off=b_off, r2=C, post=2)
+        if keep is not None:
+            keep.update(x=x, net=NET, e=E, s1=S1, t1=T1, scale=C, b_off=b_off, slope=I['slope'])
         return out[..., out_off:out_off + 256]
+
+
+class _FuseFn(torch.autograd.Function):
+    """Fuse_sft_MLP under autograd: forward = the nine weight-stationary launches of the inference path, keeping
+    net / e / the two hidden SFT activations / the scale branch; backward = the chain rule of sft.py:84-109 + resnetfc.py:49-58
+    written out on those (library GEMMs: d_input, the thirteen parameter gradients).  Not double-differentiable."""
+
+    @staticmethod
+    def forward(ctx, mod, enc_in, w, *params):
+        keep = {}
+        with torch.no_grad():
+            out = mod._fuse_native(enc_in.detach(), w, None, 0, keep=keep)
+        ctx.mod, ctx.w, ctx.in_shape = mod, w, enc_in.shape
+        ctx.b_off, ctx.slope = keep['b_off'], keep['slope']
+        ctx.save_for_backward(keep['x'], keep['net'], keep['e'], keep['s1'], keep['t1'], keep['scale'], *params)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        x, net, e, s1, t1, scale = ctx.saved_tensors[:6]
+        W0, _, W1, _, Ws, Wsc1, _, Wsc2, _, Wsh1, _, Wsh2, _ = ctx.saved_tensors[6:]
+        w, b_off, slope = ctx.w, ctx.b_off, ctx.slope
+        need = ctx.needs_input_grad[3:]
+        need_x = ctx.needs_input_grad[1]
+        g = grad_out.reshape(-1, 256).float()
+        dec = x[:, b_off:]
+        d_scale, d_shift = (w * g) * dec, w * g                   # out = dec + w (dec scale + shift)
+        mm = lambda a, b_: a.t() @ b_
+        gp = [None] * 13
+        # scale = W2 lrelu(W1 e + b1) + b2 ; shift likewise
+        dz1 = (d_scale @ Wsc2) * torch.where(s1 > 0, 1.0, slope)
+        dz2 = (d_shift @ Wsh2) * torch.where(t1 > 0, 1.0, slope)
+        if need[7]: gp[7] = mm(d_scale, s1)
+        if need[8]: gp[8] = d_scale.sum(0)
+        if need[11]: gp[11] = mm(d_shift, t1)
+        if need[12]: gp[12] = d_shift.sum(0)
+        if need[5]: gp[5] = mm(dz1, e)
+        if need[6]: gp[6] = dz1.sum(0)
+        if need[9]: gp[9] = mm(dz2, e)
+        if need[10]: gp[10] = dz2.sum(0)
+        de = dz1 @ Wsc1 + dz2 @ Wsh1
+        # e = shortcut(x) + fc_1(relu(net)) + b1 ; net = fc_0(relu(x)) + b0
+        dnet = (de @ W1) * (net > 0)
+        if need[2]: gp[2] = mm(de, torch.relu(net))
+        if need[3]: gp[3] = de.sum(0)
+        if need[4]: gp[4] = mm(de, x)
+        if need[0]: gp[0] = mm(dnet, torch.relu(x))
+        if need[1]: gp[1] = dnet.sum(0)
+        dx = None
+        if need_x:
+            dx = de @ Ws + (dnet @ W0) * (x > 0)
+            dx[:, b_off:] += g * (1.0 + w * scale)
+            dx = dx.reshape(ctx.in_shape)
+        return (None, dx, None, *gp)
 
 
 def local_features_from_maps(local_data_batch, n_freqs=7):

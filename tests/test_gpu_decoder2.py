@@ -361,3 +361,70 @@ def test_fuse_sft_mlp_native_against_float64(in_ch, n_pts, mag, monkeypatch):
         xg2 = xg.clone().requires_grad_(True)
         y = mg.fuse(xg2, xg2[..., in_ch:], w=0.7)
         assert y.requires_grad
+
+
+@pytest.mark.parametrize("in_ch,n_pts", [(257, 777), (256, 130)])
+def test_fuse_sft_mlp_under_autograd_against_float64(in_ch, n_pts, monkeypatch):
+    """Fuse_sft_MLP with a graph (stage-2 training, e3dge_full_runner.py:185-317): the forward is the nine weight-stationary launches
+    (_FuseFn), the backward the written-out chain rule of sft.py:84-109 + resnetfc.py:49-58.  d(input) and all thirteen parameter
+    gradients against float64 autograd of the same network on the CPU.  relu / leaky relu have kinks: a pre-activation within rounding
+    of zero may sit on the other side in float64, and ONE such flip moves a few gradient entries by O(1) -- so the float64 reference
+    takes its activation pattern from the forward under test (the derivative of the function that was actually computed), and the
+    forward itself is held to float64 separately.  Tolerance 2e-5 of each gradient's maximum."""
+    import copy
+    import torch.nn.functional as F
+    m = _fuse_module(in_ch, seed=11 + n_pts)
+    m64 = copy.deepcopy(m).double()
+    torch.manual_seed(5)
+    enc_in = torch.randn(2, n_pts, in_ch + 256)
+    if in_ch == 257:
+        enc_in[..., 256] = (torch.rand(2, n_pts) > 0.4).float()
+    gy = torch.randn(2, n_pts, 256)
+    mg = m.to(DEV)
+    # the forward under test, its intermediates, and the plain float64 forward
+    keep = {}
+    with torch.no_grad():
+        y_nat = mg._fuse_native(enc_in.to(DEV), 0.7, None, 0, keep=keep)
+        y64 = m64.fuse(enc_in.double(), enc_in.double()[..., in_ch:], w=0.7)
+    assert float((y_nat.cpu().double() - y64).abs().max()) <= 2e-5 * float(y64.abs().max())
+    m_net, m_s1, m_t1 = ((keep[k] > 0).cpu().reshape(2, n_pts, 256) for k in ("net", "s1", "t1"))
+    # float64 autograd with that activation pattern
+    x64 = enc_in.double().requires_grad_(True)
+    e_ = m64.encode_enc
+    net = e_.fc_0(x64 * (x64 > 0))
+    e = e_.shortcut(x64) + e_.fc_1(net * m_net)
+    lk = lambda z, msk: z * torch.where(msk, 1.0, 0.2).double()
+    sc = m64.scale[2](lk(m64.scale[0](e), m_s1))
+    sh = m64.shift[2](lk(m64.shift[0](e), m_t1))
+    dec = x64[..., in_ch:]
+    y_ref = dec + 0.7 * (dec * sc + sh)
+    assert float((y_ref.detach() - y64).abs().max()) <= 1e-4 * float(y64.abs().max())    # (the patterns differ in at most a few entries)
+    (y_ref * gy.double()).sum().backward()
+    ref = [x64.grad] + [p.grad for p in m64.parameters()]
+    # the node under test
+    xg = enc_in.to(DEV).requires_grad_(True)
+    y = mg.fuse(xg, xg[..., in_ch:], w=0.7)
+    assert "_FuseFn" in type(y.grad_fn).__name__
+    assert float((y.detach() - y_nat).abs().max()) == 0.0
+    (y * gy.to(DEV)).sum().backward()
+    got = [xg.grad] + [p.grad for p in mg.parameters()]
+    labels = ["d_input"] + [n for n, _ in m.named_parameters()]
+    assert labels[1:] == [
+        "encode_enc.fc_0.weight", "encode_enc.fc_0.bias", "encode_enc.fc_1.weight", "encode_enc.fc_1.bias", "encode_enc.shortcut.weight",
+        "scale.0.weight", "scale.0.bias", "scale.2.weight", "scale.2.bias", "shift.0.weight", "shift.0.bias", "shift.2.weight", "shift.2.bias"]
+    worst = 0.0
+    for lab, r, a in zip(labels, ref, got):
+        assert a is not None and a.shape == r.shape, lab
+        scale = float(r.abs().max())
+        err = float((a.cpu().double() - r).abs().max())
+        worst = max(worst, err / max(scale, 1e-30))
+        assert err <= 2e-5 * scale, (lab, err, scale)
+    record("fuse_sft_mlp_autograd", in_ch=in_ch, n=n_pts, worst_rel_err=worst)
+    # E3DGE_FUSE_AUTOGRAD=torch and an `out` buffer under autograd take the module path
+    monkeypatch.setenv("E3DGE_FUSE_AUTOGRAD", "torch")
+    x2 = enc_in.to(DEV).requires_grad_(True)
+    assert "_FuseFn" not in type(mg.fuse(x2, x2[..., in_ch:], w=0.7).grad_fn).__name__
+    monkeypatch.delenv("E3DGE_FUSE_AUTOGRAD")
+    wide = torch.zeros(2, n_pts, 301, device=DEV)
+    y2 = mg.fuse(x2, x2[..., in_ch:], w=0.7, out=wide, out_off=0)
+    assert y2.requires_grad and "_FuseFn" not in type(y2.grad_fn).__name__

@@ -1,0 +1,44 @@
+"""Fuse_sft_MLP under autograd at the inversion forward's size (98,304 points): forward + backward, the native forward of
+_FuseFn against the torch modules (E3DGE_FUSE_AUTOGRAD=torch)."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import e3dge_amd  # noqa
+from e3dge_amd.local_query import Fuse_sft_MLP
+
+dev = "cuda:0"
+torch.manual_seed(0)
+m = Fuse_sft_MLP().to(dev)
+with torch.no_grad():
+    for p in m.parameters():
+        p.copy_(torch.randn_like(p) * (0.1 if p.ndim == 1 else 1.0 / p.shape[1] ** 0.5))
+N = 64 * 64 * 24
+x = torch.randn(1, N, 513, device=dev)
+g = torch.randn(1, N, 256, device=dev)
+
+
+def step(fwd_only):
+    xr = x.clone().requires_grad_(True)
+    y = m.fuse(xr, xr[..., 257:])
+    if not fwd_only:
+        for p in m.parameters():
+            p.grad = None
+        y.backward(g)
+    return y
+
+
+def ms(fn, n=10):
+    fn(); fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+res = {}
+for mode in ("hip", "torch"):
+    os.environ["E3DGE_FUSE_AUTOGRAD"] = mode
+    res[mode] = {"node": type(step(True).grad_fn).__name__, "fwd_ms": round(ms(lambda: step(True)), 3), "fwd_bwd_ms": round(ms(lambda: step(False)), 3)}
+print(json.dumps({"what": "Fuse_sft_MLP under autograd, 98,304 points (times include the clone of the input)", **res}))
