@@ -1881,7 +1881,6 @@ static int conv_s1(PkConvK k, hipStream_t st) {
         return launch_s1<2, 1, 2, 1, 8, 1, 2>(k, st, "dec2 conv+store+rgb<64co,8x64>");
     }
     if (k.rgb_out) {
-        if (k.Co == 32 && shape_override("E3DGE_DEC2_S1_RGB32") == 1) return launch_s1<1, 2, 1, 1, 4, 1, 1>(k, st, "dec2 conv+rgb<32co,8x32,4w>");
         if (k.Co == 32) return launch_s1<1, 1, 2, 1, 8, 1, 1>(k, st, "dec2 conv+rgb<32co,8x64>");
         return launch_s1<2, 1, 2, 1, 8, 1, 1>(k, st, "dec2 conv+rgb<64co,8x64>");
     }

@@ -202,10 +202,10 @@ class Fuse_sft_MLP(nn.Module):
             return False
         if enc_in.shape[-1] != fc0.in_features or self.encode_enc.shortcut is None:
             return False
-        return all(p.device == enc_in.device and p.dtype == torch.float32 for p in self.parameters())
+        return all(p.device == enc_in.device and p.dtype == torch.float32 for p in _lib.params_of(self))
 
     def _wants_grad(self, enc_in):
-        return torch.is_grad_enabled() and (enc_in.requires_grad or any(p.requires_grad for p in self.parameters()))
+        return torch.is_grad_enabled() and (enc_in.requires_grad or any(p.requires_grad for p in _lib.params_of(self)))
 
     def _param_list(self):
         """The thirteen parameters in the order _FuseFn.backward returns their gradients."""
@@ -217,7 +217,7 @@ class Fuse_sft_MLP(nn.Module):
     def _images(self, device):
         """Packed weight images (e3dge_ws_pack) of the nine 256 x 256 blocks, bias / mask-column vectors; rebuilt when a
         parameter changes.  Kept outside the module (weak map): modules stay deep-copyable and state_dict-clean."""
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (str(device),)
+        key = _lib.param_key(self) + (str(device),)
         hit = _FUSE_IMAGES.get(self)
         if hit is not None and hit['key'] == key:
             return hit

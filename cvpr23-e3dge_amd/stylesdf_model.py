@@ -625,7 +625,7 @@ class Decoder(nn.Module):
 
     def _needs_graph(self, features, latent):
         return torch.is_grad_enabled() and (features.requires_grad or latent.requires_grad or
-                                            any(p.requires_grad for p in self.parameters()))
+                                            any(p.requires_grad for p in _lib.params_of(self)))
 
     def _noise_amax(self, nz):
         """amax buffer with max|noise| (the packed producers need it for their operand-scale bound).  Cached only for the
@@ -659,7 +659,7 @@ class Decoder(nn.Module):
         convs3 = [self.conv1] + list(self.convs)
         rgbs = [self.to_rgb1] + list(self.to_rgbs)
         tab = self._style_table(B, device)                 # has its own cache; rebuilt when a modulation layer / wsq changes
-        pkey = (id(tab[0]),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        pkey = (id(tab[0]),) + _lib.param_key(self)
         slot = (B, res, str(device), torch.cuda.current_stream(device).cuda_stream)
         states = _DEC2_STATES.setdefault(self, {})      # module level (weak): ctypes plans must not sit on a deep-copyable module
         hit = states.get(slot)

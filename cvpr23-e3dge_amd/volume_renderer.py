@@ -216,7 +216,7 @@ class SirenGenerator(nn.Module):
         return list(self.pts_linears) + [self.views_linears]
 
     def _key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return _lib.param_key(self)
 
     def invalidate(self):
         """Drop the packed weight image.  The cache is keyed on (data_ptr, _version) of every parameter, which catches
@@ -228,6 +228,7 @@ class SirenGenerator(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self.invalidate()
+        _lib.forget_params(self)
         return super()._apply(fn, *a, **k)
 
     def train(self, mode=True):
@@ -301,6 +302,8 @@ class SirenGenerator(nn.Module):
         """The HIP backward returns gradients for the styles (and, where stated, points / texture FiLM) only; the
         reference can also train the renderer (Generator.train_renderer = not freeze_renderer).  Make the frozen
         generator an explicit precondition instead of a silent no-op."""
+        if not any(p.requires_grad for p in _lib.params_of(self)):       # (the cheap check first: named_parameters() walks the tree, 120 us)
+            return
         hot = [n for n, p in self.named_parameters() if p.requires_grad]
         if hot:
             raise NotImplementedError(
@@ -444,6 +447,7 @@ class _PointsQuery(torch.autograd.Function):
     @staticmethod
     def forward(ctx, styles, siren, pts, viewdirs, box_scale, mfma_mode, want_eik):
         B, N = pts.shape[0], pts.shape[1]
+        ctx.set_materialize_grads(False)               # (unused outputs arrive as None in backward, not as zero tensors: a fill each)
         args = torch.empty((B, N, 9, siren.W), device=pts.device, dtype=torch.float32)
         film = siren.film_params(styles)
         sdf, raw = siren._points_launch(film, pts, viewdirs, box_scale, True, mfma_mode, args)
@@ -527,6 +531,9 @@ class _RenderQuery(torch.autograd.Function):
     @staticmethod
     def forward(ctx, styles, renderer, focal, c2w, near, far, want_eik, tex_alpha, tex_beta, shared=None):
         B, H, S = c2w.shape[0], renderer.out_im_res, renderer.N_samples
+        # seven differentiable outputs, a stage-1 loss touches three: without this autograd hands backward a zero tensor for each of the
+        # others (a fill + a transposing copy per output, and the kernels then read and add the zeros)
+        ctx.set_materialize_grads(False)
         film = renderer.siren.film_params(styles)
         args = torch.empty((B, H * H * S, 9, renderer.siren.W), device=c2w.device, dtype=torch.float32)
         tex = None if tex_alpha is None else (tex_alpha.detach(), tex_beta.detach())
