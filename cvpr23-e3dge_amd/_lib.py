@@ -256,6 +256,26 @@ def param_key(module):
     return tuple((q.data_ptr(), q._version) for q in params_of(module))
 
 
+class on_device:
+    """`with on_device(dev):` = torch.cuda.device(dev) when `dev` is not already the current device, nothing otherwise (the context
+    manager costs ~10 us of host time per launch wrapper; a single-GPU process never needs it)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        import torch
+        idx = dev.index if hasattr(dev, "index") else dev
+        self.ctx = None if idx is None or torch.cuda.current_device() == idx else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
+
+
 def require_gpu(t, name, half_ok=False):
     """`half_ok`: the two stream ops (fused_bias_act, upfirdn2d) also take float16, as the reference's do."""
     import torch

@@ -269,7 +269,7 @@ class SirenGenerator(nn.Module):
                     self.sigma_linear.std_init != 1 or self.sigma_linear.bias_init != 0:
                 raise NotImplementedError("head LinearLayers with std_init != 1 / bias_init != 0")
             packed = torch.empty(lib.e3dge_siren_packed_floats(), **f32)
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 rc = lib.e3dge_siren_pack_weights(
                     _lib.ptr(packed), _lib.ptr(w_first), _lib.ptr(b_first), _lib.ptr(w_hidden), _lib.ptr(b_hidden),
                     _lib.ptr(w_view), _lib.ptr(b_view), _lib.ptr(w_rgb), _lib.ptr(b_rgb), _lib.ptr(w_sig),
@@ -322,7 +322,7 @@ class SirenGenerator(nn.Module):
         _, wg, bg, wb, bb = self.device_image()
         B = styles.shape[0]
         film = torch.empty((B, 9, 2, self.W), device=styles.device, dtype=torch.float32)
-        with torch.cuda.device(styles.device):
+        with _lib.on_device(styles.device):
             rc = _lib.load().e3dge_film_params(_lib.ptr(film), _lib.ptr(styles), _lib.ptr(wg), _lib.ptr(bg),
                                                _lib.ptr(wb), _lib.ptr(bb), B, _lib.stream_of(styles))
         _lib.check(rc, "e3dge_film_params")
@@ -361,7 +361,7 @@ class SirenGenerator(nn.Module):
         raw = torch.empty((B, N, 260), device=pts.device, dtype=torch.float32) if want_raw else None
         if B == 0 or N == 0:
             return sdf, raw
-        with torch.cuda.device(pts.device):
+        with _lib.on_device(pts.device):
             rc = _lib.load().e3dge_siren_points_fwd(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(pts), _lib.ptr(vd),
                                                     float(box_scale), B, N, _lib.ptr(sdf), _lib.ptr(raw), _lib.ptr(save_args),
                                                     self.check_mode(mfma_mode or self.mfma_mode), _lib.stream_of(pts))
@@ -385,7 +385,7 @@ def sdf_gradient(siren, film, args, box_scale):
     B, N = args.shape[0], args.shape[1]
     rsave = torch.empty((B, N, 8, siren.W), device=args.device, dtype=torch.float32)
     eik = torch.empty((B, N, 3), device=args.device, dtype=torch.float32)
-    with torch.cuda.device(args.device):
+    with _lib.on_device(args.device):
         rc = _lib.load().e3dge_siren_sdf_grad(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), None, float(box_scale),
                                               B, N, _lib.ptr(rsave), _lib.ptr(eik), siren.check_mode(siren.bwd_mode),
                                               _lib.stream_of(args))
@@ -393,13 +393,15 @@ def sdf_gradient(siren, film, args, box_scale):
     return eik, rsave
 
 
-def tangent_arguments(siren, film, args, v, box_scale):
-    """Tangent arguments (B,N,8,256) along v = dL/de (B,N,3) (e3dge_siren_tangent)."""
-    packed = siren.device_image()[0]
+def tangent_arguments(siren, film, args, v, box_scale, images=None):
+    """Tangent arguments (B,N,8,256) along v = dL/de (B,N,3) (e3dge_siren_tangent).  `images`: siren.device_image() as the forward
+    of the same autograd node saw it (a backward differentiates the weights its saved arguments were computed with, and skipping the
+    cache-key check keeps ~20 us of host time out of the gap in front of the launch)."""
+    packed = (images if images is not None else siren.device_image())[0]
     B, N = args.shape[0], args.shape[1]
     v = v.reshape(B, N, 3).contiguous().float()
     tang = torch.empty((B, N, 8, siren.W), device=args.device, dtype=torch.float32)
-    with torch.cuda.device(args.device):
+    with _lib.on_device(args.device):
         rc = _lib.load().e3dge_siren_tangent(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), _lib.ptr(v), float(box_scale),
                                              B, N, _lib.ptr(tang), siren.check_mode(siren.bwd_mode), _lib.stream_of(args))
     _lib.check(rc, "e3dge_siren_tangent")
@@ -407,12 +409,12 @@ def tangent_arguments(siren, film, args, v, box_scale):
 
 
 def siren_backward(siren, film, args, d_feat, d_rgb, d_sdf, tang=None, rsave=None, want_d_pts=False, box_scale=1.0,
-                   tex_alpha=None):
+                   tex_alpha=None, images=None):
     """dL/d(styles) (B,9,256) and dL/d(film) (B,9,2,256) from the per-point output gradients (e3dge_siren_bwd).
     args (B,N,9,256) are the forward launch's saved pre-sine arguments; any of d_feat (B,N,256), d_rgb (B,N,3),
     d_sdf (B,N) may be None.  tang + rsave add the gradient of a loss on the eikonal term.  Returns
     (dstyles, dfilm, d_pts or None, (d_alpha, d_beta) or None)."""
-    packed, wg, _, wb, _ = siren.device_image()
+    packed, wg, _, wb, _ = images if images is not None else siren.device_image()
     B, N = args.shape[0], args.shape[1]
     dev = args.device
     lib = _lib.load()
@@ -432,7 +434,7 @@ def siren_backward(siren, film, args, d_feat, d_rgb, d_sdf, tang=None, rsave=Non
         tex_alpha=_lib.ptr(tex_alpha), batch=B, precision=siren.check_mode(siren.bwd_mode), n_pts=N, box_scale=float(box_scale),
         partials=_lib.ptr(partials), dfilm=_lib.ptr(dfilm), dstyles=_lib.ptr(dstyles), d_pts=_lib.ptr(d_pts),
         d_tex_alpha=_lib.ptr(d_ta), d_tex_beta=_lib.ptr(d_tb))
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.e3dge_siren_bwd(ctypes.byref(a), _lib.stream_of(args))
     _lib.check(rc, "e3dge_siren_bwd")
     return dstyles, dfilm, d_pts, (None if d_ta is None else (d_ta, d_tb))
@@ -452,6 +454,7 @@ class _PointsQuery(torch.autograd.Function):
         film = siren.film_params(styles)
         sdf, raw = siren._points_launch(film, pts, viewdirs, box_scale, True, mfma_mode, args)
         ctx.siren, ctx.styles_ndim, ctx.box_scale = siren, styles.ndim, float(box_scale)
+        ctx.images = siren.device_image()
         if want_eik:
             eik, rsave = sdf_gradient(siren, film, args, box_scale)
         else:
@@ -471,9 +474,9 @@ class _PointsQuery(torch.autograd.Function):
             ds = d_raw[..., 3] if ds is None else ds + d_raw[..., 3]
         tang = rs = None
         if ctx.want_eik and d_eik is not None:
-            tang, rs = tangent_arguments(ctx.siren, film, args, d_eik, ctx.box_scale), rsave
+            tang, rs = tangent_arguments(ctx.siren, film, args, d_eik, ctx.box_scale, ctx.images), rsave
         dstyles, _, d_pts, _ = siren_backward(ctx.siren, film, args, d_feat, d_rgb, ds, tang, rs,
-                                              want_d_pts=ctx.needs_input_grad[2], box_scale=ctx.box_scale)
+                                              want_d_pts=ctx.needs_input_grad[2], box_scale=ctx.box_scale, images=ctx.images)
         if ctx.styles_ndim == 2:                   # one W shared by the nine layers (reference :189-191)
             dstyles = dstyles.sum(1)
         return (dstyles if ctx.needs_input_grad[0] else None), None, d_pts, None, None, None, None
@@ -485,10 +488,10 @@ _AUX_KEYS = ('mask', 'points', 'rays_d', 'viewdirs', 'dists')
 
 class _EikShared:
     """What the eikonal tap below and _RenderQuery.backward share: the tangent arguments of the incoming d(eikonal term)."""
-    __slots__ = ("siren", "film", "args", "box_scale", "tang", "d_eik")
+    __slots__ = ("siren", "film", "args", "box_scale", "tang", "d_eik", "images")
 
     def __init__(self):
-        self.siren = self.film = self.args = self.box_scale = self.tang = self.d_eik = None
+        self.siren = self.film = self.args = self.box_scale = self.tang = self.d_eik = self.images = None
 
 
 class _EikTap(torch.autograd.Function):
@@ -507,7 +510,7 @@ class _EikTap(torch.autograd.Function):
         sh = ctx.shared
         if d_eik is not None and sh.args is not None:
             sh.d_eik = d_eik
-            sh.tang = tangent_arguments(sh.siren, sh.film, sh.args, d_eik, sh.box_scale)
+            sh.tang = tangent_arguments(sh.siren, sh.film, sh.args, d_eik, sh.box_scale, sh.images)
         return d_eik, None
 
 
@@ -548,11 +551,13 @@ class _RenderQuery(torch.autograd.Function):
         else:
             out['eikonal_term'], rsave = torch.empty(0, device=c2w.device), torch.empty(0, device=c2w.device)
         ctx.renderer, ctx.styles_ndim, ctx.want_eik = renderer, styles.ndim, want_eik
+        ctx.images = renderer.siren.device_image()
         ctx.sigmoid_beta = renderer._sigmoid_beta_value()
         ctx.has_tex = tex is not None
         ctx.shared = shared
         if shared is not None:
             shared.siren, shared.film, shared.args, shared.box_scale = renderer.siren, film, args, renderer.box_scale
+            shared.images = renderer.siren.device_image()
         ta = tex[0].contiguous() if tex is not None else torch.empty(0, device=c2w.device)
         ctx.save_for_backward(film, args, out['sdf'], out['dists'], out['points'], out['hit_prob'],
                               near.reshape(B).contiguous().float(), far.reshape(B).contiguous().float(), rsave, ta)
@@ -573,7 +578,7 @@ class _RenderQuery(torch.autograd.Function):
         d_depth_map = None if d_depth is None else d_depth.reshape(B, H * H).contiguous().float()
         d_sdf_in = None if d_sdf is None else d_sdf.reshape(B, H * H * S).contiguous().float()
         d_w_in = None if d_hit is None else d_hit.reshape(B, H * H * S).contiguous().float()
-        packed, wg, _, wb, _ = siren.device_image()
+        packed, wg, _, wb, _ = ctx.images
         lib = _lib.load()
         n_pts = H * H * S
         partials = torch.empty(max(lib.e3dge_siren_bwd_partial_floats(B, n_pts), 1), device=dev, dtype=torch.float32)
@@ -588,9 +593,9 @@ class _RenderQuery(torch.autograd.Function):
                     and sh.d_eik.shape == d_eik.shape):                     # launched early by _EikTap.backward
                 tang = sh.tang
             else:
-                tang = tangent_arguments(siren, film, args, d_eik, r.box_scale)
+                tang = tangent_arguments(siren, film, args, d_eik, r.box_scale, ctx.images)
             if sh is not None:
-                sh.tang = sh.d_eik = sh.args = sh.film = None
+                sh.tang = sh.d_eik = sh.args = sh.film = sh.images = None
             rs = rsave
         d_ta = d_tb = tex_a = None
         if ctx.has_tex:
@@ -607,7 +612,7 @@ class _RenderQuery(torch.autograd.Function):
             force_background=int(bool(r.force_background)), precision=siren.check_mode(siren.bwd_mode), d_rgb_pts=_lib.ptr(d_rgb_pts), d_sdf_pts=_lib.ptr(d_sdf_pts),
             partials=_lib.ptr(partials), dfilm=_lib.ptr(dfilm), dstyles=_lib.ptr(dstyles), d_tex_alpha=_lib.ptr(d_ta),
             d_tex_beta=_lib.ptr(d_tb))
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = lib.e3dge_siren_render_bwd(ctypes.byref(a), _lib.stream_of(film))
         _lib.check(rc, "e3dge_siren_render_bwd")
         if ctx.styles_ndim == 2:
@@ -690,7 +695,7 @@ class ResnetBlockFC(nn.Module):
             lib = _lib.load()
             packed = torch.empty(lib.e3dge_resblock_packed_floats(), device=dev, dtype=torch.float32)
             c = [p.detach().contiguous().float() for p in ps]
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 rc = lib.e3dge_resblock_pack_weights(_lib.ptr(packed), *[_lib.ptr(t) for t in c], self.size_in,
                                                      torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(rc, "e3dge_resblock_pack_weights")
@@ -711,7 +716,7 @@ class ResnetBlockFC(nn.Module):
         alpha = torch.empty((n, 256), device=f.device, dtype=torch.float32)
         beta = torch.empty((n, 256), device=f.device, dtype=torch.float32)
         packed = self.device_image()
-        with torch.cuda.device(f.device):
+        with _lib.on_device(f.device):
             rc = _lib.load().e3dge_tex_modulations_fwd(_lib.ptr(packed), _lib.ptr(f), self.size_in, n, _lib.ptr(alpha),
                                                        _lib.ptr(beta), _lib.stream_of(f))
         _lib.check(rc, "e3dge_tex_modulations_fwd")
@@ -725,7 +730,7 @@ class ResnetBlockFC(nn.Module):
         if f.shape[0] != B * H * W * S:
             raise RuntimeError(f"local features {tuple(feats.shape)} do not match the render ({B},{H},{W},{S},{self.size_in})")
         packed = self.device_image()
-        with torch.cuda.device(f.device):
+        with _lib.on_device(f.device):
             rc = _lib.load().e3dge_tex_film_fwd(_lib.ptr(packed), _lib.ptr(f), self.size_in, B, H, W, S, _lib.ptr(record_in),
                                                 _lib.ptr(record_out), _lib.stream_of(f))
         _lib.check(rc, "e3dge_tex_film_fwd")
@@ -1024,7 +1029,7 @@ class VolumeFeatureRenderer(nn.Module):
             save_args=_lib.ptr(save_args), backbone_out=_lib.ptr(bb_out),
             backbone_in=_lib.ptr(bb_in) if use is not None else None,
             weights_in=_lib.ptr(use['out']['weights']) if use is not None else None)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.load().e3dge_siren_render_fwd(ctypes.byref(args), _lib.stream_of(c2w))
         _lib.check(rc, "e3dge_siren_render_fwd")
         if bb_out is not None:
@@ -1225,7 +1230,7 @@ class VolumeFeatureRenderer(nn.Module):
             q = torch.empty((B, N * S * Sn, 3), device=dev, dtype=torch.float32)
             aux = torch.empty((B, N, S, 4), device=dev, dtype=torch.float32)
             out = torch.empty((B, N, S), device=dev, dtype=torch.float32)
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 st = _lib.stream_of(pts)
                 # launch 1: the Sn samples of the reference camera's ray through every point + where the point sits between them
                 _lib.check(lib.e3dge_hitprob_points(_lib.ptr(q), _lib.ptr(aux), _lib.ptr(pts), _lib.ptr(pc), _lib.ptr(ec), _lib.ptr(near),
