@@ -126,7 +126,8 @@ def test_every_stage_against_the_planar_kernels(gen256, form, monkeypatch):
     assert torch.equal(img2, img_fused)
 
 
-@pytest.mark.parametrize("B,res,size,per_sample_noise", [(2, 16, 128, True), (1, 8, 32, False), (3, 16, 64, False)])
+@pytest.mark.parametrize("B,res,size,per_sample_noise", [(2, 16, 128, True), (1, 8, 32, False), (3, 16, 64, False),
+                                                         (2, 128, 512, True)])      # 256^2 level: 64 channels, NOT the last -> conv + store + ToRGB
 def test_image_against_the_oracle_small_shapes(B, res, size, per_sample_noise):
     g, sd = full_state_dict(size=size, cm=1, res=res)
     g = g.to(DEV).eval()
