@@ -429,3 +429,25 @@ def test_fuse_sft_mlp_under_autograd_against_float64(in_ch, n_pts, monkeypatch):
     wide = torch.zeros(2, n_pts, 301, device=DEV)
     y2 = mg.fuse(x2, x2[..., in_ch:], w=0.7, out=wide, out_off=0)
     assert y2.requires_grad and "_FuseFn" not in type(y2.grad_fn).__name__
+
+
+def test_mid_level_torgb_in_the_epilogue_matches_the_stand_alone_launch(monkeypatch):
+    """512^2 decoder from 128^2 features: the 256^2 level has 64 channels and is not the last, so its ToRGB rides in the convolution's
+    epilogue (pkconv_s1_kernel, RGB = 2: activation stored AND reduced).  Against the same forward with the stand-alone ToRGB launch
+    (E3DGE_DEC2_FUSE_RGB_MID=0): the two sum the 64 channels in different orders -- 1e-5 of the image's range; and the stored
+    activation of that level is the same bits either way (the next level reads it)."""
+    g, _ = full_state_dict(size=512, cm=1, res=128)
+    dec = g.to(DEV).eval().decoder
+    _, wd = syn.synthetic_inputs(1, seed=9, device=DEV)
+    wd = wd[:, :dec.n_latent].contiguous()
+    feats = (0.7 * torch.randn(1, 256, 128, 128, device=DEV, generator=torch.Generator(DEV).manual_seed(3))).contiguous()
+    with torch.no_grad():
+        img, _ = dec(feats, [wd], input_is_latent=True, randomize_noise=False)
+        act = dec.dec2_unpack(3, feats.shape).clone()                 # output of the 256^2 level's stride-1 convolution
+        monkeypatch.setenv("E3DGE_DEC2_FUSE_RGB_MID", "0")
+        img0, _ = dec(feats, [wd], input_is_latent=True, randomize_noise=False)
+        act0 = dec.dec2_unpack(3, feats.shape)
+    assert tuple(act.shape) == (1, 64, 256, 256) and float((act - act0).abs().max()) == 0.0
+    err, scale = float((img - img0).abs().max()), float(img0.abs().max())
+    record("dec2_mid_torgb", err=err, img_max=scale)
+    assert err <= 1e-5 * max(scale, 1.0)
