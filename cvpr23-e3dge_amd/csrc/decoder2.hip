@@ -503,25 +503,32 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
         // (Branch-free: a load inside a divergent `if` gets its own s_waitcnt vmcnt(0) -- twelve serialized L2 round trips per pixel tile
         // for the skip image in the first version of this block.  Indices are clamped into the image, out-of-image taps get weight 0.)
         if (last_chunk) {
+            // One 64-bit base per image (wave-uniform, in SGPRs) and unsigned 32-bit per-lane offsets: as `p ? p[i64] : 0` every one of
+            // the 26 loads per pixel tile carried its own branch and 64-bit address arithmetic (6.2 scalar instructions per MFMA in the
+            // fused-ToRGB kernel, PMC).  A missing noise / skip image reads a finite dummy (the bias table) that gets weight 0.
+            const bool has_nz = a.noise != nullptr, has_sk = RGB && a.rgb_skip != nullptr;
+            const int h2 = a.H >> 1, w2 = a.W >> 1;
+            const float* __restrict__ nbase = has_nz ? a.noise + (int64_t)(a.noise_batch > 1 ? p_cur.b : 0) * a.H * a.W : a.bias;
+            const float* __restrict__ sbase = has_sk ? a.rgb_skip + (int64_t)p_cur.b * 3 * h2 * w2 : a.bias;
+            const unsigned splane = has_sk ? (unsigned)(h2 * w2) : 0u;
 #pragma unroll
             for (int pt = 0; pt < NPT; ++pt) {
                 const int oy = p_cur.ty * TH + prow0 + pt / NPX, ox = p_cur.tx * TW + pcol0 + 32 * (pt % NPX);
                 const int oyc = min(oy, a.H - 1), oxc = min(ox, a.W - 1);
-                nzr[pt] = a.noise ? a.noise[(int64_t)(a.noise_batch > 1 ? p_cur.b : 0) * a.H * a.W + (int64_t)oyc * a.W + oxc] : 0.0f;
+                nzr[pt] = nbase[has_nz ? (unsigned)(oyc * a.W + oxc) : 0u];
                 if (RGB) {
                     // raw taps (skip_combine above)
-                    const int h2 = a.H >> 1, w2 = a.W >> 1;
 #pragma unroll
                     for (int p2 = 0; p2 < 2; ++p2) {        // upfirdn2d(skip, fir, up=2, pad=(2,1)): taps and order of e3dge_upfirdn2d
                         const int ky = (oyc & 1) + 2 * p2, iy = (oyc + ky - 2) >> 1;
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             const int kx = (oxc & 1) + 2 * e, ix = (oxc + kx - 2) >> 1;
-                            const int off = min(max(iy, 0), h2 - 1) * w2 + min(max(ix, 0), w2 - 1);
-                            fwr[pt][2 * p2 + e] = a.rgb_skip ? a.rgb_fir[(3 - ky) * 4 + (3 - kx)] : 0.0f;
+                            const unsigned off = has_sk ? (unsigned)(min(max(iy, 0), h2 - 1) * w2 + min(max(ix, 0), w2 - 1)) : 0u;
+                            const float f = a.rgb_fir[(unsigned)((3 - ky) * 4 + (3 - kx))];
+                            fwr[pt][2 * p2 + e] = has_sk ? f : 0.0f;
 #pragma unroll
-                            for (int c = 0; c < 3; ++c)
-                                svr[pt][c][2 * p2 + e] = a.rgb_skip ? a.rgb_skip[((int64_t)p_cur.b * 3 + c) * h2 * w2 + off] : 0.0f;
+                            for (int c = 0; c < 3; ++c) svr[pt][c][2 * p2 + e] = sbase[c * splane + off];
                         }
                     }
                     if (!DEFER) skip_combine(pt);
