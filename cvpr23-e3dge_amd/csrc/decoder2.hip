@@ -77,10 +77,6 @@ __device__ __forceinline__ float dpp_wave_shl1(float v) {
 // ---------------------------------------------------------------------------------------------------------------------
 // fp32 (B, C, R, R) <-> packed
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) pk_zero_kernel(float* __restrict__ p, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = 0.0f;
-}
 
 __global__ void __launch_bounds__(256)
 pk_pack_kernel(uint32_t* __restrict__ out, int* __restrict__ meta, const float* __restrict__ x, const float* __restrict__ amax,
@@ -2037,19 +2033,14 @@ extern "C" int e3dge_dec2_forward(const E3dgeDec2Plan* P, e3dge_stream_t stream)
     };
 #define DEC2_STEP(expr) do { rc = (expr); if (rc) return finish(rc); mark(); } while (0)
 
-    // The amax block is zeroed by a KERNEL, not by hipMemsetAsync: captured into a HIP graph, the memset node was observed to run
-    // out of order with the kernels behind it (round 4: replays of the inversion forward came back with a handful of discrete wrong
-    // images -- the amax of the packed features or of a later activation zeroed after its producer had written it; eager launches
-    // and most replays were fine, tools/graph_debug.py).  A kernel node keeps the stream order.
-    {
-        const int n = E3DGE_AMAX_FLOATS * (3 * P->n_up + 2);
-        pk_zero_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(P->amax, n);
-        rc = check_launch("dec2 zero(amax)");
-        if (rc) return rc;
-    }
+    // The amax block is zeroed by a KERNEL (the styles launch, the first of a forward), not by hipMemsetAsync: captured into a HIP graph,
+    // the memset node was observed to run out of order with the kernels behind it (round 4: replays of the inversion forward came back
+    // with a handful of discrete wrong images -- the amax of the packed features or of a later activation zeroed after its producer had
+    // written it; eager launches and most replays were fine, tools/graph_debug.py).  A kernel node keeps the stream order.
     mark();
-    // 1. all modulation vectors + demodulation factors
-    DEC2_STEP(e3dge_decoder_styles(P->mod_table, P->n_mod, P->mod_rows, P->mod_co, P->latent, P->n_latent, P->style_dim, B, stream));
+    // 1. all modulation vectors + demodulation factors (+ the zeroing)
+    DEC2_STEP(decoder_styles_launch(P->mod_table, P->n_mod, P->mod_rows, P->mod_co, P->latent, P->n_latent, P->style_dim, B, P->amax,
+                                    E3DGE_AMAX_FLOATS * (3 * P->n_up + 2), st));
     // 2, 3. features -> packed
     const float* amax0 = P->amax;
     DEC2_STEP(e3dge_amax(P->amax, P->features, (int64_t)B * P->in_ch * P->in_res * P->in_res, stream));

@@ -19,4 +19,8 @@ __device__ __forceinline__ unsigned scale_exponent(float bound) {
 }
 
 
+// e3dge_decoder_styles (modconv.hip) with an optional block of floats to clear in the same launch (host side)
+int decoder_styles_launch(const E3dgeModLayer* table, int n_layers, int total_rows, int total_co, const float* latent, int n_latent,
+                          int style_dim, int batch, float* zero, int n_zero, hipStream_t st);
+
 }  // namespace e3dge

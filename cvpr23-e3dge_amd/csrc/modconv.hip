@@ -500,8 +500,12 @@ __global__ void __launch_bounds__(256) amax_kernel(float* __restrict__ out, cons
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 decoder_styles_kernel(const E3dgeModLayer* __restrict__ tab, int n_layers, int total_rows, const float* __restrict__ latent,
-                      int n_latent, int style_dim) {
+                      int n_latent, int style_dim, float* __restrict__ zero, int n_zero) {
     const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the packed decoder pipeline has its amax block cleared here: this is the first launch of a forward, and a kernel of its own
+    // for 4 KB of zeros cost 4.7 us of the inversion forward's timeline)
+    if (zero && b == 0)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n_zero; i += gridDim.x * 256) zero[i] = 0.0f;
     const int row = blockIdx.x * 4 + wave;
     if (row >= total_rows) return;
     int l = 0;
@@ -596,18 +600,25 @@ extern "C" int e3dge_modconv_demod(float* demod, float* s_amax, const float* sty
     return check_launch("modconv_demod");
 }
 
-extern "C" int e3dge_decoder_styles(const E3dgeModLayer* table, int n_layers, int total_rows, int total_co, const float* latent,
-                                    int n_latent, int style_dim, int batch, e3dge_stream_t stream) {
+namespace e3dge {
+int decoder_styles_launch(const E3dgeModLayer* table, int n_layers, int total_rows, int total_co, const float* latent, int n_latent,
+                          int style_dim, int batch, float* zero, int n_zero, hipStream_t st) {
     E3DGE_REQUIRE(table && latent, "decoder_styles: null pointer");
     E3DGE_REQUIRE(n_layers >= 1 && n_layers <= 64 && total_rows >= 1 && total_co >= 0 && n_latent >= 1 && style_dim >= 1 && batch >= 0,
                   "decoder_styles: bad sizes");
     if (batch == 0) return E3DGE_OK;
-    hipStream_t st = as_stream(stream);
-    decoder_styles_kernel<<<dim3((unsigned)((total_rows + 3) / 4), (unsigned)batch), dim3(256), 0, st>>>(table, n_layers, total_rows, latent, n_latent, style_dim);
+    decoder_styles_kernel<<<dim3((unsigned)((total_rows + 3) / 4), (unsigned)batch), dim3(256), 0, st>>>(table, n_layers, total_rows, latent, n_latent, style_dim,
+                                                                                                         zero, n_zero);
     int rc = check_launch("decoder_styles");
     if (rc) return rc;
     decoder_demod_kernel<<<dim3((unsigned)((total_co + n_layers + 3) / 4), (unsigned)batch), dim3(256), 0, st>>>(table, n_layers, total_co);
     return check_launch("decoder_styles(demod)");
+}
+}  // namespace e3dge
+
+extern "C" int e3dge_decoder_styles(const E3dgeModLayer* table, int n_layers, int total_rows, int total_co, const float* latent,
+                                    int n_latent, int style_dim, int batch, e3dge_stream_t stream) {
+    return decoder_styles_launch(table, n_layers, total_rows, total_co, latent, n_latent, style_dim, batch, nullptr, 0, as_stream(stream));
 }
 
 extern "C" int e3dge_amax(float* out, const float* x, int64_t n, e3dge_stream_t stream) {

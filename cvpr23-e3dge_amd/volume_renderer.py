@@ -909,10 +909,20 @@ class VolumeFeatureRenderer(nn.Module):
             if tex_conditions is not None and return_eikonal:
                 raise NotImplementedError("eikonal term together with the tex-FiLM pass")
             return _RenderQuery.differentiable(self, styles, focal, c2w, near, far, return_eikonal, tex_conditions)
-        film = self.siren.film_params(styles)
         if not return_eikonal:
             key = self._reuse_key(styles, focal, c2w, near, far) if self._reuse_enabled(None) else None
+            film = None
+            if key is not None and tex_conditions is not None and c2w.shape[0]:
+                # second pass on a first pass's record: same styles (the key says so), so the same FiLM parameters -- the record
+                # keeps them (one launch less per evaluated image)
+                rec = _BACKBONE.get(self)
+                if rec is not None and rec.get('film') is not None and \
+                        key.extended(_lib.load().e3dge_stream_capture_id(_lib.stream_of(c2w))).matches(rec['key']):
+                    film = rec['film']
+            if film is None:
+                film = self.siren.film_params(styles)
             return self.render_with_film(film, focal, c2w, near, far, tex_conditions, reuse_key=key)
+        film = self.siren.film_params(styles)
         if tex_conditions is not None:
             raise NotImplementedError("eikonal term together with the tex-FiLM pass")
         B, H, S = c2w.shape[0], self.out_im_res, self.N_samples
@@ -1035,7 +1045,7 @@ class VolumeFeatureRenderer(nn.Module):
         if bb_out is not None:
             # the record keeps the geometry tensors a second pass returns (a few MB), not the first pass's rgb / features
             geo = {k: v for k, v in out.items() if k not in ('rgb', 'features')}
-            _BACKBONE[self] = dict(key=reuse_key, buf=bb_out, out=geo, out_versions=[t._version for t in geo.values()])
+            _BACKBONE[self] = dict(key=reuse_key, buf=bb_out, out=geo, out_versions=[t._version for t in geo.values()], film=film)
         return self._render_dict({'rays_d': out['rays_d'], 'dists': out['dists'], 'hit_prob': out['weights'],
                                   'points': out['points'], 'sdf': out['sdf'], 'gen_thumb_imgs': out['rgb'],
                                   'features': out['features'], 'mask': out['mask'], 'xyz': out['xyz'],
