@@ -32,6 +32,8 @@ Extra objects on the JSON line:
                 dist_utils.py:108-130) emulated on a side stream: allreduce_ms, overlapped ms, overlap_frac.
   inversion     per-kernel table of the inversion forward (HIP events): ms, bound, achieved / peak, frac for both render passes, the
                 texture head and every launch of the decoder.
+  autograd      forward + backward of the decoder (1024^2) and of Fuse_sft_MLP (98,304 points) with a graph wanted -- inputs require grad,
+                parameters frozen, the shape of a train_ae.py forward: autograd nodes with the native forward vs the library path.
   cpu_baseline  the oracle restatement (oracle/renderer_ref.py, "port": bit-identical to the reference's PyTorch path on
                 the golden vectors) timed on this host's cores on a bounded sample.
 """
@@ -680,6 +682,50 @@ def main():
                     "HIP-event time of every launch group of one inversion forward (median of 10), against the roofline that bounds "
                     "it: mfma = algorithmic FLOPs / (dense f16 MFMA peak / 3: split-f16 needs three products), hbm = algorithmic "
                     "bytes / 8 TB/s; `bound` is the larger of the two minimum times, frac = that minimum time / measured time")}
+            # the decoder and the SFT block with a graph wanted (features / latent / inputs require grad, parameters frozen: the shape of
+            # a train_ae.py forward): autograd nodes with the native forward vs the library path
+            try:
+                def ev_fb(fn, n=5):
+                    for _ in range(2):
+                        fn()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize(); e0.record()
+                    for _ in range(n):
+                        fn()
+                    e1.record(); torch.cuda.synchronize()
+                    return e0.elapsed_time(e1) / n
+                dec_ = gl.decoder
+                fm_ = o['features'].detach()
+                ag = {}
+                for be in ("packed", "library"):
+                    os.environ["E3DGE_DECODER_AUTOGRAD"] = be
+                    try:
+                        def fb():
+                            f_, l_ = fm_.clone().requires_grad_(True), d1.detach().clone().requires_grad_(True)
+                            dec_(f_, [l_], input_is_latent=True, randomize_noise=False)[0].square().mean().backward()
+                        ag["decoder_" + be + "_fwd_bwd_ms"] = ev_fb(fb)
+                    finally:
+                        os.environ.pop("E3DGE_DECODER_AUTOGRAD", None)
+                from e3dge_amd.local_query import Fuse_sft_MLP
+                fu_ = Fuse_sft_MLP().to(dev)
+                fu_.requires_grad_(False)
+                with torch.no_grad():
+                    for prm in fu_.parameters():
+                        prm.copy_(torch.randn_like(prm) * (0.1 if prm.ndim == 1 else 1.0 / prm.shape[1] ** 0.5))
+                xin_ = torch.randn(1, RES * RES * N_SAMPLES, 513, device=dev)
+                for be in ("hip", "torch"):
+                    os.environ["E3DGE_FUSE_AUTOGRAD"] = be
+                    try:
+                        def fb2():
+                            x_ = xin_.clone().requires_grad_(True)
+                            fu_.fuse(x_, x_[..., 257:]).square().mean().backward()
+                        ag["fuse_sft_" + be + "_fwd_bwd_ms"] = ev_fb(fb2)
+                    finally:
+                        os.environ.pop("E3DGE_FUSE_AUTOGRAD", None)
+                ag["note"] = "forward + backward with a graph (inputs require grad, parameters frozen): native-forward autograd nodes vs library path"
+                result["autograd"] = ag
+            except Exception as exc:
+                result["autograd"] = {"failed": f"{type(exc).__name__}: {exc}"}
             # the same ~60 launches replayed as one HIP graph (cvpr23-e3dge_amd/graphs.py)
             try:
                 from e3dge_amd.graphs import GraphedCall
