@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E3DGE_LIB_PATH") or os.path.join(_HERE, "lib", "libe3dge_hip.so")   # override: kernel A/B variants
-ABI_VERSION = 11
+ABI_VERSION = 12
 PREC_F32, PREC_F16X3, PREC_F16X3_V1, PREC_F16X3_G2 = 0, 1, 2, 3
 AMAX_FLOATS = 64 * 32           # E3DGE_AMAX_FLOATS: one amax buffer (include/e3dge_hip.h)
 
@@ -85,7 +85,20 @@ class Dec2Plan(ctypes.Structure):
                 ("act", _vp * (2 * DEC2_MAX_UP + 2)), ("tbuf", _vp * DEC2_MAX_UP), ("amax", _vp), ("meta", _vp),
                 ("fir_blur", _vp), ("fir_up", _vp), ("negative_slope", _f32), ("act_scale", _f32),
                 ("kernel_ms", ctypes.POINTER(ctypes.c_float)), ("n_kernel_ms", _i32), ("reserved1", _i32),
-                ("fir_blur_1d", _f32 * 4), ("fir_blur_separable", _i32), ("reserved2", _i32)]
+                ("fir_blur_1d", _f32 * 4), ("fir_blur_separable", _i32), ("save_for_backward", _i32)]
+
+
+class Dec2BwdConv(ctypes.Structure):
+    """Mirror of struct E3dgeDec2BwdConv (include/e3dge_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("wpre_t", "wsq", "wimg_t")]
+
+
+class Dec2BwdPlan(ctypes.Structure):
+    """Mirror of struct E3dgeDec2BwdPlan (include/e3dge_hip.h)."""
+    _fields_ = [("d_img", _vp), ("d_features", _vp), ("conv1", Dec2BwdConv), ("up", Dec2BwdConv * DEC2_MAX_UP),
+                ("conv", Dec2BwdConv * DEC2_MAX_UP), ("gact", _vp * (2 * DEC2_MAX_UP + 2)), ("pbuf", _vp),
+                ("drgb", _vp * DEC2_MAX_UP), ("amax", _vp), ("meta", _vp), ("bounds", _vp),
+                ("kernel_ms", ctypes.POINTER(ctypes.c_float)), ("n_kernel_ms", _i32), ("reserved", _i32)]
 
 
 class WsLinear(ctypes.Structure):
@@ -129,6 +142,10 @@ SIGNATURES = {
     "e3dge_dec2_prepack_weights": (_i32, [_vp, _vp, _f32, _i32, _i32, _vp]),
     "e3dge_dec2_num_launches": (_i32, [_i32]),
     "e3dge_dec2_forward": (_i32, [ctypes.POINTER(Dec2Plan), _vp]),
+    "e3dge_dec2_prepack_weights_t": (_i32, [_vp, _vp, _f32, _i32, _i32, _i32, _vp]),
+    "e3dge_dec2_pbuf_words": (_i64, [_i32, _i32, _i32]),
+    "e3dge_dec2_bwd_num_launches": (_i32, [_i32]),
+    "e3dge_dec2_backward": (_i32, [ctypes.POINTER(Dec2Plan), ctypes.POINTER(Dec2BwdPlan), _vp]),
     "e3dge_dec2_pack": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "e3dge_dec2_unpack": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "e3dge_siren_packed_floats": (_i64, []),

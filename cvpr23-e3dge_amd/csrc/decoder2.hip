@@ -136,7 +136,26 @@ pk_prepack_kernel(float* __restrict__ wpre, const float* __restrict__ w, float s
     }
 }
 
-struct PkWConv { const float* wpre; const float* style; const float* demod; uint32_t* img; int co, ci, n_chunks; int n_items; int64_t words; };
+// Transposed arrangement for the data-gradient convolutions (round 5): rows = the forward conv's INPUT channels, reduction = its output
+// channels, taps flipped for the stride-1 convs (d x = conv(d y, flip(w)^T)), as they are for the transposed-stride ones
+// (d x = conv_stride2(d T, w^T)).  wpre_t[t][c][tap][lane][j] = scale * weight[16c + 8 (lane >> 5) + j][32t + (lane & 31)][flip ? 8 - tap : tap]
+__global__ void __launch_bounds__(256)
+pk_prepack_t_kernel(float* __restrict__ wpre, const float* __restrict__ w, float scale, int Co, int Ci, int n_chunks, int64_t n, int flip) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        int64_t r = e;
+        const int j = r & 7; r >>= 3;
+        const int l = r & 63; r >>= 6;
+        const int tap = (int)(r % 9); r /= 9;
+        const int c = (int)(r % n_chunks);
+        const int t = (int)(r / n_chunks);
+        const int ci = 32 * t + (l & 31), co = 16 * c + 8 * (l >> 5) + j;
+        wpre[e] = (co < Co && ci < Ci) ? __fmul_rn(scale, w[((int64_t)co * Ci + ci) * 9 + (flip ? 8 - tap : tap)]) : 0.0f;
+    }
+}
+
+// swap != 0 (transposed images): `style` is indexed by the image's ROW (the forward conv's input channel) and `demod` by its reduction
+// index (the forward conv's output channel); the product keeps the forward's rounding order ((scale W) s) demod
+struct PkWConv { const float* wpre; const float* style; const float* demod; uint32_t* img; int co, ci, n_chunks; int n_items; int64_t words; int swap; };
 struct PkWRgb { const float* w; const float* style; float* wm; float scale; int ci; };
 struct PkWTab { PkWConv conv[2 * E3DGE_DEC2_MAX_UP + 1]; PkWRgb rgb[E3DGE_DEC2_MAX_UP + 1]; int n_conv, n_rgb; };
 
@@ -144,8 +163,8 @@ __global__ void __launch_bounds__(256) pk_weights_kernel(const PkWTab tab) {
     const int layer = blockIdx.y, b = blockIdx.z;
     if (layer < tab.n_conv) {
         const PkWConv L = tab.conv[layer];
-        const float* __restrict__ st = L.style + (size_t)b * L.ci;
-        const float* __restrict__ dm = L.demod + (size_t)b * L.co;
+        const float* __restrict__ st = (L.swap ? L.demod : L.style) + (size_t)b * L.ci;      // per reduction index
+        const float* __restrict__ dm = (L.swap ? L.style : L.demod) + (size_t)b * L.co;      // per row
         u32x4* __restrict__ img = reinterpret_cast<u32x4*>(L.img + (size_t)b * L.words);
         for (int item = blockIdx.x * 256 + threadIdx.x; item < L.n_items; item += gridDim.x * 256) {
             const int l = item & 63;
@@ -165,7 +184,7 @@ __global__ void __launch_bounds__(256) pk_weights_kernel(const PkWTab tab) {
                     const int j = 2 * w + e2;
                     const float wv = j < 4 ? w0[j] : w1[j - 4];
                     const float s = (ci0 + j) < L.ci ? st[ci0 + j] : 0.0f;
-                    const float v = kW16Scale * __fmul_rn(__fmul_rn(wv, s), d);        // ((scale W) s) demod, then the exact x128
+                    const float v = kW16Scale * (L.swap ? __fmul_rn(__fmul_rn(wv, d), s) : __fmul_rn(__fmul_rn(wv, s), d));   // ((scale W) s) demod, then the exact x128
                     const _Float16 h = (_Float16)v;
                     const _Float16 lv = (_Float16)(v - (float)h);
                     hw |= (unsigned)__builtin_bit_cast(unsigned short, h) << (16 * e2);
@@ -209,7 +228,86 @@ struct PkConvK {
     int tiles_x, tiles_y, co_blocks, n_tiles;
     // up-sampling: positions (i, j) in [0, H] x [0, W] are processed per column block [j0, j0 + cwb), flattened q = i cwb + (j - j0)
     int cw, cwl, nblk, tpf, tpl;   // block width (all but the last / the last), blocks, WG tiles per full / last block
+    // data-gradient launches (BWD, round 5; decoder2_bwd.h): the "input" x is a packed GRADIENT, the weight images are the transposed ones
+    const unsigned char* mask_act; // packed FORWARD activation of the output's shape: the sign of its hi half selects lrelu' (1 or slope)
+    const float* rgbt_d;           // (B, 3, H, W) gradient of this level's ToRGB output or null; its (scale W) s table is rgb_wm
+    const float* rgbt_amax;        // amax buffer of rgbt_d
+    const float* rgbt_l1;          // device scalar: max_{b, ci} sum_c |rgb_wm[b][c][ci]|
+    const float* bwd_wl1;          // device scalar: bound on max_{b, row} sum |w''| of the transposed image (operator norm, max-abs)
+    float* out_f32;                // BWD = 2: fp32 (B, Co, H, W) output (the gradient of the feature map), no mask
 };
+
+// ---- epilogue of one 32-channel x 32-pixel accumulator tile of a data-gradient convolution ------------------------------------------
+// d x = acc 2^-s (+ ToRGB^T d rgb) ; d pre = lrelu'(forward activation) d x sqrt 2 (fused_bias_act grad = 1: (g alpha) scale for a
+// non-positive reference, op/fused_act.py:19-50 of the reference) -> f16 hi/lo split, packed store, max |.| tracked.  FINAL: the plain
+// fp32 (B, Co, H, W) store of d features.  Lane (half, col) holds rows 8 g4 + 4 half + j of the tile for pixel column col.
+template <bool FINAL>
+__device__ __forceinline__ void bwd_tile_epilogue(const PkConvK& a, const f32x16& d, int b, int cot, int oy, int ox, int half,
+                                                  const float* rgb_tab, int tab_stride, int tab_co0, const float (&dr)[3], float oscale,
+                                                  float sc_out, float& amax_l) {
+    const bool ok = oy < a.H && ox < a.W;
+    if (FINAL) {
+        if (ok) {
+            const int64_t hw = (int64_t)a.H * a.W;
+            float* o = a.out_f32 + ((int64_t)b * a.Co + cot * 32 + 4 * half) * hw + (int64_t)oy * a.W + ox;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(int64_t)((r & 3) + 8 * (r >> 2)) * hw] = d[r] * oscale;
+        }
+        return;
+    }
+    const int WP = a.W + 2, GO = a.Co >> 3;
+    const int64_t plane_b = (int64_t)(a.H + 2) * WP * 16;
+    const int64_t grp = ((int64_t)(b * GO + cot * 4) * 2) * plane_b;
+    // (branch-free: clamped into the image; a load inside a divergent `if` gets a wait of its own)
+    const int64_t em = grp + ((int64_t)(min(oy, a.H - 1) + 1) * WP + min(ox, a.W - 1) + 1) * 16 + half * 8;
+    uint2 mw[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) mw[g4] = *reinterpret_cast<const uint2*>(a.mask_act + em + (int64_t)g4 * 2 * plane_b);
+    const float gmul = a.act_scale * sc_out;
+    float m = 0.0f;
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+        unsigned hh[2][2], ll[2][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int g4 = 2 * gp + e, co0 = cot * 32 + 8 * g4 + 4 * half;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = d[4 * g4 + j] * oscale;
+            if (rgb_tab) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(rgb_tab + c * tab_stride + (co0 - tab_co0));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = fmaf(w4[j], dr[c], v[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned hb = ((j < 2 ? mw[g4].x : mw[g4].y) >> (16 * (j & 1))) & 0xffffu;
+                const bool pos = hb - 1u < 0x7fffu;                                       // f16 bits 0x0001 .. 0x7fff: > 0
+                const float t = pos ? v[j] : v[j] * a.slope;
+                v[j] = t * gmul;
+                m = fmaxf(m, fabsf(v[j]));
+            }
+            SPLIT2_TO(v[0], v[1], hh[e][0], ll[e][0]);
+            SPLIT2_TO(v[2], v[3], hh[e][1], ll[e][1]);
+        }
+        auto r0 = __builtin_amdgcn_permlane32_swap(hh[0][0], hh[1][0], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(hh[0][1], hh[1][1], false, false);
+        auto r2 = __builtin_amdgcn_permlane32_swap(ll[0][0], ll[1][0], false, false);
+        auto r3 = __builtin_amdgcn_permlane32_swap(ll[0][1], ll[1][1], false, false);
+        if (ok) {
+            unsigned char* dst = a.y + grp + (int64_t)((2 * gp + half) * 2) * plane_b + ((int64_t)(oy + 1) * WP + ox + 1) * 16;
+            u32x4 eh, el;
+            eh[0] = r0[0]; eh[1] = r1[0]; eh[2] = r0[1]; eh[3] = r1[1];
+            el[0] = r2[0]; el[1] = r3[0]; el[2] = r2[1]; el[3] = r3[1];
+            *reinterpret_cast<u32x4*>(dst) = eh;
+            *reinterpret_cast<u32x4*>(dst + plane_b) = el;
+        }
+    }
+    if (ok) amax_l = fmaxf(amax_l, m);
+}
 
 // one LDS-DMA piece (64 lanes x 16 B -> 1 KiB of LDS at lds_dst), global address = wave-uniform base + per-lane byte offset
 __device__ __forceinline__ void dma_piece(const void* sbase, uint32_t voff, uint32_t lds_dst) {
@@ -235,9 +333,12 @@ __device__ __forceinline__ int xcd_logical(int t, int n_tiles) {
 // the activation is reduced against the 3 x Co table (scale W) s from LDS, + bias + FIR-up-sampled skip -- and is never stored.
 // RGB = 2 (round 4: a 64-channel level that is NOT the last): the same ToRGB in the epilogue AND the packed activation stored -- the
 // stand-alone ToRGB launch re-read the whole activation (67 MB at 512^2) for three output channels.
-template <int NCT, int NPY, int NPX, int WCO, int WY, int WX, int RGB>
+// BWD (round 5): 1 = data-gradient launch (x = packed gradient, transposed weight image): the epilogue is bwd_tile_epilogue -- no noise /
+// bias, + ToRGB^T d rgb when rgbt_d is given, lrelu' from the packed forward activation mask_act; 2 = the last one (fp32 d features).
+template <int NCT, int NPY, int NPX, int WCO, int WY, int WX, int RGB, int BWD = 0>
 __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkConvK a) {
     static_assert(!RGB || WCO == 1, "fused ToRGB needs every output channel of a pixel in one wave");
+    static_assert(!(RGB && BWD), "the fused ToRGB forms are forward kernels");
     constexpr int NW = WCO * WY * WX, NT = 64 * NW;
     constexpr int TH = NPY * WY, TW = 32 * NPX * WX, PH = TH + 2, PW = TW + 2, NPIX = PH * PW, NPP = (NPIX + 63) / 64;
     constexpr int NCTB = NCT * WCO, XPLANE = NPIX * 16, XST = 4 * XPLANE, WST = NCTB * kPkSlab, STAGE = XST + WST;
@@ -258,14 +359,22 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
     const float oscale = pow2_bits(eb_in - 21u);                     // 1 / (128 * 2^(141 - eb_in))
     const float nw = a.noise ? a.noise_w[0] : 0.0f;
     float sc_out = 1.0f;
-    if (RGB != 1) {
+    if (BWD == 1) {
+        // |d pre| <= sqrt 2 (max |d y| max_row sum |w''| + max |d rgb| max_ci sum_c |(scale W) s|): the operator norms come from
+        // pk_bwd_bounds_kernel (deterministic), the maxima are measured by the producers of the two gradients
+        const float rg = a.rgbt_d ? amax_read(a.rgbt_amax, lane) * a.rgbt_l1[0] : 0.0f;
+        const float bound = a.act_scale * (amax_read(a.in_amax, lane) * a.bwd_wl1[0] * 1.002f + rg) * 1.001f;
+        const unsigned eb_out = scale_exponent(bound);
+        sc_out = pow2_bits(268u - eb_out);
+        if (blockIdx.x == 0 && tid == 0) a.out_meta[0] = (int)eb_out;
+    } else if (!BWD && RGB != 1) {
         const float nza = a.noise ? fabsf(nw) * amax_read(a.noise_amax, lane) : 0.0f;
         const float bound = a.act_scale * (amax_read(a.in_amax, lane) * a.knorm * 1.002f + nza + a.bias_amax) * 1.001f;
         const unsigned eb_out = scale_exponent(bound);
         sc_out = pow2_bits(268u - eb_out);
         if (blockIdx.x == 0 && tid == 0) a.out_meta[0] = (int)eb_out;
     }
-    for (int i = tid; i < a.Co; i += NT) tab[i] = a.bias[i];        // read after >= 1 step-top barrier
+    if (!BWD) for (int i = tid; i < a.Co; i += NT) tab[i] = a.bias[i];        // read after >= 1 step-top barrier
     int b_tab = -1;
 
     struct Pos { int k, c, b, cb, ty, tx; };
@@ -378,6 +487,23 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
     const int prow0 = wy * NPY, pcol0 = wx * NPX * 32 + col;
     const float kmul = RGB == 1 ? a.act_scale : a.act_scale * sc_out;      // lrelu(t) * act_scale * 2^k == (lrelu(t) * act_scale) * 2^k exactly
     const float kinv = RGB == 1 ? 1.0f : 1.0f / sc_out;                    // (RGB = 2: the ToRGB sums carry 2^k too and shed it, exactly, at the end)
+    // (BWD) the whole tile's epilogue, straight from the accumulators
+    auto epi_bwd = [&]() {
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+            const int oy = p_cur.ty * TH + prow0 + pt / NPX, ox = p_cur.tx * TW + pcol0 + 32 * (pt % NPX);
+            float dr[3] = {0.0f, 0.0f, 0.0f};
+            if (BWD == 1 && a.rgbt_d) {
+                const float* dp = a.rgbt_d + (int64_t)p_cur.b * 3 * a.H * a.W + (unsigned)(min(oy, a.H - 1) * a.W + min(ox, a.W - 1));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dr[c] = dp[(int64_t)c * a.H * a.W];
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                bwd_tile_epilogue<BWD == 2>(a, acc[ct][pt], p_cur.b, p_cur.cb * NCTB + wco * NCT + ct, oy, ox, half,
+                                            (BWD == 1 && a.rgbt_d) ? tab + a.Co : nullptr, a.Co, 0, dr, oscale, sc_out, amax_l);
+        }
+    };
     PK_T_INIT;
 
     // One slice of a finished tile's epilogue: pixel tile pt, co-tile ct, channel group g4 = 2 gp + e (four values per lane):
@@ -489,7 +615,9 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
         }
         // (scale W) s of this tile's sample.  Written in the tile's SECOND step: during its first one other waves may still be reading the
         // previous sample's table for the finished tile's epilogue; the host requires n_chunks >= 2, so a barrier lies before its readers.
-        if (RGB && p_cur.c == 1 && p_cur.b != b_tab) {
+        // (BWD: in the tile's FIRST step -- its epilogue never overlaps a later step, so nobody reads the table across this barrier, and a
+        // two-chunk tile reads it in its second step)
+        if ((RGB || (BWD == 1 && a.rgbt_d)) && p_cur.c == (BWD ? 0 : 1) && p_cur.b != b_tab) {
             b_tab = p_cur.b;
             const int t2 = (int)__builtin_amdgcn_readfirstlane(tid >> 6) * 64 + lane_id_fresh();     // (a kernel-lifetime copy of tid was the value spilled here)
             for (int i = t2; i < 3 * a.Co; i += NT) tab[a.Co + i] = a.rgb_wm[(size_t)b_tab * 3 * a.Co + i];
@@ -498,7 +626,7 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
         // this step's DMA pieces go out: a wait inside the epilogue would also wait for every DMA piece issued since (vmcnt is in order).
         // (Branch-free: a load inside a divergent `if` gets its own s_waitcnt vmcnt(0) -- twelve serialized L2 round trips per pixel tile
         // for the skip image in the first version of this block.  Indices are clamped into the image, out-of-image taps get weight 0.)
-        if (last_chunk) {
+        if (last_chunk && !BWD) {
             // One 64-bit base per image (wave-uniform, in SGPRs) and unsigned 32-bit per-lane offsets: as `p ? p[i64] : 0` every one of
             // the 26 loads per pixel tile carried its own branch and 64-bit address arithmetic (6.2 scalar instructions per MFMA in the
             // fused-ToRGB kernel, PMC).  A missing noise / skip image reads a finite dummy (the bias table) that gets weight 0.
@@ -592,7 +720,7 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (tap == 0 && last_chunk) {
+                if (tap == 0 && last_chunk && !BWD) {
 #pragma unroll
                     for (int pt = 0; pt < NPT; ++pt) {
                         asm volatile("" : "+v"(nzr[pt]));      // the compiler's vmcnt wait lands here
@@ -611,7 +739,9 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
         if (OVL && do_epi) taps(std::true_type{}); else taps(std::false_type{});
         PK_T(2);
         pending = false;
-        if (last_chunk) {                                // hand the tile over; its epilogue runs during the next step (or after the loop)
+        if (BWD) {
+            if (last_chunk) epi_bwd();
+        } else if (last_chunk) {                         // hand the tile over; its epilogue runs during the next step (or after the loop)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -637,7 +767,7 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
 #pragma unroll
         for (int h = 0; h < NH; ++h) epi_slice(h);
     }
-    if (RGB != 1 && a.out_amax) {
+    if (RGB != 1 && BWD != 2 && a.out_amax) {
         int l2 = lane;
         asm volatile("" : "+v"(l2));          // (fresh permute addresses: sharing them with the prologue's amax_read keeps five registers alive across the kernel)
 #pragma unroll
@@ -1718,12 +1848,12 @@ pk_torgb_kernel(float* __restrict__ y, const unsigned char* __restrict__ x, cons
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NCT, int NPY, int NPX, int WCO, int WY, int WX, int RGB = 0>
+template <int NCT, int NPY, int NPX, int WCO, int WY, int WX, int RGB = 0, int BWD = 0>
 static int launch_s1(PkConvK k, hipStream_t st, const char* what) {
     constexpr int TH = NPY * WY, TW = 32 * NPX * WX, NPIX = (TH + 2) * (TW + 2), NCTB = NCT * WCO;
     constexpr int lds_stages = 2 * (4 * NPIX * 16 + NCTB * kPkSlab);
     static_assert(lds_stages <= 160 * 1024, "LDS budget");
-    const int lds = lds_stages + 4 * k.Co * (RGB ? 4 : 1);         // + bias table (+ ToRGB table)
+    const int lds = lds_stages + 4 * k.Co * ((RGB || BWD == 1) ? 4 : 1);         // + bias table (+ ToRGB table)
     E3DGE_REQUIRE(lds <= 160 * 1024, "%s: LDS budget with Co=%d", what, k.Co);
     E3DGE_REQUIRE(k.Co % (32 * NCTB) == 0, "%s: Co=%d not a multiple of %d", what, k.Co, 32 * NCTB);
     k.tiles_y = (k.H + TH - 1) / TH;
@@ -1731,10 +1861,13 @@ static int launch_s1(PkConvK k, hipStream_t st, const char* what) {
     k.co_blocks = k.Co / (32 * NCTB);
     E3DGE_REQUIRE(!RGB || (k.co_blocks == 1 && k.n_chunks >= 2 && k.rgb_wm && k.rgb_bias && k.rgb_out), "%s: fused ToRGB needs one co-block and >= 32 input channels", what);
     E3DGE_REQUIRE(RGB != 2 || (k.y && k.out_meta), "%s: the store + ToRGB form needs the output activation", what);
+    E3DGE_REQUIRE(BWD != 1 || (k.y && k.out_meta && k.mask_act && k.bwd_wl1 && k.in_amax), "%s: data-gradient launch: missing pointer", what);
+    E3DGE_REQUIRE(BWD != 1 || !k.rgbt_d || (k.rgb_wm && k.rgbt_amax && k.rgbt_l1 && k.n_chunks >= 2), "%s: ToRGB^T needs its table, amax, norm and >= 32 input channels", what);
+    E3DGE_REQUIRE(BWD != 2 || k.out_f32, "%s: the last data-gradient launch needs out_f32", what);
     const int64_t n_tiles = (int64_t)k.B * k.co_blocks * k.tiles_y * k.tiles_x;
     E3DGE_REQUIRE(n_tiles < ((int64_t)1 << 30), "%s: too many tiles", what);
     k.n_tiles = (int)n_tiles;
-    auto fn = &pkconv_s1_kernel<NCT, NPY, NPX, WCO, WY, WX, RGB>;
+    auto fn = &pkconv_s1_kernel<NCT, NPY, NPX, WCO, WY, WX, RGB, BWD>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
     int grid = 256 * ((160 * 1024) / lds >= 2 ? 2 : 1);
@@ -1937,6 +2070,8 @@ static int launch_torgb(float* y, const unsigned char* x, const int* meta, const
     }
     return check_launch("dec2 torgb");
 }
+
+#include "decoder2_bwd.h"
 
 static int check_conv(const E3dgeDec2Conv& c, const char* what) {
     E3DGE_REQUIRE(c.wpre && c.style && c.demod && c.wimg && c.bias, "dec2 %s: null pointer", what);
@@ -2147,7 +2282,7 @@ extern "C" int e3dge_dec2_forward(const E3dgeDec2Plan* P, e3dge_stream_t stream)
             k.y = reinterpret_cast<unsigned char*>(P->act[3 + 2 * u]); k.out_meta = P->meta + 3 + 2 * u; k.out_amax = am_v;
             if (fuse_rgb) {
                 k.rgb_wm = P->rgb[u].wm; k.rgb_bias = P->rgb[u].bias; k.rgb_skip = skip; k.rgb_fir = P->fir_up; k.rgb_out = P->rgb[u].out;
-                k.rgb_store = last_level ? 0 : 1;
+                k.rgb_store = (last_level && !P->save_for_backward) ? 0 : 1;      // (a backward needs the top activation's signs)
             }
             DEC2_STEP(conv_s1(k, st));
         }
@@ -2156,6 +2291,178 @@ extern "C" int e3dge_dec2_forward(const E3dgeDec2Plan* P, e3dge_stream_t stream)
                                     P->rgb[u].bias, skip, P->fir_up, B, P->rgb[u].ci, res, st));
         skip = P->rgb[u].out;
         prev_act = 3 + 2 * u;
+    }
+#undef DEC2_STEP
+    return finish(E3DGE_OK);
+}
+
+
+// ---- backward: d image -> d features (decoder2_bwd.h) --------------------------------------------------------------------------------
+extern "C" int e3dge_dec2_prepack_weights_t(float* wpre_t, const float* weight, float scale, int co, int ci, int flip, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(wpre_t && weight && co > 0 && ci > 0, "dec2_prepack_weights_t: bad arguments");
+    E3DGE_REQUIRE(ci % 32 == 0 && co % 16 == 0, "dec2_prepack_weights_t: needs ci %% 32 == 0 and co %% 16 == 0 (the transposed image's rows are the input channels)");
+    const int64_t n = (int64_t)co * ci * 9;
+    pk_prepack_t_kernel<<<dim3(512), dim3(256), 0, as_stream(stream)>>>(wpre_t, weight, scale, co, ci, co / 16, n, flip);
+    return check_launch("dec2_prepack_weights_t");
+}
+extern "C" int64_t e3dge_dec2_pbuf_words(int batch, int channels, int res) {
+    if (batch <= 0 || channels <= 0 || res <= 0 || res % 2) return 0;
+    return (int64_t)batch * ((channels + 7) / 8) * 2 * 4 * (res / 2 + 2) * (res / 2 + 2) * 4;
+}
+extern "C" int e3dge_dec2_bwd_num_launches(int n_up) { return 5 + 4 * n_up; }
+
+extern "C" int e3dge_dec2_backward(const E3dgeDec2Plan* P, const E3dgeDec2BwdPlan* Q, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(P != nullptr && Q != nullptr, "dec2_backward: null plan");
+    E3DGE_REQUIRE(P->batch >= 0 && P->n_up >= 0 && P->n_up <= E3DGE_DEC2_MAX_UP && P->in_res >= 4 && P->in_ch > 0 && P->in_ch % 32 == 0,
+                  "dec2_backward: bad sizes (batch %d, n_up %d, in_res %d, in_ch %d)", P->batch, P->n_up, P->in_res, P->in_ch);
+    if (P->batch == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(P->save_for_backward, "dec2_backward: the forward of this plan did not keep its top activation (save_for_backward)");
+    E3DGE_REQUIRE(Q->d_img && Q->d_features && Q->amax && Q->meta && Q->bounds && P->fir_blur && P->fir_up, "dec2_backward: null pointer");
+    const int n_up = P->n_up, B = P->batch;
+    auto check_bc = [&](const E3dgeDec2Conv& c, const E3dgeDec2BwdConv& q, const char* what) -> int {
+        E3DGE_REQUIRE(q.wpre_t && q.wsq && q.wimg_t && c.style && c.demod, "dec2_backward %s: null pointer", what);
+        E3DGE_REQUIRE(c.ci % 32 == 0 && c.co % 32 == 0, "dec2_backward %s: needs ci %% 32 == 0 and co %% 32 == 0 (got %d, %d)", what, c.ci, c.co);
+        return E3DGE_OK;
+    };
+    int rc = check_bc(P->conv1, Q->conv1, "conv1");
+    if (rc) return rc;
+    E3DGE_REQUIRE(Q->gact[1] && P->act[1] && P->rgb1.wm && (n_up == 0 || Q->drgb[0]), "dec2_backward: workspace missing");
+    for (int u = 0; u < n_up; ++u) {
+        if ((rc = check_bc(P->up[u], Q->up[u], "up")) != 0 || (rc = check_bc(P->conv[u], Q->conv[u], "conv")) != 0) return rc;
+        E3DGE_REQUIRE(Q->gact[2 + 2 * u] && Q->gact[3 + 2 * u] && P->act[2 + 2 * u] && P->act[3 + 2 * u] && P->rgb[u].wm && Q->pbuf && (u == n_up - 1 || Q->drgb[1 + u]),
+                      "dec2_backward: level %d workspace missing", u);
+    }
+    hipStream_t st = as_stream(stream);
+    const int n_l = e3dge_dec2_bwd_num_launches(n_up);
+    const bool timing = Q->kernel_ms != nullptr;
+    E3DGE_REQUIRE(!timing || Q->n_kernel_ms >= n_l, "dec2_backward: kernel_ms needs %d entries", n_l);
+    hipEvent_t ev[8 + 4 * E3DGE_DEC2_MAX_UP];
+    int n_ev = 0;
+    bool ev_failed = false;
+    auto mark = [&]() {
+        if (!timing || ev_failed) return;
+        if (hipEventCreate(&ev[n_ev]) != hipSuccess) { ev_failed = true; return; }
+        if (hipEventRecord(ev[n_ev++], st) != hipSuccess) ev_failed = true;
+    };
+    auto finish = [&](int code) {
+        if (timing) {
+            if (code == 0 && ev_failed) code = fail(E3DGE_ERR_LAUNCH, "dec2_backward: HIP event create / record failed (kernel_ms)");
+            if (code == 0 && n_ev > 0) {
+                hipEventSynchronize(ev[n_ev - 1]);
+                for (int i = 0; i + 1 < n_ev; ++i) hipEventElapsedTime(&Q->kernel_ms[i], ev[i], ev[i + 1]);
+            }
+            for (int i = 0; i < n_ev; ++i) hipEventDestroy(ev[i]);
+        }
+        return code;
+    };
+#define DEC2_STEP(expr) do { rc = (expr); if (rc) return finish(rc); mark(); } while (0)
+    // amax buffers: [u + 1] d rgb of level u (u = -1: rgb1's; u = n_up - 1: d img), then G2 of level u ([n_up + 1 + (u + 1)]), G1 ([2 n_up + 2 + u]), P ([3 n_up + 2 + u])
+    auto am_d = [&](int u) { return Q->amax + (int64_t)E3DGE_AMAX_FLOATS * (u + 1); };
+    auto am_g2 = [&](int u) { return Q->amax + (int64_t)E3DGE_AMAX_FLOATS * (n_up + 2 + u); };
+    auto am_g1 = [&](int u) { return Q->amax + (int64_t)E3DGE_AMAX_FLOATS * (2 * n_up + 2 + u); };
+    auto am_p = [&](int u) { return Q->amax + (int64_t)E3DGE_AMAX_FLOATS * (3 * n_up + 2 + u); };
+    // meta: G2 of level u at [u + 1], G1 at [n_up + 1 + u], P at [2 n_up + 1 + u];  bounds: conv1 [0], up[u] [1 + 2u], conv[u] [2 + 2u], rgb of level u [2 n_up + 2 + u]
+    auto mt_g2 = [&](int u) { return Q->meta + (u + 1); };
+    auto mt_g1 = [&](int u) { return Q->meta + (n_up + 1 + u); };
+    auto mt_p = [&](int u) { return Q->meta + (2 * n_up + 1 + u); };
+    auto bd_rgb = [&](int u) { return Q->bounds + (2 * n_up + 2 + u); };
+    const E3dgeDec2Rgb& rgb_top = n_up ? P->rgb[n_up - 1] : P->rgb1;
+    auto rgb_of = [&](int u) -> const E3dgeDec2Rgb& { return u < 0 ? P->rgb1 : P->rgb[u]; };
+    auto drgb_of = [&](int u) -> const float* { return u == n_up - 1 ? Q->d_img : Q->drgb[u + 1]; };
+
+    mark();
+    {   // 1. operator norms + clear the amax block
+        PkBndTab tab{};
+        auto add = [&](const E3dgeDec2Conv& c, const E3dgeDec2BwdConv& q) {
+            PkBndConv& w = tab.conv[tab.n_conv++];
+            w.style = c.style; w.demod = c.demod; w.wsq = q.wsq; w.co = c.co; w.ci = c.ci;
+        };
+        add(P->conv1, Q->conv1);
+        for (int u = 0; u < n_up; ++u) { add(P->up[u], Q->up[u]); add(P->conv[u], Q->conv[u]); }
+        for (int u = -1; u < n_up; ++u) { PkBndRgb& w = tab.rgb[tab.n_rgb++]; w.wm = rgb_of(u).wm; w.ci = rgb_of(u).ci; }
+        tab.batch = B; tab.out = Q->bounds; tab.zero = Q->amax; tab.n_zero = E3DGE_AMAX_FLOATS * (4 * n_up + 2);
+        pk_bwd_bounds_kernel<<<dim3((unsigned)(tab.n_conv + tab.n_rgb)), dim3(256), 0, st>>>(tab);
+        DEC2_STEP(check_launch("dec2 bwd bounds"));
+    }
+    {   // 2. transposed per-sample weight images
+        PkWTab tab{};
+        auto add = [&](const E3dgeDec2Conv& c, const E3dgeDec2BwdConv& q) {
+            PkWConv& w = tab.conv[tab.n_conv++];
+            w.wpre = q.wpre_t; w.style = c.style; w.demod = c.demod; w.img = q.wimg_t; w.co = c.ci; w.ci = c.co; w.n_chunks = c.co / 16;
+            w.n_items = (c.ci / 32) * (c.co / 16) * 9 * 64;
+            w.words = e3dge_modconv_packed_words(c.ci, c.co);
+            w.swap = 1;
+        };
+        add(P->conv1, Q->conv1);
+        for (int u = 0; u < n_up; ++u) { add(P->up[u], Q->up[u]); add(P->conv[u], Q->conv[u]); }
+        pk_weights_kernel<<<dim3(96, (unsigned)tab.n_conv, (unsigned)B), dim3(256), 0, st>>>(tab);
+        DEC2_STEP(check_launch("dec2 bwd weights"));
+    }
+    const int top_res = P->in_res << n_up;
+    // 3. max |d img|
+    DEC2_STEP(e3dge_amax(am_d(n_up - 1), Q->d_img, (int64_t)B * 3 * top_res * top_res, stream));
+    {   // 4. G2[top] = lrelu'(act2[top]) sqrt 2 . ToRGB^T d img
+        const int top_act = n_up ? 3 + 2 * (n_up - 1) : 1;
+        PkRgbtK k{};
+        k.d_img = Q->d_img; k.wm = rgb_top.wm; k.act = reinterpret_cast<const unsigned char*>(P->act[top_act]);
+        k.y = reinterpret_cast<unsigned char*>(Q->gact[top_act]);
+        k.d_amax = am_d(n_up - 1); k.rgb_l1 = bd_rgb(n_up - 1); k.out_meta = mt_g2(n_up - 1); k.out_amax = am_g2(n_up - 1);
+        k.act_scale = P->act_scale; k.slope = P->negative_slope; k.B = B; k.C = rgb_top.ci; k.R = top_res;
+        E3DGE_REQUIRE(k.C % 8 == 0, "dec2_backward: top channel count %d", k.C);
+        pk_rgbt_mask_kernel<<<dim3((unsigned)(((int64_t)top_res * top_res + 255) / 256), (unsigned)(k.C / 8), (unsigned)B), dim3(256), 0, st>>>(k);
+        DEC2_STEP(check_launch("dec2 bwd rgbT+mask"));
+    }
+    auto bwd_args = [&](const E3dgeDec2Conv& c, const E3dgeDec2BwdConv& q, int res) {
+        PkConvK k{};
+        k.wimg = reinterpret_cast<const unsigned char*>(q.wimg_t);
+        k.wimg_bytes = e3dge_modconv_packed_words(c.ci, c.co) * 4;
+        k.slope = P->negative_slope; k.act_scale = P->act_scale;
+        k.B = B; k.Ci = c.co; k.Co = c.ci; k.H = res; k.W = res; k.n_chunks = c.co / 16;
+        return k;
+    };
+    int res = top_res;
+    for (int u = n_up - 1; u >= 0; --u) {
+        const int a2 = 3 + 2 * u, a1 = 2 + 2 * u, prev = u == 0 ? 1 : 3 + 2 * (u - 1);
+        {   // d rgb of the level below
+            const int h = res >> 1;
+            pk_drgb_down_kernel<<<dim3((unsigned)((h * h + 255) / 256), (unsigned)(3 * B)), dim3(256), 0, st>>>(Q->drgb[u], am_d(u - 1), drgb_of(u), P->fir_up, 3 * B, res);
+            DEC2_STEP(check_launch("dec2 bwd d_rgb"));
+        }
+        {   // G1 = lrelu'(act1) sqrt 2 . conv^T G2
+            PkConvK k = bwd_args(P->conv[u], Q->conv[u], res);
+            k.x = reinterpret_cast<const unsigned char*>(Q->gact[a2]); k.in_meta = mt_g2(u); k.in_amax = am_g2(u);
+            k.y = reinterpret_cast<unsigned char*>(Q->gact[a1]); k.out_meta = mt_g1(u); k.out_amax = am_g1(u);
+            k.mask_act = reinterpret_cast<const unsigned char*>(P->act[a1]); k.bwd_wl1 = Q->bounds + 2 + 2 * u;
+            DEC2_STEP(conv_s1_bwd<1>(k, st));
+        }
+        {   // P = phases of Blur^T G1
+            PkDblurK k{};
+            k.g = reinterpret_cast<const unsigned char*>(Q->gact[a1]); k.in_meta = mt_g1(u); k.in_amax = am_g1(u); k.fir = P->fir_blur;
+            k.p = reinterpret_cast<unsigned char*>(Q->pbuf); k.out_meta = mt_p(u); k.out_amax = am_p(u);
+            k.B = B; k.C = P->up[u].co; k.R = res;
+            const int h = res >> 1;
+            k.tiles_x = (h + 1 + kDbTJ - 1) / kDbTJ; k.tiles_y = (h + 1 + kDbTI - 1) / kDbTI;
+            const int64_t blocks = (int64_t)k.tiles_x * k.tiles_y * (k.C / 8) * B;
+            if (!(blocks < ((int64_t)1 << 31))) return finish(fail(E3DGE_ERR_INVALID_ARG, "dec2 bwd blur: too many tiles"));
+            pk_dblur_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(k);
+            DEC2_STEP(check_launch("dec2 bwd blur^T"));
+        }
+        res >>= 1;
+        {   // G2 of the level below = lrelu'(act2) sqrt 2 . (conv_stride2(P) + ToRGB^T d rgb)
+            PkConvK k = bwd_args(P->up[u], Q->up[u], res);
+            k.x = reinterpret_cast<const unsigned char*>(Q->pbuf); k.in_meta = mt_p(u); k.in_amax = am_p(u);
+            k.y = reinterpret_cast<unsigned char*>(Q->gact[prev]); k.out_meta = mt_g2(u - 1); k.out_amax = am_g2(u - 1);
+            k.mask_act = reinterpret_cast<const unsigned char*>(P->act[prev]); k.bwd_wl1 = Q->bounds + 1 + 2 * u;
+            k.rgbt_d = Q->drgb[u]; k.rgb_wm = rgb_of(u - 1).wm; k.rgbt_amax = am_d(u - 1); k.rgbt_l1 = bd_rgb(u - 1);
+            if (k.Co % 64 == 0) DEC2_STEP(launch_down<2>(k, st, "dec2 convT^T<64co,4x32>"));
+            else DEC2_STEP(launch_down<1>(k, st, "dec2 convT^T<32co,4x32>"));
+        }
+    }
+    {   // d features = conv1^T G2[-1]
+        PkConvK k = bwd_args(P->conv1, Q->conv1, res);
+        k.x = reinterpret_cast<const unsigned char*>(Q->gact[1]); k.in_meta = mt_g2(-1); k.in_amax = am_g2(-1);
+        k.out_f32 = Q->d_features;
+        DEC2_STEP(conv_s1_bwd<2>(k, st));
     }
 #undef DEC2_STEP
     return finish(E3DGE_OK);

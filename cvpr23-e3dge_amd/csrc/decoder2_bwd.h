@@ -1,0 +1,456 @@
+// Data gradient of the packed decoder pipeline (round 5; included by decoder2.hip inside namespace e3dge): d image -> d features through
+// Decoder.forward (project/models/stylesdf_model.py:742-797) with the generator frozen -- the backward that train_ae.py's stage-1 step
+// takes for every sample (trainer.py:1017-1031 puts the pixel loss on pool_256(gen_imgs); trainer.py:728 calls loss.backward()).
+// The reference differentiates ModulatedConv2d (:317-362: F.conv2d / F.conv_transpose2d on the modulated weights), Blur / Upsample
+// (op/upfirdn2d.py:18-142: the adjoint is upfirdn2d with the flipped kernel and up <-> down), FusedLeakyReLU (op/fused_act.py:19-84:
+// grad = 1 of fused_bias_act with the OUTPUT as reference) and ToRGB (:531-541) through autograd.  Here the chain is written out on
+// the packed layout, top level first:
+//
+//     G2[top]   = lrelu'(act2[top]) sqrt 2 . (ToRGB_top^T d img)                                     pk_rgbt_mask_kernel
+//     per level u = top .. 0 (resolution R, C channels; the level below has C' channels at R / 2):
+//         d rgb[u-1] = Upsample^T d rgb[u]   (4x4 FIR, stride 2)                                     pk_drgb_down_kernel
+//         G1[u]   = lrelu'(act1[u]) sqrt 2 . conv3x3(G2[u], flip(w'')^T)                              pkconv_s1_kernel<.., BWD = 1>
+//         P[u]    = Blur^T G1[u], split into the four stride-2 phases  ((R/2 + 1)^2 each)             pk_dblur_kernel
+//         G2[u-1] = lrelu'(act2[u-1]) sqrt 2 . (conv3x3_stride2(P[u], w''^T) + ToRGB_{u-1}^T d rgb[u-1])   pkconv_down_kernel
+//     d features = conv3x3(G2[-1], flip(w''_conv1)^T)                                                 pkconv_s1_kernel<.., BWD = 2>
+//
+// Every gradient tensor between the kernels is packed exactly as the activations are (16-byte entries of eight f16 hi / lo halves,
+// one-entry zero border, one scale exponent per tensor from an a-priori bound), so the convolutions are the forward's LDS-DMA + MFMA
+// machinery on transposed weight images (pk_prepack_t_kernel + pk_weights_kernel with swap).  lrelu' comes from the sign of the hi
+// half of the packed FORWARD activation (v > 0 <=> hi > 0 unless |v| < 2^-39 of the tensor's bound): no mask tensor is stored.
+// Bounds: |conv^T g| <= max|g| max_row sum|w''|, and sum_tap |w''| <= 3 sqrt(sum_tap w''^2) = 3 |s| demod sqrt(wsq) (Cauchy-Schwarz on the
+// nine taps) gives a deterministic operator norm from the (co, ci) table the forward's demodulation already uses (pk_bwd_bounds_kernel).
+
+// ---- operator norms of the transposed images + ToRGB tables (one block per layer; also clears the call's amax block) ----------------
+struct PkBndConv { const float* style; const float* demod; const float* wsq; int co, ci; };
+struct PkBndRgb { const float* wm; int ci; };
+struct PkBndTab { PkBndConv conv[2 * E3DGE_DEC2_MAX_UP + 1]; PkBndRgb rgb[E3DGE_DEC2_MAX_UP + 1]; int n_conv, n_rgb, batch, n_zero; float* out; float* zero; };
+
+__global__ void __launch_bounds__(256) pk_bwd_bounds_kernel(const PkBndTab tab) {
+    __shared__ float red[4];
+    const int layer = blockIdx.x, tid = threadIdx.x;
+    for (int i = layer * 256 + tid; i < tab.n_zero; i += gridDim.x * 256) tab.zero[i] = 0.0f;
+    float m = 0.0f;
+    if (layer < tab.n_conv) {
+        const PkBndConv L = tab.conv[layer];
+        for (int b = 0; b < tab.batch; ++b)
+            for (int ci = tid; ci < L.ci; ci += 256) {
+                float acc = 0.0f;
+                for (int co = 0; co < L.co; ++co) acc = fmaf(L.demod[(size_t)b * L.co + co], sqrtf(L.wsq[(size_t)co * L.ci + ci]), acc);
+                m = fmaxf(m, 3.0f * fabsf(L.style[(size_t)b * L.ci + ci]) * acc);
+            }
+    } else {
+        const PkBndRgb L = tab.rgb[layer - tab.n_conv];
+        for (int b = 0; b < tab.batch; ++b)
+            for (int ci = tid; ci < L.ci; ci += 256) {
+                const float* w = L.wm + (size_t)b * 3 * L.ci + ci;
+                m = fmaxf(m, fabsf(w[0]) + fabsf(w[L.ci]) + fabsf(w[2 * L.ci]));
+            }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) tab.out[layer] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * 1.0001f;
+}
+
+// ---- Upsample^T of a 3-channel image: d skip[iy][ix] = sum_{m,n} d out[2 iy - 1 + m][2 ix - 1 + n] fir[m][n]  (the adjoint of
+// upfirdn2d(skip, fir, up = 2, pad = (2, 1)) as pk_torgb_kernel / the fused ToRGB epilogues apply it) + max |.| ------------------------
+__global__ void __launch_bounds__(256)
+pk_drgb_down_kernel(float* __restrict__ y, float* __restrict__ y_amax, const float* __restrict__ x, const float* __restrict__ fir, int planes, int r) {
+    __shared__ float red[4];
+    const int h = r >> 1, hw = h * h;
+    const int p = blockIdx.x * 256 + threadIdx.x, pl = blockIdx.y;
+    float v = 0.0f;
+    if (p < hw && pl < planes) {
+        const int iy = p / h, ix = p - iy * h;
+        const float* xp = x + (int64_t)pl * r * r;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int oy = 2 * iy - 1 + m;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int ox = 2 * ix - 1 + n;
+                if (oy >= 0 && oy < r && ox >= 0 && ox < r) v = fmaf(xp[(int64_t)oy * r + ox], fir[m * 4 + n], v);
+            }
+        }
+        y[(int64_t)pl * hw + p] = v;
+    }
+    float m = fabsf(v);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomic_max_nonneg(y_amax + ((int)(blockIdx.x + blockIdx.y * gridDim.x) & (kAmaxSlots - 1)) * kAmaxStride, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
+// ---- top of the chain: G2 = lrelu'(act) sqrt 2 . (ToRGB^T d img), one thread per (pixel, group of eight channels) ---------------------
+struct PkRgbtK {
+    const float* d_img; const float* wm; const unsigned char* act; unsigned char* y;
+    const float* d_amax; const float* rgb_l1; int* out_meta; float* out_amax;
+    float act_scale, slope; int B, C, R;
+};
+__global__ void __launch_bounds__(256) pk_rgbt_mask_kernel(const PkRgbtK a) {
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63;
+    const float bound = a.act_scale * amax_read(a.d_amax, lane) * a.rgb_l1[0] * 1.001f;
+    const unsigned eb = scale_exponent(bound);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) a.out_meta[0] = (int)eb;
+    const float gmul = a.act_scale * pow2_bits(268u - eb);
+    const int p = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y, b = blockIdx.z, G = a.C >> 3, R = a.R;
+    float m = 0.0f;
+    if (p < R * R) {
+        const int y = p / R, x = p - y * R;
+        const int64_t hw = (int64_t)R * R, plane = (int64_t)(R + 2) * (R + 2);
+        const int64_t e = ((int64_t)(b * G + g) * 2) * plane + (int64_t)(y + 1) * (R + 2) + x + 1;
+        const u32x4 ah = reinterpret_cast<const u32x4*>(a.act)[e];
+        float d[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d[c] = a.d_img[((int64_t)b * 3 + c) * hw + p];
+        const float* __restrict__ w = a.wm + (size_t)b * 3 * a.C + 8 * g;          // (block-uniform: scalar loads)
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = w[j] * d[0];
+            t = fmaf(w[a.C + j], d[1], t);
+            t = fmaf(w[2 * a.C + j], d[2], t);
+            const unsigned hb = (ah[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            t = (hb - 1u < 0x7fffu) ? t : t * a.slope;
+            v[j] = t * gmul;
+            m = fmaxf(m, fabsf(v[j]));
+        }
+        u32x4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) SPLIT2_TO(v[2 * q], v[2 * q + 1], hi[q], lo[q]);
+        reinterpret_cast<u32x4*>(a.y)[e] = hi;
+        reinterpret_cast<u32x4*>(a.y)[e + plane] = lo;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+    if (lane == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomic_max_nonneg(a.out_amax + ((int)(blockIdx.x + 7 * blockIdx.y) & (kAmaxSlots - 1)) * kAmaxStride,
+                          fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * pow2_bits(eb - 14u));
+}
+
+// ---- Blur^T + stride-2 phase split -------------------------------------------------------------------------------------------------------
+// Forward: pre = upfirdn2d(T, K, pad = (1, 1)), T (2h+1)^2 -> (2h)^2:  pre[y][x] = sum_{m,n} T[y + 2 - m][x + 2 - n] K[m][n]  (the op
+// correlates with the flipped kernel).  Adjoint: d T[Y][X] = sum_{m,n} g[Y + m - 2][X + n - 2] K[m][n], g = 0 outside [0, 2h)^2.
+// Output: P (B, C/8, 2, 4, h+2, h+2) entries, P[..][2 py + px][i][j] = d T[2i + py][2j + px] (0 beyond 2h): the stride-2 convolution
+// that follows reads tap (ky, kx) from phase (ky & 1, kx & 1) at offset (ky >> 1, kx >> 1) -- unit-stride patches for its LDS-DMA.
+// A block owns 8 x 32 phase positions of one channel group; a thread all four phases of one position (coalesced 16-byte stores into
+// four planes) from the 5 x 5 neighbourhood in LDS (fp32, even / odd columns and channel halves in separate planes: lane-linear reads).
+struct PkDblurK {
+    const unsigned char* g; const int* in_meta; const float* in_amax; const float* fir;
+    unsigned char* p; int* out_meta; float* out_amax;
+    int B, C, R, tiles_x, tiles_y;
+};
+constexpr int kDbTI = 8, kDbTJ = 32, kDbRows = 2 * kDbTI + 3, kDbCols = 2 * kDbTJ + 3, kDbCP = 36;
+__global__ void __launch_bounds__(256) pk_dblur_kernel(const PkDblurK a) {
+    __shared__ f32x4 sm[kDbRows][2][2][kDbCP];           // [row][column parity][channel half][column / 2]
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int R = a.R, h = R >> 1, G = a.C >> 3;
+    int t = blockIdx.x;
+    const int tx = t % a.tiles_x; t /= a.tiles_x;
+    const int ty = t % a.tiles_y; t /= a.tiles_y;
+    const int g = t % G, b = t / G;
+    const int i0 = ty * kDbTI, j0 = tx * kDbTJ;
+    float ksum = 0.0f, K[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { K[i] = a.fir[i]; ksum += fabsf(K[i]); }
+    const float bound = amax_read(a.in_amax, lane) * ksum * 1.001f;
+    const unsigned eb = scale_exponent(bound);
+    if (blockIdx.x == 0 && tid == 0) a.out_meta[0] = (int)eb;
+    const float inv_in = pow2_bits((unsigned)a.in_meta[0] - 14u);              // 2^(eb_in - 141)
+    const float sc = pow2_bits(268u - eb);
+    {
+        const int64_t plane = (int64_t)(R + 2) * (R + 2);
+        const u32x4* __restrict__ gp = reinterpret_cast<const u32x4*>(a.g) + ((int64_t)(b * G + g) * 2) * plane;
+        for (int idx = tid; idx < kDbRows * kDbCols; idx += 256) {
+            const int r = idx / kDbCols, cx = idx - r * kDbCols;
+            const int Y = 2 * i0 - 2 + r, X = 2 * j0 - 2 + cx;
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+            if (Y >= 0 && Y < R && X >= 0 && X < R) {
+                const int64_t e = (int64_t)(Y + 1) * (R + 2) + X + 1;
+                const u32x4 hi = gp[e], lo = gp[e + plane];
+                v0[0] = (f16lo(hi[0]) + f16lo(lo[0])) * inv_in; v0[1] = (f16hi(hi[0]) + f16hi(lo[0])) * inv_in;
+                v0[2] = (f16lo(hi[1]) + f16lo(lo[1])) * inv_in; v0[3] = (f16hi(hi[1]) + f16hi(lo[1])) * inv_in;
+                v1[0] = (f16lo(hi[2]) + f16lo(lo[2])) * inv_in; v1[1] = (f16hi(hi[2]) + f16hi(lo[2])) * inv_in;
+                v1[2] = (f16lo(hi[3]) + f16lo(lo[3])) * inv_in; v1[3] = (f16hi(hi[3]) + f16hi(lo[3])) * inv_in;
+            }
+            sm[r][cx & 1][0][cx >> 1] = v0;
+            sm[r][cx & 1][1][cx >> 1] = v1;
+        }
+    }
+    __syncthreads();
+    const int ti = tid >> 5, tj = tid & 31;
+    f32x4 acc[2][4];                                     // [channel half][phase]
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) acc[ch][ph] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            f32x4 row[5];
+#pragma unroll
+            for (int c = 0; c < 5; ++c) row[c] = sm[2 * ti + r][c & 1][ch][tj + (c >> 1)];
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const int m = r - py;
+                if (m < 0 || m > 3) continue;
+#pragma unroll
+                for (int px = 0; px < 2; ++px)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const float k = K[m * 4 + n];
+                        const f32x4 x = row[n + px];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[ch][2 * py + px][j] = fmaf(x[j], k, acc[ch][2 * py + px][j]);
+                    }
+            }
+        }
+    }
+    const int i = i0 + ti, j = j0 + tj;
+    float m = 0.0f;
+    if (i <= h && j <= h) {
+        const int64_t planep = (int64_t)(h + 2) * (h + 2);
+        u32x4* __restrict__ pp = reinterpret_cast<u32x4*>(a.p) + ((int64_t)(b * G + g) * 8) * planep + (int64_t)i * (h + 2) + j;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const bool in = (2 * i + (ph >> 1) <= 2 * h) && (2 * j + (ph & 1) <= 2 * h);
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                v[q] = in ? acc[q >> 2][ph][q & 3] * sc : 0.0f;
+                m = fmaxf(m, fabsf(v[q]));
+            }
+            u32x4 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) SPLIT2_TO(v[2 * q], v[2 * q + 1], hi[q], lo[q]);
+            pp[(int64_t)ph * planep] = hi;
+            pp[(int64_t)(4 + ph) * planep] = lo;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+    if (lane == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0)
+        atomic_max_nonneg(a.out_amax + ((int)blockIdx.x & (kAmaxSlots - 1)) * kAmaxStride, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * pow2_bits(eb - 14u));
+}
+
+// ---- stride-2 3x3 convolution of the phase planes: the data gradient of conv_transpose2d(stride 2) --------------------------------------
+// d x[ci][i][j] = sum_{co, ky, kx} w''[co][ci][ky][kx] d T[co][2i + ky][2j + kx] = sum_taps w'' P[ky & 1, kx & 1][co][i + (ky >> 1)][j + (kx >> 1)].
+// The input is four times the output's pixels, so a tile's patch is sixteen planes ((k-half, hi | lo) x four phases): a workgroup of
+// four waves owns 4 x 32 output pixels x 32 NCT channels (one row per wave), 16 x 5 x 33 entries + NCT weight slabs per stage, two
+// stages (158 KB with NCT = 2: one workgroup per CU; the K loop is LDS-DMA bound at ~84 KB per 1.7 k cycles of MFMAs).  Steps, barrier
+// and DMA issue as in pkconv_s1_kernel; pieces are dealt out statically: slot sl of wave w is piece w + 4 sl -- patch pieces first
+// (plane = w + 4 (sl % 4), 64-entry round = sl / 4: the round is a compile-time constant, the plane only enters scalar address
+// arithmetic), then the weight pieces.  Epilogue = bwd_tile_epilogue (ToRGB^T of the level below + lrelu' + split + store).
+template <int NCT>
+__global__ void __launch_bounds__(256) pkconv_down_kernel(const PkConvK a) {
+    constexpr int NW = 4, NT = 256, TH = 4, TW = 32, PH = TH + 1, PW = TW + 1, NPIX = PH * PW, NPP = (NPIX + 63) / 64;
+    constexpr int NPL = 16, XPLANE = NPIX * 16, XST = NPL * XPLANE, WST = NCT * kPkSlab, STAGE = XST + WST;
+    constexpr int NXS = (NPL / NW) * NPP, NWP = NCT * 18, NWS = (NWP + NW - 1) / NW, NSLOT = NXS + NWS, PPT = (NSLOT + E3DGE_PK_ISSUE_TAPS - 1) / E3DGE_PK_ISSUE_TAPS;
+    static_assert(NPL % NW == 0, "planes are dealt out four per round");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_pk[];
+    float* const tab = reinterpret_cast<float*>(smem_pk + 2 * STAGE);        // [3][32 NCT]: (scale W) s of this workgroup's channels
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int my_tiles = (a.n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nsteps = my_tiles * a.n_chunks;
+    if (nsteps <= 0) return;
+    const int HP = a.H + 2, WP = a.W + 2, G = a.Ci >> 3;
+    const int64_t plane_b = (int64_t)HP * WP * 16;                          // bytes of one (g, hl, phase) plane of P
+
+    const float oscale = pow2_bits((unsigned)a.in_meta[0] - 21u);
+    const float rg = a.rgbt_d ? amax_read(a.rgbt_amax, lane) * a.rgbt_l1[0] : 0.0f;
+    const float bound = a.act_scale * (amax_read(a.in_amax, lane) * a.bwd_wl1[0] * 1.002f + rg) * 1.001f;
+    const unsigned eb_out = scale_exponent(bound);
+    const float sc_out = pow2_bits(268u - eb_out);
+    if (blockIdx.x == 0 && tid == 0) a.out_meta[0] = (int)eb_out;
+
+    struct Pos { int k, c, b, cb, ty, tx; };
+    auto tile_of = [&](Pos& p) {
+        if (p.k >= my_tiles) return;
+        int L = xcd_logical((int)blockIdx.x + p.k * (int)gridDim.x, a.n_tiles);
+        p.cb = L % a.co_blocks; L /= a.co_blocks;
+        p.tx = L % a.tiles_x; L /= a.tiles_x;
+        p.ty = L % a.tiles_y; p.b = L / a.tiles_y;
+    };
+    auto advance = [&](Pos& p) { if (++p.c == a.n_chunks) { p.c = 0; ++p.k; tile_of(p); } };
+
+    // static per-lane piece data: patch entry (row << 8 | column) of each 64-entry round, source offset of each weight slot
+    uint32_t pk[NPP], wvo[NWS];
+#pragma unroll
+    for (int pp = 0; pp < NPP; ++pp) {
+        const int e = pp * 64 + lane, prow = e / PW, pcol = e - prow * PW;
+        pk[pp] = e < NPIX ? (uint32_t)(prow << 8 | pcol) : 0xffffffffu;
+        asm volatile("" : "+v"(pk[pp]));
+    }
+#pragma unroll
+    for (int j = 0; j < NWS; ++j) {
+        const int i = wave + j * NW, ct = i / 18, pc = i - ct * 18;
+        wvo[j] = (uint32_t)lane * 16u + (uint32_t)((ct * a.n_chunks * 18 + pc) * 1024);
+        asm volatile("" : "+v"(wvo[j]));
+    }
+    struct Src { uint32_t wlo, whi, xlo, xhi; uint32_t vo[NPP]; };
+    auto src_of = [&](const Pos& ps) {
+        const uint64_t w = reinterpret_cast<uint64_t>(a.wimg + (int64_t)ps.b * a.wimg_bytes + ((int64_t)(ps.cb * NCT) * a.n_chunks + ps.c) * kPkSlab);
+        const uint64_t x = reinterpret_cast<uint64_t>(a.x + ((int64_t)(ps.b * G + 2 * ps.c) * 8) * plane_b);
+        Src sc;
+        sc.wlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w); sc.whi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 32));
+        sc.xlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x); sc.xhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32));
+        asm volatile("" : "+s"(sc.wlo), "+s"(sc.whi), "+s"(sc.xlo), "+s"(sc.xhi));
+        const int gy0 = ps.ty * TH, gx0 = ps.tx * TW;
+#pragma unroll
+        for (int pp = 0; pp < NPP; ++pp) {
+            // (clamped into the plane: tiles that overhang the image read entries whose results are never stored)
+            const int gy = min(gy0 + (int)(pk[pp] >> 8), HP - 1), gx = min(gx0 + (int)(pk[pp] & 255u), WP - 1);
+            sc.vo[pp] = pk[pp] == 0xffffffffu ? 0xffffffffu : (uint32_t)(gy * WP + gx) * 16u;
+        }
+        return sc;
+    };
+    const uint32_t plb = (uint32_t)plane_b;
+    auto issue = [&](const Src& sc, uint32_t xl, int s_lo, int s_hi) {
+        const void* wsrc = reinterpret_cast<const void*>((uint64_t)sc.whi << 32 | sc.wlo);
+        const uint64_t xs = (uint64_t)sc.xhi << 32 | sc.xlo;
+#pragma unroll
+        for (int sl = s_lo; sl < s_hi; ++sl) {
+            if (sl < NXS) {
+                const int pp = sl / (NPL / NW), pl = wave + NW * (sl % (NPL / NW));
+                const void* xsrc = reinterpret_cast<const void*>(xs + (uint64_t)pl * plb);
+                const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(xl + (uint32_t)(pl * XPLANE + pp * 1024)));
+                if (sc.vo[pp] != 0xffffffffu) glds16_saddr<0>(uniform_ptr(xsrc), sc.vo[pp], dst);
+            } else {
+                const int j = sl - NXS;
+                if ((j + 1) * NW <= NWP || wave + j * NW < NWP)
+                    glds16_saddr<0>(wsrc, wvo[j], xl + (uint32_t)(XST + (wave + j * NW) * 1024));
+            }
+        }
+    };
+    auto stage_lds = [&](int stage) {
+        uint32_t xl = lds_u32(smem_pk) + (uint32_t)(stage * STAGE);
+        asm volatile("" : "+s"(xl));
+        return xl;
+    };
+
+    Pos p_cur{0, 0, 0, 0, 0, 0};
+    tile_of(p_cur);
+    Pos p_nx1 = p_cur; advance(p_nx1);
+    issue(src_of(p_cur), stage_lds(0), 0, NSLOT);
+
+    f32x16 acc[NCT];
+    float amax_l = 0.0f;
+    int b_tab = -1, cb_tab = -1;
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        const bool has_next = step + 1 < nsteps, last_chunk = p_cur.c == a.n_chunks - 1;
+        const Src src_nx = src_of(p_nx1);
+        const uint32_t xl_nx = stage_lds(cur ^ 1);
+        if (p_cur.c == 0) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = zero16();
+            // (every wave has finished the previous tile's epilogue before this step's barrier; readers are >= 1 barrier away: n_chunks >= 2)
+            if (a.rgbt_d && (p_cur.b != b_tab || p_cur.cb != cb_tab)) {
+                b_tab = p_cur.b; cb_tab = p_cur.cb;
+                for (int i = tid; i < 3 * 32 * NCT; i += NT) {
+                    const int c = i / (32 * NCT), ch = i - c * 32 * NCT;
+                    tab[i] = a.rgb_wm[((size_t)b_tab * 3 + c) * a.Co + cb_tab * 32 * NCT + ch];
+                }
+            }
+        }
+        {
+            const unsigned char* xb = smem_pk + cur * STAGE;
+            const unsigned char* wb = xb + XST + lane * 16;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap % 3, ph = (ky & 1) * 2 + (kx & 1);
+                const int pix = (wave + (ky >> 1)) * PW + col + (kx >> 1);
+                const u32x4 bh = *reinterpret_cast<const u32x4*>(xb + (size_t)((half * 2 + 0) * 4 + ph) * XPLANE + pix * 16);
+                const u32x4 bl = *reinterpret_cast<const u32x4*>(xb + (size_t)((half * 2 + 1) * 4 + ph) * XPLANE + pix * 16);
+                u32x4 ah[NCT], al[NCT];
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    ah[ct] = *reinterpret_cast<const u32x4*>(wb + ct * kPkSlab + (tap * 2 + 0) * 1024);
+                    al[ct] = *reinterpret_cast<const u32x4*>(wb + ct * kPkSlab + (tap * 2 + 1) * 1024);
+                }
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma16(ah[ct], bh, acc[ct]);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma16(al[ct], bh, acc[ct]);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) acc[ct] = mfma16(ah[ct], bl, acc[ct]);
+                if (has_next && tap * PPT < NSLOT) issue(src_nx, xl_nx, tap * PPT, min((tap + 1) * PPT, NSLOT));
+                if (tap % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (last_chunk) {
+            const int oy = p_cur.ty * TH + wave, ox = p_cur.tx * TW + col;
+            float dr[3] = {0.0f, 0.0f, 0.0f};
+            if (a.rgbt_d) {
+                const float* dp = a.rgbt_d + (int64_t)p_cur.b * 3 * a.H * a.W + (unsigned)(min(oy, a.H - 1) * a.W + min(ox, a.W - 1));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dr[c] = dp[(int64_t)c * a.H * a.W];
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                bwd_tile_epilogue<false>(a, acc[ct], p_cur.b, p_cur.cb * NCT + ct, oy, ox, half, a.rgbt_d ? tab : nullptr, 32 * NCT,
+                                         p_cur.cb * 32 * NCT, dr, oscale, sc_out, amax_l);
+        }
+        p_cur = p_nx1;
+        advance(p_nx1);
+    }
+    if (a.out_amax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax_l = fmaxf(amax_l, __shfl_xor(amax_l, off, kWave));
+        if (lane == 0) atomic_max_nonneg(a.out_amax + (((int)blockIdx.x * NW + wave) & (kAmaxSlots - 1)) * kAmaxStride, amax_l / sc_out);
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------------
+template <int NCT>
+static int launch_down(PkConvK k, hipStream_t st, const char* what) {
+    constexpr int STAGE = 16 * (5 * 33) * 16 + NCT * kPkSlab, lds = 2 * STAGE + 3 * 32 * NCT * 4;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    E3DGE_REQUIRE(k.Co % (32 * NCT) == 0 && k.n_chunks >= 2, "%s: Co=%d not a multiple of %d, or fewer than 32 input channels", what, k.Co, 32 * NCT);
+    E3DGE_REQUIRE(k.y && k.out_meta && k.mask_act && k.bwd_wl1 && k.in_amax && (!k.rgbt_d || (k.rgb_wm && k.rgbt_amax && k.rgbt_l1)), "%s: missing pointer", what);
+    k.tiles_y = (k.H + 3) / 4;
+    k.tiles_x = (k.W + 31) / 32;
+    k.co_blocks = k.Co / (32 * NCT);
+    const int64_t n_tiles = (int64_t)k.B * k.co_blocks * k.tiles_y * k.tiles_x;
+    E3DGE_REQUIRE(n_tiles < ((int64_t)1 << 30), "%s: too many tiles", what);
+    k.n_tiles = (int)n_tiles;
+    auto fn = &pkconv_down_kernel<NCT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+    int grid = 256 * ((160 * 1024) / lds >= 2 ? 2 : 1);
+    if (grid > k.n_tiles) grid = k.n_tiles;
+    fn<<<dim3((unsigned)grid), dim3(256), lds, st>>>(k);
+    return check_launch(what);
+}
+
+// stride-1 data-gradient convolution: the forward's tile shapes (conv_s1), the table of ToRGB^T in LDS when the level has one
+template <int BWD>
+static int conv_s1_bwd(PkConvK k, hipStream_t st) {
+    int v = shape_override("E3DGE_DEC2_S1_BWD");
+    const int64_t px = (int64_t)k.H * k.W;
+    if (v < 0) {
+        if (k.Co % 64 != 0) v = 3;
+        else if (px <= 64 * 64) v = 0;
+        else if (px <= 128 * 128) v = 1;
+        else v = 2;
+        if (v == 2 && BWD == 1 && 158208 + 16 * k.Co > 160 * 1024) v = 3;      // (the 64-channel 8 x 64 tile + table would not fit)
+    }
+    if (k.Co % 64 != 0 && v != 3) v = 3;
+    switch (v) {
+        case 0: return launch_s1<1, 1, 1, 2, 4, 1, 0, BWD>(k, st, "dec2 conv^T<64co,4x32>");
+        case 1: return launch_s1<1, 1, 2, 2, 4, 1, 0, BWD>(k, st, "dec2 conv^T<64co,4x64>");
+        case 2: return launch_s1<2, 1, 2, 1, 8, 1, 0, BWD>(k, st, "dec2 conv^T<64co,8x64>");
+        default: return launch_s1<1, 1, 2, 1, 8, 1, 0, BWD>(k, st, "dec2 conv^T<32co,8x64>");
+    }
+}

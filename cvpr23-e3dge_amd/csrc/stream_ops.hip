@@ -276,7 +276,7 @@ modconv_weights_kernel(float* __restrict__ out, const float* __restrict__ weight
 
 using namespace e3dge;
 
-extern "C" int e3dge_abi_version(void) { return 11; }
+extern "C" int e3dge_abi_version(void) { return 12; }
 extern "C" const char* e3dge_last_error(void) { return err_buf(); }
 
 extern "C" int64_t e3dge_stream_capture_id(e3dge_stream_t stream) {

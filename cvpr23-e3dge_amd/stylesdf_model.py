@@ -140,28 +140,37 @@ def decoder_backend():
 
 def decoder_autograd_backend():
     """What Decoder.forward does when an autograd graph is wanted through it (features / latent / parameters require grad):
-    'packed' = the packed forward (e3dge_dec2_forward) wrapped in an autograd.Function whose backward recomputes the planar
-    library path (weight modulation + MIOpen) under enable_grad and differentiates that; 'library' = the library path for both
-    directions.  Forward-only cost 0.70 vs 1.0 ms at 1024^2; a full forward + backward is cheaper on the library path (no
-    recomputation) until the packed kernels get their own backward -- so 'library' is the default and E3DGE_DECODER_AUTOGRAD=packed
-    opts in (validation passes that run with grad enabled but never call backward)."""
-    v = os.environ.get("E3DGE_DECODER_AUTOGRAD", "library")
-    if v not in ("packed", "library"):
-        raise RuntimeError(f"E3DGE_DECODER_AUTOGRAD must be 'packed' or 'library', got {v!r}")
+    'auto' (default): when ONLY the feature map needs a gradient (generator frozen, decoder latent without grad: train_ae.py's
+    stage-1 step, trainer.py:1017-1031) the packed forward (e3dge_dec2_forward) runs inside an autograd.Function whose backward is
+    the packed pipeline's own data gradient (e3dge_dec2_backward, csrc/decoder2_bwd.h); anything else -- d latent, a decoder
+    parameter that requires grad -- takes the library path (weight modulation + MIOpen) for both directions.
+    'packed': always the packed forward; the backward is native when eligible, otherwise it recomputes the library path under
+    enable_grad and differentiates that (for passes that run with grad enabled but never call backward).
+    'library': the library path for both directions (round 4's default; A/B)."""
+    v = os.environ.get("E3DGE_DECODER_AUTOGRAD", "auto")
+    if v not in ("auto", "packed", "library"):
+        raise RuntimeError(f"E3DGE_DECODER_AUTOGRAD must be 'auto', 'packed' or 'library', got {v!r}")
     return v
 
 
 class _PackedDecoderFn(torch.autograd.Function):
-    """Decoder.forward as one native call (packed pipeline) that stays inside an autograd graph.  backward: the same forward is
-    re-run on the library path (every op differentiable) with the saved inputs and the SAME noise, and `torch.autograd.grad` of that
-    graph gives d features, d latent and the parameter gradients.  First-order only (reference: stylesdf_model.py:317-362, 741-797)."""
+    """Decoder.forward as one native call (packed pipeline) that stays inside an autograd graph (reference: stylesdf_model.py:317-362,
+    741-797).  backward, when only d features is wanted (generator frozen): e3dge_dec2_backward on the activations the forward left
+    in its workspace -- if another forward has used the workspace since, the packed forward is re-run first (0.65 ms at 1024^2).
+    Otherwise (d latent / parameter gradients): the same forward is re-run on the library path (every op differentiable) with the
+    saved inputs and the SAME noise, and `torch.autograd.grad` of that graph gives the gradients.  First-order only."""
 
     @staticmethod
     def forward(ctx, dec, noise, features, latent, *params):
         ctx.dec, ctx.noise, ctx.n_params = dec, noise, len(params)
         ctx.save_for_backward(features, latent)
+        need = ctx.needs_input_grad
+        ctx.native = dec._dec2_bwd_ok() and not need[3] and not any(need[4:])
         with torch.no_grad():
-            return dec._forward_packed(features, latent, noise)
+            img = dec._forward_packed(features, latent, noise, save=ctx.native)
+        if ctx.native:
+            ctx.gen = dec.__dict__['_dec2_gen']
+        return img
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -169,6 +178,14 @@ class _PackedDecoderFn(torch.autograd.Function):
         features, latent = ctx.saved_tensors
         dec = ctx.dec
         need = ctx.needs_input_grad
+        if ctx.native:
+            d_feat = None
+            if need[2]:
+                with torch.no_grad():
+                    if dec.__dict__.get('_dec2_gen') != ctx.gen:          # somebody else ran a forward on this decoder since
+                        dec._forward_packed(features, latent, ctx.noise, save=True)
+                    d_feat = dec._backward_packed(features, d_img)
+            return (None, None, d_feat, None) + (None,) * ctx.n_params
         params = [p for p in dec.parameters()]
         with torch.enable_grad():
             f_ = features.detach().requires_grad_(need[2])
@@ -263,11 +280,29 @@ class ModulatedConv2d(nn.Module):
         """Drop the packed weight images (needed after writes through `.data`; see SirenGenerator.invalidate)."""
         self._img = self._img_key = None
         self._wpre = self._wpre_key = None
+        self._wpre_t = self._wpre_t_key = None
 
     def _apply(self, fn, *a, **k):
         self._img = self._img_key = None
         self._wpre = self._wpre_key = None
+        self._wpre_t = self._wpre_t_key = None
         return super()._apply(fn, *a, **k)
+
+    def device_wpre_t(self):
+        """scale * W in the TRANSPOSED fragment order (rows = input channels, taps flipped for the stride-1 layers): what the
+        backward's weights launch streams (e3dge_dec2_prepack_weights_t; the data gradient of :331-361 of the reference)."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        if getattr(self, '_wpre_t', None) is None or self._wpre_t_key != key:
+            Co, Ci = self.out_channel, self.in_channel
+            wpre = torch.empty(Co * Ci * 9, device=w.device, dtype=torch.float32)
+            wc = w.detach().reshape(Co, Ci, 9).contiguous()
+            with torch.cuda.device(w.device):
+                rc = _lib.load().e3dge_dec2_prepack_weights_t(_lib.ptr(wpre), _lib.ptr(wc), float(self.scale), Co, Ci,
+                                                              0 if self.upsample else 1, _lib.stream_of(wc))
+            _lib.check(rc, "e3dge_dec2_prepack_weights_t")
+            self._wpre_t, self._wpre_t_key = wpre, key
+        return self._wpre_t
 
     def device_wpre(self):
         """scale * W re-arranged in MFMA A-fragment element order (fp32): what the per-forward weights launch of the packed
@@ -588,6 +623,7 @@ class Decoder(nn.Module):
             return None
         B = latent.shape[0]
         raw, buf, views, n, rows, cos = self._style_table(B, latent.device)
+        self.__dict__['_dec2_gen'] = self.__dict__.get('_dec2_gen', 0) + 1      # (the packed backward reads these buffers)
         lat = latent.contiguous()
         with torch.cuda.device(latent.device):
             rc = _lib.load().e3dge_decoder_styles(_lib.ptr(raw), n, rows, cos, _lib.ptr(lat), lat.shape[1], lat.shape[2], B,
@@ -608,9 +644,13 @@ class Decoder(nn.Module):
             return False
         if len(self.to_rgbs) > _lib.DEC2_MAX_UP or features.shape[0] < 1:
             return False
-        if self._needs_graph(features, latent) and (decoder_autograd_backend() != "packed" or
-                                                     any(n is not None and n.requires_grad for n in noise)):
-            return False
+        if self._needs_graph(features, latent):
+            mode = decoder_autograd_backend()
+            if mode == "library" or any(n is not None and n.requires_grad for n in noise):
+                return False
+            if mode == "auto" and not (self._dec2_bwd_ok() and not latent.requires_grad and
+                                       not any(p.requires_grad for p in _lib.params_of(self))):
+                return False
         for m, _ in self._mod_layers():
             if m.kernel_size == 3 and (m.in_channel % 16 or m.out_channel % 32 or not m.demodulate or m.in_channel > 1024):
                 return False
@@ -622,6 +662,13 @@ class Decoder(nn.Module):
         if B * max(self.channels.get(top, 16), 16) * (top + 4) * (top + 4) * 4 >= 2 ** 31:
             return False
         return all(n is None or (n.device == features.device and n.dtype == torch.float32) for n in noise)
+
+    def _dec2_bwd_ok(self):
+        """Can the packed pipeline differentiate itself (e3dge_dec2_backward)?  Every 3x3 layer needs 32-channel multiples on both
+        sides (the transposed weight images swap the roles); E3DGE_DEC2_BWD=library keeps round 4's recomputing backward (A/B)."""
+        if os.environ.get("E3DGE_DEC2_BWD", "native") == "library":
+            return False
+        return all(m.kernel_size != 3 or (m.in_channel % 32 == 0 and m.out_channel % 32 == 0) for m, _ in self._mod_layers())
 
     def _needs_graph(self, features, latent):
         return torch.is_grad_enabled() and (features.requires_grad or latent.requires_grad or
@@ -742,7 +789,7 @@ class Decoder(nn.Module):
         states[slot] = st
         return st
 
-    def _forward_packed(self, features, latent, noise, kernel_ms=None):
+    def _forward_packed(self, features, latent, noise, kernel_ms=None, save=False):
         """Decoder.forward body on the packed pipeline; `kernel_ms` (list) receives the HIP-event time of every launch
         (synchronous; for bench.py / tools).  The returned image is a fresh tensor; skip images live in the workspace."""
         B, res = features.shape[0], features.shape[2]
@@ -771,6 +818,8 @@ class Decoder(nn.Module):
         last = plan.rgb[len(self.to_rgbs) - 1] if len(self.to_rgbs) else plan.rgb1
         last.out = _lib.ptr(out)
         plan.features, plan.latent = _lib.ptr(x), _lib.ptr(lat)
+        plan.save_for_backward = int(bool(save))         # keep the top activation too: the backward reads every activation's signs
+        self.__dict__['_dec2_gen'] = self.__dict__.get('_dec2_gen', 0) + 1      # (a backward checks that its forward was the last one)
         ms = None
         if kernel_ms is not None:
             ms = (ctypes.c_float * st['n_launch'])()
@@ -783,6 +832,107 @@ class Decoder(nn.Module):
         if ms is not None:
             kernel_ms[:] = list(ms)
         st['hold'] = hold            # inputs of the launches just queued stay alive until the next call on this stream
+        return out
+
+    # ---- backward of the packed pipeline: d image -> d features (e3dge_dec2_backward, csrc/decoder2_bwd.h) -----------------------
+    def _dec2_bwd_state(self, st, B, res, device):
+        """Workspace + E3dgeDec2BwdPlan next to a forward state: packed gradient buffers (zero-filled once, shapes of the
+        activations), the phase-plane buffer of Blur^T, d rgb images, transposed per-sample weight images, amax / meta / norms."""
+        bw = st.get('bwd')
+        if bw is not None:
+            return bw
+        lib = _lib.load()
+        n_up = len(self.to_rgbs)
+        f32 = dict(device=device, dtype=torch.float32)
+        keep = []
+        q = _lib.Dec2BwdPlan()
+
+        def fill(dst, sc):
+            m = sc.conv
+            wimg = torch.empty(B * lib.e3dge_modconv_packed_words(m.in_channel, m.out_channel), device=device, dtype=torch.int32)
+            wsq = m.device_image()[1]
+            wpt = m.device_wpre_t()
+            keep.extend([wimg, wsq, wpt])
+            dst.wpre_t, dst.wsq, dst.wimg_t = _lib.ptr(wpt), _lib.ptr(wsq), _lib.ptr(wimg)
+        fill(q.conv1, self.conv1)
+        gacts = [None, torch.zeros_like(st['acts'][1])]
+        r, pwords = res, 0
+        for u in range(n_up):
+            fill(q.up[u], self.convs[2 * u])
+            fill(q.conv[u], self.convs[2 * u + 1])
+            d = torch.empty((B, 3, r, r), **f32)
+            keep.append(d)
+            q.drgb[u] = _lib.ptr(d)
+            r *= 2
+            gacts += [torch.zeros_like(st['acts'][2 + 2 * u]), torch.zeros_like(st['acts'][3 + 2 * u])]
+            pwords = max(pwords, lib.e3dge_dec2_pbuf_words(B, self.convs[2 * u].conv.out_channel, r))
+        for i, t in enumerate(gacts):
+            if t is not None:
+                q.gact[i] = _lib.ptr(t)
+        pbuf = torch.empty(max(pwords, 4), device=device, dtype=torch.int32)
+        amax = torch.zeros((4 * n_up + 2, _lib.AMAX_FLOATS), **f32)
+        meta = torch.zeros(3 * n_up + 1, device=device, dtype=torch.int32)
+        bounds = torch.zeros(3 * n_up + 2, **f32)
+        keep += [gacts, pbuf, amax, meta, bounds]
+        q.pbuf, q.amax, q.meta, q.bounds = _lib.ptr(pbuf), _lib.ptr(amax), _lib.ptr(meta), _lib.ptr(bounds)
+        bw = dict(plan=q, keep=keep, gacts=gacts, meta=meta, amax=amax, bounds=bounds, n_launch=lib.e3dge_dec2_bwd_num_launches(n_up))
+        st['bwd'] = bw
+        return bw
+
+    def _backward_packed(self, features, d_img, kernel_ms=None):
+        """d features for the LAST packed forward of this (batch, resolution, stream) -- it must have run with save=True."""
+        B, res = features.shape[0], features.shape[2]
+        dev = features.device
+        st = self._dec2_state(B, res, dev)
+        if not st['plan'].save_for_backward:
+            raise RuntimeError("Decoder._backward_packed: the last packed forward of this workspace did not keep its activations")
+        bw = self._dec2_bwd_state(st, B, res, dev)
+        q = bw['plan']
+        g = d_img.contiguous()
+        if g.dtype != torch.float32 or g.shape != st['outs'][-1].shape:
+            raise RuntimeError(f"d image must be float32 {tuple(st['outs'][-1].shape)}; got {g.dtype} {tuple(g.shape)}")
+        d_feat = torch.empty((B, self.conv1.conv.in_channel, res, res), device=dev, dtype=torch.float32)
+        q.d_img, q.d_features = _lib.ptr(g), _lib.ptr(d_feat)
+        ms = None
+        if kernel_ms is not None:
+            ms = (ctypes.c_float * bw['n_launch'])()
+            q.kernel_ms, q.n_kernel_ms = ctypes.cast(ms, ctypes.POINTER(ctypes.c_float)), bw['n_launch']
+        else:
+            q.kernel_ms, q.n_kernel_ms = None, 0
+        with torch.cuda.device(dev):
+            rc = _lib.load().e3dge_dec2_backward(ctypes.byref(st['plan']), ctypes.byref(q), _lib.stream_of(g))
+        _lib.check(rc, "e3dge_dec2_backward")
+        if ms is not None:
+            kernel_ms[:] = list(ms)
+        bw['hold'] = [g]
+        return d_feat
+
+    def dec2_bwd_launch_names(self):
+        """Labels of the launches of one packed backward, in the order of `kernel_ms`."""
+        names = ["norms", "weights^T", "amax(d_img)", "to_rgb^T+mask(top)"]
+        for u in reversed(range(len(self.to_rgbs))):
+            names += [f"L{u}.d_rgb", f"L{u}.conv^T", f"L{u}.blur^T", f"L{u}.convT^T"]
+        return names + ["conv1^T"]
+
+    def dec2_unpack_grad(self, index, features_shape):
+        """Debug / test view of a packed GRADIENT of the last packed backward (same indices as dec2_unpack; 0 is not a packed tensor)."""
+        B, res = features_shape[0], features_shape[2]
+        dev = next(self.parameters()).device
+        st = self._dec2_state(B, res, dev)
+        bw = st['bwd']
+        n_up = len(self.to_rgbs)
+        chans, ress, r = [None, self.conv1.conv.out_channel], [None, res], res
+        for u in range(n_up):
+            r *= 2
+            chans += [self.convs[2 * u].conv.out_channel, self.convs[2 * u + 1].conv.out_channel]
+            ress += [r, r]
+        # meta: G2 of level u at [u + 1] (activation index 3 + 2u; conv1's output: u = -1), G1 of level u at [n_up + 1 + u] (index 2 + 2u)
+        mi = (index - 3) // 2 + 1 if index % 2 == 1 else n_up + 1 + (index - 2) // 2
+        out = torch.empty((B, chans[index], ress[index], ress[index]), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            rc = _lib.load().e3dge_dec2_unpack(_lib.ptr(out), _lib.ptr(bw['gacts'][index]), bw['meta'][mi:].data_ptr(), B, chans[index],
+                                               ress[index], torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(rc, "e3dge_dec2_unpack")
         return out
 
     def dec2_launch_names(self):

@@ -175,6 +175,20 @@ def synthetic_inputs(batch=1, seed=1, device="cpu"):
     return (torch.from_numpy(w_r.astype(np.float32)).to(device), torch.from_numpy(w_d.astype(np.float32)).to(device))
 
 
+def decoder_grad_inputs(batch, size, in_res, seed=11, device="cpu", channels=256):
+    """Inputs of the decoder-gradient fixtures (oracle/gen_golden_decoder_grads.py): a feature map 0.5 * N(0,1) (B, 256, r, r), one
+    per-sample noise image per StyledConv (conv1, then two per level), and the upstream gradient N(0,1) / size of the image."""
+    rs = np.random.RandomState(seed)
+    feats = torch.from_numpy((0.5 * rs.standard_normal((batch, channels, in_res, in_res))).astype(np.float32))
+    noises, r = [], in_res
+    while r <= size:
+        for _ in range(1 if r == in_res else 2):
+            noises.append(torch.from_numpy(rs.standard_normal((batch, 1, r, r)).astype(np.float32)))
+        r *= 2
+    gy = torch.from_numpy(rs.standard_normal((batch, 3, size, size)).astype(np.float32)) / float(size)
+    return feats.to(device), [n.to(device) for n in noises], gy.to(device)
+
+
 def synthetic_tex_conditions(batch, res, n_samples, seed=5, device="cpu"):
     """Per-point texture FiLM (alpha, beta), each (B,H,W,S,256): what the local branch would hand over."""
     rs = np.random.RandomState(seed)

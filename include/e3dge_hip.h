@@ -244,7 +244,10 @@ typedef struct E3dgeDec2Plan {
      * fir_blur_1d), fir_blur_1d = (g0, g1, g1, g0) and fir_blur_separable != 0: the fused up-sampling kernel then applies the two 1-D passes (horizontal in registers,
      * vertical through LDS).  With fir_blur_separable == 0 the 4x4 taps are applied as they are (first-generation kernel). */
     float fir_blur_1d[4];
-    int32_t fir_blur_separable, reserved2;
+    int32_t fir_blur_separable;
+    /* ABI 12: != 0 keeps the packed activation of the LAST convolution too (normally it only exists inside the fused ToRGB epilogue):
+     * e3dge_dec2_backward reads the sign of every stored activation for lrelu'. */
+    int32_t save_for_backward;
 } E3dgeDec2Plan;
 /* 32-bit words of a packed tensor / floats of a T buffer / floats of a wpre image */
 int64_t e3dge_dec2_act_words(int batch, int channels, int res);
@@ -254,6 +257,44 @@ int e3dge_dec2_prepack_weights(float* wpre, const float* weight, float scale, in
 /* launches per forward with n_up levels (= number of kernel_ms entries written): 6 + 4 n_up */
 int e3dge_dec2_num_launches(int n_up);
 int e3dge_dec2_forward(const E3dgeDec2Plan* plan, e3dge_stream_t stream);
+/*
+ * ---- Backward of the packed pipeline (ABI 12): d image -> d features, generator frozen ----------------------------------------------
+ * The data gradient of Decoder.forward (project/models/stylesdf_model.py:742-797; ModulatedConv2d :317-362, StyledConv :469-507, ToRGB
+ * :531-541, Blur / Upsample -> op/upfirdn2d.py:18-142, FusedLeakyReLU -> op/fused_act.py:19-84) that train_ae.py's stage-1 step takes
+ * through the pixel loss on pool_256(gen_imgs) (trainers/trainer.py:1017-1031, :728) -- in the reference: autograd through F.conv2d /
+ * F.conv_transpose2d on the modulated weights and the two custom ops' backward classes.  Here: the same MFMA convolutions on TRANSPOSED
+ * per-sample weight images, gradients packed like the activations, lrelu' from the sign of the stored packed activations (csrc/
+ * decoder2_bwd.h).  Call it after e3dge_dec2_forward(plan) ran with plan->save_for_backward != 0 on the same workspace and BEFORE
+ * anything else overwrites that workspace (act[], style / demod / wm buffers).  d latent and parameter gradients are NOT produced.
+ * Launches: norms (+ clearing the amax block), transposed weights, amax(d img), ToRGB^T + mask at the top, then per level
+ * Upsample^T of d rgb, conv^T, Blur^T + phase split, convT^T (+ ToRGB^T of the level below), and conv1^T: 5 + 4 n_up.
+ */
+typedef struct E3dgeDec2BwdConv {
+    const float* wpre_t;      /* e3dge_dec2_prepack_weights_t image of ModulatedConv2d.weight (co*ci*9 floats)                        */
+    const float* wsq;         /* (co, ci) sum over the taps of (scale W)^2 -- the table e3dge_modconv_pack_weights writes             */
+    uint32_t* wimg_t;         /* workspace: batch * e3dge_modconv_packed_words(ci, co) words                                          */
+} E3dgeDec2BwdConv;
+typedef struct E3dgeDec2BwdPlan {
+    const float* d_img;                            /* (batch, 3, R, R), R = in_res << n_up: gradient of Decoder.forward's image       */
+    float* d_features;                             /* (batch, in_ch, in_res, in_res): result                                          */
+    E3dgeDec2BwdConv conv1;
+    E3dgeDec2BwdConv up[E3DGE_DEC2_MAX_UP];
+    E3dgeDec2BwdConv conv[E3DGE_DEC2_MAX_UP];
+    uint32_t* gact[2 * E3DGE_DEC2_MAX_UP + 2];     /* packed gradient workspaces, shapes of plan->act[i], zero-filled ONCE; [0] unused */
+    uint32_t* pbuf;                                /* phase planes of Blur^T: e3dge_dec2_pbuf_words(batch, co, res) of the largest up level */
+    float* drgb[E3DGE_DEC2_MAX_UP];                /* [i]: (batch, 3, r, r) gradient of the ToRGB image of level i - 1 (r = in_res << i) */
+    float* amax;                                   /* (4 n_up + 2) amax buffers (cleared by the call)                                 */
+    int32_t* meta;                                 /* (3 n_up + 1) ints                                                               */
+    float* bounds;                                 /* (3 n_up + 2) floats: operator norms of the transposed images / ToRGB tables     */
+    float* kernel_ms;                              /* host array or NULL: HIP-event time of every launch (makes the call synchronous) */
+    int32_t n_kernel_ms, reserved;
+} E3dgeDec2BwdPlan;
+/* weight (co, ci, 3, 3) -> wpre_t[t][c][tap][lane][j] = scale * weight[16c + 8 (lane >> 5) + j][32t + (lane & 31)][flip ? 8 - tap : tap];
+ * flip = 1 for the stride-1 convolutions, 0 for the up-sampling (transposed-stride) ones.  ci %% 32 == 0, co %% 16 == 0. */
+int e3dge_dec2_prepack_weights_t(float* wpre_t, const float* weight, float scale, int co, int ci, int flip, e3dge_stream_t stream);
+int64_t e3dge_dec2_pbuf_words(int batch, int channels, int res);
+int e3dge_dec2_bwd_num_launches(int n_up);
+int e3dge_dec2_backward(const E3dgeDec2Plan* plan, const E3dgeDec2BwdPlan* bwd, e3dge_stream_t stream);
 /* stand-alone pieces (tests, tools): fp32 (batch, c, res, res) <-> packed; both use meta[0] / amax as e3dge_dec2_forward does */
 int e3dge_dec2_pack(uint32_t* packed, int32_t* meta, const float* x, const float* amax, int batch, int channels, int res,
                     e3dge_stream_t stream);

@@ -50,7 +50,7 @@ def upfirdn2d_ref(x, kernel, up=(1, 1), down=(1, 1), pad=(0, 0, 0, 0)):
     z[:, :, ::uy, ::ux] = planes                                   # samples followed by (up-1) zeros (:167-169)
     z = F.pad(z, [max(px0, 0), max(px1, 0), max(py0, 0), max(py1, 0)])
     z = z[:, :, max(-py0, 0):z.shape[2] - max(-py1, 0), max(-px0, 0):z.shape[3] - max(-px1, 0)]
-    y = F.conv2d(z, torch.flip(kernel, [0, 1]).reshape(1, 1, kh, kw).to(z.dtype))
+    y = F.conv2d(z, torch.flip(kernel, [0, 1]).reshape(1, 1, kh, kw).to(z))        # (dtype AND device: the GPU tests run single layers on the device)
     y = y[:, :, ::dy, ::dx]
     out_h = (H * uy + py0 + py1 - kh) // dy + 1
     out_w = (W * ux + px0 + px1 - kw) // dx + 1

@@ -151,6 +151,36 @@ int main(void) {
     assert lib.e3dge_hitprob_points(None, None, None, None, None, None, None, None, 1, 4, 4, 1, None) == -1
 
 
+def test_dec2_backward_structs_layout_matches_c():
+    """ABI 12: the backward plan of the packed decoder pipeline (e3dge_dec2_backward) and the forward plan's new flag."""
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "e3dge_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(E3dgeDec2BwdConv), sizeof(E3dgeDec2BwdPlan), offsetof(E3dgeDec2BwdPlan, conv1),
+         offsetof(E3dgeDec2BwdPlan, up), offsetof(E3dgeDec2BwdPlan, conv), offsetof(E3dgeDec2BwdPlan, gact), offsetof(E3dgeDec2BwdPlan, pbuf),
+         offsetof(E3dgeDec2BwdPlan, drgb), offsetof(E3dgeDec2BwdPlan, bounds), offsetof(E3dgeDec2BwdPlan, kernel_ms),
+         offsetof(E3dgeDec2BwdPlan, n_kernel_ms), offsetof(E3dgeDec2Plan, save_for_backward));
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), c, "-o", exe], check=True)
+        got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    C, Q, P = _lib.Dec2BwdConv, _lib.Dec2BwdPlan, _lib.Dec2Plan
+    assert got == [ctypes.sizeof(C), ctypes.sizeof(Q), Q.conv1.offset, Q.up.offset, Q.conv.offset, Q.gact.offset, Q.pbuf.offset, Q.drgb.offset,
+                   Q.bounds.offset, Q.kernel_ms.offset, Q.n_kernel_ms.offset, P.save_for_backward.offset]
+    lib = _lib.load()
+    assert lib.e3dge_dec2_backward(None, None, None) == -1
+    plan = P(batch=1, n_up=1, in_res=8, in_ch=32)
+    assert lib.e3dge_dec2_backward(ctypes.byref(plan), ctypes.byref(Q()), None) == -1        # the forward did not keep its top activation
+    assert lib.e3dge_dec2_bwd_num_launches(4) == 21
+    assert lib.e3dge_dec2_pbuf_words(1, 32, 1024) == 4 * 2 * 4 * 514 * 514 * 4 and lib.e3dge_dec2_pbuf_words(1, 32, 7) == 0
+    assert lib.e3dge_dec2_prepack_weights_t(None, None, 1.0, 32, 32, 1, None) == -1
+
+
 def test_ws_linear_struct_layout_matches_c_and_arguments_are_checked():
     src = r'''
 #include <stdio.h>

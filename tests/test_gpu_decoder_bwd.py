@@ -1,0 +1,192 @@
+"""GPU: the data gradient of the packed decoder pipeline (csrc/decoder2_bwd.h, e3dge_dec2_backward): d image -> d features through
+Decoder.forward (project/models/stylesdf_model.py:742-797) with the generator frozen -- the backward of train_ae.py's stage-1 step
+(trainer.py:1017-1031, :728).
+
+Oracles: (i) `decoder_grads_256.npz`, recorded from the REFERENCE's own autograd (oracle/gen_golden_decoder_grads.py) at size 256 / cm 1,
+batch 2, per-sample noise; (ii) float64 autograd of oracle/decoder_ref.py at 1024^2 / cm 2.
+
+Tolerance (1e-3 relative on gradients).  lrelu' is a step function: a pre-activation within fp32 round-off of zero takes
+the other branch in another implementation, which changes the gradient of ITS neighbourhood by ~1/sqrt(9 C) of a typical value -- the
+reference's own fp32 gradient is 1.0e-2 (max-abs / max) away from float64 for that reason (decoder_grads_report.json) while its relative
+L2 distance is ~1e-5.  So: relative L2 error <= 1e-3 always, and the max-abs error is held to max(1e-3, 3 x the fp32 reference's own
+distance from float64), the rule tests/test_gpu_backward.py already uses."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import full_state_dict, load_golden, record
+from oracle import decoder_ref
+
+import e3dge_amd  # noqa: F401
+from e3dge_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REL_TOL = 1e-3
+
+
+def rel_max(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max())
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.fixture(scope="module")
+def gen256():
+    g, sd = full_state_dict(size=256, cm=1, res=64, n_samples=24)
+    g = g.to(DEV).eval()
+    g.requires_grad_(False)
+    return g, sd
+
+
+def _grad(dec, feats, wd, noises, gy, mode=None):
+    """d features of (img * gy).sum() through Decoder.forward; mode = value of E3DGE_DECODER_AUTOGRAD (None: the default)."""
+    if mode is not None:
+        os.environ["E3DGE_DECODER_AUTOGRAD"] = mode
+    try:
+        f = feats.detach().clone().requires_grad_(True)
+        img, _ = dec(f, [wd], input_is_latent=True, noise=noises)
+        (g,) = torch.autograd.grad(img, [f], gy)
+        return img.detach(), g, img.grad_fn
+    finally:
+        os.environ.pop("E3DGE_DECODER_AUTOGRAD", None)
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_d_features_against_the_references_own_autograd_256(gen256, batch):
+    g, _ = gen256
+    dec = g.decoder
+    gold = load_golden("decoder_grads_256")
+    B = int(gold["batch"])
+    feats, noises, gy = syn.decoder_grad_inputs(B, int(gold["size"]), int(gold["in_res"]), seed=int(gold["inputs_seed"]), device=DEV)
+    _, wd = syn.synthetic_inputs(B, seed=int(gold["styles_seed"]), device=DEV)
+    wd = wd[:, :dec.n_latent].contiguous()
+    sl = slice(0, batch)
+    feats, noises, gy, wd = feats[sl].contiguous(), [n[sl].contiguous() for n in noises], gy[sl].contiguous(), wd[sl].contiguous()
+    img, d_f, fn = _grad(dec, feats, wd, noises, gy)
+    assert "PackedDecoderFn" in type(fn).__name__, type(fn).__name__         # the packed pipeline, not the library path
+    ref = torch.from_numpy(gold["ref_d_features_sub"][sl])
+    f64 = torch.from_numpy(gold["f64_d_features_sub"][sl])
+    sub = d_f[:, ::4, ::2, ::2]
+    e = dict(batch=batch, img=float((img[:, :, ::4, ::4].cpu() - torch.from_numpy(gold["ref_img_sub4"][sl])).abs().max()),
+             l2_vs_reference=rel_l2(sub, ref), max_vs_reference=rel_max(sub, ref), max_vs_f64=rel_max(sub, f64),
+             reference_max_vs_f64=rel_max(ref, f64),
+             sum_rel=float(np.abs(d_f.double().sum(dim=(1, 2, 3)).cpu().numpy() - gold["ref_d_features_sum"][sl]).max() /
+                           gold["ref_d_features_abs_sum"][sl].max()))
+    record("dec2_bwd_vs_reference_256", **e)
+    assert e["img"] <= 1e-4
+    assert e["l2_vs_reference"] <= REL_TOL, e
+    assert e["max_vs_f64"] <= max(REL_TOL, 3 * e["reference_max_vs_f64"]), e
+    assert e["sum_rel"] <= 1e-4, e
+    # the library path (weight modulation + MIOpen + the two custom ops' backward) on the same inputs, whole tensor
+    _, d_lib, fn_lib = _grad(dec, feats, wd, noises, gy, mode="library")
+    assert "PackedDecoderFn" not in type(fn_lib).__name__
+    e2 = dict(batch=batch, l2=rel_l2(d_f, d_lib), max=rel_max(d_f, d_lib))
+    record("dec2_bwd_vs_library_256", **e2)
+    assert e2["l2"] <= REL_TOL, e2
+
+
+def test_every_packed_gradient_against_autograd_of_the_oracle(gen256):
+    """The intermediate gradients (d pre-activation of every StyledConv, unpacked from the workspace) against fp32 autograd of the
+    oracle's layers on the GPU: localises a failure to one kernel."""
+    g, sd = gen256
+    dec = g.decoder
+    gsd = {k: v.to(DEV) for k, v in sd.items()}
+    B = 2
+    feats, noises, gy = syn.decoder_grad_inputs(B, 256, 64, seed=5, device=DEV)
+    _, wd = syn.synthetic_inputs(B, seed=2, device=DEV)
+    wd = wd[:, :dec.n_latent].contiguous()
+    img, d_f, _ = _grad(dec, feats, wd, noises, gy)
+    # oracle, layer by layer, keeping every activation's gradient
+    f = feats.clone().requires_grad_(True)
+    acts = []
+    out = decoder_ref.styled_conv(gsd, 'decoder.conv1.', f, wd[:, 0], noises[0]); out.retain_grad(); acts.append(out)
+    skip = decoder_ref.to_rgb(gsd, 'decoder.to_rgb1.', out, wd[:, 1], None, upsample=False)
+    i = 1
+    for u in range(len(dec.to_rgbs)):
+        out = decoder_ref.styled_conv(gsd, f'decoder.convs.{2 * u}.', out, wd[:, i], noises[2 * u + 1], upsample=True); out.retain_grad(); acts.append(out)
+        out = decoder_ref.styled_conv(gsd, f'decoder.convs.{2 * u + 1}.', out, wd[:, i + 1], noises[2 * u + 2]); out.retain_grad(); acts.append(out)
+        skip = decoder_ref.to_rgb(gsd, f'decoder.to_rgbs.{u}.', out, wd[:, i + 2], skip)
+        i += 2
+    skip.backward(gy)
+    errs = {}
+    for idx, a in enumerate(acts, start=1):
+        # d pre = d act * lrelu'(act) * sqrt 2 (fused_bias_act grad = 1 with the output as reference)
+        want = a.grad * torch.where(a.detach() > 0, 1.0, 0.2) * (2 ** 0.5)
+        got = dec.dec2_unpack_grad(idx, feats.shape)
+        errs[f"g{idx}_l2"] = rel_l2(got, want)
+        errs[f"g{idx}_max"] = rel_max(got, want)
+    errs["d_features_l2"] = rel_l2(d_f, f.grad)
+    errs["img"] = float((img - skip.detach()).abs().max())
+    record("dec2_bwd_stages_256", **errs)
+    assert all(v <= REL_TOL for k, v in errs.items() if k.endswith("_l2")), errs
+
+
+def test_backward_after_another_forward_reruns_its_own(gen256):
+    """The backward reads the activations its forward left in the workspace; a forward in between (validation image, another
+    sample) overwrites them -- the Function notices and re-runs its forward."""
+    g, _ = gen256
+    dec = g.decoder
+    feats, noises, gy = syn.decoder_grad_inputs(1, 256, 64, seed=7, device=DEV)
+    _, wd = syn.synthetic_inputs(1, seed=3, device=DEV)
+    wd = wd[:, :dec.n_latent].contiguous()
+    _, want, _ = _grad(dec, feats, wd, noises, gy)
+    f = feats.clone().requires_grad_(True)
+    img, _ = dec(f, [wd], input_is_latent=True, noise=noises)
+    with torch.no_grad():
+        other, _ = dec(2.0 * feats.flip(1), [wd.flip(0) * 1.5], input_is_latent=True, noise=[n.flip(2) for n in noises])
+    (got,) = torch.autograd.grad(img, [f], gy)
+    assert torch.equal(got, want)
+    assert torch.isfinite(other).all()
+
+
+def test_ineligible_graphs_take_the_library_path(gen256):
+    """d latent or a parameter gradient is not produced by e3dge_dec2_backward: such forwards must not take the packed Function in the
+    default mode, and the gradients must exist."""
+    g, _ = gen256
+    dec = g.decoder
+    feats, noises, gy = syn.decoder_grad_inputs(1, 256, 64, seed=9, device=DEV)
+    _, wd = syn.synthetic_inputs(1, seed=4, device=DEV)
+    wl = wd[:, :dec.n_latent].clone().requires_grad_(True)
+    f = feats.clone().requires_grad_(True)
+    img, _ = dec(f, [wl], input_is_latent=True, noise=noises)
+    assert "PackedDecoderFn" not in type(img.grad_fn).__name__
+    d_f, d_l = torch.autograd.grad(img, [f, wl], gy)
+    assert float(d_l.abs().max()) > 0 and float(d_f.abs().max()) > 0
+    # the same d features as the packed backward gives for the detached latent
+    _, d_p, _ = _grad(dec, feats, wl.detach(), noises, gy)
+    e = dict(l2=rel_l2(d_p, d_f), max=rel_max(d_p, d_f))
+    record("dec2_bwd_vs_library_with_latent_grad", **e)
+    assert e["l2"] <= REL_TOL, e
+
+
+def test_d_features_full_size_1024_against_float64_autograd():
+    """The BASELINE decoder (1024^2, channel multiplier 2), batch 1: d features against float64 autograd of the oracle on the CPU."""
+    g, sd = full_state_dict(size=1024, cm=2, res=64, n_samples=24)
+    g = g.to(DEV).eval()
+    g.requires_grad_(False)
+    dec = g.decoder
+    feats, noises, gy = syn.decoder_grad_inputs(1, 1024, 64, seed=13, device=DEV)
+    _, wd = syn.synthetic_inputs(1, seed=1, device=DEV)
+    img, d_f, fn = _grad(dec, feats, wd, noises, gy)
+    assert "PackedDecoderFn" in type(fn).__name__
+
+    def oracle(dtype):
+        f_ = feats.cpu().to(dtype).requires_grad_(True)
+        out = decoder_ref.decoder_forward(sd, f_, wd.cpu(), noises=[n.cpu() for n in noises], dtype=dtype)
+        (gr,) = torch.autograd.grad(out, [f_], gy.cpu().to(dtype))
+        return out.detach(), gr
+    img64, g64 = oracle(torch.float64)
+    _, g32 = oracle(torch.float32)
+    e = dict(img=float((img.double().cpu() - img64).abs().max()), l2=rel_l2(d_f, g64), max=rel_max(d_f, g64),
+             oracle32_l2=rel_l2(g32, g64), oracle32_max=rel_max(g32, g64))
+    record("dec2_bwd_1024_vs_f64", **e)
+    assert e["img"] <= 1e-4
+    assert e["l2"] <= REL_TOL, e
+    assert e["max"] <= max(REL_TOL, 3 * e["oracle32_max"]), e

@@ -1,6 +1,8 @@
-"""Forward and forward + backward of the 1024^2 / channel-multiplier-2 decoder with a graph wanted (features and latent require
-grad, parameters frozen: the train_ae.py shape), E3DGE_DECODER_AUTOGRAD = packed (packed forward, library backward on recomputed
-activations) vs library.   python tools/time_decoder_autograd.py  -> one JSON line (also gpurun_out/decoder_autograd.json)"""
+"""Forward + backward of the 1024^2 / channel-multiplier-2 decoder in the shape train_ae.py's stage-1 step takes (trainer.py:1017-1031:
+the feature map requires grad, the decoder latent and the generator's parameters do not), E3DGE_DECODER_AUTOGRAD = auto (packed forward +
+e3dge_dec2_backward) vs library (weight modulation + MIOpen for both directions), plus the HIP-event time of every launch of the packed
+backward.   python tools/time_decoder_autograd.py [--batch B]  -> one JSON line (also gpurun_out/decoder_autograd.json)"""
+import argparse
 import json
 import os
 import sys
@@ -12,17 +14,23 @@ import e3dge_amd  # noqa: F401,E402
 from e3dge_amd import synthetic as syn  # noqa: E402
 from e3dge_amd.stylesdf_model import G_pred_latents  # noqa: E402
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--latent-grad", action="store_true", help="also time the round-4 shape (latent requires grad too: library path)")
+args = ap.parse_args()
 dev = "cuda:0"
 g = G_pred_latents(syn.model_opt(), syn.rendering_opt(N_samples=24), full_pipeline=True)
 syn.load_synthetic(g)
 g = g.to(dev).eval()
 g.requires_grad_(False)
 dec = g.decoder
-_, wd = syn.synthetic_inputs(1, seed=1, device=dev)
-feats = 0.5 * torch.randn(1, 256, 64, 64, device=dev)
+B = args.batch
+_, wd = syn.synthetic_inputs(B, seed=1, device=dev)
+feats = 0.5 * torch.randn(B, 256, 64, 64, device=dev)
+gy = torch.randn(B, 3, 1024, 1024, device=dev) / 1024
 
 
-def timed(fn, n=10):
+def timed(fn, n=20):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -36,22 +44,39 @@ def timed(fn, n=10):
 
 
 res = {}
-for backend in ("packed", "library"):
+for backend in ("auto", "library"):
     os.environ["E3DGE_DECODER_AUTOGRAD"] = backend
 
     def fwd():
         f = feats.detach().requires_grad_(True)
-        l = wd.detach().requires_grad_(True)
-        img, _ = dec(f, [l], input_is_latent=True, randomize_noise=False)
-        return img, f, l
+        img, _ = dec(f, [wd], input_is_latent=True, randomize_noise=False)
+        return img, f
 
     def fwd_bwd():
-        img, f, l = fwd()
-        img.square().mean().backward()
+        img, f = fwd()
+        torch.autograd.grad(img, [f], gy)
     res[backend] = {"forward_ms": round(timed(fwd), 4), "forward_backward_ms": round(timed(fwd_bwd), 4)}
+    if args.latent_grad:
+        def fwd_bwd_l():
+            f = feats.detach().requires_grad_(True)
+            l = wd.detach().requires_grad_(True)
+            img, _ = dec(f, [l], input_is_latent=True, randomize_noise=False)
+            torch.autograd.grad(img, [f, l], gy)
+        res[backend]["forward_backward_with_d_latent_ms"] = round(timed(fwd_bwd_l), 4)
+os.environ.pop("E3DGE_DECODER_AUTOGRAD", None)
 with torch.no_grad():
     res["no_graph_forward_ms"] = round(timed(lambda: dec(feats, [wd], input_is_latent=True, randomize_noise=False)), 4)
-line = json.dumps({"what": "decoder 64^2 -> 1024^2 under autograd (features + latent require grad, parameters frozen)", **res})
+    # per-launch times of one packed forward (save mode) + backward
+    noise = [getattr(dec.noises, f"noise_{i}") for i in range(dec.num_layers)]
+    kf, kb = [], []
+    for _ in range(3):
+        dec._forward_packed(feats, wd, noise, kernel_ms=kf, save=True)
+        dec._backward_packed(feats, gy, kernel_ms=kb)
+    res["forward_launches_ms"] = {n: round(v, 4) for n, v in zip(dec.dec2_launch_names(), kf)}
+    res["backward_launches_ms"] = {n: round(v, 4) for n, v in zip(dec.dec2_bwd_launch_names(), kb)}
+    res["backward_sum_of_launches_ms"] = round(sum(kb), 4)
+    res["forward_sum_of_launches_ms"] = round(sum(kf), 4)
+line = json.dumps({"what": f"decoder 64^2 -> 1024^2 under autograd, batch {B} (features require grad, latent and parameters frozen)", **res})
 print(line)
 os.makedirs("gpurun_out", exist_ok=True)
 open("gpurun_out/decoder_autograd.json", "w").write(line + "\n")
