@@ -114,6 +114,8 @@ def finalize(result):
                "inversion_fwd_ms": r.get("inversion_fwd_ms"), "inversion_fwd_graph_ms": r.get("inversion_fwd_graph_ms"),
                "inversion_fwd_no_reuse_ms": r.get("inversion_fwd_no_reuse_ms"), "c3_images_per_s": g("c3", "images_per_s"),
                "c4_ms_per_pose": g("c4", "sequential", "ms_per_pose"), "train_step_ms": r.get("train_step_ms"),
+               "train_step_full_ms": r.get("train_step_full_ms"), "decoder_packed_fwd_bwd_ms": g("autograd", "decoder_packed_fwd_bwd_ms"),
+               "decoder_library_fwd_bwd_ms": g("autograd", "decoder_library_fwd_bwd_ms"),
                "train_step_mfma_frac": g("train_step", "roofline", "frac"), "train_step_f32_fallback_ms": r.get("train_step_f32_fallback_ms"), "cpu_rays_per_s": g("cpu_baseline", "value")}
     if isinstance(inv, dict) and isinstance(inv.get("kernels"), list):
         dec = sum(k[1] for k in inv["kernels"] if k[0].startswith("decoder:"))
@@ -697,15 +699,38 @@ def main():
                 dec_ = gl.decoder
                 fm_ = o['features'].detach()
                 ag = {}
-                for be in ("packed", "library"):
-                    os.environ["E3DGE_DECODER_AUTOGRAD"] = be
+                # stage-1 shape (trainer.py:1017-1031, scripts/train/ffhq/stage1.sh --E_d_grad_false --disable_decoder_fpn): the feature map
+                # requires grad, the decoder latent and the generator do not; pixel loss on pool_256(gen_imgs).  "packed" = the default
+                # (packed forward + e3dge_dec2_backward), "library" = weight modulation + MIOpen for both directions (round 4's default)
+                pool_ = torch.nn.AdaptiveAvgPool2d((256, 256))
+                for be, env in (("packed", "auto"), ("library", "library")):
+                    os.environ["E3DGE_DECODER_AUTOGRAD"] = env
                     try:
                         def fb():
-                            f_, l_ = fm_.clone().requires_grad_(True), d1.detach().clone().requires_grad_(True)
-                            dec_(f_, [l_], input_is_latent=True, randomize_noise=False)[0].square().mean().backward()
+                            f_ = fm_.clone().requires_grad_(True)
+                            pool_(dec_(f_, [d1], input_is_latent=True, randomize_noise=False)[0]).square().mean().backward()
                         ag["decoder_" + be + "_fwd_bwd_ms"] = ev_fb(fb)
                     finally:
                         os.environ.pop("E3DGE_DECODER_AUTOGRAD", None)
+                try:        # d latent wanted too (not the stage-1 shape): no native backward for it, the library path runs
+                    def fb_l():
+                        f_, l_ = fm_.clone().requires_grad_(True), d1.detach().clone().requires_grad_(True)
+                        pool_(dec_(f_, [l_], input_is_latent=True, randomize_noise=False)[0]).square().mean().backward()
+                    ag["decoder_with_d_latent_fwd_bwd_ms"] = ev_fb(fb_l)
+                except Exception as exc:                                  # noqa: BLE001
+                    ag["decoder_with_d_latent_fwd_bwd_ms"] = f"failed: {type(exc).__name__}"
+                try:        # every launch of one packed backward (HIP events inside the native call)
+                    nz_ = [getattr(dec_.noises, f"noise_{i}") for i in range(dec_.num_layers)]
+                    gy_ = torch.randn(1, 3, 1024, 1024, device=dev) / 1024
+                    kb_ = []
+                    with torch.no_grad():
+                        for _ in range(3):
+                            dec_._forward_packed(fm_, d1, nz_, save=True)
+                            dec_._backward_packed(fm_, gy_, kernel_ms=kb_)
+                    ag["decoder_backward_launches_ms"] = {n: round(v, 4) for n, v in zip(dec_.dec2_bwd_launch_names(), kb_)}
+                    ag["decoder_backward_sum_of_launches_ms"] = round(sum(kb_), 4)
+                except Exception as exc:                                  # noqa: BLE001
+                    ag["decoder_backward_launches_ms"] = f"failed: {type(exc).__name__}: {exc}"[:160]
                 from e3dge_amd.local_query import Fuse_sft_MLP
                 fu_ = Fuse_sft_MLP().to(dev)
                 fu_.requires_grad_(False)
@@ -722,7 +747,9 @@ def main():
                         ag["fuse_sft_" + be + "_fwd_bwd_ms"] = ev_fb(fb2)
                     finally:
                         os.environ.pop("E3DGE_FUSE_AUTOGRAD", None)
-                ag["note"] = "forward + backward with a graph (inputs require grad, parameters frozen): native-forward autograd nodes vs library path"
+                ag["note"] = ("forward + backward with a graph: decoder in the stage-1 shape (features require grad, latent + parameters frozen, loss on "
+                              "pool_256(image)): packed = e3dge_dec2_forward + e3dge_dec2_backward, library = weight modulation + MIOpen; Fuse_sft_MLP: "
+                              "native-forward autograd node vs torch modules")
                 result["autograd"] = ag
             except Exception as exc:
                 result["autograd"] = {"failed": f"{type(exc).__name__}: {exc}"}
@@ -873,6 +900,44 @@ def main():
                 result["train_step_f32_fallback_ms"] = ms_f32
             except Exception as exc:
                 result["train_step_f32_fallback_ms"] = f"failed: {type(exc).__name__}: {exc}"[:120]
+            # the step train_ae.py actually runs for one sample (scripts/train/ffhq/stage1.sh: --full_pipeline): renderer forward with the
+            # eikonal terms -> decoder 64^2 -> 1024^2 -> pixel loss on pool_256(gen_imgs) (trainer.py:1017-1031) + the renderer losses,
+            # backward through the decoder (d features only: latent and generator frozen) into the renderer, down to the styles
+            try:
+                dec5 = gl.decoder if gl is not None else None
+                if dec5 is None:
+                    g5 = G_pred_latents(syn.model_opt(), syn.rendering_opt(N_samples=S5), full_pipeline=True)
+                    syn.load_synthetic(g5)
+                    dec5 = g5.decoder.to(dev).eval()
+                    dec5.requires_grad_(False)
+                _, d5 = syn.synthetic_inputs(1, seed=1 + rank, device=dev)
+                pool5 = torch.nn.AdaptiveAvgPool2d((256, 256))
+                full = {}
+                for be, env in (("packed", "auto"), ("library", "library")):
+                    os.environ["E3DGE_DECODER_AUTOGRAD"] = env
+                    try:
+                        def train_step_full():
+                            s_ = w5.clone().requires_grad_(True)
+                            o = r5(p5, f5, n5, fa5, styles=s_, return_eikonal=True, return_surface_eikonal=True)
+                            img = dec5(o['features'], [d5], input_is_latent=True, randomize_noise=False)[0]
+                            loss = ((pool5(img) ** 2).mean() + (o['gen_thumb_imgs'] ** 2).mean()
+                                    + ((o['eikonal_term'].norm(dim=-1) - 1) ** 2).mean() + (o['surface_eikonal_term'] ** 2).mean())
+                            loss.backward()
+                            return s_.grad
+                        for _ in range(3):
+                            gf = train_step_full()
+                        full[be] = wall_ms(train_step_full, n_tr)
+                        assert torch.isfinite(gf).all()
+                    finally:
+                        os.environ.pop("E3DGE_DECODER_AUTOGRAD", None)
+                result["train_step_full_ms"] = full["packed"]
+                result["train_step_full_library_decoder_ms"] = full["library"]
+                result["train_step_full_note"] = ("one stage-1 sample as train_ae.py runs it (--full_pipeline): C5 renderer step + decoder 64^2 -> 1024^2 forward "
+                                                  "and backward with the pixel loss on pool_256(gen_imgs) (trainer.py:1017-1031); decoder latent and generator "
+                                                  "frozen; packed = e3dge_dec2_forward / e3dge_dec2_backward, library = round 4's path; wall clock, max over ranks")
+            except Exception as exc:                                      # noqa: BLE001
+                result["train_step_full_ms"] = None
+                result["train_step_full_note"] = f"failed: {type(exc).__name__}: {exc}"[:200]
             result["train_step_ms"] = ms
             result["train_step_rays_per_sec"] = world * RES * RES / ms * 1e3
             result["train_step_note"] = ("C5 renderer part, 1 image 64x64x18 per GPU: forward saving arguments + eikonal term (sdf chain) + "

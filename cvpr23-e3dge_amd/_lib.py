@@ -90,7 +90,7 @@ class Dec2Plan(ctypes.Structure):
 
 class Dec2BwdConv(ctypes.Structure):
     """Mirror of struct E3dgeDec2BwdConv (include/e3dge_hip.h)."""
-    _fields_ = [(n, _vp) for n in ("wpre_t", "wsq", "wimg_t")]
+    _fields_ = [(n, _vp) for n in ("wpre_t", "wcol", "wimg_t")]
 
 
 class Dec2BwdPlan(ctypes.Structure):

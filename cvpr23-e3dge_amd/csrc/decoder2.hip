@@ -2320,7 +2320,7 @@ extern "C" int e3dge_dec2_backward(const E3dgeDec2Plan* P, const E3dgeDec2BwdPla
     E3DGE_REQUIRE(Q->d_img && Q->d_features && Q->amax && Q->meta && Q->bounds && P->fir_blur && P->fir_up, "dec2_backward: null pointer");
     const int n_up = P->n_up, B = P->batch;
     auto check_bc = [&](const E3dgeDec2Conv& c, const E3dgeDec2BwdConv& q, const char* what) -> int {
-        E3DGE_REQUIRE(q.wpre_t && q.wsq && q.wimg_t && c.style && c.demod, "dec2_backward %s: null pointer", what);
+        E3DGE_REQUIRE(q.wpre_t && q.wcol && q.wimg_t && c.style && c.demod, "dec2_backward %s: null pointer", what);
         E3DGE_REQUIRE(c.ci % 32 == 0 && c.co % 32 == 0, "dec2_backward %s: needs ci %% 32 == 0 and co %% 32 == 0 (got %d, %d)", what, c.ci, c.co);
         return E3DGE_OK;
     };
@@ -2375,7 +2375,7 @@ extern "C" int e3dge_dec2_backward(const E3dgeDec2Plan* P, const E3dgeDec2BwdPla
         PkBndTab tab{};
         auto add = [&](const E3dgeDec2Conv& c, const E3dgeDec2BwdConv& q) {
             PkBndConv& w = tab.conv[tab.n_conv++];
-            w.style = c.style; w.demod = c.demod; w.wsq = q.wsq; w.co = c.co; w.ci = c.ci;
+            w.style = c.style; w.demod = c.demod; w.wcol = q.wcol; w.co = c.co; w.ci = c.ci;
         };
         add(P->conv1, Q->conv1);
         for (int u = 0; u < n_up; ++u) { add(P->up[u], Q->up[u]); add(P->conv[u], Q->conv[u]); }

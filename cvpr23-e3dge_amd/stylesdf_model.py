@@ -850,10 +850,10 @@ class Decoder(nn.Module):
         def fill(dst, sc):
             m = sc.conv
             wimg = torch.empty(B * lib.e3dge_modconv_packed_words(m.in_channel, m.out_channel), device=device, dtype=torch.int32)
-            wsq = m.device_image()[1]
+            wcol = m.device_image()[1].sum(0).contiguous()     # (ci): column sums of the squared-norm table, for the operator-norm bound
             wpt = m.device_wpre_t()
-            keep.extend([wimg, wsq, wpt])
-            dst.wpre_t, dst.wsq, dst.wimg_t = _lib.ptr(wpt), _lib.ptr(wsq), _lib.ptr(wimg)
+            keep.extend([wimg, wcol, wpt])
+            dst.wpre_t, dst.wcol, dst.wimg_t = _lib.ptr(wpt), _lib.ptr(wcol), _lib.ptr(wimg)
         fill(q.conv1, self.conv1)
         gacts = [None, torch.zeros_like(st['acts'][1])]
         r, pwords = res, 0

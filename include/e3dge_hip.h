@@ -271,7 +271,7 @@ int e3dge_dec2_forward(const E3dgeDec2Plan* plan, e3dge_stream_t stream);
  */
 typedef struct E3dgeDec2BwdConv {
     const float* wpre_t;      /* e3dge_dec2_prepack_weights_t image of ModulatedConv2d.weight (co*ci*9 floats)                        */
-    const float* wsq;         /* (co, ci) sum over the taps of (scale W)^2 -- the table e3dge_modconv_pack_weights writes             */
+    const float* wcol;        /* (ci) column sums over co of the (co, ci) table sum_taps (scale W)^2 that e3dge_modconv_pack_weights writes */
     uint32_t* wimg_t;         /* workspace: batch * e3dge_modconv_packed_words(ci, co) words                                          */
 } E3dgeDec2BwdConv;
 typedef struct E3dgeDec2BwdPlan {

@@ -6,10 +6,13 @@ Oracles: (i) `decoder_grads_256.npz`, recorded from the REFERENCE's own autograd
 batch 2, per-sample noise; (ii) float64 autograd of oracle/decoder_ref.py at 1024^2 / cm 2.
 
 Tolerance (1e-3 relative on gradients).  lrelu' is a step function: a pre-activation within fp32 round-off of zero takes
-the other branch in another implementation, which changes the gradient of ITS neighbourhood by ~1/sqrt(9 C) of a typical value -- the
-reference's own fp32 gradient is 1.0e-2 (max-abs / max) away from float64 for that reason (decoder_grads_report.json) while its relative
-L2 distance is ~1e-5.  So: relative L2 error <= 1e-3 always, and the max-abs error is held to max(1e-3, 3 x the fp32 reference's own
-distance from float64), the rule tests/test_gpu_backward.py already uses."""
+the other branch in another implementation, and the few elements this happens to change the gradient of their whole receptive field --
+the reference's own fp32 gradient is 1.0e-2 (max-abs / max) and 7e-4 (relative L2) away from float64 for that reason
+(decoder_grads_report.json), our library path differs from the packed one by 5.6e-3 / 4.0e-4 on a batch where one sample has such an
+element and by 1.7e-6 / 1.1e-6 on one that has none.  So the arithmetic is pinned where the step function cannot interfere -- every
+packed gradient against autograd of the oracle's layers with lrelu' taken from the SAME activation signs: <= 1e-4 -- and against the
+reference's recording / float64 each error is held to max(1e-3, 3 x the fp32 reference's own distance from float64), the rule
+tests/test_gpu_backward.py already uses."""
 import os
 
 import numpy as np
@@ -75,26 +78,28 @@ def test_d_features_against_the_references_own_autograd_256(gen256, batch):
     f64 = torch.from_numpy(gold["f64_d_features_sub"][sl])
     sub = d_f[:, ::4, ::2, ::2]
     e = dict(batch=batch, img=float((img[:, :, ::4, ::4].cpu() - torch.from_numpy(gold["ref_img_sub4"][sl])).abs().max()),
-             l2_vs_reference=rel_l2(sub, ref), max_vs_reference=rel_max(sub, ref), max_vs_f64=rel_max(sub, f64),
-             reference_max_vs_f64=rel_max(ref, f64),
+             l2_vs_reference=rel_l2(sub, ref), max_vs_reference=rel_max(sub, ref), max_vs_f64=rel_max(sub, f64), l2_vs_f64=rel_l2(sub, f64),
+             reference_max_vs_f64=rel_max(ref, f64), reference_l2_vs_f64=rel_l2(ref, f64),
              sum_rel=float(np.abs(d_f.double().sum(dim=(1, 2, 3)).cpu().numpy() - gold["ref_d_features_sum"][sl]).max() /
                            gold["ref_d_features_abs_sum"][sl].max()))
     record("dec2_bwd_vs_reference_256", **e)
     assert e["img"] <= 1e-4
-    assert e["l2_vs_reference"] <= REL_TOL, e
+    assert e["l2_vs_f64"] <= max(REL_TOL, 3 * e["reference_l2_vs_f64"]), e
     assert e["max_vs_f64"] <= max(REL_TOL, 3 * e["reference_max_vs_f64"]), e
+    assert e["l2_vs_reference"] <= max(REL_TOL, 3 * e["reference_l2_vs_f64"]), e
     assert e["sum_rel"] <= 1e-4, e
     # the library path (weight modulation + MIOpen + the two custom ops' backward) on the same inputs, whole tensor
     _, d_lib, fn_lib = _grad(dec, feats, wd, noises, gy, mode="library")
     assert "PackedDecoderFn" not in type(fn_lib).__name__
     e2 = dict(batch=batch, l2=rel_l2(d_f, d_lib), max=rel_max(d_f, d_lib))
     record("dec2_bwd_vs_library_256", **e2)
-    assert e2["l2"] <= REL_TOL, e2
+    assert e2["l2"] <= max(REL_TOL, 3 * e["reference_l2_vs_f64"]), e2
 
 
 def test_every_packed_gradient_against_autograd_of_the_oracle(gen256):
-    """The intermediate gradients (d pre-activation of every StyledConv, unpacked from the workspace) against fp32 autograd of the
-    oracle's layers on the GPU: localises a failure to one kernel."""
+    """The intermediate gradients (d pre-activation of every StyledConv, unpacked from the workspace) and d features against fp32
+    autograd of the oracle's layers on the GPU, with lrelu' taken from the signs of the packed pipeline's OWN activations -- the step
+    function then cannot differ between the two, what is left is the kernels' arithmetic.  Localises a failure to one kernel."""
     g, sd = gen256
     dec = g.decoder
     gsd = {k: v.to(DEV) for k, v in sd.items()}
@@ -103,29 +108,41 @@ def test_every_packed_gradient_against_autograd_of_the_oracle(gen256):
     _, wd = syn.synthetic_inputs(B, seed=2, device=DEV)
     wd = wd[:, :dec.n_latent].contiguous()
     img, d_f, _ = _grad(dec, feats, wd, noises, gy)
-    # oracle, layer by layer, keeping every activation's gradient
     f = feats.clone().requires_grad_(True)
-    acts = []
-    out = decoder_ref.styled_conv(gsd, 'decoder.conv1.', f, wd[:, 0], noises[0]); out.retain_grad(); acts.append(out)
+    acts, pres = [], []
+
+    def styled(prefix, x, style, noise, idx, upsample=False):
+        """decoder_ref.styled_conv (StyledConv.forward :494-507) with the branch of lrelu chosen by the packed activation's sign"""
+        pre = decoder_ref.modulated_conv(gsd, prefix + 'conv.', x, style, True, upsample)
+        pre = pre + gsd[prefix + 'noise.weight'] * noise + gsd[prefix + 'activate.bias'].reshape(1, -1, 1, 1)
+        pre.retain_grad()
+        pres.append(pre)
+        mine = dec.dec2_unpack(idx, feats.shape)
+        acts.append((mine, pre.detach()))
+        return torch.where(mine > 0, pre, 0.2 * pre) * (2 ** 0.5)
+    out = styled('decoder.conv1.', f, wd[:, 0], noises[0], 1)
     skip = decoder_ref.to_rgb(gsd, 'decoder.to_rgb1.', out, wd[:, 1], None, upsample=False)
     i = 1
     for u in range(len(dec.to_rgbs)):
-        out = decoder_ref.styled_conv(gsd, f'decoder.convs.{2 * u}.', out, wd[:, i], noises[2 * u + 1], upsample=True); out.retain_grad(); acts.append(out)
-        out = decoder_ref.styled_conv(gsd, f'decoder.convs.{2 * u + 1}.', out, wd[:, i + 1], noises[2 * u + 2]); out.retain_grad(); acts.append(out)
+        out = styled(f'decoder.convs.{2 * u}.', out, wd[:, i], noises[2 * u + 1], 2 + 2 * u, upsample=True)
+        out = styled(f'decoder.convs.{2 * u + 1}.', out, wd[:, i + 1], noises[2 * u + 2], 3 + 2 * u)
         skip = decoder_ref.to_rgb(gsd, f'decoder.to_rgbs.{u}.', out, wd[:, i + 2], skip)
         i += 2
     skip.backward(gy)
     errs = {}
-    for idx, a in enumerate(acts, start=1):
-        # d pre = d act * lrelu'(act) * sqrt 2 (fused_bias_act grad = 1 with the output as reference)
-        want = a.grad * torch.where(a.detach() > 0, 1.0, 0.2) * (2 ** 0.5)
+    n_flip = 0
+    for idx, (pre, (mine, pre_v)) in enumerate(zip(pres, acts), start=1):
         got = dec.dec2_unpack_grad(idx, feats.shape)
-        errs[f"g{idx}_l2"] = rel_l2(got, want)
-        errs[f"g{idx}_max"] = rel_max(got, want)
+        errs[f"g{idx}_l2"] = rel_l2(got, pre.grad)
+        errs[f"g{idx}_max"] = rel_max(got, pre.grad)
+        n_flip += int(((mine > 0) != (pre_v > 0)).sum())
     errs["d_features_l2"] = rel_l2(d_f, f.grad)
+    errs["d_features_max"] = rel_max(d_f, f.grad)
     errs["img"] = float((img - skip.detach()).abs().max())
+    errs["activations_whose_sign_differs_from_the_oracles"] = n_flip
     record("dec2_bwd_stages_256", **errs)
-    assert all(v <= REL_TOL for k, v in errs.items() if k.endswith("_l2")), errs
+    assert errs["img"] <= 1e-4
+    assert all(v <= 1e-4 for k, v in errs.items() if k.endswith("_l2") or k.endswith("_max")), errs
 
 
 def test_backward_after_another_forward_reruns_its_own(gen256):
