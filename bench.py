@@ -772,6 +772,7 @@ def main():
         except Exception as exc:
             result["inversion_fwd_ms"] = None
             result["inversion_fwd_note"] = f"failed: {type(exc).__name__}: {exc}"
+    dec_keep = gl.decoder if gl is not None else None          # (the full stage-1 step below runs the decoder again)
     del gl
 
     # ---------------------------------------------------------------- C4: the 120-pose sweep at 128x128 rays x 48 samples
@@ -904,7 +905,7 @@ def main():
             # eikonal terms -> decoder 64^2 -> 1024^2 -> pixel loss on pool_256(gen_imgs) (trainer.py:1017-1031) + the renderer losses,
             # backward through the decoder (d features only: latent and generator frozen) into the renderer, down to the styles
             try:
-                dec5 = gl.decoder if gl is not None else None
+                dec5 = dec_keep
                 if dec5 is None:
                     g5 = G_pred_latents(syn.model_opt(), syn.rendering_opt(N_samples=S5), full_pipeline=True)
                     syn.load_synthetic(g5)

@@ -125,6 +125,8 @@ SIGNATURES = {
     "e3dge_fused_bias_act": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _i64, _i64, _i64, _vp]),
     "e3dge_fused_bias_act_f16": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _i64, _i64, _i64, _vp]),
     "e3dge_upfirdn2d_f16": (_i32, [_vp, _vp, _vp, _i64] + [_i32] * 12 + [_vp]),
+    "e3dge_fused_bias_act_f64": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _i64, _i64, _i64, _vp]),
+    "e3dge_upfirdn2d_f64": (_i32, [_vp, _vp, _vp, _i64] + [_i32] * 12 + [_vp]),
     "e3dge_noise_bias_act": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _i64, _i64, _i64, _i64, _vp]),
     "e3dge_upfirdn2d": (_i32, [_vp, _vp, _vp, _i64] + [_i32] * 12 + [_vp]),
     "e3dge_upfirdn2d_out_size": (_i32, [_i32] * 6),
@@ -294,10 +296,11 @@ class on_device:
 
 
 def require_gpu(t, name, half_ok=False):
-    """`half_ok`: the two stream ops (fused_bias_act, upfirdn2d) also take float16, as the reference's do."""
+    """`half_ok`: the two stream ops (fused_bias_act, upfirdn2d) also take float16 and float64, as the reference's do
+    (AT_DISPATCH_FLOATING_TYPES_AND_HALF)."""
     import torch
     if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
         raise RuntimeError(f"{name} must be a GPU (HIP) tensor; this build has no CPU path "
                            f"(got {getattr(t, 'device', type(t))})")
-    if t.dtype != torch.float32 and not (half_ok and t.dtype == torch.float16):
-        raise RuntimeError(f"{name} must be float32{' or float16' if half_ok else ''} (got {t.dtype})")
+    if t.dtype != torch.float32 and not (half_ok and t.dtype in (torch.float16, torch.float64)):
+        raise RuntimeError(f"{name} must be float32{', float16 or float64' if half_ok else ''} (got {t.dtype})")

@@ -322,6 +322,57 @@ extern "C" int e3dge_fused_bias_act_f16(void* y, const void* x, const void* bias
                                         static_cast<const _Float16*>(ref), act, grad, alpha, scale, n, step_b, size_b, stream);
 }
 
+// fp64 form (ABI 12): the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF (fused_bias_act_kernel.cu:79), so double tensors --
+// what torch.autograd.gradcheck / gradgradcheck feed an op -- run its kernel with scalar_t = double arithmetic.  Same here: a plain
+// element kernel in double (alpha / scale arrive as float and are widened, as `scalar_t alpha = (scalar_t)alpha` does there).
+namespace e3dge {
+template <int MODE, bool HAS_BIAS, bool HAS_REF>
+__global__ void __launch_bounds__(kActThreads)
+bias_act_elem_f64_kernel(double* __restrict__ y, const double* __restrict__ x, const double* __restrict__ bias,
+                         const double* __restrict__ ref, double alpha, double scale, int n, int step_b, int size_b) {
+    for (int i = blockIdx.x * kActThreads + threadIdx.x; i < n; i += gridDim.x * kActThreads) {
+        double v = x[i];
+        if (HAS_BIAS) v += bias[(i / step_b) % size_b];
+        double o;
+        if (MODE == kLinear) o = v;
+        else if (MODE == kZero) o = 0.0;
+        else if (MODE == kLrelu) o = v > 0.0 ? v : v * alpha;
+        else o = (HAS_REF ? ref[i] : 0.0) > 0.0 ? v : v * alpha;
+        y[i] = o * scale;
+    }
+}
+template <int MODE>
+static int dispatch_bias_act_f64(double* y, const double* x, const double* bias, const double* ref, float alpha, float scale, int64_t n,
+                                 int64_t step_b, int64_t size_b, hipStream_t st) {
+    const bool hb = bias != nullptr && size_b > 0, hr = (MODE == kLreluGrad) && ref != nullptr;
+    int64_t blocks = (n + kActThreads - 1) / kActThreads;
+    if (blocks > 8192) blocks = 8192;
+    const dim3 g((unsigned)blocks), t(kActThreads);
+    const int sb = hb ? (int)step_b : 1, zb = hb ? (int)size_b : 1;
+    if (hb && hr) bias_act_elem_f64_kernel<MODE, true, true><<<g, t, 0, st>>>(y, x, bias, ref, alpha, scale, (int)n, sb, zb);
+    else if (hb) bias_act_elem_f64_kernel<MODE, true, false><<<g, t, 0, st>>>(y, x, bias, ref, alpha, scale, (int)n, sb, zb);
+    else if (hr) bias_act_elem_f64_kernel<MODE, false, true><<<g, t, 0, st>>>(y, x, bias, ref, alpha, scale, (int)n, sb, zb);
+    else bias_act_elem_f64_kernel<MODE, false, false><<<g, t, 0, st>>>(y, x, bias, ref, alpha, scale, (int)n, sb, zb);
+    return check_launch("fused_bias_act(f64)");
+}
+}  // namespace e3dge
+
+extern "C" int e3dge_fused_bias_act_f64(double* y, const double* x, const double* bias, const double* ref, int act, int grad, float alpha,
+                                        float scale, int64_t n, int64_t step_b, int64_t size_b, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "fused_bias_act_f64: n=%lld outside int32 range", (long long)n);
+    if (n == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(x && y, "fused_bias_act_f64: null x/y");
+    const bool has_bias = bias != nullptr && size_b > 0;
+    E3DGE_REQUIRE(!has_bias || step_b >= 1, "fused_bias_act_f64: step_b=%lld", (long long)step_b);
+    hipStream_t st = as_stream(stream);
+    switch (act * 10 + grad) {       // the reference's table (:35-45)
+        case 12: case 32: return dispatch_bias_act_f64<kZero>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
+        case 30: return dispatch_bias_act_f64<kLrelu>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
+        case 31: return dispatch_bias_act_f64<kLreluGrad>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
+        default: return dispatch_bias_act_f64<kLinear>(y, x, has_bias ? bias : nullptr, ref, alpha, scale, n, step_b, size_b, st);
+    }
+}
+
 extern "C" int e3dge_noise_bias_act(float* y, const float* x, const float* noise,
                                     const float* noise_weight, const float* bias, float alpha,
                                     float scale, int64_t batch, int64_t channels, int64_t hw,

@@ -356,6 +356,35 @@ upfirdn2d_generic_kernel(T* __restrict__ y, const T* __restrict__ x,
     }
 }
 
+// fp64 form (ABI 12; upfirdn2d_kernel.cu:311 dispatches double too): the generic kernel in double arithmetic, taps in double -- what
+// torch.autograd.gradcheck feeds the op.
+__global__ void __launch_bounds__(kUpThreads)
+upfirdn2d_generic_f64_kernel(double* __restrict__ y, const double* __restrict__ x, const double* __restrict__ k, UpfirdnGeom g, int64_t total) {
+    for (int64_t o = (int64_t)blockIdx.x * kUpThreads + threadIdx.x; o < total; o += (int64_t)gridDim.x * kUpThreads) {
+        const int ox = (int)(o % g.out_w);
+        const int64_t t = o / g.out_w;
+        const int oy = (int)(t % g.out_h);
+        const int64_t plane = t / g.out_h;
+        const double* xp = x + plane * (int64_t)g.in_h * g.in_w;
+        const int by = oy * g.down_y - g.pad_y0, bx = ox * g.down_x - g.pad_x0;
+        double acc = 0.0;
+        for (int ky = 0; ky < g.kh; ++ky) {
+            const int sy = by + ky;
+            if (sy < 0) continue;
+            const int iy = sy / g.up_y;
+            if (iy * g.up_y != sy || iy >= g.in_h) continue;
+            for (int kx = 0; kx < g.kw; ++kx) {
+                const int sx = bx + kx;
+                if (sx < 0) continue;
+                const int ix = sx / g.up_x;
+                if (ix * g.up_x != sx || ix >= g.in_w) continue;
+                acc = fma(xp[(int64_t)iy * g.in_w + ix], k[(g.kh - 1 - ky) * g.kw + (g.kw - 1 - kx)], acc);
+            }
+        }
+        y[o] = acc;
+    }
+}
+
 template <int UP, int DN, int KH, int KW, typename T = float>
 static int launch_tiled(T* y, const T* x, const float* k, const UpfirdnGeom& g,
                         int64_t major, hipStream_t st) {
@@ -415,6 +444,25 @@ extern "C" int e3dge_upfirdn2d_f16(void* y, const void* x, const float* k, int64
                                    int pad_x0, int pad_x1, int pad_y0, int pad_y1, e3dge_stream_t stream) {
     return upfirdn2d_any<_Float16>(static_cast<_Float16*>(y), static_cast<const _Float16*>(x), k, major, in_h, in_w, kh, kw, up_x, up_y,
                                    down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1, stream);
+}
+
+extern "C" int e3dge_upfirdn2d_f64(double* y, const double* x, const double* k, int64_t major, int in_h, int in_w, int kh, int kw, int up_x,
+                                   int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(up_x >= 1 && up_y >= 1 && down_x >= 1 && down_y >= 1, "upfirdn2d_f64: up/down must be >= 1");
+    E3DGE_REQUIRE(kh >= 1 && kw >= 1 && kh <= 32 && kw <= 32, "upfirdn2d_f64: kernel %dx%d outside 1..32", kh, kw);
+    E3DGE_REQUIRE(major >= 0 && in_h >= 1 && in_w >= 1, "upfirdn2d_f64: bad input extent");
+    const int out_h = e3dge_upfirdn2d_out_size(in_h, up_y, down_y, pad_y0, pad_y1, kh);
+    const int out_w = e3dge_upfirdn2d_out_size(in_w, up_x, down_x, pad_x0, pad_x1, kw);
+    E3DGE_REQUIRE(out_h > 0 && out_w > 0, "upfirdn2d_f64: empty output (%d x %d)", out_h, out_w);
+    if (major == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(x && y && k, "upfirdn2d_f64: null pointer");
+    E3DGE_REQUIRE(major * (int64_t)out_h * out_w < ((int64_t)1 << 40), "upfirdn2d_f64: output too large");
+    UpfirdnGeom g{in_h, in_w, out_h, out_w, up_x, up_y, down_x, down_y, pad_x0, pad_y0, kh, kw};
+    const int64_t total = major * (int64_t)out_h * out_w;
+    int64_t blocks = (total + kUpThreads - 1) / kUpThreads;
+    if (blocks > 16384) blocks = 16384;
+    upfirdn2d_generic_f64_kernel<<<dim3((unsigned)blocks), dim3(kUpThreads), 0, as_stream(stream)>>>(y, x, k, g, total);
+    return check_launch("upfirdn2d(f64)");
 }
 
 extern "C" int e3dge_blur_noise_bias_act(float* y, const float* x, const float* k, const float* noise, const float* noise_weight,

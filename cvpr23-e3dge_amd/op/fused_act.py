@@ -38,7 +38,8 @@ def fused_bias_act(input, bias, refer, act, grad, alpha, scale):
     for d in x.shape[2:]:
         step_b *= d
     y = torch.empty_like(x)
-    fn = _lib.load().e3dge_fused_bias_act_f16 if half else _lib.load().e3dge_fused_bias_act
+    lib = _lib.load()
+    fn = lib.e3dge_fused_bias_act_f16 if half else (lib.e3dge_fused_bias_act_f64 if x.dtype == torch.float64 else lib.e3dge_fused_bias_act)
     with torch.cuda.device(x.device):
         rc = fn(_lib.ptr(y), _lib.ptr(x), _lib.ptr(b), _lib.ptr(r), int(act), int(grad), float(alpha), float(scale),
                 x.numel(), step_b, 0 if b is None else b.numel(), _lib.stream_of(x))

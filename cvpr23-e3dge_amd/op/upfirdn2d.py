@@ -44,10 +44,10 @@ class Geometry(NamedTuple):
 
 
 def _launch(planes, kernel, geo):
-    """planes (major, in_h, in_w) contiguous fp32 or fp16 on the GPU -> (major, out_h, out_w), same dtype.  The FIR taps go
-    to the kernel as fp32 either way (the half form computes in fp32 and rounds once on store)."""
+    """planes (major, in_h, in_w) contiguous fp32, fp16 or fp64 on the GPU -> (major, out_h, out_w), same dtype.  The FIR taps go
+    to the kernel as fp32 for fp32 / fp16 planes (the half form computes in fp32 and rounds once on store), as fp64 for fp64 planes."""
     major, in_h, in_w = planes.shape
-    kernel = kernel.float()
+    kernel = kernel.double().contiguous() if planes.dtype == torch.float64 else kernel.float()
     kh, kw = kernel.shape
     (ux, uy), (dx, dy), (px0, px1, py0, py1) = geo.up, geo.down, geo.pad
     lib = _lib.load()
@@ -57,7 +57,7 @@ def _launch(planes, kernel, geo):
         raise RuntimeError(f"upfirdn2d: empty output for input {in_h}x{in_w}, up {geo.up}, down {geo.down}, "
                            f"pad {geo.pad}, kernel {kh}x{kw}")
     y = planes.new_empty((major, out_h, out_w))
-    fn = lib.e3dge_upfirdn2d_f16 if planes.dtype == torch.float16 else lib.e3dge_upfirdn2d
+    fn = lib.e3dge_upfirdn2d_f16 if planes.dtype == torch.float16 else (lib.e3dge_upfirdn2d_f64 if planes.dtype == torch.float64 else lib.e3dge_upfirdn2d)
     with torch.cuda.device(planes.device):
         rc = fn(_lib.ptr(y), _lib.ptr(planes), _lib.ptr(kernel), major, in_h, in_w, kh, kw,
                 ux, uy, dx, dy, px0, px1, py0, py1, _lib.stream_of(planes))

@@ -84,6 +84,14 @@ int e3dge_fused_bias_act_f16(void* y, const void* x, const void* bias, const voi
                              int64_t n, int64_t step_b, int64_t size_b, e3dge_stream_t stream);
 int e3dge_upfirdn2d_f16(void* y, const void* x, const float* k, int64_t major, int in_h, int in_w, int kh, int kw, int up_x, int up_y,
                         int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, e3dge_stream_t stream);
+/* Double-precision forms of the two ops (ABI 12): the reference's AT_DISPATCH_FLOATING_TYPES_AND_HALF (fused_bias_act_kernel.cu:79,
+ * upfirdn2d_kernel.cu:311) includes double, which is what torch.autograd.gradcheck / gradgradcheck feed an op.  Arithmetic is double
+ * throughout (scalar_t = double in the reference); alpha / scale are widened from float as fused_bias_act.cpp:11-20 passes them; the FIR
+ * taps are double (the reference reads kernel.data_ptr<scalar_t>()).  Plain element kernels: correctness tools, not stream-rate code. */
+int e3dge_fused_bias_act_f64(double* y, const double* x, const double* bias, const double* ref, int act, int grad, float alpha, float scale,
+                             int64_t n, int64_t step_b, int64_t size_b, e3dge_stream_t stream);
+int e3dge_upfirdn2d_f64(double* y, const double* x, const double* k, int64_t major, int in_h, int in_w, int kh, int kw, int up_x, int up_y,
+                        int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, e3dge_stream_t stream);
 /* Output extent helper (same formula as above); returns <0 if the result would be empty. */
 int e3dge_upfirdn2d_out_size(int in, int up, int down, int pad0, int pad1, int k);
 

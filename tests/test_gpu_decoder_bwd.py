@@ -183,6 +183,35 @@ def test_ineligible_graphs_take_the_library_path(gen256):
     assert e["l2"] <= REL_TOL, e
 
 
+def test_library_path_d_features_and_d_latent_against_the_references_autograd_256(gen256):
+    """The path every forward with d latent (or a trainable decoder parameter) takes -- weight modulation + MIOpen + the two custom
+    ops' backward classes -- against the reference's recording at the size where all four fused custom-op shapes occur, batch 2,
+    per-sample noise (round-4 review, item 7: it was pinned at size 64 only)."""
+    g, _ = gen256
+    dec = g.decoder
+    gold = load_golden("decoder_grads_256")
+    B = int(gold["batch"])
+    feats, noises, gy = syn.decoder_grad_inputs(B, int(gold["size"]), int(gold["in_res"]), seed=int(gold["inputs_seed"]), device=DEV)
+    _, wd = syn.synthetic_inputs(B, seed=int(gold["styles_seed"]), device=DEV)
+    f = feats.clone().requires_grad_(True)
+    wl = wd[:, :dec.n_latent].clone().requires_grad_(True)
+    img, _ = dec(f, [wl], input_is_latent=True, noise=noises)
+    assert "PackedDecoderFn" not in type(img.grad_fn).__name__
+    d_f, d_l = torch.autograd.grad(img, [f, wl], gy)
+    ref_f, f64_f = torch.from_numpy(gold["ref_d_features_sub"]), torch.from_numpy(gold["f64_d_features_sub"])
+    ref_l, f64_l = torch.from_numpy(gold["ref_d_latent"]), torch.from_numpy(gold["f64_d_latent"])
+    sub = d_f[:, ::4, ::2, ::2]
+    e = dict(d_features_l2_vs_f64=rel_l2(sub, f64_f), d_features_max_vs_f64=rel_max(sub, f64_f),
+             reference_d_features_l2_vs_f64=rel_l2(ref_f, f64_f), reference_d_features_max_vs_f64=rel_max(ref_f, f64_f),
+             d_latent_l2_vs_f64=rel_l2(d_l, f64_l), d_latent_max_vs_f64=rel_max(d_l, f64_l),
+             reference_d_latent_l2_vs_f64=rel_l2(ref_l, f64_l), reference_d_latent_max_vs_f64=rel_max(ref_l, f64_l),
+             img=float((img.detach()[:, :, ::4, ::4].cpu() - torch.from_numpy(gold["ref_img_sub4"])).abs().max()))
+    record("dec_library_bwd_vs_reference_256", **e)
+    assert e["img"] <= 1e-4
+    for k in ("d_features_l2", "d_features_max", "d_latent_l2", "d_latent_max"):
+        assert e[k + "_vs_f64"] <= max(REL_TOL, 3 * e["reference_" + k + "_vs_f64"]), (k, e)
+
+
 def test_d_features_full_size_1024_against_float64_autograd():
     """The BASELINE decoder (1024^2, channel multiplier 2), batch 1: d features against float64 autograd of the oracle on the CPU."""
     g, sd = full_state_dict(size=1024, cm=2, res=64, n_samples=24)

@@ -226,6 +226,49 @@ def test_half_precision_entry_points_of_the_two_ops():
     record("half_entry_points", worst_ulp=worst)
 
 
+def test_double_precision_entry_points_and_gradcheck():
+    """ABI 12: e3dge_fused_bias_act_f64 / e3dge_upfirdn2d_f64 -- the reference's dispatch includes double (fused_bias_act_kernel.cu:79,
+    upfirdn2d_kernel.cu:311), which is what torch.autograd.gradcheck / gradgradcheck run an op in.  Values against the oracle in float64
+    (<= 1e-14), then gradcheck and gradgradcheck of the public ops ON the GPU kernels, as one would run them on the reference's."""
+    rs = np.random.RandomState(11)
+    x = torch.from_numpy(rs.standard_normal((2, 6, 5, 7)))
+    b = torch.from_numpy(rs.standard_normal(6))
+    r = torch.from_numpy(rs.standard_normal((2, 6, 5, 7)))
+    worst = 0.0
+    for act, grad in [(1, 0), (1, 1), (1, 2), (3, 0), (3, 1), (3, 2)]:
+        for bias in (b, None):
+            for ref in (r, None):
+                want = ops_ref.fused_bias_act_ref(x, bias, ref, act, grad, 0.2, 1.3)
+                got = op.fused_bias_act(x.to(DEV), None if bias is None else bias.to(DEV), None if ref is None else ref.to(DEV), act, grad, 0.2, 1.3)
+                assert got.dtype == torch.float64
+                worst = max(worst, maxerr(got, want))
+    # (alpha and scale travel as float, as in the reference's binding: compare with the same widened values)
+    a32, s32 = float(np.float32(0.2)), float(np.float32(1.3))
+    want = ops_ref.fused_bias_act_ref(x, b, None, 3, 0, a32, s32)
+    assert maxerr(op.fused_bias_act(x.to(DEV), b.to(DEV), None, 3, 0, 0.2, 1.3), want) <= 1e-14
+    assert worst <= 1e-6          # (0.2 vs float(0.2f): the widening above is the whole difference)
+    g = load_golden("upfirdn2d")
+    for name in ('blur_up', 'upsample', 'downsample', 'blur_down', 'k3', 'crop'):
+        up, down, p0, p1 = [int(v) for v in g[name + '_cfg']]
+        xd = torch.from_numpy(np.asarray(g[name + '_x'])).double()
+        k = torch.from_numpy(np.asarray(g[name + '_k'])).double()
+        want = ops_ref.upfirdn2d_ref_simple(xd, k, up=up, down=down, pad=(p0, p1))
+        got = op.upfirdn2d(xd.to(DEV), k.to(DEV), up=up, down=down, pad=(p0, p1))
+        assert got.dtype == torch.float64 and maxerr(got, want) <= 1e-13, name
+    # gradcheck / gradgradcheck on the GPU ops (inputs away from the kink of lrelu)
+    xs = torch.from_numpy(rs.standard_normal((2, 3, 4, 5)))
+    xs = (xs + 0.3 * torch.sign(xs)).to(DEV).requires_grad_(True)
+    bs = torch.zeros(3, dtype=torch.float64, device=DEV, requires_grad=True)
+    assert torch.autograd.gradcheck(lambda t, u: op.fused_leaky_relu(t, u, 0.2, 2 ** 0.5), (xs, bs), eps=1e-6, atol=1e-6)
+    assert torch.autograd.gradgradcheck(lambda t, u: op.fused_leaky_relu(t, u, 0.2, 2 ** 0.5), (xs, bs), eps=1e-6, atol=1e-6)
+    xu = torch.from_numpy(rs.standard_normal((1, 2, 5, 6))).to(DEV).requires_grad_(True)
+    k4 = torch.from_numpy(np.outer([1, 3, 3, 1], [1, 3, 3, 1]) / 64.0).to(DEV)
+    for kw in (dict(up=2, pad=(2, 1)), dict(down=2, pad=(1, 1)), dict(pad=(1, 1))):
+        assert torch.autograd.gradcheck(lambda t: op.upfirdn2d(t, k4, **kw), (xu,), eps=1e-6, atol=1e-7)
+        assert torch.autograd.gradgradcheck(lambda t: op.upfirdn2d(t, k4, **kw), (xu,), eps=1e-6, atol=1e-7)
+    record("double_entry_points", worst=worst)
+
+
 def test_upfirdn2d_asymmetric_raw():
     g = load_golden("upfirdn2d")
     ux, uy, dx, dy, px0, px1, py0, py1 = [int(v) for v in g['asym_cfg']]
