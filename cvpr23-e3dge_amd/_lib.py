@@ -250,19 +250,31 @@ def stream_of(t):
 
 def params_of(module):
     """The module's parameters as `module.parameters()` yields them, without walking the module tree on every call: the
-    (sub-module, name) slots are listed once and looked up per call, so a replaced Parameter object is still seen; a sub-module or
-    parameter ADDED later is not (call `forget_params(module)` after such surgery).  `module.parameters()` costs ~1.3 us per parameter
-    -- 77 us for the SIREN, called by every launch wrapper to key its weight-image cache: ~0.7 ms of host time per training step,
-    which the GPU spent idle between launches (rocprofv3 kernel trace, round 4)."""
-    slots = module.__dict__.get('_e3dge_param_slots')
-    if slots is None:
-        seen, slots = set(), []
-        for m in module.modules():
-            for n, q in m._parameters.items():
-                if q is not None and id(q) not in seen:
-                    seen.add(id(q))
-                    slots.append((m._parameters, n))
-        module.__dict__['_e3dge_param_slots'] = slots
+    (sub-module, name) slots are listed once and looked up per call, so a replaced Parameter object is still seen.  The listing is
+    re-validated cheaply on every call -- the number of entries of every sub-module's `_parameters` / `_modules` dict it was built from
+    -- so a parameter or sub-module ADDED or REMOVED later (weight_norm, parametrize, add_module) rebuilds it instead of leaving the
+    weight-image caches and requires_grad checks looking at detached parameters (round-4 advisor finding).  `module.parameters()`
+    costs ~1.3 us per parameter -- 77 us for the SIREN, called by every launch wrapper to key its weight-image cache: ~0.7 ms of host
+    time per training step, which the GPU spent idle between launches (rocprofv3 kernel trace, round 4); the check is ~2 us."""
+    cached = module.__dict__.get('_e3dge_param_slots')
+    if cached is not None and cached[2] == id(module):      # (a shallow copy -- DataParallel's replicas -- carries the master's listing)
+        slots, checks, _ = cached
+        if all(len(d) == n for d, n in checks):
+            try:
+                out = [d[n] for d, n in slots]
+                if all(q is not None for q in out):
+                    return out
+            except KeyError:
+                pass
+    seen, slots, checks = set(), [], []
+    for m in module.modules():
+        checks.append((m._parameters, len(m._parameters)))
+        checks.append((m._modules, len(m._modules)))
+        for n, q in m._parameters.items():
+            if q is not None and id(q) not in seen:
+                seen.add(id(q))
+                slots.append((m._parameters, n))
+    module.__dict__['_e3dge_param_slots'] = (slots, checks, id(module))
     return [d[n] for d, n in slots]
 
 

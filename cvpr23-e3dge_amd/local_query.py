@@ -182,7 +182,7 @@ class Fuse_sft_MLP(nn.Module):
         if self._native_ok(enc_in):
             if not self._wants_grad(enc_in):
                 return self._fuse_native(enc_in, float(w), out, out_off)
-            if out is None and fuse_autograd_backend() == "hip":
+            if out is None and fuse_autograd_backend() == "hip" and self._fusefn_ok(enc_in, dec_feat, w):
                 # training (round 4): the same nine launches as the forward of an autograd node; its backward is library GEMMs on
                 # the intermediates the launches left behind (the 3D-projected block of enc_in IS dec_feat, as on the inference path)
                 return _FuseFn.apply(self, enc_in, float(w), *self._param_list())
@@ -203,6 +203,17 @@ class Fuse_sft_MLP(nn.Module):
         if enc_in.shape[-1] != fc0.in_features or self.encode_enc.shortcut is None:
             return False
         return all(p.device == enc_in.device and p.dtype == torch.float32 for p in _lib.params_of(self))
+
+    def _fusefn_ok(self, enc_in, dec_feat, w):
+        """_FuseFn differentiates w.r.t. enc_in and the parameters only, and reads dec_feat out of enc_in's last 256 columns: an empty
+        input, a weight tensor that requires grad, or a dec_feat that is NOT that view (its own gradient would be dropped) take the torch
+        modules instead (round-4 advisor findings)."""
+        if enc_in.numel() == 0 or (torch.is_tensor(w) and (w.requires_grad or w.numel() != 1)):
+            return False
+        b_off = enc_in.shape[-1] - 256
+        tail = enc_in[..., b_off:]
+        return (torch.is_tensor(dec_feat) and dec_feat.shape == tail.shape and dec_feat.data_ptr() == tail.data_ptr()
+                and dec_feat.stride() == tail.stride())
 
     def _wants_grad(self, enc_in):
         return torch.is_grad_enabled() and (enc_in.requires_grad or any(p.requires_grad for p in _lib.params_of(self)))
@@ -373,7 +384,8 @@ def local_features_from_maps(local_data_batch, n_freqs=7):
     if torch.is_grad_enabled() and (maps['ref'].requires_grad or maps['que'].requires_grad or pts.requires_grad or
                                     any(p_.requires_grad for p_ in fuse.parameters())):
         # training form (stage 2 trains the hourglass filters and Fuse_sft_MLP through this, e3dge_full_runner.py:185-317): the
-        # same values assembled from differentiable pieces -- gathers with the HIP backward, Fuse_sft_MLP as torch modules
+        # same values assembled from differentiable pieces -- gathers with the HIP backward, Fuse_sft_MLP as the _FuseFn node (native
+        # forward, written-out backward) or, when that does not apply, as torch modules
         a, _, _ = query_feature_map(pts, local_data_batch['que_calibs'], maps['que'])
         dec, in_img, _ = query_feature_map(pts, local_data_batch['ref_calibs'], maps['ref'])
         cols = [a]
@@ -383,9 +395,15 @@ def local_features_from_maps(local_data_batch, n_freqs=7):
                 _, vis, _ = query_feature_map(surf, local_data_batch['ref_calibs'])
             cols.append(vis.reshape(B, H * W, 1).expand(B, H * W, S).reshape(B, N, 1))
         cols.append(dec)
-        fused = fuse.fuse(torch.cat(cols, -1), dec)
-        with torch.no_grad():
-            enc_p = pos_encoding(pts.detach(), n_freqs)
+        enc_in = torch.cat(cols, -1)
+        fused = fuse.fuse(enc_in, enc_in[..., enc_in.shape[-1] - dec.shape[-1]:])      # (dec as the view of enc_in that it is)
+        if pts.requires_grad:
+            # the 45 positional-encoding columns carry a gradient to the points too (PosEncoding.forward, misc_utils.py:148-185):
+            # plain differentiable torch ops here -- the kernel has no backward, and silently dropping it was an advisor finding
+            enc_p = torch.cat([pts] + [fn(pts * float(2 ** k)) for k in range(n_freqs) for fn in (torch.sin, torch.cos)], -1)
+        else:
+            with torch.no_grad():
+                enc_p = pos_encoding(pts.detach(), n_freqs)
         feats = torch.cat([fused, enc_p], -1)
         return feats.reshape(B, H, W, S, feats.shape[-1]), in_img.reshape(B, H, W, S, 1)
     enc_in = torch.empty((B, N, n_enc + C), device=pts.device, dtype=torch.float32)       # [2D-aligned | vis mask | 3D-projected]
@@ -402,12 +420,14 @@ def local_features_from_maps(local_data_batch, n_freqs=7):
     return feats.reshape(B, H, W, S, C + width), in_img.reshape(B, H, W, S, 1)
 
 
-def tex_modulations_from_maps(local_head, renderer, cam_poses, focal, near, far, local_data_batch):
-    """(alpha, beta), each (B,H,W,S,256), for the renderer's second pass (called by VolumeFeatureRenderer.forward)."""
+def tex_modulations_from_maps(local_head, renderer, cam_poses, focal, near, far, local_data_batch, lazy=False):
+    """(alpha, beta), each (B,H,W,S,256), for the renderer's second pass.  `lazy=True` (VolumeFeatureRenderer.forward only, without an
+    autograd graph): a private _LazyTex instead -- the renderer then decides between the fused head + FiLM launch on the record path
+    and materialising (alpha, beta); external callers always get the documented tuple."""
     feats, in_img = local_features_from_maps(local_data_batch)
     local_data_batch['in_img_mask'] = in_img
     head = local_head.local_feat_to_tex_modulations_linear
-    if not torch.is_grad_enabled():
-        from .volume_renderer import _LazyTex            # the renderer decides: fused head + FiLM launch on the record path, or (alpha, beta)
+    if lazy and not torch.is_grad_enabled():
+        from .volume_renderer import _LazyTex
         return _LazyTex(head, feats)
     return head.tex_modulations(feats)

@@ -81,7 +81,26 @@ class _ReuseKey:
         return all((t._version == s[1]) for t, s in zip(rec_key.tensors, rec_key.sig) if torch.is_tensor(t))
 
 
-_FILM_RECORD = weakref.WeakKeyDictionary()                             # renderer -> FiLM-ed layer-7 record (e3dge_tex_film_fwd output)
+# renderer -> {(kind, stream, bytes, device): [buffer, pinned]}: the raw storage of the layer-7 records ('bb': written by a first pass,
+# 'film': the FiLM-ed copy e3dge_tex_film_fwd writes).  One buffer per STREAM and size -- two streams rendering with one renderer do not
+# share storage -- and a buffer that a HIP-graph capture has seen is PINNED: the graph holds its raw pointer, so it is never replaced or
+# dropped (an eager render of another batch size, or invalidate(), used to free the one buffer per renderer while a captured graph still
+# wrote ~100 MB into it on every replay; round-4 advisor finding).  Unpinned buffers of another size on the same stream are released.
+_RECORD_BUFS = weakref.WeakKeyDictionary()
+
+
+def _record_buffer(renderer, kind, n_bytes, dev, stream, capturing, zero):
+    pool = _RECORD_BUFS.setdefault(renderer, {})
+    key = (kind, stream, int(n_bytes), str(dev))
+    ent = pool.get(key)
+    if ent is None:
+        for k in [k for k, e in pool.items() if k[0] == kind and k[1] == stream and not e[1]]:
+            pool.pop(k)
+        buf = (torch.zeros if zero else torch.empty)(int(n_bytes), device=dev, dtype=torch.uint8)
+        ent = pool[key] = [buf, False]
+    if capturing:
+        ent[1] = True
+    return ent[0]
 _BACKBONE = weakref.WeakKeyDictionary()                                # renderer -> {key, buf (record), out (first pass's tensors)}
 _SIDE_STREAMS = {}                                                     # per device (module level: modules stay deep-copyable)
 
@@ -763,9 +782,9 @@ class LocalTexHead(nn.Module):
         super().__init__()
         self.local_feat_to_tex_modulations_linear = ResnetBlockFC(feats_dim, 512)
 
-    def tex_modulations_from_maps(self, renderer, cam_poses, focal, near, far, local_data_batch):
+    def tex_modulations_from_maps(self, renderer, cam_poses, focal, near, far, local_data_batch, lazy=False):
         from .local_query import tex_modulations_from_maps
-        return tex_modulations_from_maps(self, renderer, cam_poses, focal, near, far, local_data_batch)
+        return tex_modulations_from_maps(self, renderer, cam_poses, focal, near, far, local_data_batch, lazy=lazy)
 
 
 class SirenLocalGlobal(nn.Module):
@@ -981,13 +1000,12 @@ class VolumeFeatureRenderer(nn.Module):
         if reuse_key is not None and B > 0 and self._reuse_enabled(save_args):
             # producer and consumer of a record must be both eager or both inside the same graph capture (a graph holding only the
             # second pass would replay against whatever the record held at capture time)
-            reuse_key = reuse_key.extended(_lib.load().e3dge_stream_capture_id(_lib.stream_of(c2w)))
+            cap_id = _lib.load().e3dge_stream_capture_id(_lib.stream_of(c2w))
+            reuse_key = reuse_key.extended(cap_id)
             rec = _BACKBONE.get(self)
             if tex_conditions is None:                       # first pass: leave a record behind
                 n_bytes = _lib.load().e3dge_siren_backbone_bytes(B, H, Wd, S)
-                buf = rec['buf'] if rec is not None and rec['buf'].numel() == n_bytes and rec['buf'].device == dev else \
-                    torch.empty(n_bytes, device=dev, dtype=torch.uint8)
-                bb_out = buf
+                bb_out = _record_buffer(self, 'bb', n_bytes, dev, _lib.stream_of(c2w), cap_id != 0, zero=False)
                 _BACKBONE[self] = None                        # (not valid until the launch below is queued)
             elif rec is not None and reuse_key.matches(rec['key']) and \
                     all(t._version == v for t, v in zip(rec['out'].values(), rec['out_versions'])):
@@ -999,11 +1017,10 @@ class VolumeFeatureRenderer(nn.Module):
             n_rec = use['buf'].numel() if use is not None else 0
             if (use is not None and _fuse_texfilm() and lazy.feats.dtype == torch.float32 and lazy.feats.device == dev
                     and tuple(lazy.feats.shape[:4]) == (B, H, Wd, S) and 0 < n_rec < 2 ** 32 and B * H * Wd * S < 2 ** 31):
-                # the FiLM-ed record outlives the layer-7 records it is computed from (one buffer per renderer, zero-filled ONCE:
+                # the FiLM-ed record outlives the layer-7 records it is computed from (one buffer per stream and size, zero-filled ONCE:
                 # padding slabs are never written): allocating it per record put a 100-MB fill into every captured forward
-                tb_ = _FILM_RECORD.get(self)
-                if tb_ is None or tb_.numel() != n_rec or tb_.device != dev:
-                    tb_ = _FILM_RECORD[self] = torch.zeros(n_rec, device=dev, dtype=torch.uint8)
+                tb_ = _record_buffer(self, 'film', n_rec, dev, _lib.stream_of(c2w),
+                                     _lib.load().e3dge_stream_capture_id(_lib.stream_of(c2w)) != 0, zero=True)
                 use['tex_buf'] = tb_
                 bb_in = lazy.head.tex_film(lazy.feats, use['buf'], tb_, B, H, Wd, S)
             else:
@@ -1076,7 +1093,10 @@ class VolumeFeatureRenderer(nn.Module):
         detected without it."""
         self._sb_key = None
         _BACKBONE.pop(self, None)                             # (the first pass's layer-7 record was computed from the old values)
-        _FILM_RECORD.pop(self, None)
+        pool = _RECORD_BUFS.get(self)
+        if pool:                                              # storage a captured graph points into stays; the rest is released
+            for k in [k for k, e in pool.items() if not e[1]]:
+                pool.pop(k)
         for m in self.modules():
             if m is not self and hasattr(m, 'invalidate'):
                 m.invalidate()
@@ -1111,7 +1131,7 @@ class VolumeFeatureRenderer(nn.Module):
             elif local_data_batch.get('feature_maps', None) is not None and self.network.netLocal is not None:
                 # feature maps of the local branch: the per-point query (projection + bilinear gather + positional
                 # encoding, e3dge_full_runner.py:185-317) runs in HIP and feeds the texture head directly
-                tex = self.network.netLocal.tex_modulations_from_maps(self, cam_poses, focal, near, far, local_data_batch)
+                tex = self.network.netLocal.tex_modulations_from_maps(self, cam_poses, focal, near, far, local_data_batch, lazy=True)
                 if isinstance(tex, _LazyTex) and not self._lazy_tex_ok(tex.feats, tex.head):
                     tex = tex.materialize()
             else:

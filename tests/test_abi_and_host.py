@@ -347,3 +347,30 @@ def test_modules_are_deep_copyable():
     g2 = copy.deepcopy(g)
     assert g2.state_dict().keys() == g.state_dict().keys()
     assert g2.renderer.opt.N_samples == g.renderer.opt.N_samples and g2.renderer.opt.no_such_option is None
+
+
+def test_params_of_notices_added_removed_and_replaced_parameters():
+    """_lib.params_of caches the (sub-module, name) slots of a module; the weight-image caches and the requires_grad checks of the launch
+    wrappers are keyed on what it returns, so it must keep matching module.parameters() through module surgery (round-4 advisor finding)."""
+    import copy
+    import torch
+    from torch import nn
+    m = nn.Sequential(nn.Linear(3, 4), nn.Linear(4, 2))
+    same = lambda mod: [id(p) for p in _lib.params_of(mod)] == [id(p) for p in mod.parameters()]
+    assert same(m) and same(m)
+    m[0].weight = nn.Parameter(torch.zeros(4, 3))                  # replaced object, same slot
+    assert same(m)
+    m.add_module("extra", nn.Linear(2, 2))                         # sub-module added later
+    assert same(m) and len(_lib.params_of(m)) == 6
+    m[1].register_parameter("gain", nn.Parameter(torch.ones(1)))   # parameter added later
+    assert same(m) and len(_lib.params_of(m)) == 7
+    del m[1]._parameters["gain"]                                   # parameter removed (weight_norm / parametrize do this): no KeyError
+    assert same(m) and len(_lib.params_of(m)) == 6
+    m[0].bias = None
+    assert same(m) and len(_lib.params_of(m)) == 5
+    twin = copy.copy(m)                                            # a shallow copy (DataParallel's replicas) with its own parameter dicts
+    twin._modules = {k: copy.copy(v) for k, v in m._modules.items()}
+    for v in twin._modules.values():
+        v._parameters = {k: nn.Parameter(p.detach().clone()) for k, p in v._parameters.items() if p is not None}
+    assert same(twin) and same(m)
+    assert same(copy.deepcopy(m))

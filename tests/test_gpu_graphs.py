@@ -84,6 +84,51 @@ def test_backbone_record_never_crosses_a_capture_boundary():
     assert not torch.equal(e1, e2)
 
 
+def test_record_buffers_a_capture_has_seen_survive_eager_renders_of_other_sizes():
+    """Round-4 advisor finding: the layer-7 record and its FiLM-ed copy lived in ONE buffer per renderer; a captured graph holds raw
+    pointers into them, and an eager render of another batch size (or invalidate()) replaced / freed the buffer -- the next replay then
+    wrote ~100 MB into memory the caching allocator may have handed to somebody else.  Now the storage is per (stream, size) and pinned
+    once a capture has seen it: replays interleaved with eager renders of other batch sizes, invalidate() and fresh allocations stay
+    bit-identical, and the tensors allocated in between keep their contents."""
+    from e3dge_amd import volume_renderer as vr
+    from e3dge_amd.volume_renderer import VolumeFeatureRenderer
+    res, S = 16, 24
+    g, sd = full_state_dict(res=res, n_samples=S)
+    r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S, enable_local_model=True, L_pred_tex_modulations=True), out_im_res=res, mode='test')
+    r.load_state_dict({k: (syn.synthetic_tensor('renderer.' + k, v.shape) * 0.05 if 'netLocal' in k else
+                           sd['renderer.' + k.replace('network.netGlobal.', 'network.')]) for k, v in r.state_dict().items()})
+    r = r.to(DEV).eval()
+    cam = lambda b: generate_camera_params(res, DEV, locations=torch.zeros(b, 2, device=DEV))[:4]
+    p1, p3 = cam(1), cam(3)
+    f1, f3 = syn.synthetic_local_feats(1, res, S, device=DEV), syn.synthetic_local_feats(3, res, S, seed=9, device=DEV)
+    w1, w2 = (syn.synthetic_inputs(1, seed=s, device=DEV)[0] for s in (5, 6))
+    w3 = syn.synthetic_inputs(3, seed=7, device=DEV)[0]
+
+    def both(w):
+        r(*p1, styles=w)
+        return r(*p1, styles=w, local_data_batch={'feats': f1})['features']
+
+    def both3():
+        r(*p3, styles=w3)
+        return r(*p3, styles=w3, local_data_batch={'feats': f3})['features']
+    with torch.no_grad():
+        e1, e2, e3 = both(w1).clone(), both(w2).clone(), both3().clone()
+        gc = GraphedCall(both, w1)
+        pinned = {k: e[0].data_ptr() for k, e in vr._RECORD_BUFS[r].items() if e[1]}
+        assert pinned, "the capture must have pinned its record storage"
+        for w, want in ((w2, e2), (w1, e1)):
+            assert torch.equal(gc(w), want)
+            assert torch.equal(both3(), e3)                         # eager, three images: other buffer sizes on the current stream
+            r.invalidate()                                           # drops records and unpinned storage only
+            canary = [torch.full((1 << 22,), float(i), device=DEV) for i in range(8)]      # 128 MB of fresh allocations
+            assert torch.equal(gc(w), want)
+            torch.cuda.synchronize()
+            assert all(float(c.min()) == float(c.max()) == float(i) for i, c in enumerate(canary))
+            del canary
+        now = {k: e[0].data_ptr() for k, e in vr._RECORD_BUFS[r].items() if e[1]}
+        assert all(now.get(k) == v for k, v in pinned.items())
+
+
 def test_replays_of_a_captured_decoder_forward_stay_bit_identical():
     """Round 4: replays of the captured inversion forward came back with a handful of discrete WRONG images, erratically -- the
     hipMemsetAsync that zeroed the decoder's amax block is a memset node in the graph, and those were seen running out of order

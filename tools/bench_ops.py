@@ -56,6 +56,18 @@ with torch.no_grad():
         t = timeit(lambda: op.fused_leaky_relu(a, b))
         by = 8 * a.numel()
         cases.append(dict(op="fused_bias_act (lrelu fwd)", shape=[C, L, L], bytes=by, us=t * 1e6, GBps=by / t / 1e9))
+        # round 5: the half-precision forms (ABI 11 re-templated both ops; algorithmic bytes = 2 per element and direction)
+        xh, ah, bh = x.half(), a.half(), b.half()
+        t = timeit(lambda: op.upfirdn2d(xh, k4, pad=(1, 1)))
+        by = 2 * (xh.numel() + C * L * L)
+        cases.append(dict(op="upfirdn2d blur fp16 (up1,down1,4x4)", shape=[C, L + 1, L + 1], bytes=by, us=t * 1e6, GBps=by / t / 1e9))
+        t = timeit(lambda: op.fused_leaky_relu(ah, bh))
+        by = 4 * ah.numel()
+        cases.append(dict(op="fused_bias_act fp16 (lrelu fwd)", shape=[C, L, L], bytes=by, us=t * 1e6, GBps=by / t / 1e9))
+        r_ = torch.randn(1, C, L, L, device=dev)
+        t = timeit(lambda: op.fused_bias_act(a, None, r_, 3, 1, 0.2, 2 ** 0.5))
+        by = 12 * a.numel()
+        cases.append(dict(op="fused_bias_act (lrelu bwd: grad = 1, ref = output)", shape=[C, L, L], bytes=by, us=t * 1e6, GBps=by / t / 1e9))
         t = timeit(lambda: op.noise_bias_act(a, nz, nw, b))
         by = 8 * a.numel() + 4 * nz.numel()
         cases.append(dict(op="noise_bias_act (noise+bias+lrelu)", shape=[C, L, L], bytes=by, us=t * 1e6, GBps=by / t / 1e9))

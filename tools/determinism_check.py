@@ -41,8 +41,8 @@ def stages():
     out = {"pass1.features": o1['features'].clone(), "pass1.weights": o1['hit_prob'].clone(), "record": rec['buf'].clone()}
     o2 = gl([w1, d1], p1, f1, n1, fa1, input_is_latent=True, randomize_noise=False, local_data_batch={'feats': feats})
     rec = vr._BACKBONE.get(gl.renderer)
-    if vr._FILM_RECORD.get(gl.renderer) is not None:
-        out["film_record"] = vr._FILM_RECORD[gl.renderer].clone()
+    if rec is not None and rec.get('tex_buf') is not None:
+        out["film_record"] = rec['tex_buf'].clone()
     out["pass2.features"] = o2['features'].clone()
     for i in range(2 * len(dec.to_rgbs) + 1):          # packed activations of the decoder (the last one is not stored: fused ToRGB)
         try:
