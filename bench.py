@@ -112,9 +112,14 @@ def finalize(result):
     summary = {"rays_per_s": r.get("value"), "roofline_frac": g("roofline", "frac"), "sustained_median_rays_per_s": g("sustained", "median_rays_per_s"),
                "strict_f32_rays_per_s": r.get("strict_f32_rays_per_s"), "strict_f32_frac": r.get("strict_f32_frac"),
                "inversion_fwd_ms": r.get("inversion_fwd_ms"), "inversion_fwd_graph_ms": r.get("inversion_fwd_graph_ms"),
+               "inversion_fwd_graph_steady_ms": r.get("inversion_fwd_graph_steady_ms"),
                "inversion_fwd_no_reuse_ms": r.get("inversion_fwd_no_reuse_ms"), "c3_images_per_s": g("c3", "images_per_s"),
+               "ranks_joined": r.get("ranks_joined"), "c3_per_rank_images_per_s_min": g("c3", "per_rank_images_per_s_min"),
+               "c3_per_rank_images_per_s_max": g("c3", "per_rank_images_per_s_max"),
+               "train_step_allreduce_busbw_GBps": g("train_step", "allreduce_busbw_GBps"),
+               "train_step_with_allreduce_ms": g("train_step", "step_with_allreduce_ms"),
                "c4_ms_per_pose": g("c4", "sequential", "ms_per_pose"), "train_step_ms": r.get("train_step_ms"),
-               "train_step_full_ms": r.get("train_step_full_ms"), "decoder_packed_fwd_bwd_ms": g("autograd", "decoder_packed_fwd_bwd_ms"),
+               "train_step_full_ms": r.get("train_step_full_ms"), "train_step_batch4_ms_per_sample": r.get("train_step_batch4_ms_per_sample"), "decoder_packed_fwd_bwd_ms": g("autograd", "decoder_packed_fwd_bwd_ms"),
                "decoder_library_fwd_bwd_ms": g("autograd", "decoder_library_fwd_bwd_ms"),
                "train_step_mfma_frac": g("train_step", "roofline", "frac"), "train_step_f32_fallback_ms": r.get("train_step_f32_fallback_ms"), "cpu_rays_per_s": g("cpu_baseline", "value")}
     if isinstance(inv, dict) and isinstance(inv.get("kernels"), list):
@@ -566,10 +571,14 @@ def main():
                 barrier()
                 t0 = time.perf_counter()
                 table = sharded_eval.evaluate_sharded(unit, n_units, rank, world, device=dev)   # one all_gather at the end
+                own3 = time.perf_counter() - t0                    # this rank's own time for its shard (incl. the gather)
                 barrier()
                 e3 = max_over_ranks(time.perf_counter() - t0)
+                n_mine3 = len(range(rank, n_units, world))
+                rate3 = [n / t for n, t in zip(all_ranks(float(n_mine3)), all_ranks(own3))]
             assert tuple(table.shape) == (n_units, 8) and torch.isfinite(table).all()
             result["c3"] = {"images": n_units, "images_per_rank": c3_per_rank, "images_per_s": n_units / e3, "wall_s": e3,
+                            "per_rank_images_per_s_min": min(rate3), "per_rank_images_per_s_max": max(rate3),
                             "ms_per_image_per_gpu": 1e3 * e3 / c3_per_rank, "mean_psnr": float(table[:, 5].mean()),
                             "mean_ssim": float(table[:, 6].mean()),
                             "note": "BASELINE configs[2]: per image pass #1 render + texture head on (64,64,24,301) local features + "
@@ -651,12 +660,16 @@ def main():
                 for _ in range(3):
                     inversion(w1, d1)
                 torch.cuda.synchronize()
+                ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t1 = time.perf_counter()
                 n_inv = 10
+                ev_a.record()
                 for _ in range(n_inv):
                     o = inversion(w1, d1)
+                ev_b.record()
                 torch.cuda.synchronize()
                 result["inversion_fwd_ms"] = 1e3 * (time.perf_counter() - t1) / n_inv
+                result["inversion_fwd_events_ms"] = ev_a.elapsed_time(ev_b) / n_inv
                 if os.environ.get("E3DGE_REUSE_BACKBONE", "1") != "0":
                     # the same forward with pass #2 as a full render launch (what rounds 1-2 measured)
                     os.environ["E3DGE_REUSE_BACKBONE"] = "0"
@@ -760,10 +773,22 @@ def main():
                 img_g = gi(w1, d1)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
+                ev_a.record()
                 for _ in range(n_inv):
                     img_g = gi(w1, d1)
+                ev_b.record()
                 torch.cuda.synchronize()
                 result["inversion_fwd_graph_ms"] = 1e3 * (time.perf_counter() - t1) / n_inv
+                result["inversion_fwd_graph_events_ms"] = ev_a.elapsed_time(ev_b) / n_inv
+                # steady state: 50 back-to-back replays between two events (the 10-iteration wall clock above carries the fixed cost of the
+                # first replay after a synchronize -- the runtime re-arms the graph's ~25 packets before anything runs -- and the two
+                # input copies per call; tools/graph_vs_eager.py)
+                ev_a.record()
+                for _ in range(50):
+                    gi.graph.replay()
+                ev_b.record()
+                torch.cuda.synchronize()
+                result["inversion_fwd_graph_steady_ms"] = ev_a.elapsed_time(ev_b) / 50
                 result["inversion_fwd_graph_max_abs_diff_vs_eager"] = float((img_g - ref_img).abs().max())
                 del gi
             except Exception as exc:
@@ -901,6 +926,26 @@ def main():
                 result["train_step_f32_fallback_ms"] = ms_f32
             except Exception as exc:
                 result["train_step_f32_fallback_ms"] = f"failed: {type(exc).__name__}: {exc}"[:120]
+            # scripts/train/ffhq/stage1.sh trains with batch_size=4 PER GPU; BASELINE configs[4] (bs=8 on 8 GPUs) is one sample per GPU, and at
+            # 64x64x18 one sample is 576 workgroup tiles of 128 points = 2.25 rounds of the 256 CUs, i.e. 3 rounds with the last one a
+            # quarter full.  Four samples are 9 full rounds: the same kernels, per sample (supplement, not the C5 number)
+            try:
+                w5b, _ = syn.synthetic_inputs(4, seed=11 + rank, device=dev)
+                p5b, f5b, n5b, fa5b, _ = generate_camera_params(RES, dev, locations=torch.zeros(4, 2, device=dev))
+
+                def train_step_b4():
+                    s_ = w5b.clone().requires_grad_(True)
+                    o = r5(p5b, f5b, n5b, fa5b, styles=s_, return_eikonal=True, return_surface_eikonal=True)
+                    loss = ((o['gen_thumb_imgs'] ** 2).mean() + ((o['eikonal_term'].norm(dim=-1) - 1) ** 2).mean()
+                            + (o['surface_eikonal_term'] ** 2).mean())
+                    loss.backward()
+                    return s_.grad
+                for _ in range(2):
+                    g4 = train_step_b4()
+                result["train_step_batch4_ms_per_sample"] = wall_ms(train_step_b4, 5) / 4
+                assert torch.isfinite(g4).all()
+            except Exception as exc:                                      # noqa: BLE001
+                result["train_step_batch4_ms_per_sample"] = f"failed: {type(exc).__name__}: {exc}"[:160]
             # the step train_ae.py actually runs for one sample (scripts/train/ffhq/stage1.sh: --full_pipeline): renderer forward with the
             # eikonal terms -> decoder 64^2 -> 1024^2 -> pixel loss on pool_256(gen_imgs) (trainer.py:1017-1031) + the renderer losses,
             # backward through the decoder (d features only: latent and generator frozen) into the renderer, down to the styles

@@ -116,15 +116,22 @@ def test_record_buffers_a_capture_has_seen_survive_eager_renders_of_other_sizes(
         gc = GraphedCall(both, w1)
         pinned = {k: e[0].data_ptr() for k, e in vr._RECORD_BUFS[r].items() if e[1]}
         assert pinned, "the capture must have pinned its record storage"
-        for w, want in ((w2, e2), (w1, e1)):
+        for w, want in ((w2, e2), (w1, e1), (w2, e2)):
             assert torch.equal(gc(w), want)
             assert torch.equal(both3(), e3)                         # eager, three images: other buffer sizes on the current stream
-            r.invalidate()                                           # drops records and unpinned storage only
             canary = [torch.full((1 << 22,), float(i), device=DEV) for i in range(8)]      # 128 MB of fresh allocations
             assert torch.equal(gc(w), want)
             torch.cuda.synchronize()
             assert all(float(c.min()) == float(c.max()) == float(i) for i, c in enumerate(canary))
             del canary
+        # invalidate() drops the records and the UNPINNED storage.  (It also drops the packed weight images the graph reads, so the replay's
+        # VALUES are no longer defined -- a weight update needs a new capture, as documented -- but what the replay WRITES must still land
+        # in storage that is alive: the canaries allocated into the freed memory keep their contents.)
+        r.invalidate()
+        canary = [torch.full((1 << 22,), float(i), device=DEV) for i in range(16)]
+        gc(w1)
+        torch.cuda.synchronize()
+        assert all(float(c.min()) == float(c.max()) == float(i) for i, c in enumerate(canary))
         now = {k: e[0].data_ptr() for k, e in vr._RECORD_BUFS[r].items() if e[1]}
         assert all(now.get(k) == v for k, v in pinned.items())
 

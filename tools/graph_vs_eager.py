@@ -99,6 +99,18 @@ with torch.no_grad():
     res["inversion_forward_ms"] = {"eager": round(t_e, 4), "graph_as_GraphedCall": round(t_g, 4), "bare_replay": round(t_r, 4),
                                    "eager_host_enqueue_ms": round(host, 4)}
 
+    # what bench.py's wall clock sees: n iterations between two synchronizes, per iteration
+    def wall(fn, n):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t) / n
+    res["wall_clock_ms_per_forward"] = {f"{name}_n{n}": round(wall(fn, n), 4) for n in (1, 10, 100)
+                                        for name, fn in (("eager", lambda: inversion(w1, d1)), ("graphed_call", lambda: gi(w1, d1)),
+                                                         ("bare_replay", gi.graph.replay))}
+
     # 3. a slow host: every e3dge launch preceded by a spin
     from e3dge_amd import _lib
     lib = _lib.load()
