@@ -105,21 +105,23 @@ class WsLinear(ctypes.Structure):
     """Mirror of struct E3dgeWsLinear (include/e3dge_hip.h)."""
     _fields_ = [(n, _vp) for n in ("wimg", "x", "amax_in", "bias", "colw", "m", "r1", "r2", "y", "amax_out")] + [("n_rows", _i64)] + [
         (n, _i32) for n in ("ld_x", "off_x", "ld_m", "off_m", "ld_r1", "off_r1", "ld_r2", "off_r2", "ld_y", "off_y", "pre_relu", "post")] + [
-        ("slope", _f32), ("w_fuse", _f32)]
+        ("slope", _f32), ("w_fuse", _f32), ("xmul", _vp), ("amax_xmul", _vp), ("ld_xmul", _i32), ("off_xmul", _i32), ("x_scale", _f32),
+        ("reserved", _i32)]
 
 
-# include/e3dge_hip_experimental.h: present only in -DE3DGE_EXPERIMENTAL builds (tools/build_variant.sh)
-EXPERIMENTAL_SIGNATURES = {"e3dge_ws_chain": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp])}
+# include/e3dge_hip_experimental.h: -DE3DGE_EXPERIMENTAL builds (tools/build_variant.sh) carry two more precision modes; no extra symbols
+EXPERIMENTAL_SIGNATURES = {}
 
 
 def has_experimental():
-    """Was the loaded library built with -DE3DGE_EXPERIMENTAL (modes f16x3_v1 / f16x3_g2, e3dge_ws_chain)?"""
-    return hasattr(load(), "e3dge_ws_chain")
+    """Was the loaded library built with -DE3DGE_EXPERIMENTAL (modes f16x3_v1 / f16x3_g2)?"""
+    return bool(load().e3dge_build_flags() & 1)
 
 
 # name -> (restype, argtypes); every symbol include/e3dge_hip.h declares.
 SIGNATURES = {
     "e3dge_abi_version": (_i32, []),
+    "e3dge_build_flags": (_i32, []),
     "e3dge_last_error": (ctypes.c_char_p, []),
     "e3dge_stream_capture_id": (_i64, [_vp]),
     "e3dge_fused_bias_act": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _f32, _f32, _i64, _i64, _i64, _vp]),

@@ -278,6 +278,13 @@ using namespace e3dge;
 
 extern "C" int e3dge_abi_version(void) { return 12; }
 extern "C" const char* e3dge_last_error(void) { return err_buf(); }
+extern "C" int e3dge_build_flags(void) {
+#ifdef E3DGE_EXPERIMENTAL
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" int64_t e3dge_stream_capture_id(e3dge_stream_t stream) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;

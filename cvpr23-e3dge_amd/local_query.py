@@ -255,6 +255,70 @@ class Fuse_sft_MLP(nn.Module):
         _FUSE_IMAGES[self] = hit
         return hit
 
+    def _images_t(self, device):
+        """Packed images of the TRANSPOSED 256 x 256 blocks (d input = d output @ W is the layer of W^T): built on the first backward."""
+        I = self._images(device)
+        if 'sc2_t' not in I:
+            lib = _lib.load()
+            enc, b_off = self.encode_enc, I['b_off']
+
+            def img_t(w):
+                w = w.detach().t().contiguous()
+                t = torch.empty(lib.e3dge_ws_image_bytes(1), dtype=torch.uint8, device=device)
+                with torch.cuda.device(device):
+                    _lib.check(lib.e3dge_ws_pack(_lib.ptr(t), _lib.ptr(w), 1, _lib.stream_of(w)), "e3dge_ws_pack")
+                return t
+            f0, sc = enc.fc_0.weight, enc.shortcut.weight
+            I.update(sc2_t=img_t(self.scale[2].weight), sh2_t=img_t(self.shift[2].weight), sc1_t=img_t(self.scale[0].weight),
+                     sh1_t=img_t(self.shift[0].weight), f1_t=img_t(enc.fc_1.weight), sa_t=img_t(sc[:, :256]), sb_t=img_t(sc[:, b_off:]),
+                     f0a_t=img_t(f0[:, :256]), f0b_t=img_t(f0[:, b_off:]))
+        return I
+
+    def _fuse_bwd_native(self, g, x, net, s1, t1, scale, am_x, w, b_off, slope, need_x):
+        """The data-gradient chain of sft.py:84-109 + resnetfc.py:49-58 as e3dge_ws_linear launches on the transposed images (round 5):
+        dz1 = (w g . dec) Wsc2 . lrelu'(s1), dz2 = (w g) Wsh2 . lrelu'(t1), de = dz1 Wsc1 + dz2 Wsh1, dnet = de W1 . [net > 0],
+        dx = de Ws + (dnet W0) . [x > 0], dx[dec block] += g (1 + w scale).  Returns (dz1, dz2, de, dnet, dx or None)."""
+        N = g.shape[0]
+        dev = g.device
+        ld = x.shape[1]
+        I = self._images_t(dev)
+        lib = _lib.load()
+        st = _lib.stream_of(g)
+        f32 = dict(device=dev, dtype=torch.float32)
+        dz1, dz2, de, dnet = (torch.empty((N, 256), **f32) for _ in range(4))
+        dx = torch.empty((N, ld), **f32) if need_x else None
+        am = torch.zeros((5, _lib.AMAX_FLOATS), **f32)              # g, dz1, dz2, de, dnet
+
+        def lin(wimg, xin, am_in, y, ld_x=256, ld_y=256, off_y=0, post=0, sl=0.0, r1=None, r1_ld=256, r1_off=0, r2=None, r2_ld=256, r2_off=0,
+                xmul=None, amax_out=None, x_scale=1.0):
+            a = _lib.WsLinear()
+            a.wimg, a.x, a.amax_in, a.y, a.amax_out = _lib.ptr(wimg), _lib.ptr(xin), _lib.ptr(am_in), _lib.ptr(y), _lib.ptr(amax_out)
+            a.r1, a.r2 = _lib.ptr(r1), _lib.ptr(r2)
+            a.n_rows = N
+            a.ld_x, a.off_x, a.ld_y, a.off_y = ld_x, 0, ld_y, off_y
+            a.ld_r1, a.off_r1, a.ld_r2, a.off_r2, a.ld_m, a.off_m = r1_ld, r1_off, r2_ld, r2_off, 1, 0
+            a.post, a.slope, a.w_fuse, a.x_scale = post, sl, w, x_scale
+            if xmul is not None:
+                a.xmul, a.amax_xmul, a.ld_xmul, a.off_xmul = _lib.ptr(xmul), _lib.ptr(am_x), ld, b_off
+            _lib.check(lib.e3dge_ws_linear(ctypes.byref(a), st), "e3dge_ws_linear")
+        with torch.cuda.device(dev):
+            _lib.check(lib.e3dge_amax(_lib.ptr(am[0]), _lib.ptr(g), g.numel(), st), "e3dge_amax")
+            lin(I['sc2_t'], g, am[0], dz1, post=3, sl=slope, r1=s1, xmul=x, x_scale=w, amax_out=am[1])
+            lin(I['sh2_t'], g, am[0], dz2, post=3, sl=slope, r1=t1, x_scale=w, amax_out=am[2])
+            lin(I['sc1_t'], dz1, am[1], de)
+            lin(I['sh1_t'], dz2, am[2], de, r1=de, amax_out=am[3])
+            lin(I['f1_t'], de, am[3], dnet, post=3, sl=0.0, r1=net, amax_out=am[4])
+            if need_x:
+                lin(I['sa_t'], de, am[3], dx, ld_y=ld, off_y=0)
+                lin(I['f0a_t'], dnet, am[4], dx, ld_y=ld, off_y=0, post=3, sl=0.0, r1=x, r1_ld=ld, r1_off=0, r2=dx, r2_ld=ld, r2_off=0)
+                lin(I['sb_t'], de, am[3], dx, ld_y=ld, off_y=b_off, post=4, r1=g, r2=scale)
+                lin(I['f0b_t'], dnet, am[4], dx, ld_y=ld, off_y=b_off, post=3, sl=0.0, r1=x, r1_ld=ld, r1_off=b_off, r2=dx, r2_ld=ld, r2_off=b_off)
+        if need_x and I['has_col']:
+            # the visibility-mask column (one input column of fc_0 and of the shortcut): two matrix-vector products
+            enc = self.encode_enc
+            dx[:, 256] = de @ enc.shortcut.weight.detach()[:, 256] + (dnet @ enc.fc_0.weight.detach()[:, 256]) * (x[:, 256] > 0)
+        return dz1, dz2, de, dnet, dx
+
     def _fuse_native(self, enc_in, w, out, out_off, keep=None):
         """`keep` (a dict): every intermediate gets a buffer of its own and is left there for _FuseFn.backward --
         net (fc_0's output), e (the block's output), s1 / t1 (the SFT branches' hidden activations), scale (the scale branch)."""
@@ -308,14 +372,15 @@ class Fuse_sft_MLP(nn.Module):
             lin(I['sh1'], E, 256, 0, am[2], T1, bias=I['bsh1'], post=1, amax_out=am[4])
             lin(I['sh2'], T1, 256, 0, am[4], o2, ld_y=o2.shape[-1], off_y=out_off, bias=I['bsh2'], r1=x, r1_ld=ld, r1_off=b_off, r2=C, post=2)
         if keep is not None:
-            keep.update(x=x, net=NET, e=E, s1=S1, t1=T1, scale=C, b_off=b_off, slope=I['slope'])
+            keep.update(x=x, net=NET, e=E, s1=S1, t1=T1, scale=C, b_off=b_off, slope=I['slope'], am_x=am[0])
         return out[..., out_off:out_off + 256]
 
 
 class _FuseFn(torch.autograd.Function):
-    """Fuse_sft_MLP under autograd: forward = the nine weight-stationary launches of the inference path, keeping
-    net / e / the two hidden SFT activations / the scale branch; backward = the chain rule of sft.py:84-109 + resnetfc.py:49-58
-    written out on those (library GEMMs: d_input, the thirteen parameter gradients).  Not double-differentiable."""
+    """Fuse_sft_MLP under autograd: forward = the nine weight-stationary launches of the inference path, keeping net / e / the two hidden
+    SFT activations / the scale branch; backward = the chain rule of sft.py:84-109 + resnetfc.py:49-58 written out on those -- since
+    round 5 the data-gradient chain is nine more e3dge_ws_linear launches on the transposed weight images (Fuse_sft_MLP._fuse_bwd_native;
+    E3DGE_FUSE_BWD=torch keeps round 4's library GEMMs), the thirteen parameter gradients stay library GEMMs.  Not double-differentiable."""
 
     @staticmethod
     def forward(ctx, mod, enc_in, w, *params):
@@ -323,7 +388,7 @@ class _FuseFn(torch.autograd.Function):
         with torch.no_grad():
             out = mod._fuse_native(enc_in.detach(), w, None, 0, keep=keep)
         ctx.mod, ctx.w, ctx.in_shape = mod, w, enc_in.shape
-        ctx.b_off, ctx.slope = keep['b_off'], keep['slope']
+        ctx.b_off, ctx.slope, ctx.am_x = keep['b_off'], keep['slope'], keep['am_x']
         ctx.save_for_backward(keep['x'], keep['net'], keep['e'], keep['s1'], keep['t1'], keep['scale'], *params)
         return out
 
@@ -335,11 +400,31 @@ class _FuseFn(torch.autograd.Function):
         w, b_off, slope = ctx.w, ctx.b_off, ctx.slope
         need = ctx.needs_input_grad[3:]
         need_x = ctx.needs_input_grad[1]
-        g = grad_out.reshape(-1, 256).float()
+        g = grad_out.reshape(-1, 256).float().contiguous()
         dec = x[:, b_off:]
-        d_scale, d_shift = (w * g) * dec, w * g                   # out = dec + w (dec scale + shift)
         mm = lambda a, b_: a.t() @ b_
         gp = [None] * 13
+        if os.environ.get("E3DGE_FUSE_BWD", "hip") == "hip":
+            # round 5: the data-gradient chain as nine e3dge_ws_linear launches on the transposed weight images; the thirteen parameter
+            # gradients (reductions over the points: library GEMMs with K = number of points) only when a parameter wants one
+            dz1, dz2, de, dnet, dx = ctx.mod._fuse_bwd_native(g, x, net, s1, t1, scale, ctx.am_x, w, b_off, slope, need_x)
+            if any(need):
+                d_scale, d_shift = (w * g) * dec, w * g
+                if need[7]: gp[7] = mm(d_scale, s1)
+                if need[8]: gp[8] = d_scale.sum(0)
+                if need[11]: gp[11] = mm(d_shift, t1)
+                if need[12]: gp[12] = d_shift.sum(0)
+                if need[5]: gp[5] = mm(dz1, e)
+                if need[6]: gp[6] = dz1.sum(0)
+                if need[9]: gp[9] = mm(dz2, e)
+                if need[10]: gp[10] = dz2.sum(0)
+                if need[2]: gp[2] = mm(de, torch.relu(net))
+                if need[3]: gp[3] = de.sum(0)
+                if need[4]: gp[4] = mm(de, x)
+                if need[0]: gp[0] = mm(dnet, torch.relu(x))
+                if need[1]: gp[1] = dnet.sum(0)
+            return (None, dx.reshape(ctx.in_shape) if dx is not None else None, None, *gp)
+        d_scale, d_shift = (w * g) * dec, w * g                   # out = dec + w (dec scale + shift)
         # scale = W2 lrelu(W1 e + b1) + b2 ; shift likewise
         dz1 = (d_scale @ Wsc2) * torch.where(s1 > 0, 1.0, slope)
         dz2 = (d_shift @ Wsh2) * torch.where(t1 > 0, 1.0, slope)

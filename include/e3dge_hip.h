@@ -29,6 +29,8 @@ enum {
 
 /* ABI version; bumped whenever a signature below changes. */
 int e3dge_abi_version(void);
+/* bit 0: built with -DE3DGE_EXPERIMENTAL (the A/B-only precisions of include/e3dge_hip_experimental.h exist) */
+int e3dge_build_flags(void);
 /* 0 when `stream` is not being captured into a HIP graph, otherwise a positive id unique to the capture session (-1: query failed).
  * Host-side caches that hand device buffers from one launch to a later one (the backbone record of E3dgeRenderArgs) use it to
  * keep producer and consumer inside the same capture -- a graph that holds only the consumer would replay against a stale buffer. */
@@ -602,7 +604,7 @@ int e3dge_selftest_mfma16(float* c, const float* a, const float* b, int k, e3dge
 int e3dge_selftest_mfma16x16(float* c, const float* a, const float* b, int k, e3dge_stream_t stream);
 /* Weight-stationary split-f16 layers (csrc/siren_ws.hip): the weights of a 256 x 256 layer live in registers, activations in LDS.
  *   wimg   : e3dge_ws_image_bytes(n_layers) bytes, written by e3dge_ws_pack from fp32 weights (n_layers, 256, 256) [out][in]
- * (The round-3 study chain e3dge_ws_chain -- DESIGN.md 4.1d -- is only in -DE3DGE_EXPERIMENTAL builds: include/e3dge_hip_experimental.h.) */
+ * (The round-3 study chain e3dge_ws_chain -- DESIGN.md 4.1d -- was removed in round 5.) */
 int64_t e3dge_ws_image_bytes(int n_layers);
 int e3dge_ws_pack(void* wimg, const float* weights, int n_layers, e3dge_stream_t stream);
 /* One 256 x 256 linear layer over the rows of a matrix, weight-stationary split-f16 (the layers of Fuse_sft_MLP,
@@ -611,7 +613,12 @@ int e3dge_ws_pack(void* wimg, const float* weights, int n_layers, e3dge_stream_t
  * pre = relu (pre_relu != 0) or identity; post: 0 identity, 1 leaky relu (slope), 2 the SFT fuse  D + w_fuse (D S + v)  with
  * D = r1, S = r2 and v the bracket without r1, r2.  wimg = e3dge_ws_pack(W, 1).  amax_in: amax buffer (E3DGE_AMAX_FLOATS) holding
  * max |x| over the tensor x comes from (operand scale; NULL: values of order 1), amax_out: NULL or the buffer that receives max |y|
- * (zero it first).  Pointers other than wimg, x, y may be NULL (colw and m together); row pitches in floats, any alignment. */
+ * (zero it first).  Pointers other than wimg, x, y may be NULL (colw and m together); row pitches in floats, any alignment.
+ * ABI 12 -- what the BACKWARD of those layers needs (d input = d output @ W is the same layer on the image of W^T):
+ *   input side:  x <- x (.) xmul[row, off_xmul + k] * x_scale  (xmul NULL: x * x_scale; x_scale 0 = unset = 1; amax_xmul = amax buffer of xmul)
+ *   post 3:      y = v * (r1 > 0 ? 1 : slope) + r2     the backward through lrelu (slope) / relu (slope 0) whose output / input is r1
+ *   post 4:      y = v + r1 (1 + w_fuse r2)            d dec of the SFT fuse: v + g (1 + w scale)
+ * y may alias r2 (posts 0, 1, 3) -- every element is read by the thread that writes it. */
 typedef struct E3dgeWsLinear {
     const void* wimg; const float* x; const float* amax_in; const float* bias; const float* colw; const float* m;
     const float* r1; const float* r2; float* y; float* amax_out;
@@ -619,6 +626,10 @@ typedef struct E3dgeWsLinear {
     int32_t ld_x, off_x, ld_m, off_m, ld_r1, off_r1, ld_r2, off_r2, ld_y, off_y;
     int32_t pre_relu, post;
     float slope, w_fuse;
+    const float* xmul; const float* amax_xmul;
+    int32_t ld_xmul, off_xmul;
+    float x_scale;
+    int32_t reserved;
 } E3dgeWsLinear;
 int e3dge_ws_linear(const E3dgeWsLinear* args, e3dge_stream_t stream);
 /* Accuracy self-test of the kernel's sine: y[i] = sin(x[i]) with the device routine the SIREN layers use. */

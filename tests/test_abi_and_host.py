@@ -207,8 +207,6 @@ int main(void) {
     assert lib.e3dge_ws_linear(ctypes.byref(W(wimg=one, x=one, y=one, n_rows=4, ld_x=256, ld_y=256, colw=one)), None) == -1  # colw without m
     assert lib.e3dge_ws_linear(ctypes.byref(W(wimg=one, x=one, y=one, n_rows=0, ld_x=256, ld_y=256)), None) == 0          # nothing to do
     assert lib.e3dge_ws_pack(None, None, 1, None) == -1
-    if _lib.has_experimental():
-        assert lib.e3dge_ws_chain(None, None, None, None, 1, 128, 0, None, None) == -1
 
 
 def test_host_helpers_that_need_no_gpu(lib):
