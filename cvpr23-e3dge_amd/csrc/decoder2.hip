@@ -241,10 +241,22 @@ struct PkConvK {
 // d x = acc 2^-s (+ ToRGB^T d rgb) ; d pre = lrelu'(forward activation) d x sqrt 2 (fused_bias_act grad = 1: (g alpha) scale for a
 // non-positive reference, op/fused_act.py:19-50 of the reference) -> f16 hi/lo split, packed store, max |.| tracked.  FINAL: the plain
 // fp32 (B, Co, H, W) store of d features.  Lane (half, col) holds rows 8 g4 + 4 half + j of the tile for pixel column col.
+// The sign words of the tile's four channel groups (the lane's 8 bytes of each packed hi entry): requested one step BEFORE the tile's
+// last chunk, so that they have landed by that step's vmcnt(0) + barrier -- loaded inside the epilogue they waited for a cold line AND
+// (vmcnt retires in order) for every LDS-DMA piece of the next step issued since.
+__device__ __forceinline__ void bwd_mask_load(const PkConvK& a, int b, int cot, int oy, int ox, int half, uint2 (&mw)[4]) {
+    const int WP = a.W + 2, GO = a.Co >> 3;
+    const int64_t plane_b = (int64_t)(a.H + 2) * WP * 16;
+    // (branch-free: clamped into the image; a load inside a divergent `if` gets a wait of its own)
+    const int64_t em = ((int64_t)(b * GO + cot * 4) * 2) * plane_b + ((int64_t)(min(oy, a.H - 1) + 1) * WP + min(ox, a.W - 1) + 1) * 16 + half * 8;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) mw[g4] = *reinterpret_cast<const uint2*>(a.mask_act + em + (int64_t)g4 * 2 * plane_b);
+}
+
 template <bool FINAL>
 __device__ __forceinline__ void bwd_tile_epilogue(const PkConvK& a, const f32x16& d, int b, int cot, int oy, int ox, int half,
-                                                  const float* rgb_tab, int tab_stride, int tab_co0, const float (&dr)[3], float oscale,
-                                                  float sc_out, float& amax_l) {
+                                                  const float* rgb_tab, int tab_stride, int tab_co0, const float (&dr)[3], const uint2 (&mw)[4],
+                                                  float oscale, float sc_out, float& amax_l) {
     const bool ok = oy < a.H && ox < a.W;
     if (FINAL) {
         if (ok) {
@@ -258,11 +270,6 @@ __device__ __forceinline__ void bwd_tile_epilogue(const PkConvK& a, const f32x16
     const int WP = a.W + 2, GO = a.Co >> 3;
     const int64_t plane_b = (int64_t)(a.H + 2) * WP * 16;
     const int64_t grp = ((int64_t)(b * GO + cot * 4) * 2) * plane_b;
-    // (branch-free: clamped into the image; a load inside a divergent `if` gets a wait of its own)
-    const int64_t em = grp + ((int64_t)(min(oy, a.H - 1) + 1) * WP + min(ox, a.W - 1) + 1) * 16 + half * 8;
-    uint2 mw[4];
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) mw[g4] = *reinterpret_cast<const uint2*>(a.mask_act + em + (int64_t)g4 * 2 * plane_b);
     const float gmul = a.act_scale * sc_out;
     float m = 0.0f;
 #pragma unroll
@@ -487,21 +494,43 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
     const int prow0 = wy * NPY, pcol0 = wx * NPX * 32 + col;
     const float kmul = RGB == 1 ? a.act_scale : a.act_scale * sc_out;      // lrelu(t) * act_scale * 2^k == (lrelu(t) * act_scale) * 2^k exactly
     const float kinv = RGB == 1 ? 1.0f : 1.0f / sc_out;                    // (RGB = 2: the ToRGB sums carry 2^k too and shed it, exactly, at the end)
-    // (BWD) the whole tile's epilogue, straight from the accumulators
-    auto epi_bwd = [&]() {
+    // (BWD) the tile's sign words and d rgb values: requested at the top of the step BEFORE the last chunk's, pinned at the top of the last
+    // chunk's step (everything has landed behind that step's vmcnt(0)); then the whole tile's epilogue, straight from the accumulators
+    uint2 mwp[BWD == 1 ? NCT * NPT : 1][4];
+    float drp[BWD == 1 ? NPT : 1][3];
+    auto bwd_prefetch = [&]() {
 #pragma unroll
         for (int pt = 0; pt < NPT; ++pt) {
             const int oy = p_cur.ty * TH + prow0 + pt / NPX, ox = p_cur.tx * TW + pcol0 + 32 * (pt % NPX);
-            float dr[3] = {0.0f, 0.0f, 0.0f};
-            if (BWD == 1 && a.rgbt_d) {
+            drp[pt][0] = drp[pt][1] = drp[pt][2] = 0.0f;
+            if (a.rgbt_d) {
                 const float* dp = a.rgbt_d + (int64_t)p_cur.b * 3 * a.H * a.W + (unsigned)(min(oy, a.H - 1) * a.W + min(ox, a.W - 1));
 #pragma unroll
-                for (int c = 0; c < 3; ++c) dr[c] = dp[(int64_t)c * a.H * a.W];
+                for (int c = 0; c < 3; ++c) drp[pt][c] = dp[(int64_t)c * a.H * a.W];
             }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) bwd_mask_load(a, p_cur.b, p_cur.cb * NCTB + wco * NCT + ct, oy, ox, half, mwp[ct * NPT + pt]);
+        }
+    };
+    auto bwd_pin = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCT * NPT; ++i)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(mwp[i][g4].x), "+v"(mwp[i][g4].y));
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) asm volatile("" : "+v"(drp[pt][0]), "+v"(drp[pt][1]), "+v"(drp[pt][2]));
+    };
+    auto epi_bwd = [&]() {
+        const uint2 none[4] = {};
+        const float zero3[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+            const int oy = p_cur.ty * TH + prow0 + pt / NPX, ox = p_cur.tx * TW + pcol0 + 32 * (pt % NPX);
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
                 bwd_tile_epilogue<BWD == 2>(a, acc[ct][pt], p_cur.b, p_cur.cb * NCTB + wco * NCT + ct, oy, ox, half,
-                                            (BWD == 1 && a.rgbt_d) ? tab + a.Co : nullptr, a.Co, 0, dr, oscale, sc_out, amax_l);
+                                            (BWD == 1 && a.rgbt_d) ? tab + a.Co : nullptr, a.Co, 0, BWD == 1 ? drp[pt] : zero3,
+                                            BWD == 1 ? mwp[ct * NPT + pt] : none, oscale, sc_out, amax_l);
         }
     };
     PK_T_INIT;
@@ -607,6 +636,10 @@ __global__ void __launch_bounds__(64 * WCO * WY * WX) pkconv_s1_kernel(const PkC
         const Src src_nx = src_of(p_nx1);                // (past the last step: unused)
         const uint32_t xl_nx = stage_lds(cur ^ 1);
         const bool do_epi = pending;                     // (a tile's epilogue runs in the step after its last chunk)
+        if (BWD == 1) {                                  // (host: n_chunks >= 2)
+            if (p_cur.c == a.n_chunks - 2) bwd_prefetch();
+            if (last_chunk) bwd_pin();
+        }
         if (p_cur.c == 0) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
@@ -1861,7 +1894,7 @@ static int launch_s1(PkConvK k, hipStream_t st, const char* what) {
     k.co_blocks = k.Co / (32 * NCTB);
     E3DGE_REQUIRE(!RGB || (k.co_blocks == 1 && k.n_chunks >= 2 && k.rgb_wm && k.rgb_bias && k.rgb_out), "%s: fused ToRGB needs one co-block and >= 32 input channels", what);
     E3DGE_REQUIRE(RGB != 2 || (k.y && k.out_meta), "%s: the store + ToRGB form needs the output activation", what);
-    E3DGE_REQUIRE(BWD != 1 || (k.y && k.out_meta && k.mask_act && k.bwd_wl1 && k.in_amax), "%s: data-gradient launch: missing pointer", what);
+    E3DGE_REQUIRE(BWD != 1 || (k.y && k.out_meta && k.mask_act && k.bwd_wl1 && k.in_amax && k.n_chunks >= 2), "%s: data-gradient launch: missing pointer, or fewer than 32 input channels", what);
     E3DGE_REQUIRE(BWD != 1 || !k.rgbt_d || (k.rgb_wm && k.rgbt_amax && k.rgbt_l1 && k.n_chunks >= 2), "%s: ToRGB^T needs its table, amax, norm and >= 32 input channels", what);
     E3DGE_REQUIRE(BWD != 2 || k.out_f32, "%s: the last data-gradient launch needs out_f32", what);
     const int64_t n_tiles = (int64_t)k.B * k.co_blocks * k.tiles_y * k.tiles_x;

@@ -354,6 +354,8 @@ __global__ void __launch_bounds__(256) pkconv_down_kernel(const PkConvK a) {
     issue(src_of(p_cur), stage_lds(0), 0, NSLOT);
 
     f32x16 acc[NCT];
+    uint2 mwp[NCT][4];
+    float drp[3] = {0.0f, 0.0f, 0.0f};
     float amax_l = 0.0f;
     int b_tab = -1, cb_tab = -1;
     for (int step = 0; step < nsteps; ++step) {
@@ -362,6 +364,25 @@ __global__ void __launch_bounds__(256) pkconv_down_kernel(const PkConvK a) {
         const bool has_next = step + 1 < nsteps, last_chunk = p_cur.c == a.n_chunks - 1;
         const Src src_nx = src_of(p_nx1);
         const uint32_t xl_nx = stage_lds(cur ^ 1);
+        // the tile's sign words / d rgb values: requested one step before its last chunk, pinned behind that chunk's barrier (see bwd_mask_load)
+        if (p_cur.c == a.n_chunks - 2) {
+            const int oy = p_cur.ty * TH + wave, ox = p_cur.tx * TW + col;
+            drp[0] = drp[1] = drp[2] = 0.0f;
+            if (a.rgbt_d) {
+                const float* dp = a.rgbt_d + (int64_t)p_cur.b * 3 * a.H * a.W + (unsigned)(min(oy, a.H - 1) * a.W + min(ox, a.W - 1));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) drp[c] = dp[(int64_t)c * a.H * a.W];
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) bwd_mask_load(a, p_cur.b, p_cur.cb * NCT + ct, oy, ox, half, mwp[ct]);
+        }
+        if (last_chunk) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) asm volatile("" : "+v"(mwp[ct][g4].x), "+v"(mwp[ct][g4].y));
+            asm volatile("" : "+v"(drp[0]), "+v"(drp[1]), "+v"(drp[2]));
+        }
         if (p_cur.c == 0) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) acc[ct] = zero16();
@@ -401,16 +422,10 @@ __global__ void __launch_bounds__(256) pkconv_down_kernel(const PkConvK a) {
         }
         if (last_chunk) {
             const int oy = p_cur.ty * TH + wave, ox = p_cur.tx * TW + col;
-            float dr[3] = {0.0f, 0.0f, 0.0f};
-            if (a.rgbt_d) {
-                const float* dp = a.rgbt_d + (int64_t)p_cur.b * 3 * a.H * a.W + (unsigned)(min(oy, a.H - 1) * a.W + min(ox, a.W - 1));
-#pragma unroll
-                for (int c = 0; c < 3; ++c) dr[c] = dp[(int64_t)c * a.H * a.W];
-            }
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
                 bwd_tile_epilogue<false>(a, acc[ct], p_cur.b, p_cur.cb * NCT + ct, oy, ox, half, a.rgbt_d ? tab : nullptr, 32 * NCT,
-                                         p_cur.cb * 32 * NCT, dr, oscale, sc_out, amax_l);
+                                         p_cur.cb * 32 * NCT, drp, mwp[ct], oscale, sc_out, amax_l);
         }
         p_cur = p_nx1;
         advance(p_nx1);

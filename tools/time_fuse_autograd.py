@@ -41,4 +41,11 @@ res = {}
 for mode in ("hip", "torch"):
     os.environ["E3DGE_FUSE_AUTOGRAD"] = mode
     res[mode] = {"node": type(step(True).grad_fn).__name__, "fwd_ms": round(ms(lambda: step(True)), 3), "fwd_bwd_ms": round(ms(lambda: step(False)), 3)}
+# round 5: parameters frozen (bench.py's shape: the data gradient only), native backward chain vs round 4's library GEMMs
+m.requires_grad_(False)
+os.environ["E3DGE_FUSE_AUTOGRAD"] = "hip"
+for bwd in ("hip", "torch"):
+    os.environ["E3DGE_FUSE_BWD"] = bwd
+    res["frozen_bwd_" + bwd] = {"fwd_bwd_ms": round(ms(lambda: step(False)), 3)}
+os.environ.pop("E3DGE_FUSE_BWD", None)
 print(json.dumps({"what": "Fuse_sft_MLP under autograd, 98,304 points (times include the clone of the input)", **res}))
