@@ -772,6 +772,15 @@ def main():
                 gi = GraphedCall(lambda a, b: inversion(a, b)['gen_imgs'], w1, d1)
                 img_g = gi(w1, d1)
                 torch.cuda.synchronize()
+                # the first replays of a freshly instantiated graph are slower than the rest (tools/graph_vs_eager.py: blocks of ten replays
+                # right after the capture); rounds 3-4 timed exactly those -- which is where "a replay slower than 21 eager launches" came from
+                e_c0, e_c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e_c0.record()
+                for _ in range(n_inv):
+                    gi(w1, d1)
+                e_c1.record()
+                torch.cuda.synchronize()
+                result["inversion_fwd_graph_first10_ms"] = e_c0.elapsed_time(e_c1) / n_inv
                 t1 = time.perf_counter()
                 ev_a.record()
                 for _ in range(n_inv):

@@ -86,6 +86,17 @@ def inversion(w_r, w_d):
 
 with torch.no_grad():
     gi = GraphedCall(inversion, w1, d1)
+    # blocks of ten replays straight after the capture (no warm-up): is a fresh graph slower at first?
+    blocks = []
+    for _ in range(5):
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_.record()
+        for _ in range(10):
+            gi(w1, d1)
+        b_.record()
+        torch.cuda.synchronize()
+        blocks.append(round(a_.elapsed_time(b_) / 10, 4))
+    res["graphed_call_ms_in_blocks_of_10_after_capture"] = blocks
     t_e = ev_ms(lambda: inversion(w1, d1))
     t_g = ev_ms(lambda: gi(w1, d1))
     t_r = ev_ms(gi.graph.replay)
