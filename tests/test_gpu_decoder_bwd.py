@@ -40,6 +40,19 @@ def rel_l2(a, b):
     return float((a - b).norm() / b.norm())
 
 
+def _bound_looseness(dec, batch, res=64):
+    """bound / measured maximum of every packed gradient tensor of the last backward: meta = biased exponent of the a-priori bound the
+    tensor was scaled by (the bound lies in [2^(eb-127), 2^(eb-126))), amax = the maximum its producer measured."""
+    st = dec._dec2_state(batch, res, torch.device(DEV))['bwd']
+    meta = st['meta'].cpu().numpy().astype(np.int64)
+    amax = st['amax'].cpu().numpy().reshape(st['amax'].shape[0], -1).max(1)
+    n_up = len(dec.to_rgbs)
+    loose = [2.0 ** (int(meta[i]) - 126) / float(amax[n_up + 1 + i]) for i in range(n_up + 1)]                       # G2 of levels -1 .. n_up - 1
+    loose += [2.0 ** (int(meta[n_up + 1 + u]) - 126) / float(amax[2 * n_up + 2 + u]) for u in range(n_up)]           # G1
+    loose += [2.0 ** (int(meta[2 * n_up + 1 + u]) - 126) / float(amax[3 * n_up + 2 + u]) for u in range(n_up)]       # P
+    return loose
+
+
 @pytest.fixture(scope="module")
 def gen256():
     g, sd = full_state_dict(size=256, cm=1, res=64, n_samples=24)
@@ -140,7 +153,11 @@ def test_every_packed_gradient_against_autograd_of_the_oracle(gen256):
     errs["d_features_max"] = rel_max(d_f, f.grad)
     errs["img"] = float((img - skip.detach()).abs().max())
     errs["activations_whose_sign_differs_from_the_oracles"] = n_flip
+    loose = _bound_looseness(dec, B)
+    errs["bound_over_measured_max_log2_min"] = float(np.log2(min(loose)))
+    errs["bound_over_measured_max_log2_max"] = float(np.log2(max(loose)))
     record("dec2_bwd_stages_256", **errs)
+    assert min(loose) >= 1.0 and max(loose) <= 2.0 ** 12, loose           # a bound, and not looser than the split tolerates
     assert errs["img"] <= 1e-4
     assert all(v <= 1e-4 for k, v in errs.items() if k.endswith("_l2") or k.endswith("_max")), errs
 
@@ -230,9 +247,12 @@ def test_d_features_full_size_1024_against_float64_autograd():
         return out.detach(), gr
     img64, g64 = oracle(torch.float64)
     _, g32 = oracle(torch.float32)
+    loose = _bound_looseness(dec, 1)
     e = dict(img=float((img.double().cpu() - img64).abs().max()), l2=rel_l2(d_f, g64), max=rel_max(d_f, g64),
-             oracle32_l2=rel_l2(g32, g64), oracle32_max=rel_max(g32, g64))
+             oracle32_l2=rel_l2(g32, g64), oracle32_max=rel_max(g32, g64),
+             bound_over_measured_max_log2_min=float(np.log2(min(loose))), bound_over_measured_max_log2_max=float(np.log2(max(loose))))
     record("dec2_bwd_1024_vs_f64", **e)
+    assert min(loose) >= 1.0 and max(loose) <= 2.0 ** 12, loose
     assert e["img"] <= 1e-4
     assert e["l2"] <= REL_TOL, e
     assert e["max"] <= max(REL_TOL, 3 * e["oracle32_max"]), e
