@@ -121,6 +121,7 @@ def finalize(result):
                "c4_ms_per_pose": g("c4", "sequential", "ms_per_pose"), "train_step_ms": r.get("train_step_ms"),
                "train_step_full_ms": r.get("train_step_full_ms"), "train_step_batch4_ms_per_sample": r.get("train_step_batch4_ms_per_sample"), "decoder_packed_fwd_bwd_ms": g("autograd", "decoder_packed_fwd_bwd_ms"),
                "decoder_library_fwd_bwd_ms": g("autograd", "decoder_library_fwd_bwd_ms"),
+               "fuse_sft_hip_fwd_bwd_ms": g("autograd", "fuse_sft_hip_fwd_bwd_ms"), "tex_head_fwd_bwd_ms": g("autograd", "tex_head_fwd_bwd_ms"),
                "train_step_mfma_frac": g("train_step", "roofline", "frac"), "train_step_f32_fallback_ms": r.get("train_step_f32_fallback_ms"), "cpu_rays_per_s": g("cpu_baseline", "value")}
     if isinstance(inv, dict) and isinstance(inv.get("kernels"), list):
         dec = sum(k[1] for k in inv["kernels"] if k[0].startswith("decoder:"))
@@ -760,6 +761,19 @@ def main():
                         ag["fuse_sft_" + be + "_fwd_bwd_ms"] = ev_fb(fb2)
                     finally:
                         os.environ.pop("E3DGE_FUSE_AUTOGRAD", None)
+                try:        # the texture head (ResnetBlockFC 301 -> 512 on 98,304 points) under autograd: native forward, library backward
+                    head_ = gl.renderer.network.netLocal.local_feat_to_tex_modulations_linear
+                    f_h = feats.detach().clone()
+
+                    def fb3():
+                        x_ = f_h.clone().requires_grad_(True)
+                        al_, be_ = head_.tex_modulations(x_)
+                        (al_.square().mean() + be_.square().mean()).backward()
+                    ag["tex_head_fwd_bwd_ms"] = ev_fb(fb3)
+                    with torch.no_grad():
+                        ag["tex_head_fwd_ms"] = ev_fb(lambda: head_.tex_modulations(f_h))
+                except Exception as exc:                                  # noqa: BLE001
+                    ag["tex_head_fwd_bwd_ms"] = f"failed: {type(exc).__name__}: {exc}"[:160]
                 ag["note"] = ("forward + backward with a graph: decoder in the stage-1 shape (features require grad, latent + parameters frozen, loss on "
                               "pool_256(image)): packed = e3dge_dec2_forward + e3dge_dec2_backward, library = weight modulation + MIOpen; Fuse_sft_MLP: "
                               "native-forward autograd node vs torch modules")

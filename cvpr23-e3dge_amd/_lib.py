@@ -182,6 +182,7 @@ SIGNATURES = {
     "e3dge_ws_image_bytes": (_i64, [_i32]),
     "e3dge_ws_pack": (_i32, [_vp, _vp, _i32, _vp]),
     "e3dge_ws_linear": (_i32, [ctypes.POINTER(WsLinear), _vp]),
+    "e3dge_ws_rowdot2": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp]),
     "e3dge_selftest_sin": (_i32, [_vp, _vp, _i32, _vp]),
     "e3dge_selftest_sin_poly": (_i32, [_vp, _vp, _i32, _vp]),
 }

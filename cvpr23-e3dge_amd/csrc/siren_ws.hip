@@ -243,6 +243,39 @@ extern "C" int e3dge_ws_pack(void* wimg, const float* weights, int n_layers, e3d
 }
 
 
+namespace e3dge {
+// out[row * ld_out + off_out] = sum_k a[row][k] u[k] + gate(row) * sum_k b[row][k] v[k],  gate = (g[row * ld_g + off_g] > 0) or 1 without g:
+// the data gradient of ONE extra input column of two 256-wide linear layers (the visibility-mask column of Fuse_sft_MLP's 513-wide
+// input: d x[:, 256] = de Ws[:, 256] + (dnet W0[:, 256]) [x[:, 256] > 0]).  One wave per row, 16 B per lane; fixed-order reduction.
+__global__ void __launch_bounds__(256)
+ws_rowdot2_kernel(float* __restrict__ out, int ld_out, int off_out, const float* __restrict__ a, const float* __restrict__ u,
+                  const float* __restrict__ b, const float* __restrict__ v, const float* __restrict__ g, int ld_g, int off_g, int64_t n_rows) {
+    const int lane = threadIdx.x & 63;
+    const f32x4v u4 = *reinterpret_cast<const f32x4v*>(u + 4 * lane), v4 = *reinterpret_cast<const f32x4v*>(v + 4 * lane);
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (int64_t)gridDim.x * 4) {
+        const f32x4v a4 = *reinterpret_cast<const f32x4v*>(a + row * kWidth + 4 * lane), b4 = *reinterpret_cast<const f32x4v*>(b + row * kWidth + 4 * lane);
+        float sa = fmaf(a4[3], u4[3], fmaf(a4[2], u4[2], fmaf(a4[1], u4[1], a4[0] * u4[0])));
+        float sb = fmaf(b4[3], v4[3], fmaf(b4[2], v4[2], fmaf(b4[1], v4[1], b4[0] * v4[0])));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { sa += __shfl_xor(sa, off, kWave); sb += __shfl_xor(sb, off, kWave); }
+        if (lane == 0) out[row * ld_out + off_out] = sa + ((!g || g[row * ld_g + off_g] > 0.0f) ? sb : 0.0f);
+    }
+}
+}  // namespace e3dge
+
+extern "C" int e3dge_ws_rowdot2(float* out, int ld_out, int off_out, const float* a, const float* u, const float* b, const float* v,
+                                const float* gate, int ld_gate, int off_gate, int64_t n_rows, e3dge_stream_t stream) {
+    using namespace e3dge;
+    E3DGE_REQUIRE(out && a && u && b && v && n_rows >= 0 && ld_out > off_out && off_out >= 0 && (!gate || (ld_gate > off_gate && off_gate >= 0)),
+                  "ws_rowdot2: bad arguments");
+    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(u) | reinterpret_cast<uintptr_t>(v)) & 15) == 0,
+                  "ws_rowdot2: a, b (n_rows, 256) and u, v (256) must be 16-byte aligned");
+    if (n_rows == 0) return E3DGE_OK;
+    const int64_t blocks = (n_rows + 3) / 4;
+    ws_rowdot2_kernel<<<dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, as_stream(stream)>>>(out, ld_out, off_out, a, u, b, v, gate, ld_gate, off_gate, n_rows);
+    return check_launch("ws_rowdot2");
+}
+
 static_assert(sizeof(E3dgeWsLinear) == sizeof(e3dge::WsLinK), "E3dgeWsLinear mirrors WsLinK");
 
 extern "C" int e3dge_ws_linear(const E3dgeWsLinear* args, e3dge_stream_t stream) {

@@ -313,10 +313,10 @@ class Fuse_sft_MLP(nn.Module):
                 lin(I['f0a_t'], dnet, am[4], dx, ld_y=ld, off_y=0, post=3, sl=0.0, r1=x, r1_ld=ld, r1_off=0, r2=dx, r2_ld=ld, r2_off=0)
                 lin(I['sb_t'], de, am[3], dx, ld_y=ld, off_y=b_off, post=4, r1=g, r2=scale)
                 lin(I['f0b_t'], dnet, am[4], dx, ld_y=ld, off_y=b_off, post=3, sl=0.0, r1=x, r1_ld=ld, r1_off=b_off, r2=dx, r2_ld=ld, r2_off=b_off)
-        if need_x and I['has_col']:
-            # the visibility-mask column (one input column of fc_0 and of the shortcut): two matrix-vector products
-            enc = self.encode_enc
-            dx[:, 256] = de @ enc.shortcut.weight.detach()[:, 256] + (dnet @ enc.fc_0.weight.detach()[:, 256]) * (x[:, 256] > 0)
+            if need_x and I['has_col']:
+                # the visibility-mask column (one input column of fc_0 and of the shortcut): two row dot products in one launch
+                _lib.check(lib.e3dge_ws_rowdot2(_lib.ptr(dx), ld, 256, _lib.ptr(de), _lib.ptr(I['scol']), _lib.ptr(dnet), _lib.ptr(I['f0col']),
+                                                _lib.ptr(x), ld, 256, N, st), "e3dge_ws_rowdot2")
         return dz1, dz2, de, dnet, dx
 
     def _fuse_native(self, enc_in, w, out, out_off, keep=None):

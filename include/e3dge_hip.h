@@ -632,6 +632,11 @@ typedef struct E3dgeWsLinear {
     int32_t reserved;
 } E3dgeWsLinear;
 int e3dge_ws_linear(const E3dgeWsLinear* args, e3dge_stream_t stream);
+/* out[row * ld_out + off_out] = a[row, :] . u + [gate[row * ld_gate + off_gate] > 0] (b[row, :] . v)   (gate NULL: 1); a, b (n_rows, 256), u, v (256).
+ * The data gradient of ONE extra input column shared by two 256-wide layers -- the visibility-mask column of Fuse_sft_MLP's 513-wide input
+ * (sft.py:103-109 / resnetfc.py:49-58: d x[:, 256] = de Ws[:, 256] + (dnet W0[:, 256]) [x[:, 256] > 0]). */
+int e3dge_ws_rowdot2(float* out, int ld_out, int off_out, const float* a, const float* u, const float* b, const float* v, const float* gate,
+                     int ld_gate, int off_gate, int64_t n_rows, e3dge_stream_t stream);
 /* Accuracy self-test of the kernel's sine: y[i] = sin(x[i]) with the device routine the SIREN layers use. */
 int e3dge_selftest_sin(float* y, const float* x, int n, e3dge_stream_t stream);
 /* The alternative 13-op polynomial sine (kernels built with -DE3DGE_POLY_SINE use it). */
