@@ -786,6 +786,7 @@ def main():
                 gi = GraphedCall(lambda a, b: inversion(a, b)['gen_imgs'], w1, d1)
                 img_g = gi(w1, d1)
                 torch.cuda.synchronize()
+                spin(args.prewarm_ms / 2)        # the same clock state as the eager figure above (the autograd leg in between is host-bound: the GPU clocks down)
                 # the first replays of a freshly instantiated graph are slower than the rest (tools/graph_vs_eager.py: blocks of ten replays
                 # right after the capture); rounds 3-4 timed exactly those -- which is where "a replay slower than 21 eager launches" came from
                 e_c0, e_c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -929,8 +930,11 @@ def main():
                     fn()
                 barrier()
                 return 1e3 * max_over_ranks(time.perf_counter() - t0) / n
+            # (the autograd legs above leave a few hundred MB of cached blocks of odd sizes behind; with them the step's 0.7-GB buffers and
+            # the side stream's record_stream-held blocks did not settle within the warm-up on one box: 3.27 instead of 2.53 ms)
+            torch.cuda.empty_cache()
             spin(args.prewarm_ms / 2)
-            for _ in range(3):
+            for _ in range(5):
                 gr = train_step()
             n_tr = 10
             ms = wall_ms(train_step, n_tr)

@@ -97,6 +97,12 @@ with torch.no_grad():
         torch.cuda.synchronize()
         blocks.append(round(a_.elapsed_time(b_) / 10, 4))
     res["graphed_call_ms_in_blocks_of_10_after_capture"] = blocks
+    # clock ramp: the GPU clocks down within ~100 ms of idling and needs as long to come back; every figure below is taken
+    # after 200 ms of the same work, so eager and replay are compared at the same clock
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.2:
+        inversion(w1, d1)
+    torch.cuda.synchronize()
     t_e = ev_ms(lambda: inversion(w1, d1))
     t_g = ev_ms(lambda: gi(w1, d1))
     t_r = ev_ms(gi.graph.replay)
