@@ -977,32 +977,36 @@ def main():
             # eikonal terms -> decoder 64^2 -> 1024^2 -> pixel loss on pool_256(gen_imgs) (trainer.py:1017-1031) + the renderer losses,
             # backward through the decoder (d features only: latent and generator frozen) into the renderer, down to the styles
             try:
-                dec5 = dec_keep
-                if dec5 is None:
-                    g5 = G_pred_latents(syn.model_opt(), syn.rendering_opt(N_samples=S5), full_pipeline=True)
-                    syn.load_synthetic(g5)
-                    dec5 = g5.decoder.to(dev).eval()
-                    dec5.requires_grad_(False)
+                # through the generator's own entry point, as trainer.py:881-897 calls it (renderer -> decoder in one forward)
+                g5 = G_pred_latents(syn.model_opt(), syn.rendering_opt(N_samples=S5), full_pipeline=True)
+                syn.load_synthetic(g5)
+                g5 = g5.to(dev).eval()
+                g5.requires_grad_(False)
                 _, d5 = syn.synthetic_inputs(1, seed=1 + rank, device=dev)
                 pool5 = torch.nn.AdaptiveAvgPool2d((256, 256))
                 full = {}
-                for be, env in (("packed", "auto"), ("library", "library")):
+
+                def train_step_full():
+                    s_ = w5.clone().requires_grad_(True)
+                    o = g5([s_, d5], p5, f5, n5, fa5, input_is_latent=True, randomize_noise=False, return_eikonal=True,
+                           return_surface_eikonal=True)
+                    loss = ((pool5(o['gen_imgs']) ** 2).mean() + (o['gen_thumb_imgs'] ** 2).mean()
+                            + ((o['eikonal_term'].norm(dim=-1) - 1) ** 2).mean() + (o['surface_eikonal_term'] ** 2).mean())
+                    loss.backward()
+                    return s_.grad
+                for be, env, ov in (("packed", "auto", "1"), ("library", "library", "1"), ("packed_no_overlap", "auto", "0")):
                     os.environ["E3DGE_DECODER_AUTOGRAD"] = env
+                    os.environ["E3DGE_OVERLAP_DECODER"] = ov
                     try:
-                        def train_step_full():
-                            s_ = w5.clone().requires_grad_(True)
-                            o = r5(p5, f5, n5, fa5, styles=s_, return_eikonal=True, return_surface_eikonal=True)
-                            img = dec5(o['features'], [d5], input_is_latent=True, randomize_noise=False)[0]
-                            loss = ((pool5(img) ** 2).mean() + (o['gen_thumb_imgs'] ** 2).mean()
-                                    + ((o['eikonal_term'].norm(dim=-1) - 1) ** 2).mean() + (o['surface_eikonal_term'] ** 2).mean())
-                            loss.backward()
-                            return s_.grad
                         for _ in range(3):
                             gf = train_step_full()
                         full[be] = wall_ms(train_step_full, n_tr)
                         assert torch.isfinite(gf).all()
                     finally:
                         os.environ.pop("E3DGE_DECODER_AUTOGRAD", None)
+                        os.environ.pop("E3DGE_OVERLAP_DECODER", None)
+                result["train_step_full_no_overlap_ms"] = full["packed_no_overlap"]
+                del g5
                 result["train_step_full_ms"] = full["packed"]
                 result["train_step_full_library_decoder_ms"] = full["library"]
                 result["train_step_full_note"] = ("one stage-1 sample as train_ae.py runs it (--full_pipeline): C5 renderer step + decoder 64^2 -> 1024^2 forward "

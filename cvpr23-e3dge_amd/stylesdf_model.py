@@ -1140,24 +1140,33 @@ class G_pred_latents(Generator):
             encoder_latent = styles[0]
         renderer_latent = self.styles_and_noise_forward([encoder_latent], inject_index, truncation,
                                                         truncation_latent, input_is_latent)
-        render_out = self.renderer(cam_poses, focals, near, far, styles=renderer_latent[0],
-                                   return_eikonal=return_eikonal, return_mesh=return_mesh,
-                                   mesh_with_shading=mesh_with_shading, sample_mode=sample_mode,
-                                   geometry_sample=geometry_sample, return_surface_eikonal=return_surface_eikonal,
-                                   sample_without_grad=sample_without_grad, **kwargs)
-        render_out['styles'] = renderer_latent[0]
-        if renderer_only:
-            return render_out
-        if (self.full_pipeline or sample_with_decoder) and not sample_with_renderer:
-            if decoder_latent is None:
-                decoder_latent = renderer_latent
-            elif not isinstance(decoder_latent, list):
-                decoder_latent = [decoder_latent]
-            gen_imgs, decoder_latent = self.decoder(
-                render_out['features'], decoder_latent, transform=None, return_latents=return_latents,
-                inject_index=inject_index, truncation=truncation, truncation_latent=truncation_latent, noise=noise,
-                input_is_latent=input_is_latent, randomize_noise=randomize_noise, mesh_path=mesh_path,
-                conditions=conditions)
-            render_out['gen_imgs'] = gen_imgs
-            render_out['decoder_latent'] = decoder_latent
+        will_decode = (not renderer_only) and (self.full_pipeline or sample_with_decoder) and not sample_with_renderer
+        # the stage-1 step (trainer.py:881-897 with return_eikonal): the eikonal chains of the renderer do not feed the decoder, so they may run
+        # beside its forward / backward on a side stream (volume_renderer.begin_deferred / finish_deferred)
+        deferred = will_decode and return_eikonal and torch.is_grad_enabled() and not sample_without_grad and \
+            hasattr(self.renderer, 'begin_deferred') and self.renderer.begin_deferred()
+        try:
+            render_out = self.renderer(cam_poses, focals, near, far, styles=renderer_latent[0],
+                                       return_eikonal=return_eikonal, return_mesh=return_mesh,
+                                       mesh_with_shading=mesh_with_shading, sample_mode=sample_mode,
+                                       geometry_sample=geometry_sample, return_surface_eikonal=return_surface_eikonal,
+                                       sample_without_grad=sample_without_grad, **kwargs)
+            render_out['styles'] = renderer_latent[0]
+            if renderer_only:
+                return render_out
+            if will_decode:
+                if decoder_latent is None:
+                    decoder_latent = renderer_latent
+                elif not isinstance(decoder_latent, list):
+                    decoder_latent = [decoder_latent]
+                gen_imgs, decoder_latent = self.decoder(
+                    render_out['features'], decoder_latent, transform=None, return_latents=return_latents,
+                    inject_index=inject_index, truncation=truncation, truncation_latent=truncation_latent, noise=noise,
+                    input_is_latent=input_is_latent, randomize_noise=randomize_noise, mesh_path=mesh_path,
+                    conditions=conditions)
+                render_out['gen_imgs'] = gen_imgs
+                render_out['decoder_latent'] = decoder_latent
+        finally:
+            if deferred:
+                self.renderer.finish_deferred(render_out if 'render_out' in locals() else {})
         return render_out

@@ -105,12 +105,20 @@ _BACKBONE = weakref.WeakKeyDictionary()                                # rendere
 _SIDE_STREAMS = {}                                                     # per device (module level: modules stay deep-copyable)
 
 
-def _side_stream(dev):
-    key = str(dev)
+def _side_stream(dev, idx=0):
+    key = (str(dev), idx)
     st = _SIDE_STREAMS.get(key)
     if st is None:
         st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
     return st
+
+
+# Round 5: when the generator runs the decoder behind the renderer under grad (train_ae.py's stage-1 step, --full_pipeline), the ray
+# samples' sdf chain (forward) and their tangent pass (backward) do not feed the decoder: they go to a second side stream and run BESIDE
+# the decoder's forward / backward, and the launch stream waits for them only when the generator hands its outputs over / when the
+# render node's backward needs the tangent.  E3DGE_OVERLAP_DECODER=0 keeps everything on the launch stream.
+def _overlap_decoder():
+    return os.environ.get("E3DGE_OVERLAP_DECODER", "1") != "0"
 
 
 # backward-type launches additionally know the experimental 8-wave layout (E3DGE_PREC_F16X3_G2; tools/bwd_ab.py)
@@ -507,10 +515,11 @@ _AUX_KEYS = ('mask', 'points', 'rays_d', 'viewdirs', 'dists')
 
 class _EikShared:
     """What the eikonal tap below and _RenderQuery.backward share: the tangent arguments of the incoming d(eikonal term)."""
-    __slots__ = ("siren", "film", "args", "box_scale", "tang", "d_eik", "images")
+    __slots__ = ("siren", "film", "args", "box_scale", "tang", "d_eik", "images", "side", "tang_stream")
 
     def __init__(self):
         self.siren = self.film = self.args = self.box_scale = self.tang = self.d_eik = self.images = None
+        self.side = self.tang_stream = None          # (deferred mode: the stream the chain ran on / the tangent runs on)
 
 
 class _EikTap(torch.autograd.Function):
@@ -529,7 +538,18 @@ class _EikTap(torch.autograd.Function):
         sh = ctx.shared
         if d_eik is not None and sh.args is not None:
             sh.d_eik = d_eik
-            sh.tang = tangent_arguments(sh.siren, sh.film, sh.args, d_eik, sh.box_scale, sh.images)
+            if sh.side is not None:
+                # deferred mode: this node was created AFTER the decoder's, so its backward runs BEFORE the decoder's; the tangent goes to the
+                # side stream and the decoder's backward launches that follow on this stream run beside it
+                cur = torch.cuda.current_stream(d_eik.device)
+                sh.side.wait_stream(cur)
+                with torch.cuda.stream(sh.side):
+                    sh.tang = tangent_arguments(sh.siren, sh.film, sh.args, d_eik, sh.box_scale, sh.images)
+                d_eik.record_stream(sh.side)
+                sh.tang.record_stream(cur)
+                sh.tang_stream = sh.side
+            else:
+                sh.tang = tangent_arguments(sh.siren, sh.film, sh.args, d_eik, sh.box_scale, sh.images)
         return d_eik, None
 
 
@@ -547,7 +567,10 @@ class _RenderQuery(torch.autograd.Function):
         if not want_eik:
             out['eikonal_term'] = None
         elif out['eikonal_term'].requires_grad:
-            out['eikonal_term'] = _EikTap.apply(out['eikonal_term'], shared)
+            if shared.side is not None:
+                renderer._deferred_tap = shared          # finish_deferred() applies the tap behind the decoder's forward
+            else:
+                out['eikonal_term'] = _EikTap.apply(out['eikonal_term'], shared)
         return renderer._render_dict(out, c2w, near, far)
 
     @staticmethod
@@ -564,7 +587,19 @@ class _RenderQuery(torch.autograd.Function):
         # only, not on the sdf chain below, and runs beside it on a side stream
         renderer._render_done = torch.cuda.Event()
         renderer._render_done.record(torch.cuda.current_stream(c2w.device))
-        if want_eik:
+        if want_eik and shared is not None and getattr(renderer, '_defer_sync', False) and B > 0:
+            # the sdf chain beside whatever the caller launches next on this stream (the decoder's forward): second side stream
+            cur = torch.cuda.current_stream(c2w.device)
+            side2 = _side_stream(c2w.device, 1)
+            side2.wait_event(renderer._render_done)
+            with torch.cuda.stream(side2):
+                eik, rsave = sdf_gradient(renderer.siren, film, args, renderer.box_scale)
+            args.record_stream(side2); film.record_stream(side2)
+            eik.record_stream(cur); rsave.record_stream(cur)
+            shared.side = side2
+            renderer._pending_sync.append(side2)
+            out['eikonal_term'] = eik.reshape(B, H, H, S, 3)
+        elif want_eik:
             eik, rsave = sdf_gradient(renderer.siren, film, args, renderer.box_scale)
             out['eikonal_term'] = eik.reshape(B, H, H, S, 3)
         else:
@@ -611,10 +646,12 @@ class _RenderQuery(torch.autograd.Function):
             if (sh is not None and sh.tang is not None and sh.d_eik.data_ptr() == d_eik.data_ptr()
                     and sh.d_eik.shape == d_eik.shape):                     # launched early by _EikTap.backward
                 tang = sh.tang
+                if sh.tang_stream is not None:                              # (deferred mode: it ran on the side stream)
+                    torch.cuda.current_stream(dev).wait_stream(sh.tang_stream)
             else:
                 tang = tangent_arguments(siren, film, args, d_eik, r.box_scale, ctx.images)
             if sh is not None:
-                sh.tang = sh.d_eik = sh.args = sh.film = sh.images = None
+                sh.tang = sh.d_eik = sh.args = sh.film = sh.images = sh.tang_stream = None
             rs = rsave
         d_ta = d_tb = tex_a = None
         if ctx.has_tex:
@@ -1105,6 +1142,28 @@ class VolumeFeatureRenderer(nn.Module):
         self._sb_key = None
         return super().train(mode)
 
+    # ---- deferred synchronisation (the generator runs the decoder between begin_deferred() and finish_deferred()) ------------------------
+    def begin_deferred(self):
+        """The next forward may leave its side-stream work (sdf chain of the ray samples, surface-normal query) un-joined: the caller
+        promises to call finish_deferred(render_out) before anybody reads 'eikonal_term' / 'surface_eikonal_term'."""
+        self._defer_sync = bool(_overlap_decoder() and _SIDE_STREAM)
+        self._pending_sync = []
+        self._deferred_tap = None
+        return self._defer_sync
+
+    def finish_deferred(self, render_out):
+        """Join the side streams on the current stream and put the tangent tap on the eikonal term (created HERE, behind the decoder's
+        node, so that autograd runs it before the decoder's backward)."""
+        pend, tap = getattr(self, '_pending_sync', None) or [], getattr(self, '_deferred_tap', None)
+        self._defer_sync, self._pending_sync, self._deferred_tap = False, [], None
+        if pend:
+            cur = torch.cuda.current_stream(pend[0].device)
+            for st in pend:
+                cur.wait_stream(st)
+        if tap is not None and render_out.get('eikonal_term', None) is not None:
+            render_out['eikonal_term'] = _EikTap.apply(render_out['eikonal_term'], tap)
+        return render_out
+
     # -------------------------------------------------------------------------------------------------
     def forward(self, cam_poses, focal, near, far, styles=None, return_eikonal=False, geometry_sample=None,
                 return_surface_eikonal=False, local_data_batch=None, sample_mode=False, return_mesh=False,
@@ -1177,7 +1236,10 @@ class VolumeFeatureRenderer(nn.Module):
                 render_out['xyz'].record_stream(side)
                 if torch.is_tensor(styles):
                     styles.record_stream(side)
-                cur.wait_stream(side)
+                if getattr(self, '_defer_sync', False):
+                    self._pending_sync.append(side)          # (finish_deferred() waits, behind the decoder's forward)
+                else:
+                    cur.wait_stream(side)
                 se.record_stream(cur)
                 render_out['surface_eikonal_term'] = se
             else:

@@ -219,6 +219,41 @@ def test_generator_backward_end_to_end(sd):
     assert e['d_decoder_latent'] <= max(REL_TOL, 3 * e['oracle32_d_decoder_latent']), e
 
 
+def test_generator_step_with_the_eikonal_chains_beside_the_decoder_is_bit_identical(sd, monkeypatch):
+    """Round 5: in G_pred_latents.forward under grad with return_eikonal (the stage-1 step, trainer.py:881-897) the ray samples' sdf chain
+    runs on a side stream beside the decoder's forward and their tangent pass beside the decoder's backward
+    (volume_renderer.begin_deferred / finish_deferred; E3DGE_OVERLAP_DECODER=0 keeps the launch stream).  Same kernels, same inputs:
+    every output and the gradient to the styles must be bit-identical in both orders, repeatedly."""
+    from e3dge_amd.camera_utils import generate_camera_params
+    g, _ = full_state_dict(size=64, cm=1, res=16, n_samples=18)
+    g = g.to(DEV).eval()
+    g.requires_grad_(False)
+    wr0, wd0 = syn.synthetic_inputs(2, seed=6, device=DEV)
+    wd0 = wd0[:, :g.decoder.n_latent].contiguous()
+    poses, focal, near, far, _ = generate_camera_params(16, DEV, locations=torch.tensor([[0.2, 0.1], [-0.1, 0.05]], device=DEV))
+
+    def step(overlap):
+        monkeypatch.setenv("E3DGE_OVERLAP_DECODER", overlap)
+        wr = wr0.clone().requires_grad_(True)
+        o = g([wr, wd0], poses, focal, near, far, input_is_latent=True, randomize_noise=False, return_eikonal=True,
+              return_surface_eikonal=True)
+        assert "PackedDecoderFn" in type(o['gen_imgs'].grad_fn).__name__
+        loss = ((o['gen_imgs'] ** 2).mean() + (o['gen_thumb_imgs'] ** 2).mean() + ((o['eikonal_term'].norm(dim=-1) - 1) ** 2).mean()
+                + (o['surface_eikonal_term'] ** 2).mean())
+        loss.backward()
+        torch.cuda.synchronize()
+        return {k: o[k].detach().clone() for k in ('gen_imgs', 'gen_thumb_imgs', 'eikonal_term', 'surface_eikonal_term')}, wr.grad.clone(), loss.detach()
+    base_o, base_g, base_l = step("0")
+    assert torch.isfinite(base_g).all() and float(base_g.abs().max()) > 0
+    for overlap in ("1", "0", "1", "1"):
+        o, gr, l = step(overlap)
+        assert torch.equal(l, base_l)
+        for k in base_o:
+            assert torch.equal(o[k], base_o[k]), (overlap, k)
+        assert torch.equal(gr, base_g), overlap
+    assert not getattr(g.renderer, '_defer_sync', False) and not getattr(g.renderer, '_pending_sync', None)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # eikonal term (a10): value, and the gradient of a loss on it (the reference's create_graph=True double backward)
 # ----------------------------------------------------------------------------------------------------------------
