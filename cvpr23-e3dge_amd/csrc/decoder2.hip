@@ -2355,6 +2355,7 @@ extern "C" int e3dge_dec2_backward(const E3dgeDec2Plan* P, const E3dgeDec2BwdPla
     auto check_bc = [&](const E3dgeDec2Conv& c, const E3dgeDec2BwdConv& q, const char* what) -> int {
         E3DGE_REQUIRE(q.wpre_t && q.wcol && q.wimg_t && c.style && c.demod, "dec2_backward %s: null pointer", what);
         E3DGE_REQUIRE(c.ci % 32 == 0 && c.co % 32 == 0, "dec2_backward %s: needs ci %% 32 == 0 and co %% 32 == 0 (got %d, %d)", what, c.ci, c.co);
+        E3DGE_REQUIRE(what[0] != 'u' || c.ci % 64 == 0, "dec2_backward up: the stride-2 data-gradient kernel owns 64 channels per workgroup (ci = %d)", c.ci);
         return E3DGE_OK;
     };
     int rc = check_bc(P->conv1, Q->conv1, "conv1");
@@ -2487,8 +2488,7 @@ extern "C" int e3dge_dec2_backward(const E3dgeDec2Plan* P, const E3dgeDec2BwdPla
             k.y = reinterpret_cast<unsigned char*>(Q->gact[prev]); k.out_meta = mt_g2(u - 1); k.out_amax = am_g2(u - 1);
             k.mask_act = reinterpret_cast<const unsigned char*>(P->act[prev]); k.bwd_wl1 = Q->bounds + 1 + 2 * u;
             k.rgbt_d = Q->drgb[u]; k.rgb_wm = rgb_of(u - 1).wm; k.rgbt_amax = am_d(u - 1); k.rgbt_l1 = bd_rgb(u - 1);
-            if (k.Co % 64 == 0) DEC2_STEP(launch_down<2>(k, st, "dec2 convT^T<64co,4x32>"));
-            else DEC2_STEP(launch_down<1>(k, st, "dec2 convT^T<32co,4x32>"));
+            DEC2_STEP(launch_down<2>(k, st, "dec2 convT^T<64co,4x32>"));      // (64 output channels per workgroup: check_bc requires up.ci % 64 == 0)
         }
     }
     {   // d features = conv1^T G2[-1]

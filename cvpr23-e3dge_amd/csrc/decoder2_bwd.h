@@ -442,7 +442,7 @@ template <int NCT>
 static int launch_down(PkConvK k, hipStream_t st, const char* what) {
     constexpr int STAGE = 16 * (5 * 33) * 16 + NCT * kPkSlab, lds = 2 * STAGE + 3 * 32 * NCT * 4;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    E3DGE_REQUIRE(k.Co % (32 * NCT) == 0 && k.n_chunks >= 2, "%s: Co=%d not a multiple of %d, or fewer than 32 input channels", what, k.Co, 32 * NCT);
+    E3DGE_REQUIRE(k.Co % (32 * NCT) == 0 && k.n_chunks >= 2, "%s: Co=%d not a multiple of %d, or fewer than 32 input channels", what, k.Co, 32 * NCT);      // (only NCT = 2 is instantiated)
     E3DGE_REQUIRE(k.y && k.out_meta && k.mask_act && k.bwd_wl1 && k.in_amax && (!k.rgbt_d || (k.rgb_wm && k.rgbt_amax && k.rgbt_l1)), "%s: missing pointer", what);
     k.tiles_y = (k.H + 3) / 4;
     k.tiles_x = (k.W + 31) / 32;

@@ -665,10 +665,11 @@ class Decoder(nn.Module):
 
     def _dec2_bwd_ok(self):
         """Can the packed pipeline differentiate itself (e3dge_dec2_backward)?  Every 3x3 layer needs 32-channel multiples on both
-        sides (the transposed weight images swap the roles); E3DGE_DEC2_BWD=library keeps round 4's recomputing backward (A/B)."""
+        sides (the transposed weight images swap the roles), the up-sampling ones 64 input channels (one workgroup of the stride-2
+        data-gradient kernel owns 64); E3DGE_DEC2_BWD=library keeps round 4's recomputing backward (A/B)."""
         if os.environ.get("E3DGE_DEC2_BWD", "native") == "library":
             return False
-        return all(m.kernel_size != 3 or (m.in_channel % 32 == 0 and m.out_channel % 32 == 0) for m, _ in self._mod_layers())
+        return all(m.kernel_size != 3 or (m.in_channel % (64 if m.upsample else 32) == 0 and m.out_channel % 32 == 0) for m, _ in self._mod_layers())
 
     def _needs_graph(self, features, latent):
         return torch.is_grad_enabled() and (features.requires_grad or latent.requires_grad or
