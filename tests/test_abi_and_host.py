@@ -372,3 +372,36 @@ def test_params_of_notices_added_removed_and_replaced_parameters():
         v._parameters = {k: nn.Parameter(p.detach().clone()) for k, p in v._parameters.items() if p is not None}
     assert same(twin) and same(m)
     assert same(copy.deepcopy(m))
+
+
+def test_decoder_autograd_dispatch_rules_on_the_host(monkeypatch):
+    """Which forwards may take the packed decoder inside an autograd graph (round 5, host logic only -- no GPU needed to decide):
+    the packed backward exists for d features only, needs 32-channel multiples on both sides of every 3x3 layer and 64 input channels
+    on the up-sampling ones; the mode switch rejects unknown values; CPU tensors never take the packed path."""
+    import torch
+    from e3dge_amd import synthetic as syn
+    from e3dge_amd import stylesdf_model as sm
+    for v in ("auto", "packed", "library"):
+        monkeypatch.setenv("E3DGE_DECODER_AUTOGRAD", v)
+        assert sm.decoder_autograd_backend() == v
+    monkeypatch.setenv("E3DGE_DECODER_AUTOGRAD", "fast")
+    with pytest.raises(RuntimeError):
+        sm.decoder_autograd_backend()
+    monkeypatch.delenv("E3DGE_DECODER_AUTOGRAD")
+    assert sm.decoder_autograd_backend() == "auto"
+
+    def dec(size, cm, res=64):
+        g = sm.G_pred_latents(syn.model_opt(size=size, channel_multiplier=cm, renderer_spatial_output_dim=res), syn.rendering_opt(), full_pipeline=True)
+        return g.decoder
+    assert dec(1024, 2)._dec2_bwd_ok()                       # 512 / 256 / 128 / 64 / 32 channels
+    assert dec(256, 1)._dec2_bwd_ok()                        # 256 / 128 / 64
+    assert not dec(1024, 1)._dec2_bwd_ok()                   # the last level has 16 channels: not a 32-channel multiple
+    monkeypatch.setenv("E3DGE_DEC2_BWD", "library")
+    assert not dec(256, 1)._dec2_bwd_ok()
+    monkeypatch.delenv("E3DGE_DEC2_BWD")
+    d = dec(256, 1)
+    f = torch.zeros(1, 256, 64, 64, requires_grad=True)
+    lat = torch.zeros(1, d.n_latent, 512)
+    assert d._needs_graph(f, lat) and not d._dec2_ok(f, lat, [None] * d.num_layers, None)      # CPU tensors: never the packed path
+    with torch.no_grad():
+        assert not d._needs_graph(f, lat)
