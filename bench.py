@@ -122,6 +122,8 @@ def finalize(result):
                "train_step_full_ms": r.get("train_step_full_ms"), "train_step_batch4_ms_per_sample": r.get("train_step_batch4_ms_per_sample"), "decoder_packed_fwd_bwd_ms": g("autograd", "decoder_packed_fwd_bwd_ms"),
                "decoder_library_fwd_bwd_ms": g("autograd", "decoder_library_fwd_bwd_ms"),
                "fuse_sft_hip_fwd_bwd_ms": g("autograd", "fuse_sft_hip_fwd_bwd_ms"), "tex_head_fwd_bwd_ms": g("autograd", "tex_head_fwd_bwd_ms"),
+               "blur_hbm_frac_1024": g("stream_ops", "blur_f32", "hbm_frac"), "bias_act_hbm_frac_1024": g("stream_ops", "bias_act_f32", "hbm_frac"),
+               "blur_f16_hbm_frac_1024": g("stream_ops", "blur_f16", "hbm_frac"), "bias_act_f16_hbm_frac_1024": g("stream_ops", "bias_act_f16", "hbm_frac"),
                "train_step_mfma_frac": g("train_step", "roofline", "frac"), "train_step_f32_fallback_ms": r.get("train_step_f32_fallback_ms"), "cpu_rays_per_s": g("cpu_baseline", "value")}
     if isinstance(inv, dict) and isinstance(inv.get("kernels"), list):
         dec = sum(k[1] for k in inv["kernels"] if k[0].startswith("decoder:"))
@@ -903,6 +905,39 @@ def main():
             del rs_
         except Exception as exc:
             result["surface"] = {"failed": f"{type(exc).__name__}: {exc}"}
+
+    # ---------------------------------------------------------------- the two stream ops at the decoder's top-level size (HBM fractions)
+    if rank == 0 and not args.no_inversion:
+        try:
+            from e3dge_amd import op as e3op
+            from e3dge_amd.stylesdf_model import make_kernel
+            k4_ = (make_kernel([1, 3, 3, 1]) * 4).to(dev)
+
+            def ev_op(fn, n=30):
+                for _ in range(5):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(); e0.record()
+                for _ in range(n):
+                    fn()
+                e1.record(); torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / n * 1e-3
+            so = {}
+            with torch.no_grad():
+                xb = torch.randn(1, 32, 1025, 1025, device=dev)
+                xa = torch.randn(1, 32, 1024, 1024, device=dev)
+                bb = torch.randn(32, device=dev)
+                for tag, xb_, xa_, bb_, bpe in (("f32", xb, xa, bb, 4), ("f16", xb.half(), xa.half(), bb.half(), 2)):
+                    t_blur = ev_op(lambda: e3op.upfirdn2d(xb_, k4_, pad=(1, 1)))
+                    t_act = ev_op(lambda: e3op.fused_leaky_relu(xa_, bb_))
+                    so["blur_" + tag] = {"us": 1e6 * t_blur, "hbm_frac": bpe * (xb_.numel() + 32 * 1024 * 1024) / t_blur / (PEAK_HBM_GBPS * 1e9)}
+                    so["bias_act_" + tag] = {"us": 1e6 * t_act, "hbm_frac": 2 * bpe * xa_.numel() / t_act / (PEAK_HBM_GBPS * 1e9)}
+                del xb, xa
+            so["note"] = ("upfirdn2d (Blur: up 1, down 1, 4x4 FIR) on (1, 32, 1025, 1025) and fused_leaky_relu on (1, 32, 1024, 1024): algorithmic bytes "
+                          "(in + out) / HIP-event time of 30 back-to-back launches / 8 TB/s; tools/bench_ops.py has every decoder size, graph-timed")
+            result["stream_ops"] = so
+        except Exception as exc:                                          # noqa: BLE001
+            result["stream_ops"] = {"failed": f"{type(exc).__name__}: {exc}"[:160]}
 
     # ---------------------------------------------------------------- C5: stage-1 training step of the renderer
     if not args.no_train_step:
