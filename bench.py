@@ -105,7 +105,7 @@ def finalize(result):
     if isinstance(inv, dict) and isinstance(inv.get("kernels"), list):
         rows = []
         for k in inv["kernels"]:
-            rows.append([k.get("name", "")[:80], round(k.get("ms", 0.0), 4), k.get("bound", ""), round(k.get("frac", 0.0), 3)])
+            rows.append([k.get("name", "")[:46], round(k.get("ms", 0.0), 4), k.get("bound", ""), round(k.get("frac", 0.0), 3)])
         inv["kernels"] = rows
         inv["kernel_cols"] = ["name", "ms", "bound", "frac"]
     g = lambda *ks: __import__("functools").reduce(lambda d, k: d.get(k) if isinstance(d, dict) else None, ks, r)
