@@ -146,7 +146,10 @@ def decoder_autograd_backend():
     parameter that requires grad -- takes the library path (weight modulation + MIOpen) for both directions.
     'packed': always the packed forward; the backward is native when eligible, otherwise it recomputes the library path under
     enable_grad and differentiates that (for passes that run with grad enabled but never call backward).
-    'library': the library path for both directions (round 4's default; A/B)."""
+    'library': the library path for both directions (round 4's default; A/B).  The packed node is first-order only: a second
+    differentiation through the decoder (create_graph=True; not something the reference's encoder training does) raises from
+    `once_differentiable` -- run such a step with E3DGE_DECODER_AUTOGRAD=library, whose custom ops are twice differentiable as the
+    reference's are."""
     v = os.environ.get("E3DGE_DECODER_AUTOGRAD", "auto")
     if v not in ("auto", "packed", "library"):
         raise RuntimeError(f"E3DGE_DECODER_AUTOGRAD must be 'auto', 'packed' or 'library', got {v!r}")
