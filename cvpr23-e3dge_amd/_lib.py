@@ -98,7 +98,8 @@ class Dec2BwdPlan(ctypes.Structure):
     _fields_ = [("d_img", _vp), ("d_features", _vp), ("conv1", Dec2BwdConv), ("up", Dec2BwdConv * DEC2_MAX_UP),
                 ("conv", Dec2BwdConv * DEC2_MAX_UP), ("gact", _vp * (2 * DEC2_MAX_UP + 2)), ("pbuf", _vp),
                 ("drgb", _vp * DEC2_MAX_UP), ("amax", _vp), ("meta", _vp), ("bounds", _vp),
-                ("kernel_ms", ctypes.POINTER(ctypes.c_float)), ("n_kernel_ms", _i32), ("reserved", _i32)]
+                ("kernel_ms", ctypes.POINTER(ctypes.c_float)), ("n_kernel_ms", _i32), ("reserved", _i32),
+                ("d_latent", _vp), ("ds_part", _vp), ("ds_part_floats", _i64)]
 
 
 class WsLinear(ctypes.Structure):
@@ -150,6 +151,7 @@ SIGNATURES = {
     "e3dge_dec2_pbuf_words": (_i64, [_i32, _i32, _i32]),
     "e3dge_dec2_bwd_num_launches": (_i32, [_i32]),
     "e3dge_dec2_backward": (_i32, [ctypes.POINTER(Dec2Plan), ctypes.POINTER(Dec2BwdPlan), _vp]),
+    "e3dge_dec2_dlatent_ws_floats": (_i64, [ctypes.POINTER(Dec2Plan)]),
     "e3dge_dec2_pack": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "e3dge_dec2_unpack": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "e3dge_siren_packed_floats": (_i64, []),

@@ -2344,6 +2344,27 @@ extern "C" int64_t e3dge_dec2_pbuf_words(int batch, int channels, int res) {
 }
 extern "C" int e3dge_dec2_bwd_num_launches(int n_up) { return 5 + 4 * n_up; }
 
+namespace e3dge {
+constexpr int kDsChunk = 4096;            // pixels per block of pk_dstyle_sums_kernel
+// channels / resolution of packed activation i of a plan ([1] conv1 out, [2 + 2u] up out, [3 + 2u] conv out)
+static void dec2_act_shape(const E3dgeDec2Plan* P, int i, int* C, int* R) {
+    if (i == 1) { *C = P->conv1.co; *R = P->in_res; return; }
+    const int u = (i - 2) / 2;
+    *C = (i & 1) ? P->conv[u].co : P->up[u].co;
+    *R = P->in_res << (u + 1);
+}
+}  // namespace e3dge
+extern "C" int64_t e3dge_dec2_dlatent_ws_floats(const E3dgeDec2Plan* P) {
+    if (!P || P->batch <= 0 || P->n_up < 0 || P->n_up > E3DGE_DEC2_MAX_UP) return 0;
+    int64_t n = (int64_t)P->batch * P->in_ch;
+    for (int i = 1; i <= 2 * P->n_up + 1; ++i) {
+        int C, R;
+        e3dge::dec2_act_shape(P, i, &C, &R);
+        n += (int64_t)P->batch * (C / 8) * (((int64_t)R * R + e3dge::kDsChunk - 1) / e3dge::kDsChunk) * 24;
+    }
+    return n;
+}
+
 extern "C" int e3dge_dec2_backward(const E3dgeDec2Plan* P, const E3dgeDec2BwdPlan* Q, e3dge_stream_t stream) {
     E3DGE_REQUIRE(P != nullptr && Q != nullptr, "dec2_backward: null plan");
     E3DGE_REQUIRE(P->batch >= 0 && P->n_up >= 0 && P->n_up <= E3DGE_DEC2_MAX_UP && P->in_res >= 4 && P->in_ch > 0 && P->in_ch % 32 == 0,
@@ -2496,6 +2517,50 @@ extern "C" int e3dge_dec2_backward(const E3dgeDec2Plan* P, const E3dgeDec2BwdPla
         k.x = reinterpret_cast<const unsigned char*>(Q->gact[1]); k.in_meta = mt_g2(-1); k.in_amax = am_g2(-1);
         k.out_f32 = Q->d_features;
         DEC2_STEP(conv_s1_bwd<2>(k, st));
+    }
+    if (Q->d_latent) {
+        // ---- optional: d latent from per-channel sums over the tensors the chain left behind (decoder2_bwd.h, "d latent") ----
+        if (!(Q->ds_part && Q->ds_part_floats >= e3dge_dec2_dlatent_ws_floats(P) && P->features && P->mod_table))
+            return finish(fail(E3DGE_ERR_INVALID_ARG, "dec2_backward: d_latent needs ds_part (e3dge_dec2_dlatent_ws_floats floats), the forward's features and mod_table"));
+        if (!(P->style_dim <= 1024 && P->n_mod == 3 * n_up + 2))
+            return finish(fail(E3DGE_ERR_INVALID_ARG, "dec2_backward: d_latent needs style_dim <= 1024 and the 3 n_up + 2 rows of the forward's modulation table"));
+        float* part[2 * E3DGE_DEC2_MAX_UP + 2] = {};
+        int nch[2 * E3DGE_DEC2_MAX_UP + 2] = {};
+        float* cursor = Q->ds_part;
+        float* p_conv1 = cursor; cursor += (int64_t)B * P->in_ch;
+        for (int i = 1; i <= 2 * n_up + 1; ++i) {
+            int C, R;
+            dec2_act_shape(P, i, &C, &R);
+            const bool odd = (i & 1) != 0;
+            const int u = odd ? (i - 3) / 2 : (i - 2) / 2;                 // level (odd: conv / rgb of level u, u = -1: conv1 / rgb1)
+            const E3dgeDec2Conv& prod = i == 1 ? P->conv1 : (odd ? P->conv[u] : P->up[u]);
+            PkDsSumsK k{};
+            k.act = reinterpret_cast<const unsigned char*>(P->act[i]); k.g = reinterpret_cast<const unsigned char*>(Q->gact[i]);
+            k.act_meta = P->meta + i; k.g_meta = odd ? mt_g2(u) : mt_g1(u);
+            k.noise = prod.noise; k.noise_w = prod.noise_w; k.noise_batch = prod.noise_batch; k.bias = prod.bias;
+            if (odd) { k.wm = rgb_of(u).wm; k.drgb = drgb_of(u); }
+            k.slope = P->negative_slope; k.act_scale = P->act_scale; k.C = C; k.R = R; k.chunk = kDsChunk;
+            k.n_chunks = (int)(((int64_t)R * R + kDsChunk - 1) / kDsChunk);
+            k.part = cursor; part[i] = cursor; nch[i] = k.n_chunks;
+            cursor += (int64_t)B * (C / 8) * k.n_chunks * 24;
+            pk_dstyle_sums_kernel<<<dim3((unsigned)k.n_chunks, (unsigned)(C / 8), (unsigned)B), dim3(256), 0, st>>>(k);
+            if ((rc = check_launch("dec2 bwd style sums")) != 0) return finish(rc);
+        }
+        pk_dot_planes_kernel<<<dim3((unsigned)P->in_ch, (unsigned)B), dim3(256), 0, st>>>(p_conv1, P->features, Q->d_features, P->in_ch, P->in_res * P->in_res);
+        if ((rc = check_launch("dec2 bwd d features . features")) != 0) return finish(rc);
+        PkDlatK k{};
+        k.tab = P->mod_table; k.n_rows = P->n_mod; k.n_latent = P->n_latent; k.style_dim = P->style_dim; k.d_latent = Q->d_latent;
+        // table rows (Decoder._mod_layers): 0 conv1, 1 rgb1, then per level up (2 + 3u), conv (3 + 3u), rgb (4 + 3u)
+        k.row[0] = PkDsRow{p_conv1, part[1], 0, nch[1], 3};
+        k.row[1] = PkDsRow{part[1], nullptr, nch[1], 0, 2};
+        for (int u = 0; u < n_up; ++u) {
+            const int prev = u == 0 ? 1 : 3 + 2 * (u - 1), a1 = 2 + 2 * u, a2 = 3 + 2 * u;
+            k.row[2 + 3 * u] = PkDsRow{part[prev], part[a1], nch[prev], nch[a1], 0};
+            k.row[3 + 3 * u] = PkDsRow{part[a1], part[a2], nch[a1], nch[a2], 0};
+            k.row[4 + 3 * u] = PkDsRow{part[a2], nullptr, nch[a2], 0, 2};
+        }
+        pk_dlatent_kernel<<<dim3((unsigned)P->n_latent, (unsigned)B), dim3(256), 0, st>>>(k);
+        if ((rc = check_launch("dec2 bwd d latent")) != 0) return finish(rc);
     }
 #undef DEC2_STEP
     return finish(E3DGE_OK);

@@ -437,6 +437,158 @@ __global__ void __launch_bounds__(256) pkconv_down_kernel(const PkConvK a) {
     }
 }
 
+
+// ---- d latent (round 5, optional): the gradient to the decoder's W+ latent WITHOUT a weight-gradient contraction ---------------------------
+// For a modulated 3x3 layer  w'' = (scale W) s[ci] demod[co],  demod = rsqrt(sum_{ci,t} ((scale W) s)^2 + eps)  (stylesdf_model.py:317-326):
+//     dL/ds[ci] = (1 / s[ci]) sum_p x[ci,p] dx[ci,p]  -  s[ci] sum_co demod[co]^2 wsq[co][ci] (sum_p g[co,p] y[co,p])
+// with x the layer's input, dx ITS data gradient (this layer's contribution only, before the producer's lrelu'), g = dL/d(pre-activation) of the
+// layer's output and y its convolution output before noise and bias (for the up-sampling layers after the blur: <Blur^T g, T> = <g, Blur T>).
+// The first sum is sum_{co,t} dL/dw'' w'' regrouped by input channel, the second the same regrouped by output channel (the demodulation's own
+// derivative): the (co, ci, 9) weight gradient itself -- a GEMM over all pixels -- is never formed.  ToRGB (no demodulation):
+// dL/ds[ci] = (1 / s[ci]) sum_p act[ci,p] v[ci,p], v = ToRGB^T d rgb.  Everything is per-channel dot products of tensors the backward
+// has left in its workspace: for every activation tensor A (packed forward) with G = dL/d(pre) (packed gradient), mask gain m and v:
+//     dx = G / m - v,   S1 = sum_p A dx  (-> the 3x3 layer that CONSUMES A),   S2 = sum_p G y  (-> the layer that PRODUCED A),   S3 = sum_p A v  (-> A's ToRGB)
+// (pk_dstyle_sums_kernel: one streaming pass over A and G, fixed-order two-level reduction), then dL/dlatent = modulation^T dL/ds
+// (pk_dlatent_kernel; EqualLinear :234-244).
+struct PkDsSumsK {
+    const unsigned char* act; const unsigned char* g; const int* act_meta; const int* g_meta;
+    const float* noise; const float* noise_w; const float* bias;      // of the PRODUCING layer (noise (noise_batch, R, R) or null)
+    const float* wm; const float* drgb;                                 // ToRGB table (B, 3, C) and d rgb (B, 3, R, R), or null
+    float* part;                                                        // (B * C/8, n_chunks, 3, 8)
+    float slope, act_scale; int C, R, noise_batch, n_chunks, chunk;
+};
+__global__ void __launch_bounds__(256) pk_dstyle_sums_kernel(const PkDsSumsK a) {
+    __shared__ float red[4][24];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int chunk = blockIdx.x, g = blockIdx.y, b = blockIdx.z, G = a.C >> 3, R = a.R;
+    const int64_t plane = (int64_t)(R + 2) * (R + 2), hw = (int64_t)R * R;
+    const u32x4* __restrict__ ap = reinterpret_cast<const u32x4*>(a.act) + ((int64_t)(b * G + g) * 2) * plane;
+    const u32x4* __restrict__ gp = reinterpret_cast<const u32x4*>(a.g) + ((int64_t)(b * G + g) * 2) * plane;
+    const float inv_a = pow2_bits((unsigned)a.act_meta[0] - 14u), inv_g = pow2_bits((unsigned)a.g_meta[0] - 14u);
+    const float nw = a.noise ? a.noise_w[0] : 0.0f;
+    const float* __restrict__ nz = a.noise ? a.noise + (int64_t)(a.noise_batch > 1 ? b : 0) * hw : nullptr;
+    float bs[8], w[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bs[j] = a.bias[8 * g + j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w[c][j] = a.wm ? a.wm[((size_t)b * 3 + c) * a.C + 8 * g + j] : 0.0f;
+    }
+    const float m_pos = a.act_scale, m_neg = a.act_scale * a.slope;
+    float s1[8] = {}, s2[8] = {}, s3[8] = {};
+    const int p_end = min((chunk + 1) * a.chunk, (int)hw);
+    for (int p = chunk * a.chunk + tid; p < p_end; p += 256) {
+        const int y = p / R, x = p - y * R;
+        const int64_t e = (int64_t)(y + 1) * (R + 2) + x + 1;
+        const u32x4 ah = ap[e], al = ap[e + plane], gh = gp[e], gl = gp[e + plane];
+        float d[3] = {0.f, 0.f, 0.f};
+        if (a.drgb) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) d[c] = a.drgb[((int64_t)b * 3 + c) * hw + p];
+        }
+        const float nzv = nz ? nw * nz[p] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned hb = (ah[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            const float m = (hb - 1u < 0x7fffu) ? m_pos : m_neg;                        // the backward's own branch test
+            const float av = ((j & 1) ? f16hi(ah[j >> 1]) + f16hi(al[j >> 1]) : f16lo(ah[j >> 1]) + f16lo(al[j >> 1])) * inv_a;
+            const float gv = ((j & 1) ? f16hi(gh[j >> 1]) + f16hi(gl[j >> 1]) : f16lo(gh[j >> 1]) + f16lo(gl[j >> 1])) * inv_g;
+            const float v = fmaf(w[2][j], d[2], fmaf(w[1][j], d[1], w[0][j] * d[0]));
+            const float yv = av / m - nzv - bs[j];
+            s1[j] = fmaf(av, gv / m - v, s1[j]);
+            s2[j] = fmaf(gv, yv, s2[j]);
+            s3[j] = fmaf(av, v, s3[j]);
+        }
+    }
+    float vals[24];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { vals[j] = s1[j]; vals[8 + j] = s2[j]; vals[16 + j] = s3[j]; }
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vals[i] += __shfl_xor(vals[i], off, kWave);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) red[wv][i] = vals[i];
+    }
+    __syncthreads();
+    if (tid < 24) a.part[((int64_t)(b * G + g) * a.n_chunks + chunk) * 24 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// conv1's input is the fp32 feature map: S1[b][ci] = sum_p features d features, one block per (ci, b)
+__global__ void __launch_bounds__(256) pk_dot_planes_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ dx, int C, int hw) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float* xp = x + ((int64_t)b * C + c) * hw;
+    const float* dp = dx + ((int64_t)b * C + c) * hw;
+    float s = 0.0f;
+    for (int p = threadIdx.x; p < hw; p += 256) s = fmaf(xp[p], dp[p], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, kWave);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[(int64_t)b * C + c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// dL/dlatent[b][li][k] = sum over the table rows with latent_index == li of lin_scale sum_ci dL/ds[ci] mod_weight[ci][k]
+struct PkDsRow { const float* p1; const float* p2; int n1, n2, sum1; };      // sum1: 0 = S1, 2 = S3 of the partial layout, 3 = plain (b, ci) array
+struct PkDlatK { const E3dgeModLayer* tab; PkDsRow row[3 * E3DGE_DEC2_MAX_UP + 2]; int n_rows, n_latent, style_dim; float* d_latent; };
+__global__ void __launch_bounds__(256) pk_dlatent_kernel(const PkDlatK a) {
+    __shared__ float ds[1024], r2[1024];
+    const int li = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};                                   // k = tid + 256 q, style_dim <= 1024
+    for (int t = 0; t < a.n_rows; ++t) {
+        const E3dgeModLayer L = a.tab[t];
+        if (L.latent_index != li) continue;                                // (block-uniform)
+        const PkDsRow rw = a.row[t];
+        const float* __restrict__ s = L.style_out + (size_t)b * L.ci;
+        const bool conv = L.demod_out != nullptr;
+        if (conv) {                                                         // r2[co] = demod^2 sum_p g y
+            for (int co = tid; co < L.co; co += 256) {
+                const float* pp = rw.p2 + ((int64_t)(b * (L.co >> 3) + (co >> 3)) * rw.n2) * 24 + 8 + (co & 7);
+                float v = 0.0f;
+                for (int c = 0; c < rw.n2; ++c) v += pp[(int64_t)c * 24];
+                const float dm = L.demod_out[(size_t)b * L.co + co];
+                r2[co] = dm * dm * v;
+            }
+        }
+        __syncthreads();
+        for (int ci = tid; ci < L.ci; ci += 256) {
+            float r1 = 0.0f;
+            if (rw.sum1 == 3) r1 = rw.p1[(int64_t)b * L.ci + ci];
+            else {
+                const float* pp = rw.p1 + ((int64_t)(b * (L.ci >> 3) + (ci >> 3)) * rw.n1) * 24 + 8 * rw.sum1 + (ci & 7);
+                for (int c = 0; c < rw.n1; ++c) r1 += pp[(int64_t)c * 24];
+            }
+            const float sv = s[ci];
+            float d = fabsf(sv) > 1e-30f ? r1 / sv : 0.0f;
+            if (conv) {
+                float tb = 0.0f;
+                for (int co = 0; co < L.co; ++co) tb = fmaf(r2[co], L.wsq[(size_t)co * L.ci + ci], tb);
+                d -= sv * tb;
+            }
+            ds[ci] = d;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = tid + 256 * q;
+            if (k < a.style_dim) {
+                float v = 0.0f;
+                for (int ci = 0; ci < L.ci; ++ci) v = fmaf(ds[ci], L.mod_weight[(size_t)ci * a.style_dim + k], v);
+                acc[q] = fmaf(v, L.lin_scale, acc[q]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = tid + 256 * q;
+        if (k < a.style_dim) a.d_latent[((int64_t)b * a.n_latent + li) * a.style_dim + k] = acc[q];
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------------------------
 template <int NCT>
 static int launch_down(PkConvK k, hipStream_t st, const char* what) {

@@ -168,7 +168,7 @@ class _PackedDecoderFn(torch.autograd.Function):
         ctx.dec, ctx.noise, ctx.n_params = dec, noise, len(params)
         ctx.save_for_backward(features, latent)
         need = ctx.needs_input_grad
-        ctx.native = dec._dec2_bwd_ok() and not need[3] and not any(need[4:])
+        ctx.native = dec._dec2_bwd_ok() and not any(need[4:]) and (not need[3] or decoder_dlatent_native())
         with torch.no_grad():
             img = dec._forward_packed(features, latent, noise, save=ctx.native)
         if ctx.native:
@@ -182,13 +182,13 @@ class _PackedDecoderFn(torch.autograd.Function):
         dec = ctx.dec
         need = ctx.needs_input_grad
         if ctx.native:
-            d_feat = None
-            if need[2]:
+            d_feat = d_lat = None
+            if need[2] or need[3]:
                 with torch.no_grad():
                     if dec.__dict__.get('_dec2_gen') != ctx.gen:          # somebody else ran a forward on this decoder since
                         dec._forward_packed(features, latent, ctx.noise, save=True)
-                    d_feat = dec._backward_packed(features, d_img)
-            return (None, None, d_feat, None) + (None,) * ctx.n_params
+                    d_feat, d_lat = dec._backward_packed(features, d_img, want_latent=need[3], latent_shape=latent.shape)
+            return (None, None, d_feat if need[2] else None, d_lat) + (None,) * ctx.n_params
         params = [p for p in dec.parameters()]
         with torch.enable_grad():
             f_ = features.detach().requires_grad_(need[2])
@@ -202,6 +202,12 @@ class _PackedDecoderFn(torch.autograd.Function):
         for n in need[4:]:
             out.append(grads.pop(0) if n else None)
         return tuple(out)
+
+
+def decoder_dlatent_native():
+    """E3DGE_DEC2_DLATENT=0: a decoder latent that requires grad takes the library path (round 4); default: e3dge_dec2_backward also
+    returns d latent (per-channel sums over the tensors its chain leaves behind + modulation^T, csrc/decoder2_bwd.h)."""
+    return os.environ.get("E3DGE_DEC2_DLATENT", "1") != "0"
 
 
 def modconv_backend():
@@ -651,7 +657,7 @@ class Decoder(nn.Module):
             mode = decoder_autograd_backend()
             if mode == "library" or any(n is not None and n.requires_grad for n in noise):
                 return False
-            if mode == "auto" and not (self._dec2_bwd_ok() and not latent.requires_grad and
+            if mode == "auto" and not (self._dec2_bwd_ok() and (not latent.requires_grad or decoder_dlatent_native()) and
                                        not any(p.requires_grad for p in _lib.params_of(self))):
                 return False
         for m, _ in self._mod_layers():
@@ -883,8 +889,9 @@ class Decoder(nn.Module):
         st['bwd'] = bw
         return bw
 
-    def _backward_packed(self, features, d_img, kernel_ms=None):
-        """d features for the LAST packed forward of this (batch, resolution, stream) -- it must have run with save=True."""
+    def _backward_packed(self, features, d_img, kernel_ms=None, want_latent=False, latent_shape=None):
+        """(d features, d latent or None) for the LAST packed forward of this (batch, resolution, stream) -- it must have run with
+        save=True.  d latent (B, n_latent, style_dim): 2 n_up + 3 more launches inside the same native call."""
         B, res = features.shape[0], features.shape[2]
         dev = features.device
         st = self._dec2_state(B, res, dev)
@@ -897,6 +904,15 @@ class Decoder(nn.Module):
             raise RuntimeError(f"d image must be float32 {tuple(st['outs'][-1].shape)}; got {g.dtype} {tuple(g.shape)}")
         d_feat = torch.empty((B, self.conv1.conv.in_channel, res, res), device=dev, dtype=torch.float32)
         q.d_img, q.d_features = _lib.ptr(g), _lib.ptr(d_feat)
+        d_lat = None
+        if want_latent:
+            if 'ds_part' not in bw:
+                n = _lib.load().e3dge_dec2_dlatent_ws_floats(ctypes.byref(st['plan']))
+                bw['ds_part'] = torch.empty(max(int(n), 1), device=dev, dtype=torch.float32)
+            d_lat = torch.empty((B, self.n_latent, self.style_dim), device=dev, dtype=torch.float32)
+            q.d_latent, q.ds_part, q.ds_part_floats = _lib.ptr(d_lat), _lib.ptr(bw['ds_part']), bw['ds_part'].numel()
+        else:
+            q.d_latent, q.ds_part, q.ds_part_floats = None, None, 0
         ms = None
         if kernel_ms is not None:
             ms = (ctypes.c_float * bw['n_launch'])()
@@ -909,7 +925,9 @@ class Decoder(nn.Module):
         if ms is not None:
             kernel_ms[:] = list(ms)
         bw['hold'] = [g]
-        return d_feat
+        if d_lat is not None and latent_shape is not None and tuple(latent_shape) != tuple(d_lat.shape):
+            d_lat = d_lat.reshape(latent_shape)
+        return d_feat, d_lat
 
     def dec2_bwd_launch_names(self):
         """Labels of the launches of one packed backward, in the order of `kernel_ms`."""

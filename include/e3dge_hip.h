@@ -296,14 +296,22 @@ typedef struct E3dgeDec2BwdPlan {
     float* amax;                                   /* (4 n_up + 2) amax buffers (cleared by the call)                                 */
     int32_t* meta;                                 /* (3 n_up + 1) ints                                                               */
     float* bounds;                                 /* (3 n_up + 2) floats: operator norms of the transposed images / ToRGB tables     */
-    float* kernel_ms;                              /* host array or NULL: HIP-event time of every launch (makes the call synchronous) */
+    float* kernel_ms;                              /* host array or NULL: HIP-event time of every launch of the d-features chain (makes the call synchronous) */
     int32_t n_kernel_ms, reserved;
+    /* optional: the gradient to the decoder's W+ latent, (batch, n_latent, style_dim), or NULL.  Formed from per-channel dot products of
+     * the tensors the chain leaves in its workspace -- dL/ds[ci] = (1/s) sum_p x dx - s sum_co demod^2 wsq sum_p g y (3x3 layers),
+     * (1/s) sum_p act (ToRGB^T d rgb) (ToRGB), then modulation^T -- no weight-gradient contraction (csrc/decoder2_bwd.h).  2 n_up + 3 more
+     * launches.  Needs plan->features / mod_table as the forward had them and ds_part = e3dge_dec2_dlatent_ws_floats(plan) floats. */
+    float* d_latent;
+    float* ds_part;
+    int64_t ds_part_floats;
 } E3dgeDec2BwdPlan;
 /* weight (co, ci, 3, 3) -> wpre_t[t][c][tap][lane][j] = scale * weight[16c + 8 (lane >> 5) + j][32t + (lane & 31)][flip ? 8 - tap : tap];
  * flip = 1 for the stride-1 convolutions, 0 for the up-sampling (transposed-stride) ones.  ci %% 32 == 0, co %% 16 == 0. */
 int e3dge_dec2_prepack_weights_t(float* wpre_t, const float* weight, float scale, int co, int ci, int flip, e3dge_stream_t stream);
 int64_t e3dge_dec2_pbuf_words(int batch, int channels, int res);
 int e3dge_dec2_bwd_num_launches(int n_up);
+int64_t e3dge_dec2_dlatent_ws_floats(const E3dgeDec2Plan* plan);
 int e3dge_dec2_backward(const E3dgeDec2Plan* plan, const E3dgeDec2BwdPlan* bwd, e3dge_stream_t stream);
 /* stand-alone pieces (tests, tools): fp32 (batch, c, res, res) <-> packed; both use meta[0] / amax as e3dge_dec2_forward does */
 int e3dge_dec2_pack(uint32_t* packed, int32_t* meta, const float* x, const float* amax, int batch, int channels, int res,

@@ -101,6 +101,19 @@ def test_d_features_against_the_references_own_autograd_256(gen256, batch):
     assert e["max_vs_f64"] <= max(REL_TOL, 3 * e["reference_max_vs_f64"]), e
     assert e["l2_vs_reference"] <= max(REL_TOL, 3 * e["reference_l2_vs_f64"]), e
     assert e["sum_rel"] <= 1e-4, e
+    # d latent from the same native call (per-channel sums + modulation^T, no weight-gradient contraction) against the recording
+    f2 = feats.detach().clone().requires_grad_(True)
+    l2 = wd.detach().clone().requires_grad_(True)
+    img2, _ = dec(f2, [l2], input_is_latent=True, noise=noises)
+    assert "PackedDecoderFn" in type(img2.grad_fn).__name__
+    d_f2, d_l = torch.autograd.grad(img2, [f2, l2], gy)
+    assert torch.equal(d_f2, d_f)
+    ref_l, f64_l = torch.from_numpy(gold["ref_d_latent"][sl]), torch.from_numpy(gold["f64_d_latent"][sl])
+    e3 = dict(batch=batch, l2_vs_reference=rel_l2(d_l, ref_l), max_vs_reference=rel_max(d_l, ref_l), l2_vs_f64=rel_l2(d_l, f64_l),
+              max_vs_f64=rel_max(d_l, f64_l), reference_l2_vs_f64=rel_l2(ref_l, f64_l), reference_max_vs_f64=rel_max(ref_l, f64_l))
+    record("dec2_bwd_d_latent_vs_reference_256", **e3)
+    assert e3["l2_vs_f64"] <= max(REL_TOL, 3 * e3["reference_l2_vs_f64"]), e3
+    assert e3["max_vs_f64"] <= max(REL_TOL, 3 * e3["reference_max_vs_f64"]), e3
     # the library path (weight modulation + MIOpen + the two custom ops' backward) on the same inputs, whole tensor
     _, d_lib, fn_lib = _grad(dec, feats, wd, noises, gy, mode="library")
     assert "PackedDecoderFn" not in type(fn_lib).__name__
@@ -180,29 +193,44 @@ def test_backward_after_another_forward_reruns_its_own(gen256):
     assert torch.isfinite(other).all()
 
 
-def test_ineligible_graphs_take_the_library_path(gen256):
-    """d latent or a parameter gradient is not produced by e3dge_dec2_backward: such forwards must not take the packed Function in the
-    default mode, and the gradients must exist."""
+def test_ineligible_graphs_take_the_library_path(gen256, monkeypatch):
+    """Parameter gradients are not produced by e3dge_dec2_backward, and E3DGE_DEC2_DLATENT=0 switches the native d latent off: such
+    forwards must not take the packed Function in the default mode, the gradients must exist, and d features / d latent must agree
+    with what the packed backward gives."""
     g, _ = gen256
     dec = g.decoder
     feats, noises, gy = syn.decoder_grad_inputs(1, 256, 64, seed=9, device=DEV)
     _, wd = syn.synthetic_inputs(1, seed=4, device=DEV)
-    wl = wd[:, :dec.n_latent].clone().requires_grad_(True)
-    f = feats.clone().requires_grad_(True)
-    img, _ = dec(f, [wl], input_is_latent=True, noise=noises)
-    assert "PackedDecoderFn" not in type(img.grad_fn).__name__
-    d_f, d_l = torch.autograd.grad(img, [f, wl], gy)
-    assert float(d_l.abs().max()) > 0 and float(d_f.abs().max()) > 0
-    # the same d features as the packed backward gives for the detached latent
-    _, d_p, _ = _grad(dec, feats, wl.detach(), noises, gy)
-    e = dict(l2=rel_l2(d_p, d_f), max=rel_max(d_p, d_f))
+    wl0 = wd[:, :dec.n_latent].contiguous()
+
+    def run():
+        f = feats.clone().requires_grad_(True)
+        wl = wl0.clone().requires_grad_(True)
+        img, _ = dec(f, [wl], input_is_latent=True, noise=noises)
+        return type(img.grad_fn).__name__, torch.autograd.grad(img, [f, wl], gy)
+    name_p, (df_p, dl_p) = run()
+    assert "PackedDecoderFn" in name_p
+    monkeypatch.setenv("E3DGE_DEC2_DLATENT", "0")
+    name_l, (df_l, dl_l) = run()
+    monkeypatch.delenv("E3DGE_DEC2_DLATENT")
+    assert "PackedDecoderFn" not in name_l
+    e = dict(d_features_l2=rel_l2(df_p, df_l), d_latent_l2=rel_l2(dl_p, dl_l), d_latent_max=rel_max(dl_p, dl_l))
     record("dec2_bwd_vs_library_with_latent_grad", **e)
-    assert e["l2"] <= REL_TOL, e
+    assert e["d_features_l2"] <= REL_TOL and e["d_latent_l2"] <= REL_TOL, e
+    dec.conv1.activate.bias.requires_grad_(True)
+    try:
+        f = feats.clone().requires_grad_(True)
+        img, _ = dec(f, [wl0], input_is_latent=True, noise=noises)
+        assert "PackedDecoderFn" not in type(img.grad_fn).__name__
+        d_f, d_b = torch.autograd.grad(img, [f, dec.conv1.activate.bias], gy)
+        assert float(d_b.abs().max()) > 0 and rel_l2(d_f, df_l) <= REL_TOL
+    finally:
+        dec.conv1.activate.bias.requires_grad_(False)
 
 
 def test_library_path_d_features_and_d_latent_against_the_references_autograd_256(gen256):
-    """The path every forward with d latent (or a trainable decoder parameter) takes -- weight modulation + MIOpen + the two custom
-    ops' backward classes -- against the reference's recording at the size where all four fused custom-op shapes occur, batch 2,
+    """The path every forward with a trainable decoder parameter (or E3DGE_DECODER_AUTOGRAD=library) takes -- weight modulation + MIOpen +
+    the two custom ops' backward classes -- against the reference's recording at the size where all four fused custom-op shapes occur, batch 2,
     per-sample noise (round-4 review, item 7: it was pinned at size 64 only)."""
     g, _ = gen256
     dec = g.decoder
@@ -212,7 +240,11 @@ def test_library_path_d_features_and_d_latent_against_the_references_autograd_25
     _, wd = syn.synthetic_inputs(B, seed=int(gold["styles_seed"]), device=DEV)
     f = feats.clone().requires_grad_(True)
     wl = wd[:, :dec.n_latent].clone().requires_grad_(True)
-    img, _ = dec(f, [wl], input_is_latent=True, noise=noises)
+    os.environ["E3DGE_DECODER_AUTOGRAD"] = "library"
+    try:
+        img, _ = dec(f, [wl], input_is_latent=True, noise=noises)
+    finally:
+        os.environ.pop("E3DGE_DECODER_AUTOGRAD", None)
     assert "PackedDecoderFn" not in type(img.grad_fn).__name__
     d_f, d_l = torch.autograd.grad(img, [f, wl], gy)
     ref_f, f64_f = torch.from_numpy(gold["ref_d_features_sub"]), torch.from_numpy(gold["f64_d_features_sub"])
