@@ -119,7 +119,7 @@ def finalize(result):
                "train_step_allreduce_busbw_GBps": g("train_step", "allreduce_busbw_GBps"),
                "train_step_with_allreduce_ms": g("train_step", "step_with_allreduce_ms"),
                "c4_ms_per_pose": g("c4", "sequential", "ms_per_pose"), "train_step_ms": r.get("train_step_ms"),
-               "train_step_full_ms": r.get("train_step_full_ms"), "train_step_batch4_ms_per_sample": r.get("train_step_batch4_ms_per_sample"), "decoder_packed_fwd_bwd_ms": g("autograd", "decoder_packed_fwd_bwd_ms"),
+               "train_step_full_ms": r.get("train_step_full_ms"), "train_step_full_both_latents_ms": r.get("train_step_full_both_latents_ms"), "train_step_batch4_ms_per_sample": r.get("train_step_batch4_ms_per_sample"), "decoder_packed_fwd_bwd_ms": g("autograd", "decoder_packed_fwd_bwd_ms"),
                "decoder_library_fwd_bwd_ms": g("autograd", "decoder_library_fwd_bwd_ms"),
                "fuse_sft_hip_fwd_bwd_ms": g("autograd", "fuse_sft_hip_fwd_bwd_ms"), "tex_head_fwd_bwd_ms": g("autograd", "tex_head_fwd_bwd_ms"),
                "blur_hbm_frac_1024": g("stream_ops", "blur_f32", "hbm_frac"), "bias_act_hbm_frac_1024": g("stream_ops", "bias_act_f32", "hbm_frac"),
@@ -1029,9 +1029,10 @@ def main():
                 pool5 = torch.nn.AdaptiveAvgPool2d((256, 256))
                 full = {}
 
-                def train_step_full():
+                def train_step_full(latent_grad=False):
                     s_ = w5.clone().requires_grad_(True)
-                    o = g5([s_, d5], p5, f5, n5, fa5, input_is_latent=True, randomize_noise=False, return_eikonal=True,
+                    dl_ = d5.clone().requires_grad_(True) if latent_grad else d5
+                    o = g5([s_, dl_], p5, f5, n5, fa5, input_is_latent=True, randomize_noise=False, return_eikonal=True,
                            return_surface_eikonal=True)
                     loss = ((pool5(o['gen_imgs']) ** 2).mean() + (o['gen_thumb_imgs'] ** 2).mean()
                             + ((o['eikonal_term'].norm(dim=-1) - 1) ** 2).mean() + (o['surface_eikonal_term'] ** 2).mean())
@@ -1049,6 +1050,18 @@ def main():
                         os.environ.pop("E3DGE_DECODER_AUTOGRAD", None)
                         os.environ.pop("E3DGE_OVERLAP_DECODER", None)
                 result["train_step_full_no_overlap_ms"] = full["packed_no_overlap"]
+                # both latents trainable (what the encoder's two heads receive, trainer.py:881-897): d latent from e3dge_dec2_backward too
+                for be, env in (("packed", "auto"), ("library", "library")):
+                    os.environ["E3DGE_DECODER_AUTOGRAD"] = env
+                    try:
+                        for _ in range(3):
+                            gf = train_step_full(True)
+                        full[be + "_both"] = wall_ms(lambda: train_step_full(True), n_tr)
+                        assert torch.isfinite(gf).all()
+                    finally:
+                        os.environ.pop("E3DGE_DECODER_AUTOGRAD", None)
+                result["train_step_full_both_latents_ms"] = full["packed_both"]
+                result["train_step_full_both_latents_library_ms"] = full["library_both"]
                 del g5
                 result["train_step_full_ms"] = full["packed"]
                 result["train_step_full_library_decoder_ms"] = full["library"]

@@ -657,9 +657,7 @@ static int launch_resblock(ResblockK k, bool film, hipStream_t st, const char* w
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);       // per device, cheap: set on every launch
     if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(resblock): %s", hipGetErrorString(e));
     const int64_t tiles = (k.n_pts + kTilePts - 1) / kTilePts;
-    int spw = (int)((tiles + 255) / 256);
-    if (spw < 1) spw = 1;
-    if (spw > 8) spw = 8;
+    const int spw = pick_subtiles_per_wg(tiles, 1);
     k.subtiles_per_wg = spw;
     const int64_t grid = (tiles + spw - 1) / spw;
     E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "%s: grid too large", what);

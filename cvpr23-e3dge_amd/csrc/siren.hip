@@ -1108,11 +1108,8 @@ extern "C" int e3dge_siren_points_fwd(const float* packed, const float* film, co
     SirenK k{};
     k.packed = packed; k.film = film; k.pts = pts; k.vdirs = viewdirs; k.box_scale = box_scale;
     k.batch = batch; k.n_pts = n_pts; k.sdf = sdf; k.raw = raw;
-    // sub-tiles per workgroup: enough workgroups to cover the chip, at most 8 sub-tiles each
     const int64_t tiles = (n_pts + kTilePts - 1) / kTilePts;
-    int spw = (int)((tiles * batch + 255) / 256);
-    if (spw < 1) spw = 1;
-    if (spw > 8) spw = 8;
+    const int spw = pick_subtiles_per_wg(tiles, batch);
     k.subtiles_per_wg = spw;
     k.wgs_per_img = (int)((tiles + spw - 1) / spw);
     const int64_t grid = (int64_t)k.wgs_per_img * batch;

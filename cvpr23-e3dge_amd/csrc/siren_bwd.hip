@@ -1048,9 +1048,7 @@ using namespace e3dge;
 
 static int bwd_geometry(int batch, int64_t n_pts, int* subtiles_per_wg, int* wgs_per_img) {
     const int64_t tiles = (n_pts + kTilePts - 1) / kTilePts;
-    int spw = (int)((tiles * batch + 255) / 256);
-    if (spw < 1) spw = 1;
-    if (spw > 8) spw = 8;
+    const int spw = pick_subtiles_per_wg(tiles, batch);
     *subtiles_per_wg = spw;
     *wgs_per_img = (int)((tiles + spw - 1) / spw);
     return 0;

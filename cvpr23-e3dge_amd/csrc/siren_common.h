@@ -18,6 +18,21 @@ constexpr int kBigLayers = 8;                   // pts_linears.1..7 + views_line
 constexpr int kChunksPerPass = kBigLayers * kNT;  // 64 chunks = 2 MiB per 128-point sub-tile
 constexpr int kNBuf = 3;                        // LDS weight buffers
 constexpr int kTilePts = 128;                   // points per sub-tile (4 waves x 32)
+
+// 128-point sub-tiles a workgroup of a points launch walks one after the other.  One workgroup owns a CU (LDS), so a launch of `grid`
+// workgroups of spw sub-tiles each lasts ceil(grid / 256) rounds x spw sub-tile times: take the spw <= 8 with the shortest launch and,
+// among equals, the largest (fewest per-workgroup partial sums, and the CUs of an unfilled single round stay free for a side stream).
+// (Until round 5 this was min(8, ceil(tiles / 256)): 4 x 576 tiles became 288 workgroups of 8 = two rounds of 8 for 9 rounds of work.)
+inline int pick_subtiles_per_wg(long long tiles_per_img, int batch) {
+    int best = 1;
+    long long best_span = -1;
+    for (int spw = 1; spw <= 8; ++spw) {
+        const long long grid = ((tiles_per_img + spw - 1) / spw) * batch;
+        const long long span = ((grid + 255) / 256) * spw;
+        if (best_span < 0 || span <= best_span) { best_span = span; best = spw; }
+    }
+    return best;
+}
 constexpr int kThreads = 256;
 constexpr int kRMax = 16;                       // max rays per workgroup (LDS feature accumulators)
 constexpr int kFPitch = kWidth + 1;             // padded pitch of the feature accumulators

@@ -1,6 +1,6 @@
 """The stage-1 (C5) renderer step of bench.py alone -- 64x64 rays x 18 samples, eikonal + surface-normal terms, backward to the
 styles -- N times: run under rocprofv3 (--kernel-trace --stats / --pmc FETCH_SIZE / WRITE_SIZE) for its per-kernel composition and
-HBM traffic.   python tools/c5_step.py [iters]"""
+HBM traffic.   python tools/c5_step.py [iters] [samples per step]"""
 import os
 import sys
 
@@ -13,13 +13,14 @@ from e3dge_amd.camera_utils import generate_camera_params  # noqa: E402
 from e3dge_amd.volume_renderer import VolumeFeatureRenderer  # noqa: E402
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 dev = "cuda:0"
 r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=18), out_im_res=64, mode='test')
 syn.load_synthetic(r, prefix='renderer.')
 r = r.to(dev)
 r.requires_grad_(False)
-w, _ = syn.synthetic_inputs(1, seed=1, device=dev)
-p, f, n, fa, _ = generate_camera_params(64, dev, locations=torch.zeros(1, 2, device=dev))
+w, _ = syn.synthetic_inputs(B, seed=1, device=dev)
+p, f, n, fa, _ = generate_camera_params(64, dev, locations=torch.zeros(B, 2, device=dev))
 
 
 def step():
@@ -38,4 +39,4 @@ for _ in range(iters):
     g = step()
 b.record()
 torch.cuda.synchronize()
-print(f"stage-1 step 64x64x18: {a.elapsed_time(b) / iters:.3f} ms; |dstyles| max {float(g.abs().max()):.3e}")
+print(f"stage-1 step {B} x 64x64x18: {a.elapsed_time(b) / iters:.3f} ms ({a.elapsed_time(b) / iters / B:.3f} per sample); |dstyles| max {float(g.abs().max()):.3e}")
