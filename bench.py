@@ -119,7 +119,7 @@ def finalize(result):
                "train_step_allreduce_busbw_GBps": g("train_step", "allreduce_busbw_GBps"),
                "train_step_with_allreduce_ms": g("train_step", "step_with_allreduce_ms"),
                "c4_ms_per_pose": g("c4", "sequential", "ms_per_pose"), "train_step_ms": r.get("train_step_ms"),
-               "train_step_full_ms": r.get("train_step_full_ms"), "train_step_full_both_latents_ms": r.get("train_step_full_both_latents_ms"), "train_step_batch4_ms_per_sample": r.get("train_step_batch4_ms_per_sample"), "decoder_packed_fwd_bwd_ms": g("autograd", "decoder_packed_fwd_bwd_ms"),
+               "train_step_full_ms": r.get("train_step_full_ms"), "train_step_full_both_latents_ms": r.get("train_step_full_both_latents_ms"), "train_step_full_batch4_ms_per_sample": r.get("train_step_full_batch4_ms_per_sample"), "train_step_batch4_ms_per_sample": r.get("train_step_batch4_ms_per_sample"), "decoder_packed_fwd_bwd_ms": g("autograd", "decoder_packed_fwd_bwd_ms"),
                "decoder_library_fwd_bwd_ms": g("autograd", "decoder_library_fwd_bwd_ms"),
                "fuse_sft_hip_fwd_bwd_ms": g("autograd", "fuse_sft_hip_fwd_bwd_ms"), "tex_head_fwd_bwd_ms": g("autograd", "tex_head_fwd_bwd_ms"),
                "blur_hbm_frac_1024": g("stream_ops", "blur_f32", "hbm_frac"), "bias_act_hbm_frac_1024": g("stream_ops", "bias_act_f32", "hbm_frac"),
@@ -1062,6 +1062,24 @@ def main():
                         os.environ.pop("E3DGE_DECODER_AUTOGRAD", None)
                 result["train_step_full_both_latents_ms"] = full["packed_both"]
                 result["train_step_full_both_latents_library_ms"] = full["library_both"]
+                # and at stage1.sh's batch_size = 4 per GPU (both latents trainable): per sample
+                try:
+                    _, d5b = syn.synthetic_inputs(4, seed=21 + rank, device=dev)
+
+                    def train_step_full_b4():
+                        s_, dl_ = w5b.clone().requires_grad_(True), d5b.clone().requires_grad_(True)
+                        o = g5([s_, dl_], p5b, f5b, n5b, fa5b, input_is_latent=True, randomize_noise=False, return_eikonal=True,
+                               return_surface_eikonal=True)
+                        loss = ((pool5(o['gen_imgs']) ** 2).mean() + (o['gen_thumb_imgs'] ** 2).mean()
+                                + ((o['eikonal_term'].norm(dim=-1) - 1) ** 2).mean() + (o['surface_eikonal_term'] ** 2).mean())
+                        loss.backward()
+                        return s_.grad
+                    for _ in range(2):
+                        gf = train_step_full_b4()
+                    result["train_step_full_batch4_ms_per_sample"] = wall_ms(train_step_full_b4, 5) / 4
+                    assert torch.isfinite(gf).all()
+                except Exception as exc:                                      # noqa: BLE001
+                    result["train_step_full_batch4_ms_per_sample"] = f"failed: {type(exc).__name__}: {exc}"[:160]
                 del g5
                 result["train_step_full_ms"] = full["packed"]
                 result["train_step_full_library_decoder_ms"] = full["library"]

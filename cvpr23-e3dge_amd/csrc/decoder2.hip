@@ -2360,9 +2360,9 @@ extern "C" int64_t e3dge_dec2_dlatent_ws_floats(const E3dgeDec2Plan* P) {
     for (int i = 1; i <= 2 * P->n_up + 1; ++i) {
         int C, R;
         e3dge::dec2_act_shape(P, i, &C, &R);
-        n += (int64_t)P->batch * (C / 8) * (((int64_t)R * R + e3dge::kDsChunk - 1) / e3dge::kDsChunk) * 24;
+        n += (int64_t)P->batch * (C / 8) * ((((int64_t)R * R + e3dge::kDsChunk - 1) / e3dge::kDsChunk) + 1) * 24;      // chunk partials + their fold
     }
-    return n;
+    return n + (int64_t)P->batch * (3 * P->n_up + 2) * 1024;                                                           // dL/ds per modulation row
 }
 
 extern "C" int e3dge_dec2_backward(const E3dgeDec2Plan* P, const E3dgeDec2BwdPlan* Q, e3dge_stream_t stream) {
@@ -2522,8 +2522,8 @@ extern "C" int e3dge_dec2_backward(const E3dgeDec2Plan* P, const E3dgeDec2BwdPla
         // ---- optional: d latent from per-channel sums over the tensors the chain left behind (decoder2_bwd.h, "d latent") ----
         if (!(Q->ds_part && Q->ds_part_floats >= e3dge_dec2_dlatent_ws_floats(P) && P->features && P->mod_table))
             return finish(fail(E3DGE_ERR_INVALID_ARG, "dec2_backward: d_latent needs ds_part (e3dge_dec2_dlatent_ws_floats floats), the forward's features and mod_table"));
-        if (!(P->style_dim <= 1024 && P->n_mod == 3 * n_up + 2))
-            return finish(fail(E3DGE_ERR_INVALID_ARG, "dec2_backward: d_latent needs style_dim <= 1024 and the 3 n_up + 2 rows of the forward's modulation table"));
+        if (!(P->style_dim <= 1024 && P->in_ch <= 1024 && P->conv1.co <= 1024 && P->n_mod == 3 * n_up + 2))
+            return finish(fail(E3DGE_ERR_INVALID_ARG, "dec2_backward: d_latent needs style_dim and channel counts <= 1024 and the 3 n_up + 2 rows of the forward's modulation table"));
         float* part[2 * E3DGE_DEC2_MAX_UP + 2] = {};
         int nch[2 * E3DGE_DEC2_MAX_UP + 2] = {};
         float* cursor = Q->ds_part;
@@ -2548,18 +2548,37 @@ extern "C" int e3dge_dec2_backward(const E3dgeDec2Plan* P, const E3dgeDec2BwdPla
         }
         pk_dot_planes_kernel<<<dim3((unsigned)P->in_ch, (unsigned)B), dim3(256), 0, st>>>(p_conv1, P->features, Q->d_features, P->in_ch, P->in_res * P->in_res);
         if ((rc = check_launch("dec2 bwd d features . features")) != 0) return finish(rc);
-        PkDlatK k{};
-        k.tab = P->mod_table; k.n_rows = P->n_mod; k.n_latent = P->n_latent; k.style_dim = P->style_dim; k.d_latent = Q->d_latent;
+        // the chunks of every tensor folded in one launch, then dL/ds per modulation row, then modulation^T
+        float* sums[2 * E3DGE_DEC2_MAX_UP + 2] = {};
+        PkDsFoldK kf{};
+        int blocks = 0;
+        for (int i = 1; i <= 2 * n_up + 1; ++i) {
+            int C, R;
+            dec2_act_shape(P, i, &C, &R);
+            sums[i] = cursor; cursor += (int64_t)B * (C / 8) * 24;
+            kf.t[i - 1] = PkDsFoldT{part[i], sums[i], C / 8, nch[i], blocks};
+            blocks += B * (C / 8);
+        }
+        kf.n_tensors = 2 * n_up + 1;
+        pk_dstyle_fold_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(kf);
+        if ((rc = check_launch("dec2 bwd style sums (fold)")) != 0) return finish(rc);
+        float* ds = cursor; cursor += (int64_t)B * P->n_mod * 1024;
+        PkDsK kd{};
+        kd.tab = P->mod_table; kd.n_rows = P->n_mod; kd.ds = ds;
         // table rows (Decoder._mod_layers): 0 conv1, 1 rgb1, then per level up (2 + 3u), conv (3 + 3u), rgb (4 + 3u)
-        k.row[0] = PkDsRow{p_conv1, part[1], 0, nch[1], 3};
-        k.row[1] = PkDsRow{part[1], nullptr, nch[1], 0, 2};
+        kd.row[0] = PkDsRow{p_conv1, sums[1], 3};
+        kd.row[1] = PkDsRow{sums[1], nullptr, 2};
         for (int u = 0; u < n_up; ++u) {
             const int prev = u == 0 ? 1 : 3 + 2 * (u - 1), a1 = 2 + 2 * u, a2 = 3 + 2 * u;
-            k.row[2 + 3 * u] = PkDsRow{part[prev], part[a1], nch[prev], nch[a1], 0};
-            k.row[3 + 3 * u] = PkDsRow{part[a1], part[a2], nch[a1], nch[a2], 0};
-            k.row[4 + 3 * u] = PkDsRow{part[a2], nullptr, nch[a2], 0, 2};
+            kd.row[2 + 3 * u] = PkDsRow{sums[prev], sums[a1], 0};
+            kd.row[3 + 3 * u] = PkDsRow{sums[a1], sums[a2], 0};
+            kd.row[4 + 3 * u] = PkDsRow{sums[a2], nullptr, 2};
         }
-        pk_dlatent_kernel<<<dim3((unsigned)P->n_latent, (unsigned)B), dim3(256), 0, st>>>(k);
+        pk_dstyle_kernel<<<dim3((unsigned)P->n_mod, (unsigned)B), dim3(256), 0, st>>>(kd);
+        if ((rc = check_launch("dec2 bwd d styles")) != 0) return finish(rc);
+        PkDlatK k{};
+        k.tab = P->mod_table; k.ds = ds; k.n_rows = P->n_mod; k.n_latent = P->n_latent; k.style_dim = P->style_dim; k.d_latent = Q->d_latent;
+        pk_dlatent_kernel<<<dim3((unsigned)P->n_latent, (unsigned)B, (unsigned)((P->style_dim + 63) / 64)), dim3(256), 0, st>>>(k);
         if ((rc = check_launch("dec2 bwd d latent")) != 0) return finish(rc);
     }
 #undef DEC2_STEP

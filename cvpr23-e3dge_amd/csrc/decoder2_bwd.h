@@ -448,8 +448,8 @@ __global__ void __launch_bounds__(256) pkconv_down_kernel(const PkConvK a) {
 // dL/ds[ci] = (1 / s[ci]) sum_p act[ci,p] v[ci,p], v = ToRGB^T d rgb.  Everything is per-channel dot products of tensors the backward
 // has left in its workspace: for every activation tensor A (packed forward) with G = dL/d(pre) (packed gradient), mask gain m and v:
 //     dx = G / m - v,   S1 = sum_p A dx  (-> the 3x3 layer that CONSUMES A),   S2 = sum_p G y  (-> the layer that PRODUCED A),   S3 = sum_p A v  (-> A's ToRGB)
-// (pk_dstyle_sums_kernel: one streaming pass over A and G, fixed-order two-level reduction), then dL/dlatent = modulation^T dL/ds
-// (pk_dlatent_kernel; EqualLinear :234-244).
+// (pk_dstyle_sums_kernel: one streaming pass over A and G, per-chunk partials; pk_dstyle_fold_kernel: the chunks, fixed order), then dL/ds per
+// modulation row (pk_dstyle_kernel) and dL/dlatent = modulation^T dL/ds (pk_dlatent_kernel; EqualLinear :234-244).
 struct PkDsSumsK {
     const unsigned char* act; const unsigned char* g; const int* act_meta; const int* g_meta;
     const float* noise; const float* noise_w; const float* bias;      // of the PRODUCING layer (noise (noise_batch, R, R) or null)
@@ -477,6 +477,7 @@ __global__ void __launch_bounds__(256) pk_dstyle_sums_kernel(const PkDsSumsK a) 
     const float m_pos = a.act_scale, m_neg = a.act_scale * a.slope;
     float s1[8] = {}, s2[8] = {}, s3[8] = {};
     const int p_end = min((chunk + 1) * a.chunk, (int)hw);
+#pragma unroll 4                                                             // (four pixels' sixteen 16-byte loads in flight per thread)
     for (int p = chunk * a.chunk + tid; p < p_end; p += 256) {
         const int y = p / R, x = p - y * R;
         const int64_t e = (int64_t)(y + 1) * (R + 2) + x + 1;
@@ -531,62 +532,87 @@ __global__ void __launch_bounds__(256) pk_dot_planes_kernel(float* __restrict__ 
     if (threadIdx.x == 0) out[(int64_t)b * C + c] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// dL/dlatent[b][li][k] = sum over the table rows with latent_index == li of lin_scale sum_ci dL/ds[ci] mod_weight[ci][k]
-struct PkDsRow { const float* p1; const float* p2; int n1, n2, sum1; };      // sum1: 0 = S1, 2 = S3 of the partial layout, 3 = plain (b, ci) array
-struct PkDlatK { const E3dgeModLayer* tab; PkDsRow row[3 * E3DGE_DEC2_MAX_UP + 2]; int n_rows, n_latent, style_dim; float* d_latent; };
+// The fold of the chunk partials, one block per (tensor, sample, channel group): sums[(b * G + g) * 24 + v] = sum over chunks, ten slices of the
+// chunks summed by ten thread rows and folded in fixed order
+struct PkDsFoldT { const float* part; float* sums; int groups, n_chunks, first_block; };
+struct PkDsFoldK { PkDsFoldT t[2 * E3DGE_DEC2_MAX_UP + 2]; int n_tensors; };
+__global__ void __launch_bounds__(256) pk_dstyle_fold_kernel(const PkDsFoldK a) {
+    __shared__ float red[10][24];
+    int ti = 0;
+    while (ti + 1 < a.n_tensors && (int)blockIdx.x >= a.t[ti + 1].first_block) ++ti;
+    const PkDsFoldT t = a.t[ti];
+    const int bg = (int)blockIdx.x - t.first_block, tid = threadIdx.x;         // bg = b * groups + g
+    if (tid < 240) {
+        const int v = tid % 24, sl = tid / 24;
+        const float* __restrict__ pp = t.part + (int64_t)bg * t.n_chunks * 24 + v;
+        float acc = 0.0f;
+        for (int c = sl; c < t.n_chunks; c += 10) acc += pp[(int64_t)c * 24];
+        red[sl][v] = acc;
+    }
+    __syncthreads();
+    if (tid < 24) {
+        float acc = red[0][tid];
+#pragma unroll
+        for (int sl = 1; sl < 10; ++sl) acc += red[sl][tid];
+        t.sums[(int64_t)bg * 24 + tid] = acc;
+    }
+}
+
+// dL/ds of one modulation row (table rows of Decoder._mod_layers), one block per (row, sample):  ds[(b * n_rows + t) * 1024 + ci]
+struct PkDsRow { const float* p1; const float* p2; int sum1; };               // folded sums of the consumed / produced tensor; sum1: 0 = S1, 2 = S3, 3 = p1 is a plain (b, ci) array
+struct PkDsK { const E3dgeModLayer* tab; PkDsRow row[3 * E3DGE_DEC2_MAX_UP + 2]; int n_rows; float* ds; };
+__global__ void __launch_bounds__(256) pk_dstyle_kernel(const PkDsK a) {
+    __shared__ float r2[1024];
+    const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const E3dgeModLayer L = a.tab[t];
+    const PkDsRow rw = a.row[t];
+    const float* __restrict__ s = L.style_out + (size_t)b * L.ci;
+    const bool conv = L.demod_out != nullptr;
+    if (conv) {                                                             // r2[co] = demod^2 sum_p g y
+        for (int co = tid; co < L.co; co += 256) {
+            const float v = rw.p2[((int64_t)b * (L.co >> 3) + (co >> 3)) * 24 + 8 + (co & 7)];
+            const float dm = L.demod_out[(size_t)b * L.co + co];
+            r2[co] = dm * dm * v;
+        }
+    }
+    __syncthreads();
+    for (int ci = tid; ci < L.ci; ci += 256) {
+        const float r1 = rw.sum1 == 3 ? rw.p1[(int64_t)b * L.ci + ci] : rw.p1[((int64_t)b * (L.ci >> 3) + (ci >> 3)) * 24 + 8 * rw.sum1 + (ci & 7)];
+        const float sv = s[ci];
+        float d = fabsf(sv) > 1e-30f ? r1 / sv : 0.0f;
+        if (conv) {
+            float tb[4] = {0.f, 0.f, 0.f, 0.f};                              // four independent chains (co is a multiple of 32), folded in fixed order
+            for (int co = 0; co < L.co; co += 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tb[q] = fmaf(r2[co + q], L.wsq[(size_t)(co + q) * L.ci + ci], tb[q]);
+            }
+            d -= sv * ((tb[0] + tb[1]) + (tb[2] + tb[3]));
+        }
+        a.ds[((int64_t)b * a.n_rows + t) * 1024 + ci] = d;
+    }
+}
+
+// dL/dlatent[b][li][k] = sum over the table rows with latent_index == li of lin_scale sum_ci dL/ds[ci] mod_weight[ci][k]  (EqualLinear^T);
+// one block per (latent row, sample, 64 columns k): four thread rows take a quarter of the input channels each, folded in fixed order
+struct PkDlatK { const E3dgeModLayer* tab; const float* ds; int n_rows, n_latent, style_dim; float* d_latent; };
 __global__ void __launch_bounds__(256) pk_dlatent_kernel(const PkDlatK a) {
-    __shared__ float ds[1024], r2[1024];
-    const int li = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};                                   // k = tid + 256 q, style_dim <= 1024
+    __shared__ float red[4][64];
+    const int li = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, kk = tid & 63, q = tid >> 6;
+    const int k = (int)blockIdx.z * 64 + kk;
+    float acc = 0.0f;
     for (int t = 0; t < a.n_rows; ++t) {
         const E3dgeModLayer L = a.tab[t];
         if (L.latent_index != li) continue;                                // (block-uniform)
-        const PkDsRow rw = a.row[t];
-        const float* __restrict__ s = L.style_out + (size_t)b * L.ci;
-        const bool conv = L.demod_out != nullptr;
-        if (conv) {                                                         // r2[co] = demod^2 sum_p g y
-            for (int co = tid; co < L.co; co += 256) {
-                const float* pp = rw.p2 + ((int64_t)(b * (L.co >> 3) + (co >> 3)) * rw.n2) * 24 + 8 + (co & 7);
-                float v = 0.0f;
-                for (int c = 0; c < rw.n2; ++c) v += pp[(int64_t)c * 24];
-                const float dm = L.demod_out[(size_t)b * L.co + co];
-                r2[co] = dm * dm * v;
-            }
-        }
-        __syncthreads();
-        for (int ci = tid; ci < L.ci; ci += 256) {
-            float r1 = 0.0f;
-            if (rw.sum1 == 3) r1 = rw.p1[(int64_t)b * L.ci + ci];
-            else {
-                const float* pp = rw.p1 + ((int64_t)(b * (L.ci >> 3) + (ci >> 3)) * rw.n1) * 24 + 8 * rw.sum1 + (ci & 7);
-                for (int c = 0; c < rw.n1; ++c) r1 += pp[(int64_t)c * 24];
-            }
-            const float sv = s[ci];
-            float d = fabsf(sv) > 1e-30f ? r1 / sv : 0.0f;
-            if (conv) {
-                float tb = 0.0f;
-                for (int co = 0; co < L.co; ++co) tb = fmaf(r2[co], L.wsq[(size_t)co * L.ci + ci], tb);
-                d -= sv * tb;
-            }
-            ds[ci] = d;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = tid + 256 * q;
-            if (k < a.style_dim) {
-                float v = 0.0f;
-                for (int ci = 0; ci < L.ci; ++ci) v = fmaf(ds[ci], L.mod_weight[(size_t)ci * a.style_dim + k], v);
-                acc[q] = fmaf(v, L.lin_scale, acc[q]);
-            }
-        }
-        __syncthreads();
+        const float* __restrict__ ds = a.ds + ((int64_t)b * a.n_rows + t) * 1024;
+        const int per = (L.ci + 3) >> 2, c0 = q * per, c1 = min(L.ci, c0 + per);
+        float v = 0.0f;
+        if (k < a.style_dim)
+            for (int ci = c0; ci < c1; ++ci) v = fmaf(ds[ci], L.mod_weight[(size_t)ci * a.style_dim + k], v);
+        acc = fmaf(v, L.lin_scale, acc);
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k = tid + 256 * q;
-        if (k < a.style_dim) a.d_latent[((int64_t)b * a.n_latent + li) * a.style_dim + k] = acc[q];
-    }
+    red[q][kk] = acc;
+    __syncthreads();
+    if (q == 0 && k < a.style_dim) a.d_latent[((int64_t)b * a.n_latent + li) * a.style_dim + k] = (red[0][kk] + red[1][kk]) + (red[2][kk] + red[3][kk]);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------------

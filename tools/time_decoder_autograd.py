@@ -16,7 +16,8 @@ from e3dge_amd.stylesdf_model import G_pred_latents  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1)
-ap.add_argument("--latent-grad", action="store_true", help="also time the round-4 shape (latent requires grad too: library path)")
+ap.add_argument("--latent-grad", action="store_true", help="also time the shape with the latent trainable too (native since round 5: per-channel sums)")
+ap.add_argument("--only-latent", action="store_true", help="profiling: run only the packed forward + backward with d latent, 20 times")
 args = ap.parse_args()
 dev = "cuda:0"
 g = G_pred_latents(syn.model_opt(), syn.rendering_opt(N_samples=24), full_pipeline=True)
@@ -44,6 +45,14 @@ def timed(fn, n=20):
 
 
 res = {}
+if args.only_latent:
+    def fwd_bwd_l0():
+        f = feats.detach().requires_grad_(True)
+        l = wd.detach().requires_grad_(True)
+        img, _ = dec(f, [l], input_is_latent=True, randomize_noise=False)
+        torch.autograd.grad(img, [f, l], gy)
+    print(json.dumps({"forward_backward_with_d_latent_ms": round(timed(fwd_bwd_l0), 4)}))
+    sys.exit(0)
 for backend in ("auto", "library"):
     os.environ["E3DGE_DECODER_AUTOGRAD"] = backend
 
