@@ -628,6 +628,8 @@ __global__ void __launch_bounds__(kThreads) resblock_kernel(const ResblockK a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#include "resblock_bwd.h"
+
 }  // namespace e3dge
 
 using namespace e3dge;
@@ -677,6 +679,42 @@ extern "C" int e3dge_tex_modulations_fwd(const float* packed, const float* feats
     ResblockK k{};
     k.packed = packed; k.feats = feats; k.alpha = alpha; k.beta = beta; k.n_pts = n_pts; k.cin = cin;
     return launch_resblock(k, false, as_stream(stream), "tex_modulations_fwd");
+}
+
+extern "C" int64_t e3dge_resblock_bwd_packed_floats(void) { return kRbBPackedFloats; }
+
+extern "C" int e3dge_resblock_bwd_pack_weights(float* packed, const float* w0, const float* b0, const float* w1, const float* ws, int cin,
+                                               e3dge_stream_t stream) {
+    E3DGE_REQUIRE(packed && w0 && b0 && w1 && ws, "resblock_bwd_pack_weights: null pointer");
+    E3DGE_REQUIRE(cin >= 1 && cin <= kRbKin, "resblock_bwd_pack_weights: cin=%d outside [1, %d]", cin, kRbKin);
+    resblock_bwd_pack_kernel<<<dim3(1024), dim3(256), 0, as_stream(stream)>>>(packed, w0, b0, w1, ws, cin);
+    return check_launch("resblock_bwd_pack_weights");
+}
+
+extern "C" int64_t e3dge_tex_modulations_bwd_ws_floats(int64_t n_pts) { return n_pts > 0 ? 2 * n_pts * (int64_t)kRbWsRow : 0; }
+
+extern "C" int e3dge_tex_modulations_bwd(const float* packed_bwd, const float* feats, int cin, int64_t n_pts, const float* d_alpha,
+                                         const float* d_beta, float* d_feats, float* ws, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(n_pts >= 0, "tex_modulations_bwd: bad size");
+    if (n_pts == 0) return E3DGE_OK;
+    E3DGE_REQUIRE(packed_bwd && feats && d_alpha && d_beta && d_feats && ws, "tex_modulations_bwd: null pointer");
+    E3DGE_REQUIRE(cin >= 1 && cin <= kRbKin, "tex_modulations_bwd: cin=%d outside [1, %d]", cin, kRbKin);
+    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed_bwd) | reinterpret_cast<uintptr_t>(d_alpha) | reinterpret_cast<uintptr_t>(d_beta) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0,
+                  "tex_modulations_bwd: packed / d_alpha / d_beta / ws must be 16-B aligned");
+    E3DGE_REQUIRE(n_pts * (int64_t)kRbWsRow * 4 < ((int64_t)1 << 32) * 1024, "tex_modulations_bwd: too many points");
+    ResblockBwdK k{};
+    k.packed = packed_bwd; k.feats = feats; k.d_alpha = d_alpha; k.d_beta = d_beta; k.d_feats = d_feats; k.ws = ws;
+    k.n_pts = n_pts; k.cin = cin;
+    hipStream_t st = as_stream(stream);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kRbBLdsBytes);
+    if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(resblock_bwd): %s", hipGetErrorString(e));
+    const int64_t tiles = (n_pts + kTilePts - 1) / kTilePts;
+    const int spw = pick_subtiles_per_wg(tiles, 1);
+    k.subtiles_per_wg = spw;
+    const int64_t grid = (tiles + spw - 1) / spw;
+    E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "tex_modulations_bwd: grid too large");
+    resblock_bwd_kernel<<<dim3((unsigned)grid), dim3(kThreads), kRbBLdsBytes, st>>>(k);
+    return check_launch("tex_modulations_bwd");
 }
 
 extern "C" int e3dge_tex_film_fwd(const float* packed, const float* feats, int cin, int batch, int height, int width, int n_samples,

@@ -687,13 +687,24 @@ def _resblock_backward_torch(x, w0, b0, w1, ws, dy):
     return dx, dnet.t() @ r0, dnet.sum(0), dy.t() @ r1, dy.sum(0), dy.t() @ x
 
 
+def tex_head_backward_backend():
+    """E3DGE_TEXHEAD_BWD = hip (default: e3dge_tex_modulations_bwd, one launch) | library (round 4's GEMM chain with recomputation)."""
+    v = os.environ.get("E3DGE_TEXHEAD_BWD", "hip").lower()
+    if v not in ("hip", "library"):
+        raise ValueError(f"E3DGE_TEXHEAD_BWD={v!r}: expected hip or library")
+    return v
+
+
 class _TexHead(torch.autograd.Function):
     """The fused texture head with a backward (stage-2 training differentiates the second pass,
-    e3dge_full_runner.py:185-317): forward = e3dge_tex_modulations_fwd, backward = GPU library GEMMs with recomputation."""
+    e3dge_full_runner.py:185-317): forward = e3dge_tex_modulations_fwd; backward = e3dge_tex_modulations_bwd for the data gradient (round 5:
+    one launch, net recomputed inside, d net left in the workspace) + library GEMMs on (d net, relu(x), relu(net), d out, x) for whichever
+    parameter gradients are wanted.  E3DGE_TEXHEAD_BWD=library restores round 4's chain of library GEMMs."""
 
     @staticmethod
     def forward(ctx, feats2d, block, w0, b0, w1, b1, ws):
         ctx.save_for_backward(feats2d, w0, b0, w1, ws)
+        ctx.block = block
         return block._launch(feats2d)
 
     @staticmethod
@@ -704,11 +715,29 @@ class _TexHead(torch.autograd.Function):
             d_alpha = torch.zeros_like(d_beta)
         if d_beta is None:
             d_beta = torch.zeros_like(d_alpha)
-        dy = torch.cat([d_alpha, d_beta], -1).contiguous()
-        dx, dw0, db0, dw1, db1, dws = _resblock_backward_torch(x, w0, b0, w1, ws, dy)
         need = ctx.needs_input_grad
-        return (dx if need[0] else None, None, dw0 if need[2] else None, db0 if need[3] else None,
-                dw1 if need[4] else None, db1 if need[5] else None, dws if need[6] else None)
+        if tex_head_backward_backend() == "library" or x.shape[0] == 0:
+            dy = torch.cat([d_alpha, d_beta], -1).contiguous()
+            dx, dw0, db0, dw1, db1, dws = _resblock_backward_torch(x, w0, b0, w1, ws, dy)
+            return (dx if need[0] else None, None, dw0 if need[2] else None, db0 if need[3] else None,
+                    dw1 if need[4] else None, db1 if need[5] else None, dws if need[6] else None)
+        d_alpha, d_beta = d_alpha.contiguous().float(), d_beta.contiguous().float()
+        dx, dnet = ctx.block._launch_bwd(x, d_alpha, d_beta)
+        dw0 = db0 = dw1 = db1 = dws = None
+        if need[2] or need[4]:
+            r0 = torch.relu(x)
+        if need[2]:
+            dw0 = dnet.t() @ r0
+        if need[3]:
+            db0 = dnet.sum(0)
+        if need[4]:
+            r1 = torch.relu(torch.addmm(b0, r0, w0.t()))
+            dw1 = torch.cat([d_alpha.t() @ r1, d_beta.t() @ r1], 0)
+        if need[5]:
+            db1 = torch.cat([d_alpha.sum(0), d_beta.sum(0)], 0)
+        if need[6]:
+            dws = torch.cat([d_alpha.t() @ x, d_beta.t() @ x], 0)
+        return (dx if need[0] else None, None, dw0, db0, dw1, db1, dws)
 
 
 class ResnetBlockFC(nn.Module):
@@ -731,8 +760,9 @@ class ResnetBlockFC(nn.Module):
         self._cache = None
 
     def invalidate(self):
-        """Drop the packed weight image (needed after writes through `.data`; see SirenGenerator.invalidate)."""
+        """Drop the packed weight images (needed after writes through `.data`; see SirenGenerator.invalidate)."""
         self._cache = self._cache_key = None
+        self._cache_bwd = self._cache_bwd_key = None
 
     def _apply(self, fn, *a, **k):
         self.invalidate()
@@ -760,6 +790,41 @@ class ResnetBlockFC(nn.Module):
                 raise RuntimeError(f"texture-head weights up to {wmax:g} do not fit the f16x3 weight image (|w| < 500)")
             self._cache, self._cache_key = packed, key
         return self._cache
+
+    def device_image_bwd(self):
+        """The backward's weight image (W_0, W_1^T, W_s^T, W_0^T chunks + b_0), rebuilt when a parameter changes."""
+        ps = [self.fc_0.weight, self.fc_0.bias, self.fc_1.weight, self.shortcut.weight]
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in ps)
+        if key != getattr(self, "_cache_bwd_key", None) or getattr(self, "_cache_bwd", None) is None:
+            dev = ps[0].device
+            _lib.require_gpu(ps[0], "ResnetBlockFC weights")
+            lib = _lib.load()
+            packed = torch.empty(lib.e3dge_resblock_bwd_packed_floats(), device=dev, dtype=torch.float32)
+            c = [p.detach().contiguous().float() for p in ps]
+            with _lib.on_device(dev):
+                rc = lib.e3dge_resblock_bwd_pack_weights(_lib.ptr(packed), *[_lib.ptr(t) for t in c], self.size_in,
+                                                         torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(rc, "e3dge_resblock_bwd_pack_weights")
+            wmax = max(float(t.abs().max().item()) for t in (c[0], c[2], c[3]))
+            if wmax >= 500.0:
+                raise RuntimeError(f"texture-head weights up to {wmax:g} do not fit the f16x3 weight image (|w| < 500)")
+            self._cache_bwd, self._cache_bwd_key = packed, key
+        return self._cache_bwd
+
+    def _launch_bwd(self, x, d_alpha, d_beta):
+        """x (n, size_in), d_alpha / d_beta (n, 256), contiguous fp32 on the GPU -> (d x (n, size_in), d net (n, size_in) view of the workspace)."""
+        _lib.require_gpu(x, "feats")
+        n = x.shape[0]
+        lib = _lib.load()
+        packed = self.device_image_bwd()
+        x = x.contiguous()
+        dx = torch.empty_like(x)
+        ws = torch.empty(lib.e3dge_tex_modulations_bwd_ws_floats(n), device=x.device, dtype=torch.float32)
+        with _lib.on_device(x.device):
+            rc = lib.e3dge_tex_modulations_bwd(_lib.ptr(packed), _lib.ptr(x), self.size_in, n, _lib.ptr(d_alpha), _lib.ptr(d_beta),
+                                               _lib.ptr(dx), _lib.ptr(ws), _lib.stream_of(x))
+        _lib.check(rc, "e3dge_tex_modulations_bwd")
+        return dx, ws[:n * 320].view(n, 320)[:, :self.size_in]
 
     def forward(self, x):
         """(.., size_in) -> (.., 512) like the reference module."""

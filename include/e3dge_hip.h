@@ -542,6 +542,19 @@ int e3dge_resblock_pack_weights(float* packed, const float* w0, const float* b0,
                                 const float* ws, int cin, e3dge_stream_t stream);
 int e3dge_tex_modulations_fwd(const float* packed, const float* feats, int cin, int64_t n_pts,
                               float* alpha, float* beta, e3dge_stream_t stream);
+/* Data gradient of the head (round 5): d feats = W_s^T d out + (W_0^T ((W_1^T d out) [net > 0])) [x > 0], d out = [d alpha | d beta] -- what
+ * autograd runs through ResnetBlockFC (helper_modules/resnetfc.py:49-58) for the stage-2 losses (e3dge_full_runner.py:185-317); the reference
+ * has no hand-written backward.  One launch, split-f16 contractions like the forward; net is recomputed (signs only).
+ *   packed_bwd   e3dge_resblock_bwd_packed_floats() floats from e3dge_resblock_bwd_pack_weights (W_0, W_1^T, W_s^T, W_0^T images + b_0)
+ *   d_alpha, d_beta (n_pts, 256), 16-byte aligned     d_feats (n_pts, cin) out
+ *   ws           e3dge_tex_modulations_bwd_ws_floats(n_pts) floats, 16-byte aligned; on return ws[0 .. n_pts * 320) holds d net = d L / d (fc_0
+ *                output) as (n_pts, 320) rows (columns >= cin are zero) -- the operand of the parameter gradients, which stay library GEMMs */
+int64_t e3dge_resblock_bwd_packed_floats(void);
+int e3dge_resblock_bwd_pack_weights(float* packed_bwd, const float* w0, const float* b0, const float* w1, const float* ws, int cin,
+                                    e3dge_stream_t stream);
+int64_t e3dge_tex_modulations_bwd_ws_floats(int64_t n_pts);
+int e3dge_tex_modulations_bwd(const float* packed_bwd, const float* feats, int cin, int64_t n_pts, const float* d_alpha, const float* d_beta,
+                              float* d_feats, float* ws, e3dge_stream_t stream);
 /* The head INSIDE the second render pass's data flow (ABI 11; SURVEY.md 8 f1 as specified: (alpha, beta) never materialise):
  * feats (batch, height, width, n_samples, cin) -> h' = (alpha + 1) h8 + beta, where h8 is the layer-7 output that render
  * pass #1 left in `backbone_in` (e3dge_siren_render_fwd backbone_out, e3dge_siren_backbone_bytes bytes) -- the FiLM step of

@@ -131,6 +131,87 @@ def test_texhead_backward_against_f64_autograd():
     assert max(errs.values()) <= 2e-5, errs
 
 
+def _head_grads(h, feats, ga, gb, params=False):
+    f = feats.detach().clone().requires_grad_(True)
+    for p_ in h.parameters():
+        p_.requires_grad_(params)
+        p_.grad = None
+    a, b = h.tex_modulations(f)
+    ((a * ga).sum() + (b * gb).sum()).backward()
+    return f.grad, {n: p_.grad for n, p_ in h.named_parameters()} if params else {}
+
+
+@pytest.mark.parametrize("cin,n", [(301, 1), (301, 127), (301, 129), (301, 1000), (320, 257), (64, 300), (5, 3), (3, 1), (1, 70)])
+def test_texhead_data_gradient_kernel_sizes(cin, n, monkeypatch):
+    """e3dge_tex_modulations_bwd (round 5) on ragged sizes: row ends that are not 16-byte aligned, fewer rows than a tile, the tensor's last rows
+    (clamped reads), cin below one quad.  Against float64 autograd of the oracle (2e-5 of the gradient's maximum + the relu-branch allowance
+    below) and against round 4's library chain on the same inputs."""
+    h, sd = make_head(cin)
+    rs = np.random.RandomState(cin + n)
+    feats = torch.from_numpy(rs.standard_normal((n, cin)).astype(np.float32)).to(DEV)
+    ga = torch.from_numpy(rs.standard_normal((n, 256)).astype(np.float32)).to(DEV)
+    gb = torch.from_numpy(rs.standard_normal((n, 256)).astype(np.float32)).to(DEV)
+    g_hip, _ = _head_grads(h, feats, ga, gb)
+    monkeypatch.setenv("E3DGE_TEXHEAD_BWD", "library")
+    g_lib, _ = _head_grads(h, feats, ga, gb)
+    monkeypatch.delenv("E3DGE_TEXHEAD_BWD")
+    sd64 = {k: v.double() for k, v in sd.items()}
+    f64 = feats.cpu().double().requires_grad_(True)
+    ta, tb = renderer_ref.tex_modulations(sd64, PREFIX, f64, dtype=torch.float64)
+    ((ta * ga.cpu().double()).sum() + (tb * gb.cpu().double()).sum()).backward()
+    scale = float(f64.grad.abs().max())
+    e_hip = float((g_hip.cpu().double() - f64.grad).abs().max()) / scale
+    e_lib = float((g_lib.cpu().double() - f64.grad).abs().max()) / scale
+    record("texhead_bwd_sizes", cin=cin, n=n, hip_vs_f64=e_hip, library_vs_f64=e_lib)
+    assert torch.isfinite(g_hip).all() and g_hip.shape == (n, cin)
+    # a hidden unit within rounding of 0 may take the other relu branch than float64 does (the library chain has the same freedom): allow what
+    # the fp32 library path shows on the same inputs
+    assert e_hip <= max(2e-5, 2 * e_lib), (e_hip, e_lib)
+
+
+@pytest.mark.parametrize("mag_x,mag_g", [(1e-3, 1e-6), (1.0, 1e4), (50.0, 1e-2), (1e3, 1.0)])
+def test_texhead_data_gradient_magnitudes(mag_x, mag_g):
+    """Block scaling of the three operands (x, d out, d net) over ten orders of magnitude, rows of very different size in one tile."""
+    h, sd = make_head(301)
+    rs = np.random.RandomState(17)
+    n = 300
+    row = torch.from_numpy(np.exp(rs.uniform(-6, 6, (n, 1))).astype(np.float32)).to(DEV)
+    feats = mag_x * torch.from_numpy(rs.standard_normal((n, 301)).astype(np.float32)).to(DEV)
+    ga = mag_g * row * torch.from_numpy(rs.standard_normal((n, 256)).astype(np.float32)).to(DEV)
+    gb = mag_g * row * torch.from_numpy(rs.standard_normal((n, 256)).astype(np.float32)).to(DEV)
+    g_hip, _ = _head_grads(h, feats, ga, gb)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    f64 = feats.cpu().double().requires_grad_(True)
+    ta, tb = renderer_ref.tex_modulations(sd64, PREFIX, f64, dtype=torch.float64)
+    ((ta * ga.cpu().double()).sum() + (tb * gb.cpu().double()).sum()).backward()
+    rel = ((g_hip.cpu().double() - f64.grad).abs().amax(1) / f64.grad.abs().amax(1).clamp_min(1e-300))       # per point: every row has its own scale
+    record("texhead_bwd_magnitudes", mag_x=mag_x, mag_g=mag_g, worst_row=float(rel.max()), median_row=float(rel.median()))
+    assert float(rel.median()) <= 2e-6 and float((rel > 2e-5).double().mean()) <= 0.02, (float(rel.max()), float(rel.median()))
+
+
+def test_texhead_backward_zero_initialised_head_and_parameter_gradients(monkeypatch):
+    """The reference initialises the head to zero (HGPIFuGANNetResidualInputResnetFC.py:88-93): d feats = 0 exactly, and the parameter gradients
+    (library GEMMs on the kernel's d net) equal the library chain's."""
+    h = ResnetBlockFC(301, 512).to(DEV)
+    rs = np.random.RandomState(3)
+    feats = torch.from_numpy(rs.standard_normal((200, 301)).astype(np.float32)).to(DEV)
+    ga = torch.from_numpy(rs.standard_normal((200, 256)).astype(np.float32)).to(DEV)
+    gb = torch.from_numpy(rs.standard_normal((200, 256)).astype(np.float32)).to(DEV)
+    g0, p0 = _head_grads(h, feats, ga, gb, params=True)
+    assert float(g0.abs().max()) == 0.0
+    h2, _ = make_head(301)
+    g_hip, p_hip = _head_grads(h2, feats, ga, gb, params=True)
+    monkeypatch.setenv("E3DGE_TEXHEAD_BWD", "library")
+    g_lib, p_lib = _head_grads(h2, feats, ga, gb, params=True)
+    errs = {"feats": float((g_hip - g_lib).abs().max() / g_lib.abs().max())}
+    for k in p_lib:
+        errs[k] = float((p_hip[k] - p_lib[k]).abs().max() / p_lib[k].abs().max().clamp_min(1e-30))
+    record("texhead_bwd_hip_vs_library", **errs)
+    assert max(errs.values()) <= 2e-5, errs
+    for p_ in h2.parameters():
+        p_.requires_grad_(True)
+
+
 def test_second_pass_from_local_feats():
     """VolumeFeatureRenderer.forward with local_data_batch={'feats': ...} (the reference's second pass with already
     queried local features, :434-437 + :327-336 + :217-220) == the oracle's render with the oracle's (alpha, beta)."""
