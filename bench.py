@@ -772,7 +772,7 @@ def main():
                         ag["fuse_sft_" + be + "_fwd_bwd_ms"] = ev_fb(fb2)
                     finally:
                         os.environ.pop("E3DGE_FUSE_AUTOGRAD", None)
-                try:        # the texture head (ResnetBlockFC 301 -> 512 on 98,304 points) under autograd: native forward, library backward
+                try:        # the texture head (ResnetBlockFC 301 -> 512 on 98,304 points) under autograd: native forward, e3dge_tex_modulations_bwd (round 5) vs library GEMMs
                     head_ = gl.renderer.network.netLocal.local_feat_to_tex_modulations_linear
                     f_h = feats.detach().clone()
 
@@ -781,6 +781,11 @@ def main():
                         al_, be_ = head_.tex_modulations(x_)
                         (al_.square().mean() + be_.square().mean()).backward()
                     ag["tex_head_fwd_bwd_ms"] = ev_fb(fb3)
+                    os.environ["E3DGE_TEXHEAD_BWD"] = "library"
+                    try:
+                        ag["tex_head_library_fwd_bwd_ms"] = ev_fb(fb3)
+                    finally:
+                        os.environ.pop("E3DGE_TEXHEAD_BWD", None)
                     with torch.no_grad():
                         ag["tex_head_fwd_ms"] = ev_fb(lambda: head_.tex_modulations(f_h))
                 except Exception as exc:                                  # noqa: BLE001
