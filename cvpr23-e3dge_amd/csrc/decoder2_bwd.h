@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(256) pk_dstyle_sums_kernel(const PkDsSumsK a) 
 #pragma unroll
         for (int c = 0; c < 3; ++c) w[c][j] = a.wm ? a.wm[((size_t)b * 3 + c) * a.C + 8 * g + j] : 0.0f;
     }
-    const float m_pos = a.act_scale, m_neg = a.act_scale * a.slope;
+    const float i_pos = 1.0f / a.act_scale, i_neg = 1.0f / (a.act_scale * a.slope);          // (a division per element is ~10 instructions)
     float s1[8] = {}, s2[8] = {}, s3[8] = {};
     const int p_end = min((chunk + 1) * a.chunk, (int)hw);
 #pragma unroll 4                                                             // (four pixels' sixteen 16-byte loads in flight per thread)
@@ -491,12 +491,12 @@ __global__ void __launch_bounds__(256) pk_dstyle_sums_kernel(const PkDsSumsK a) 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const unsigned hb = (ah[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-            const float m = (hb - 1u < 0x7fffu) ? m_pos : m_neg;                        // the backward's own branch test
+            const float im = (hb - 1u < 0x7fffu) ? i_pos : i_neg;                       // the backward's own branch test
             const float av = ((j & 1) ? f16hi(ah[j >> 1]) + f16hi(al[j >> 1]) : f16lo(ah[j >> 1]) + f16lo(al[j >> 1])) * inv_a;
             const float gv = ((j & 1) ? f16hi(gh[j >> 1]) + f16hi(gl[j >> 1]) : f16lo(gh[j >> 1]) + f16lo(gl[j >> 1])) * inv_g;
             const float v = fmaf(w[2][j], d[2], fmaf(w[1][j], d[1], w[0][j] * d[0]));
-            const float yv = av / m - nzv - bs[j];
-            s1[j] = fmaf(av, gv / m - v, s1[j]);
+            const float yv = av * im - nzv - bs[j];
+            s1[j] = fmaf(av, gv * im - v, s1[j]);
             s2[j] = fmaf(gv, yv, s2[j]);
             s3[j] = fmaf(av, v, s3[j]);
         }
@@ -582,9 +582,12 @@ __global__ void __launch_bounds__(256) pk_dstyle_kernel(const PkDsK a) {
         float d = fabsf(sv) > 1e-30f ? r1 / sv : 0.0f;
         if (conv) {
             float tb[4] = {0.f, 0.f, 0.f, 0.f};                              // four independent chains (co is a multiple of 32), folded in fixed order
-            for (int co = 0; co < L.co; co += 4) {
+            for (int co = 0; co < L.co; co += 16) {                          // sixteen loads in flight: the loop is latency-, not bandwidth-bound
+                float w[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) tb[q] = fmaf(r2[co + q], L.wsq[(size_t)(co + q) * L.ci + ci], tb[q]);
+                for (int q = 0; q < 16; ++q) w[q] = L.wsq[(size_t)(co + q) * L.ci + ci];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) tb[q & 3] = fmaf(r2[co + q], w[q], tb[q & 3]);
             }
             d -= sv * ((tb[0] + tb[1]) + (tb[2] + tb[3]));
         }
@@ -606,8 +609,17 @@ __global__ void __launch_bounds__(256) pk_dlatent_kernel(const PkDlatK a) {
         const float* __restrict__ ds = a.ds + ((int64_t)b * a.n_rows + t) * 1024;
         const int per = (L.ci + 3) >> 2, c0 = q * per, c1 = min(L.ci, c0 + per);
         float v = 0.0f;
-        if (k < a.style_dim)
-            for (int ci = c0; ci < c1; ++ci) v = fmaf(ds[ci], L.mod_weight[(size_t)ci * a.style_dim + k], v);
+        if (k < a.style_dim) {
+            int ci = c0;
+            for (; ci + 8 <= c1; ci += 8) {                                // eight loads in flight (latency-bound otherwise); same summation order
+                float w[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) w[q] = L.mod_weight[(size_t)(ci + q) * a.style_dim + k];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v = fmaf(ds[ci + q], w[q], v);
+            }
+            for (; ci < c1; ++ci) v = fmaf(ds[ci], L.mod_weight[(size_t)ci * a.style_dim + k], v);
+        }
         acc = fmaf(v, L.lin_scale, acc);
     }
     red[q][kk] = acc;
