@@ -110,6 +110,12 @@ class WsLinear(ctypes.Structure):
         ("reserved", _i32)]
 
 
+class Wgrad(ctypes.Structure):
+    """Mirror of struct E3dgeWgrad (include/e3dge_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("a", "amax_a", "b", "amax_b", "c", "ws")] + [("ws_floats", _i64), ("n_rows", _i64)] + [
+        (n, _i32) for n in ("lda", "off_a", "m", "ldb", "off_b", "n", "ldc", "relu_b")]
+
+
 # include/e3dge_hip_experimental.h: -DE3DGE_EXPERIMENTAL builds (tools/build_variant.sh) carry two more precision modes; no extra symbols
 EXPERIMENTAL_SIGNATURES = {}
 
@@ -172,7 +178,9 @@ SIGNATURES = {
     "e3dge_resblock_bwd_packed_floats": (_i64, []),
     "e3dge_resblock_bwd_pack_weights": (_i32, [_vp] * 5 + [_i32, _vp]),
     "e3dge_tex_modulations_bwd_ws_floats": (_i64, [_i64]),
-    "e3dge_tex_modulations_bwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "e3dge_tex_modulations_bwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "e3dge_wgrad_ws_floats": (_i64, [_i32, _i32, _i64]),
+    "e3dge_wgrad": (_i32, [_vp, _vp]),
     "e3dge_local_query": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "e3dge_local_query_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "e3dge_pos_encoding": (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _vp]),

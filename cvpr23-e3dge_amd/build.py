@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libe3dge_hip.so"
-SOURCES = ["stream_ops.hip", "upfirdn2d.hip", "siren.hip", "siren_bwd.hip", "resblock.hip", "modconv.hip", "decoder2.hip", "local_query.hip", "metrics.hip", "align_volume.hip", "hitprob.hip", "siren_ws.hip"]
+SOURCES = ["stream_ops.hip", "upfirdn2d.hip", "siren.hip", "siren_bwd.hip", "resblock.hip", "modconv.hip", "decoder2.hip", "local_query.hip", "metrics.hip", "align_volume.hip", "hitprob.hip", "siren_ws.hip", "wgrad.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=on", "-fno-slp-vectorize",
          "-Wno-unused-result"]  # no SLP: packed-f32 VALU next to MFMAs is slower and un-does the epilogue interleave

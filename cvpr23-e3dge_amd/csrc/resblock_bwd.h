@@ -113,6 +113,7 @@ struct ResblockBwdK {
     const float* d_beta;
     float* d_feats;             // (n_pts, cin) out
     float* ws;                  // 2 x (n_pts, 320): d net (valid on return, rows padded to 320) | W_s^T d out
+    float* net_out;             // null, or (n_pts, 320): net as recomputed by G1
     long long n_pts;
     int cin, subtiles_per_wg;
 };
@@ -277,8 +278,13 @@ __global__ void __launch_bounds__(kThreads) resblock_bwd_kernel(const ResblockBw
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4*>(b0_s + 32 * t + 8 * q + 4 * half);
+                    f32x4 nv;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) rb_push_sign(word, (P0[4 * q + j] + P1[4 * q + j]) * inv_x + b4[j]);     // the forward's expression for net
+                    for (int j = 0; j < 4; ++j) {
+                        nv[j] = (P0[4 * q + j] + P1[4 * q + j]) * inv_x + b4[j];      // the forward's expression for net
+                        rb_push_sign(word, nv[j]);
+                    }
+                    if (a.net_out && valid) *reinterpret_cast<f32x4*>(a.net_out + (pt0 * kRbWsRow + row_off + 32u * t + 8 * q)) = nv;
                 }
                 if (t & 1) { msk[((kRbTilesIn / 2) + (t >> 1)) * kThreads + tid] = word; word = 0u; }
             }

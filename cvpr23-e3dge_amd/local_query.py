@@ -409,19 +409,29 @@ class _FuseFn(torch.autograd.Function):
             # gradients (reductions over the points: library GEMMs with K = number of points) only when a parameter wants one
             dz1, dz2, de, dnet, dx = ctx.mod._fuse_bwd_native(g, x, net, s1, t1, scale, ctx.am_x, w, b_off, slope, need_x)
             if any(need):
+                # the seven weight gradients: e3dge_wgrad (split-f16 MFMA, split over the points, fixed-order fold; E3DGE_WGRAD=library = matmul),
+                # the relu of a layer's input folded into the operand load
+                from .wgrad import amax_of, wgrad
                 d_scale, d_shift = (w * g) * dec, w * g
-                if need[7]: gp[7] = mm(d_scale, s1)
+                am = {}
+
+                def wg(a_, b_, relu=False):
+                    for t_ in (a_, b_):
+                        if id(t_) not in am:
+                            am[id(t_)] = amax_of(t_)
+                    return wgrad(a_, b_, relu_b=relu, amax_a=am[id(a_)], amax_b=am[id(b_)])
+                if need[7]: gp[7] = wg(d_scale, s1)
                 if need[8]: gp[8] = d_scale.sum(0)
-                if need[11]: gp[11] = mm(d_shift, t1)
+                if need[11]: gp[11] = wg(d_shift, t1)
                 if need[12]: gp[12] = d_shift.sum(0)
-                if need[5]: gp[5] = mm(dz1, e)
+                if need[5]: gp[5] = wg(dz1, e)
                 if need[6]: gp[6] = dz1.sum(0)
-                if need[9]: gp[9] = mm(dz2, e)
+                if need[9]: gp[9] = wg(dz2, e)
                 if need[10]: gp[10] = dz2.sum(0)
-                if need[2]: gp[2] = mm(de, torch.relu(net))
+                if need[2]: gp[2] = wg(de, net, True)
                 if need[3]: gp[3] = de.sum(0)
-                if need[4]: gp[4] = mm(de, x)
-                if need[0]: gp[0] = mm(dnet, torch.relu(x))
+                if need[4]: gp[4] = wg(de, x)
+                if need[0]: gp[0] = wg(dnet, x, True)
                 if need[1]: gp[1] = dnet.sum(0)
             return (None, dx.reshape(ctx.in_shape) if dx is not None else None, None, *gp)
         d_scale, d_shift = (w * g) * dec, w * g                   # out = dec + w (dec scale + shift)

@@ -721,22 +721,29 @@ class _TexHead(torch.autograd.Function):
             dx, dw0, db0, dw1, db1, dws = _resblock_backward_torch(x, w0, b0, w1, ws, dy)
             return (dx if need[0] else None, None, dw0 if need[2] else None, db0 if need[3] else None,
                     dw1 if need[4] else None, db1 if need[5] else None, dws if need[6] else None)
+        from .wgrad import amax_of, wgrad
         d_alpha, d_beta = d_alpha.contiguous().float(), d_beta.contiguous().float()
-        dx, dnet = ctx.block._launch_bwd(x, d_alpha, d_beta)
+        dx, dnet_p, net_p = ctx.block._launch_bwd(x, d_alpha, d_beta, want_net=need[4])      # (n, 320) rows, columns >= cin zero
         dw0 = db0 = dw1 = db1 = dws = None
-        if need[2] or need[4]:
-            r0 = torch.relu(x)
+        cin = x.shape[1]
+        dnet = dnet_p[:, :cin]
+        am_x = amax_of(x) if (need[2] or need[6]) else None
+        am_a, am_b = (amax_of(d_alpha), amax_of(d_beta)) if (need[4] or need[6]) else (None, None)
         if need[2]:
-            dw0 = dnet.t() @ r0
+            dw0 = wgrad(dnet, x, relu_b=True, amax_a=amax_of(dnet_p), amax_b=am_x)     # d net^T relu(x)
         if need[3]:
-            db0 = dnet.sum(0)
-        if need[4]:
-            r1 = torch.relu(torch.addmm(b0, r0, w0.t()))
-            dw1 = torch.cat([d_alpha.t() @ r1, d_beta.t() @ r1], 0)
+            db0 = dnet_p.sum(0)[:cin]                                             # (the contiguous rows: a strided view reduces 25x slower)
+        if need[4]:                                                               # d out^T relu(net), net as the backward kernel recomputed it
+            dw1 = torch.empty((512, cin), device=x.device, dtype=torch.float32)
+            am_n, net = amax_of(net_p), net_p[:, :cin]
+            wgrad(d_alpha, net, relu_b=True, amax_a=am_a, amax_b=am_n, out=dw1[:256])
+            wgrad(d_beta, net, relu_b=True, amax_a=am_b, amax_b=am_n, out=dw1[256:])
         if need[5]:
             db1 = torch.cat([d_alpha.sum(0), d_beta.sum(0)], 0)
         if need[6]:
-            dws = torch.cat([d_alpha.t() @ x, d_beta.t() @ x], 0)
+            dws = torch.empty((512, cin), device=x.device, dtype=torch.float32)
+            wgrad(d_alpha, x, amax_a=am_a, amax_b=am_x, out=dws[:256])
+            wgrad(d_beta, x, amax_a=am_b, amax_b=am_x, out=dws[256:])
         return (dx if need[0] else None, None, dw0, db0, dw1, db1, dws)
 
 
@@ -811,8 +818,9 @@ class ResnetBlockFC(nn.Module):
             self._cache_bwd, self._cache_bwd_key = packed, key
         return self._cache_bwd
 
-    def _launch_bwd(self, x, d_alpha, d_beta):
-        """x (n, size_in), d_alpha / d_beta (n, 256), contiguous fp32 on the GPU -> (d x (n, size_in), d net (n, size_in) view of the workspace)."""
+    def _launch_bwd(self, x, d_alpha, d_beta, want_net=False):
+        """x (n, size_in), d_alpha / d_beta (n, 256), contiguous fp32 on the GPU -> (d x (n, size_in), d net as (n, 320) rows of the workspace
+        (columns >= size_in are zero), net likewise or None)."""
         _lib.require_gpu(x, "feats")
         n = x.shape[0]
         lib = _lib.load()
@@ -820,11 +828,12 @@ class ResnetBlockFC(nn.Module):
         x = x.contiguous()
         dx = torch.empty_like(x)
         ws = torch.empty(lib.e3dge_tex_modulations_bwd_ws_floats(n), device=x.device, dtype=torch.float32)
+        net = torch.empty((n, 320), device=x.device, dtype=torch.float32) if want_net else None
         with _lib.on_device(x.device):
             rc = lib.e3dge_tex_modulations_bwd(_lib.ptr(packed), _lib.ptr(x), self.size_in, n, _lib.ptr(d_alpha), _lib.ptr(d_beta),
-                                               _lib.ptr(dx), _lib.ptr(ws), _lib.stream_of(x))
+                                               _lib.ptr(dx), _lib.ptr(ws), _lib.ptr(net) if want_net else None, _lib.stream_of(x))
         _lib.check(rc, "e3dge_tex_modulations_bwd")
-        return dx, ws[:n * 320].view(n, 320)[:, :self.size_in]
+        return dx, ws[:n * 320].view(n, 320), net
 
     def forward(self, x):
         """(.., size_in) -> (.., 512) like the reference module."""

@@ -548,13 +548,14 @@ int e3dge_tex_modulations_fwd(const float* packed, const float* feats, int cin, 
  *   packed_bwd   e3dge_resblock_bwd_packed_floats() floats from e3dge_resblock_bwd_pack_weights (W_0, W_1^T, W_s^T, W_0^T images + b_0)
  *   d_alpha, d_beta (n_pts, 256), 16-byte aligned     d_feats (n_pts, cin) out
  *   ws           e3dge_tex_modulations_bwd_ws_floats(n_pts) floats, 16-byte aligned; on return ws[0 .. n_pts * 320) holds d net = d L / d (fc_0
- *                output) as (n_pts, 320) rows (columns >= cin are zero) -- the operand of the parameter gradients, which stay library GEMMs */
+ *                output) as (n_pts, 320) rows (columns >= cin are zero) -- the operand of the parameter gradients (e3dge_wgrad)
+ *   net_out      NULL, or (n_pts, 320) rows receiving net = fc_0(relu(x)) as recomputed (the input of fc_1's parameter gradient, before its relu) */
 int64_t e3dge_resblock_bwd_packed_floats(void);
 int e3dge_resblock_bwd_pack_weights(float* packed_bwd, const float* w0, const float* b0, const float* w1, const float* ws, int cin,
                                     e3dge_stream_t stream);
 int64_t e3dge_tex_modulations_bwd_ws_floats(int64_t n_pts);
 int e3dge_tex_modulations_bwd(const float* packed_bwd, const float* feats, int cin, int64_t n_pts, const float* d_alpha, const float* d_beta,
-                              float* d_feats, float* ws, e3dge_stream_t stream);
+                              float* d_feats, float* ws, float* net_out, e3dge_stream_t stream);
 /* The head INSIDE the second render pass's data flow (ABI 11; SURVEY.md 8 f1 as specified: (alpha, beta) never materialise):
  * feats (batch, height, width, n_samples, cin) -> h' = (alpha + 1) h8 + beta, where h8 is the layer-7 output that render
  * pass #1 left in `backbone_in` (e3dge_siren_render_fwd backbone_out, e3dge_siren_backbone_bytes bytes) -- the FiLM step of
@@ -658,6 +659,19 @@ int e3dge_ws_linear(const E3dgeWsLinear* args, e3dge_stream_t stream);
  * (sft.py:103-109 / resnetfc.py:49-58: d x[:, 256] = de Ws[:, 256] + (dnet W0[:, 256]) [x[:, 256] > 0]). */
 int e3dge_ws_rowdot2(float* out, int ld_out, int off_out, const float* a, const float* u, const float* b, const float* v, const float* gate,
                      int ld_gate, int off_gate, int64_t n_rows, e3dge_stream_t stream);
+/* Parameter gradient of a fully connected layer of the local branch (round 5):  c (m, n) = sum over rows p of a[p, off_a : off_a + m]^T f(b[p, off_b : off_b + n]),
+ * f = relu when relu_b != 0 -- autograd's `grad_output.t() @ input` for the nn.Linear layers of ResnetBlockFC (helper_modules/resnetfc.py:49-58)
+ * and Fuse_sft_MLP (helper_modules/sft.py:84-110) in the stage-2 step (e3dge_full_runner.py:185-317), with the relu of the layer's input folded in.
+ * a, b: fp32 rows of lda / ldb floats (4-byte aligned; any row pitch), amax_a / amax_b: amax buffers (e3dge_amax) bounding |a| / |b|;
+ * ws: e3dge_wgrad_ws_floats(m, n, n_rows) floats (split-K partial blocks, folded in fixed order: bit-reproducible).  Split-f16 x 3, fp32 accumulate. */
+typedef struct E3dgeWgrad {
+    const float* a; const float* amax_a; const float* b; const float* amax_b;
+    float* c; float* ws;
+    int64_t ws_floats, n_rows;
+    int32_t lda, off_a, m, ldb, off_b, n, ldc, relu_b;
+} E3dgeWgrad;
+int64_t e3dge_wgrad_ws_floats(int m, int n, int64_t n_rows);
+int e3dge_wgrad(const E3dgeWgrad* args, e3dge_stream_t stream);
 /* Accuracy self-test of the kernel's sine: y[i] = sin(x[i]) with the device routine the SIREN layers use. */
 int e3dge_selftest_sin(float* y, const float* x, int n, e3dge_stream_t stream);
 /* The alternative 13-op polynomial sine (kernels built with -DE3DGE_POLY_SINE use it). */

@@ -209,6 +209,41 @@ int main(void) {
     assert lib.e3dge_ws_pack(None, None, 1, None) == -1
 
 
+def test_wgrad_and_texhead_bwd_layout_and_argument_checks():
+    """Round 5: struct E3dgeWgrad against the ctypes mirror (compiled C probe), the workspace formulas, and validation before any launch."""
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "e3dge_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(E3dgeWgrad), offsetof(E3dgeWgrad, c), offsetof(E3dgeWgrad, ws_floats), offsetof(E3dgeWgrad, n_rows),
+         offsetof(E3dgeWgrad, lda), offsetof(E3dgeWgrad, ldc), offsetof(E3dgeWgrad, relu_b));
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), c, "-o", exe], check=True)
+        got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    G = _lib.Wgrad
+    assert got == [ctypes.sizeof(G), G.c.offset, G.ws_floats.offset, G.n_rows.offset, G.lda.offset, G.ldc.offset, G.relu_b.offset]
+    lib = _lib.load()
+    # 98,304 points, 512 x 301 outputs: 4 x 3 blocks, 512 // 12 = 42 slabs of 2,368 points (a multiple of 32)
+    assert lib.e3dge_wgrad_ws_floats(512, 301, 98304) == 42 * 12 * 128 * 128
+    assert lib.e3dge_wgrad_ws_floats(5, 3, 1) == 128 * 128 and lib.e3dge_wgrad_ws_floats(0, 3, 10) == 0
+    assert lib.e3dge_wgrad(None, None) == -1
+    one = ctypes.c_void_p(16)
+    assert lib.e3dge_wgrad(ctypes.byref(G(a=one, amax_a=one, b=one, amax_b=one, c=one, ws=one, n_rows=4, lda=3, m=4, ldb=4, n=4, ldc=4, ws_floats=1 << 20)), None) == -1   # m > lda
+    assert lib.e3dge_wgrad(ctypes.byref(G(a=one, amax_a=one, b=one, amax_b=one, c=one, ws=one, n_rows=4, lda=4, m=4, ldb=4, n=4, ldc=4, ws_floats=16)), None) == -1        # workspace
+    assert lib.e3dge_wgrad(ctypes.byref(G(c=one, n_rows=4, m=0, n=4, ldc=4)), None) == 0                                                                                # nothing to do
+    assert lib.e3dge_tex_modulations_bwd_ws_floats(1000) == 2 * 1000 * 320 and lib.e3dge_tex_modulations_bwd_ws_floats(0) == 0
+    assert lib.e3dge_resblock_bwd_packed_floats() == 120 * 5120 + 320
+    assert lib.e3dge_tex_modulations_bwd(None, None, 301, 5, None, None, None, None, None, None) == -1
+    assert lib.e3dge_tex_modulations_bwd(one, one, 321, 5, one, one, one, one, None, None) == -1       # cin > 320
+    assert lib.e3dge_tex_modulations_bwd(None, None, 301, 0, None, None, None, None, None, None) == 0   # nothing to do
+    assert lib.e3dge_resblock_bwd_pack_weights(None, None, None, None, None, 301, None) == -1
+
+
 def test_host_helpers_that_need_no_gpu(lib):
     assert lib.e3dge_upfirdn2d_out_size(129, 1, 1, 1, 1, 4) == 128     # Blur after the 64->129 transposed conv
     assert lib.e3dge_upfirdn2d_out_size(64, 2, 1, 2, 1, 4) == 128      # skip Upsample

@@ -212,6 +212,47 @@ def test_texhead_backward_zero_initialised_head_and_parameter_gradients(monkeypa
         p_.requires_grad_(True)
 
 
+@pytest.mark.parametrize("P,m,n,relu", [(1, 5, 3, False), (31, 128, 128, True), (33, 129, 127, False), (1000, 301, 301, True),
+                                          (4097, 256, 301, False), (20000, 512, 320, True), (300, 1, 600, False)])
+def test_wgrad_against_float64(P, m, n, relu, monkeypatch):
+    """e3dge_wgrad: a^T f(b) over ragged sizes (fewer rows than a step, block edges, rows that are not 16-byte aligned, more than 512 columns),
+    with magnitudes ten decades apart between the operands; against float64 and against the library matmul (fp32).  Tolerance: 2e-6 of the
+    result's maximum + what fp32 summation of P terms costs the library path on the same data; bit-identical on repetition."""
+    from e3dge_amd.wgrad import wgrad
+    rs = np.random.RandomState(P + m)
+    a = torch.from_numpy((1e-5 * rs.standard_normal((P, m + 3))).astype(np.float32)).to(DEV)[:, 1:m + 1]          # a view: pitch m + 3, offset 1
+    b = torch.from_numpy((3e4 * rs.standard_normal((P, n))).astype(np.float32)).to(DEV)
+    c = wgrad(a, b, relu_b=relu)
+    c2 = wgrad(a, b, relu_b=relu)
+    ref = a.double().t() @ (torch.relu(b.double()) if relu else b.double())
+    lib = a.t() @ (torch.relu(b) if relu else b)
+    scale = float(ref.abs().max())
+    e_hip, e_lib = float((c.double() - ref).abs().max()) / scale, float((lib.double() - ref).abs().max()) / scale
+    record("wgrad_vs_f64", P=P, m=m, n=n, relu=int(relu), hip=e_hip, library=e_lib)
+    assert c.shape == (m, n) and torch.equal(c, c2)
+    assert e_hip <= 2e-6 + 2 * e_lib, (e_hip, e_lib)
+    out = torch.full((m, n + 5), 7.0, device=DEV)
+    wgrad(a, b, relu_b=relu, out=out[:, 2:n + 2])
+    assert torch.equal(out[:, 2:n + 2], c) and float(out[:, :2].min()) == 7.0 and float(out[:, n + 2:].min()) == 7.0
+
+
+def test_texhead_parameter_gradients_native_vs_library(monkeypatch):
+    """The head trainable: the five parameter gradients from e3dge_wgrad on the backward kernel's d net / net against the library chain."""
+    h, _ = make_head(301)
+    rs = np.random.RandomState(9)
+    feats = torch.from_numpy(rs.standard_normal((3000, 301)).astype(np.float32)).to(DEV)
+    ga = torch.from_numpy(rs.standard_normal((3000, 256)).astype(np.float32)).to(DEV)
+    gb = torch.from_numpy(rs.standard_normal((3000, 256)).astype(np.float32)).to(DEV)
+    g_hip, p_hip = _head_grads(h, feats, ga, gb, params=True)
+    monkeypatch.setenv("E3DGE_TEXHEAD_BWD", "library")
+    g_lib, p_lib = _head_grads(h, feats, ga, gb, params=True)
+    errs = {"feats": float((g_hip - g_lib).abs().max() / g_lib.abs().max())}
+    for k in p_lib:
+        errs[k] = float((p_hip[k] - p_lib[k]).abs().max() / p_lib[k].abs().max())
+    record("texhead_param_grads_hip_vs_library", **errs)
+    assert max(errs.values()) <= 2e-5, errs
+
+
 def test_second_pass_from_local_feats():
     """VolumeFeatureRenderer.forward with local_data_batch={'feats': ...} (the reference's second pass with already
     queried local features, :434-437 + :327-336 + :217-220) == the oracle's render with the oracle's (alpha, beta)."""

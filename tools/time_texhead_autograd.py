@@ -41,6 +41,10 @@ def fb():
 
 
 res = {}
+if len(sys.argv) > 1 and sys.argv[1] == "--profile-trainable":        # for rocprofv3 --kernel-trace --stats: only the trainable HIP step
+    h.requires_grad_(True)
+    print(json.dumps({"fwd_bwd_ms_hip_trainable": timed(fb)}))
+    sys.exit(0)
 for params in (False, True):
     h.requires_grad_(params)
     for be in ("hip", "library"):
@@ -51,6 +55,9 @@ h.requires_grad_(False)
 with torch.no_grad():
     res["forward_ms"] = timed(lambda: h.tex_modulations(x))
     res["backward_kernel_ms"] = timed(lambda: h._launch_bwd(x, ga, gb))
+    from e3dge_amd.wgrad import wgrad  # noqa: E402
+    res["wgrad_512x301_ms"] = timed(lambda: (wgrad(ga, x), wgrad(gb, x)))
+    res["matmul_512x301_ms"] = timed(lambda: (ga.t() @ x, gb.t() @ x))
     res["x_clone_ms"] = timed(lambda: x.clone())
 flop = 2 * n * (301 * 301 * 2 + 2 * 512 * 301)
 res["backward_algorithmic_gflop"] = round(flop / 1e9, 2)
