@@ -770,7 +770,10 @@ def main():
                             x_ = xin_.clone().requires_grad_(True)
                             fu_.fuse(x_, x_[..., 257:]).square().mean().backward()
                         ag["fuse_sft_" + be + "_fwd_bwd_ms"] = ev_fb(fb2)
+                        fu_.requires_grad_(True)          # stage 2 trains this module: + the thirteen parameter gradients (e3dge_wgrad vs matmul)
+                        ag["fuse_sft_" + be + "_trainable_fwd_bwd_ms"] = ev_fb(fb2)
                     finally:
+                        fu_.requires_grad_(False)
                         os.environ.pop("E3DGE_FUSE_AUTOGRAD", None)
                 try:        # the texture head (ResnetBlockFC 301 -> 512 on 98,304 points) under autograd: native forward, e3dge_tex_modulations_bwd (round 5) vs library GEMMs
                     head_ = gl.renderer.network.netLocal.local_feat_to_tex_modulations_linear
@@ -781,10 +784,15 @@ def main():
                         al_, be_ = head_.tex_modulations(x_)
                         (al_.square().mean() + be_.square().mean()).backward()
                     ag["tex_head_fwd_bwd_ms"] = ev_fb(fb3)
+                    head_.requires_grad_(True)
+                    ag["tex_head_trainable_fwd_bwd_ms"] = ev_fb(fb3)
                     os.environ["E3DGE_TEXHEAD_BWD"] = "library"
                     try:
+                        ag["tex_head_library_trainable_fwd_bwd_ms"] = ev_fb(fb3)
+                        head_.requires_grad_(False)
                         ag["tex_head_library_fwd_bwd_ms"] = ev_fb(fb3)
                     finally:
+                        head_.requires_grad_(False)
                         os.environ.pop("E3DGE_TEXHEAD_BWD", None)
                     with torch.no_grad():
                         ag["tex_head_fwd_ms"] = ev_fb(lambda: head_.tex_modulations(f_h))
