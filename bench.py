@@ -134,6 +134,8 @@ def finalize(result):
         if isinstance(r.get(key), dict):
             r[key].pop("note", None)
     r.pop("stream_ops", None)
+    for key in ("train_step_full_note", "train_step_note", "inversion_fwd_note"):       # (DESIGN.md section 5 says what these legs are)
+        r.pop(key, None)
     r["summary"] = summary
     return r
 
@@ -1132,6 +1134,9 @@ def main():
                                "saved_state_hbm_frac": t_b / (ms * 1e-3), "traffic": tr_traffic,
                                "note": "bound = the 30 GEMM chains of the step on f16 MFMA / 3; saved-state bytes are a design cost, not algorithmic; "
                                        "traffic = PMC FETCH x2 + WRITE per step (profiles/traffic_pmc.json)"}}
+            b4 = result.get("train_step_batch4_ms_per_sample")
+            if isinstance(b4, float):       # the same arithmetic per sample at stage1.sh's four samples per GPU (three full 256-CU rounds per launch instead of 2.25)
+                ts["roofline_batch4"] = {"ms_per_sample": b4, "achieved": flop_step / (b4 * 1e-3) / 1e12, "frac": t_f / (b4 * 1e-3)}
             if dist is not None:
                 # stage 1 trains the encoder under DDP -- 1.03 GB of fp32 gradients all-reduced per step
                 # (trainer.py:1737-1778, dist_utils.py:108-130).  The encoder is out of scope; its collective is emulated with a
