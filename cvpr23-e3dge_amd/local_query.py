@@ -277,7 +277,7 @@ class Fuse_sft_MLP(nn.Module):
     def _fuse_bwd_native(self, g, x, net, s1, t1, scale, am_x, w, b_off, slope, need_x):
         """The data-gradient chain of sft.py:84-109 + resnetfc.py:49-58 as e3dge_ws_linear launches on the transposed images (round 5):
         dz1 = (w g . dec) Wsc2 . lrelu'(s1), dz2 = (w g) Wsh2 . lrelu'(t1), de = dz1 Wsc1 + dz2 Wsh1, dnet = de W1 . [net > 0],
-        dx = de Ws + (dnet W0) . [x > 0], dx[dec block] += g (1 + w scale).  Returns (dz1, dz2, de, dnet, dx or None)."""
+        dx = de Ws + (dnet W0) . [x > 0], dx[dec block] += g (1 + w scale).  Returns (dz1, dz2, de, dnet, dx or None, the amax buffers of g / dz1 / dz2 / de / dnet)."""
         N = g.shape[0]
         dev = g.device
         ld = x.shape[1]
@@ -317,7 +317,7 @@ class Fuse_sft_MLP(nn.Module):
                 # the visibility-mask column (one input column of fc_0 and of the shortcut): two row dot products in one launch
                 _lib.check(lib.e3dge_ws_rowdot2(_lib.ptr(dx), ld, 256, _lib.ptr(de), _lib.ptr(I['scol']), _lib.ptr(dnet), _lib.ptr(I['f0col']),
                                                 _lib.ptr(x), ld, 256, N, st), "e3dge_ws_rowdot2")
-        return dz1, dz2, de, dnet, dx
+        return dz1, dz2, de, dnet, dx, am
 
     def _fuse_native(self, enc_in, w, out, out_off, keep=None):
         """`keep` (a dict): every intermediate gets a buffer of its own and is left there for _FuseFn.backward --
@@ -372,7 +372,7 @@ class Fuse_sft_MLP(nn.Module):
             lin(I['sh1'], E, 256, 0, am[2], T1, bias=I['bsh1'], post=1, amax_out=am[4])
             lin(I['sh2'], T1, 256, 0, am[4], o2, ld_y=o2.shape[-1], off_y=out_off, bias=I['bsh2'], r1=x, r1_ld=ld, r1_off=b_off, r2=C, post=2)
         if keep is not None:
-            keep.update(x=x, net=NET, e=E, s1=S1, t1=T1, scale=C, b_off=b_off, slope=I['slope'], am_x=am[0])
+            keep.update(x=x, net=NET, e=E, s1=S1, t1=T1, scale=C, b_off=b_off, slope=I['slope'], am_x=am[0], am=am)
         return out[..., out_off:out_off + 256]
 
 
@@ -388,7 +388,7 @@ class _FuseFn(torch.autograd.Function):
         with torch.no_grad():
             out = mod._fuse_native(enc_in.detach(), w, None, 0, keep=keep)
         ctx.mod, ctx.w, ctx.in_shape = mod, w, enc_in.shape
-        ctx.b_off, ctx.slope, ctx.am_x = keep['b_off'], keep['slope'], keep['am_x']
+        ctx.b_off, ctx.slope, ctx.am_x, ctx.am_fwd = keep['b_off'], keep['slope'], keep['am_x'], keep['am']
         ctx.save_for_backward(keep['x'], keep['net'], keep['e'], keep['s1'], keep['t1'], keep['scale'], *params)
         return out
 
@@ -407,13 +407,16 @@ class _FuseFn(torch.autograd.Function):
         if os.environ.get("E3DGE_FUSE_BWD", "hip") == "hip":
             # round 5: the data-gradient chain as nine e3dge_ws_linear launches on the transposed weight images; the thirteen parameter
             # gradients (reductions over the points: library GEMMs with K = number of points) only when a parameter wants one
-            dz1, dz2, de, dnet, dx = ctx.mod._fuse_bwd_native(g, x, net, s1, t1, scale, ctx.am_x, w, b_off, slope, need_x)
+            dz1, dz2, de, dnet, dx, am_b = ctx.mod._fuse_bwd_native(g, x, net, s1, t1, scale, ctx.am_x, w, b_off, slope, need_x)
             if any(need):
                 # the seven weight gradients: e3dge_wgrad (split-f16 MFMA, split over the points, fixed-order fold; E3DGE_WGRAD=library = matmul),
                 # the relu of a layer's input folded into the operand load
                 from .wgrad import amax_of, wgrad
                 d_scale, d_shift = (w * g) * dec, w * g
-                am = {}
+                # amax buffers the two chains already hold: the forward's (x, net, e, s1, t1), the backward's (g, dz1, dz2, de, dnet); d shift = w g
+                af = ctx.am_fwd
+                am = {id(x): af[0], id(net): af[1], id(e): af[2], id(s1): af[3], id(t1): af[4],
+                      id(dz1): am_b[1], id(dz2): am_b[2], id(de): am_b[3], id(dnet): am_b[4], id(d_shift): am_b[0] * abs(w)}
 
                 def wg(a_, b_, relu=False):
                     for t_ in (a_, b_):

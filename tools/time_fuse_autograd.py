@@ -38,6 +38,10 @@ def ms(fn, n=10):
 
 
 res = {}
+if len(sys.argv) > 1 and sys.argv[1] == "--profile-trainable":        # for rocprofv3 --kernel-trace --stats: only the trainable HIP step
+    os.environ["E3DGE_FUSE_AUTOGRAD"] = "hip"
+    print(json.dumps({"fwd_bwd_ms_hip_trainable": round(ms(lambda: step(False), 20), 3)}))
+    sys.exit(0)
 for mode in ("hip", "torch"):
     os.environ["E3DGE_FUSE_AUTOGRAD"] = mode
     res[mode] = {"node": type(step(True).grad_fn).__name__, "fwd_ms": round(ms(lambda: step(True)), 3), "fwd_bwd_ms": round(ms(lambda: step(False)), 3)}
