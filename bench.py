@@ -988,8 +988,10 @@ def main():
                     fn()
                 barrier()
                 return 1e3 * max_over_ranks(time.perf_counter() - t0) / n
-            # (the autograd legs above leave a few hundred MB of cached blocks of odd sizes behind; with them the step's 0.7-GB buffers and
-            # the side stream's record_stream-held blocks did not settle within the warm-up on one box: 3.27 instead of 2.53 ms)
+            # (round 5 read this step at 3.27 instead of 2.53 ms on two boxes.  It is the clock: the GPU clocks down while the host is busy --
+            # a process start, the host-bound autograd legs above -- and a handful of 2.5-ms warm-up steps does not bring it back: every
+            # process but the first on a fresh box reads tools/c5_step.py at 3.4-4.1 ms after three warm-up steps and at 2.51 after 0.4 s
+            # of them.  Hence the spin below; the empty_cache() was the first suspect and stays.)
             torch.cuda.empty_cache()
             spin(args.prewarm_ms / 2)
             for _ in range(5):

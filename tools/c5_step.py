@@ -30,8 +30,11 @@ def step():
     return s.grad
 
 
-for _ in range(3):
-    step()
+import time  # noqa: E402
+t_w = time.perf_counter()
+while time.perf_counter() - t_w < 0.4:      # the GPU clocks down while a process starts (imports: ~2 s of idling) and needs ~0.2 s of work to come
+    step()                                   # back: three warm-up steps read 3.4-4.1 ms in every process but the first on a fresh box
+torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize()
 a.record()
