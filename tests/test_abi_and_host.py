@@ -244,6 +244,26 @@ int main(void) {
     assert lib.e3dge_resblock_bwd_pack_weights(None, None, None, None, None, 301, None) == -1
 
 
+def test_wgrad_host_side_rules(monkeypatch):
+    """e3dge_amd.wgrad: the library backend is plain matmul (CPU tensors included); the native one refuses CPU tensors and odd layouts loudly."""
+    import torch
+    from e3dge_amd import wgrad as W
+    a, b = torch.randn(7, 3), torch.randn(7, 5)
+    monkeypatch.setenv("E3DGE_WGRAD", "library")
+    assert torch.allclose(W.wgrad(a, b, relu_b=True), a.t() @ torch.relu(b))
+    out = torch.zeros(3, 9)
+    W.wgrad(a, b, out=out[:, 2:7])
+    assert torch.allclose(out[:, 2:7], a.t() @ b) and float(out[:, :2].abs().max()) == 0.0
+    monkeypatch.setenv("E3DGE_WGRAD", "hip")
+    with pytest.raises(RuntimeError, match="GPU"):
+        W.wgrad(a, b)
+    with pytest.raises(ValueError, match="unit column stride"):
+        W.wgrad(a.t().contiguous().t(), b)
+    monkeypatch.setenv("E3DGE_WGRAD", "fast")
+    with pytest.raises(ValueError, match="E3DGE_WGRAD"):
+        W.wgrad(a, b)
+
+
 def test_host_helpers_that_need_no_gpu(lib):
     assert lib.e3dge_upfirdn2d_out_size(129, 1, 1, 1, 1, 4) == 128     # Blur after the 64->129 transposed conv
     assert lib.e3dge_upfirdn2d_out_size(64, 2, 1, 2, 1, 4) == 128      # skip Upsample
