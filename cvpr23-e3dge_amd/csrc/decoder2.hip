@@ -2189,13 +2189,13 @@ extern "C" int e3dge_dec2_forward(const E3dgeDec2Plan* P, e3dge_stream_t stream)
         if (timing) {
             if (code == 0 && ev_failed) code = fail(E3DGE_ERR_LAUNCH, "dec2_forward: HIP event create / record failed (kernel_ms)");
             if (code == 0 && n_ev > 0) {
-                hipEventSynchronize(ev[n_ev - 1]);
+                if (hipEventSynchronize(ev[n_ev - 1]) != hipSuccess) code = fail(E3DGE_ERR_LAUNCH, "dec2: hipEventSynchronize failed (kernel_ms)");
                 for (int i = 0; i + 1 < n_ev; ++i) {
-                    hipEventElapsedTime(&P->kernel_ms[i], ev[i], ev[i + 1]);
+                    if (hipEventElapsedTime(&P->kernel_ms[i], ev[i], ev[i + 1]) != hipSuccess) P->kernel_ms[i] = -1.0f;
                     if (fused_away[i + 1]) P->kernel_ms[i] = 0.0f;        // this launch does not exist: its work is part of the previous one
                 }
             }
-            for (int i = 0; i < n_ev; ++i) hipEventDestroy(ev[i]);
+            for (int i = 0; i < n_ev; ++i) (void)hipEventDestroy(ev[i]);
         }
         return code;
     };
@@ -2403,10 +2403,11 @@ extern "C" int e3dge_dec2_backward(const E3dgeDec2Plan* P, const E3dgeDec2BwdPla
         if (timing) {
             if (code == 0 && ev_failed) code = fail(E3DGE_ERR_LAUNCH, "dec2_backward: HIP event create / record failed (kernel_ms)");
             if (code == 0 && n_ev > 0) {
-                hipEventSynchronize(ev[n_ev - 1]);
-                for (int i = 0; i + 1 < n_ev; ++i) hipEventElapsedTime(&Q->kernel_ms[i], ev[i], ev[i + 1]);
+                if (hipEventSynchronize(ev[n_ev - 1]) != hipSuccess) code = fail(E3DGE_ERR_LAUNCH, "dec2: hipEventSynchronize failed (kernel_ms)");
+                for (int i = 0; i + 1 < n_ev; ++i)
+                    if (hipEventElapsedTime(&Q->kernel_ms[i], ev[i], ev[i + 1]) != hipSuccess) Q->kernel_ms[i] = -1.0f;
             }
-            for (int i = 0; i < n_ev; ++i) hipEventDestroy(ev[i]);
+            for (int i = 0; i < n_ev; ++i) (void)hipEventDestroy(ev[i]);
         }
         return code;
     };
