@@ -701,7 +701,6 @@ extern "C" int e3dge_tex_modulations_bwd(const float* packed_bwd, const float* f
     E3DGE_REQUIRE(cin >= 1 && cin <= kRbKin, "tex_modulations_bwd: cin=%d outside [1, %d]", cin, kRbKin);
     E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed_bwd) | reinterpret_cast<uintptr_t>(d_alpha) | reinterpret_cast<uintptr_t>(d_beta) | reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(net_out)) & 15) == 0,
                   "tex_modulations_bwd: packed / d_alpha / d_beta / ws / net_out must be 16-B aligned");
-    E3DGE_REQUIRE(n_pts * (int64_t)kRbWsRow * 4 < ((int64_t)1 << 32) * 1024, "tex_modulations_bwd: too many points");
     ResblockBwdK k{};
     k.packed = packed_bwd; k.feats = feats; k.d_alpha = d_alpha; k.d_beta = d_beta; k.d_feats = d_feats; k.ws = ws; k.net_out = net_out;
     k.n_pts = n_pts; k.cin = cin;
