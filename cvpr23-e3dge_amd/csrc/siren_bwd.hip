@@ -624,8 +624,10 @@ constexpr int kChLdsW = 0;
 constexpr int kChLdsFilm = kChLdsW + kNBuf * kChunkFloats;      // [8][256] gamma of the backbone layers
 constexpr int kChLdsW0 = kChLdsFilm + 8 * kWidth;               // [3][256] first-layer weights, column-major
 constexpr int kChLdsHead = kChLdsW0 + 3 * kWidth;               // w_sigma[256]
-constexpr int kChLdsFloats = kChLdsHead + kWidth;
+constexpr int kChLdsSt = kChLdsHead + kWidth;                    // [4 waves][2 tiles][32 points][32 floats]: the store transpose (see ch_put / ch_drain)
+constexpr int kChLdsFloats = kChLdsSt + 4 * 2 * 1024;
 constexpr int kChLdsBytes = kChLdsFloats * 4;
+static_assert(kChLdsBytes <= 160 * 1024, "LDS budget (chain)");
 
 template <bool TANGENT, bool F16>
 __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK a) {
@@ -702,10 +704,29 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
         const int pc = valid ? p : (npts - 1);
         const int64_t gpt = (int64_t)b * a.n_pts + pt0 + pc;
         const float* __restrict__ ap = a.args + gpt * (9 * kWidth);
-        float* __restrict__ sp = a.save + gpt * (8 * kWidth);
+        // The saved tile of a layer (16 values per lane: quads 2q + half of its point's 128-byte line) leaves through LDS: written as the lane
+        // holds it, read back so that EIGHT lanes cover one point's whole line -- a store instruction then writes 8 full 128-B lines instead
+        // of 32 quarter lines (timing ablations, DESIGN.md 4.6: the quarter-line stores cost 0.7 ms of the 8.7-ms step at four samples per
+        // GPU).  Piece p of point c sits at slot p ^ ((c >> 1) & 7) of the point's eight 16-byte slots: conflict-free for both the
+        // 16 consecutive points of a write and the 2 points x 8 pieces of a read.  Two tile buffers per wave; only this wave touches them.
+        float* const stl = smem + kChLdsSt + wave * 2048;
+        const int st_wr = col * 32, st_pc = 4 * half, st_sw = 4 * ((col >> 1) & 7);              // write: quad q -> float (8 q + 4 half) ^ st_sw of the point's 32
+        const int dc = lane >> 3, dp = lane & 7;                                                   // drain: this lane = piece dp of points 8 i + dc
+        const int n_rows_ok = npts - (sub * kTilePts + 32 * wave);                                 // rows of this wave's 32 that exist
+        float* const sw0 = a.save + ((int64_t)b * a.n_pts + pt0 + sub * kTilePts + 32 * wave) * (8 * kWidth);   // wave-uniform: the wave's first row
+        const int st_goff = dc * (8 * kWidth) + 4 * dp;
+        auto ch_put = [&](int buf, int q, const f32x4& v) {
+            *reinterpret_cast<f32x4*>(stl + buf * 1024 + st_wr + ((8 * q + st_pc) ^ st_sw)) = v;
+        };
+        auto ch_drain_piece = [&](int buf, int i, float* __restrict__ layer_base, int tp) {      // piece i of four: points 8 i .. 8 i + 7
+            const int c = 8 * i + dc;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stl + buf * 1024 + c * 32 + 4 * (dp ^ ((4 * i + (dc >> 1)) & 7)));
+            if (c < n_rows_ok) *reinterpret_cast<f32x4*>(layer_base + st_goff + i * (8 * 8 * kWidth) + 32 * tp) = v;
+        };
 
         // ---- first layer of the chain (no GEMM) ----
         {
+            float* __restrict__ sp = a.save + gpt * (8 * kWidth);
             int half_p = half;                       // opaque: keeps the address math of this block inside the loop
             asm volatile("" : "+v"(half_p));         // (see siren_bwd_kernel)
             const int l0 = TANGENT ? 0 : 7;
@@ -754,21 +775,22 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
             const int l = TANGENT ? step + 1 : 6 - step;                 // layer whose argument / gamma the epilogue uses
             const float* __restrict__ gl = gam_s + l * kWidth;
             const float* __restrict__ apl = ap + l * kWidth;
-            float* __restrict__ spl = sp + l * kWidth;
+            float* __restrict__ swl = sw0 + l * kWidth;
             f32x16 prev;
             f32x4 argb[2][4];
-            f32x4 st4[4];                                                // the finished tile's values, stored one wait later
             auto epilogue = [&](int tp, const f32x16& accv, const f32x4 (&ar)[4], f32x16& dst) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const f32x4 g4 = *reinterpret_cast<const f32x4*>(gl + 32 * tp + 8 * q + 4 * half);
+                    f32x4 s4;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float ga = g4[j] * accv[4 * q + j];
-                        st4[q][j] = TANGENT ? ga : accv[4 * q + j];
+                        s4[j] = TANGENT ? ga : accv[4 * q + j];
                         dst[4 * q + j] = cos_hw_f32(ar[q][j]) * ga;
                         if (kInter) gmax = fmaxf(gmax, fabsf(dst[4 * q + j]));
                     }
+                    ch_put(tp & 1, q, s4);                                   // stored by ch_drain_piece one chunk wait later
                 }
             };
             // F16: the same work for tile tp issued from inside the next GEMM tile, one accumulator register per k-step; the
@@ -781,7 +803,8 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
                 e_st[j] = TANGENT ? ga : prev[r];
                 dst[r] = cos_hw_f32(argb[tp & 1][q][j]) * ga;
                 gmax = fmaxf(gmax, fabsf(dst[r]));
-                if (j == 3 && valid) *reinterpret_cast<f32x4*>(spl + 32 * tp + 8 * q + 4 * half) = e_st;
+                if (j == 3) ch_put(tp & 1, q, e_st);
+                if (tp > 0 && r >= 4 && r < 8) ch_drain_piece((tp - 1) & 1, r - 4, swl, tp - 1);       // tile tp - 1: written during the previous GEMM tile
             };
 #pragma unroll
             for (int t = 0; t < kNT; ++t) {
@@ -791,9 +814,9 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
 #pragma unroll
                         for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(argb[(t - 1) & 1][q]));
                     }
-                    if (!kInter && t > 1 && valid) {                     // tile t-2 finished during the previous GEMM tile
+                    if (!kInter && t > 1) {                              // tile t-2 finished during the previous GEMM tile
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(spl + 32 * (t - 2) + 8 * q + 4 * half) = st4[q];
+                        for (int i = 0; i < 4; ++i) ch_drain_piece((t - 2) & 1, i, swl, t - 2);
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) argb[t & 1][q] = *reinterpret_cast<const f32x4*>(apl + 32 * t + 8 * q + 4 * half);
@@ -820,18 +843,14 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
                 prev = acc;
                 if (kInter) asm volatile("" : "+v"(prev));
             }
-            // tail of the layer: tile 6 is still pending in st4 (fp32 path), tile 7 has no GEMM tile after it
-            if (!kInter && valid) {
+            // tail of the layer: tile 6 is still in its LDS buffer, tile 7 has no GEMM tile after it
 #pragma unroll
-                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(spl + 32 * (kNT - 2) + 8 * q + 4 * half) = st4[q];
-            }
+            for (int i = 0; i < 4; ++i) ch_drain_piece((kNT - 2) & 1, i, swl, kNT - 2);
 #pragma unroll
             for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(argb[(kNT - 1) & 1][q]));
             epilogue(kNT - 1, prev, argb[(kNT - 1) & 1], out[kNT - 1]);
-            if (valid) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(spl + 32 * (kNT - 1) + 8 * q + 4 * half) = st4[q];
-            }
+            for (int i = 0; i < 4; ++i) ch_drain_piece((kNT - 1) & 1, i, swl, kNT - 1);
             if (step < 6) next_operand();
         }
 

@@ -11,15 +11,26 @@ for B in 1 2 4; do
   python $REPO/tools/c5_step.py 20 $B 2>&1 | tail -1 | tee -a "$OUT/timed.txt"
 done
 for B in 1 4; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/b$B" -o t -- python $REPO/tools/c5_step.py 10 $B > "$OUT/b$B.log" 2>&1
-  python - "$OUT/b$B" "$OUT/kernel_stats_b$B.txt" <<'PY'
-import csv, glob, os, sys
-d, out = sys.argv[1:3]
-st = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
-rows = list(csv.DictReader(open(st[0])))
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/b$B" -o t -- python $REPO/tools/c5_step.py 10 $B > "$OUT/b$B.log" 2>&1
+  python - "$OUT/b$B" "$OUT/kernel_stats_b$B.txt" $B <<'PY'
+# per (kernel, grid) averages: the ray samples' launch and the surface points' launch of the same kernel are different rows
+import collections, csv, glob, os, re, sys
+d, out, B = sys.argv[1], sys.argv[2], sys.argv[3]
+tr = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+agg = collections.defaultdict(lambda: [0, 0])
+for r in csv.DictReader(open(tr[0])):
+    if "e3dge::" not in r["Kernel_Name"]:
+        continue
+    name = re.sub(r"void |e3dge::|\(.*", "", r["Kernel_Name"])
+    wgs = int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)
+    a = agg[(name, wgs)]
+    a[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); a[1] += 1
+rows = sorted(agg.items(), key=lambda kv: -kv[1][0])
 with open(out, "w") as f:
-    for r in rows[:14]:
-        f.write(f"{r['Name'][:90]:<90} {r['Calls']:>6} {float(r['AverageNs']):>12.0f} {r['Percentage']:>7}\n")
+    f.write(f"rocprofv3 --kernel-trace -- python tools/c5_step.py 10 {B}: e3dge kernels by (kernel, workgroups); avg us per launch, launches, share of the e3dge total\n")
+    tot = sum(v[0] for _, v in rows)
+    for (name, wgs), v in rows[:16]:
+        f.write(f"{name[:70]:<70} {wgs:>6} wgs {v[0] / v[1] / 1e3:>9.1f} us {v[1]:>5} {100 * v[0] / tot:>6.2f} %\n")
 print(open(out).read())
 PY
   rm -rf "$OUT/b$B"
