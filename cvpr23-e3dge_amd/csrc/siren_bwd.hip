@@ -726,7 +726,6 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
 
         // ---- first layer of the chain (no GEMM) ----
         {
-            float* __restrict__ sp = a.save + gpt * (8 * kWidth);
             int half_p = half;                       // opaque: keeps the address math of this block inside the loop
             asm volatile("" : "+v"(half_p));         // (see siren_bwd_kernel)
             const int l0 = TANGENT ? 0 : 7;
@@ -756,7 +755,7 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
 #pragma unroll
                         for (int j = 0; j < 4; ++j) x4[j] = w4[j] * seed;                                          // r_7
                     }
-                    if (valid) *reinterpret_cast<f32x4*>(sp + l0 * kWidth + o) = x4;
+                    ch_put(t & 1, q, x4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                     {
@@ -765,6 +764,8 @@ __global__ void __launch_bounds__(kThreads) siren_chain_kernel(const SirenChainK
                     }
                 }
                 asm volatile("" : "+a"(out[t]));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ch_drain_piece(t & 1, i, sw0 + l0 * kWidth, t);
             }
             next_operand();
         }
