@@ -478,12 +478,19 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
                     pipe.sync();
                     if (F16) {                                           // streams of tile t itself: used one GEMM tile later
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            arg2[t & 1][q] = *reinterpret_cast<const f32x4*>(apl + 32 * t + 8 * q + 4 * half);
-                            if (EIK) {
-                                tg2[t & 1][q] = *reinterpret_cast<const f32x4*>(tpl + 32 * t + 8 * q + 4 * half);
-                                rs2[t & 1][q] = *reinterpret_cast<const f32x4*>(rpl + 32 * t + 8 * q + 4 * half);
-                            }
+                        for (int q = 0; q < 4; ++q) arg2[t & 1][q] = *reinterpret_cast<const f32x4*>(apl + 32 * t + 8 * q + 4 * half);
+                        if (EIK) {
+                            // The four quarter-line loads of a stream BACK TO BACK, stream after stream (round 5).  A tile's streams are 3 x 32 rows x
+                            // 128 B per wave = 48 KB per CU, more than the L1 holds: interleaved (arg, ta, r per quad) a line's four accesses were
+                            // spread over twelve instructions of every wave and mostly missed again -- L2 served each line up to four times.
+                            // Timing ablations: no streams -1.24 ms, whole-line loads -0.76 ms, this order -0.58 ms of the
+                            // 7.98-ms step at four samples per GPU (-0.38 / -0.20 / -0.10 of 2.46 ms at one).
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) tg2[t & 1][q] = *reinterpret_cast<const f32x4*>(tpl + 32 * t + 8 * q + 4 * half);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) rs2[t & 1][q] = *reinterpret_cast<const f32x4*>(rpl + 32 * t + 8 * q + 4 * half);
                         }
                         return;
                     }
@@ -499,12 +506,13 @@ __global__ void __launch_bounds__(kThreads) siren_bwd_kernel(const SirenBwdK a) 
 #pragma unroll
                         for (int q = 0; q < 4; ++q) argt[q] = *reinterpret_cast<const f32x4*>(apl + 32 * (kNT - 1) + 8 * q + 4 * half);
                     }
-                    if (EIK && t > 0) {     // the second-order streams of the same tile
+                    if (EIK && t > 0) {     // the second-order streams of the same tile, stream after stream (see the f16 branch)
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            tgb[q] = *reinterpret_cast<const f32x4*>(tpl + 32 * (t - 1) + 8 * q + 4 * half);
-                            rsb[q] = *reinterpret_cast<const f32x4*>(rpl + 32 * (t - 1) + 8 * q + 4 * half);
-                        }
+                        for (int q = 0; q < 4; ++q) tgb[q] = *reinterpret_cast<const f32x4*>(tpl + 32 * (t - 1) + 8 * q + 4 * half);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) rsb[q] = *reinterpret_cast<const f32x4*>(rpl + 32 * (t - 1) + 8 * q + 4 * half);
                     }
                 };
                 f32x16 acc = zero16();
