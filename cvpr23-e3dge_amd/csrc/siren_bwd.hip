@@ -1061,8 +1061,13 @@ film_bwd_kernel(float* __restrict__ dstyles, const float* __restrict__ dfilm, co
     const float* __restrict__ Wg = wg + (int64_t)l * kWidth * kWidth;
     const float* __restrict__ Wb = wb + (int64_t)l * kWidth * kWidth;
     float acc = 0.0f;
-    for (int n = 0; n < kWidth; ++n)                                   // lanes along k: coalesced rows
-        acc += 15.0f * Wg[(int64_t)n * kWidth + k] * dg[n] + 0.25f * Wb[(int64_t)n * kWidth + k] * db[n];
+    for (int n0 = 0; n0 < kWidth; n0 += 16) {                          // lanes along k: coalesced rows; 32 loads in flight (nine blocks of
+        float wgv[16], wbv[16];                                        // 256 dependent round trips were 28 us at the end of every backward)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { wgv[i] = Wg[(int64_t)(n0 + i) * kWidth + k]; wbv[i] = Wb[(int64_t)(n0 + i) * kWidth + k]; }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += 15.0f * wgv[i] * dg[n0 + i] + 0.25f * wbv[i] * db[n0 + i];       // (the same expression, the same order)
+    }
     dstyles[((int64_t)b * 9 + l) * kWidth + k] = acc;
 }
 
