@@ -140,10 +140,11 @@ def decoder_backend():
 
 def decoder_autograd_backend():
     """What Decoder.forward does when an autograd graph is wanted through it (features / latent / parameters require grad):
-    'auto' (default): when ONLY the feature map needs a gradient (generator frozen, decoder latent without grad: train_ae.py's
-    stage-1 step, trainer.py:1017-1031) the packed forward (e3dge_dec2_forward) runs inside an autograd.Function whose backward is
-    the packed pipeline's own data gradient (e3dge_dec2_backward, csrc/decoder2_bwd.h); anything else -- d latent, a decoder
-    parameter that requires grad -- takes the library path (weight modulation + MIOpen) for both directions.
+    'auto' (default): when the feature map and / or the decoder latent need a gradient and no decoder parameter does (generator frozen:
+    train_ae.py's stage-1 step, trainer.py:1017-1031, where the encoder predicts both latents, :881-897) the packed forward
+    (e3dge_dec2_forward) runs inside an autograd.Function whose backward is the packed pipeline's own e3dge_dec2_backward
+    (csrc/decoder2_bwd.h: d features, and d latent from per-channel sums unless E3DGE_DEC2_DLATENT=0); a decoder parameter that
+    requires grad takes the library path (weight modulation + MIOpen) for both directions.
     'packed': always the packed forward; the backward is native when eligible, otherwise it recomputes the library path under
     enable_grad and differentiates that (for passes that run with grad enabled but never call backward).
     'library': the library path for both directions (round 4's default; A/B).  The packed node is first-order only: a second
@@ -158,9 +159,9 @@ def decoder_autograd_backend():
 
 class _PackedDecoderFn(torch.autograd.Function):
     """Decoder.forward as one native call (packed pipeline) that stays inside an autograd graph (reference: stylesdf_model.py:317-362,
-    741-797).  backward, when only d features is wanted (generator frozen): e3dge_dec2_backward on the activations the forward left
-    in its workspace -- if another forward has used the workspace since, the packed forward is re-run first (0.65 ms at 1024^2).
-    Otherwise (d latent / parameter gradients): the same forward is re-run on the library path (every op differentiable) with the
+    741-797).  backward, when only d features / d latent are wanted (generator frozen): e3dge_dec2_backward on the activations the forward
+    left in its workspace -- if another forward has used the workspace since, the packed forward is re-run first (0.65 ms at 1024^2).
+    Otherwise (parameter gradients, or d latent with E3DGE_DEC2_DLATENT=0): the same forward is re-run on the library path (every op differentiable) with the
     saved inputs and the SAME noise, and `torch.autograd.grad` of that graph gives the gradients.  First-order only."""
 
     @staticmethod
