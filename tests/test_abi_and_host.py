@@ -278,6 +278,25 @@ def test_points_launch_geometry_minimises_the_span_in_256_cu_rounds(lib):
     assert lib.e3dge_siren_bwd_partial_floats(1, 98304) == 256 * per_wg                       # 768 tiles: 256 workgroups x 3
 
 
+def test_round5_backend_switches_are_validated(monkeypatch):
+    """The A/B switches of round 5 accept their documented values only (a typo must not silently select a path)."""
+    from e3dge_amd import stylesdf_model as sm, volume_renderer as vr
+    monkeypatch.setenv("E3DGE_TEXHEAD_BWD", "library")
+    assert vr.tex_head_backward_backend() == "library"
+    monkeypatch.setenv("E3DGE_TEXHEAD_BWD", "Hip")
+    assert vr.tex_head_backward_backend() == "hip"
+    monkeypatch.setenv("E3DGE_TEXHEAD_BWD", "fast")
+    with pytest.raises(ValueError, match="E3DGE_TEXHEAD_BWD"):
+        vr.tex_head_backward_backend()
+    monkeypatch.delenv("E3DGE_DEC2_DLATENT", raising=False)
+    assert sm.decoder_dlatent_native() is True
+    monkeypatch.setenv("E3DGE_DEC2_DLATENT", "0")
+    assert sm.decoder_dlatent_native() is False
+    monkeypatch.setenv("E3DGE_DECODER_AUTOGRAD", "fast")
+    with pytest.raises(RuntimeError, match="E3DGE_DECODER_AUTOGRAD"):
+        sm.decoder_autograd_backend()
+
+
 def test_host_helpers_that_need_no_gpu(lib):
     assert lib.e3dge_upfirdn2d_out_size(129, 1, 1, 1, 1, 4) == 128     # Blur after the 64->129 transposed conv
     assert lib.e3dge_upfirdn2d_out_size(64, 2, 1, 2, 1, 4) == 128      # skip Upsample
