@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E3DGE_LIB_PATH") or os.path.join(_HERE, "lib", "libe3dge_hip.so")   # override: kernel A/B variants
-ABI_VERSION = 12
+ABI_VERSION = 13
 PREC_F32, PREC_F16X3, PREC_F16X3_V1, PREC_F16X3_G2 = 0, 1, 2, 3
 AMAX_FLOATS = 64 * 32           # E3DGE_AMAX_FLOATS: one amax buffer (include/e3dge_hip.h)
 
@@ -170,6 +170,7 @@ SIGNATURES = {
     "e3dge_siren_bwd": (_i32, [ctypes.POINTER(SirenBwdArgs), _vp]),
     "e3dge_siren_sdf_grad": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _i64, _vp, _vp, _i32, _vp]),
     "e3dge_siren_tangent": (_i32, [_vp, _vp, _vp, _vp, _f32, _i32, _i64, _vp, _i32, _vp]),
+    "e3dge_siren_tangent_tr": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _i32, _i64, _vp, _i32, _vp]),
     "e3dge_siren_render_bwd": (_i32, [ctypes.POINTER(RenderBwdArgs), _vp]),
     "e3dge_resblock_packed_floats": (_i64, []),
     "e3dge_resblock_pack_weights": (_i32, [_vp] * 6 + [_i32, _vp]),

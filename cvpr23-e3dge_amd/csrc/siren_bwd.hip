@@ -622,6 +622,7 @@ struct SirenChainK {
     const float* args;       // (batch, n_pts, 9, 256)
     const float* seed;       // TANGENT: v (batch, n_pts, 3);  else: per-point scale of r_7 (batch, n_pts) or null (= 1)
     float* save;             // (batch, n_pts, 8, 256): ta_l or r_l
+    const float* rmul;       // 8-wave tangent kernel, product form: r_l of the sdf chain (batch, n_pts, 8, 256); save <- ta_l r_l
     float* eik;              // (batch, n_pts, 3), sdf chain only
     float box_scale;
     long long n_pts;
@@ -1049,6 +1050,35 @@ bwd_reduce_kernel(float* __restrict__ dfilm, const float* __restrict__ partials,
     }
 }
 
+// The 8-wave kernels (siren16_bwd.h) leave per slice S_a = sum(da a [+ ta r cos a]) in the gamma rows and S_b = sum(da) in the beta rows:
+// with z = (a - beta) / gamma,  d gamma = sum(da z [+ ...] / gamma) = (S_a - beta S_b) / gamma,  d beta = S_b.  One thread folds both rows
+// of a (layer, feature) over its share of the slices; fixed association order -> bit-reproducible.
+__global__ void __launch_bounds__(64 * kRedGroups)
+bwd_reduce_fin_kernel(float* __restrict__ dfilm, const float* __restrict__ partials, const float* __restrict__ film, int n_slices) {
+    __shared__ float part[2][kRedGroups][64];
+    const int b = blockIdx.y;
+    const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int ln = blockIdx.x * 64 + el;                               // (layer, feature) < 9*256
+    const int l = ln >> 8, n = ln & 255;
+    const float* p = partials + (int64_t)b * n_slices * (9 * 2 * kWidth) + (l * 2) * kWidth + n;
+    float sa = 0.0f, sb = 0.0f;
+    for (int s = g; s < n_slices; s += kRedGroups) {
+        sa += p[(int64_t)s * (9 * 2 * kWidth)];
+        sb += p[(int64_t)s * (9 * 2 * kWidth) + kWidth];
+    }
+    part[0][g][el] = sa; part[1][g][el] = sb;
+    __syncthreads();
+    if (g == 0) {
+        float ta = 0.0f, tb = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kRedGroups; ++i) { ta += part[0][i][el]; tb += part[1][i][el]; }
+        const float* fb = film + ((int64_t)b * 9 + l) * 2 * kWidth;
+        float* o = dfilm + ((int64_t)b * 9 + l) * 2 * kWidth;
+        o[n] = __fdiv_rn(ta - fb[kWidth + n] * tb, fb[n]);
+        o[kWidth + n] = tb;
+    }
+}
+
 // d(styles)[b][l][k] = 15 * sum_n Wg_l[n][k] dgamma[b][l][n] + 0.25 * sum_n Wb_l[n][k] dbeta[b][l][n]
 // (backward of LinearLayer.forward :76-80; film_params_kernel is the forward)
 __global__ void __launch_bounds__(256)
@@ -1073,9 +1103,7 @@ film_bwd_kernel(float* __restrict__ dstyles, const float* __restrict__ dfilm, co
 
 }  // namespace e3dge
 
-#ifdef E3DGE_EXPERIMENTAL      // the 8-wave backward / chain kernels (mode f16x3_g2): slower than the default and 16-196 B of scratch -- A/B builds only
-#include "siren16_bwd.h"
-#endif
+#include "siren16_bwd.h"      // the 8-wave x 16-point generation (E3DGE_PREC_F16X3_G2)
 
 using namespace e3dge;
 
@@ -1091,7 +1119,7 @@ extern "C" int64_t e3dge_siren_bwd_partial_floats(int batch, int64_t n_pts) {
     if (batch <= 0 || n_pts <= 0) return 0;
     int spw, wpi;
     bwd_geometry(batch, n_pts, &spw, &wpi);
-    return (int64_t)batch * wpi * (9 * 2 * kWidth);
+    return (int64_t)batch * wpi * spw * (9 * 2 * kWidth);      // one slice per sub-tile (8-wave kernels); per workgroup (first generation)
 }
 
 static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfilm, float* dstyles, hipStream_t st) {
@@ -1102,8 +1130,12 @@ static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfil
                     reinterpret_cast<uintptr_t>(k.d_featmap)) & 15) == 0,
                   "siren_bwd: packed/args/d_feat must be 16-B aligned");
     float* const partials = k.partials;
-    E3DGE_REQUIRE((k.tang == nullptr) == (k.rsave == nullptr), "siren_bwd: tang and rsave must come together");
     E3DGE_REQUIRE(k.precision >= E3DGE_PREC_F32 && k.precision <= E3DGE_PREC_F16X3_G2, "siren_bwd: precision=%d", k.precision);
+    const bool gen2 = k.precision == E3DGE_PREC_F16X3_G2;
+    // first generation: tang = ta_l and rsave = r_l, both or neither; 8-wave generation: tang = the products ta_l r_l of
+    // e3dge_siren_tangent_tr, rsave must be NULL
+    if (gen2) E3DGE_REQUIRE(k.rsave == nullptr, "siren_bwd: precision f16x3_g2 takes the products ta*r in `tang` (e3dge_siren_tangent_tr) and no rsave");
+    else E3DGE_REQUIRE((k.tang == nullptr) == (k.rsave == nullptr), "siren_bwd: tang and rsave must come together");
     E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(k.tang) | reinterpret_cast<uintptr_t>(k.rsave)) & 15) == 0, "siren_bwd: tang/rsave must be 16-B aligned");
     const bool tex = k.tex_alpha != nullptr;
     E3DGE_REQUIRE(tex == (k.d_tex_alpha != nullptr) && tex == (k.d_tex_beta != nullptr), "siren_bwd: tex_alpha, d_tex_alpha, d_tex_beta must come together");
@@ -1120,39 +1152,32 @@ static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfil
         &siren_bwd_kernel<false, false, true, false>, &siren_bwd_kernel<false, true, true, false>};
     E3DGE_REQUIRE(!(tex && k.d_pts), "siren_bwd: d_pts is not available on the tex-FiLM pass");
     const int f16 = k.precision != E3DGE_PREC_F32;
-#ifdef E3DGE_EXPERIMENTAL
-    // second generation (8 waves x 16 points): [dpts][eik], then the tex variant
+    // 8-wave generation (8 waves x 16 points): [dpts][eik], then the tex variant
     static const KernelFn fns16[5] = {
         &siren16_bwd_kernel<false, false, false>, &siren16_bwd_kernel<true, false, false>,
         &siren16_bwd_kernel<false, false, true>, &siren16_bwd_kernel<true, false, true>,
         &siren16_bwd_kernel<false, true, false>};
-    const bool gen2 = k.precision == E3DGE_PREC_F16X3_G2;
-    const KernelFn fn = gen2 ? fns16[tex ? 4 : 2 * (k.d_pts != nullptr) + (k.tang != nullptr)]
-                             : fns[tex ? 8 + f16 : 4 * (k.d_pts != nullptr) + 2 * (k.tang != nullptr) + f16];
-    const int lds_bytes = gen2 ? kB16LdsBytes : kBwdLdsBytes;
-#else
-    E3DGE_REQUIRE(k.precision != E3DGE_PREC_F16X3_G2, "siren_bwd: precision f16x3_g2 is only in -DE3DGE_EXPERIMENTAL builds");
-    const KernelFn fn = fns[tex ? 8 + f16 : 4 * (k.d_pts != nullptr) + 2 * (k.tang != nullptr) + f16];
-    const int lds_bytes = kBwdLdsBytes;
-#endif
+    const bool eik = k.tang != nullptr, dpts = k.d_pts != nullptr;
+    const KernelFn fn = gen2 ? fns16[tex ? 4 : 2 * dpts + eik] : fns[tex ? 8 + f16 : 4 * dpts + 2 * eik + f16];
+    const int lds_bytes = gen2 ? b16_lds_bytes(eik ? 2 : 1, dpts) : kBwdLdsBytes;
     k.precision = f16 ? E3DGE_PREC_F16X3 : E3DGE_PREC_F32;
     {   // the attribute is per device (and cheap): set it on the launch's device every time
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(siren_bwd): %s", hipGetErrorString(e));
     }
     bwd_geometry(batch, n_pts, &k.subtiles_per_wg, &k.wgs_per_img);
+    if (gen2) E3DGE_REQUIRE((int64_t)k.subtiles_per_wg * kTilePts * 9 * kWidth * 4 < ((int64_t)1 << 31), "siren_bwd: workgroup span exceeds the 32-bit stream offsets");
     if (n_pts > 0) {
         const int64_t grid = (int64_t)k.wgs_per_img * batch;
         E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_bwd: grid too large");
-#ifdef E3DGE_EXPERIMENTAL
         fn<<<dim3((unsigned)grid), dim3(gen2 ? k16Threads : kThreads), lds_bytes, st>>>(k);
-#else
-        fn<<<dim3((unsigned)grid), dim3(kThreads), lds_bytes, st>>>(k);
-#endif
         int rc = check_launch("siren_bwd");
         if (rc) return rc;
     }
-    bwd_reduce_kernel<<<dim3(9 * 2 * kWidth / 64, (unsigned)batch), dim3(64 * kRedGroups), 0, st>>>(dfilm, partials, n_pts > 0 ? k.wgs_per_img : 0);
+    if (gen2)
+        bwd_reduce_fin_kernel<<<dim3(9 * kWidth / 64, (unsigned)batch), dim3(64 * kRedGroups), 0, st>>>(dfilm, partials, k.film, n_pts > 0 ? k.wgs_per_img * k.subtiles_per_wg : 0);
+    else
+        bwd_reduce_kernel<<<dim3(9 * 2 * kWidth / 64, (unsigned)batch), dim3(64 * kRedGroups), 0, st>>>(dfilm, partials, n_pts > 0 ? k.wgs_per_img : 0);
     int rc = check_launch("siren_bwd(reduce)");
     if (rc) return rc;
     film_bwd_kernel<<<dim3((unsigned)(batch * 9)), dim3(256), 0, st>>>(dstyles, dfilm, wg, wb);
@@ -1210,52 +1235,56 @@ extern "C" int e3dge_siren_render_bwd(const E3dgeRenderBwdArgs* r, e3dge_stream_
 }
 
 template <bool TANGENT>
-static int launch_chain(const float* packed, const float* film, const float* args, const float* seed, float box_scale,
+static int launch_chain(const float* packed, const float* film, const float* args, const float* seed, const float* rmul, float box_scale,
                         int batch, int64_t n_pts, float* save, float* eik, int precision, hipStream_t st, const char* what) {
     E3DGE_REQUIRE(precision >= E3DGE_PREC_F32 && precision <= E3DGE_PREC_F16X3_G2, "%s: precision=%d", what, precision);
     E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "%s: bad sizes", what);
     if (batch == 0 || n_pts == 0) return E3DGE_OK;
     E3DGE_REQUIRE(packed && film && args && save && (TANGENT ? seed != nullptr : eik != nullptr), "%s: null pointer", what);
-    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(args) | reinterpret_cast<uintptr_t>(save)) & 15) == 0,
-                  "%s: packed/args/save must be 16-B aligned", what);
-#ifdef E3DGE_EXPERIMENTAL
+    E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(args) | reinterpret_cast<uintptr_t>(save) |
+                    reinterpret_cast<uintptr_t>(rmul)) & 15) == 0, "%s: packed/args/save/rsave must be 16-B aligned", what);
     const bool gen2 = precision == E3DGE_PREC_F16X3_G2;
-#else
-    constexpr bool gen2 = false;
-    E3DGE_REQUIRE(precision != E3DGE_PREC_F16X3_G2, "%s: precision f16x3_g2 is only in -DE3DGE_EXPERIMENTAL builds", what);
-#endif
+    E3DGE_REQUIRE(rmul == nullptr || (TANGENT && gen2), "%s: the product form (ta * r) exists for the tangent pass in precision f16x3_g2 only", what);
+    const bool tr = rmul != nullptr;
+    typedef void (*ChainFn)(const SirenChainK);
+    ChainFn fn;
+    int lds_bytes = kChLdsBytes, threads = kThreads;
+    if (gen2) {
+        if (TANGENT) fn = tr ? &siren16_chain_kernel<TANGENT, TANGENT> : &siren16_chain_kernel<TANGENT, false>;
+        else fn = &siren16_chain_kernel<TANGENT, false>;
+        lds_bytes = c16_lds_bytes(tr ? 2 : 1); threads = k16Threads;
+    } else {
+        fn = (precision != E3DGE_PREC_F32) ? &siren_chain_kernel<TANGENT, true> : &siren_chain_kernel<TANGENT, false>;
+    }
     {   // per device, cheap: set on every launch
-        const void* fn = (precision != E3DGE_PREC_F32) ? reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, true>)
-                                                       : reinterpret_cast<const void*>(&siren_chain_kernel<TANGENT, false>);
-        int lds_bytes = kChLdsBytes;
-#ifdef E3DGE_EXPERIMENTAL
-        if (gen2) { fn = reinterpret_cast<const void*>(&siren16_chain_kernel<TANGENT>); lds_bytes = kC16LdsBytes; }
-#endif
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
     }
     SirenChainK k{};
-    k.packed = packed; k.film = film; k.args = args; k.seed = seed; k.save = save; k.eik = eik; k.box_scale = box_scale;
+    k.packed = packed; k.film = film; k.args = args; k.seed = seed; k.save = save; k.rmul = rmul; k.eik = eik; k.box_scale = box_scale;
     k.n_pts = n_pts; k.batch = batch;
     bwd_geometry(batch, n_pts, &k.subtiles_per_wg, &k.wgs_per_img);
+    if (gen2) E3DGE_REQUIRE((int64_t)k.subtiles_per_wg * kTilePts * 9 * kWidth * 4 < ((int64_t)1 << 31), "%s: workgroup span exceeds the 32-bit stream offsets", what);
     const int64_t grid = (int64_t)k.wgs_per_img * batch;
     E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "%s: grid too large", what);
-#ifdef E3DGE_EXPERIMENTAL
-    if (gen2) { siren16_chain_kernel<TANGENT><<<dim3((unsigned)grid), dim3(k16Threads), kC16LdsBytes, st>>>(k); return check_launch(what); }
-#endif
-    if (precision != E3DGE_PREC_F32) siren_chain_kernel<TANGENT, true><<<dim3((unsigned)grid), dim3(kThreads), kChLdsBytes, st>>>(k);
-    else siren_chain_kernel<TANGENT, false><<<dim3((unsigned)grid), dim3(kThreads), kChLdsBytes, st>>>(k);
+    fn<<<dim3((unsigned)grid), dim3(threads), lds_bytes, st>>>(k);
     return check_launch(what);
 }
 
 extern "C" int e3dge_siren_sdf_grad(const float* packed, const float* film, const float* args, const float* seed,
                                     float box_scale, int batch, int64_t n_pts, float* rsave, float* eik,
                                     int precision, e3dge_stream_t stream) {
-    return launch_chain<false>(packed, film, args, seed, box_scale, batch, n_pts, rsave, eik, precision, as_stream(stream), "siren_sdf_grad");
+    return launch_chain<false>(packed, film, args, seed, nullptr, box_scale, batch, n_pts, rsave, eik, precision, as_stream(stream), "siren_sdf_grad");
 }
 
 extern "C" int e3dge_siren_tangent(const float* packed, const float* film, const float* args, const float* v,
                                    float box_scale, int batch, int64_t n_pts, float* tang, int precision,
                                    e3dge_stream_t stream) {
-    return launch_chain<true>(packed, film, args, v, box_scale, batch, n_pts, tang, nullptr, precision, as_stream(stream), "siren_tangent");
+    return launch_chain<true>(packed, film, args, v, nullptr, box_scale, batch, n_pts, tang, nullptr, precision, as_stream(stream), "siren_tangent");
+}
+
+extern "C" int e3dge_siren_tangent_tr(const float* packed, const float* film, const float* args, const float* v, const float* rsave,
+                                      float box_scale, int batch, int64_t n_pts, float* tr, int precision, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(rsave != nullptr, "siren_tangent_tr: rsave is required");
+    return launch_chain<true>(packed, film, args, v, rsave, box_scale, batch, n_pts, tr, nullptr, precision, as_stream(stream), "siren_tangent_tr");
 }

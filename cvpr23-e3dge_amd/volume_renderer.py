@@ -121,7 +121,7 @@ def _overlap_decoder():
     return os.environ.get("E3DGE_OVERLAP_DECODER", "1") != "0"
 
 
-# backward-type launches additionally know the experimental 8-wave layout (E3DGE_PREC_F16X3_G2; tools/bwd_ab.py)
+# backward-type launches additionally know the 8-wave x 16-point layout (E3DGE_PREC_F16X3_G2, csrc/siren16_bwd.h)
 BWD_MODES = dict(MFMA_MODES, f16x3_g2=_lib.PREC_F16X3_G2)
 _STRICT_CACHE = os.environ.get("E3DGE_STRICT_WEIGHT_CACHE", "0") not in ("", "0")
 
@@ -420,19 +420,28 @@ def sdf_gradient(siren, film, args, box_scale):
     return eik, rsave
 
 
-def tangent_arguments(siren, film, args, v, box_scale, images=None):
+def tangent_arguments(siren, film, args, v, box_scale, images=None, rsave=None):
     """Tangent arguments (B,N,8,256) along v = dL/de (B,N,3) (e3dge_siren_tangent).  `images`: siren.device_image() as the forward
     of the same autograd node saw it (a backward differentiates the weights its saved arguments were computed with, and skipping the
-    cache-key check keeps ~20 us of host time out of the gap in front of the launch)."""
+    cache-key check keeps ~20 us of host time out of the gap in front of the launch).
+    Returns (tang, rs) as e3dge_siren_bwd / e3dge_siren_render_bwd take them: in the 8-wave backward mode (`f16x3_g2`) with `rsave`
+    given, `tang` holds the PRODUCTS ta_l r_l (e3dge_siren_tangent_tr: the only form in which the two ever enter the second-order
+    backward) and rs is None; otherwise (ta_l, rsave)."""
     packed = (images if images is not None else siren.device_image())[0]
     B, N = args.shape[0], args.shape[1]
     v = v.reshape(B, N, 3).contiguous().float()
     tang = torch.empty((B, N, 8, siren.W), device=args.device, dtype=torch.float32)
+    prec = siren.check_mode(siren.bwd_mode)
     with _lib.on_device(args.device):
-        rc = _lib.load().e3dge_siren_tangent(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), _lib.ptr(v), float(box_scale),
-                                             B, N, _lib.ptr(tang), siren.check_mode(siren.bwd_mode), _lib.stream_of(args))
+        if prec == _lib.PREC_F16X3_G2 and rsave is not None:
+            rc = _lib.load().e3dge_siren_tangent_tr(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), _lib.ptr(v), _lib.ptr(rsave),
+                                                    float(box_scale), B, N, _lib.ptr(tang), prec, _lib.stream_of(args))
+            rsave = None
+        else:
+            rc = _lib.load().e3dge_siren_tangent(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), _lib.ptr(v), float(box_scale),
+                                                 B, N, _lib.ptr(tang), prec, _lib.stream_of(args))
     _lib.check(rc, "e3dge_siren_tangent")
-    return tang
+    return tang, rsave
 
 
 def siren_backward(siren, film, args, d_feat, d_rgb, d_sdf, tang=None, rsave=None, want_d_pts=False, box_scale=1.0,
@@ -501,7 +510,7 @@ class _PointsQuery(torch.autograd.Function):
             ds = d_raw[..., 3] if ds is None else ds + d_raw[..., 3]
         tang = rs = None
         if ctx.want_eik and d_eik is not None:
-            tang, rs = tangent_arguments(ctx.siren, film, args, d_eik, ctx.box_scale, ctx.images), rsave
+            tang, rs = tangent_arguments(ctx.siren, film, args, d_eik, ctx.box_scale, ctx.images, rsave)
         dstyles, _, d_pts, _ = siren_backward(ctx.siren, film, args, d_feat, d_rgb, ds, tang, rs,
                                               want_d_pts=ctx.needs_input_grad[2], box_scale=ctx.box_scale, images=ctx.images)
         if ctx.styles_ndim == 2:                   # one W shared by the nine layers (reference :189-191)
@@ -515,10 +524,10 @@ _AUX_KEYS = ('mask', 'points', 'rays_d', 'viewdirs', 'dists')
 
 class _EikShared:
     """What the eikonal tap below and _RenderQuery.backward share: the tangent arguments of the incoming d(eikonal term)."""
-    __slots__ = ("siren", "film", "args", "box_scale", "tang", "d_eik", "images", "side", "tang_stream")
+    __slots__ = ("siren", "film", "args", "box_scale", "tang", "d_eik", "images", "side", "tang_stream", "rsave", "rs")
 
     def __init__(self):
-        self.siren = self.film = self.args = self.box_scale = self.tang = self.d_eik = self.images = None
+        self.siren = self.film = self.args = self.box_scale = self.tang = self.d_eik = self.images = self.rsave = self.rs = None
         self.side = self.tang_stream = None          # (deferred mode: the stream the chain ran on / the tangent runs on)
 
 
@@ -544,12 +553,12 @@ class _EikTap(torch.autograd.Function):
                 cur = torch.cuda.current_stream(d_eik.device)
                 sh.side.wait_stream(cur)
                 with torch.cuda.stream(sh.side):
-                    sh.tang = tangent_arguments(sh.siren, sh.film, sh.args, d_eik, sh.box_scale, sh.images)
+                    sh.tang, sh.rs = tangent_arguments(sh.siren, sh.film, sh.args, d_eik, sh.box_scale, sh.images, sh.rsave)
                 d_eik.record_stream(sh.side)
                 sh.tang.record_stream(cur)
                 sh.tang_stream = sh.side
             else:
-                sh.tang = tangent_arguments(sh.siren, sh.film, sh.args, d_eik, sh.box_scale, sh.images)
+                sh.tang, sh.rs = tangent_arguments(sh.siren, sh.film, sh.args, d_eik, sh.box_scale, sh.images, sh.rsave)
         return d_eik, None
 
 
@@ -612,6 +621,7 @@ class _RenderQuery(torch.autograd.Function):
         if shared is not None:
             shared.siren, shared.film, shared.args, shared.box_scale = renderer.siren, film, args, renderer.box_scale
             shared.images = renderer.siren.device_image()
+            shared.rsave = rsave if want_eik else None
         ta = tex[0].contiguous() if tex is not None else torch.empty(0, device=c2w.device)
         ctx.save_for_backward(film, args, out['sdf'], out['dists'], out['points'], out['hit_prob'],
                               near.reshape(B).contiguous().float(), far.reshape(B).contiguous().float(), rsave, ta)
@@ -645,14 +655,13 @@ class _RenderQuery(torch.autograd.Function):
             sh = ctx.shared
             if (sh is not None and sh.tang is not None and sh.d_eik.data_ptr() == d_eik.data_ptr()
                     and sh.d_eik.shape == d_eik.shape):                     # launched early by _EikTap.backward
-                tang = sh.tang
+                tang, rs = sh.tang, sh.rs
                 if sh.tang_stream is not None:                              # (deferred mode: it ran on the side stream)
                     torch.cuda.current_stream(dev).wait_stream(sh.tang_stream)
             else:
-                tang = tangent_arguments(siren, film, args, d_eik, r.box_scale, ctx.images)
+                tang, rs = tangent_arguments(siren, film, args, d_eik, r.box_scale, ctx.images, rsave)
             if sh is not None:
-                sh.tang = sh.d_eik = sh.args = sh.film = sh.images = sh.tang_stream = None
-            rs = rsave
+                sh.tang = sh.d_eik = sh.args = sh.film = sh.images = sh.tang_stream = sh.rsave = sh.rs = None
         d_ta = d_tb = tex_a = None
         if ctx.has_tex:
             tex_a = ta

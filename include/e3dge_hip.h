@@ -349,9 +349,10 @@ int e3dge_hitprob_composite(float* out, const float* sdf, const float* aux, cons
 #define E3DGE_PREC_F16X3_V1 2     /* forward launches: the first-generation split-f16 kernel (4 waves x 32 points,
                                      v_mfma_f32_32x32x16_f16), kept for A/B measurements; backward-type launches: same as
                                      E3DGE_PREC_F16X3 */
-#define E3DGE_PREC_F16X3_G2 3     /* backward-type launches only (e3dge_siren_bwd / _render_bwd / _sdf_grad / _tangent): the
-                                     8-wave x 16-point layout of the forward kernel applied to the backward chains.  Same results
-                                     within rounding, not faster -- kept for A/B measurements (tools/bwd_ab.py) */
+#define E3DGE_PREC_F16X3_G2 3     /* backward-type launches only (e3dge_siren_bwd / _render_bwd / _sdf_grad / _tangent / _tangent_tr):
+                                     the 8-wave x 16-point layout of the forward kernel applied to the backward chains, saved-state
+                                     streams by LDS-DMA (csrc/siren16_bwd.h).  Same block-scaled split-f16 arithmetic
+                                     as E3DGE_PREC_F16X3; the second-order inputs come as the products ta_l r_l (see below) */
 
 /* Number of floats of the packed weight image produced by e3dge_siren_pack_weights. */
 int64_t e3dge_siren_packed_floats(void);
@@ -501,6 +502,12 @@ int e3dge_siren_sdf_grad(const float* packed, const float* film, const float* ar
                          e3dge_stream_t stream);
 int e3dge_siren_tangent(const float* packed, const float* film, const float* args, const float* v,
                         float box_scale, int batch, int64_t n_pts, float* tang, int precision, e3dge_stream_t stream);
+/* ABI 13, precision E3DGE_PREC_F16X3_G2 only: the tangent pass in product form.  ta_l and r_l enter the second-order backward only as
+ * ta_l * r_l (adj(a_l) -= sin(a_l) ta_l r_l, adj(gamma_l) += ta_l r_l cos(a_l) / gamma_l), so this launch reads rsave (the sdf
+ * chain's r_l) beside the arguments and stores tr (batch, n_pts, 8, 256) = ta_l r_l; e3dge_siren_bwd / e3dge_siren_render_bwd in the
+ * same precision take it as `tang` with `rsave` = NULL -- one 8-KB-per-point stream less in the longest kernel of the training step. */
+int e3dge_siren_tangent_tr(const float* packed, const float* film, const float* args, const float* v, const float* rsave,
+                           float box_scale, int batch, int64_t n_pts, float* tr, int precision, e3dge_stream_t stream);
 
 /* Backward of e3dge_siren_render_fwd: volume_integration (volume_renderer.py:809-943) back to the per-point outputs
  * (one wave per ray), then the MLP chain above.  Gradient maps are ROW-MAJOR PER RAY (ray = (b*H + y)*W + x):

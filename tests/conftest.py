@@ -76,13 +76,13 @@ def maxerr(a, b):
 
 
 def contraction_modes(*modes):
-    """Contraction modes to parametrize over: the experimental ones (first-generation split-f16 forward 'f16x3_v1', the 8-wave
-    backward kernels 'f16x3_g2') exist only in -DE3DGE_EXPERIMENTAL builds of the library (include/e3dge_hip_experimental.h) and
-    are dropped when the loaded library does not have them."""
+    """Contraction modes to parametrize over: the experimental one (first-generation split-f16 forward 'f16x3_v1') exists only in
+    -DE3DGE_EXPERIMENTAL builds of the library (include/e3dge_hip_experimental.h) and is dropped when the loaded library does not
+    have it.  'f16x3_g2' (the 8-wave backward-type kernels, csrc/siren16_bwd.h) is part of every build since round 6."""
     import e3dge_amd  # noqa: F401
     from e3dge_amd import _lib
     try:
         exp = _lib.has_experimental()
     except Exception:
         exp = False
-    return [m for m in modes if exp or m not in ("f16x3_v1", "f16x3_g2")]
+    return [m for m in modes if exp or m != "f16x3_v1"]

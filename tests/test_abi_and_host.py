@@ -267,15 +267,15 @@ def test_wgrad_host_side_rules(monkeypatch):
 def test_points_launch_geometry_minimises_the_span_in_256_cu_rounds(lib):
     """Round 5: the sub-tiles a workgroup of a points launch walks are chosen by the launch's span (rounds of 256 workgroups x sub-tiles), the
     largest count among the shortest spans.  Visible through the backward's partial-sum workspace = batch x workgroups per image x 9 x 2 x 256."""
-    per_wg = 9 * 2 * 256
+    per_wg = 9 * 2 * 256                                            # (round 6: one slice per 128-point sub-tile -- workgroups x sub-tiles per workgroup)
     tiles = 73728 // 128                                            # 64 x 64 x 18 samples: 576 tiles of 128 points
-    assert lib.e3dge_siren_bwd_partial_floats(1, 73728) == 1 * (tiles // 3) * per_wg          # 192 workgroups x 3 (one round; 64 CUs stay free)
-    assert lib.e3dge_siren_bwd_partial_floats(2, 73728) == 2 * 116 * per_wg                   # 5 sub-tiles: 232 workgroups, one round of 5
+    assert lib.e3dge_siren_bwd_partial_floats(1, 73728) == 1 * (tiles // 3) * 3 * per_wg      # 192 workgroups x 3 (one round; 64 CUs stay free)
+    assert lib.e3dge_siren_bwd_partial_floats(2, 73728) == 2 * 116 * 5 * per_wg               # 5 sub-tiles: 232 workgroups, one round of 5
     # four samples: 8 sub-tiles would be 288 workgroups = TWO rounds of 8 for 9 rounds of work (the rule until round 5); 3 x 768 = three full rounds
-    assert lib.e3dge_siren_bwd_partial_floats(4, 73728) == 4 * 192 * per_wg
-    assert lib.e3dge_siren_bwd_partial_floats(8, 73728) == 8 * 96 * per_wg                    # 6 sub-tiles: 768 workgroups, three rounds of 6 = 18
+    assert lib.e3dge_siren_bwd_partial_floats(4, 73728) == 4 * 192 * 3 * per_wg
+    assert lib.e3dge_siren_bwd_partial_floats(8, 73728) == 8 * 96 * 6 * per_wg                # 6 sub-tiles: 768 workgroups, three rounds of 6 = 18
     assert lib.e3dge_siren_bwd_partial_floats(1, 4096) == 32 * per_wg                         # the surface points: one tile per workgroup
-    assert lib.e3dge_siren_bwd_partial_floats(1, 98304) == 256 * per_wg                       # 768 tiles: 256 workgroups x 3
+    assert lib.e3dge_siren_bwd_partial_floats(1, 98304) == 256 * 3 * per_wg                       # 768 tiles: 256 workgroups x 3
 
 
 def test_round5_backend_switches_are_validated(monkeypatch):

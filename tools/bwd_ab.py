@@ -1,4 +1,4 @@
-"""A/B of the backward-direction kernels: first generation (mode f16x3: 4 waves x 32 points) vs the 8-wave layout (f16x3_g2) vs fp32,
+"""A/B of the backward-direction kernels: first generation (mode f16x3: 4 waves x 32 points) vs the 8-wave layout (f16x3_g2, round 6) vs fp32,
 on a saved 64x64x24 forward, per entry point: time per call and the largest deviation from the fp32 kernels relative to the
 largest fp32 value of the same output.   python tools/bwd_ab.py [batch] [iters]"""
 import json
@@ -16,7 +16,7 @@ from e3dge_amd.volume_renderer import (VolumeFeatureRenderer, sdf_gradient, sire
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-dev, res, S = "cuda:0", 64, 24
+dev, res, S = "cuda:0", 64, int(os.environ.get("BWD_AB_S", "24"))
 r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S), out_im_res=res, mode='test')
 syn.load_synthetic(r, prefix='renderer.')
 r = r.to(dev)
@@ -65,14 +65,17 @@ results, ref = {}, {}
 for mode in os.environ.get("BWD_AB_MODES", "f32,f16x3,f16x3_g2").split(","):
     r.siren.bwd_mode = mode
     eik, rsave = sdf_gradient(r.siren, film, args, box)
-    tang = tangent_arguments(r.siren, film, args, v, box)
+    tang, rs_ = tangent_arguments(r.siren, film, args, v, box, rsave=rsave)      # (f16x3_g2: tang = the products ta r, rs_ None)
     cases = {
         "bwd": lambda: siren_backward(r.siren, film, args, d_feat, d_rgb, d_sdf),
         "bwd_dpts": lambda: siren_backward(r.siren, film, args, d_feat, d_rgb, d_sdf, want_d_pts=True, box_scale=box),
-        "bwd_eik": lambda: siren_backward(r.siren, film, args, d_feat, d_rgb, d_sdf, tang=tang, rsave=rsave),
+        "bwd_eik": lambda: siren_backward(r.siren, film, args, d_feat, d_rgb, d_sdf, tang=tang, rsave=rs_),
+        "bwd_eik_dpts": lambda: siren_backward(r.siren, film, args, d_feat, d_rgb, d_sdf, tang=tang, rsave=rs_, want_d_pts=True, box_scale=box),
         "bwd_tex": lambda: siren_backward(r.siren, film, args, d_feat, d_rgb, d_sdf, tex_alpha=tex_alpha),
         "sdf_grad": lambda: sdf_gradient(r.siren, film, args, box),
-        "tangent": lambda: tangent_arguments(r.siren, film, args, v, box),
+        "tangent": lambda: tangent_arguments(r.siren, film, args, v, box)[0],
+        "tangent_tr": lambda: (tangent_arguments(r.siren, film, args, v, box, rsave=rsave)[0] if mode == "f16x3_g2"
+                               else tangent_arguments(r.siren, film, args, v, box)[0] * rsave),
     }
     for name, fn in cases.items():
         ms, out = timed(fn)
