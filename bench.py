@@ -988,6 +988,12 @@ def main():
                     fn()
                 barrier()
                 return 1e3 * max_over_ranks(time.perf_counter() - t0) / n
+
+            def block_stats(fn, steps, blocks=5):
+                """The same estimator for every training leg (round 6): `blocks` blocks of `steps` steps, wall clock between barriers, max
+                over ranks per block; the MEDIAN block is the figure, min / max go on the line beside it."""
+                v = sorted(wall_ms(fn, steps) for _ in range(blocks))
+                return {"median": statistics.median(v), "min": v[0], "max": v[-1], "blocks": blocks, "steps_per_block": steps}
             # (round 5 read this step at 3.27 instead of 2.53 ms on two boxes.  It is the clock: the GPU clocks down while the host is busy --
             # a process start, the host-bound autograd legs above -- and a handful of 2.5-ms warm-up steps does not bring it back: every
             # process but the first on a fresh box reads tools/c5_step.py at 3.4-4.1 ms after three warm-up steps and at 2.51 after 0.4 s
@@ -996,8 +1002,9 @@ def main():
             spin(args.prewarm_ms / 2)
             for _ in range(5):
                 gr = train_step()
-            n_tr = 10
-            ms = wall_ms(train_step, n_tr)
+            n_tr = 4
+            st1 = block_stats(train_step, n_tr)
+            ms = st1["median"]
             assert torch.isfinite(gr).all()
             # the fp32 fallback of the same step (what a checkpoint with |w| >= 256 takes): two of its kernels still spill (20 / 60 B
             # of scratch, tools/scratch_report.sh) -- its cost goes on the line instead of being implied
@@ -1006,7 +1013,7 @@ def main():
                 r5.siren.mfma_mode = r5.siren.bwd_mode = "f32"
                 for _ in range(2):
                     train_step()
-                ms_f32 = wall_ms(train_step, 5)
+                ms_f32 = block_stats(train_step, 2, 3)["median"]
                 r5.siren.mfma_mode, r5.siren.bwd_mode = m0, b0
                 if isinstance(result.get("modes"), dict) and "f32" in result["modes"]:
                     result["modes"]["f32"]["train_step_ms"] = ms_f32
@@ -1029,7 +1036,9 @@ def main():
                     return s_.grad
                 for _ in range(3):
                     g4 = train_step_b4()
-                result["train_step_batch4_ms_per_sample"] = min(wall_ms(train_step_b4, 3) for _ in range(3)) / 4
+                st4 = block_stats(train_step_b4, 3)
+                result["train_step_batch4_ms_per_sample"] = st4["median"] / 4
+                result["train_step_batch4_ms_per_sample_min"] = st4["min"] / 4
                 assert torch.isfinite(g4).all()
             except Exception as exc:                                      # noqa: BLE001
                 result["train_step_batch4_ms_per_sample"] = f"failed: {type(exc).__name__}: {exc}"[:160]
@@ -1061,7 +1070,8 @@ def main():
                     try:
                         for _ in range(3):
                             gf = train_step_full()
-                        full[be] = wall_ms(train_step_full, n_tr)
+                        full_st = block_stats(train_step_full, n_tr)
+                        full[be], full[be + "_min"] = full_st["median"], full_st["min"]
                         assert torch.isfinite(gf).all()
                     finally:
                         os.environ.pop("E3DGE_DECODER_AUTOGRAD", None)
@@ -1073,7 +1083,7 @@ def main():
                     try:
                         for _ in range(3):
                             gf = train_step_full(True)
-                        full[be + "_both"] = wall_ms(lambda: train_step_full(True), n_tr)
+                        full[be + "_both"] = block_stats(lambda: train_step_full(True), n_tr)["median"]
                         assert torch.isfinite(gf).all()
                     finally:
                         os.environ.pop("E3DGE_DECODER_AUTOGRAD", None)
@@ -1094,15 +1104,28 @@ def main():
                     for _ in range(4):
                         gf = train_step_full_b4()
                     # (13 GB of new blocks at this batch: one bench run read 28.6 ms per step over five steps right after two warm-ups, the
-                    # stand-alone tools/full_step_b4.py 13.5 ms from its second step on -- the allocator was still growing.  Three blocks of
-                    # three steps, the fastest block.)
-                    result["train_step_full_batch4_ms_per_sample"] = min(wall_ms(train_step_full_b4, 3) for _ in range(3)) / 4
+                    # stand-alone tools/full_step_b4.py 13.5 ms from its second step on -- the allocator was still growing.  Five blocks of
+                    # three steps like every other leg: median, the fastest block beside it.)
+                    stf4 = block_stats(train_step_full_b4, 3)
+                    result["train_step_full_batch4_ms_per_sample"] = stf4["median"] / 4
+                    result["train_step_full_batch4_ms_per_sample_min"] = stf4["min"] / 4
                     assert torch.isfinite(gf).all()
                 except Exception as exc:                                      # noqa: BLE001
                     result["train_step_full_batch4_ms_per_sample"] = f"failed: {type(exc).__name__}: {exc}"[:160]
                 del g5
                 result["train_step_full_ms"] = full["packed"]
+                result["train_step_full_ms_min"] = full["packed_min"]
                 result["train_step_full_library_decoder_ms"] = full["library"]
+                # roofline of the whole sample (round 6): the renderer's 30 GEMM chains + the decoder's nine 3x3 layers forward and
+                # data-gradient backward (125.6 GFLOP each at 1024^2, channel multiplier 2) over the measured step, on f16 MFMA / 3.
+                # The caller's pool_256 (~0.16 ms of adaptive_avg_pool forward + backward, profiles/r5_full_step_timeline.txt) is inside
+                # the measured time and outside the flop count.
+                fl_full = 30 * 131072.0 * (RES * RES * S5 + RES * RES) + 2 * 125.6e9
+                result["train_step_full"] = {"step_ms": full["packed"], "roofline": {
+                    "bound": "mfma", "achieved": fl_full / (full["packed"] * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / 3, "unit": "TFLOP/s",
+                    "frac": fl_full / (PEAK_F16_MFMA_TFLOPS / 3 * 1e12) / (full["packed"] * 1e-3), "flop_per_step": fl_full,
+                    "note": "renderer step (306 GFLOP) + decoder forward + data-gradient backward (2 x 125.6 GFLOP); ~4 % of the measured "
+                            "time is the caller's pool_256, counted in the time only"}}
                 result["train_step_full_note"] = ("one stage-1 sample as train_ae.py runs it (--full_pipeline): C5 renderer step + decoder 64^2 -> 1024^2 forward "
                                                   "and backward with the pixel loss on pool_256(gen_imgs) (trainer.py:1017-1031); decoder latent and generator "
                                                   "frozen; packed = e3dge_dec2_forward / e3dge_dec2_backward, library = round 4's path; wall clock, max over ranks")
@@ -1110,11 +1133,13 @@ def main():
                 result["train_step_full_ms"] = None
                 result["train_step_full_note"] = f"failed: {type(exc).__name__}: {exc}"[:200]
             result["train_step_ms"] = ms
+            result["train_step_ms_min"] = st1["min"]
             result["train_step_rays_per_sec"] = world * RES * RES / ms * 1e3
             result["train_step_note"] = ("C5 renderer part, 1 image 64x64x18 per GPU: forward saving arguments + eikonal term (sdf chain) + "
                                          "surface normals at the integrated point (kept in the graph), loss = mean(rgb^2) + "
                                          "mean((|eik|-1)^2) + mean(surf_eik^2), backward to the styles incl. the double backward "
-                                         f"(tangent + second-order chain); backward mode {r5.siren.bwd_mode}; max over ranks between barriers")
+                                         f"(tangent + second-order chain); backward mode {r5.siren.bwd_mode}; median of 5 blocks of 4 steps, max over ranks between barriers "
+                                         "(the same estimator on every training leg; *_min = the fastest block)")
             # roofline of the step as a whole: 30 GEMM chains of 131,072 FLOP per point (forward 8 + sdf chain 7 + tangent 7
             # + second-order backward 8) over 64*64*18 ray samples + 4,096 surface points, and the saved state -- 9 x 256 pre-sine
             # arguments written once and read three times, r_l and ta_l (8 x 256 each) written and read once = 66 KB per ray sample
@@ -1141,7 +1166,8 @@ def main():
                                        "traffic = PMC FETCH x2 + WRITE per step (profiles/traffic_pmc.json)"}}
             b4 = result.get("train_step_batch4_ms_per_sample")
             if isinstance(b4, float):       # the same arithmetic per sample at stage1.sh's four samples per GPU (three full 256-CU rounds per launch instead of 2.25)
-                ts["roofline_batch4"] = {"ms_per_sample": b4, "achieved": flop_step / (b4 * 1e-3) / 1e12, "frac": t_f / (b4 * 1e-3)}
+                ts["roofline_batch4"] = {"ms_per_sample": b4, "achieved": flop_step / (b4 * 1e-3) / 1e12, "frac": t_f / (b4 * 1e-3),
+                                         "estimator": "median of 5 blocks of 3 steps", "ms_per_sample_min": result.get("train_step_batch4_ms_per_sample_min")}
             if dist is not None:
                 # stage 1 trains the encoder under DDP -- 1.03 GB of fp32 gradients all-reduced per step
                 # (trainer.py:1737-1778, dist_utils.py:108-130).  The encoder is out of scope; its collective is emulated with a

@@ -33,38 +33,95 @@
 #pragma once
 #define E3DGE_16_HELPERS_ONLY
 #include "siren16.h"
+#include <utility>
 
 namespace e3dge {
 
-constexpr int kT3Dist = 3;                        // stream tiles in flight ahead of the tile being consumed
-constexpr int kT3Slots = 4;                       // ring slots of 1 KiB per wave and stream (= kT3Dist + the one being read)
-constexpr int kT3RingFloats = 8 * kT3Slots * 256; // one stream, eight waves: 32 KiB
-static_assert(k16Tiles % kT3Slots == 0, "static slot index = tile index mod kT3Slots");
+// f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}): a loop whose index is a constant expression in the
+// body BY CONSTRUCTION.  (`#pragma unroll` over the sixteen tiles of a layer silently gave up on the two-stream kernels once the body held
+// four DMA statements behind a sixteen-way switch on the tile index: the pre-unroll size estimate passed the pragma threshold, the tile
+// index stayed a run-time value and out[] moved to scratch.)
+template <class F, int... Is> __device__ __forceinline__ void t3_static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void t3_static_for(F&& f) {
+    t3_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// ring slots of 1 KiB per wave and stream; a stream tile is fetched (slots - 1) tiles ahead of the tile being consumed.  One stream:
+// eight slots (64 KiB of ring); two streams: four each (LDS: 64 KiB of weight buffers + 64 KiB of ring + tables).
+#ifndef E3DGE_T3_SLOTS1
+#define E3DGE_T3_SLOTS1 8
+#endif
+constexpr int t3_slots(int ns) { return ns == 1 ? E3DGE_T3_SLOTS1 : 4; }
+constexpr int t3_ring_floats(int ns) { return 8 * t3_slots(ns) * 256; }      // one stream, eight waves
+static_assert(k16Tiles % t3_slots(1) == 0 && k16Tiles % t3_slots(2) == 0, "static slot index = tile index mod slots");
+// Who issues what (E3DGE_T3_SPLIT, default on).  vmcnt retires in order, so a wave that waits for its (L2-resident, two tiles old)
+// weight pieces also waits for every older stream load of its own -- cold HBM lines with a tail latency of microseconds: with one
+// queue per wave the streams' budget is three tiles whatever the ring depth, and the ablations of round 6 (tools/r6_chain_abl.sh)
+// put the exposed wait at half of the chain kernels' time.  So the queues are separated BY WAVE: waves 0-3 issue the whole weight
+// chunk (4 pieces each), waves 4-7 issue the stream tiles of waves w-4 and w (any wave may DMA into any LDS address); every wave
+// waits for its own operations and the tile's barrier publishes all of them.  A stream's budget is then its ring depth.
+#ifndef E3DGE_T3_SPLIT
+#define E3DGE_T3_SPLIT 1
+#endif
+constexpr bool kT3Split = E3DGE_T3_SPLIT != 0;
 
 // backward kernel: weights | ring (1 or 2 streams) | gamma [9][256] | w_sigma [256] | wave slices [8][256][2] | W0 [3][256] (d_pts)
 constexpr int kB16LdsW = 0;
 constexpr int kB16LdsRing = kB16LdsW + k16NBuf * k16ChunkFloats;
-constexpr int b16_lds_gam(int ns) { return kB16LdsRing + ns * kT3RingFloats; }
+constexpr int b16_lds_gam(int ns) { return kB16LdsRing + ns * t3_ring_floats(ns); }
 constexpr int b16_lds_head(int ns) { return b16_lds_gam(ns) + 9 * kWidth; }
 constexpr int b16_lds_wave(int ns) { return b16_lds_head(ns) + kWidth; }
 constexpr int b16_lds_w0(int ns) { return b16_lds_wave(ns) + 8 * 2 * kWidth; }
 constexpr int b16_lds_bytes(int ns, bool dpts) { return (b16_lds_w0(ns) + (dpts ? 3 * kWidth : 0)) * 4; }
-static_assert(b16_lds_bytes(2, true) <= 160 * 1024, "LDS budget (backward)");
+static_assert(b16_lds_bytes(2, true) <= 160 * 1024 && b16_lds_bytes(1, true) <= 160 * 1024, "LDS budget (backward)");
 static_assert(k16Chunks % k16NBuf == 0 && (7 * k16Tiles) % k16NBuf == 0 && k16Tiles % k16NBuf == 0, "static buffer index = tile index mod k16NBuf");
 
 // chain kernels: weights | ring | gamma [8][256] | W0 [3][256] | w_sigma [256]
 constexpr int kC16LdsW = 0;
 constexpr int kC16LdsRing = kC16LdsW + k16NBuf * k16ChunkFloats;
-constexpr int c16_lds_gam(int ns) { return kC16LdsRing + ns * kT3RingFloats; }
+constexpr int c16_lds_gam(int ns) { return kC16LdsRing + ns * t3_ring_floats(ns); }
 constexpr int c16_lds_w0(int ns) { return c16_lds_gam(ns) + 8 * kWidth; }
 constexpr int c16_lds_head(int ns) { return c16_lds_w0(ns) + 3 * kWidth; }
 constexpr int c16_lds_bytes(int ns) { return (c16_lds_head(ns) + kWidth) * 4; }
-static_assert(c16_lds_bytes(2) <= 160 * 1024, "LDS budget (chain)");
+static_assert(c16_lds_bytes(2) <= 160 * 1024 && c16_lds_bytes(1) <= 160 * 1024, "LDS budget (chain)");
 
 constexpr int kB16Ring = 2;                       // k-steps of weight fragments held (registers are the scarce resource here)
+// Timing ablations (tools/build_variant.sh -DE3DGE_T3_ABL=bits; results are wrong with any bit set):
+//   1 = no stream DMA (the epilogues read whatever the ring holds)      2 = no stores of the chain kernels
+//   16 = hot rows: every lane streams (and stores) the workgroup's first row -- the same instruction mix against cache-resident data
+#ifndef E3DGE_T3_ABL
+#define E3DGE_T3_ABL 0
+#endif
+// Layout of the saved state (pre-sine arguments (.., 9, 256), r_l / ta_l r_l (.., 8, 256)):
+//   point-major (kT3Blocked = false): row p = the L x 256 floats of point p.  A wave's tile access touches 16 rows: 64 B in each.
+//   slab-major  (kT3Blocked = true) : 16 consecutive points form a slab [L layers][16 tiles][lane (q, n) = 16 q + n][4 floats]: the
+//       16 points x 16 features of one (layer, tile) are 1 KiB contiguous in exactly the order the 64 lanes hold them -- every stream
+//       DMA and every store of a wave is ONE contiguous KiB (8 full lines, one DRAM page) instead of sixteen 64-byte pieces.
+//       Same number of bytes (rows padded to a multiple of 16 per image); slab s starts where row 16 s starts.
+#ifndef E3DGE_T3_BLOCKED
+#define E3DGE_T3_BLOCKED 0
+#endif
+constexpr bool kT3Blocked = E3DGE_T3_BLOCKED != 0;
+constexpr int kT3LayerF = kT3Blocked ? 16 * kWidth : kWidth;      // floats between consecutive layers of a point / slab
+constexpr int kT3TileF = kT3Blocked ? kWidth : 16;                // floats between consecutive 16-feature tiles
+// float offset of lane (n = pl & 15 of the slab, q)'s 4 values of (layer 0, tile 0), relative to the workgroup's first row; L layers per row
+__device__ __forceinline__ uint32_t t3_row_floats(int pl, int q, int L) {
+    return kT3Blocked ? (uint32_t)((pl >> 4) * L * (16 * kWidth) + (q * 16 + (pl & 15)) * 4) : (uint32_t)(pl * L * kWidth + q * 4);
+}
+constexpr int kT3StreamOps = (E3DGE_T3_ABL & 1) ? 0 : 1;      // counted operations per stream and tile / per store and tile
+constexpr int kT3StoreOps = (E3DGE_T3_ABL & 2) ? 0 : 1;
 
 __device__ __forceinline__ f32x4v ld4(const float* p) { return *reinterpret_cast<const f32x4v*>(p); }
 __device__ __forceinline__ void st4(float* p, const f32x4v& v) { *reinterpret_cast<f32x4v*>(p) = v; }
+__device__ __forceinline__ void st4_chain(float* p, const f32x4v& v) {      // the per-tile store of the chain kernels (see E3DGE_T3_ABL)
+#if !(E3DGE_T3_ABL & 2)
+    *reinterpret_cast<f32x4v*>(p) = v;
+#else
+    if (v[0] == 1.2345e-30f) *reinterpret_cast<f32x4v*>(p) = v;
+#endif
+}
 
 // ---- the in-order memory queue (see the header comment) ----
 #ifdef E3DGE_T3_STRICT      // debugging: every counted wait drains the queue (a result that differs from the default build is a race)
@@ -86,21 +143,89 @@ __device__ __forceinline__ void t3_barrier() {
 // One stream tile (16 points x 16 features of one layer = 1 KiB) of this wave into ring slot TILE & 3.  `gbase` (scalar) = the
 // stream at the workgroup's first point, `voff` = the lane's byte offset (point row + layer + 16 q), the tile's 64 bytes go into
 // the instruction's immediate -- which the hardware adds to the LDS address as well, so it is taken off the slot base.
-template <int TILE>
-__device__ __forceinline__ void t3_issue(const void* gbase, uint32_t voff, uint32_t ring_lds) {
-    constexpr int kImm = TILE * 64;
-    glds16_saddr<kImm>(gbase, voff, ring_lds + (uint32_t)((TILE & (kT3Slots - 1)) * 1024 - kImm));
+// a wave-uniform value in an SGPR, opaquely (the optimiser folds __builtin_amdgcn_readfirstlane of a value it knows to be uniform and may
+// then keep it in a VGPR -- which an "s" asm operand silently accepts and the assembler rejects)
+__device__ __forceinline__ int t3_scalar(int v) {
+    int r;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(r) : "v"(v));
+    return r;
 }
-__device__ __forceinline__ void t3_issue_tile(int tile, const void* gbase, uint32_t voff, uint32_t ring_lds) {   // tile: a constant after unrolling
-    switch (tile & 15) {
-        case 0: t3_issue<0>(gbase, voff, ring_lds); break;    case 1: t3_issue<1>(gbase, voff, ring_lds); break;
-        case 2: t3_issue<2>(gbase, voff, ring_lds); break;    case 3: t3_issue<3>(gbase, voff, ring_lds); break;
-        case 4: t3_issue<4>(gbase, voff, ring_lds); break;    case 5: t3_issue<5>(gbase, voff, ring_lds); break;
-        case 6: t3_issue<6>(gbase, voff, ring_lds); break;    case 7: t3_issue<7>(gbase, voff, ring_lds); break;
-        case 8: t3_issue<8>(gbase, voff, ring_lds); break;    case 9: t3_issue<9>(gbase, voff, ring_lds); break;
-        case 10: t3_issue<10>(gbase, voff, ring_lds); break;  case 11: t3_issue<11>(gbase, voff, ring_lds); break;
-        case 12: t3_issue<12>(gbase, voff, ring_lds); break;  case 13: t3_issue<13>(gbase, voff, ring_lds); break;
-        case 14: t3_issue<14>(gbase, voff, ring_lds); break;  default: t3_issue<15>(gbase, voff, ring_lds); break;
+// Role-conditional forms: the scalar test and the branch live INSIDE the asm statement, so the compiler keeps seeing one straight-line
+// tile (a C++ `if (role)` around the DMA split every unrolled tile into basic blocks and cost the chain kernels 60 registers).
+template <int OFF_BYTES>
+__device__ __forceinline__ void glds16_saddr_if(int flag, const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lt3skip%=\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n.Lt3skip%=:"
+                 :: "s"(flag), "v"(voff), "s"(sbase), "s"(lds_addr), "n"(OFF_BYTES) : "memory", "scc");
+}
+__device__ __forceinline__ void glds16_saddr_x4_if(int flag, const void* sbase, uint32_t voff, uint32_t lds_addr) {     // four 1-KiB pieces
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lt3skip%=\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:0\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n.Lt3skip%=:"
+                 :: "s"(flag), "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "scc");
+}
+// s_waitcnt vmcnt(A) if flag else vmcnt(B)
+template <int A, int B> __device__ __forceinline__ void t3_wait_by_role(int flag) {
+#ifdef E3DGE_T3_STRICT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    static_assert(A >= 0 && A < 64 && B >= 0 && B < 64, "vmcnt is six bits");
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lt3w%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lt3e%=\n.Lt3w%=:\n\ts_waitcnt vmcnt(%2)\n.Lt3e%=:"
+                 :: "s"(flag), "n"(A), "n"(B) : "memory", "scc");
+#endif
+}
+template <int TILE, int SLOTS>
+__device__ __forceinline__ void t3_issue(int flag, const void* gbase, uint32_t voff, uint32_t ring_lds) {
+    // (the immediate is 12 bits: slab-major tiles are 1 KiB apart, so only tile & 3 fits and the rest goes into the lane offset)
+    constexpr int kImm = kT3Blocked ? (TILE & 3) * 1024 : TILE * 64;
+    constexpr uint32_t kAdd = kT3Blocked ? (uint32_t)(TILE >> 2) * 4096u : 0u;
+    if (kT3Split) glds16_saddr_if<kImm>(flag, gbase, voff + kAdd, ring_lds + (uint32_t)((TILE & (SLOTS - 1)) * 1024 - kImm));
+    else glds16_saddr<kImm>(gbase, voff + kAdd, ring_lds + (uint32_t)((TILE & (SLOTS - 1)) * 1024 - kImm));
+}
+// flag (scalar): this wave issues stream tiles (always 1 without the role split)
+template <int TILE, int SLOTS>
+__device__ __forceinline__ void t3_issue_tile(int flag, const void* gbase, uint32_t voff, uint32_t ring_lds) {
+    if (E3DGE_T3_ABL & 1) return;
+    if (E3DGE_T3_ABL & 16) voff &= (kT3Blocked ? 1023u : 63u);
+    t3_issue<(TILE & 15), SLOTS>(flag, gbase, voff, ring_lds);
+}
+// The weight pipe of the 8-wave kernels with the issue roles above: `active` waves (0-3 when split: a quarter of the chunk each in four
+// pieces; every wave an eighth in two pieces otherwise) issue, every wave keeps the bookkeeping.
+struct T3WeightPipe : ChunkPipe16 {
+    int active;
+    __device__ __forceinline__ void init3(float* wbuf_, const float* image, int wave_u, int lane, int count_ = k16Chunks) {
+        active = t3_scalar((!kT3Split || wave_u < 4) ? 1 : 0);
+        init(wbuf_, image, kT3Split ? 2 * (wave_u & 3) : wave_u, lane, count_);     // split: img / lds_base at wave_u * 4 KiB
+    }
+    __device__ __forceinline__ void issue3() {
+        const char* s = img + (size_t)idx * (k16ChunkFloats * 4);
+        const uint32_t d = lds_base + (uint32_t)buf * (k16ChunkFloats * 4);
+        if (kT3Split) {
+            glds16_saddr_x4_if(active, s, voff, d);
+        } else {
+            glds16_saddr<0>(s, voff, d);
+            glds16_saddr<1024>(s, voff, d);
+        }
+        idx = (idx + 1 == count) ? 0 : idx + 1;
+        buf = (buf + 1 == k16NBuf) ? 0 : buf + 1;
+    }
+    __device__ __forceinline__ void prime3() { issue3(); issue3(); issue3(); }
+};
+constexpr int kT3WOps = kT3Split ? 4 : 2;         // weight pieces per issuing wave and tile
+// Counted waits of the hook of tile t (see the header comment).  NS streams, NO stores per tile and wave, D = stream distance.
+//   one queue per wave: the weight chunk of tile t+1 (hook t-2) is awaited; younger = streams of hook t-2, stores, all of hook t-1
+//   split, weight waves: younger = stores of two gaps + the four pieces of hook t-1
+//   split, stream waves: the streams of hook t-D are awaited; younger = D-1 hooks of 2 NS stream tiles + the stores of D gaps
+// (tile 0 of a layer has no interleaved epilogue: the gap between hooks 0 and 1 holds no store)
+template <int NS, int NO, int D> __device__ __forceinline__ void t3_hook_wait(int t, int w_role) {     // w_role: scalar 0 / 1
+    constexpr int S = NS * kT3StreamOps, O = NO * kT3StoreOps;
+    if (!kT3Split) {
+        if (t == 2) t3_wait<2 + 2 * S + O>(); else t3_wait<2 + 2 * S + 2 * O>();
+    } else {
+        constexpr int kS = (D - 1) * 2 * S;
+        if (t == 2 && t == D) t3_wait_by_role<4 + O, kS + (D - 1) * O>(w_role);
+        else if (t == 2) t3_wait_by_role<4 + O, kS + D * O>(w_role);
+        else if (t == D) t3_wait_by_role<4 + 2 * O, kS + (D - 1) * O>(w_role);
+        else t3_wait_by_role<4 + 2 * O, kS + D * O>(w_role);
     }
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const float* p) {
@@ -140,8 +265,8 @@ __device__ __forceinline__ void sincos_hw16(float x, float& sn, float& cs) {
 // Partial sums: slice (workgroup, sub-tile) of a.partials, [9][2][256] = sum(da a [+ ta r cos a]), sum(da) per layer and feature.
 template <bool EIK, bool TEX, bool DPTS>
 __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK a) {
-    constexpr int NS = EIK ? 2 : 1;
-    constexpr int kWaitN = 2 + 2 * NS;             // no regular stores in this kernel (d_pts / d_tex / partial slices are extras)
+    constexpr int NS = EIK ? 2 : 1;                // streams: arguments [, ta r]; no regular stores (d_pts / d_tex / partial slices are extras)
+    constexpr int kSlots = t3_slots(NS), kDist = kSlots - 1, kRingF = t3_ring_floats(NS);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wbuf = smem + kB16LdsW;
     float* const gam_s = smem + b16_lds_gam(NS);
@@ -167,29 +292,40 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
     }
 
     const int wave_u = __builtin_amdgcn_readfirstlane(tid_k >> 6);
+    const int w_role = t3_scalar((kT3Split && wave_u < 4) ? 1 : 0), s_role = t3_scalar(1 - w_role);    // weight waves issue no streams (scalar flags)
     const int64_t base_pt = (int64_t)b * a.n_pts + pt0;                       // the workgroup's first point
     const char* const g_args = reinterpret_cast<const char*>(a.args + base_pt * (9 * kWidth));
     const char* const g_tr = EIK ? reinterpret_cast<const char*>(a.tang + base_pt * (8 * kWidth)) : nullptr;
-    const uint32_t ring_a = lds_addr_of(smem + kB16LdsRing) + (uint32_t)wave_u * 4096u;
-    const uint32_t ring_t = ring_a + (uint32_t)kT3RingFloats * 4u;
-    // per-lane row offsets of a sub-tile (rows beyond the tensor read the last valid row)
-    auto row_of = [&](int sub) {
-        const int p = sub * kTilePts + 16 * (tid_k >> 6) + (tid_k & 15);
+    // ring bases (LDS byte address of slot 0) of the waves this wave fetches for: itself (B) and, when split, wave - 4 (A)
+    const uint32_t ring_b = lds_addr_of(smem + kB16LdsRing) + (uint32_t)wave_u * (kSlots * 1024u);
+    constexpr uint32_t kStream1 = (uint32_t)kRingF * 4u;                      // byte distance of the second stream's ring
+    // row (relative to the workgroup's first) of this lane's column in wave `w` of sub-tile `sub`; rows beyond the tensor read the last valid row
+    auto row_of = [&](int sub, int w, int tid_x) {
+        const int p = sub * kTilePts + 16 * w + (tid_x & 15);
         return p < npts ? p : npts - 1;
     };
-
-    ChunkPipe16 pipe;
-    pipe.init(wbuf, packed + kOffBigT16b, tid_k >> 6, tid_k & 63);
-    pipe.prime();
-    {   // streams of the first three tiles of the first sub-tile (layer 7)
-        const uint32_t r0 = (uint32_t)row_of(0), qb = (uint32_t)((tid_k >> 4) & 3) * 16u;
-        const uint32_t va = r0 * (9u * kWidth * 4u) + 7u * 1024u + qb, vt = r0 * (8u * kWidth * 4u) + 7u * 1024u + qb;
-#pragma unroll
-        for (int t = 0; t < kT3Dist; ++t) {
-            t3_issue_tile(t, g_args, va, ring_a);
-            if (EIK) t3_issue_tile(t, g_tr, vt, ring_t);
+    // the stream tiles of (sub-tile, layer, tile) for the waves this wave serves
+    auto issue_streams = [&](auto tile_c, int sub, int layer) {
+        constexpr int tile = decltype(tile_c)::value;
+        int tid_i = tid_k;
+        asm volatile("" : "+v"(tid_i));             // recomputed at every use: nothing of this lives across a tile
+        uint32_t ring_o = ring_b;
+        asm volatile("" : "+s"(ring_o));            // (the per-tile slot addresses are loop invariants the compiler would hoist into ~60 SGPRs)
+        const int q0 = (tid_i >> 4) & 3;
+        const int rb = row_of(sub, tid_i >> 6, tid_i);
+        t3_issue_tile<tile, kSlots>(s_role, g_args, 4u * (t3_row_floats(rb, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o);
+        if (EIK) t3_issue_tile<tile, kSlots>(s_role, g_tr, 4u * (t3_row_floats(rb, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o + kStream1);
+        if (kT3Split) {
+            const int ra = row_of(sub, (tid_i >> 6) - 4, tid_i);
+            t3_issue_tile<tile, kSlots>(s_role, g_args, 4u * (t3_row_floats(ra, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u));
+            if (EIK) t3_issue_tile<tile, kSlots>(s_role, g_tr, 4u * (t3_row_floats(ra, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u) + kStream1);
         }
-    }
+    };
+
+    T3WeightPipe pipe;
+    pipe.init3(wbuf, packed + kOffBigT16b, wave_u, tid_k & 63);
+    pipe.prime3();
+    t3_static_for<kDist>([&](auto tc) { issue_streams(tc, 0, 7); });          // the first tiles of the first sub-tile (layer 7)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     u32x4 ringH[kB16Ring], ringL[kB16Ring];
@@ -214,7 +350,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
         const bool valid = p < npts;
         const int pc = valid ? p : (npts - 1);
         const int64_t gpt = base_pt + pc;
-        const float* __restrict__ ap = a.args + gpt * (9 * kWidth) + 4 * q;
+        const float* __restrict__ ap = a.args + base_pt * (9 * kWidth) + t3_row_floats(pc, q, 9);
         const float vmask = valid ? 1.0f : 0.0f;                       // padded lanes contribute nothing
         const float* __restrict__ txa = TEX ? a.tex_alpha + gpt * kWidth + 4 * q : nullptr;
         float* __restrict__ dta = TEX ? a.d_tex_alpha + gpt * kWidth + 4 * q : nullptr;
@@ -223,13 +359,8 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
         gmax = 0.0f;
         float drgb[3] = {0.f, 0.f, 0.f};
         if (a.d_rgb && valid) { drgb[0] = a.d_rgb[gpt * 3]; drgb[1] = a.d_rgb[gpt * 3 + 1]; drgb[2] = a.d_rgb[gpt * 3 + 2]; }
-        // stream offsets of this sub-tile and of the next one (the last layer's hooks prefetch across the sub-tile boundary)
-        const uint32_t vo_a = (uint32_t)pc * (9u * kWidth * 4u) + (uint32_t)q * 16u;
-        const uint32_t vo_t = (uint32_t)pc * (8u * kWidth * 4u) + (uint32_t)q * 16u;
-        const int pn = row_of(sub + 1 < n_sub ? sub + 1 : sub);
-        const uint32_t vo_a_n = (uint32_t)pn * (9u * kWidth * 4u) + (uint32_t)q * 16u;
-        const uint32_t vo_t_n = (uint32_t)pn * (8u * kWidth * 4u) + (uint32_t)q * 16u;
-        const float* const ring_rd = smem + kB16LdsRing + wave * (kT3Slots * 256) + lane * 4;     // this lane's 16 bytes of slot 0, stream 0
+        const int sub_n = sub + 1 < n_sub ? sub + 1 : sub;             // (the last layer's hooks prefetch across the sub-tile boundary)
+        const float* const ring_rd = smem + kB16LdsRing + wave * (kSlots * 256) + lane * 4;     // this lane's 16 bytes of slot 0, stream 0
 
         // sum(da), sum(da a ...) over this wave's 16 points for the 16 features of tile t: row sums, then the lanes
         // n < 4 of every row publish value n into this wave's slice
@@ -280,7 +411,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
                 f32x4v arb[4], dfb[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    arb[u] = ld4(ap + 8 * kWidth + 16 * (t4 + u));
+                    arb[u] = ld4(ap + 8 * kT3LayerF + kT3TileF * (t4 + u));
                     dfb[u] = df ? ld4(df + 16 * (t4 + u)) : zero4();
                 }
 #pragma unroll
@@ -315,10 +446,8 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
             const float* __restrict__ fg = gam_s + Lm1 * kWidth + 4 * q;
             const float sdf_term = (Gb == 0) ? dsdf : 0.0f;              // the sdf head reads the backbone output h8
             const bool tex_here = TEX && Gb == 0;                        // this GEMM's result is dL/dh8' (view-layer input)
-            // stream offsets: this layer's tiles, and the tiles the last three hooks fetch for the next layer (layer 7 of the next sub-tile at the end)
-            const uint32_t va_cur = vo_a + (uint32_t)Lm1 * 1024u, vt_cur = vo_t + (uint32_t)Lm1 * 1024u;
-            const uint32_t va_nxt = Gb < 7 ? va_cur - 1024u : vo_a_n + 7u * 1024u;
-            const uint32_t vt_nxt = Gb < 7 ? vt_cur - 1024u : vo_t_n + 7u * 1024u;
+            // the last hooks of a layer fetch the first tiles of the next one (layer 7 of the next sub-tile at the end)
+            const int sub_x = Gb < 7 ? sub : sub_n, lay_x = Gb < 7 ? Lm1 - 1 : 7;
             f32x4v prev = zero4();
             f32x4v a4 = zero4(), tr4 = zero4(), al2[2];                   // streams of the tile whose epilogue is running
             f32x4v e_g = zero4(), e_w = zero4(), e_da = zero4(), e_db = zero4();
@@ -326,8 +455,8 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
             auto epi_load = [&](int tp) {
                 const int o = 16 * tp;
                 e_g = ld4(fg + o); e_w = ld4(wsig_s + 4 * q + o);
-                a4 = ld4(ring_rd + (tp & (kT3Slots - 1)) * 256);
-                if (EIK) tr4 = ld4(ring_rd + kT3RingFloats + (tp & (kT3Slots - 1)) * 256);
+                a4 = ld4(ring_rd + (tp & (kSlots - 1)) * 256);
+                if (EIK) tr4 = ld4(ring_rd + kRingF + (tp & (kSlots - 1)) * 256);
             };
             auto epi_val = [&](int tp, int r) {                           // tp, r: compile-time constants at every call site
                 const float ar = a4[r];
@@ -354,16 +483,17 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
                 if (tex_here && valid) { st4(dta + 16 * tp, e_da); st4(dtb + 16 * tp, e_db); }
                 reduce_store(tp, rb, rg);
             };
-#pragma unroll
-            for (int t = 0; t < k16Tiles; ++t) {
-                // after k-step 1: the counted wait (weight chunk t+1 and, being older, the streams of tile t), the barrier, the next
-                // weight chunk, then the streams three tiles ahead
+            t3_static_for<k16Tiles>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                // after k-step 1: the counted wait, the barrier (publishes every wave's finished DMA), the next weight chunk, then the
+                // streams kDist tiles ahead
                 auto hook = [&]() {
-                    t3_wait<kWaitN>();
+                    t3_hook_wait<NS, 0, kDist>(t, w_role);
                     t3_barrier();
-                    pipe.issue_chunk();
-                    t3_issue_tile(t + kT3Dist, g_args, t + kT3Dist < k16Tiles ? va_cur : va_nxt, ring_a);
-                    if (EIK) t3_issue_tile(t + kT3Dist, g_tr, t + kT3Dist < k16Tiles ? vt_cur : vt_nxt, ring_t);
+                    pipe.issue3();
+                    constexpr int tn = (t + kDist) & 15;
+                    if (t + kDist < k16Tiles) issue_streams(std::integral_constant<int, tn>{}, sub, Lm1);
+                    else issue_streams(std::integral_constant<int, tn>{}, sub_x, lay_x);
                     if (TEX) {
                         if (t > 0) asm volatile("" : "+v"(al2[(t - 1) & 1]));
                         al2[t & 1] = tex_here ? ld4(txa + 16 * t) : zero4();
@@ -381,7 +511,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
                 }
                 pipe.advance();
                 prev = (acc + accb) * inv_scale;
-            }
+            });
             if (TEX) asm volatile("" : "+v"(al2[(k16Tiles - 1) & 1]));
             epi_load(k16Tiles - 1);
 #pragma unroll
@@ -425,6 +555,7 @@ template <bool TANGENT, bool TR>
 __global__ void __launch_bounds__(k16Threads) siren16_chain_kernel(const SirenChainK a) {
     static_assert(TANGENT || !TR, "the product form belongs to the tangent pass");
     constexpr int NS = TR ? 2 : 1;
+    constexpr int kSlots = t3_slots(NS), kDist = kSlots - 1, kRingF = t3_ring_floats(NS);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wbuf = smem + kC16LdsW;
     float* const gam_s = smem + c16_lds_gam(NS);
@@ -451,30 +582,38 @@ __global__ void __launch_bounds__(k16Threads) siren16_chain_kernel(const SirenCh
     constexpr int kChainChunks = 7 * k16Tiles;
     constexpr int kFirstGemmLayer = TANGENT ? 1 : 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid_k >> 6);
+    const int w_role = t3_scalar((kT3Split && wave_u < 4) ? 1 : 0), s_role = t3_scalar(1 - w_role);
     const int64_t base_pt = (int64_t)b * a.n_pts + pt0;
     const char* const g_args = reinterpret_cast<const char*>(a.args + base_pt * (9 * kWidth));
     const char* const g_r = TR ? reinterpret_cast<const char*>(a.rmul + base_pt * (8 * kWidth)) : nullptr;
-    const uint32_t ring_a = lds_addr_of(smem + kC16LdsRing) + (uint32_t)wave_u * 4096u;
-    const uint32_t ring_r = ring_a + (uint32_t)kT3RingFloats * 4u;
-    auto row_of = [&](int sub) {
-        const int p = sub * kTilePts + 16 * (tid_k >> 6) + (tid_k & 15);
-        return p < npts ? p : npts - 1;
+    const uint32_t ring_b = lds_addr_of(smem + kC16LdsRing) + (uint32_t)wave_u * (kSlots * 1024u);
+    constexpr uint32_t kStream1 = (uint32_t)kRingF * 4u;
+    auto row_of = [&](int sub, int w, int tid_x) {
+        const int p = sub * kTilePts + 16 * w + (tid_x & 15);
+        return (E3DGE_T3_ABL & 16) ? 0 : (p < npts ? p : npts - 1);
+    };
+    auto issue_streams = [&](auto tile_c, int sub, int layer) {
+        constexpr int tile = decltype(tile_c)::value;     // see siren16_bwd_kernel
+        int tid_i = tid_k;
+        asm volatile("" : "+v"(tid_i));
+        uint32_t ring_o = ring_b;
+        asm volatile("" : "+s"(ring_o));
+        const int q0 = (tid_i >> 4) & 3;
+        const int rb = row_of(sub, tid_i >> 6, tid_i);
+        t3_issue_tile<tile, kSlots>(s_role, g_args, 4u * (t3_row_floats(rb, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o);
+        if (TR) t3_issue_tile<tile, kSlots>(s_role, g_r, 4u * (t3_row_floats(rb, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o + kStream1);
+        if (kT3Split) {
+            const int ra = row_of(sub, (tid_i >> 6) - 4, tid_i);
+            t3_issue_tile<tile, kSlots>(s_role, g_args, 4u * (t3_row_floats(ra, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u));
+            if (TR) t3_issue_tile<tile, kSlots>(s_role, g_r, 4u * (t3_row_floats(ra, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u) + kStream1);
+        }
     };
 
-    ChunkPipe16 pipe;
+    T3WeightPipe pipe;
     // tangent: hidden layers 1..7 are the first 7 layers of the forward image; sdf chain: skip the view layer's transposed chunks
-    pipe.init(wbuf, packed + (TANGENT ? kOffBig16b : kOffBigT16b + (int64_t)k16Tiles * k16ChunkFloats), tid_k >> 6, tid_k & 63, kChainChunks);
-    pipe.prime();
-    {
-        const uint32_t r0 = (uint32_t)row_of(0), qb = (uint32_t)((tid_k >> 4) & 3) * 16u;
-        const uint32_t va = r0 * (9u * kWidth * 4u) + (uint32_t)kFirstGemmLayer * 1024u + qb;
-        const uint32_t vr = r0 * (8u * kWidth * 4u) + (uint32_t)kFirstGemmLayer * 1024u + qb;
-#pragma unroll
-        for (int t = 0; t < kT3Dist; ++t) {
-            t3_issue_tile(t, g_args, va, ring_a);
-            if (TR) t3_issue_tile(t, g_r, vr, ring_r);
-        }
-    }
+    pipe.init3(wbuf, packed + (TANGENT ? kOffBig16b : kOffBigT16b + (int64_t)k16Tiles * k16ChunkFloats), wave_u, tid_k & 63, kChainChunks);
+    pipe.prime3();
+    t3_static_for<kDist>([&](auto tc) { issue_streams(tc, 0, kFirstGemmLayer); });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     u32x4 ringH[kB16Ring], ringL[kB16Ring];
@@ -497,17 +636,13 @@ __global__ void __launch_bounds__(k16Threads) siren16_chain_kernel(const SirenCh
         // Rows beyond the tensor are exact clones of the last valid row: same loads, same arithmetic, the same values stored to the
         // same addresses -- every store of this kernel is unconditional (the counted waits rely on it).
         const int p = sub * kTilePts + 16 * wave + col;
-        const int pc = p < npts ? p : (npts - 1);
+        const int pc = (E3DGE_T3_ABL & 16) ? 0 : (p < npts ? p : (npts - 1));
         const int64_t gpt = base_pt + pc;
-        const float* __restrict__ ap = a.args + gpt * (9 * kWidth) + 4 * q;
-        const float* __restrict__ rp = TR ? a.rmul + gpt * (8 * kWidth) + 4 * q : nullptr;
-        float* __restrict__ sp = a.save + gpt * (8 * kWidth) + 4 * q;
-        const uint32_t vo_a = (uint32_t)pc * (9u * kWidth * 4u) + (uint32_t)q * 16u;
-        const uint32_t vo_r = (uint32_t)pc * (8u * kWidth * 4u) + (uint32_t)q * 16u;
-        const int pn = row_of(sub + 1 < n_sub ? sub + 1 : sub);
-        const uint32_t vo_a_n = (uint32_t)pn * (9u * kWidth * 4u) + (uint32_t)q * 16u;
-        const uint32_t vo_r_n = (uint32_t)pn * (8u * kWidth * 4u) + (uint32_t)q * 16u;
-        const float* const ring_rd = smem + kC16LdsRing + wave * (kT3Slots * 256) + lane * 4;
+        const float* __restrict__ ap = a.args + base_pt * (9 * kWidth) + t3_row_floats(pc, q, 9);
+        const float* __restrict__ rp = TR ? a.rmul + base_pt * (8 * kWidth) + t3_row_floats(pc, q, 8) : nullptr;
+        float* __restrict__ sp = a.save + base_pt * (8 * kWidth) + t3_row_floats(pc, q, 8);
+        const int sub_n = sub + 1 < n_sub ? sub + 1 : sub;
+        const float* const ring_rd = smem + kC16LdsRing + wave * (kSlots * 256) + lane * 4;
         gmax = 0.0f;
 
         // ---- first layer of the chain (no GEMM): its arguments (and r) by ordinary loads, eight tiles in flight ----
@@ -526,8 +661,8 @@ __global__ void __launch_bounds__(k16Threads) siren16_chain_kernel(const SirenCh
                 f32x4v arb[8], rmb[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    arb[u] = ld4(ap + l0 * kWidth + 16 * (t8 + u));
-                    if (TR) rmb[u] = ld4(rp + l0 * kWidth + 16 * (t8 + u));
+                    arb[u] = ld4(ap + l0 * kT3LayerF + kT3TileF * (t8 + u));
+                    if (TR) rmb[u] = ld4(rp + l0 * kT3LayerF + kT3TileF * (t8 + u));
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -543,7 +678,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_chain_kernel(const SirenCh
 #pragma unroll
                         for (int r = 0; r < 4; ++r) x4[r] = w4[r] * seed;                                           // r_7
                     }
-                    st4(sp + l0 * kWidth + o, TR ? x4 * rmb[u] : x4);
+                    st4_chain(sp + l0 * kT3LayerF + kT3TileF * t, TR ? x4 * rmb[u] : x4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         out[t][r] = cos_hw_f32(arb[u][r]) * (TANGENT ? x4[r] : g4[r] * x4[r]);
@@ -560,17 +695,15 @@ __global__ void __launch_bounds__(k16Threads) siren16_chain_kernel(const SirenCh
         for (int step = 0; step < 7; ++step) {
             const int l = TANGENT ? step + 1 : 6 - step;                 // layer whose argument / gamma the epilogue uses
             const float* __restrict__ gl = gam_s + l * kWidth + 4 * q;
-            float* __restrict__ spl = sp + l * kWidth;
-            const uint32_t va_cur = vo_a + (uint32_t)l * 1024u, vr_cur = vo_r + (uint32_t)l * 1024u;
-            const uint32_t va_nxt = step < 6 ? (TANGENT ? va_cur + 1024u : va_cur - 1024u) : vo_a_n + (uint32_t)kFirstGemmLayer * 1024u;
-            const uint32_t vr_nxt = step < 6 ? (TANGENT ? vr_cur + 1024u : vr_cur - 1024u) : vo_r_n + (uint32_t)kFirstGemmLayer * 1024u;
+            float* __restrict__ spl = sp + l * kT3LayerF;
+            const int sub_x = step < 6 ? sub : sub_n, lay_x = step < 6 ? (TANGENT ? l + 1 : l - 1) : kFirstGemmLayer;
             f32x4v prev = zero4();
             f32x4v a4 = zero4(), r4 = zero4();
             f32x4v e_g = zero4(), e_st = zero4();
             auto epi_load = [&](int tp) {
                 e_g = ld4(gl + 16 * tp);
-                a4 = ld4(ring_rd + (tp & (kT3Slots - 1)) * 256);
-                if (TR) r4 = ld4(ring_rd + kT3RingFloats + (tp & (kT3Slots - 1)) * 256);
+                a4 = ld4(ring_rd + (tp & (kSlots - 1)) * 256);
+                if (TR) r4 = ld4(ring_rd + kRingF + (tp & (kSlots - 1)) * 256);
             };
             auto epi_val = [&](int tp, int r) {
                 const float ga = e_g[r] * prev[r];
@@ -578,14 +711,15 @@ __global__ void __launch_bounds__(k16Threads) siren16_chain_kernel(const SirenCh
                 out[tp][r] = cos_hw_f32(a4[r]) * ga;
                 gmax = fmaxf(gmax, fabsf(out[tp][r]));
             };
-#pragma unroll
-            for (int t = 0; t < k16Tiles; ++t) {
+            t3_static_for<k16Tiles>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
                 auto hook = [&]() {                                      // see siren16_bwd_kernel; one store per tile here
-                    if (t == 2) t3_wait<2 + 2 * NS + 1>(); else t3_wait<2 + 2 * NS + 2>();   // (tile 0 has no epilogue: one store less behind tile 2's chunk)
+                    t3_hook_wait<NS, 1, kDist>(t, w_role);
                     t3_barrier();
-                    pipe.issue_chunk();
-                    t3_issue_tile(t + kT3Dist, g_args, t + kT3Dist < k16Tiles ? va_cur : va_nxt, ring_a);
-                    if (TR) t3_issue_tile(t + kT3Dist, g_r, t + kT3Dist < k16Tiles ? vr_cur : vr_nxt, ring_r);
+                    pipe.issue3();
+                    constexpr int tn = (t + kDist) & 15;
+                    if (t + kDist < k16Tiles) issue_streams(std::integral_constant<int, tn>{}, sub, l);
+                    else issue_streams(std::integral_constant<int, tn>{}, sub_x, lay_x);
                 };
                 f32x4v acc = zero4(), accb = zero4();
                 if (t == 0) {
@@ -594,16 +728,16 @@ __global__ void __launch_bounds__(k16Threads) siren16_chain_kernel(const SirenCh
                     tile16<false, kB16Ring>(pipe, lane, inH, inL, acc, accb, ringH, ringL, [&](int g) {
                         if (g == 0) epi_load(t - 1);
                         else if (g <= 4) epi_val(t - 1, g - 1);
-                        else if (g == 5) st4(spl + 16 * (t - 1), e_st);
+                        else if (g == 5) st4_chain(spl + kT3TileF * (t - 1), e_st);
                     }, hook, t % k16NBuf);
                 }
                 pipe.advance();
                 prev = (acc + accb) * inv_scale;
-            }
+            });
             epi_load(k16Tiles - 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) epi_val(k16Tiles - 1, r);
-            st4(spl + 16 * (k16Tiles - 1), e_st);
+            st4_chain(spl + kT3TileF * (k16Tiles - 1), e_st);
             if (step < 6) {
                 inv_scale = scale_split16(out, inH, inL, gmax);
                 gmax = 0.0f;

@@ -337,9 +337,10 @@ template <int MODE, bool HAS_BIAS, bool HAS_REF>
 __global__ void __launch_bounds__(kActThreads)
 bias_act_elem_f64_kernel(double* __restrict__ y, const double* __restrict__ x, const double* __restrict__ bias,
                          const double* __restrict__ ref, double alpha, double scale, int n, int step_b, int size_b) {
-    for (int i = blockIdx.x * kActThreads + threadIdx.x; i < n; i += gridDim.x * kActThreads) {
+    // (64-bit index: n may be within one grid stride of INT_MAX, where an int increment would overflow)
+    for (int64_t i = (int64_t)blockIdx.x * kActThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kActThreads) {
         double v = x[i];
-        if (HAS_BIAS) v += bias[(i / step_b) % size_b];
+        if (HAS_BIAS) v += bias[(int)((i / step_b) % size_b)];
         double o;
         if (MODE == kLinear) o = v;
         else if (MODE == kZero) o = 0.0;

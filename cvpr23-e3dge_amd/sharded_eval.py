@@ -22,10 +22,11 @@ def shard_indices(n_units, rank, world_size):
     return list(range(rank, n_units, world_size))
 
 
-def gather_metric_rows(local_rows, n_units, rank, world_size, group=None):
+def gather_metric_rows(local_rows, n_units, rank, world_size, group=None, force_collective=False):
     """local_rows (n_local, M) on this rank's device, rows in shard_indices order -> (n_units, M) in global unit
     order on EVERY rank.  One all_gather of a (ceil(n/W), M) block per rank; ragged tails are padded with NaN and
-    dropped after the gather."""
+    dropped after the gather.  A single rank needs no collective; `force_collective=True` issues the all_gather anyway
+    (an initialised process group is then required): with it a one-GPU lease executes the RCCL leg of this path."""
     n_local = len(shard_indices(n_units, rank, world_size))
     if local_rows.ndim != 2 or local_rows.shape[0] != n_local:
         raise ValueError(f"expected ({n_local}, M) rows on rank {rank}, got {tuple(local_rows.shape)}")
@@ -33,7 +34,7 @@ def gather_metric_rows(local_rows, n_units, rank, world_size, group=None):
     M = local_rows.shape[1]
     block = torch.full((per_rank, M), float('nan'), dtype=local_rows.dtype, device=local_rows.device)
     block[:n_local] = local_rows
-    if world_size == 1:
+    if world_size == 1 and not force_collective:
         gathered = [block]
     else:
         gathered = [torch.empty_like(block) for _ in range(world_size)]
@@ -46,7 +47,7 @@ def gather_metric_rows(local_rows, n_units, rank, world_size, group=None):
     return out
 
 
-def evaluate_sharded(unit_fn, n_units, rank=0, world_size=1, device="cpu", group=None, n_streams=1):
+def evaluate_sharded(unit_fn, n_units, rank=0, world_size=1, device="cpu", group=None, n_streams=1, force_collective=False):
     """Runs `unit_fn(i) -> (M,) tensor of metric scalars` for the units this rank owns and returns the (n_units, M)
     table (identical on all ranks).  `unit_fn` is where the hot path is called (renderer / generator forward on
     this rank's GPU); nothing is exchanged between ranks until the final gather.
@@ -73,7 +74,7 @@ def evaluate_sharded(unit_fn, n_units, rank=0, world_size=1, device="cpu", group
     else:
         probe = unit_fn.__dict__.get('n_metrics', N_METRICS)
         local = torch.empty((0, probe), device=device)
-    return gather_metric_rows(local, n_units, rank, world_size, group)
+    return gather_metric_rows(local, n_units, rank, world_size, group, force_collective)
 
 
 # ------------------------------------------------------------------------------------------------------------------

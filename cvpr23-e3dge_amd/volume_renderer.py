@@ -101,6 +101,7 @@ def _record_buffer(renderer, kind, n_bytes, dev, stream, capturing, zero):
     if capturing:
         ent[1] = True
     return ent[0]
+_WMAX_STATE = weakref.WeakKeyDictionary()                              # ResnetBlockFC -> pinned host scalar + event of the deferred weight-range check
 _BACKBONE = weakref.WeakKeyDictionary()                                # renderer -> {key, buf (record), out (first pass's tensors)}
 _SIDE_STREAMS = {}                                                     # per device (module level: modules stay deep-copyable)
 
@@ -821,11 +822,33 @@ class ResnetBlockFC(nn.Module):
                 rc = lib.e3dge_resblock_bwd_pack_weights(_lib.ptr(packed), *[_lib.ptr(t) for t in c], self.size_in,
                                                          torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(rc, "e3dge_resblock_bwd_pack_weights")
-            wmax = max(float(t.abs().max().item()) for t in (c[0], c[2], c[3]))
-            if wmax >= 500.0:
-                raise RuntimeError(f"texture-head weights up to {wmax:g} do not fit the f16x3 weight image (|w| < 500)")
+            # Range check of the f16x3 image (|w| < 500) without stalling the launch queue: a training head rebuilds this image every
+            # step, and three blocking .item() reads per rebuild sat in front of every backward (round-5 advisor finding).  The first
+            # image is checked synchronously; after that the maximum is reduced on the device, copied to pinned host memory without
+            # blocking, and examined at the NEXT rebuild (by then the copy has long finished) -- weights drift, they do not jump.
+            st = _WMAX_STATE.setdefault(self, {})          # (module-level: modules stay deep-copyable / picklable)
+            self._check_pending_wmax(st)
+            wmax_dev = torch.stack([t.abs().max() for t in (c[0], c[2], c[3])]).max()
+            if "host" not in st:
+                self._raise_if_out_of_range(float(wmax_dev.item()))
+                st["host"] = torch.zeros(1, dtype=torch.float32).pin_memory()
+            else:
+                st["host"].copy_(wmax_dev.reshape(1), non_blocking=True)
+                st["event"] = torch.cuda.Event()
+                st["event"].record(torch.cuda.current_stream(dev))
             self._cache_bwd, self._cache_bwd_key = packed, key
         return self._cache_bwd
+
+    @staticmethod
+    def _raise_if_out_of_range(wmax):
+        if not wmax < 500.0:
+            raise RuntimeError(f"texture-head weights up to {wmax:g} do not fit the f16x3 weight image (|w| < 500)")
+
+    def _check_pending_wmax(self, st):
+        ev = st.get("event")
+        if ev is not None and ev.query():
+            st["event"] = None
+            self._raise_if_out_of_range(float(st["host"][0]))
 
     def _launch_bwd(self, x, d_alpha, d_beta, want_net=False):
         """x (n, size_in), d_alpha / d_beta (n, 256), contiguous fp32 on the GPU -> (d x (n, size_in), d net as (n, 320) rows of the workspace

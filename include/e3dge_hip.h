@@ -81,7 +81,11 @@ int e3dge_upfirdn2d(float* y, const float* x, const float* k, int64_t major, int
 /* Half-precision forms of the two ops (ABI 11; the reference dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF:
  * fused_bias_act_kernel.cu:79, upfirdn2d_kernel.cu:311).  x, y, bias, ref are IEEE fp16 tensors; the FIR taps stay fp32.  Arithmetic
  * is fp32 with ONE rounding (RNE) on store -- at least as accurate as the reference's scalar_t = half arithmetic, which rounds after
- * every operation; parity is stated against the fp32 op on the widened inputs, rounded to fp16 (tests/test_gpu_selftest_and_ops.py). */
+ * every operation; parity is stated against the fp32 op on the widened inputs, rounded to fp16 (tests/test_gpu_selftest_and_ops.py).
+ * What the half forms are FOR: e3dge_fused_bias_act_f16 is a stream-rate kernel (half the bytes, 0.8 of HBM like the fp32 form).
+ * e3dge_upfirdn2d_f16 exists for DISPATCH PARITY with upfirdn2d_kernel.cu:311 only: it stages the same fp32 LDS patch as the fp32 form
+ * and is bound by that stage, so a half Blur takes the wall time of the fp32 Blur (0.31 of HBM on half the bytes, bench `stream_ops`);
+ * the decoder itself never calls it -- its blurs are fused into the packed fp32-accurate convolutions (e3dge_dec2_forward). */
 int e3dge_fused_bias_act_f16(void* y, const void* x, const void* bias, const void* ref, int act, int grad, float alpha, float scale,
                              int64_t n, int64_t step_b, int64_t size_b, e3dge_stream_t stream);
 int e3dge_upfirdn2d_f16(void* y, const void* x, const float* k, int64_t major, int in_h, int in_w, int kh, int kw, int up_x, int up_y,

@@ -74,6 +74,32 @@ def _grad(dec, feats, wd, noises, gy, mode=None):
         os.environ.pop("E3DGE_DECODER_AUTOGRAD", None)
 
 
+def _sign_flips_vs_float64(dec, sd, feats, wd, noises):
+    """(# pre-activations of the StyledConvs whose sign in the packed pipeline differs from a float64 forward of the oracle, # of them)."""
+    sd64 = {k: v.detach().cpu().double() for k, v in sd.items()}
+    f64, w64, n64 = feats.detach().cpu().double(), wd.detach().cpu().double(), [n.detach().cpu().double() for n in noises]
+    pres = []
+
+    def styled(prefix, x, style, noise, upsample=False):
+        pre = decoder_ref.modulated_conv(sd64, prefix + 'conv.', x, style, True, upsample)
+        pre = pre + sd64[prefix + 'noise.weight'] * noise + sd64[prefix + 'activate.bias'].reshape(1, -1, 1, 1)
+        pres.append(pre)
+        return torch.where(pre > 0, pre, 0.2 * pre) * (2 ** 0.5)
+    with torch.no_grad():
+        out = styled('decoder.conv1.', f64, w64[:, 0], n64[0])
+        i = 1
+        for u in range(len(dec.to_rgbs)):
+            out = styled(f'decoder.convs.{2 * u}.', out, w64[:, i], n64[2 * u + 1], upsample=True)
+            out = styled(f'decoder.convs.{2 * u + 1}.', out, w64[:, i + 1], n64[2 * u + 2])
+            i += 2
+    n_flip = n_act = 0
+    for idx, pre in enumerate(pres, start=1):
+        mine = dec.dec2_unpack(idx, feats.shape).cpu()
+        n_flip += int(((mine > 0) != (pre > 0)).sum())
+        n_act += pre.numel()
+    return n_flip, n_act
+
+
 @pytest.mark.parametrize("batch", [1, 2])
 def test_d_features_against_the_references_own_autograd_256(gen256, batch):
     g, _ = gen256
@@ -95,7 +121,17 @@ def test_d_features_against_the_references_own_autograd_256(gen256, batch):
              reference_max_vs_f64=rel_max(ref, f64), reference_l2_vs_f64=rel_l2(ref, f64),
              sum_rel=float(np.abs(d_f.double().sum(dim=(1, 2, 3)).cpu().numpy() - gold["ref_d_features_sum"][sl]).max() /
                            gold["ref_d_features_abs_sum"][sl].max()))
-    record("dec2_bwd_vs_reference_256", **e)
+    # Whenever the loose branch of a bound below is what lets the comparison pass (an error above REL_TOL), the explanation -- a few
+    # pre-activations within fp32 round-off of zero take the other branch of lrelu' in float64 -- is CHECKED, not assumed: the signs of
+    # the packed pipeline's own activations against a float64 forward of the oracle (CPU), layer by layer.
+    if max(e["l2_vs_f64"], e["max_vs_f64"], e["l2_vs_reference"]) > REL_TOL:
+        n_flip, n_act = _sign_flips_vs_float64(dec, gen256[1], feats, wd, noises)
+        e["activations_whose_sign_differs_from_float64"] = n_flip
+        e["activations"] = n_act
+        record("dec2_bwd_vs_reference_256", **e)
+        assert 0 < n_flip <= 16 * batch, e           # a handful of 5.5 M activations per sample; 0 would leave the error unexplained
+    else:
+        record("dec2_bwd_vs_reference_256", **e)
     assert e["img"] <= 1e-4
     assert e["l2_vs_f64"] <= max(REL_TOL, 3 * e["reference_l2_vs_f64"]), e
     assert e["max_vs_f64"] <= max(REL_TOL, 3 * e["reference_max_vs_f64"]), e

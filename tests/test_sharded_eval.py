@@ -30,6 +30,20 @@ def test_single_process_gather_is_identity():
     assert torch.equal(out, rows)
 
 
+def test_forced_collective_on_a_single_rank_gloo():
+    """force_collective=True takes the all_gather branch even for one rank (the GPU twin of this test runs it over nccl = RCCL)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        rows = torch.arange(40, dtype=torch.float32).reshape(5, 8)
+        out = se.gather_metric_rows(rows, 5, 0, 1, force_collective=True)
+        assert torch.equal(out, rows)
+        table = se.evaluate_sharded(lambda i: torch.full((8,), float(i)), 3, 0, 1, force_collective=True)
+        assert torch.equal(table[:, 0], torch.arange(3.0))
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
