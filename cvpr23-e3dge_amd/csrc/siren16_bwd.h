@@ -143,12 +143,15 @@ __device__ __forceinline__ void t3_barrier() {
 // One stream tile (16 points x 16 features of one layer = 1 KiB) of this wave into ring slot TILE & 3.  `gbase` (scalar) = the
 // stream at the workgroup's first point, `voff` = the lane's byte offset (point row + layer + 16 q), the tile's 64 bytes go into
 // the instruction's immediate -- which the hardware adds to the LDS address as well, so it is taken off the slot base.
-// a wave-uniform value in an SGPR, opaquely (the optimiser folds __builtin_amdgcn_readfirstlane of a value it knows to be uniform and may
-// then keep it in a VGPR -- which an "s" asm operand silently accepts and the assembler rejects)
-__device__ __forceinline__ int t3_scalar(int v) {
-    int r;
-    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(r) : "v"(v));
-    return r;
+// Issue roles as scalar flags, computed by SALU instructions only: (wave < 4, wave >= 4).  `wave_s` must come straight from
+// __builtin_amdgcn_readfirstlane (then it IS an SGPR; a C++ select on it may be evaluated in the VALU, and an "s" asm operand silently
+// accepts the resulting VGPR).  An earlier form read the flag back with v_readfirstlane inside an asm statement: the compiler cannot
+// see the VALU-writes-SGPR / SALU-reads hazards of gfx950 in there, the flags came out inverted or stale on the MI355X and waves 0-3
+// issued the stream tiles of waves -4..-1 (tools/ubench/asm_if.hip reproduces it in isolation).
+__device__ __forceinline__ void t3_roles(int wave_s, int& w_role, int& s_role) {
+    int w, st;
+    asm volatile("s_cmp_lt_u32 %2, 4\n\ts_cselect_b32 %0, 1, 0\n\ts_cselect_b32 %1, 0, 1" : "=s"(w), "=s"(st) : "s"(wave_s) : "scc");
+    w_role = w; s_role = st;
 }
 // Role-conditional forms: the scalar test and the branch live INSIDE the asm statement, so the compiler keeps seeing one straight-line
 // tile (a C++ `if (role)` around the DMA split every unrolled tile into basic blocks and cost the chain kernels 60 registers).
@@ -192,8 +195,10 @@ __device__ __forceinline__ void t3_issue_tile(int flag, const void* gbase, uint3
 // pieces; every wave an eighth in two pieces otherwise) issue, every wave keeps the bookkeeping.
 struct T3WeightPipe : ChunkPipe16 {
     int active;
-    __device__ __forceinline__ void init3(float* wbuf_, const float* image, int wave_u, int lane, int count_ = k16Chunks) {
-        active = t3_scalar((!kT3Split || wave_u < 4) ? 1 : 0);
+    __device__ __forceinline__ void init3(float* wbuf_, const float* image, int wave_u, int lane, int count_ = k16Chunks) {     // wave_u: from readfirstlane
+        int s_unused;
+        active = 1;
+        if (kT3Split) t3_roles(wave_u, active, s_unused);
         init(wbuf_, image, kT3Split ? 2 * (wave_u & 3) : wave_u, lane, count_);     // split: img / lds_base at wave_u * 4 KiB
     }
     __device__ __forceinline__ void issue3() {
@@ -292,7 +297,8 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
     }
 
     const int wave_u = __builtin_amdgcn_readfirstlane(tid_k >> 6);
-    const int w_role = t3_scalar((kT3Split && wave_u < 4) ? 1 : 0), s_role = t3_scalar(1 - w_role);    // weight waves issue no streams (scalar flags)
+    int w_role = 0, s_role = 1;                                               // weight waves issue no streams (scalar flags)
+    if (kT3Split) t3_roles(wave_u, w_role, s_role);
     const int64_t base_pt = (int64_t)b * a.n_pts + pt0;                       // the workgroup's first point
     const char* const g_args = reinterpret_cast<const char*>(a.args + base_pt * (9 * kWidth));
     const char* const g_tr = EIK ? reinterpret_cast<const char*>(a.tang + base_pt * (8 * kWidth)) : nullptr;
@@ -301,7 +307,8 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
     constexpr uint32_t kStream1 = (uint32_t)kRingF * 4u;                      // byte distance of the second stream's ring
     // row (relative to the workgroup's first) of this lane's column in wave `w` of sub-tile `sub`; rows beyond the tensor read the last valid row
     auto row_of = [&](int sub, int w, int tid_x) {
-        const int p = sub * kTilePts + 16 * w + (tid_x & 15);
+        int p = sub * kTilePts + 16 * w + (tid_x & 15);
+        if (E3DGE_T3_ABL & 128) p = p < 0 ? 0 : p;
         return p < npts ? p : npts - 1;
     };
     // the stream tiles of (sub-tile, layer, tile) for the waves this wave serves
@@ -315,10 +322,11 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
         const int rb = row_of(sub, tid_i >> 6, tid_i);
         t3_issue_tile<tile, kSlots>(s_role, g_args, 4u * (t3_row_floats(rb, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o);
         if (EIK) t3_issue_tile<tile, kSlots>(s_role, g_tr, 4u * (t3_row_floats(rb, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o + kStream1);
-        if (kT3Split) {
+        if (kT3Split && !(E3DGE_T3_ABL & 64)) {
             const int ra = row_of(sub, (tid_i >> 6) - 4, tid_i);
-            t3_issue_tile<tile, kSlots>(s_role, g_args, 4u * (t3_row_floats(ra, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u));
-            if (EIK) t3_issue_tile<tile, kSlots>(s_role, g_tr, 4u * (t3_row_floats(ra, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u) + kStream1);
+            [[maybe_unused]] const int s_role_a = s_role;
+            t3_issue_tile<tile, kSlots>(s_role_a, g_args, 4u * (t3_row_floats(ra, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u));
+            if (EIK) t3_issue_tile<tile, kSlots>(s_role_a, g_tr, 4u * (t3_row_floats(ra, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u) + kStream1);
         }
     };
 
@@ -582,14 +590,16 @@ __global__ void __launch_bounds__(k16Threads) siren16_chain_kernel(const SirenCh
     constexpr int kChainChunks = 7 * k16Tiles;
     constexpr int kFirstGemmLayer = TANGENT ? 1 : 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid_k >> 6);
-    const int w_role = t3_scalar((kT3Split && wave_u < 4) ? 1 : 0), s_role = t3_scalar(1 - w_role);
+    int w_role = 0, s_role = 1;
+    if (kT3Split) t3_roles(wave_u, w_role, s_role);
     const int64_t base_pt = (int64_t)b * a.n_pts + pt0;
     const char* const g_args = reinterpret_cast<const char*>(a.args + base_pt * (9 * kWidth));
     const char* const g_r = TR ? reinterpret_cast<const char*>(a.rmul + base_pt * (8 * kWidth)) : nullptr;
     const uint32_t ring_b = lds_addr_of(smem + kC16LdsRing) + (uint32_t)wave_u * (kSlots * 1024u);
     constexpr uint32_t kStream1 = (uint32_t)kRingF * 4u;
     auto row_of = [&](int sub, int w, int tid_x) {
-        const int p = sub * kTilePts + 16 * w + (tid_x & 15);
+        int p = sub * kTilePts + 16 * w + (tid_x & 15);
+        if (E3DGE_T3_ABL & 128) p = p < 0 ? 0 : p;
         return (E3DGE_T3_ABL & 16) ? 0 : (p < npts ? p : npts - 1);
     };
     auto issue_streams = [&](auto tile_c, int sub, int layer) {
@@ -602,10 +612,11 @@ __global__ void __launch_bounds__(k16Threads) siren16_chain_kernel(const SirenCh
         const int rb = row_of(sub, tid_i >> 6, tid_i);
         t3_issue_tile<tile, kSlots>(s_role, g_args, 4u * (t3_row_floats(rb, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o);
         if (TR) t3_issue_tile<tile, kSlots>(s_role, g_r, 4u * (t3_row_floats(rb, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o + kStream1);
-        if (kT3Split) {
+        if (kT3Split && !(E3DGE_T3_ABL & 64)) {
             const int ra = row_of(sub, (tid_i >> 6) - 4, tid_i);
-            t3_issue_tile<tile, kSlots>(s_role, g_args, 4u * (t3_row_floats(ra, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u));
-            if (TR) t3_issue_tile<tile, kSlots>(s_role, g_r, 4u * (t3_row_floats(ra, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u) + kStream1);
+            [[maybe_unused]] const int s_role_a = s_role;
+            t3_issue_tile<tile, kSlots>(s_role_a, g_args, 4u * (t3_row_floats(ra, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u));
+            if (TR) t3_issue_tile<tile, kSlots>(s_role_a, g_r, 4u * (t3_row_floats(ra, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u) + kStream1);
         }
     };
 
