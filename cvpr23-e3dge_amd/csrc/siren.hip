@@ -1043,7 +1043,7 @@ extern "C" int e3dge_siren_render_fwd(const E3dgeRenderArgs* r, e3dge_stream_t s
                     reinterpret_cast<uintptr_t>(r->tex_alpha) | reinterpret_cast<uintptr_t>(r->tex_beta)) & 15) == 0,
                   "siren_render_fwd: packed/film/tex pointers must be 16-B aligned");
     E3DGE_REQUIRE(r->sigmoid_beta != 0.0f, "siren_render_fwd: sigmoid_beta must be non-zero");
-    E3DGE_REQUIRE(r->precision == E3DGE_PREC_F32 || r->precision == E3DGE_PREC_F16X3 || r->precision == E3DGE_PREC_F16X3_V1, "siren_render_fwd: precision=%d", r->precision);
+    E3DGE_REQUIRE(r->precision >= E3DGE_PREC_F32 && r->precision <= E3DGE_PREC_F16X3_G2, "siren_render_fwd: precision=%d", r->precision);
     if (r->batch == 0) return E3DGE_OK;
     const int64_t HW = (int64_t)r->height * r->width;
     E3DGE_REQUIRE(HW * r->batch * (int64_t)r->n_samples < ((int64_t)1 << 40), "siren_render_fwd: too many points");
@@ -1060,8 +1060,12 @@ extern "C" int e3dge_siren_render_fwd(const E3dgeRenderArgs* r, e3dge_stream_t s
     const int64_t grid = (int64_t)k.tiles_per_img * r->batch;
     E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_render_fwd: grid too large");
     k.save_args = r->save_args;
+    // precision f16x3_g2 on a forward launch = the f16x3 kernel, with the saved arguments in the slab-major layout its backward-type
+    // kernels read (siren_common.h); without save_args the two are the same launch
+    k.save_blocked = (r->precision == E3DGE_PREC_F16X3_G2 && r->save_args) ? 1 : 0;
+    const int precision = r->precision == E3DGE_PREC_F16X3_G2 ? E3DGE_PREC_F16X3 : r->precision;
     if (r->backbone_out || r->backbone_in) {
-        E3DGE_REQUIRE(r->precision == E3DGE_PREC_F16X3 && !r->save_args, "siren_render_fwd: the backbone hand-over needs precision f16x3 and no save_args");
+        E3DGE_REQUIRE(precision == E3DGE_PREC_F16X3 && !r->save_args, "siren_render_fwd: the backbone hand-over needs precision f16x3 and no save_args");
         E3DGE_REQUIRE(!(r->backbone_out && r->backbone_in), "siren_render_fwd: backbone_out and backbone_in are exclusive");
         E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(r->backbone_out) | reinterpret_cast<uintptr_t>(r->backbone_in)) & 15) == 0, "siren_render_fwd: backbone record must be 16-B aligned");
         if (r->backbone_in)
@@ -1070,7 +1074,7 @@ extern "C" int e3dge_siren_render_fwd(const E3dgeRenderArgs* r, e3dge_stream_t s
         k.bb_out = r->backbone_out; k.bb_in = r->backbone_in; k.weights_in = r->weights_in;
         k.bb_subs = (k.R * r->n_samples + kTilePts - 1) / kTilePts;
     }
-    int rc = launch_siren<0>(k, r->precision, grid, as_stream(stream));
+    int rc = launch_siren<0>(k, precision, grid, as_stream(stream));
     if (rc) return rc;
     return check_launch("siren_render_fwd");
 }
@@ -1098,7 +1102,7 @@ extern "C" int64_t e3dge_siren_backbone_bytes(int batch, int height, int width, 
 extern "C" int e3dge_siren_points_fwd(const float* packed, const float* film, const float* pts,
                                       const float* viewdirs, float box_scale, int batch, int64_t n_pts,
                                       float* sdf, float* raw, float* save_args, int precision, e3dge_stream_t stream) {
-    E3DGE_REQUIRE(precision == E3DGE_PREC_F32 || precision == E3DGE_PREC_F16X3 || precision == E3DGE_PREC_F16X3_V1, "siren_points_fwd: precision=%d", precision);
+    E3DGE_REQUIRE(precision >= E3DGE_PREC_F32 && precision <= E3DGE_PREC_F16X3_G2, "siren_points_fwd: precision=%d", precision);
     E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "siren_points_fwd: bad sizes");
     if (batch == 0 || n_pts == 0) return E3DGE_OK;
     E3DGE_REQUIRE(packed && film && pts, "siren_points_fwd: null input pointer");
@@ -1115,6 +1119,8 @@ extern "C" int e3dge_siren_points_fwd(const float* packed, const float* film, co
     const int64_t grid = (int64_t)k.wgs_per_img * batch;
     E3DGE_REQUIRE(grid < ((int64_t)1 << 31), "siren_points_fwd: grid too large");
     k.save_args = save_args;
+    k.save_blocked = (precision == E3DGE_PREC_F16X3_G2 && save_args) ? 1 : 0;      // (see e3dge_siren_render_fwd)
+    if (precision == E3DGE_PREC_F16X3_G2) precision = E3DGE_PREC_F16X3;
     int rc = launch_siren<1>(k, precision, grid, as_stream(stream));
     if (rc) return rc;
     return check_launch("siren_points_fwd");

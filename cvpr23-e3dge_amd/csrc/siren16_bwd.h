@@ -56,14 +56,17 @@ template <int N, class F> __device__ __forceinline__ void t3_static_for(F&& f) {
 constexpr int t3_slots(int ns) { return ns == 1 ? E3DGE_T3_SLOTS1 : 4; }
 constexpr int t3_ring_floats(int ns) { return 8 * t3_slots(ns) * 256; }      // one stream, eight waves
 static_assert(k16Tiles % t3_slots(1) == 0 && k16Tiles % t3_slots(2) == 0, "static slot index = tile index mod slots");
-// Who issues what (E3DGE_T3_SPLIT, default on).  vmcnt retires in order, so a wave that waits for its (L2-resident, two tiles old)
-// weight pieces also waits for every older stream load of its own -- cold HBM lines with a tail latency of microseconds: with one
-// queue per wave the streams' budget is three tiles whatever the ring depth, and the ablations of round 6 (tools/r6_chain_abl.sh)
-// put the exposed wait at half of the chain kernels' time.  So the queues are separated BY WAVE: waves 0-3 issue the whole weight
-// chunk (4 pieces each), waves 4-7 issue the stream tiles of waves w-4 and w (any wave may DMA into any LDS address); every wave
-// waits for its own operations and the tile's barrier publishes all of them.  A stream's budget is then its ring depth.
+// Who issues what (E3DGE_T3_SPLIT, default OFF -- an experiment that is kept because its result decides where the time is NOT).
+// vmcnt retires in order, so a wave that waits for its (L2-resident, two tiles old) weight pieces also waits for every older stream
+// load of its own: with one queue per wave the streams' latency budget is three tiles whatever the ring depth.  E3DGE_T3_SPLIT=1
+// separates the queues BY WAVE -- waves 0-3 issue the whole weight chunk (4 pieces each), waves 4-7 the stream tiles of waves w-4
+// and w (any wave may DMA into any LDS address), every wave waits for its own operations and the tile's barrier publishes all of
+// them; a stream's budget is then its ring depth (7 tiles with one stream).  Measured (MI355X, 64x64x18, tools/r6_chain_abl.sh):
+// sdf chain 0.439 vs 0.444 ms, tangent 0.437 vs 0.439, second-order backward 0.492 vs 0.480 -- nothing: the streams were not
+// latency-bound, they were ACCESS-PATTERN-bound (sixteen 64-byte pieces per instruction; the slab-major layout above takes the same
+// kernels to 0.325 / 0.321 / 0.468 ms, and 0.237 / 0.235 / 0.431 with cache-resident rows).
 #ifndef E3DGE_T3_SPLIT
-#define E3DGE_T3_SPLIT 1
+#define E3DGE_T3_SPLIT 0
 #endif
 constexpr bool kT3Split = E3DGE_T3_SPLIT != 0;
 
@@ -101,7 +104,7 @@ constexpr int kB16Ring = 2;                       // k-steps of weight fragments
 //       DMA and every store of a wave is ONE contiguous KiB (8 full lines, one DRAM page) instead of sixteen 64-byte pieces.
 //       Same number of bytes (rows padded to a multiple of 16 per image); slab s starts where row 16 s starts.
 #ifndef E3DGE_T3_BLOCKED
-#define E3DGE_T3_BLOCKED 0
+#define E3DGE_T3_BLOCKED 1      // (0 = point-major, as the first-generation kernels: A/B builds; the forward then must not be asked for slabs)
 #endif
 constexpr bool kT3Blocked = E3DGE_T3_BLOCKED != 0;
 constexpr int kT3LayerF = kT3Blocked ? 16 * kWidth : kWidth;      // floats between consecutive layers of a point / slab
@@ -299,9 +302,10 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
     const int wave_u = __builtin_amdgcn_readfirstlane(tid_k >> 6);
     int w_role = 0, s_role = 1;                                               // weight waves issue no streams (scalar flags)
     if (kT3Split) t3_roles(wave_u, w_role, s_role);
-    const int64_t base_pt = (int64_t)b * a.n_pts + pt0;                       // the workgroup's first point
-    const char* const g_args = reinterpret_cast<const char*>(a.args + base_pt * (9 * kWidth));
-    const char* const g_tr = EIK ? reinterpret_cast<const char*>(a.tang + base_pt * (8 * kWidth)) : nullptr;
+    const int64_t base_pt = (int64_t)b * a.n_pts + pt0;                       // the workgroup's first point in the caller's (point-major) tensors
+    const int64_t base_row = (int64_t)b * saved_rows_per_image(kT3Blocked, a.n_pts) + pt0;      // ... and its row in the saved state
+    const char* const g_args = reinterpret_cast<const char*>(a.args + base_row * (9 * kWidth));
+    const char* const g_tr = EIK ? reinterpret_cast<const char*>(a.tang + base_row * (8 * kWidth)) : nullptr;
     // ring bases (LDS byte address of slot 0) of the waves this wave fetches for: itself (B) and, when split, wave - 4 (A)
     const uint32_t ring_b = lds_addr_of(smem + kB16LdsRing) + (uint32_t)wave_u * (kSlots * 1024u);
     constexpr uint32_t kStream1 = (uint32_t)kRingF * 4u;                      // byte distance of the second stream's ring
@@ -358,7 +362,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
         const bool valid = p < npts;
         const int pc = valid ? p : (npts - 1);
         const int64_t gpt = base_pt + pc;
-        const float* __restrict__ ap = a.args + base_pt * (9 * kWidth) + t3_row_floats(pc, q, 9);
+        const float* __restrict__ ap = a.args + base_row * (9 * kWidth) + t3_row_floats(pc, q, 9);
         const float vmask = valid ? 1.0f : 0.0f;                       // padded lanes contribute nothing
         const float* __restrict__ txa = TEX ? a.tex_alpha + gpt * kWidth + 4 * q : nullptr;
         float* __restrict__ dta = TEX ? a.d_tex_alpha + gpt * kWidth + 4 * q : nullptr;
@@ -593,8 +597,9 @@ __global__ void __launch_bounds__(k16Threads) siren16_chain_kernel(const SirenCh
     int w_role = 0, s_role = 1;
     if (kT3Split) t3_roles(wave_u, w_role, s_role);
     const int64_t base_pt = (int64_t)b * a.n_pts + pt0;
-    const char* const g_args = reinterpret_cast<const char*>(a.args + base_pt * (9 * kWidth));
-    const char* const g_r = TR ? reinterpret_cast<const char*>(a.rmul + base_pt * (8 * kWidth)) : nullptr;
+    const int64_t base_row = (int64_t)b * saved_rows_per_image(kT3Blocked, a.n_pts) + pt0;
+    const char* const g_args = reinterpret_cast<const char*>(a.args + base_row * (9 * kWidth));
+    const char* const g_r = TR ? reinterpret_cast<const char*>(a.rmul + base_row * (8 * kWidth)) : nullptr;
     const uint32_t ring_b = lds_addr_of(smem + kC16LdsRing) + (uint32_t)wave_u * (kSlots * 1024u);
     constexpr uint32_t kStream1 = (uint32_t)kRingF * 4u;
     auto row_of = [&](int sub, int w, int tid_x) {
@@ -649,9 +654,9 @@ __global__ void __launch_bounds__(k16Threads) siren16_chain_kernel(const SirenCh
         const int p = sub * kTilePts + 16 * wave + col;
         const int pc = (E3DGE_T3_ABL & 16) ? 0 : (p < npts ? p : (npts - 1));
         const int64_t gpt = base_pt + pc;
-        const float* __restrict__ ap = a.args + base_pt * (9 * kWidth) + t3_row_floats(pc, q, 9);
-        const float* __restrict__ rp = TR ? a.rmul + base_pt * (8 * kWidth) + t3_row_floats(pc, q, 8) : nullptr;
-        float* __restrict__ sp = a.save + base_pt * (8 * kWidth) + t3_row_floats(pc, q, 8);
+        const float* __restrict__ ap = a.args + base_row * (9 * kWidth) + t3_row_floats(pc, q, 9);
+        const float* __restrict__ rp = TR ? a.rmul + base_row * (8 * kWidth) + t3_row_floats(pc, q, 8) : nullptr;
+        float* __restrict__ sp = a.save + base_row * (8 * kWidth) + t3_row_floats(pc, q, 8);
         const int sub_n = sub + 1 < n_sub ? sub + 1 : sub;
         const float* const ring_rd = smem + kC16LdsRing + wave * (kSlots * 256) + lane * 4;
         gmax = 0.0f;

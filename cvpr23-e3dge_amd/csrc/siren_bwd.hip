@@ -916,6 +916,7 @@ struct CompositeBwdK {
     float sigmoid_beta;
     int S, force_bg;
     long long n_rays, rays_per_img;
+    int args_blocked;        // the saved arguments are slab-major (siren_common.h): precision f16x3_g2
 };
 
 constexpr int kCbStride = 8;     // floats of LDS per sample: dw, alpha, T, dalpha/dsdf, rgb[3], d_sdf
@@ -948,7 +949,9 @@ __global__ void __launch_bounds__(kThreads) composite_bwd_kernel(const Composite
             // phase 1: recompute feat / rgb of every sample, four wave-wide dot products each
             for (int s = 0; s < S; ++s) {
                 const long long gpt = ray * S + s;
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(a.args + gpt * (9 * kWidth) + 8 * kWidth + 4 * lane);
+                // the view layer's 256 arguments of this sample, features 4 lane .. 4 lane + 3 (slab-major: tile lane >> 2, q = lane & 3)
+                const long long arow = (long long)b * saved_rows_per_image(a.args_blocked != 0, a.rays_per_img * S) + (gpt - (long long)b * a.rays_per_img * S);
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(a.args + saved_elem_floats(a.args_blocked != 0, arow, 8, 4 * lane, 9));
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1215,6 +1218,7 @@ extern "C" int e3dge_siren_render_bwd(const E3dgeRenderBwdArgs* r, e3dge_stream_
     c.d_sdf_in = r->d_sdf; c.d_weights = r->d_weights; c.d_rgb_pts = r->d_rgb_pts; c.d_sdf_pts = r->d_sdf_pts;
     c.sigmoid_beta = r->sigmoid_beta; c.S = r->n_samples; c.force_bg = r->force_background;
     c.n_rays = HW * r->batch; c.rays_per_img = HW;
+    c.args_blocked = (r->precision == E3DGE_PREC_F16X3_G2 && kT3Blocked) ? 1 : 0;
     const size_t lds = (size_t)4 * r->n_samples * kCbStride * sizeof(float);
     {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&composite_bwd_kernel),

@@ -123,6 +123,7 @@ struct SirenK {
     const float* pts; const float* vdirs; long long n_pts; int subtiles_per_wg, wgs_per_img;
     float* raw;
     float* save_args;          // training: (points, 9, 256) pre-sine arguments of every layer, or null
+    int save_blocked;          // save_args in the slab-major layout of the 8-wave backward-type kernels (saved_row_floats below)
     // backbone hand-over between the two passes of one evaluated image (siren16_kernel<0, false, CACHE>): pass #1 writes the packed
     // (hi, lo) output of layer 7 per 16-point slab, pass #2 (texture FiLM) reads it and the composite weights instead of
     // recomputing layers 0..7, the sdf head and the transmittance scan -- they do not depend on the texture conditions
@@ -130,6 +131,26 @@ struct SirenK {
 };
 
 void siren_record_layout(int batch, int height, int width, int n_samples, int* R, int* tiles_per_img, int* subs);   // siren.hip
+
+// ---- layouts of the saved state (pre-sine arguments: L = 9 layers per point; r_l, ta_l r_l: L = 8) ----
+//   point-major: row p = the L x 256 floats of point p (E3DGE_PREC_F32 / _F16X3 backward-type kernels).
+//   slab-major (E3DGE_PREC_F16X3_G2): 16 consecutive rows form a slab [L layers][16 tiles of 16 features][lane = 16 q + n][4 floats],
+//       n = row & 15, feature = 16 tile + 4 q + j: the 16 points x 16 features of one (layer, tile) are ONE contiguous KiB in exactly the
+//       order the 64 lanes of an 8-wave kernel hold them (C/D fragment of v_mfma_f32_16x16x32_f16) -- a wave's store / stream DMA of a
+//       tile is 8 full 128-byte lines of one DRAM page instead of sixteen 64-byte pieces in sixteen rows 9 KiB apart.  Rows per image
+//       are padded to a multiple of 16; slab s starts where row 16 s would start, the tensor is otherwise the same size.
+constexpr int kSlabLayerF = 16 * kWidth;          // floats between the layers of a slab
+constexpr int kSlabTileF = kWidth;                // floats between the 16-feature tiles of a slab layer
+__host__ __device__ __forceinline__ int64_t saved_rows_per_image(bool blocked, int64_t n) { return blocked ? ((n + 15) & ~(int64_t)15) : n; }
+// float offset of the 4 values [feature 4 q .. 4 q + 3 of tile 0, layer 0] of row `row` (rows counted over the padded images)
+__device__ __forceinline__ int64_t saved_row_floats(bool blocked, int64_t row, int q, int L) {
+    return blocked ? (row >> 4) * L * kSlabLayerF + (q * 16 + (int)(row & 15)) * 4 : row * L * kWidth + q * 4;
+}
+// float offset of ONE value (row, layer, feature)
+__device__ __forceinline__ int64_t saved_elem_floats(bool blocked, int64_t row, int layer, int feature, int L) {
+    return blocked ? ((row >> 4) * L + layer) * kSlabLayerF + (feature >> 4) * kSlabTileF + (((feature >> 2) & 3) * 16 + (int)(row & 15)) * 4 + (feature & 3)
+                   : (row * L + layer) * kWidth + feature;
+}
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers

@@ -138,13 +138,34 @@ def default_mfma_mode():
 
 
 def default_bwd_mode():
-    """The same choice for the backward-type kernels (E3DGE_BWD_MODE; default = the forward mode): 'f16x3' scales every
-    gradient operand per point by a power of two before the (hi, lo) split."""
+    """The same choice for the backward-type kernels (E3DGE_BWD_MODE).  Default: 'f16x3_g2' beside the f16x3 forward -- the 8-wave
+    kernels of csrc/siren16_bwd.h (block-scaled split-f16 like 'f16x3', saved state slab-major, second-order inputs as the products
+    ta r; round 6) --, 'f32' beside the f32 forward.  'f16x3' = the first-generation 4-wave kernels."""
     import os
-    mode = os.environ.get("E3DGE_BWD_MODE", default_mfma_mode())
+    fwd = default_mfma_mode()
+    mode = os.environ.get("E3DGE_BWD_MODE", "f16x3_g2" if fwd == "f16x3" else fwd)
     if mode not in BWD_MODES:
         raise RuntimeError(f"E3DGE_BWD_MODE must be one of {sorted(BWD_MODES)}, got {mode!r}")
     return mode
+
+
+def saved_state_buffer(B, N, L, device, W=256):
+    """Uninitialised (B, N, L, W) fp32 scratch for the saved state of a training launch (pre-sine arguments: L = 9; r_l / ta_l r_l:
+    L = 8).  The rows of an image are padded to a multiple of 16 -- the slab-major layout of the f16x3_g2 kernels (siren_common.h)
+    addresses whole 16-row slabs -- and the tensor returned is the (B, N, ..) view of it: only its data pointer is ever used."""
+    n16 = (int(N) + 15) // 16 * 16
+    return torch.empty((int(B), n16, int(L), int(W)), device=device, dtype=torch.float32)[:, :int(N)]
+
+
+def saved_state_point_major(t, slab_major):
+    """Debug / test view of a saved-state tensor made by saved_state_buffer: (B, N, L, W) indexed [image, point, layer, feature] whatever
+    the storage layout -- slab-major (siren_common.h: [slab of 16 rows][layer][tile of 16 features][q][row & 15][4]) is re-ordered."""
+    if not slab_major:
+        return t
+    B, N, L, W = t.shape
+    n16 = (N + 15) // 16 * 16
+    v = torch.as_strided(t, (B, n16 // 16, L, W // 16, 4, 16, 4), (n16 * L * W, 16 * L * W, 16 * W, 256, 64, 4, 1))   # [b, slab, layer, tile, q, n, j]
+    return v.permute(0, 1, 5, 2, 3, 4, 6).reshape(B, n16, L, W)[:, :N]
 
 
 def _opt_get(opt, name, default=None):
@@ -326,6 +347,21 @@ class SirenGenerator(nn.Module):
             mode = "f32"
         return BWD_MODES[mode]
 
+    def saved_state_is_slab_major(self):
+        """Layout in which the training launches of this module save their state (see saved_state_point_major)."""
+        return self.check_mode(self.bwd_mode) == _lib.PREC_F16X3_G2
+
+    def save_precision(self, mfma_mode=None):
+        """Precision code of a forward launch that saves its pre-sine arguments: the forward's own, or E3DGE_PREC_F16X3_G2 (= the
+        f16x3 forward writing the slab-major layout) when the backward-type kernels run in mode f16x3_g2."""
+        fwd = self.check_mode(mfma_mode or self.mfma_mode)
+        if self.check_mode(self.bwd_mode) == _lib.PREC_F16X3_G2:
+            if fwd != _lib.PREC_F16X3:
+                raise RuntimeError("backward mode 'f16x3_g2' reads the saved arguments slab-major, which only the 'f16x3' forward writes "
+                                   f"(forward mode {mfma_mode or self.mfma_mode!r})")
+            return _lib.PREC_F16X3_G2
+        return fwd
+
     def require_frozen(self, what):
         """The HIP backward returns gradients for the styles (and, where stated, points / texture FiLM) only; the
         reference can also train the renderer (Generator.train_renderer = not freeze_renderer).  Make the frozen
@@ -375,7 +411,7 @@ class SirenGenerator(nn.Module):
         if not want_eikonal:
             return self._points_launch(film, pts, viewdirs, box_scale, want_raw, mfma_mode, save_args)
         B, N = pts.shape[0], pts.shape[1]
-        args = save_args if save_args is not None else torch.empty((B, N, 9, self.W), device=pts.device, dtype=torch.float32)
+        args = save_args if save_args is not None else saved_state_buffer(B, N, 9, pts.device, self.W)
         sdf, raw = self._points_launch(film, pts, viewdirs, box_scale, want_raw, mfma_mode, args)
         eik = sdf_gradient(self, film, args, box_scale)[0] if live else torch.empty((B, N, 3), device=pts.device)
         return sdf, raw, eik
@@ -392,7 +428,8 @@ class SirenGenerator(nn.Module):
         with _lib.on_device(pts.device):
             rc = _lib.load().e3dge_siren_points_fwd(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(pts), _lib.ptr(vd),
                                                     float(box_scale), B, N, _lib.ptr(sdf), _lib.ptr(raw), _lib.ptr(save_args),
-                                                    self.check_mode(mfma_mode or self.mfma_mode), _lib.stream_of(pts))
+                                                    self.save_precision(mfma_mode) if save_args is not None else self.check_mode(mfma_mode or self.mfma_mode),
+                                                    _lib.stream_of(pts))
         _lib.check(rc, "e3dge_siren_points_fwd")
         return sdf, raw
 
@@ -411,7 +448,7 @@ def sdf_gradient(siren, film, args, box_scale):
     the per-layer r_l = d sdf / d h_l (B,N,8,256) a loss on e needs for its backward."""
     packed = siren.device_image()[0]
     B, N = args.shape[0], args.shape[1]
-    rsave = torch.empty((B, N, 8, siren.W), device=args.device, dtype=torch.float32)
+    rsave = saved_state_buffer(B, N, 8, args.device, siren.W)
     eik = torch.empty((B, N, 3), device=args.device, dtype=torch.float32)
     with _lib.on_device(args.device):
         rc = _lib.load().e3dge_siren_sdf_grad(_lib.ptr(packed), _lib.ptr(film), _lib.ptr(args), None, float(box_scale),
@@ -431,7 +468,7 @@ def tangent_arguments(siren, film, args, v, box_scale, images=None, rsave=None):
     packed = (images if images is not None else siren.device_image())[0]
     B, N = args.shape[0], args.shape[1]
     v = v.reshape(B, N, 3).contiguous().float()
-    tang = torch.empty((B, N, 8, siren.W), device=args.device, dtype=torch.float32)
+    tang = saved_state_buffer(B, N, 8, args.device, siren.W)
     prec = siren.check_mode(siren.bwd_mode)
     with _lib.on_device(args.device):
         if prec == _lib.PREC_F16X3_G2 and rsave is not None:
@@ -487,7 +524,7 @@ class _PointsQuery(torch.autograd.Function):
     def forward(ctx, styles, siren, pts, viewdirs, box_scale, mfma_mode, want_eik):
         B, N = pts.shape[0], pts.shape[1]
         ctx.set_materialize_grads(False)               # (unused outputs arrive as None in backward, not as zero tensors: a fill each)
-        args = torch.empty((B, N, 9, siren.W), device=pts.device, dtype=torch.float32)
+        args = saved_state_buffer(B, N, 9, pts.device, siren.W)
         film = siren.film_params(styles)
         sdf, raw = siren._points_launch(film, pts, viewdirs, box_scale, True, mfma_mode, args)
         ctx.siren, ctx.styles_ndim, ctx.box_scale = siren, styles.ndim, float(box_scale)
@@ -590,7 +627,7 @@ class _RenderQuery(torch.autograd.Function):
         # others (a fill + a transposing copy per output, and the kernels then read and add the zeros)
         ctx.set_materialize_grads(False)
         film = renderer.siren.film_params(styles)
-        args = torch.empty((B, H * H * S, 9, renderer.siren.W), device=c2w.device, dtype=torch.float32)
+        args = saved_state_buffer(B, H * H * S, 9, c2w.device, renderer.siren.W)
         tex = None if tex_alpha is None else (tex_alpha.detach(), tex_beta.detach())
         out = renderer.render_with_film(film, focal, c2w, near, far, tex, save_args=args)
         # marks "xyz is ready" on the launch stream: the surface-normal query that follows in forward() depends on this launch
@@ -1088,7 +1125,7 @@ class VolumeFeatureRenderer(nn.Module):
         if tex_conditions is not None:
             raise NotImplementedError("eikonal term together with the tex-FiLM pass")
         B, H, S = c2w.shape[0], self.out_im_res, self.N_samples
-        args = torch.empty((B, H * H * S, 9, self.siren.W), device=c2w.device, dtype=torch.float32)
+        args = saved_state_buffer(B, H * H * S, 9, c2w.device, self.siren.W)
         out = self.render_with_film(film, focal, c2w, near, far, None, save_args=args)
         if B:
             out['eikonal_term'] = sdf_gradient(self.siren, film, args, self.box_scale)[0].reshape(B, H, H, S, 3)
@@ -1193,7 +1230,8 @@ class VolumeFeatureRenderer(nn.Module):
             sigmoid_beta=self._sigmoid_beta_value(),
             box_scale=float(self.box_scale), mask_depth_thresh=float(self.mask_depth_thresh),
             batch=B, height=H, width=Wd, n_samples=S, res=int(self.out_im_res),
-            force_background=int(bool(self.force_background)), precision=self.siren.check_mode(self.siren.mfma_mode),
+            force_background=int(bool(self.force_background)),
+            precision=self.siren.save_precision() if save_args is not None else self.siren.check_mode(self.siren.mfma_mode),
             rgb=op['rgb'], features=op['features'], xyz=op['xyz'], depth=op['depth'], mask=op['mask'], sdf=op['sdf'],
             weights=op['weights'], points=op['points'], rays_d=op['rays_d'], viewdirs=op['viewdirs'], dists=op['dists'],
             save_args=_lib.ptr(save_args), backbone_out=_lib.ptr(bb_out),

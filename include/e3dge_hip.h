@@ -353,10 +353,17 @@ int e3dge_hitprob_composite(float* out, const float* sdf, const float* aux, cons
 #define E3DGE_PREC_F16X3_V1 2     /* forward launches: the first-generation split-f16 kernel (4 waves x 32 points,
                                      v_mfma_f32_32x32x16_f16), kept for A/B measurements; backward-type launches: same as
                                      E3DGE_PREC_F16X3 */
-#define E3DGE_PREC_F16X3_G2 3     /* backward-type launches only (e3dge_siren_bwd / _render_bwd / _sdf_grad / _tangent / _tangent_tr):
-                                     the 8-wave x 16-point layout of the forward kernel applied to the backward chains, saved-state
-                                     streams by LDS-DMA (csrc/siren16_bwd.h).  Same block-scaled split-f16 arithmetic
-                                     as E3DGE_PREC_F16X3; the second-order inputs come as the products ta_l r_l (see below) */
+#define E3DGE_PREC_F16X3_G2 3     /* The training configuration of E3DGE_PREC_F16X3 (round 6, csrc/siren16_bwd.h):
+                                     * backward-type launches (e3dge_siren_bwd / _render_bwd / _sdf_grad / _tangent / _tangent_tr): the 8-wave x
+                                       16-point layout of the forward kernel, saved-state streams by LDS-DMA through a per-wave ring.  Same
+                                       block-scaled split-f16 arithmetic as E3DGE_PREC_F16X3; the second-order inputs come as the products
+                                       ta_l r_l (e3dge_siren_tangent_tr);
+                                     * forward launches (e3dge_siren_render_fwd / _points_fwd): the E3DGE_PREC_F16X3 kernel; `save_args` is
+                                       written SLAB-MAJOR, which is what the launches above read (and write: rsave, tang): 16 consecutive
+                                       rows of an image form a slab [L layers][16 tiles][lane 16 q + (row & 15)][4 floats] (feature =
+                                       16 tile + 4 q + j; L = 9 for save_args, 8 for rsave / tang), so that a wave's tile is one contiguous
+                                       KiB.  Rows per image are padded to a multiple of 16: every saved-state buffer of this precision
+                                       holds batch * ceil16(n_pts) * L * 256 floats.  Point-major (batch, n_pts, L, 256) everywhere else. */
 
 /* Number of floats of the packed weight image produced by e3dge_siren_pack_weights. */
 int64_t e3dge_siren_packed_floats(void);

@@ -14,7 +14,7 @@ from oracle import renderer_ref
 
 import e3dge_amd  # noqa: F401
 from e3dge_amd import synthetic as syn
-from e3dge_amd.volume_renderer import siren_backward
+from e3dge_amd.volume_renderer import saved_state_buffer, saved_state_point_major, siren_backward
 from test_gpu_renderer import make_renderer
 
 pytestmark = pytest.mark.gpu
@@ -100,7 +100,7 @@ def test_dfilm_and_determinism(sd):
     vd = torch.zeros_like(pts)
     g = torch.from_numpy(rs.normal(size=(2, n, 260)).astype(np.float32)).to(DEV)
     film = r.siren.film_params(wr)
-    args = torch.empty(2, n, 9, 256, device=DEV)
+    args = saved_state_buffer(2, n, 9, DEV)              # (rows padded to 16 per image: the default backward mode reads slabs)
     r.siren._points_launch(film, pts * r.box_scale / r.box_scale, vd, r.box_scale, True, None, args)
     outs = [siren_backward(r.siren, film, args, g[..., 4:], g[..., :3], g[..., 3]) for _ in range(2)]
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
@@ -109,7 +109,7 @@ def test_dfilm_and_determinism(sd):
     f = renderer_ref.film_params(sd64, 'renderer.network.', wr.cpu().double())
     # re-evaluate the network from explicit (gamma, beta): d/dfilm via the chain rule of the style linears is what
     # test_points_backward checks; here check that the saved arguments reproduce gamma * (W h + b) + beta
-    a0 = args[0, 0, 0].double().cpu()
+    a0 = saved_state_point_major(args, r.siren.saved_state_is_slab_major())[0, 0, 0].double().cpu()
     w0 = torch.from_numpy(np.asarray(sd['renderer.network.pts_linears.0.weight'])).double()
     b0 = torch.from_numpy(np.asarray(sd['renderer.network.pts_linears.0.bias'])).double()
     x = pts[0, 0].double().cpu() / 0.12

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import e3dge_amd  # noqa: F401,E402
 from e3dge_amd import synthetic as syn  # noqa: E402
 from e3dge_amd.camera_utils import generate_camera_params  # noqa: E402
-from e3dge_amd.volume_renderer import (VolumeFeatureRenderer, sdf_gradient, siren_backward,  # noqa: E402
+from e3dge_amd.volume_renderer import (saved_state_buffer, VolumeFeatureRenderer, sdf_gradient, siren_backward,  # noqa: E402
                                        tangent_arguments)
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1
@@ -25,7 +25,7 @@ wr, _ = syn.synthetic_inputs(batch, seed=7, device=dev)
 poses, focal, near, far, _ = generate_camera_params(res, dev, batch=batch)
 film = r.siren.film_params(wr)
 n_pts = res * res * S
-args = torch.empty(batch, n_pts, 9, 256, device=dev)
+args = saved_state_buffer(batch, n_pts, 9, dev)
 with torch.no_grad():
     r.render_with_film(film, focal, poses, near, far, None, save_args=args)
 g = torch.Generator(device=dev).manual_seed(3)

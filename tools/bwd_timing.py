@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import e3dge_amd  # noqa: F401,E402
 from e3dge_amd import _lib, synthetic as syn  # noqa: E402
 from e3dge_amd.camera_utils import generate_camera_params  # noqa: E402
-from e3dge_amd.volume_renderer import VolumeFeatureRenderer, siren_backward  # noqa: E402
+from e3dge_amd.volume_renderer import saved_state_buffer, VolumeFeatureRenderer, siren_backward  # noqa: E402
 
 dev, res, S = "cuda:0", 64, 24
 r = VolumeFeatureRenderer(syn.rendering_opt(N_samples=S), out_im_res=res, mode='test')
@@ -20,7 +20,7 @@ wr, _ = syn.synthetic_inputs(1, seed=7, device=dev)
 poses, focal, near, far, _ = generate_camera_params(res, dev)
 film = r.siren.film_params(wr)
 n_pts = res * res * S
-args = torch.empty(1, n_pts, 9, 256, device=dev)
+args = saved_state_buffer(1, n_pts, 9, dev)
 with torch.no_grad():
     r.render_with_film(film, focal, poses, near, far, None, save_args=args)
 d_rgb, d_sdf, d_feat = torch.randn(1, n_pts, 3, device=dev), torch.randn(1, n_pts, device=dev), torch.randn(1, n_pts, 256, device=dev)

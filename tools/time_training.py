@@ -9,7 +9,7 @@ sys.path.insert(0, ".")
 import e3dge_amd  # noqa: F401,E402
 from e3dge_amd import synthetic as syn  # noqa: E402
 from e3dge_amd.camera_utils import generate_camera_params  # noqa: E402
-from e3dge_amd.volume_renderer import VolumeFeatureRenderer  # noqa: E402
+from e3dge_amd.volume_renderer import saved_state_buffer, VolumeFeatureRenderer  # noqa: E402
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -77,7 +77,7 @@ from e3dge_amd.volume_renderer import siren_backward  # noqa: E402
 
 film = r.siren.film_params(wr)
 n_pts = res * res * S
-args = torch.empty(batch, n_pts, 9, 256, device=dev)
+args = saved_state_buffer(batch, n_pts, 9, dev)
 with torch.no_grad():
     out = r.render_with_film(film, focal, poses, near, far, None, save_args=args)
 d_rgb_pts = torch.randn(batch, n_pts, 3, device=dev)
