@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import e3dge_amd  # noqa: F401,E402
 from e3dge_amd import synthetic as syn  # noqa: E402
 from e3dge_amd.camera_utils import generate_camera_params  # noqa: E402
-from e3dge_amd.volume_renderer import (saved_state_buffer, VolumeFeatureRenderer, sdf_gradient, siren_backward,  # noqa: E402
+from e3dge_amd.volume_renderer import (saved_state_buffer, saved_state_point_major, VolumeFeatureRenderer, sdf_gradient, siren_backward,  # noqa: E402
                                        tangent_arguments)
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1
@@ -25,9 +25,12 @@ wr, _ = syn.synthetic_inputs(batch, seed=7, device=dev)
 poses, focal, near, far, _ = generate_camera_params(res, dev, batch=batch)
 film = r.siren.film_params(wr)
 n_pts = res * res * S
-args = saved_state_buffer(batch, n_pts, 9, dev)
-with torch.no_grad():
-    r.render_with_film(film, focal, poses, near, far, None, save_args=args)
+def saved_arguments():
+    """The forward's saved pre-sine arguments in the layout the CURRENT backward mode reads (slab-major for f16x3_g2)."""
+    a_ = saved_state_buffer(batch, n_pts, 9, dev)
+    with torch.no_grad():
+        r.render_with_film(film, focal, poses, near, far, None, save_args=a_)
+    return a_
 g = torch.Generator(device=dev).manual_seed(3)
 d_rgb = torch.randn(batch, n_pts, 3, device=dev, generator=g)
 d_sdf = torch.randn(batch, n_pts, device=dev, generator=g)
@@ -64,6 +67,8 @@ def flat(out):
 results, ref = {}, {}
 for mode in os.environ.get("BWD_AB_MODES", "f32,f16x3,f16x3_g2").split(","):
     r.siren.bwd_mode = mode
+    r.siren.mfma_mode = "f32" if mode == "f32" else "f16x3"
+    args = saved_arguments()
     eik, rsave = sdf_gradient(r.siren, film, args, box)
     tang, rs_ = tangent_arguments(r.siren, film, args, v, box, rsave=rsave)      # (f16x3_g2: tang = the products ta r, rs_ None)
     cases = {
@@ -72,10 +77,11 @@ for mode in os.environ.get("BWD_AB_MODES", "f32,f16x3,f16x3_g2").split(","):
         "bwd_eik": lambda: siren_backward(r.siren, film, args, d_feat, d_rgb, d_sdf, tang=tang, rsave=rs_),
         "bwd_eik_dpts": lambda: siren_backward(r.siren, film, args, d_feat, d_rgb, d_sdf, tang=tang, rsave=rs_, want_d_pts=True, box_scale=box),
         "bwd_tex": lambda: siren_backward(r.siren, film, args, d_feat, d_rgb, d_sdf, tex_alpha=tex_alpha),
-        "sdf_grad": lambda: sdf_gradient(r.siren, film, args, box),
-        "tangent": lambda: tangent_arguments(r.siren, film, args, v, box)[0],
-        "tangent_tr": lambda: (tangent_arguments(r.siren, film, args, v, box, rsave=rsave)[0] if mode == "f16x3_g2"
+        "sdf_grad": lambda: (lambda e_, r_: (e_, saved_state_point_major(r_, mode == "f16x3_g2")))(*sdf_gradient(r.siren, film, args, box)),
+        "tangent": lambda: saved_state_point_major(tangent_arguments(r.siren, film, args, v, box)[0], mode == "f16x3_g2"),
+        "tangent_tr": lambda: (saved_state_point_major(tangent_arguments(r.siren, film, args, v, box, rsave=rsave)[0], True) if mode == "f16x3_g2"
                                else tangent_arguments(r.siren, film, args, v, box)[0] * rsave),
+        "save_fwd": lambda: saved_arguments()[:, :1, :1],
     }
     for name, fn in cases.items():
         ms, out = timed(fn)

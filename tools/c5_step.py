@@ -31,6 +31,8 @@ def step():
 
 
 import time  # noqa: E402
+step()                                       # (the first step of a process pays one-off costs -- weight images, first launches -- and may alone exceed the window below)
+torch.cuda.synchronize()
 t_w = time.perf_counter()
 while time.perf_counter() - t_w < 0.4:      # the GPU clocks down while a process starts (imports: ~2 s of idling) and needs ~0.2 s of work to come
     step()                                   # back: three warm-up steps read 3.4-4.1 ms in every process but the first on a fresh box
