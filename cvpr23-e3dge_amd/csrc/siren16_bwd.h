@@ -311,8 +311,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
     constexpr uint32_t kStream1 = (uint32_t)kRingF * 4u;                      // byte distance of the second stream's ring
     // row (relative to the workgroup's first) of this lane's column in wave `w` of sub-tile `sub`; rows beyond the tensor read the last valid row
     auto row_of = [&](int sub, int w, int tid_x) {
-        int p = sub * kTilePts + 16 * w + (tid_x & 15);
-        if (E3DGE_T3_ABL & 128) p = p < 0 ? 0 : p;
+        const int p = sub * kTilePts + 16 * w + (tid_x & 15);
         return p < npts ? p : npts - 1;
     };
     // the stream tiles of (sub-tile, layer, tile) for the waves this wave serves
@@ -326,11 +325,10 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
         const int rb = row_of(sub, tid_i >> 6, tid_i);
         t3_issue_tile<tile, kSlots>(s_role, g_args, 4u * (t3_row_floats(rb, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o);
         if (EIK) t3_issue_tile<tile, kSlots>(s_role, g_tr, 4u * (t3_row_floats(rb, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o + kStream1);
-        if (kT3Split && !(E3DGE_T3_ABL & 64)) {
+        if (kT3Split) {
             const int ra = row_of(sub, (tid_i >> 6) - 4, tid_i);
-            [[maybe_unused]] const int s_role_a = s_role;
-            t3_issue_tile<tile, kSlots>(s_role_a, g_args, 4u * (t3_row_floats(ra, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u));
-            if (EIK) t3_issue_tile<tile, kSlots>(s_role_a, g_tr, 4u * (t3_row_floats(ra, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u) + kStream1);
+            t3_issue_tile<tile, kSlots>(s_role, g_args, 4u * (t3_row_floats(ra, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u));
+            if (EIK) t3_issue_tile<tile, kSlots>(s_role, g_tr, 4u * (t3_row_floats(ra, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u) + kStream1);
         }
     };
 
@@ -603,8 +601,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_chain_kernel(const SirenCh
     const uint32_t ring_b = lds_addr_of(smem + kC16LdsRing) + (uint32_t)wave_u * (kSlots * 1024u);
     constexpr uint32_t kStream1 = (uint32_t)kRingF * 4u;
     auto row_of = [&](int sub, int w, int tid_x) {
-        int p = sub * kTilePts + 16 * w + (tid_x & 15);
-        if (E3DGE_T3_ABL & 128) p = p < 0 ? 0 : p;
+        const int p = sub * kTilePts + 16 * w + (tid_x & 15);
         return (E3DGE_T3_ABL & 16) ? 0 : (p < npts ? p : npts - 1);
     };
     auto issue_streams = [&](auto tile_c, int sub, int layer) {
@@ -617,11 +614,10 @@ __global__ void __launch_bounds__(k16Threads) siren16_chain_kernel(const SirenCh
         const int rb = row_of(sub, tid_i >> 6, tid_i);
         t3_issue_tile<tile, kSlots>(s_role, g_args, 4u * (t3_row_floats(rb, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o);
         if (TR) t3_issue_tile<tile, kSlots>(s_role, g_r, 4u * (t3_row_floats(rb, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o + kStream1);
-        if (kT3Split && !(E3DGE_T3_ABL & 64)) {
+        if (kT3Split) {
             const int ra = row_of(sub, (tid_i >> 6) - 4, tid_i);
-            [[maybe_unused]] const int s_role_a = s_role;
-            t3_issue_tile<tile, kSlots>(s_role_a, g_args, 4u * (t3_row_floats(ra, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u));
-            if (TR) t3_issue_tile<tile, kSlots>(s_role_a, g_r, 4u * (t3_row_floats(ra, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u) + kStream1);
+            t3_issue_tile<tile, kSlots>(s_role, g_args, 4u * (t3_row_floats(ra, q0, 9) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u));
+            if (TR) t3_issue_tile<tile, kSlots>(s_role, g_r, 4u * (t3_row_floats(ra, q0, 8) + (uint32_t)layer * kT3LayerF), ring_o - 4u * (kSlots * 1024u) + kStream1);
         }
     };
 

@@ -946,39 +946,52 @@ __global__ void __launch_bounds__(kThreads) composite_bwd_kernel(const Composite
             if (a.d_rgbmap) { drgb[0] = a.d_rgbmap[ray * 3]; drgb[1] = a.d_rgbmap[ray * 3 + 1]; drgb[2] = a.d_rgbmap[ray * 3 + 2]; }
             if (a.d_xyzmap) { dxyz[0] = a.d_xyzmap[ray * 3]; dxyz[1] = a.d_xyzmap[ray * 3 + 1]; dxyz[2] = a.d_xyzmap[ray * 3 + 2]; }
             const float ddepth = a.d_depthmap ? a.d_depthmap[ray] : 0.0f;
-            // phase 1: recompute feat / rgb of every sample, four wave-wide dot products each
-            for (int s = 0; s < S; ++s) {
-                const long long gpt = ray * S + s;
-                // the view layer's 256 arguments of this sample, features 4 lane .. 4 lane + 3 (slab-major: tile lane >> 2, q = lane & 3)
-                const long long arow = (long long)b * saved_rows_per_image(a.args_blocked != 0, a.rays_per_img * S) + (gpt - (long long)b * a.rays_per_img * S);
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(a.args + saved_elem_floats(a.args_blocked != 0, arow, 8, 4 * lane, 9));
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
+            // phase 1: recompute feat / rgb of every sample, four wave-wide dot products each.  The S argument rows of a ray are fetched six
+            // at a time (round 6: one load in flight per wave made this kernel a chain of S cold-HBM round trips, 48-61 us for 4,096 rays)
+            const long long arow0 = (long long)b * saved_rows_per_image(a.args_blocked != 0, a.rays_per_img * S) + (ray * S - (long long)b * a.rays_per_img * S);
+            constexpr int kCbAhead = 6;
+            for (int s0 = 0; s0 < S; s0 += kCbAhead) {
+                f32x4 a4s[kCbAhead];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float f = sin_f32(a4[j]);
-                    v[0] = fmaf(df4[j], f, v[0]);
-                    v[1] = fmaf(wr4[0][j], f, v[1]);
-                    v[2] = fmaf(wr4[1][j], f, v[2]);
-                    v[3] = fmaf(wr4[2][j], f, v[3]);
+                for (int u = 0; u < kCbAhead; ++u) {
+                    // the view layer's 256 arguments of the sample, features 4 lane .. 4 lane + 3 (slab-major: tile lane >> 2, q = lane & 3)
+                    const int sc = min(s0 + u, S - 1);
+                    a4s[u] = *reinterpret_cast<const f32x4*>(a.args + saved_elem_floats(a.args_blocked != 0, arow0 + sc, 8, 4 * lane, 9));
                 }
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
+                for (int u = 0; u < kCbAhead; ++u) {
+                    const int s = s0 + u;
+                    if (s >= S) break;
+                    const long long gpt = ray * S + s;
+                    const f32x4 a4 = a4s[u];
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) v[i] += __shfl_xor(v[i], off, kWave);
-                }
-                if (lane == 0) {
-                    const float tv = a.t_vals[s];
-                    const float z = nearv * (1.0f - tv) + farv * tv;
-                    const float* pp = a.points + gpt * 3;
-                    float dw = v[0] + dxyz[0] * pp[0] + dxyz[1] * pp[1] + dxyz[2] * pp[2] + ddepth * z;
-                    if (a.d_weights) dw += a.d_weights[gpt];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float rc = v[1 + c] + bhead[1 + c];
-                        ws[s * kCbStride + 4 + c] = rc;
-                        dw = fmaf(2.0f * drgb[c], sigmoid_f32(rc), dw);
+                    for (int j = 0; j < 4; ++j) {
+                        const float f = sin_f32(a4[j]);
+                        v[0] = fmaf(df4[j], f, v[0]);
+                        v[1] = fmaf(wr4[0][j], f, v[1]);
+                        v[2] = fmaf(wr4[1][j], f, v[2]);
+                        v[3] = fmaf(wr4[2][j], f, v[3]);
                     }
-                    ws[s * kCbStride + 0] = dw;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] += __shfl_xor(v[i], off, kWave);
+                    }
+                    if (lane == 0) {
+                        const float tv = a.t_vals[s];
+                        const float z = nearv * (1.0f - tv) + farv * tv;
+                        const float* pp = a.points + gpt * 3;
+                        float dw = v[0] + dxyz[0] * pp[0] + dxyz[1] * pp[1] + dxyz[2] * pp[2] + ddepth * z;
+                        if (a.d_weights) dw += a.d_weights[gpt];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float rc = v[1 + c] + bhead[1 + c];
+                            ws[s * kCbStride + 4 + c] = rc;
+                            dw = fmaf(2.0f * drgb[c], sigmoid_f32(rc), dw);
+                        }
+                        ws[s * kCbStride + 0] = dw;
+                    }
                 }
             }
             // phase 2: alpha and d(alpha)/d(sdf), lanes over samples
@@ -1056,16 +1069,19 @@ bwd_reduce_kernel(float* __restrict__ dfilm, const float* __restrict__ partials,
 // The 8-wave kernels (siren16_bwd.h) leave per slice S_a = sum(da a [+ ta r cos a]) in the gamma rows and S_b = sum(da) in the beta rows:
 // with z = (a - beta) / gamma,  d gamma = sum(da z [+ ...] / gamma) = (S_a - beta S_b) / gamma,  d beta = S_b.  One thread folds both rows
 // of a (layer, feature) over its share of the slices; fixed association order -> bit-reproducible.
-__global__ void __launch_bounds__(64 * kRedGroups)
+// 16 (layer, feature) pairs x 64 slice groups per block: 144 blocks per image (the 8-wave kernels leave one slice per 128-point sub-tile --
+// 576 per 64x64x18 image; 36 blocks per image took 130 us at four images per step).
+constexpr int kFinPairs = 16, kFinGroups = 64;
+__global__ void __launch_bounds__(kFinPairs * kFinGroups)
 bwd_reduce_fin_kernel(float* __restrict__ dfilm, const float* __restrict__ partials, const float* __restrict__ film, int n_slices) {
-    __shared__ float part[2][kRedGroups][64];
+    __shared__ float part[2][kFinGroups][kFinPairs];
     const int b = blockIdx.y;
-    const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int ln = blockIdx.x * 64 + el;                               // (layer, feature) < 9*256
+    const int el = threadIdx.x & (kFinPairs - 1), g = threadIdx.x / kFinPairs;
+    const int ln = blockIdx.x * kFinPairs + el;                        // (layer, feature) < 9*256
     const int l = ln >> 8, n = ln & 255;
     const float* p = partials + (int64_t)b * n_slices * (9 * 2 * kWidth) + (l * 2) * kWidth + n;
     float sa = 0.0f, sb = 0.0f;
-    for (int s = g; s < n_slices; s += kRedGroups) {
+    for (int s = g; s < n_slices; s += kFinGroups) {
         sa += p[(int64_t)s * (9 * 2 * kWidth)];
         sb += p[(int64_t)s * (9 * 2 * kWidth) + kWidth];
     }
@@ -1073,8 +1089,8 @@ bwd_reduce_fin_kernel(float* __restrict__ dfilm, const float* __restrict__ parti
     __syncthreads();
     if (g == 0) {
         float ta = 0.0f, tb = 0.0f;
-#pragma unroll
-        for (int i = 0; i < kRedGroups; ++i) { ta += part[0][i][el]; tb += part[1][i][el]; }
+#pragma unroll 8
+        for (int i = 0; i < kFinGroups; ++i) { ta += part[0][i][el]; tb += part[1][i][el]; }
         const float* fb = film + ((int64_t)b * 9 + l) * 2 * kWidth;
         float* o = dfilm + ((int64_t)b * 9 + l) * 2 * kWidth;
         o[n] = __fdiv_rn(ta - fb[kWidth + n] * tb, fb[n]);
@@ -1178,7 +1194,7 @@ static int launch_bwd(SirenBwdK k, const float* wg, const float* wb, float* dfil
         if (rc) return rc;
     }
     if (gen2)
-        bwd_reduce_fin_kernel<<<dim3(9 * kWidth / 64, (unsigned)batch), dim3(64 * kRedGroups), 0, st>>>(dfilm, partials, k.film, n_pts > 0 ? k.wgs_per_img * k.subtiles_per_wg : 0);
+        bwd_reduce_fin_kernel<<<dim3(9 * kWidth / kFinPairs, (unsigned)batch), dim3(kFinPairs * kFinGroups), 0, st>>>(dfilm, partials, k.film, n_pts > 0 ? k.wgs_per_img * k.subtiles_per_wg : 0);
     else
         bwd_reduce_kernel<<<dim3(9 * 2 * kWidth / 64, (unsigned)batch), dim3(64 * kRedGroups), 0, st>>>(dfilm, partials, n_pts > 0 ? k.wgs_per_img : 0);
     int rc = check_launch("siren_bwd(reduce)");
