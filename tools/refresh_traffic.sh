@@ -74,18 +74,41 @@ if c and "f16x3" in res:
             e["shader_clock_ghz"] = cyc / (dur[0] / dur[1])
             e["profiled_kernel_us"] = dur[0] / dur[1] / 1e3
 ent = {}
+split = collections.defaultdict(dict)          # kernel -> {counter: KB per step}
+import re
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     c = glob.glob(os.path.join(out, f"train_{ctr}", "**", "*counter_collection.csv"), recursive=True)
     if c:
         rows = [r for r in csv.DictReader(open(c[0])) if r["Counter_Name"] == ctr]
         tot = sum(float(r["Counter_Value"]) for r in rows)
-        # steps in the run = launches of the ray samples' second-order backward (tools/c5_step.py warms the clock for 0.4 s before its timed steps)
-        n_steps = sum(1 for r in rows if "siren_bwd_kernel<true, true, false, false>" in r.get("Kernel_Name", r.get("Kernel Name", "")))
+        # steps in the run = launches of the saving render forward (one per step; tools/c5_step.py warms the clock for 0.4 s before its timed steps)
+        kname = lambda r: r.get("Kernel_Name", r.get("Kernel Name", ""))
+        n_steps = sum(1 for r in rows if "siren16_kernel<0, true" in kname(r) or "siren_kernel<0, 0, true" in kname(r))
         ent[ctr + "_KB"] = tot / max(n_steps, 1)
         ent[ctr + "_steps"] = n_steps
+        per = collections.defaultdict(float)
+        for r in rows:
+            k = kname(r)
+            name = re.sub(r"void |e3dge::|\(.*", "", k) if "e3dge::" in k else "(framework kernels)"
+            wgs = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) // max(int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1), 1)
+            per[(name, wgs if "e3dge::" in k else 0)] += float(r["Counter_Value"])
+        for key, v in per.items():
+            split[key][ctr] = v / max(n_steps, 1)
 if len(ent) == 4:
-    ent["note"] = "all kernels of tools/c5_step.py 20 (stage-1 steps 64x64x18, counted by their second-order backward launches), per step"
+    ent["note"] = "all kernels of tools/c5_step.py 20 (stage-1 steps 64x64x18, counted by their saving render forwards), per step"
     res["train_step"] = ent
+    with open(os.path.join(out, "train_step_pmc_by_kernel.txt"), "w") as f:
+        f.write("HBM traffic of one stage-1 step by (kernel, workgroups): rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python tools/c5_step.py 20;\n"
+                "MB per step; FETCH doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md)\n")
+        rows_ = sorted(split.items(), key=lambda kv: -(2 * kv[1].get("FETCH_SIZE", 0) + kv[1].get("WRITE_SIZE", 0)))
+        tf = tw = 0.0
+        for (name, wgs), v in rows_:
+            fm, wm = 2 * v.get("FETCH_SIZE", 0) / 1024, v.get("WRITE_SIZE", 0) / 1024
+            tf += fm; tw += wm
+            if fm + wm >= 1.0:
+                f.write(f"{name[:64]:<64} {wgs:>5} wgs  read {fm:9.1f} MB  write {wm:9.1f} MB\n")
+        f.write(f"{'total':<64} {'':>9}  read {tf:9.1f} MB  write {tw:9.1f} MB  = {(tf + tw) / 1024:.2f} GB per step\n")
+    print(open(os.path.join(out, "train_step_pmc_by_kernel.txt")).read())
 json.dump(res, open(os.path.join(out, "traffic_pmc.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
