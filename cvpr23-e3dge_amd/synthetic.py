@@ -205,3 +205,39 @@ def synthetic_local_feats(batch, res, n_samples, cin=301, seed=5, device='cpu'):
     f = rs.standard_normal((batch, res, res, n_samples, cin)).astype(np.float32)
     f *= (0.2 + 3.0 * rs.uniform(size=(1, 1, 1, 1, cin))).astype(np.float32)
     return torch.from_numpy(f).to(device)
+
+
+# ---- stage-2 step fixture (oracle/gen_golden_stage2.py, tests/test_gpu_stage2.py, bench.py): inputs and the two trainable modules ----
+STAGE2_FUSE_PREFIX = 'Fuse_sft_block.'
+STAGE2_HEAD_PREFIX = 'renderer.network.netLocal.local_feat_to_tex_modulations_linear.'
+
+
+def stage2_inputs(res, n_samples, size, channels=256, map_hw=16, seed=31, device="cpu"):
+    """Feature maps of the reference / query view (B = 1; stand-ins for the hourglass filters' outputs), the decoder's per-layer noise
+    images and the two fixed upstream gradients of L = <g_img, image> + <g_rgb, thumbnail>."""
+    rs = np.random.RandomState(seed)
+    t = lambda a: torch.from_numpy(a.astype(np.float32)).to(device)
+    out = dict(ref_map=t(rs.standard_normal((1, channels, map_hw, map_hw))), que_map=t(rs.standard_normal((1, channels, map_hw, map_hw))))
+    noises, r = [], res
+    while r <= size:
+        for _ in range(1 if r == res else 2):
+            noises.append(t(rs.standard_normal((1, 1, r, r))))
+        r *= 2
+    out['noises'] = noises
+    out['g_img'] = t(rs.standard_normal((1, 3, size, size)) / float(size))
+    out['g_rgb'] = t(rs.standard_normal((1, 3, res, res)) / float(res))
+    return out
+
+
+def stage2_fuse_state(template):
+    """Fuse_sft_MLP parameters: N(0,1) / sqrt(fan-in) weights, N(0,1)-family biases (activations stay O(1))."""
+    sd = {}
+    for k, v in template.items():
+        t = synthetic_tensor(STAGE2_FUSE_PREFIX + k, v.shape)
+        sd[k] = t / np.sqrt(v.shape[1]) if k.endswith('weight') else t
+    return sd
+
+
+def stage2_head_state(template):
+    """Texture-head parameters: a small FiLM perturbation (the reference zero-initialises fc_1, which would test nothing)."""
+    return {k: 0.05 * synthetic_tensor(STAGE2_HEAD_PREFIX + k, v.shape) for k, v in template.items()}
