@@ -46,8 +46,9 @@ def _setup():
 
 
 def test_stage2_restatement_reproduces_the_references_autograd():
-    """fp32 autograd of the restatement == the reference's recorded gradients (0.0 when recorded; 2e-4 allowed), and the float64
-    autograd stored beside them is reproduced too."""
+    """fp32 autograd of the restatement == the reference's recorded gradients: 0.0 on every tensor in the authoring container (the report
+    written beside the fixture, asserted below).  On another host the CPU library's summation order differs and lrelu' of the decoder is
+    a step function: 2.4e-4 was read on the GPU box's CPU where the recording itself is 2-5e-3 from float64 -- the bound here is 1e-3."""
     from oracle import renderer_ref, training_ref
     gold, g, sd, inp, fuse, fsd, wr, wd, res, S = _setup()
     T = lambda k: torch.from_numpy(gold[k])
@@ -63,9 +64,9 @@ def test_stage2_restatement_reproduces_the_references_autograd():
     keys = [k[4:] for k in gold.files if k.startswith('ref_d_')]
     assert len(keys) == 3 + 13 + 5, keys
     worst = max(_rel(_sub(grads[k]), gold['ref_' + k]) for k in keys)
-    assert worst <= 2e-4, worst
+    assert worst <= 1e-3, worst
     rep = json.load(open(os.path.join(GOLDEN, "grads_stage2_report.json")))
-    assert max(rep['restatement_vs_reference'].values()) <= 2e-4 and rep['tex_effect_on_features'] > 1e-2
+    assert max(rep['restatement_vs_reference'].values()) <= 1e-6 and rep['tex_effect_on_features'] > 1e-2
 
 
 @pytest.mark.gpu
@@ -108,7 +109,7 @@ def test_stage2_step_against_the_references_own_autograd():
     got = dict(d_ref_map=rm.grad, d_que_map=qm.grad, d_styles=s.grad)
     got.update({'d_fuse.' + n: p.grad for n, p in fuse.named_parameters()})
     got.update({'d_head.' + n: p.grad for n, p in head.named_parameters()})
-    errs = dict(loss=abs(float(loss) - float(gold['ref_loss'])) / abs(float(gold['ref_loss'])),
+    errs = dict(loss=abs(float(loss.detach()) - float(gold['ref_loss'])) / abs(float(gold['ref_loss'])),
                 img=float((img[:, :, ::8, ::8].cpu() - torch.from_numpy(gold['ref_img_sub8'])).abs().max()),
                 thumb=float((out['gen_thumb_imgs'].cpu() - torch.from_numpy(gold['ref_thumb'])).abs().max()))
     keys = [k[4:] for k in gold.files if k.startswith('ref_d_')]
