@@ -48,8 +48,14 @@ namespace e3dge {
 // pre = relu or identity; post = identity | leaky relu | the SFT fuse  D + w (D S + v)  with D = r1, S = r2.
 // A workgroup keeps the whole weight image in registers for its lifetime (8 waves x 32 output features)
 // and walks groups of 64 rows: the rows of group g + 1 are fetched (global -> registers) before the contraction of group g
-// and converted / written to the other LDS buffer after it.  Operand scale: 2^(141 - eb) with eb from the input tensor's amax
-// buffer (decoder_common.h), so any magnitude works; the output's amax is tracked for the next layer.
+// and converted / written to the other LDS buffer after it.
+// Operand scale (round 6): one power of two per ROW AND 32-COLUMN BLOCK, taken from the block's own maximum when it is staged -- a
+// k-step of the contraction is exactly one wave's 32 columns, so the block's inverse scale is applied when the k-step's three MFMAs
+// are added to the row's total (one fma per accumulator register and k-step; no extra barrier: wave g stages block g of every row).
+// Until round 6 the scale was one per TENSOR (from its amax buffer): right for activations, wrong for the gradients of the backward
+// chain, whose rows span many orders of magnitude -- rows far below the tensor's maximum lost the low (lo) half of the split and the
+// stage-2 step's Fuse_sft_MLP gradients sat at 1e-4 (relative L2) where fp32 is at 2e-5 (tests/test_gpu_stage2.py).
+// amax_in / amax_xmul are no longer read; the output's amax is still tracked for callers that want it.
 // =====================================================================================================================
 struct __attribute__((packed, aligned(4))) F4U { float v[4]; };      // 16-byte access at 4-byte alignment (row pitch 513 floats)
 
@@ -64,18 +70,16 @@ struct WsLinK {
     const float* xmul; const float* amax_xmul; int ld_xmul, off_xmul; float x_scale; int reserved;
 };
 constexpr int kWlRows = 64, kWlBufBytes = 2 * kWsSetBytes;
+constexpr int kWlScaleFloats = kWlRows * 8;                 // per buffer: [row 64][block 8] inverse operand scales
 
 __global__ void __launch_bounds__(kWsThreads) ws_linear_kernel(const WsLinK a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* const tab = reinterpret_cast<float*>(smem + 2 * kWlBufBytes);           // bias[256], colw[256]
+    float* const inv_s = tab + 2 * kWidth;                                         // [buffer 2][row 64][block 8]: 1 / (128 * block scale)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, q = lane >> 4;
     const int64_t n_groups = (a.n_rows + kWlRows - 1) / kWlRows;
     if ((int64_t)blockIdx.x >= n_groups) return;
-    // operand scale from a bound on the staged input: max |x| (x max |xmul|) |x_scale|
     const float xs = a.x_scale == 0.0f ? 1.0f : a.x_scale;           // (0 = unset: callers that zero-initialise the struct)
-    const float in_bound = (a.amax_in ? amax_read(a.amax_in, lane) : 1.0f) * (a.xmul && a.amax_xmul ? amax_read(a.amax_xmul, lane) : 1.0f) * fabsf(xs);
-    const unsigned eb = (a.amax_in || (a.xmul && a.amax_xmul)) ? scale_exponent(in_bound) : 127u + 14u;
-    const float in_scale = __uint_as_float((268u - eb) << 23), oscale = __uint_as_float((eb - 21u) << 23);
     if (tid < kWidth) { tab[tid] = a.bias ? a.bias[tid] : 0.0f; tab[kWidth + tid] = a.colw ? a.colw[tid] : 0.0f; }
     WsRegs R;
 #pragma unroll
@@ -112,11 +116,31 @@ __global__ void __launch_bounds__(kWsThreads) ws_linear_kernel(const WsLinK a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 u = sa[t], w = sb[t];
+            float m = 0.0f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (a.pre_relu) { u[i] = fmaxf(u[i], 0.0f); w[i] = fmaxf(w[i], 0.0f); }
-                u[i] *= in_scale; w[i] *= in_scale;
+                m = fmaxf(m, fmaxf(fabsf(u[i]), fabsf(w[i])));
             }
+            {   // max over the four lanes (q) that hold this row's 32 columns of the block: the exchanges of sum_over_q (siren16.h)
+                const unsigned mu = __builtin_bit_cast(unsigned, m);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(mu, mu, false, false);
+                m = fmaxf(__builtin_bit_cast(float, (unsigned)r1[0]), __builtin_bit_cast(float, (unsigned)r1[1]));
+                const unsigned mv_ = __builtin_bit_cast(unsigned, m);
+                const auto r2 = __builtin_amdgcn_permlane32_swap(mv_, mv_, false, false);
+                m = fmaxf(__builtin_bit_cast(float, (unsigned)r2[0]), __builtin_bit_cast(float, (unsigned)r2[1]));
+            }
+            // block maximum into [2^13, 2^14): m in [2^(e-127), 2^(e-126)) -> scale 2^(140 - e); 1 / (128 scale) = 2^(e - 147)
+            const unsigned e = min(max((__float_as_uint(m) >> 23) & 255u, 24u), 254u);      // (an all-zero block: any scale; inf / nan: propagate)
+            const float in_scale = __uint_as_float((267u - e) << 23);
+            {   // (address from an opaque copy of the lane index: kept live across the kernel these few words of address arithmetic are
+                //  what tips the 256-register allocation into spilling weight fragments)
+                int lane_o = lane;
+                asm volatile("" : "+v"(lane_o));
+                if ((lane_o >> 4) == 0) inv_s[(buf * kWlRows + 32 * half + 16 * t + (lane_o & 15)) * 8 + wave] = __uint_as_float((e - 20u) << 23);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { u[i] *= in_scale; w[i] *= in_scale; }
             const HiLo p0 = split2(u[0], u[1]), p1 = split2(u[2], u[3]), p2 = split2(w[0], w[1]), p3 = split2(w[2], w[3]);
             char* o = smem + buf * kWlBufBytes + half * kWsSetBytes + (((wave * 2 + t) * 4 + q) * 16 + n) * 16;
             *reinterpret_cast<u32x4*>(o) = u32x4{p0.h, p1.h, p2.h, p3.h};
@@ -136,32 +160,47 @@ __global__ void __launch_bounds__(kWsThreads) ws_linear_kernel(const WsLinK a) {
         for (int st = 0; st < 2; ++st) {
             if (has_next) stage_load(grp + gridDim.x, st);
             const char* xr = smem + buf * kWlBufBytes + st * kWsSetBytes + (q * 16 + n) * 16;
-            WsAcc acc;
-            u32x4 xh[2][2], xl[2][2];
+            WsAcc acc;                      // the rows' totals; every k-step adds its three products x the block's inverse scale
+            u32x4 xh[2][2], xl[2];          // hi fragments a k-step ahead; lo (third pass only) fetched at the start of its own k-step
+            int n_o = n;
+            asm volatile("" : "+v"(n_o));
+            const float* const inv_r = inv_s + (buf * kWlRows + st * 32 + n_o) * 8;    // [pt * 128 + block]: read a k-step ahead (registers are scarce)
+            float inv[2][2] = {{inv_r[0], inv_r[128]}, {0.f, 0.f}};                      // [k-step parity][pt]
 #pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                xh[0][pt] = *reinterpret_cast<const u32x4*>(xr + pt * 1024);
-                xl[0][pt] = *reinterpret_cast<const u32x4*>(xr + pt * 1024 + kWsHalfBytes);
-            }
+            for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) acc.t[ft][pt] = zero4();
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) xh[0][pt] = *reinterpret_cast<const u32x4*>(xr + pt * 1024);
 #pragma unroll
             for (int g = 0; g < kWsSteps; ++g) {
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) xl[pt] = *reinterpret_cast<const u32x4*>(xr + g * 2048 + pt * 1024 + kWsHalfBytes);
                 if (g + 1 < kWsSteps) {
 #pragma unroll
                     for (int pt = 0; pt < 2; ++pt) {
                         xh[(g + 1) & 1][pt] = *reinterpret_cast<const u32x4*>(xr + (g + 1) * 2048 + pt * 1024);
-                        xl[(g + 1) & 1][pt] = *reinterpret_cast<const u32x4*>(xr + (g + 1) * 2048 + pt * 1024 + kWsHalfBytes);
+                        inv[(g + 1) & 1][pt] = inv_r[pt * 128 + g + 1];
                     }
                 }
+                // one 16-feature tile at a time: 8 registers of partial products instead of 16 (the kernel sits at the 256-register limit)
 #pragma unroll
-                for (int pass = 0; pass < 3; ++pass)
+                for (int ft = 0; ft < 2; ++ft) {
+                    f32x4v part[2];
 #pragma unroll
-                    for (int ft = 0; ft < 2; ++ft)
+                    for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
                         for (int pt = 0; pt < 2; ++pt) {
                             const u32x4 wa = (pass == 1) ? R.wl[ft][g] : R.wh[ft][g];
-                            const u32x4 xb = (pass == 2) ? xl[g & 1][pt] : xh[g & 1][pt];
-                            acc.t[ft][pt] = mfma16x16(wa, xb, (g == 0 && pass == 0) ? zero4() : acc.t[ft][pt]);
+                            const u32x4 xb = (pass == 2) ? xl[pt] : xh[g & 1][pt];
+                            part[pt] = mfma16x16(wa, xb, pass == 0 ? zero4() : part[pt]);
                         }
+#pragma unroll
+                    for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc.t[ft][pt][i] = fmaf(part[pt][i], inv[g & 1][pt], acc.t[ft][pt][i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // one k-step's partial products at a time (eight independent sets in flight spill)
             }
             // ---- post: this lane's features 32 wave + 16 ft + 4 q .. + 3 of the rows 16 pt + n of the set ----
 #pragma unroll
@@ -180,7 +219,7 @@ __global__ void __launch_bounds__(kWsThreads) ws_linear_kernel(const WsLinK a) {
                     F4U out;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float t = fmaf(acc.t[ft][pt][i], oscale, b4[i]);
+                        float t = acc.t[ft][pt][i] + b4[i];
                         t = fmaf(c4[i], mv, t);
                         if (a.post == 2) {
                             t = fmaf(a.w_fuse, fmaf(d1[i], d2[i], t), d1[i]);                  // D + w (D S + shift)
@@ -293,7 +332,7 @@ extern "C" int e3dge_ws_linear(const E3dgeWsLinear* args, e3dge_stream_t stream)
     if (args->n_rows == 0) return E3DGE_OK;
     WsLinK k;
     memcpy(&k, args, sizeof(k));
-    const int lds = 2 * kWlBufBytes + 2 * kWidth * 4;
+    const int lds = 2 * kWlBufBytes + 2 * kWidth * 4 + 2 * kWlScaleFloats * 4;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ws_linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(E3DGE_ERR_LAUNCH, "hipFuncSetAttribute(ws_linear): %s", hipGetErrorString(e));
     const int64_t n_groups = (k.n_rows + kWlRows - 1) / kWlRows;

@@ -53,11 +53,13 @@ def restated_c5(sd, poses, focal, near, far, styles, res, n_samples, dtype):
 
 
 def restated_stage2(sd, fuse_sd, head_sd, inp, pts5, xyz, ref_calibs, que_calibs, cam, styles, wd, res, n_samples, dtype,
-                    fuse_prefix='Fuse_sft_block.', head_prefix='renderer.network.netLocal.local_feat_to_tex_modulations_linear.'):
+                    fuse_prefix='Fuse_sft_block.', head_prefix='renderer.network.netLocal.local_feat_to_tex_modulations_linear.', g_feat=None):
     """One stage-2 pass (que_render_given_ref, e3dge_full_runner.py:185-317: query on both views -> Fuse_sft_MLP -> PE -> texture head
     -> second renderer pass with the per-point FiLM -> decoder) under autograd in `dtype`, with the loss of oracle/gen_golden_stage2.py:
     L = <g_img, image> + <g_rgb, thumbnail>.  fuse_sd / head_sd: un-prefixed parameter dicts; cam = (poses, focal, near, far).
-    Returns (loss, image, thumbnail, {gradient name: tensor}) -- d_ref_map, d_que_map, d_styles, d_fuse.<param>, d_head.<param>."""
+    Returns (loss, image, thumbnail, {gradient name: tensor}) -- d_ref_map, d_que_map, d_styles, d_fuse.<param>, d_head.<param>.
+    g_feat (B,256,H,W) given: the decoder is left out and L = <g_feat, feature map> + <g_rgb, thumbnail> (no lrelu' step functions
+    between the loss and the path: the arithmetic can be held to fp32 accuracy); image is None then."""
     from oracle import decoder_ref, local_ref, renderer_ref
     leaf = lambda t: t.detach().to(dtype).clone().requires_grad_(True)
     d = lambda t: t.detach().to(dtype)
@@ -67,10 +69,14 @@ def restated_stage2(sd, fuse_sd, head_sd, inp, pts5, xyz, ref_calibs, que_calibs
     f_, _ = local_ref.local_features(fs, fuse_prefix, d(pts5), d(xyz), rm, qm, d(ref_calibs), d(que_calibs))
     tex = renderer_ref.tex_modulations({**sd, **hs}, head_prefix, f_, dtype=dtype)
     o = renderer_ref.render(sd, cam[0], cam[1], cam[2], cam[3], w_, res=res, n_samples=n_samples, tex=tex, dtype=dtype)
-    im = decoder_ref.decoder_forward(sd, o['features'], wd, noises=inp['noises'], dtype=dtype)
-    loss = (im * d(inp['g_img'])).sum() + (o['gen_thumb_imgs'] * d(inp['g_rgb'])).sum()
+    if g_feat is None:
+        im = decoder_ref.decoder_forward(sd, o['features'], wd, noises=inp['noises'], dtype=dtype)
+        loss = (im * d(inp['g_img'])).sum() + (o['gen_thumb_imgs'] * d(inp['g_rgb'])).sum()
+    else:
+        im = None
+        loss = (o['features'] * d(g_feat)).sum() + (o['gen_thumb_imgs'] * d(inp['g_rgb'])).sum()
     gs = torch.autograd.grad(loss, [rm, qm, w_] + list(fs.values()) + list(hs.values()))
     grads = dict(d_ref_map=gs[0], d_que_map=gs[1], d_styles=gs[2])
     grads.update({'d_fuse.' + k[len(fuse_prefix):]: t for k, t in zip(fs, gs[3:3 + len(fs)])})
     grads.update({'d_head.' + k[len(head_prefix):]: t for k, t in zip(hs, gs[3 + len(fs):])})
-    return float(loss.detach()), im.detach(), o["gen_thumb_imgs"].detach(), grads
+    return float(loss.detach()), None if im is None else im.detach(), o["gen_thumb_imgs"].detach(), grads

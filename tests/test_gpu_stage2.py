@@ -32,6 +32,22 @@ def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
 
 
+def _gather(fmap, p1, calibs):
+    """(1, N, C) bilinear samples of a feature map at the first pass's points (the product's own query kernel)."""
+    from e3dge_amd.local_query import query_feature_map
+    pts = p1['points'].reshape(1, -1, 3)
+    return query_feature_map(pts, calibs, fmap.detach())[0]
+
+
+def _vis(p1, calibs):
+    from e3dge_amd.local_query import query_feature_map
+    B, _, H, W = p1['xyz'].shape
+    S = p1['points'].shape[3]
+    surf = p1['xyz'].reshape(B, 3, H * W).permute(0, 2, 1)
+    vis = query_feature_map(surf, calibs)[1]
+    return vis.reshape(B, H * W, 1).expand(B, H * W, S).reshape(B, H * W * S, 1).float()
+
+
 def _setup():
     from e3dge_amd.local_query import Fuse_sft_MLP
     gold = load_golden("grads_stage2_16x24")
@@ -128,3 +144,51 @@ def test_stage2_step_against_the_references_own_autograd():
     record("stage2_step_vs_reference_16x24", **{k: (v if not isinstance(v, dict) else json.dumps(v)) for k, v in errs.items()})
     assert errs['loss'] <= 1e-4 and errs['img'] <= 1e-4 and errs['thumb'] <= 5e-6, errs
     assert not bad, bad
+    # The same graph WITHOUT the decoder (loss on the feature map and the thumbnail): no lrelu' between the loss and the path, so the
+    # arithmetic of gather / fuse / head / texture-FiLM render and of their backward kernels is held to fp32 accuracy against float64
+    # autograd of the restatement (CPU, a few seconds).
+    from oracle import renderer_ref, training_ref
+    rs = np.random.RandomState(77)
+    g_feat = torch.from_numpy((rs.standard_normal((1, 256, res, res)) / 256.0).astype(np.float32))
+    for t in [rm, qm, s] + list(fuse.parameters()) + list(head.parameters()):
+        t.grad = None
+    out = r(*cam, styles=s, local_data_batch=dict(feature_maps=dict(ref=rm, que=qm), ref_calibs=T('ref_calibs'), que_calibs=T('que_calibs'),
+                                                  points=p1['points'], xyz=p1['xyz'], fuse_sft_block=fuse))
+    ((out['features'] * g_feat.to(DEV)).sum() + (out['gen_thumb_imgs'] * inp['g_rgb'].to(DEV)).sum()).backward()
+    got = dict(d_ref_map=rm.grad, d_que_map=qm.grad, d_styles=s.grad)
+    got.update({'d_fuse.' + n: p.grad for n, p in fuse.named_parameters()})
+    got.update({'d_head.' + n: p.grad for n, p in head.named_parameters()})
+    c = lambda t: t.detach().cpu()
+    args = (sd, fsd, hsd, inp, c(p1['points']), c(p1['xyz']), c(T('ref_calibs')), c(T('que_calibs')), tuple(c(t) for t in cam), wr, wd, res, S)
+    _, _, _, g64 = training_ref.restated_stage2(*args, torch.float64, g_feat=g_feat)
+    _, _, _, g32 = training_ref.restated_stage2(*args, torch.float32, g_feat=g_feat)
+    l2 = lambda a, b: float((a.detach().double().cpu() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
+    e2 = {k: dict(max_hip=_rel(got[k], g64[k]), max_oracle_fp32=_rel(g32[k], g64[k]), l2_hip=l2(got[k], g64[k]), l2_oracle_fp32=l2(g32[k], g64[k]))
+          for k in g64}
+    record("stage2_step_without_decoder_vs_f64", **{k: json.dumps(v) for k, v in e2.items()})
+    # relu / lrelu inside Fuse_sft_MLP are step functions too: a pre-activation within the forward's rounding of zero takes the other
+    # branch (found in round 6 with tools/r6_stage2_dbg.py: ONE of the 1.57 M hidden activations of the shift branch, |value| 9e-8, and
+    # with it 1.2e-4 of relative L2 on every gradient downstream of it -- the library backward on the same saved tensors reads the same).
+    # So: the arithmetic is held to fp32 accuracy wherever no such element exists, the loose branch is allowed only when the flipped
+    # activations are actually THERE, and they are counted.
+    from e3dge_amd.local_query import Fuse_sft_MLP
+    f64m = Fuse_sft_MLP(257, 256).double().to(DEV)
+    f64m.load_state_dict({k: v.double() for k, v in fuse.state_dict().items()})
+    with torch.no_grad():
+        enc_in = torch.cat([_gather(qm, p1, T('que_calibs')), _vis(p1, T('ref_calibs')), _gather(rm, p1, T('ref_calibs'))], -1)
+        keep = {}
+        fuse._fuse_native(enc_in, 1, None, 0, keep=keep)
+        x64 = enc_in.double().reshape(-1, 513)
+        net64 = f64m.encode_enc.fc_0(torch.relu(x64))
+        e64 = f64m.encode_enc.shortcut(x64) + f64m.encode_enc.fc_1(torch.relu(net64))
+        flips = sum(int(((keep[k].reshape(r_.shape) > 0) != (r_ > 0)).sum())
+                    for k, r_ in (("net", net64), ("s1", f64m.scale[0](e64)), ("t1", f64m.shift[0](e64))))
+    tight = {k: v for k, v in e2.items() if not (v['l2_hip'] <= max(5e-5, 2 * v['l2_oracle_fp32']) and v['max_hip'] <= max(2e-4, 4 * v['max_oracle_fp32']))}
+    record("stage2_step_without_decoder_sign_flips", flipped_hidden_activations=flips, gradients_beyond_fp32_accuracy=len(tight))
+    assert flips <= 8, flips
+    if flips == 0:
+        assert not tight, tight
+    worst = {k: v for k, v in e2.items() if not (v['l2_hip'] <= 5e-4 and v['max_hip'] <= 5e-3)}
+    assert not worst, worst
+    head_and_styles = {k: v for k, v in e2.items() if k.startswith('d_head') or k == 'd_styles'}          # upstream of every step function of the fuse block
+    assert all(v['l2_hip'] <= max(5e-5, 2 * v['l2_oracle_fp32']) for v in head_and_styles.values()), head_and_styles
