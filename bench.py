@@ -800,6 +800,63 @@ def main():
                         ag["tex_head_fwd_ms"] = ev_fb(lambda: head_.tex_modulations(f_h))
                 except Exception as exc:                                  # noqa: BLE001
                     ag["tex_head_fwd_bwd_ms"] = f"failed: {type(exc).__name__}: {exc}"[:160]
+                # ---- the stage-2 training step end to end (round 6): que_render_given_ref under autograd, both trainable modules ----
+                # (e3dge_full_runner.py:185-317: first render of the query view, gathers on the two feature maps, Fuse_sft_MLP, PE, texture
+                #  head, second render with the per-point FiLM, decoder, pixel loss on pool_256 + thumbnail loss; backward into the feature
+                #  maps, Fuse_sft_MLP, the texture head and the renderer latent.  Pinned against the reference's own autograd at 16x16x24 by
+                #  tests/test_gpu_stage2.py.)
+                try:
+                    fu2 = Fuse_sft_MLP().to(dev)
+                    with torch.no_grad():
+                        for prm in fu2.parameters():
+                            prm.copy_(torch.randn_like(prm) * (0.1 if prm.ndim == 1 else 1.0 / prm.shape[1] ** 0.5))
+                    fu2.requires_grad_(True)
+                    head_ = gl.renderer.network.netLocal.local_feat_to_tex_modulations_linear
+                    g2_ = torch.Generator(device=dev).manual_seed(11)
+                    maps2 = {k: torch.randn(1, 256, 128, 128, device=dev, generator=g2_).requires_grad_(True) for k in ("ref", "que")}
+                    cq_ = generate_camera_params(RES, dev, locations=torch.zeros(1, 2, device=dev), return_calibs=True)['calibs']
+                    cr_ = generate_camera_params(RES, dev, locations=torch.tensor([[-0.2, 0.05]], device=dev), return_calibs=True)['calibs']
+                    pool2 = torch.nn.AdaptiveAvgPool2d((256, 256))
+
+                    def stage2_step():
+                        with torch.no_grad():
+                            o1 = gl.renderer(p1, f1, n1, fa1, styles=w1)                       # the query view's first render: points, xyz
+                        s_ = w1.clone().requires_grad_(True)
+                        for t_ in list(maps2.values()) + list(fu2.parameters()) + list(head_.parameters()):
+                            t_.grad = None
+                        o2 = gl([s_, d1], p1, f1, n1, fa1, input_is_latent=True, randomize_noise=False,
+                                local_data_batch=dict(feature_maps=maps2, ref_calibs=cr_, que_calibs=cq_, points=o1['points'], xyz=o1['xyz'],
+                                                      fuse_sft_block=fu2))
+                        ((pool2(o2['gen_imgs']) ** 2).mean() + (o2['gen_thumb_imgs'] ** 2).mean()).backward()
+                        return s_.grad
+                    head_.requires_grad_(True)
+                    try:
+                        gs2 = stage2_step()
+                        assert torch.isfinite(gs2).all() and all(m_.grad is not None and torch.isfinite(m_.grad).all() for m_ in maps2.values())
+                        assert all(p_.grad is not None for p_ in fu2.parameters()) and all(p_.grad is not None for p_ in head_.parameters())
+                        ts2 = sorted(ev_fb(stage2_step, n=4) for _ in range(5))
+                    finally:
+                        head_.requires_grad_(False)
+                    n_p2 = RES * RES * N_SAMPLES
+                    fl2 = dict(render_first=FLOP_PER_RAY * RES * RES, render_second_saving=FLOP_PER_RAY * RES * RES,
+                               render_backward=8 * 131072.0 * n_p2, fuse_fwd_bwd_wgrad=3 * 2.0 * 9 * 65536 * n_p2,
+                               head_fwd_bwd_wgrad=3 * 2.0 * 398825 * n_p2, decoder_fwd_bwd=2 * 125.6e9)
+                    fl2_tot = sum(fl2.values())
+                    result["train_step_stage2_ms"] = ts2[len(ts2) // 2]
+                    result["train_step_stage2"] = {
+                        "step_ms": ts2[len(ts2) // 2], "step_ms_min": ts2[0], "estimator": "median of 5 blocks of 4 steps, HIP events",
+                        "roofline": {"bound": "mfma", "achieved": fl2_tot / (ts2[len(ts2) // 2] * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / 3,
+                                     "unit": "TFLOP/s", "frac": fl2_tot / (PEAK_F16_MFMA_TFLOPS / 3 * 1e12) / (ts2[len(ts2) // 2] * 1e-3),
+                                     "flop_per_step": fl2_tot, "flop_by_part_G": {k_: round(v_ / 1e9, 1) for k_, v_ in fl2.items()}},
+                        "note": "one stage-2 sample, 64x64x24 points, two (1,256,128,128) feature maps, Fuse_sft_MLP and the texture head trainable, "
+                                "generator frozen: first render + 3 gathers + Fuse_sft_MLP + PE + texture head + texture-FiLM render (saving) + decoder "
+                                "1024^2 + loss on pool_256(image) and the thumbnail; backward through all of it (e3dge_dec2_backward, "
+                                "e3dge_siren_render_bwd in the 8-wave TEX form, e3dge_tex_modulations_bwd + e3dge_wgrad, the Fuse_sft_MLP node, "
+                                "e3dge_local_query_bwd).  The hourglass image filters are outside the path (SURVEY 2)."}
+                    del fu2, maps2
+                except Exception as exc:                                  # noqa: BLE001
+                    result["train_step_stage2_ms"] = None
+                    result["train_step_stage2"] = {"failed": f"{type(exc).__name__}: {exc}"[:240]}
                 ag["note"] = ("forward + backward with a graph: decoder in the stage-1 shape (features require grad, latent + parameters frozen, loss on "
                               "pool_256(image)): packed = e3dge_dec2_forward + e3dge_dec2_backward, library = weight modulation + MIOpen; Fuse_sft_MLP: "
                               "native-forward autograd node vs torch modules")
