@@ -49,9 +49,13 @@ namespace e3dge {
 // A workgroup keeps the whole weight image in registers for its lifetime (8 waves x 32 output features)
 // and walks groups of 64 rows: the rows of group g + 1 are fetched (global -> registers) before the contraction of group g
 // and converted / written to the other LDS buffer after it.
-// Operand scale (round 6): one power of two per ROW AND 32-COLUMN BLOCK, taken from the block's own maximum when it is staged -- a
-// k-step of the contraction is exactly one wave's 32 columns, so the block's inverse scale is applied when the k-step's three MFMAs
-// are added to the row's total (one fma per accumulator register and k-step; no extra barrier: wave g stages block g of every row).
+// Operand scale (round 6): one power of two per ROW.  A row's 256 columns are staged by eight waves (32 columns = one k-step each),
+// so no wave sees the row's maximum when it converts its block: every block is converted with the scale of its OWN maximum and leaves
+// that scale in an LDS table; the contraction -- behind the group's barrier -- takes the row's scale as the smallest of the eight and
+// multiplies the k-step's packed f16 fragments by the (power-of-two, <= 1) ratio on their way from LDS to the matrix pipe (four
+// v_pk_mul_f16 per fragment, exact; a block more than 2^24 below its row's maximum becomes zero, as it should).  One accumulator set,
+// no extra barrier.  (A first form kept per-block partial products and rescaled them in fp32: 2x slower -- every k-step's MFMAs
+// became a dependent chain in front of sixteen VALU fmas -- and 352 B of scratch.)
 // Until round 6 the scale was one per TENSOR (from its amax buffer): right for activations, wrong for the gradients of the backward
 // chain, whose rows span many orders of magnitude -- rows far below the tensor's maximum lost the low (lo) half of the split and the
 // stage-2 step's Fuse_sft_MLP gradients sat at 1e-4 (relative L2) where fp32 is at 2e-5 (tests/test_gpu_stage2.py).
@@ -160,47 +164,55 @@ __global__ void __launch_bounds__(kWsThreads) ws_linear_kernel(const WsLinK a) {
         for (int st = 0; st < 2; ++st) {
             if (has_next) stage_load(grp + gridDim.x, st);
             const char* xr = smem + buf * kWlBufBytes + st * kWsSetBytes + (q * 16 + n) * 16;
-            WsAcc acc;                      // the rows' totals; every k-step adds its three products x the block's inverse scale
-            u32x4 xh[2][2], xl[2];          // hi fragments a k-step ahead; lo (third pass only) fetched at the start of its own k-step
+            WsAcc acc;
+            u32x4 xh[2][2], xl[2][2];
             int n_o = n;
             asm volatile("" : "+v"(n_o));
-            const float* const inv_r = inv_s + (buf * kWlRows + st * 32 + n_o) * 8;    // [pt * 128 + block]: read a k-step ahead (registers are scarce)
-            float inv[2][2] = {{inv_r[0], inv_r[128]}, {0.f, 0.f}};                      // [k-step parity][pt]
+            const float* const inv_r = inv_s + (buf * kWlRows + st * 32 + n_o) * 8;    // [pt * 128 + block]: 1 / (128 x block scale)
+            float inv_row[2], rinv_row[2], inv_g[2][2];                                   // row scale (largest block maximum), its reciprocal; [k-step parity][pt]
 #pragma unroll
-            for (int ft = 0; ft < 2; ++ft)
+            for (int pt = 0; pt < 2; ++pt) {
+                const f32x4v i0 = *reinterpret_cast<const f32x4v*>(inv_r + pt * 128), i1 = *reinterpret_cast<const f32x4v*>(inv_r + pt * 128 + 4);
+                inv_row[pt] = fmaxf(fmaxf(fmaxf(i0[0], i0[1]), fmaxf(i0[2], i0[3])), fmaxf(fmaxf(i1[0], i1[1]), fmaxf(i1[2], i1[3])));
+                rinv_row[pt] = __uint_as_float((254u << 23) - __float_as_uint(inv_row[pt]));       // exact reciprocal of a power of two
+                inv_g[0][pt] = i0[0];
+            }
+            auto rescaled = [](u32x4 v, float ratio) -> u32x4 {      // the 8 packed f16 of a fragment x ratio, a power of two <= 1 (four v_pk_mul_f16)
+                const _Float16 r = (_Float16)ratio;                    // exact
+                const half8 r8 = {r, r, r, r, r, r, r, r};
+                return __builtin_bit_cast(u32x4, __builtin_bit_cast(half8, v) * r8);
+            };
 #pragma unroll
-                for (int pt = 0; pt < 2; ++pt) acc.t[ft][pt] = zero4();
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) xh[0][pt] = *reinterpret_cast<const u32x4*>(xr + pt * 1024);
+            for (int pt = 0; pt < 2; ++pt) {
+                xh[0][pt] = *reinterpret_cast<const u32x4*>(xr + pt * 1024);
+                xl[0][pt] = *reinterpret_cast<const u32x4*>(xr + pt * 1024 + kWsHalfBytes);
+            }
 #pragma unroll
             for (int g = 0; g < kWsSteps; ++g) {
-#pragma unroll
-                for (int pt = 0; pt < 2; ++pt) xl[pt] = *reinterpret_cast<const u32x4*>(xr + g * 2048 + pt * 1024 + kWsHalfBytes);
                 if (g + 1 < kWsSteps) {
 #pragma unroll
                     for (int pt = 0; pt < 2; ++pt) {
                         xh[(g + 1) & 1][pt] = *reinterpret_cast<const u32x4*>(xr + (g + 1) * 2048 + pt * 1024);
-                        inv[(g + 1) & 1][pt] = inv_r[pt * 128 + g + 1];
+                        xl[(g + 1) & 1][pt] = *reinterpret_cast<const u32x4*>(xr + (g + 1) * 2048 + pt * 1024 + kWsHalfBytes);
+                        inv_g[(g + 1) & 1][pt] = inv_r[pt * 128 + g + 1];
                     }
                 }
-                // one 16-feature tile at a time: 8 registers of partial products instead of 16 (the kernel sits at the 256-register limit)
 #pragma unroll
-                for (int ft = 0; ft < 2; ++ft) {
-                    f32x4v part[2];
+                for (int pt = 0; pt < 2; ++pt) {
+                    const float ratio = inv_g[g & 1][pt] * rinv_row[pt];
+                    xh[g & 1][pt] = rescaled(xh[g & 1][pt], ratio);
+                    xl[g & 1][pt] = rescaled(xl[g & 1][pt], ratio);
+                }
 #pragma unroll
-                    for (int pass = 0; pass < 3; ++pass)
+                for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
                         for (int pt = 0; pt < 2; ++pt) {
                             const u32x4 wa = (pass == 1) ? R.wl[ft][g] : R.wh[ft][g];
-                            const u32x4 xb = (pass == 2) ? xl[pt] : xh[g & 1][pt];
-                            part[pt] = mfma16x16(wa, xb, pass == 0 ? zero4() : part[pt]);
+                            const u32x4 xb = (pass == 2) ? xl[g & 1][pt] : xh[g & 1][pt];
+                            acc.t[ft][pt] = mfma16x16(wa, xb, (g == 0 && pass == 0) ? zero4() : acc.t[ft][pt]);
                         }
-#pragma unroll
-                    for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) acc.t[ft][pt][i] = fmaf(part[pt][i], inv[g & 1][pt], acc.t[ft][pt][i]);
-                }
-                __builtin_amdgcn_sched_barrier(0);      // one k-step's partial products at a time (eight independent sets in flight spill)
             }
             // ---- post: this lane's features 32 wave + 16 ft + 4 q .. + 3 of the rows 16 pt + n of the set ----
 #pragma unroll
@@ -219,7 +231,7 @@ __global__ void __launch_bounds__(kWsThreads) ws_linear_kernel(const WsLinK a) {
                     F4U out;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float t = acc.t[ft][pt][i] + b4[i];
+                        float t = fmaf(acc.t[ft][pt][i], inv_row[pt], b4[i]);
                         t = fmaf(c4[i], mv, t);
                         if (a.post == 2) {
                             t = fmaf(a.w_fuse, fmaf(d1[i], d2[i], t), d1[i]);                  // D + w (D S + shift)
