@@ -100,6 +100,12 @@ struct LocalQueryBwdK {
     int B, C, h, w, ld, col_off;
 };
 
+// Round 6: (i) a wave walks kLqRun CONSECUTIVE points and keeps the four corner sums in registers while the corner pixel stays the
+// same -- the samples of a ray project to one pixel of their own view's map (24 atomics' worth of contention per address in the first
+// version) and to neighbouring pixels of the other view's --, (ii) an atomic instruction covers 64 consecutive floats (two cache lines)
+// instead of 64 floats 16 bytes apart (eight lines): the stage-2 step spent 2.4 of its 10.9 ms in the two launches of the first version.
+constexpr int kLqRun = 32;
+
 __global__ void __launch_bounds__(256) local_query_bwd_kernel(const LocalQueryBwdK a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float zsign;
@@ -110,67 +116,105 @@ __global__ void __launch_bounds__(256) local_query_bwd_kernel(const LocalQueryBw
         zsign = hz < 0.0f ? -1.0f : 1.0f;
     }
     const long long total = (long long)a.B * a.N;
-    for (long long pt = (long long)blockIdx.x * 4 + wave; pt < total; pt += (long long)gridDim.x * 4) {
-        const int b = (int)(pt / a.N);
-        const float* c = a.calibs + (size_t)b * 12;
-        const float* p = a.pts + (size_t)pt * 3;
-        const float px = p[0], py = p[1], pz = p[2];
-        const float hx = c[3] + (c[0] * px + c[1] * py + c[2] * pz);
-        const float hy = c[7] + (c[4] * px + c[5] * py + c[6] * pz);
-        const float hz = c[11] + (c[8] * px + c[9] * py + c[10] * pz);
-        const float z = zsign * hz;
-        const float x = hx / z, y = -(hy / z);
-        const float fx = ((x + 1.0f) * (float)a.w - 1.0f) * 0.5f, fy = ((y + 1.0f) * (float)a.h - 1.0f) * 0.5f;
-        const float x0f = floorf(fx), y0f = floorf(fy);
-        const float tx = fx - x0f, ty = fy - y0f;
-        const bool finite = fx > -2.0f && fx < (float)a.w + 1.0f && fy > -2.0f && fy < (float)a.h + 1.0f;
-        const int x0 = finite ? (int)x0f : -5, y0 = finite ? (int)y0f : -5;
-        const float w00 = (1.0f - tx) * (1.0f - ty), w01 = tx * (1.0f - ty), w10 = (1.0f - tx) * ty, w11 = tx * ty;
-        const bool vx0 = x0 >= 0 && x0 < a.w, vx1 = x0 + 1 >= 0 && x0 + 1 < a.w;
-        const bool vy0 = y0 >= 0 && y0 < a.h, vy1 = y0 + 1 >= 0 && y0 + 1 < a.h;
-        const size_t moff = (size_t)b * a.h * a.w * a.C;
-        const size_t o00 = moff + ((size_t)y0 * a.w + x0) * a.C, o01 = o00 + a.C, o10 = o00 + (size_t)a.w * a.C, o11 = o10 + a.C;
-        const float* g = a.d_out + (size_t)pt * a.ld + a.col_off;
-        float gx = 0.0f, gy = 0.0f;
-        for (int ch = lane * 4; ch < a.C; ch += 256) {
-            lq_f4 d;
-            if ((a.ld & 3) == 0 && (a.col_off & 3) == 0) d = *reinterpret_cast<const lq_f4*>(g + ch);
-            else { d[0] = g[ch]; d[1] = g[ch + 1]; d[2] = g[ch + 2]; d[3] = g[ch + 3]; }
-            if (a.d_fmap) {
+    const long long n_runs = (total + kLqRun - 1) / kLqRun;
+    const int n_c4 = a.C / 4;                                   // float4 groups per row; this lane's channels: 64 j + lane, j < C / 64 (+ tail)
+    const int n_j = (a.C + 63) / 64;
+    for (long long run = (long long)blockIdx.x * 4 + wave; run < n_runs; run += (long long)gridDim.x * 4) {
+        const long long p0 = run * kLqRun, p1 = p0 + kLqRun < total ? p0 + kLqRun : total;
+        // the corner sums of the current pixel: [corner][j]
+        float acc[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[k][j] = 0.0f;
+        bool have = false;                                      // a pixel is being accumulated: (cb, cy, cx) = image, top-left corner (-1 .. h-1, -1 .. w-1)
+        int cb = 0, cy = 0, cx = 0;
+        bool cvx0 = false, cvx1 = false, cvy0 = false, cvy1 = false;
+        auto flush = [&]() {
+            if (!have || !a.d_fmap) return;
+            float* base = a.d_fmap + (((long long)cb * a.h + cy) * a.w + cx) * (long long)a.C;     // (only valid corners are dereferenced)
+            const size_t row = (size_t)a.w * a.C;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = 64 * j + lane;
+                if (j < n_j && ch < a.C) {
+                    if (cvy0 && cvx0) atomicAdd(base + ch, acc[0][j]);
+                    if (cvy0 && cvx1) atomicAdd(base + a.C + ch, acc[1][j]);
+                    if (cvy1 && cvx0) atomicAdd(base + row + ch, acc[2][j]);
+                    if (cvy1 && cvx1) atomicAdd(base + row + a.C + ch, acc[3][j]);
+                }
+                acc[0][j] = acc[1][j] = acc[2][j] = acc[3][j] = 0.0f;
+            }
+        };
+        for (long long pt = p0; pt < p1; ++pt) {
+            const int b = (int)(pt / a.N);
+            const float* c = a.calibs + (size_t)b * 12;
+            const float* p = a.pts + (size_t)pt * 3;
+            const float px = p[0], py = p[1], pz = p[2];
+            const float hx = c[3] + (c[0] * px + c[1] * py + c[2] * pz);
+            const float hy = c[7] + (c[4] * px + c[5] * py + c[6] * pz);
+            const float hz = c[11] + (c[8] * px + c[9] * py + c[10] * pz);
+            const float z = zsign * hz;
+            const float x = hx / z, y = -(hy / z);
+            const float fx = ((x + 1.0f) * (float)a.w - 1.0f) * 0.5f, fy = ((y + 1.0f) * (float)a.h - 1.0f) * 0.5f;
+            const float x0f = floorf(fx), y0f = floorf(fy);
+            const float tx = fx - x0f, ty = fy - y0f;
+            const bool finite = fx > -2.0f && fx < (float)a.w + 1.0f && fy > -2.0f && fy < (float)a.h + 1.0f;
+            const int x0 = finite ? (int)x0f : -5, y0 = finite ? (int)y0f : -5;
+            const float w00 = (1.0f - tx) * (1.0f - ty), w01 = tx * (1.0f - ty), w10 = (1.0f - tx) * ty, w11 = tx * ty;
+            const bool vx0 = x0 >= 0 && x0 < a.w, vx1 = x0 + 1 >= 0 && x0 + 1 < a.w;
+            const bool vy0 = y0 >= 0 && y0 < a.h, vy1 = y0 + 1 >= 0 && y0 + 1 < a.h;
+            const bool any = (vx0 || vx1) && (vy0 || vy1);
+            const float* g = a.d_out + (size_t)pt * a.ld + a.col_off;
+            if (a.d_fmap && any) {
+                if (!have || b != cb || y0 != cy || x0 != cx) {
+                    flush();
+                    have = true; cb = b; cy = y0; cx = x0; cvx0 = vx0; cvx1 = vx1; cvy0 = vy0; cvy1 = vy1;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (vy0 && vx0) atomicAdd(a.d_fmap + o00 + ch + j, w00 * d[j]);
-                    if (vy0 && vx1) atomicAdd(a.d_fmap + o01 + ch + j, w01 * d[j]);
-                    if (vy1 && vx0) atomicAdd(a.d_fmap + o10 + ch + j, w10 * d[j]);
-                    if (vy1 && vx1) atomicAdd(a.d_fmap + o11 + ch + j, w11 * d[j]);
+                    const int ch = 64 * j + lane;
+                    if (j < n_j && ch < a.C) {
+                        const float d = g[ch];
+                        acc[0][j] = fmaf(w00, d, acc[0][j]); acc[1][j] = fmaf(w01, d, acc[1][j]);
+                        acc[2][j] = fmaf(w10, d, acc[2][j]); acc[3][j] = fmaf(w11, d, acc[3][j]);
+                    }
                 }
             }
             if (a.d_pts) {
-                const lq_f4 zero = {0.f, 0.f, 0.f, 0.f};
-                const lq_f4 f00 = (vy0 && vx0) ? *reinterpret_cast<const lq_f4*>(a.fmap + o00 + ch) : zero;
-                const lq_f4 f01 = (vy0 && vx1) ? *reinterpret_cast<const lq_f4*>(a.fmap + o01 + ch) : zero;
-                const lq_f4 f10 = (vy1 && vx0) ? *reinterpret_cast<const lq_f4*>(a.fmap + o10 + ch) : zero;
-                const lq_f4 f11 = (vy1 && vx1) ? *reinterpret_cast<const lq_f4*>(a.fmap + o11 + ch) : zero;
+                const size_t moff = (size_t)b * a.h * a.w * a.C;
+                const size_t o00 = moff + ((size_t)y0 * a.w + x0) * a.C, o01 = o00 + a.C, o10 = o00 + (size_t)a.w * a.C, o11 = o10 + a.C;
+                float gx = 0.0f, gy = 0.0f;
+                for (int c4 = lane; c4 < n_c4; c4 += 64) {
+                    const int ch = 4 * c4;
+                    lq_f4 d;
+                    if ((a.ld & 3) == 0 && (a.col_off & 3) == 0) d = *reinterpret_cast<const lq_f4*>(g + ch);
+                    else { d[0] = g[ch]; d[1] = g[ch + 1]; d[2] = g[ch + 2]; d[3] = g[ch + 3]; }
+                    const lq_f4 zero = {0.f, 0.f, 0.f, 0.f};
+                    const lq_f4 f00 = (vy0 && vx0) ? *reinterpret_cast<const lq_f4*>(a.fmap + o00 + ch) : zero;
+                    const lq_f4 f01 = (vy0 && vx1) ? *reinterpret_cast<const lq_f4*>(a.fmap + o01 + ch) : zero;
+                    const lq_f4 f10 = (vy1 && vx0) ? *reinterpret_cast<const lq_f4*>(a.fmap + o10 + ch) : zero;
+                    const lq_f4 f11 = (vy1 && vx1) ? *reinterpret_cast<const lq_f4*>(a.fmap + o11 + ch) : zero;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    gx = fmaf(d[j], (1.0f - ty) * (f01[j] - f00[j]) + ty * (f11[j] - f10[j]), gx);
-                    gy = fmaf(d[j], (1.0f - tx) * (f10[j] - f00[j]) + tx * (f11[j] - f01[j]), gy);
+                    for (int j = 0; j < 4; ++j) {
+                        gx = fmaf(d[j], (1.0f - ty) * (f01[j] - f00[j]) + ty * (f11[j] - f10[j]), gx);
+                        gy = fmaf(d[j], (1.0f - tx) * (f10[j] - f00[j]) + tx * (f11[j] - f01[j]), gy);
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { gx += __shfl_xor(gx, off, kWave); gy += __shfl_xor(gy, off, kWave); }
+                if (lane == 0) {
+                    const float dx = gx * (0.5f * (float)a.w), dy = gy * (0.5f * (float)a.h);     // d fx / d x = w / 2
+                    // x = hx / z, y = -hy / z, z = zsign hz
+                    const float dhx = dx / z, dhy = -dy / z, dhz = zsign * (-(dx * x + dy * y) / z);
+                    float* q = a.d_pts + (size_t)pt * 3;
+                    q[0] = c[0] * dhx + c[4] * dhy + c[8] * dhz;
+                    q[1] = c[1] * dhx + c[5] * dhy + c[9] * dhz;
+                    q[2] = c[2] * dhx + c[6] * dhy + c[10] * dhz;
                 }
             }
         }
-        if (a.d_pts) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { gx += __shfl_xor(gx, off, kWave); gy += __shfl_xor(gy, off, kWave); }
-            if (lane == 0) {
-                const float dx = gx * (0.5f * (float)a.w), dy = gy * (0.5f * (float)a.h);     // d fx / d x = w / 2
-                // x = hx / z, y = -hy / z, z = zsign hz
-                const float dhx = dx / z, dhy = -dy / z, dhz = zsign * (-(dx * x + dy * y) / z);
-                float* q = a.d_pts + (size_t)pt * 3;
-                q[0] = c[0] * dhx + c[4] * dhy + c[8] * dhz;
-                q[1] = c[1] * dhx + c[5] * dhy + c[9] * dhz;
-                q[2] = c[2] * dhx + c[6] * dhy + c[10] * dhz;
-            }
-        }
+        flush();
     }
 }
 
@@ -230,7 +274,8 @@ extern "C" int e3dge_local_query_bwd(float* d_fmap_nhwc, float* d_pts, const flo
     LocalQueryBwdK k{};
     k.pts = pts; k.calibs = calibs; k.fmap = fmap_nhwc; k.d_out = d_out; k.d_fmap = d_fmap_nhwc; k.d_pts = d_pts; k.N = n_pts; k.B = batch;
     k.C = channels; k.h = fh; k.w = fw; k.ld = ld; k.col_off = col_off;
-    int64_t blocks = ((int64_t)batch * n_pts + 3) / 4;
+    E3DGE_REQUIRE(channels <= 256, "local_query_bwd: at most 256 channels (four per lane)");
+    int64_t blocks = (((int64_t)batch * n_pts + kLqRun - 1) / kLqRun + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
     local_query_bwd_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(k);
     return check_launch("local_query_bwd");
