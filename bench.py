@@ -119,7 +119,7 @@ def finalize(result):
                "train_step_allreduce_busbw_GBps": g("train_step", "allreduce_busbw_GBps"),
                "train_step_with_allreduce_ms": g("train_step", "step_with_allreduce_ms"),
                "c4_ms_per_pose": g("c4", "sequential", "ms_per_pose"), "train_step_ms": r.get("train_step_ms"),
-               "train_step_full_ms": r.get("train_step_full_ms"), "train_step_full_both_latents_ms": r.get("train_step_full_both_latents_ms"), "train_step_full_batch4_ms_per_sample": r.get("train_step_full_batch4_ms_per_sample"), "train_step_batch4_ms_per_sample": r.get("train_step_batch4_ms_per_sample"), "decoder_packed_fwd_bwd_ms": g("autograd", "decoder_packed_fwd_bwd_ms"),
+               "train_step_full_ms": r.get("train_step_full_ms"), "train_step_stage2_ms": r.get("train_step_stage2_ms"), "train_step_full_both_latents_ms": r.get("train_step_full_both_latents_ms"), "train_step_full_batch4_ms_per_sample": r.get("train_step_full_batch4_ms_per_sample"), "train_step_batch4_ms_per_sample": r.get("train_step_batch4_ms_per_sample"), "decoder_packed_fwd_bwd_ms": g("autograd", "decoder_packed_fwd_bwd_ms"),
                "decoder_library_fwd_bwd_ms": g("autograd", "decoder_library_fwd_bwd_ms"),
                "fuse_sft_hip_fwd_bwd_ms": g("autograd", "fuse_sft_hip_fwd_bwd_ms"), "tex_head_fwd_bwd_ms": g("autograd", "tex_head_fwd_bwd_ms"),
                "blur_hbm_frac_1024": g("stream_ops", "blur_f32", "hbm_frac"), "bias_act_hbm_frac_1024": g("stream_ops", "bias_act_f32", "hbm_frac"),
@@ -130,9 +130,13 @@ def finalize(result):
         summary["decoder_ms_sum_of_launches"] = round(dec, 4)
     # the prose of these objects is DESIGN.md section 5's; their notes and the stream_ops detail are dropped from the line (its four fractions are in
     # `summary`) so that the whole line stays within the tail the driver records
-    for key in ("autograd", "c3", "local_features", "c4", "surface", "inversion"):
+    for key in ("autograd", "c3", "local_features", "c4", "surface", "inversion", "train_step_stage2", "train_step_full"):
         if isinstance(r.get(key), dict):
             r[key].pop("note", None)
+            if isinstance(r[key].get("roofline"), dict):
+                r[key]["roofline"].pop("note", None)
+    if isinstance(g("autograd", "decoder_packed_fwd_bwd_roofline"), dict):
+        r["autograd"]["decoder_packed_fwd_bwd_roofline"].pop("note", None)
     r.pop("stream_ops", None)
     for key in ("train_step_full_note", "train_step_note", "inversion_fwd_note"):       # (DESIGN.md section 5 says what these legs are)
         r.pop(key, None)
@@ -734,6 +738,12 @@ def main():
                             f_ = fm_.clone().requires_grad_(True)
                             pool_(dec_(f_, [d1], input_is_latent=True, randomize_noise=False)[0]).square().mean().backward()
                         ag["decoder_" + be + "_fwd_bwd_ms"] = ev_fb(fb)
+                        if be == "packed":      # roofline of the decoder's forward + data-gradient backward (nine 3x3 layers each way, 125.6 GFLOP each)
+                            t_ = ag["decoder_packed_fwd_bwd_ms"]
+                            ag["decoder_packed_fwd_bwd_roofline"] = {
+                                "bound": "mfma", "achieved": 2 * 125.6e9 / (t_ * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / 3, "unit": "TFLOP/s",
+                                "frac": 2 * 125.6e9 / (PEAK_F16_MFMA_TFLOPS / 3 * 1e12) / (t_ * 1e-3), "flop": 2 * 125.6e9,
+                                "note": "e3dge_dec2_forward + e3dge_dec2_backward + the caller's pool_256 and loss; event time of forward + backward"}
                     finally:
                         os.environ.pop("E3DGE_DECODER_AUTOGRAD", None)
                 try:        # d latent wanted too (not the stage-1 shape): no native backward for it, the library path runs
