@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("E3DGE_LIB_PATH") or os.path.join(_HERE, "lib", "libe3dge_hip.so")   # override: kernel A/B variants
-ABI_VERSION = 13
+ABI_VERSION = 14
 PREC_F32, PREC_F16X3, PREC_F16X3_V1, PREC_F16X3_G2 = 0, 1, 2, 3
 AMAX_FLOATS = 64 * 32           # E3DGE_AMAX_FLOATS: one amax buffer (include/e3dge_hip.h)
 
@@ -113,7 +113,8 @@ class WsLinear(ctypes.Structure):
 class Wgrad(ctypes.Structure):
     """Mirror of struct E3dgeWgrad (include/e3dge_hip.h)."""
     _fields_ = [(n, _vp) for n in ("a", "amax_a", "b", "amax_b", "c", "ws")] + [("ws_floats", _i64), ("n_rows", _i64)] + [
-        (n, _i32) for n in ("lda", "off_a", "m", "ldb", "off_b", "n", "ldc", "relu_b")]
+        (n, _i32) for n in ("lda", "off_a", "m", "ldb", "off_b", "n", "ldc", "relu_b")] + [(n, _vp) for n in ("xcol", "colsum", "ccol")] + [
+        (n, _i32) for n in ("ld_xcol", "ld_ccol", "b_gap_at", "b_gap")]
 
 
 # include/e3dge_hip_experimental.h: -DE3DGE_EXPERIMENTAL builds (tools/build_variant.sh) carry two more precision modes; no extra symbols

@@ -276,7 +276,7 @@ modconv_weights_kernel(float* __restrict__ out, const float* __restrict__ weight
 
 using namespace e3dge;
 
-extern "C" int e3dge_abi_version(void) { return 13; }
+extern "C" int e3dge_abi_version(void) { return 14; }
 extern "C" const char* e3dge_last_error(void) { return err_buf(); }
 extern "C" int e3dge_build_flags(void) {
 #ifdef E3DGE_EXPERIMENTAL

@@ -418,24 +418,29 @@ class _FuseFn(torch.autograd.Function):
                 am = {id(x): af[0], id(net): af[1], id(e): af[2], id(s1): af[3], id(t1): af[4],
                       id(dz1): am_b[1], id(dz2): am_b[2], id(de): am_b[3], id(dnet): am_b[4], id(d_shift): am_b[0] * abs(w)}
 
-                def wg(a_, b_, relu=False):
-                    for t_ in (a_, b_):
-                        if id(t_) not in am:
-                            am[id(t_)] = amax_of(t_)
-                    return wgrad(a_, b_, relu_b=relu, amax_a=am[id(a_)], amax_b=am[id(b_)])
-                if need[7]: gp[7] = wg(d_scale, s1)
-                if need[8]: gp[8] = d_scale.sum(0)
-                if need[11]: gp[11] = wg(d_shift, t1)
-                if need[12]: gp[12] = d_shift.sum(0)
-                if need[5]: gp[5] = wg(dz1, e)
-                if need[6]: gp[6] = dz1.sum(0)
-                if need[9]: gp[9] = wg(dz2, e)
-                if need[10]: gp[10] = dz2.sum(0)
-                if need[2]: gp[2] = wg(de, net, True)
-                if need[3]: gp[3] = de.sum(0)
-                if need[4]: gp[4] = wg(de, x)
-                if need[0]: gp[0] = wg(dnet, x, True)
-                if need[1]: gp[1] = dnet.sum(0)
+                gap = 256 if (b_off == 257 and x.shape[1] == 513) else None      # the visibility-mask column of the 513-wide input
+
+                def wg(iw, ib, a_, b_, relu=False, gap_col=None):
+                    """weight gradient iw and bias gradient ib (None: the layer has none) of one layer: ONE pass over the rows when both are wanted"""
+                    want_b = ib is not None and need[ib]
+                    if need[iw]:
+                        for t_ in (a_, b_):
+                            if id(t_) not in am:
+                                am[id(t_)] = amax_of(t_)
+                        r = wgrad(a_, b_, relu_b=relu, amax_a=am[id(a_)], amax_b=am[id(b_)], colsum=want_b, gap_col=gap_col)
+                        if want_b:
+                            gp[iw], gp[ib] = r
+                        else:
+                            gp[iw] = r
+                    elif want_b:
+                        gp[ib] = a_.sum(0)
+                wg(7, 8, d_scale, s1)
+                wg(11, 12, d_shift, t1)
+                wg(5, 6, dz1, e)
+                wg(9, 10, dz2, e)
+                wg(2, 3, de, net, True)
+                wg(4, None, de, x, gap_col=gap)
+                wg(0, 1, dnet, x, True, gap_col=gap)
             return (None, dx.reshape(ctx.in_shape) if dx is not None else None, None, *gp)
         d_scale, d_shift = (w * g) * dec, w * g                   # out = dec + w (dec scale + shift)
         # scale = W2 lrelu(W1 e + b1) + b2 ; shift likewise

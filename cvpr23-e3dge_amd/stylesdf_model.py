@@ -147,10 +147,11 @@ def decoder_autograd_backend():
     requires grad takes the library path (weight modulation + MIOpen) for both directions.
     'packed': always the packed forward; the backward is native when eligible, otherwise it recomputes the library path under
     enable_grad and differentiates that (for passes that run with grad enabled but never call backward).
-    'library': the library path for both directions (round 4's default; A/B).  The packed node is first-order only: a second
-    differentiation through the decoder (create_graph=True; not something the reference's encoder training does) raises from
-    `once_differentiable` -- run such a step with E3DGE_DECODER_AUTOGRAD=library, whose custom ops are twice differentiable as the
-    reference's are."""
+    'library': the library path for both directions (round 4's default; A/B).  The packed node's native backward is first-order only: a
+    backward taken with create_graph=True (a second differentiation through the decoder; not something the reference's encoder training
+    does) is re-routed by the node itself to the library path, whose custom ops are twice differentiable as the reference's are
+    (round 6; it raised before).  Parameter writes through `.data` between a forward and its backward bump no version counter and are
+    not seen by either path: call `invalidate()` and run the forward again."""
     v = os.environ.get("E3DGE_DECODER_AUTOGRAD", "auto")
     if v not in ("auto", "packed", "library"):
         raise RuntimeError(f"E3DGE_DECODER_AUTOGRAD must be 'auto', 'packed' or 'library', got {v!r}")
@@ -162,7 +163,8 @@ class _PackedDecoderFn(torch.autograd.Function):
     741-797).  backward, when only d features / d latent are wanted (generator frozen): e3dge_dec2_backward on the activations the forward
     left in its workspace -- if another forward has used the workspace since, the packed forward is re-run first (0.65 ms at 1024^2).
     Otherwise (parameter gradients, or d latent with E3DGE_DEC2_DLATENT=0): the same forward is re-run on the library path (every op differentiable) with the
-    saved inputs and the SAME noise, and `torch.autograd.grad` of that graph gives the gradients.  First-order only."""
+    saved inputs and the SAME noise, and `torch.autograd.grad` of that graph gives the gradients.  A backward under create_graph=True takes
+    that library route too, with the graph kept (round 6)."""
 
     @staticmethod
     def forward(ctx, dec, noise, features, latent, *params):
@@ -177,11 +179,22 @@ class _PackedDecoderFn(torch.autograd.Function):
         return img
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, d_img):
         features, latent = ctx.saved_tensors
         dec = ctx.dec
         need = ctx.needs_input_grad
+        if torch.is_grad_enabled():
+            # create_graph=True: this backward is itself being recorded (a path-length / R1-type penalty through the frozen decoder).  The
+            # native chain is first-order only, so the pass is re-routed to the library path, whose custom ops are twice differentiable
+            # as the reference's are (op/fused_act.py:19-84, op/upfirdn2d.py:18-142): the forward is recomputed from the ORIGINAL inputs
+            # (their graph stays attached) and differentiated with create_graph=True.
+            params = [p for p in dec.parameters()]
+            img = dec._forward_layers(features, latent, ctx.noise, None)
+            wrt_all = [features, latent] + params
+            want = [bool(n) and t.requires_grad for n, t in zip(need[2:], wrt_all)]
+            wrt = [t for t, w_ in zip(wrt_all, want) if w_]
+            grads = list(torch.autograd.grad(img, wrt, d_img, create_graph=True, allow_unused=True)) if wrt else []
+            return (None, None) + tuple(grads.pop(0) if w_ else None for w_ in want)
         if ctx.native:
             d_feat = d_lat = None
             if need[2] or need[3]:

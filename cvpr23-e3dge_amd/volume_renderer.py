@@ -81,26 +81,49 @@ class _ReuseKey:
         return all((t._version == s[1]) for t, s in zip(rec_key.tensors, rec_key.sig) if torch.is_tensor(t))
 
 
-# renderer -> {(kind, stream, bytes, device): [buffer, pinned]}: the raw storage of the layer-7 records ('bb': written by a first pass,
-# 'film': the FiLM-ed copy e3dge_tex_film_fwd writes).  One buffer per STREAM and size -- two streams rendering with one renderer do not
-# share storage -- and a buffer that a HIP-graph capture has seen is PINNED: the graph holds its raw pointer, so it is never replaced or
-# dropped (an eager render of another batch size, or invalidate(), used to free the one buffer per renderer while a captured graph still
-# wrote ~100 MB into it on every replay; round-4 advisor finding).  Unpinned buffers of another size on the same stream are released.
+# renderer -> {(kind, stream, bytes, device): [buffer, pinned, last use]}: the raw storage of the layer-7 records ('bb': written by a first
+# pass, 'film': the FiLM-ed copy e3dge_tex_film_fwd writes).  One buffer per STREAM and size -- two streams rendering with one renderer do
+# not share storage -- and a buffer that a HIP-graph capture has seen is PINNED: the graph holds its raw pointer, so it is never replaced
+# or dropped by a render or by invalidate() (round-4 advisor finding); `release_record_buffers(renderer)` drops the pinned ones once the
+# graphs that captured them are gone.  Unpinned buffers: the two most recently used sizes per (kind, stream) stay (alternating batch sizes
+# do not re-allocate and re-zero ~100 MB per switch), older ones are released.  A zero-filled buffer ('film': zeroed ONCE, the launches
+# only ever write the rows they own) must exist BEFORE a capture: the fill would be captured and re-run on every replay, and the storage
+# would live in the graph's private pool while eager renders use it too -- a first-seen key mid-capture raises (graphs.GraphedCall warms
+# up on its capture stream, which creates it).
 _RECORD_BUFS = weakref.WeakKeyDictionary()
+_RECORD_KEEP = 2
+_record_clock = [0]
 
 
 def _record_buffer(renderer, kind, n_bytes, dev, stream, capturing, zero):
     pool = _RECORD_BUFS.setdefault(renderer, {})
     key = (kind, stream, int(n_bytes), str(dev))
     ent = pool.get(key)
+    _record_clock[0] += 1
     if ent is None:
-        for k in [k for k, e in pool.items() if k[0] == kind and k[1] == stream and not e[1]]:
+        if capturing and zero:
+            raise RuntimeError(f"renderer record buffer '{kind}' ({int(n_bytes)} bytes) would be allocated and zero-filled inside a HIP-graph "
+                               "capture: run the same call once eagerly on the capture stream first (graphs.GraphedCall does)")
+        loose = sorted((k for k, e in pool.items() if k[0] == kind and k[1] == stream and not e[1]), key=lambda k: pool[k][2])
+        for k in loose[:max(0, len(loose) - (_RECORD_KEEP - 1))]:
             pool.pop(k)
         buf = (torch.zeros if zero else torch.empty)(int(n_bytes), device=dev, dtype=torch.uint8)
-        ent = pool[key] = [buf, False]
+        ent = pool[key] = [buf, False, 0]
+    ent[2] = _record_clock[0]
     if capturing:
         ent[1] = True
     return ent[0]
+
+
+def release_record_buffers(renderer, pinned_only=False):
+    """Drop the renderer's record buffers, INCLUDING the ones a HIP-graph capture pinned: call it after the graphs that captured this
+    renderer's second pass have been destroyed (their replays write through the raw pointers)."""
+    pool = _RECORD_BUFS.get(renderer)
+    if pool:
+        for k in [k for k, e in pool.items() if e[1] or not pinned_only]:
+            pool.pop(k)
+
+
 _WMAX_STATE = weakref.WeakKeyDictionary()                              # ResnetBlockFC -> pinned host scalar + event of the deferred weight-range check
 _BACKBONE = weakref.WeakKeyDictionary()                                # renderer -> {key, buf (record), out (first pass's tensors)}
 _SIDE_STREAMS = {}                                                     # per device (module level: modules stay deep-copyable)
@@ -776,21 +799,28 @@ class _TexHead(torch.autograd.Function):
         dnet = dnet_p[:, :cin]
         am_x = amax_of(x) if (need[2] or need[6]) else None
         am_a, am_b = (amax_of(d_alpha), amax_of(d_beta)) if (need[4] or need[6]) else (None, None)
+        # (round 6: the bias gradients -- column sums of d net / d out -- come from the weight gradient's pass over the same rows)
         if need[2]:
-            dw0 = wgrad(dnet, x, relu_b=True, amax_a=amax_of(dnet_p), amax_b=am_x)     # d net^T relu(x)
-        if need[3]:
+            r = wgrad(dnet, x, relu_b=True, amax_a=amax_of(dnet_p), amax_b=am_x, colsum=need[3])     # d net^T relu(x)
+            dw0, db0 = r if need[3] else (r, None)
+        elif need[3]:
             db0 = dnet_p.sum(0)[:cin]                                             # (the contiguous rows: a strided view reduces 25x slower)
+        db1a = db1b = None
         if need[4]:                                                               # d out^T relu(net), net as the backward kernel recomputed it
             dw1 = torch.empty((512, cin), device=x.device, dtype=torch.float32)
             am_n, net = amax_of(net_p), net_p[:, :cin]
-            wgrad(d_alpha, net, relu_b=True, amax_a=am_a, amax_b=am_n, out=dw1[:256])
-            wgrad(d_beta, net, relu_b=True, amax_a=am_b, amax_b=am_n, out=dw1[256:])
-        if need[5]:
-            db1 = torch.cat([d_alpha.sum(0), d_beta.sum(0)], 0)
+            ra = wgrad(d_alpha, net, relu_b=True, amax_a=am_a, amax_b=am_n, out=dw1[:256], colsum=need[5])
+            rb = wgrad(d_beta, net, relu_b=True, amax_a=am_b, amax_b=am_n, out=dw1[256:], colsum=need[5])
+            if need[5]:
+                db1a, db1b = ra[1], rb[1]
         if need[6]:
             dws = torch.empty((512, cin), device=x.device, dtype=torch.float32)
-            wgrad(d_alpha, x, amax_a=am_a, amax_b=am_x, out=dws[:256])
-            wgrad(d_beta, x, amax_a=am_b, amax_b=am_x, out=dws[256:])
+            ra = wgrad(d_alpha, x, amax_a=am_a, amax_b=am_x, out=dws[:256], colsum=need[5] and db1a is None)
+            rb = wgrad(d_beta, x, amax_a=am_b, amax_b=am_x, out=dws[256:], colsum=need[5] and db1a is None)
+            if need[5] and db1a is None:
+                db1a, db1b = ra[1], rb[1]
+        if need[5]:
+            db1 = torch.cat([db1a, db1b], 0) if db1a is not None else torch.cat([d_alpha.sum(0), d_beta.sum(0)], 0)
         return (dx if need[0] else None, None, dw0, db0, dw1, db1, dws)
 
 

@@ -681,12 +681,21 @@ int e3dge_ws_rowdot2(float* out, int ld_out, int off_out, const float* a, const 
  * f = relu when relu_b != 0 -- autograd's `grad_output.t() @ input` for the nn.Linear layers of ResnetBlockFC (helper_modules/resnetfc.py:49-58)
  * and Fuse_sft_MLP (helper_modules/sft.py:84-110) in the stage-2 step (e3dge_full_runner.py:185-317), with the relu of the layer's input folded in.
  * a, b: fp32 rows of lda / ldb floats (4-byte aligned; any row pitch), amax_a / amax_b: amax buffers (e3dge_amax) bounding |a| / |b|;
- * ws: e3dge_wgrad_ws_floats(m, n, n_rows) floats (split-K partial blocks, folded in fixed order: bit-reproducible).  Split-f16 x 3, fp32 accumulate. */
+ * ws: e3dge_wgrad_ws_floats(m, n, n_rows) floats (split-K partial blocks, folded in fixed order: bit-reproducible).  Split-f16 x 3, fp32 accumulate.
+ * ABI 14 (round 6) -- what rides with the same pass over the rows (all optional, NULL / 0 = off):
+ *   colsum (m):          sum_p a[p, off_a + i]                       autograd's `grad_output.sum(0)`, the layer's bias gradient
+ *   xcol, ccol:          ccol[i * ld_ccol] = sum_p a[p, off_a + i] f(xcol[p * ld_xcol])   one more column of b that the block grid leaves out
+ *   b_gap_at, b_gap:     columns [b_gap_at, b_gap_at + b_gap) of b's rows (and of c's) are skipped: c[:, j] for j >= b_gap_at comes from
+ *                        b[:, off_b + j + b_gap] and lands in c[:, j + b_gap]; n counts the columns that ARE contracted.  b_gap_at: a
+ *                        multiple of 256.  (Fuse_sft_MLP's 513-wide input: 256 features | visibility mask | 256 features -- n = 512,
+ *                        b_gap_at = 256, b_gap = 1, xcol = b + off_b + 256, ccol = c + 256.) */
 typedef struct E3dgeWgrad {
     const float* a; const float* amax_a; const float* b; const float* amax_b;
     float* c; float* ws;
     int64_t ws_floats, n_rows;
     int32_t lda, off_a, m, ldb, off_b, n, ldc, relu_b;
+    const float* xcol; float* colsum; float* ccol;
+    int32_t ld_xcol, ld_ccol, b_gap_at, b_gap;
 } E3dgeWgrad;
 int64_t e3dge_wgrad_ws_floats(int m, int n, int64_t n_rows);
 int e3dge_wgrad(const E3dgeWgrad* args, e3dge_stream_t stream);

@@ -216,8 +216,9 @@ def test_wgrad_and_texhead_bwd_layout_and_argument_checks():
 #include <stddef.h>
 #include "e3dge_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(E3dgeWgrad), offsetof(E3dgeWgrad, c), offsetof(E3dgeWgrad, ws_floats), offsetof(E3dgeWgrad, n_rows),
-         offsetof(E3dgeWgrad, lda), offsetof(E3dgeWgrad, ldc), offsetof(E3dgeWgrad, relu_b));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(E3dgeWgrad), offsetof(E3dgeWgrad, c), offsetof(E3dgeWgrad, ws_floats), offsetof(E3dgeWgrad, n_rows),
+         offsetof(E3dgeWgrad, lda), offsetof(E3dgeWgrad, ldc), offsetof(E3dgeWgrad, relu_b), offsetof(E3dgeWgrad, xcol), offsetof(E3dgeWgrad, ccol),
+         offsetof(E3dgeWgrad, ld_xcol), offsetof(E3dgeWgrad, b_gap));
   return 0; }'''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
@@ -226,16 +227,22 @@ int main(void) {
         subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), c, "-o", exe], check=True)
         got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
     G = _lib.Wgrad
-    assert got == [ctypes.sizeof(G), G.c.offset, G.ws_floats.offset, G.n_rows.offset, G.lda.offset, G.ldc.offset, G.relu_b.offset]
+    assert got == [ctypes.sizeof(G), G.c.offset, G.ws_floats.offset, G.n_rows.offset, G.lda.offset, G.ldc.offset, G.relu_b.offset, G.xcol.offset, G.ccol.offset,
+                   G.ld_xcol.offset, G.b_gap.offset]
     lib = _lib.load()
-    # 98,304 points, 512 x 301 outputs: 4 x 3 blocks, 512 // 12 = 42 slabs of 2,368 points (a multiple of 32)
-    assert lib.e3dge_wgrad_ws_floats(512, 301, 98304) == 42 * 12 * 128 * 128
-    assert lib.e3dge_wgrad_ws_floats(5, 3, 1) == 128 * 128 and lib.e3dge_wgrad_ws_floats(0, 3, 10) == 0
+    # round 6: blocks of 256 x 256.  98,304 points, 512 x 301 outputs: 2 x 2 blocks, 256 // 4 = 64 slabs; behind the partial blocks the column
+    # partials (2 x 256 per slab and block row).  256 x 256: one block, 256 slabs.
+    assert lib.e3dge_wgrad_ws_floats(512, 301, 98304) == 64 * 2 * (2 * 256 * 256 + 2 * 256)
+    assert lib.e3dge_wgrad_ws_floats(256, 256, 98304) == 256 * (256 * 256 + 2 * 256)
+    assert lib.e3dge_wgrad_ws_floats(5, 3, 1) == 256 * 256 + 2 * 256 and lib.e3dge_wgrad_ws_floats(0, 3, 10) == 0
     assert lib.e3dge_wgrad(None, None) == -1
     one = ctypes.c_void_p(16)
     assert lib.e3dge_wgrad(ctypes.byref(G(a=one, amax_a=one, b=one, amax_b=one, c=one, ws=one, n_rows=4, lda=3, m=4, ldb=4, n=4, ldc=4, ws_floats=1 << 20)), None) == -1   # m > lda
     assert lib.e3dge_wgrad(ctypes.byref(G(a=one, amax_a=one, b=one, amax_b=one, c=one, ws=one, n_rows=4, lda=4, m=4, ldb=4, n=4, ldc=4, ws_floats=16)), None) == -1        # workspace
     assert lib.e3dge_wgrad(ctypes.byref(G(c=one, n_rows=4, m=0, n=4, ldc=4)), None) == 0                                                                                # nothing to do
+    ok = dict(a=one, amax_a=one, b=one, amax_b=one, c=one, ws=one, n_rows=4, lda=4, m=4, ldb=600, n=512, ldc=600, ws_floats=1 << 30)
+    assert lib.e3dge_wgrad(ctypes.byref(G(b_gap=1, b_gap_at=100, **ok)), None) == -1                    # the gap starts at a multiple of 256
+    assert lib.e3dge_wgrad(ctypes.byref(G(xcol=one, ld_xcol=1, **ok)), None) == -1                      # xcol without ccol
     assert lib.e3dge_tex_modulations_bwd_ws_floats(1000) == 2 * 1000 * 320 and lib.e3dge_tex_modulations_bwd_ws_floats(0) == 0
     assert lib.e3dge_resblock_bwd_packed_floats() == 120 * 5120 + 320
     assert lib.e3dge_tex_modulations_bwd(None, None, 301, 5, None, None, None, None, None, None) == -1

@@ -264,6 +264,36 @@ def test_ineligible_graphs_take_the_library_path(gen256, monkeypatch):
         dec.conv1.activate.bias.requires_grad_(False)
 
 
+def test_double_backward_through_the_packed_node_reroutes_to_the_library_path(gen256, monkeypatch):
+    """Round-5 advisor finding: with the generator frozen the decoder node's native backward is first-order, and a create_graph=True pass
+    (an R1 / path-length type penalty on d image / d features) used to raise.  The node now notices that its backward is being recorded and
+    differentiates the library path instead: the penalty's gradient must equal the one E3DGE_DECODER_AUTOGRAD=library gives."""
+    g, _ = gen256
+    dec = g.decoder
+    feats, noises, gy = syn.decoder_grad_inputs(1, 256, 64, seed=11, device=DEV)
+    _, wd = syn.synthetic_inputs(1, seed=4, device=DEV)
+    wl0 = wd[:, :dec.n_latent].contiguous()
+
+    def penalty_grad():
+        f = feats.clone().requires_grad_(True)
+        wl = wl0.clone().requires_grad_(True)
+        img, _ = dec(f, [wl], input_is_latent=True, noise=noises)
+        name = type(img.grad_fn).__name__
+        (df,) = torch.autograd.grad((img * gy).sum(), [f], create_graph=True)
+        assert df.requires_grad
+        # (the decoder is piecewise LINEAR in the features; the second derivative that exists is the mixed one, through the modulated weights)
+        (d2,) = torch.autograd.grad(df.pow(2).sum(), [wl])
+        return name, df.detach(), d2
+    name_p, df_p, d2_p = penalty_grad()
+    assert "PackedDecoderFn" in name_p
+    monkeypatch.setenv("E3DGE_DECODER_AUTOGRAD", "library")
+    name_l, df_l, d2_l = penalty_grad()
+    assert "PackedDecoderFn" not in name_l
+    e = dict(d_features_l2=rel_l2(df_p, df_l), second_order_l2=rel_l2(d2_p, d2_l))
+    record("dec2_double_backward_reroute", **e)
+    assert float(d2_p.abs().max()) > 0 and e["d_features_l2"] <= 1e-5 and e["second_order_l2"] <= 1e-4, e
+
+
 def test_library_path_d_features_and_d_latent_against_the_references_autograd_256(gen256):
     """The path every forward with a trainable decoder parameter (or E3DGE_DECODER_AUTOGRAD=library) takes -- weight modulation + MIOpen +
     the two custom ops' backward classes -- against the reference's recording at the size where all four fused custom-op shapes occur, batch 2,

@@ -134,6 +134,16 @@ def test_record_buffers_a_capture_has_seen_survive_eager_renders_of_other_sizes(
         assert all(float(c.min()) == float(c.max()) == float(i) for i, c in enumerate(canary))
         now = {k: e[0].data_ptr() for k, e in vr._RECORD_BUFS[r].items() if e[1]}
         assert all(now.get(k) == v for k, v in pinned.items())
+        # round 6: pinned storage is released on request once its graphs are gone; a zero-filled record buffer first seen INSIDE a
+        # capture raises instead of capturing its 100-MB fill (round-5 advisor finding)
+        del gc
+        vr.release_record_buffers(r)
+        assert not vr._RECORD_BUFS[r]
+        with pytest.raises(RuntimeError, match="inside a HIP-graph capture"):
+            vr._record_buffer(r, 'film', 1 << 20, torch.device(DEV), 12345, True, zero=True)
+        assert not vr._RECORD_BUFS[r]
+        torch.cuda.synchronize()
+        assert torch.equal(both(w1), e1)
 
 
 def test_replays_of_a_captured_decoder_forward_stay_bit_identical():

@@ -234,6 +234,36 @@ def test_wgrad_against_float64(P, m, n, relu, monkeypatch):
     out = torch.full((m, n + 5), 7.0, device=DEV)
     wgrad(a, b, relu_b=relu, out=out[:, 2:n + 2])
     assert torch.equal(out[:, 2:n + 2], c) and float(out[:, :2].min()) == 7.0 and float(out[:, n + 2:].min()) == 7.0
+    # round 6: the bias gradient (column sums of a) from the same launch; the matrix itself must not change by a bit
+    c3, cs = wgrad(a, b, relu_b=relu, colsum=True)
+    e_cs = float((cs.double() - a.double().sum(0)).abs().max() / a.double().sum(0).abs().max().clamp_min(1e-300))
+    e_cs_lib = float((a.sum(0).double() - a.double().sum(0)).abs().max() / a.double().sum(0).abs().max().clamp_min(1e-300))
+    record("wgrad_colsum_vs_f64", P=P, m=m, hip=e_cs, library=e_cs_lib)
+    assert torch.equal(c3, c) and cs.shape == (m,) and e_cs <= 2e-6 + 2 * e_cs_lib, (e_cs, e_cs_lib)
+
+
+@pytest.mark.parametrize("P,m,relu", [(700, 256, True), (5000, 256, False), (98304, 256, True), (333, 40, False)])
+def test_wgrad_with_the_mask_column_left_out_of_the_block_grid(P, m, relu):
+    """Round 6: Fuse_sft_MLP's 513-wide input (256 features | visibility mask | 256 features): `gap_col=256` contracts 512 columns on the
+    matrix pipe and the mask column as a weighted column sum in the same launch.  Against float64, and the 512 regular columns against
+    two plain calls on the two halves (other slab counts: equal to rounding)."""
+    from e3dge_amd.wgrad import wgrad
+    rs = np.random.RandomState(P)
+    a = torch.from_numpy(rs.standard_normal((P, m)).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rs.standard_normal((P, 513)).astype(np.float32)).to(DEV)
+    b[:, 256] = (b[:, 256] > 0).float()
+    c, cs = wgrad(a, b, relu_b=relu, colsum=True, gap_col=256)
+    ref = a.double().t() @ (torch.relu(b.double()) if relu else b.double())
+    lib = a.t() @ (torch.relu(b) if relu else b)
+    scale = float(ref.abs().max())
+    e_hip, e_lib = float((c.double() - ref).abs().max()) / scale, float((lib.double() - ref).abs().max()) / scale
+    e_col = float((c[:, 256].double() - ref[:, 256]).abs().max()) / float(ref[:, 256].abs().max())
+    record("wgrad_gap_col_vs_f64", P=P, m=m, hip=e_hip, library=e_lib, mask_column=e_col)
+    assert e_hip <= 2e-6 + 2 * e_lib and e_col <= 2e-6 + 2 * e_lib, (e_hip, e_col, e_lib)
+    halves = torch.cat([wgrad(a, b[:, :256], relu_b=relu), wgrad(a, b[:, 257:], relu_b=relu)], 1)
+    both = torch.cat([c[:, :256], c[:, 257:]], 1)
+    assert float((both - halves).abs().max()) <= 2e-6 * scale
+    assert float((cs.double() - a.double().sum(0)).abs().max()) <= 1e-5 * float(a.double().sum(0).abs().max())
 
 
 def test_texhead_parameter_gradients_native_vs_library(monkeypatch):
