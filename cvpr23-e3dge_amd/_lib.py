@@ -38,7 +38,7 @@ class RenderBwdArgs(ctypes.Structure):
                                    "d_weights", "tex_alpha")] + [
         ("sigmoid_beta", _f32), ("batch", _i32), ("height", _i32), ("width", _i32), ("n_samples", _i32),
         ("force_background", _i32), ("precision", _i32)] + [(n, _vp) for n in ("d_rgb_pts", "d_sdf_pts", "partials", "dfilm", "dstyles",
-                                                                                "d_tex_alpha", "d_tex_beta")]
+                                                                                "d_tex_alpha", "d_tex_beta")] + [("phase", _i32)]
 
 
 class SirenBwdArgs(ctypes.Structure):

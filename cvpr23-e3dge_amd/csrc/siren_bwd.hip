@@ -1249,9 +1249,13 @@ extern "C" int e3dge_siren_render_bwd(const E3dgeRenderBwdArgs* r, e3dge_stream_
     }
     int64_t grid = (c.n_rays + 3) / 4;
     if (grid > 256 * 16) grid = 256 * 16;
-    composite_bwd_kernel<<<dim3((unsigned)grid), dim3(kThreads), lds, st>>>(c);
-    int rc = check_launch("siren_render_bwd(composite)");
-    if (rc) return rc;
+    E3DGE_REQUIRE(r->phase >= 0 && r->phase <= 2, "siren_render_bwd: phase=%d (0 = both launches, 1 = compositing only, 2 = network only)", r->phase);
+    if (r->phase != 2) {
+        composite_bwd_kernel<<<dim3((unsigned)grid), dim3(kThreads), lds, st>>>(c);
+        int rc = check_launch("siren_render_bwd(composite)");
+        if (rc) return rc;
+    }
+    if (r->phase == 1) return E3DGE_OK;
     SirenBwdK k{};
     k.packed = r->packed; k.film = r->film; k.args = r->args; k.d_feat = nullptr; k.d_rgb = r->d_rgb_pts; k.d_sdf = r->d_sdf_pts;
     k.d_featmap = r->d_feat_map; k.weights = r->weights; k.samples = r->n_samples;

@@ -481,17 +481,18 @@ def sdf_gradient(siren, film, args, box_scale):
     return eik, rsave
 
 
-def tangent_arguments(siren, film, args, v, box_scale, images=None, rsave=None):
+def tangent_arguments(siren, film, args, v, box_scale, images=None, rsave=None, out=None):
     """Tangent arguments (B,N,8,256) along v = dL/de (B,N,3) (e3dge_siren_tangent).  `images`: siren.device_image() as the forward
     of the same autograd node saw it (a backward differentiates the weights its saved arguments were computed with, and skipping the
     cache-key check keeps ~20 us of host time out of the gap in front of the launch).
     Returns (tang, rs) as e3dge_siren_bwd / e3dge_siren_render_bwd take them: in the 8-wave backward mode (`f16x3_g2`) with `rsave`
     given, `tang` holds the PRODUCTS ta_l r_l (e3dge_siren_tangent_tr: the only form in which the two ever enter the second-order
-    backward) and rs is None; otherwise (ta_l, rsave)."""
+    backward) and rs is None; otherwise (ta_l, rsave).  `out`: a saved_state_buffer(B, N, 8, ...) to write into (a caller that launches on a side
+    stream allocates it on ITS stream: GB-sized blocks that change streams are what the caching allocator handles worst)."""
     packed = (images if images is not None else siren.device_image())[0]
     B, N = args.shape[0], args.shape[1]
     v = v.reshape(B, N, 3).contiguous().float()
-    tang = saved_state_buffer(B, N, 8, args.device, siren.W)
+    tang = out if out is not None else saved_state_buffer(B, N, 8, args.device, siren.W)
     prec = siren.check_mode(siren.bwd_mode)
     with _lib.on_device(args.device):
         if prec == _lib.PREC_F16X3_G2 and rsave is not None:
@@ -608,16 +609,26 @@ class _EikTap(torch.autograd.Function):
         sh = ctx.shared
         if d_eik is not None and sh.args is not None:
             sh.d_eik = d_eik
-            if sh.side is not None:
+            side = sh.side
+            if side is None and _SIDE_STREAM and d_eik.is_cuda and os.environ.get("E3DGE_OVERLAP_COMPOSITE", "0") == "1":
+                # round 6, measured and left OFF: with the tangent pass on a side stream, what _RenderQuery.backward launches before it needs
+                # the tangent (the row copies of the incoming gradients, the backward of the compositing: e3dge_siren_render_bwd phase 1) runs
+                # beside it -- 1.81 / 1.87 / 1.88 ms per step against 1.80 / 1.85 / 1.84 without on one box: the 60 us it hides come back as
+                # a slower tangent pass and the extra stream hand-over
+                side = _side_stream(d_eik.device, 1)
+            if side is not None:
                 # deferred mode: this node was created AFTER the decoder's, so its backward runs BEFORE the decoder's; the tangent goes to the
                 # side stream and the decoder's backward launches that follow on this stream run beside it
                 cur = torch.cuda.current_stream(d_eik.device)
-                sh.side.wait_stream(cur)
-                with torch.cuda.stream(sh.side):
-                    sh.tang, sh.rs = tangent_arguments(sh.siren, sh.film, sh.args, d_eik, sh.box_scale, sh.images, sh.rsave)
-                d_eik.record_stream(sh.side)
-                sh.tang.record_stream(cur)
-                sh.tang_stream = sh.side
+                # (the output is allocated HERE, on the stream that consumes and frees it: allocated on the side stream and handed over with
+                # record_stream, its 0.6 GB per sample came back too late for the next step and every step paid a fresh hipMalloc --
+                # 2.0 instead of 1.57 ms per sample at four samples per GPU)
+                buf = saved_state_buffer(sh.args.shape[0], sh.args.shape[1], 8, sh.args.device, sh.siren.W)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    sh.tang, sh.rs = tangent_arguments(sh.siren, sh.film, sh.args, d_eik, sh.box_scale, sh.images, sh.rsave, out=buf)
+                d_eik.record_stream(side)
+                sh.tang_stream = side
             else:
                 sh.tang, sh.rs = tangent_arguments(sh.siren, sh.film, sh.args, d_eik, sh.box_scale, sh.images, sh.rsave)
         return d_eik, None
@@ -712,13 +723,13 @@ class _RenderQuery(torch.autograd.Function):
         dfilm = torch.empty((B, 9, 2, siren.W), device=dev, dtype=torch.float32)
         dstyles = torch.empty((B, 9, siren.W), device=dev, dtype=torch.float32)
         tang = rs = None
+        wait_for = None
         if ctx.want_eik and d_eik is not None:
             sh = ctx.shared
             if (sh is not None and sh.tang is not None and sh.d_eik.data_ptr() == d_eik.data_ptr()
                     and sh.d_eik.shape == d_eik.shape):                     # launched early by _EikTap.backward
                 tang, rs = sh.tang, sh.rs
-                if sh.tang_stream is not None:                              # (deferred mode: it ran on the side stream)
-                    torch.cuda.current_stream(dev).wait_stream(sh.tang_stream)
+                wait_for = sh.tang_stream                                   # (it ran on a side stream: waited for between the two launches below)
             else:
                 tang, rs = tangent_arguments(siren, film, args, d_eik, r.box_scale, ctx.images, rsave)
             if sh is not None:
@@ -739,7 +750,15 @@ class _RenderQuery(torch.autograd.Function):
             partials=_lib.ptr(partials), dfilm=_lib.ptr(dfilm), dstyles=_lib.ptr(dstyles), d_tex_alpha=_lib.ptr(d_ta),
             d_tex_beta=_lib.ptr(d_tb))
         with _lib.on_device(dev):
-            rc = lib.e3dge_siren_render_bwd(ctypes.byref(a), _lib.stream_of(film))
+            if wait_for is None:
+                rc = lib.e3dge_siren_render_bwd(ctypes.byref(a), _lib.stream_of(film))
+            else:
+                a.phase = 1                                                  # the backward of the compositing does not read the tangent
+                rc = lib.e3dge_siren_render_bwd(ctypes.byref(a), _lib.stream_of(film))
+                torch.cuda.current_stream(dev).wait_stream(wait_for)
+                if rc == 0:
+                    a.phase = 2
+                    rc = lib.e3dge_siren_render_bwd(ctypes.byref(a), _lib.stream_of(film))
         _lib.check(rc, "e3dge_siren_render_bwd")
         if ctx.styles_ndim == 2:
             dstyles = dstyles.sum(1)

@@ -541,6 +541,9 @@ typedef struct E3dgeRenderBwdArgs {
     float* d_rgb_pts; float* d_sdf_pts; float* partials;
     float* dfilm; float* dstyles;
     float* d_tex_alpha; float* d_tex_beta;
+    int phase;               /* ABI 14: 0 = both launches; 1 = only the backward of the compositing (reads the d_*_map / d_sdf / d_weights inputs, writes
+                                d_rgb_pts / d_sdf_pts; needs neither tang nor rsave); 2 = only the network backward on what phase 1 left in those buffers.
+                                Lets a caller run phase 1 beside e3dge_siren_tangent(_tr) on another stream and wait for the tangent before phase 2. */
 } E3dgeRenderBwdArgs;
 int e3dge_siren_render_bwd(const E3dgeRenderBwdArgs* args, e3dge_stream_t stream);
 

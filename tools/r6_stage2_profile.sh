@@ -9,7 +9,8 @@ rows = list(csv.DictReader(open(tr[0])))
 agg = collections.defaultdict(lambda: [0, 0])
 steps = sum(1 for r in rows if "siren16_kernel<0, true" in r["Kernel_Name"])
 for r in rows:
-    name = re.sub(r"void |e3dge::|\(.*", "", r["Kernel_Name"])[:70]
+    name = re.sub(r"void |e3dge::", "", r["Kernel_Name"])
+    name = re.sub(r"\(.*", "", name)[:70] if not name.startswith("at::") else re.sub(r"at::native::|\(anonymous namespace\)::|std::array<char\*, \d+ul>|<unnamed>::", "", name)[:110]
     a = agg[name]; a[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); a[1] += 1
 tot = sum(v[0] for v in agg.values())
 out = [f"stage-2 step (tools/stage2_step.py): kernel time per step by kernel name, {steps} steps in the trace; total {tot / steps / 1e6:.3f} ms of kernels per step"]
