@@ -148,6 +148,7 @@ SIGNATURES = {
     "e3dge_modconv_pack_weights": (_i32, [_vp, _vp, _vp, _f32, _i32, _i32, _vp]),
     "e3dge_modconv_demod": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "e3dge_amax": (_i32, [_vp, _vp, _i64, _vp]),
+    "e3dge_amax_rows": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp]),
     "e3dge_modconv3x3": (_i32, [ctypes.POINTER(ModconvArgs), _vp]),
     "e3dge_dec2_act_words": (_i64, [_i32, _i32, _i32]),
     "e3dge_dec2_tbuf_floats": (_i64, [_i32, _i32, _i32]),

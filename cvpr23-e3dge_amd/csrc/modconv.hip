@@ -621,6 +621,32 @@ extern "C" int e3dge_decoder_styles(const E3dgeModLayer* table, int n_layers, in
     return decoder_styles_launch(table, n_layers, total_rows, total_co, latent, n_latent, style_dim, batch, nullptr, 0, as_stream(stream));
 }
 
+// the same over the first `width` columns of rows of pitch `ld` (a column block of a wider row tensor: the gradient of a cat's first piece)
+__global__ void __launch_bounds__(256) amax_rows_kernel(float* __restrict__ out, const float* __restrict__ x, int64_t n_rows, int width, int64_t ld) {
+    __shared__ float part[4];
+    float m = 0.0f;
+    const int64_t n = n_rows * width;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / width;
+        m = fmaxf(m, fabsf(x[r * ld + (i - r * width)]));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomic_max_nonneg(out + ((int)blockIdx.x & (kAmaxSlots - 1)) * kAmaxStride, fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])));
+}
+
+extern "C" int e3dge_amax_rows(float* out, const float* x, int64_t n_rows, int width, int64_t ld, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(out && n_rows >= 0 && width >= 0 && ld >= width && (x || n_rows * width == 0), "amax_rows: bad arguments");
+    if (n_rows * width == 0) return E3DGE_OK;
+    int64_t blocks = (n_rows * width + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    amax_rows_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(out, x, n_rows, width, ld);
+    return check_launch("amax_rows");
+}
+
 extern "C" int e3dge_amax(float* out, const float* x, int64_t n, e3dge_stream_t stream) {
     E3DGE_REQUIRE(out && (x || n == 0) && n >= 0, "amax: bad arguments");
     if (n == 0) return E3DGE_OK;

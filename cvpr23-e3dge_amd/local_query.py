@@ -122,6 +122,55 @@ class _GatherFn(torch.autograd.Function):
         return d_p, None, (d_fm.permute(0, 3, 1, 2) if need_f else None)
 
 
+class _EncInFn(torch.autograd.Function):
+    """Round 6: the 2 C (+ 1)-wide input rows of Fuse_sft_MLP -- [gather on the query view's map | visibility mask | gather on the reference
+    view's map] (e3dge_full_runner.py:185-317, HGPIFuGANNet.py:85-151) -- as ONE node: both e3dge_local_query launches write into the row
+    buffer (no torch.cat), and the backward hands each e3dge_local_query_bwd its column block of the incoming gradient in place (row pitch
+    and offset; no .contiguous() of the slices).  Gradient to the two feature maps only: points that require grad take the composed path."""
+
+    @staticmethod
+    def forward(ctx, pts, que_calibs, ref_calibs, vis, que_map, ref_map):
+        B, N, _ = pts.shape
+        C = que_map.shape[1]
+        n_enc = C + (1 if vis is not None else 0)
+        with torch.no_grad():
+            enc_in = torch.empty((B, N, n_enc + C), device=pts.device, dtype=torch.float32)
+            query_feature_map(pts.detach(), que_calibs.detach(), que_map.detach(), out=enc_in, col_off=0)
+            _, in_img, _ = query_feature_map(pts.detach(), ref_calibs.detach(), ref_map.detach(), out=enc_in, col_off=n_enc)
+            if vis is not None:
+                enc_in[..., C] = vis
+        ctx.save_for_backward(pts, que_calibs, ref_calibs, que_map, ref_map)
+        ctx.n_enc = n_enc
+        ctx.mark_non_differentiable(in_img)
+        return enc_in, in_img
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_enc, _d_mask):
+        pts, que_calibs, ref_calibs, que_map, ref_map = ctx.saved_tensors
+        B, N, _ = pts.shape
+        g = d_enc.float()
+        if not g.is_contiguous():
+            g = g.contiguous()
+        ld = g.shape[-1]
+        p = pts.detach().contiguous()
+        out = []
+        for need, fmap, calibs, off in ((ctx.needs_input_grad[4], que_map, que_calibs, 0), (ctx.needs_input_grad[5], ref_map, ref_calibs, ctx.n_enc)):
+            if not need:
+                out.append(None)
+                continue
+            C, h, w = fmap.shape[1:]
+            fm = fmap.detach().permute(0, 2, 3, 1).contiguous()
+            d_fm = torch.zeros((B, h, w, C), device=g.device, dtype=torch.float32)
+            c = calibs.detach()[:, :3, :4].contiguous()
+            with torch.cuda.device(g.device):
+                rc = _lib.load().e3dge_local_query_bwd(_lib.ptr(d_fm), None, _lib.ptr(g), ld, off, _lib.ptr(p), _lib.ptr(c), _lib.ptr(fm),
+                                                       B, N, C, h, w, _lib.stream_of(g))
+            _lib.check(rc, "e3dge_local_query_bwd")
+            out.append(d_fm.permute(0, 3, 1, 2))
+        return None, None, None, None, out[0], out[1]
+
+
 def pos_encoding(pts, n_freqs=7, out=None, col_off=0):
     """PosEncoding.forward (project/utils/misc_utils.py:148-185): (..., 3) -> (..., 3 * (2 n_freqs + 1)); with `out`
     (M, ld) the columns go to out[:, col_off:...]."""
@@ -185,7 +234,7 @@ class Fuse_sft_MLP(nn.Module):
             if out is None and fuse_autograd_backend() == "hip" and self._fusefn_ok(enc_in, dec_feat, w):
                 # training (round 4): the same nine launches as the forward of an autograd node; its backward is library GEMMs on
                 # the intermediates the launches left behind (the 3D-projected block of enc_in IS dec_feat, as on the inference path)
-                return _FuseFn.apply(self, enc_in, float(w), *self._param_list())
+                return _FuseFn.apply(self, enc_in, float(w), None, 0, *self._param_list())
         e = self.encode_enc(enc_in)
         res = dec_feat + w * (dec_feat * self.scale(e) + self.shift(e))
         if out is None:
@@ -274,10 +323,11 @@ class Fuse_sft_MLP(nn.Module):
                      f0a_t=img_t(f0[:, :256]), f0b_t=img_t(f0[:, b_off:]))
         return I
 
-    def _fuse_bwd_native(self, g, x, net, s1, t1, scale, am_x, w, b_off, slope, need_x):
+    def _fuse_bwd_native(self, g, x, net, s1, t1, scale, am_x, w, b_off, slope, need_x, ld_g=256):
         """The data-gradient chain of sft.py:84-109 + resnetfc.py:49-58 as e3dge_ws_linear launches on the transposed images (round 5):
         dz1 = (w g . dec) Wsc2 . lrelu'(s1), dz2 = (w g) Wsh2 . lrelu'(t1), de = dz1 Wsc1 + dz2 Wsh1, dnet = de W1 . [net > 0],
-        dx = de Ws + (dnet W0) . [x > 0], dx[dec block] += g (1 + w scale).  Returns (dz1, dz2, de, dnet, dx or None, the amax buffers of g / dz1 / dz2 / de / dnet)."""
+        dx = de Ws + (dnet W0) . [x > 0], dx[dec block] += g (1 + w scale).  Returns (dz1, dz2, de, dnet, dx or None, the amax buffers of g / dz1 / dz2 / de / dnet).
+        `g`: (N, 256) rows of pitch `ld_g` floats (round 6: the first 256 of the 301 gradient columns of the assembled features, read in place)."""
         N = g.shape[0]
         dev = g.device
         ld = x.shape[1]
@@ -302,16 +352,19 @@ class Fuse_sft_MLP(nn.Module):
                 a.xmul, a.amax_xmul, a.ld_xmul, a.off_xmul = _lib.ptr(xmul), _lib.ptr(am_x), ld, b_off
             _lib.check(lib.e3dge_ws_linear(ctypes.byref(a), st), "e3dge_ws_linear")
         with torch.cuda.device(dev):
-            _lib.check(lib.e3dge_amax(_lib.ptr(am[0]), _lib.ptr(g), g.numel(), st), "e3dge_amax")
-            lin(I['sc2_t'], g, am[0], dz1, post=3, sl=slope, r1=s1, xmul=x, x_scale=w, amax_out=am[1])
-            lin(I['sh2_t'], g, am[0], dz2, post=3, sl=slope, r1=t1, x_scale=w, amax_out=am[2])
+            if ld_g == 256:
+                _lib.check(lib.e3dge_amax(_lib.ptr(am[0]), _lib.ptr(g), g.numel(), st), "e3dge_amax")
+            else:
+                _lib.check(lib.e3dge_amax_rows(_lib.ptr(am[0]), _lib.ptr(g), N, 256, ld_g, st), "e3dge_amax_rows")
+            lin(I['sc2_t'], g, am[0], dz1, ld_x=ld_g, post=3, sl=slope, r1=s1, xmul=x, x_scale=w, amax_out=am[1])
+            lin(I['sh2_t'], g, am[0], dz2, ld_x=ld_g, post=3, sl=slope, r1=t1, x_scale=w, amax_out=am[2])
             lin(I['sc1_t'], dz1, am[1], de)
             lin(I['sh1_t'], dz2, am[2], de, r1=de, amax_out=am[3])
             lin(I['f1_t'], de, am[3], dnet, post=3, sl=0.0, r1=net, amax_out=am[4])
             if need_x:
                 lin(I['sa_t'], de, am[3], dx, ld_y=ld, off_y=0)
                 lin(I['f0a_t'], dnet, am[4], dx, ld_y=ld, off_y=0, post=3, sl=0.0, r1=x, r1_ld=ld, r1_off=0, r2=dx, r2_ld=ld, r2_off=0)
-                lin(I['sb_t'], de, am[3], dx, ld_y=ld, off_y=b_off, post=4, r1=g, r2=scale)
+                lin(I['sb_t'], de, am[3], dx, ld_y=ld, off_y=b_off, post=4, r1=g, r1_ld=ld_g, r2=scale)
                 lin(I['f0b_t'], dnet, am[4], dx, ld_y=ld, off_y=b_off, post=3, sl=0.0, r1=x, r1_ld=ld, r1_off=b_off, r2=dx, r2_ld=ld, r2_off=b_off)
             if need_x and I['has_col']:
                 # the visibility-mask column (one input column of fc_0 and of the shortcut): two row dot products in one launch
@@ -383,10 +436,19 @@ class _FuseFn(torch.autograd.Function):
     E3DGE_FUSE_BWD=torch keeps round 4's library GEMMs), the thirteen parameter gradients stay library GEMMs.  Not double-differentiable."""
 
     @staticmethod
-    def forward(ctx, mod, enc_in, w, *params):
+    def forward(ctx, mod, enc_in, w, pe_pts, n_freqs, *params):
+        """pe_pts (round 6): None, or the points (.., 3) whose positional encoding (PosEncoding.forward, misc_utils.py:148-185) fills the
+        columns behind the 256 fused ones -- the node then returns the assembled (.., 256 + 3 (2 n_freqs + 1)) feature rows, written in place
+        (no torch.cat), and its backward reads the first 256 gradient columns in place (no .contiguous())."""
         keep = {}
         with torch.no_grad():
-            out = mod._fuse_native(enc_in.detach(), w, None, 0, keep=keep)
+            if pe_pts is None:
+                out = mod._fuse_native(enc_in.detach(), w, None, 0, keep=keep)
+            else:
+                width = 3 * (2 * n_freqs + 1)
+                out = torch.empty(enc_in.shape[:-1] + (256 + width,), device=enc_in.device, dtype=torch.float32)
+                mod._fuse_native(enc_in.detach(), w, out, 0, keep=keep)
+                pos_encoding(pe_pts.detach(), n_freqs, out=out.reshape(-1, 256 + width), col_off=256)
         ctx.mod, ctx.w, ctx.in_shape = mod, w, enc_in.shape
         ctx.b_off, ctx.slope, ctx.am_x, ctx.am_fwd = keep['b_off'], keep['slope'], keep['am_x'], keep['am']
         ctx.save_for_backward(keep['x'], keep['net'], keep['e'], keep['s1'], keep['t1'], keep['scale'], *params)
@@ -398,16 +460,20 @@ class _FuseFn(torch.autograd.Function):
         x, net, e, s1, t1, scale = ctx.saved_tensors[:6]
         W0, _, W1, _, Ws, Wsc1, _, Wsc2, _, Wsh1, _, Wsh2, _ = ctx.saved_tensors[6:]
         w, b_off, slope = ctx.w, ctx.b_off, ctx.slope
-        need = ctx.needs_input_grad[3:]
+        need = ctx.needs_input_grad[5:]
         need_x = ctx.needs_input_grad[1]
-        g = grad_out.reshape(-1, 256).float().contiguous()
+        g_rows = grad_out.reshape(-1, grad_out.shape[-1]).float()
+        if g_rows.stride(-1) != 1 or (g_rows.shape[0] > 1 and g_rows.stride(0) < g_rows.shape[1]) or g_rows.data_ptr() % 4:
+            g_rows = g_rows.contiguous()
+        ld_g = g_rows.stride(0) if g_rows.shape[0] > 1 else g_rows.shape[1]
+        g = g_rows[:, :256]                                   # (a view when the node also produced the positional-encoding columns)
         dec = x[:, b_off:]
         mm = lambda a, b_: a.t() @ b_
         gp = [None] * 13
         if os.environ.get("E3DGE_FUSE_BWD", "hip") == "hip":
             # round 5: the data-gradient chain as nine e3dge_ws_linear launches on the transposed weight images; the thirteen parameter
             # gradients (reductions over the points: library GEMMs with K = number of points) only when a parameter wants one
-            dz1, dz2, de, dnet, dx, am_b = ctx.mod._fuse_bwd_native(g, x, net, s1, t1, scale, ctx.am_x, w, b_off, slope, need_x)
+            dz1, dz2, de, dnet, dx, am_b = ctx.mod._fuse_bwd_native(g, x, net, s1, t1, scale, ctx.am_x, w, b_off, slope, need_x, ld_g=ld_g)
             if any(need):
                 # the seven weight gradients: e3dge_wgrad (split-f16 MFMA, split over the points, fixed-order fold; E3DGE_WGRAD=library = matmul),
                 # the relu of a layer's input folded into the operand load
@@ -441,7 +507,7 @@ class _FuseFn(torch.autograd.Function):
                 wg(2, 3, de, net, True)
                 wg(4, None, de, x, gap_col=gap)
                 wg(0, 1, dnet, x, True, gap_col=gap)
-            return (None, dx.reshape(ctx.in_shape) if dx is not None else None, None, *gp)
+            return (None, dx.reshape(ctx.in_shape) if dx is not None else None, None, None, None, *gp)
         d_scale, d_shift = (w * g) * dec, w * g                   # out = dec + w (dec scale + shift)
         # scale = W2 lrelu(W1 e + b1) + b2 ; shift likewise
         dz1 = (d_scale @ Wsc2) * torch.where(s1 > 0, 1.0, slope)
@@ -467,7 +533,7 @@ class _FuseFn(torch.autograd.Function):
             dx = de @ Ws + (dnet @ W0) * (x > 0)
             dx[:, b_off:] += g * (1.0 + w * scale)
             dx = dx.reshape(ctx.in_shape)
-        return (None, dx, None, *gp)
+        return (None, dx, None, None, None, *gp)
 
 
 def local_features_from_maps(local_data_batch, n_freqs=7):
@@ -489,14 +555,24 @@ def local_features_from_maps(local_data_batch, n_freqs=7):
         # training form (stage 2 trains the hourglass filters and Fuse_sft_MLP through this, e3dge_full_runner.py:185-317): the
         # same values assembled from differentiable pieces -- gathers with the HIP backward, Fuse_sft_MLP as the _FuseFn node (native
         # forward, written-out backward) or, when that does not apply, as torch modules
+        vis_rows = None
+        if add_mask:
+            with torch.no_grad():
+                surf = local_data_batch['xyz'].detach().reshape(B, 3, H * W).permute(0, 2, 1)
+                _, vis_, _ = query_feature_map(surf, local_data_batch['ref_calibs'])
+                vis_rows = vis_.reshape(B, H * W, 1).expand(B, H * W, S).reshape(B, N)
+        if (not pts.requires_grad and isinstance(fuse, Fuse_sft_MLP) and fuse_autograd_backend() == "hip" and C == 256
+                and os.environ.get("E3DGE_LOCAL_FEATS_NODES", "fused") == "fused"):
+            # round 6: two nodes instead of eight -- the row buffers are written and read in place (E3DGE_LOCAL_FEATS_NODES=composed: as before)
+            enc_in, in_img = _EncInFn.apply(pts, local_data_batch['que_calibs'], local_data_batch['ref_calibs'], vis_rows, maps['que'], maps['ref'])
+            if fuse._native_ok(enc_in) and fuse._wants_grad(enc_in):
+                feats = _FuseFn.apply(fuse, enc_in, 1.0, pts, n_freqs, *fuse._param_list())
+                return feats.reshape(B, H, W, S, feats.shape[-1]), in_img.reshape(B, H, W, S, 1)
         a, _, _ = query_feature_map(pts, local_data_batch['que_calibs'], maps['que'])
         dec, in_img, _ = query_feature_map(pts, local_data_batch['ref_calibs'], maps['ref'])
         cols = [a]
         if add_mask:
-            with torch.no_grad():
-                surf = local_data_batch['xyz'].detach().reshape(B, 3, H * W).permute(0, 2, 1)
-                _, vis, _ = query_feature_map(surf, local_data_batch['ref_calibs'])
-            cols.append(vis.reshape(B, H * W, 1).expand(B, H * W, S).reshape(B, N, 1))
+            cols.append(vis_rows.reshape(B, N, 1))
         cols.append(dec)
         enc_in = torch.cat(cols, -1)
         fused = fuse.fuse(enc_in, enc_in[..., enc_in.shape[-1] - dec.shape[-1]:])      # (dec as the view of enc_in that it is)

@@ -166,6 +166,9 @@ int e3dge_modconv_pack_weights(uint32_t* image, float* wsq, const float* weight,
 int e3dge_modconv_demod(float* demod, float* s_amax, const float* style, const float* wsq, int batch, int co, int ci,
                         int demodulate, e3dge_stream_t stream);
 int e3dge_amax(float* out, const float* x, int64_t n, e3dge_stream_t stream);
+/* ABI 14: the same over the first `width` columns of `n_rows` rows of pitch `ld` floats (4-byte aligned): a column block of a wider row tensor,
+ * e.g. the first 256 of the 301 gradient columns torch.cat's backward hands to Fuse_sft_MLP (sft.py:84-110 behind e3dge_full_runner.py:185-317). */
+int e3dge_amax_rows(float* out, const float* x, int64_t n_rows, int width, int64_t ld, e3dge_stream_t stream);
 int e3dge_modconv3x3(const E3dgeModconvArgs* args, e3dge_stream_t stream);
 
 /*

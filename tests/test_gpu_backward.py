@@ -551,3 +551,25 @@ def test_stream_overlap_of_the_training_step_changes_no_bit(sd, monkeypatch):
             for a, b in zip(got, ref):
                 assert torch.equal(a, b)
     assert torch.isfinite(ref[1]).all() and float(ref[1].abs().max()) > 0
+
+
+def test_two_phase_render_backward_beside_the_tangent_changes_no_bit(sd, monkeypatch):
+    """Round 6: e3dge_siren_render_bwd in two phases (compositing | network) with the tangent pass on a side stream
+    (E3DGE_OVERLAP_COMPOSITE=1; measured no faster and off by default) is the same arithmetic in another launch order."""
+    from e3dge_amd.camera_utils import generate_camera_params
+    res, S = 16, 18
+    r = make_renderer(full_state_dict(res=res, n_samples=S)[1], res, S)
+    wr, _ = syn.synthetic_inputs(2, seed=22, device=DEV)
+    poses, focal, near, far, _ = generate_camera_params(res, DEV, locations=torch.tensor([[0.1, 0.05], [-0.2, 0.0]], device=DEV))
+
+    def step():
+        s_ = wr.clone().requires_grad_(True)
+        o = r(poses, focal, near, far, styles=s_, return_eikonal=True, return_surface_eikonal=True)
+        ((o['gen_thumb_imgs'] ** 2).mean() + ((o['eikonal_term'].norm(dim=-1) - 1) ** 2).mean() + (o['surface_eikonal_term'] ** 2).mean()).backward()
+        torch.cuda.synchronize()
+        return s_.grad.clone()
+    ref = step()
+    monkeypatch.setenv("E3DGE_OVERLAP_COMPOSITE", "1")
+    for _ in range(3):
+        assert torch.equal(step(), ref)
+    assert torch.isfinite(ref).all() and float(ref.abs().max()) > 0

@@ -198,3 +198,37 @@ def test_training_form_of_the_local_features_matches_the_inference_form():
     got.square().mean().backward()
     assert all(m.grad is not None and torch.isfinite(m.grad).all() and float(m.grad.abs().max()) > 0 for m in maps.values())
     assert all(p_.grad is not None for p_ in fuse.parameters())
+
+
+@pytest.mark.gpu
+def test_two_node_training_form_equals_the_composed_one(monkeypatch):
+    """Round 6: the training form as two nodes (_EncInFn: both gathers into the row buffer, their backward on column blocks of the incoming
+    gradient in place; _FuseFn with the positional-encoding columns in its own output, the first 256 gradient columns read in place) against
+    the composed form (E3DGE_LOCAL_FEATS_NODES=composed: gathers, cat, _FuseFn, cat): identical values, the same gradients for both maps
+    and all thirteen parameters to rounding -- the loss weights the 45 encoding columns too, so a wrong pitch or offset anywhere shows."""
+    from e3dge_amd.local_query import Fuse_sft_MLP, local_features_from_maps
+    DEV = "cuda:0"
+    torch.manual_seed(5)
+    B, H, S, C = 2, 8, 6, 256
+    fuse = Fuse_sft_MLP(C + 1, C).to(DEV)
+    for p_ in fuse.parameters():
+        torch.nn.init.normal_(p_, std=0.05)
+    maps = {'ref': torch.randn(B, C, 16, 16, device=DEV).requires_grad_(True), 'que': torch.randn(B, C, 24, 24, device=DEV).requires_grad_(True)}
+    calib = torch.tensor([[[2.0, 0.0, 0.0, 0.0], [0.0, 2.0, 0.0, 0.0], [0.0, 0.0, 1.0, 2.0]]], device=DEV).repeat(B, 1, 1)
+    batch = dict(feature_maps=maps, ref_calibs=calib, que_calibs=calib.clone(), points=(torch.rand(B, H, H, S, 3, device=DEV) - 0.5),
+                 xyz=(torch.rand(B, 3, H, H, device=DEV) - 0.5), fuse_sft_block=fuse)
+    gw = torch.randn(B, H, H, S, 301, device=DEV)
+
+    def run():
+        for t_ in list(maps.values()) + list(fuse.parameters()):
+            t_.grad = None
+        f, m = local_features_from_maps(batch)
+        (f * gw).sum().backward()
+        return f.detach().clone(), m.clone(), [maps['ref'].grad.clone(), maps['que'].grad.clone()] + [p_.grad.clone() for p_ in fuse.parameters()], f.grad_fn
+    f1, m1, g1, fn1 = run()
+    monkeypatch.setenv("E3DGE_LOCAL_FEATS_NODES", "composed")
+    f0, m0, g0, fn0 = run()
+    assert "FuseFn" in type(fn1).__name__ or "FuseFn" in str(fn1.next_functions), type(fn1).__name__
+    assert torch.equal(f1, f0) and torch.equal(m1, m0)
+    for a, b in zip(g1, g0):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), (a.shape, float((a - b).abs().max()), float(b.abs().max()))
