@@ -450,12 +450,14 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
         // =====================================================================================
         // 2. the chain: GEMM Gb (layer L = 8 - Gb) turns g_L into dh_{L-1}; its epilogue makes g_{L-1}
         // =====================================================================================
-#pragma unroll 1
-        for (int Gb = 0; Gb < kBigLayers; ++Gb) {
+        // (TEX: layer 8's pass is peeled off -- `first` is a compile-time constant -- so that the registers only it needs, the texture FiLM's
+        // alpha tiles and the two gradient tiles it stores, are dead in the loop over the other seven layers: kept in one runtime loop they
+        // cost the kernel 32 B of scratch per lane, and a scratch reload waits for every LDS-DMA piece in flight)
+        auto layer = [&](const int Gb, auto first_c) __attribute__((always_inline)) {
+            constexpr bool tex_here = TEX && decltype(first_c)::value;   // this GEMM's result is dL/dh8' (view-layer input)
             const int Lm1 = 7 - Gb;                                      // layer whose argument / FiLM the epilogue uses
             const float* __restrict__ fg = gam_s + Lm1 * kWidth + 4 * q;
             const float sdf_term = (Gb == 0) ? dsdf : 0.0f;              // the sdf head reads the backbone output h8
-            const bool tex_here = TEX && Gb == 0;                        // this GEMM's result is dL/dh8' (view-layer input)
             // the last hooks of a layer fetch the first tiles of the next one (layer 7 of the next sub-tile at the end)
             const int sub_x = Gb < 7 ? sub : sub_n, lay_x = Gb < 7 ? Lm1 - 1 : 7;
             f32x4v prev = zero4();
@@ -504,9 +506,9 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
                     constexpr int tn = (t + kDist) & 15;
                     if (t + kDist < k16Tiles) issue_streams(std::integral_constant<int, tn>{}, sub, Lm1);
                     else issue_streams(std::integral_constant<int, tn>{}, sub_x, lay_x);
-                    if (TEX) {
+                    if (tex_here) {
                         if (t > 0) asm volatile("" : "+v"(al2[(t - 1) & 1]));
-                        al2[t & 1] = tex_here ? ld4(txa + 16 * t) : zero4();
+                        al2[t & 1] = ld4(txa + 16 * t);
                     }
                 };
                 f32x4v acc = zero4(), accb = zero4();
@@ -522,7 +524,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
                 pipe.advance();
                 prev = (acc + accb) * inv_scale;
             });
-            if (TEX) asm volatile("" : "+v"(al2[(k16Tiles - 1) & 1]));
+            if (tex_here) asm volatile("" : "+v"(al2[(k16Tiles - 1) & 1]));
             epi_load(k16Tiles - 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) epi_val(k16Tiles - 1, r);
@@ -530,7 +532,10 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
             if (Gb + 1 < kBigLayers) next_operand();
             t3_barrier();
             fold(Lm1);
-        }
+        };
+        if (TEX) layer(0, std::true_type{});
+#pragma unroll 1
+        for (int Gb = TEX ? 1 : 0; Gb < kBigLayers; ++Gb) layer(Gb, std::false_type{});
         // ---- optional: dL/dx = s W_0^T g_0 (g_0 = gamma_0 * adj(a_0) is in out[]) ----
         if (DPTS) {
             float ex = 0.f, ey = 0.f, ez = 0.f;
@@ -545,8 +550,12 @@ __global__ void __launch_bounds__(k16Threads) siren16_bwd_kernel(const SirenBwdK
                 }
             }
             ex = sum_over_q(ex); ey = sum_over_q(ey); ez = sum_over_q(ez);
-            if (valid && q == 0) {
-                float* o = a.d_pts + gpt * 3;
+            // (the point's index is recomputed from the thread index: kept live across the eight layers it was spilled)
+            int tid_d = tid_k;
+            asm volatile("" : "+v"(tid_d));
+            const int p_d = sub * kTilePts + 16 * (tid_d >> 6) + (tid_d & 15);
+            if (p_d < npts && ((tid_d >> 4) & 3) == 0) {
+                float* o = a.d_pts + (base_pt + p_d) * 3;
                 o[0] = ex * a.box_scale; o[1] = ey * a.box_scale; o[2] = ez * a.box_scale;
             }
         }
