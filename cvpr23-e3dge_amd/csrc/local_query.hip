@@ -104,7 +104,7 @@ struct LocalQueryBwdK {
 // same -- the samples of a ray project to one pixel of their own view's map (24 atomics' worth of contention per address in the first
 // version) and to neighbouring pixels of the other view's --, (ii) an atomic instruction covers 64 consecutive floats (two cache lines)
 // instead of 64 floats 16 bytes apart (eight lines): the stage-2 step spent 2.4 of its 10.9 ms in the two launches of the first version.
-constexpr int kLqRun = 32;
+constexpr int kLqRun = 32, kLqBatch = 4;
 
 __global__ void __launch_bounds__(256) local_query_bwd_kernel(const LocalQueryBwdK a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -146,11 +146,37 @@ __global__ void __launch_bounds__(256) local_query_bwd_kernel(const LocalQueryBw
                 acc[0][j] = acc[1][j] = acc[2][j] = acc[3][j] = 0.0f;
             }
         };
-        for (long long pt = p0; pt < p1; ++pt) {
+        // The points come in batches of kLqBatch whose coordinates and gradient rows are requested one batch AHEAD: vmcnt retires in order,
+        // so a row load issued behind a pixel's atomics waited for them (and for its own HBM round trip) inside a 32-deep serial chain --
+        // 195 us per launch for 100 MB of rows.  Now a batch's loads are in the queue before the previous batch's atomics.
+        struct Pt { float x, y, z; float g[4]; };
+        Pt nxt[kLqBatch], cur[kLqBatch];
+        auto load_batch = [&](long long q0, Pt (&d)[kLqBatch]) {
+#pragma unroll
+            for (int k = 0; k < kLqBatch; ++k) {
+                const long long q = q0 + k < p1 ? q0 + k : p1 - 1;         // (clamped: rows past the run are loaded twice, never used)
+                const float* p = a.pts + (size_t)q * 3;
+                d[k].x = p[0]; d[k].y = p[1]; d[k].z = p[2];
+                const float* g = a.d_out + (size_t)q * a.ld + a.col_off;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ch = 64 * j + lane;
+                    d[k].g[j] = (j < n_j && ch < a.C) ? g[ch] : 0.0f;
+                }
+            }
+        };
+        load_batch(p0, nxt);
+        for (long long pb = p0; pb < p1; pb += kLqBatch) {
+#pragma unroll
+            for (int k = 0; k < kLqBatch; ++k) cur[k] = nxt[k];
+            if (pb + kLqBatch < p1) load_batch(pb + kLqBatch, nxt);
+#pragma unroll
+          for (int k = 0; k < kLqBatch; ++k) {
+            const long long pt = pb + k;
+            if (pt >= p1) break;
             const int b = (int)(pt / a.N);
             const float* c = a.calibs + (size_t)b * 12;
-            const float* p = a.pts + (size_t)pt * 3;
-            const float px = p[0], py = p[1], pz = p[2];
+            const float px = cur[k].x, py = cur[k].y, pz = cur[k].z;
             const float hx = c[3] + (c[0] * px + c[1] * py + c[2] * pz);
             const float hy = c[7] + (c[4] * px + c[5] * py + c[6] * pz);
             const float hz = c[11] + (c[8] * px + c[9] * py + c[10] * pz);
@@ -173,12 +199,9 @@ __global__ void __launch_bounds__(256) local_query_bwd_kernel(const LocalQueryBw
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int ch = 64 * j + lane;
-                    if (j < n_j && ch < a.C) {
-                        const float d = g[ch];
-                        acc[0][j] = fmaf(w00, d, acc[0][j]); acc[1][j] = fmaf(w01, d, acc[1][j]);
-                        acc[2][j] = fmaf(w10, d, acc[2][j]); acc[3][j] = fmaf(w11, d, acc[3][j]);
-                    }
+                    const float d = cur[k].g[j];                         // (0 beyond C)
+                    acc[0][j] = fmaf(w00, d, acc[0][j]); acc[1][j] = fmaf(w01, d, acc[1][j]);
+                    acc[2][j] = fmaf(w10, d, acc[2][j]); acc[3][j] = fmaf(w11, d, acc[3][j]);
                 }
             }
             if (a.d_pts) {
@@ -213,6 +236,7 @@ __global__ void __launch_bounds__(256) local_query_bwd_kernel(const LocalQueryBw
                     q[2] = c[2] * dhx + c[6] * dhy + c[10] * dhz;
                 }
             }
+          }
         }
         flush();
     }

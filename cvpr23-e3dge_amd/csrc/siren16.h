@@ -62,6 +62,17 @@ constexpr int k16LdsBytes = k16LdsFloats * 4;
 static_assert(k16LdsBytes <= 160 * 1024, "LDS budget");
 static_assert((k16LdsFilm % 4) == 0 && (k16LdsHead % 4) == 0 && (k16LdsW0 % 4) == 0 && (k16LdsWvt % 4) == 0, "alignment");
 
+// one 16-byte store of saved state (E3DGE_NT_STORES=1: non-temporal -- an A/B of round 6)
+#ifndef E3DGE_NT_STORES
+#define E3DGE_NT_STORES 1
+#endif
+__device__ __forceinline__ void save_st4(float* p, const f32x4v& v) {
+#if E3DGE_NT_STORES
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4v*>(p));
+#else
+    *reinterpret_cast<f32x4v*>(p) = v;
+#endif
+}
 __device__ __forceinline__ f32x4v mfma16x16(u32x4 a, u32x4 b, f32x4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
 }
@@ -468,7 +479,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
                     arg[r] = fmaf(g4[r], lin, b4[r]);
                     v[r] = sin_f32(arg[r]);
                 }
-                if (SAVE) *reinterpret_cast<f32x4v*>(sv + t * sv_ts) = arg;
+                if (SAVE) save_st4(sv + t * sv_ts, arg);
                 SPLIT2_TO(v[0], v[1], inH[t >> 1][2 * (t & 1)], inL[t >> 1][2 * (t & 1)]);
                 SPLIT2_TO(v[2], v[3], inH[t >> 1][2 * (t & 1) + 1], inL[t >> 1][2 * (t & 1) + 1]);
             }
@@ -490,7 +501,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
                 f32x4v arg, v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { arg[r] = fmaf(g4[r], pv[r], b4[r]); v[r] = sin_f32(arg[r]); }
-                if (SAVE) *reinterpret_cast<f32x4v*>(sv + L * sv_ls + tp * sv_ts) = arg;
+                if (SAVE) save_st4(sv + L * sv_ls + tp * sv_ts, arg);
                 SPLIT2_TO(v[0], v[1], outH[tp >> 1][2 * (tp & 1)], outL[tp >> 1][2 * (tp & 1)]);
                 SPLIT2_TO(v[2], v[3], outH[tp >> 1][2 * (tp & 1) + 1], outL[tp >> 1][2 * (tp & 1) + 1]);
             };
@@ -526,7 +537,7 @@ __global__ void __launch_bounds__(k16Threads) siren16_kernel(const SirenK a) {
 #else
                             for (int r = 0; r < 4; ++r) x4[r] = sin_poly_f32(arg4[r]);
 #endif
-                            if (SAVE) *reinterpret_cast<f32x4v*>(sv + L * sv_ls + (t - 1) * sv_ts) = arg4;
+                            if (SAVE) save_st4(sv + L * sv_ls + (t - 1) * sv_ts, arg4);
                         } else if (g == 4) {
                             SPLIT2_TO(x4[0], x4[1], outH[(t - 1) >> 1][2 * ((t - 1) & 1)], outL[(t - 1) >> 1][2 * ((t - 1) & 1)]);
                             SPLIT2_TO(x4[2], x4[3], outH[(t - 1) >> 1][2 * ((t - 1) & 1) + 1], outL[(t - 1) >> 1][2 * ((t - 1) & 1) + 1]);

@@ -120,7 +120,7 @@ __device__ __forceinline__ f32x4v ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, const f32x4v& v) { *reinterpret_cast<f32x4v*>(p) = v; }
 __device__ __forceinline__ void st4_chain(float* p, const f32x4v& v) {      // the per-tile store of the chain kernels (see E3DGE_T3_ABL)
 #if !(E3DGE_T3_ABL & 2)
-    *reinterpret_cast<f32x4v*>(p) = v;
+    save_st4(p, v);
 #else
     if (v[0] == 1.2345e-30f) *reinterpret_cast<f32x4v*>(p) = v;
 #endif
@@ -158,15 +158,23 @@ __device__ __forceinline__ void t3_roles(int wave_s, int& w_role, int& s_role) {
 }
 // Role-conditional forms: the scalar test and the branch live INSIDE the asm statement, so the compiler keeps seeing one straight-line
 // tile (a C++ `if (role)` around the DMA split every unrolled tile into basic blocks and cost the chain kernels 60 registers).
+#ifndef E3DGE_NT_LOADS
+#define E3DGE_NT_LOADS 0
+#endif
+#if E3DGE_NT_LOADS
+#define E3DGE_T3_NT " nt"
+#else
+#define E3DGE_T3_NT ""
+#endif
 template <int OFF_BYTES>
 __device__ __forceinline__ void glds16_saddr_if(int flag, const void* sbase, uint32_t voff, uint32_t lds_addr) {
-    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lt3skip%=\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n.Lt3skip%=:"
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lt3skip%=\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4" E3DGE_T3_NT "\n.Lt3skip%=:"
                  :: "s"(flag), "v"(voff), "s"(sbase), "s"(lds_addr), "n"(OFF_BYTES) : "memory", "scc");
 }
 __device__ __forceinline__ void glds16_saddr_x4_if(int flag, const void* sbase, uint32_t voff, uint32_t lds_addr) {     // four 1-KiB pieces
     asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lt3skip%=\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:0\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-                 "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072\n.Lt3skip%=:"
+                 "global_load_lds_dwordx4 %1, %2 offset:0" E3DGE_T3_NT "\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024" E3DGE_T3_NT "\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:2048" E3DGE_T3_NT "\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072" E3DGE_T3_NT "\n.Lt3skip%=:"
                  :: "s"(flag), "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "scc");
 }
 // s_waitcnt vmcnt(A) if flag else vmcnt(B)
