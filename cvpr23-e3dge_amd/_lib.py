@@ -186,6 +186,8 @@ SIGNATURES = {
     "e3dge_wgrad": (_i32, [_vp, _vp]),
     "e3dge_local_query": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
     "e3dge_local_query_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),
+    "e3dge_local_query_sort_ws_ints": (_i64, [_i32, _i64, _i32, _i32]),
+    "e3dge_local_query_bwd_sorted": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "e3dge_pos_encoding": (_i32, [_vp, _i32, _i32, _vp, _i64, _i32, _vp]),
     "e3dge_image_metrics_scratch_floats": (_i64, [_i32, _i32, _i32, _i32]),
     "e3dge_image_metrics": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),

@@ -96,6 +96,7 @@ struct LocalQueryBwdK {
     const float* d_out;     // (B, N, ld): gradient of the features, columns [col_off, col_off + C)
     float* d_fmap;          // (B, h, w, C) channel-last, zero-filled by the caller, or null
     float* d_pts;           // (B, N, 3) or null
+    const int* order;       // null, or a permutation of the B N points: the kernel walks order[0], order[1], ... (round 6: sorted by corner pixel)
     long long N;
     int B, C, h, w, ld, col_off;
 };
@@ -105,6 +106,7 @@ struct LocalQueryBwdK {
 // version) and to neighbouring pixels of the other view's --, (ii) an atomic instruction covers 64 consecutive floats (two cache lines)
 // instead of 64 floats 16 bytes apart (eight lines): the stage-2 step spent 2.4 of its 10.9 ms in the two launches of the first version.
 constexpr int kLqRun = 32, kLqBatch = 4;
+static_assert(kLqRun <= 64, "a run's entries of `order` live in one register");
 
 __global__ void __launch_bounds__(256) local_query_bwd_kernel(const LocalQueryBwdK a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -149,12 +151,23 @@ __global__ void __launch_bounds__(256) local_query_bwd_kernel(const LocalQueryBw
         // The points come in batches of kLqBatch whose coordinates and gradient rows are requested one batch AHEAD: vmcnt retires in order,
         // so a row load issued behind a pixel's atomics waited for them (and for its own HBM round trip) inside a 32-deep serial chain --
         // 195 us per launch for 100 MB of rows.  Now a batch's loads are in the queue before the previous batch's atomics.
-        struct Pt { float x, y, z; float g[4]; };
+        struct Pt { long long q; float x, y, z; float g[4]; };
         Pt nxt[kLqBatch], cur[kLqBatch];
-        auto load_batch = [&](long long q0, Pt (&d)[kLqBatch]) {
+        long long ixn[kLqBatch];
+        // (the run's kLqRun <= 64 entries of `order` in ONE load, lane k holding entry k; a batch's indices are lane reads of that register)
+        const int my_entry = a.order ? a.order[p0 + lane < p1 ? p0 + lane : p1 - 1] : 0;
+        auto load_idx = [&](long long e0) {
 #pragma unroll
             for (int k = 0; k < kLqBatch; ++k) {
-                const long long q = q0 + k < p1 ? q0 + k : p1 - 1;         // (clamped: rows past the run are loaded twice, never used)
+                const long long e = e0 + k < p1 ? e0 + k : p1 - 1;         // (clamped: entries past the run are loaded twice, never used)
+                ixn[k] = a.order ? (long long)__shfl(my_entry, (int)(e - p0), kWave) : e;
+            }
+        };
+        auto load_batch = [&](Pt (&d)[kLqBatch]) {
+#pragma unroll
+            for (int k = 0; k < kLqBatch; ++k) {
+                const long long q = ixn[k];
+                d[k].q = q;
                 const float* p = a.pts + (size_t)q * 3;
                 d[k].x = p[0]; d[k].y = p[1]; d[k].z = p[2];
                 const float* g = a.d_out + (size_t)q * a.ld + a.col_off;
@@ -165,15 +178,20 @@ __global__ void __launch_bounds__(256) local_query_bwd_kernel(const LocalQueryBw
                 }
             }
         };
-        load_batch(p0, nxt);
+        load_idx(p0);
+        load_batch(nxt);
+        if (p0 + kLqBatch < p1) load_idx(p0 + kLqBatch);
         for (long long pb = p0; pb < p1; pb += kLqBatch) {
 #pragma unroll
             for (int k = 0; k < kLqBatch; ++k) cur[k] = nxt[k];
-            if (pb + kLqBatch < p1) load_batch(pb + kLqBatch, nxt);
+            if (pb + kLqBatch < p1) {
+                load_batch(nxt);
+                if (pb + 2 * kLqBatch < p1) load_idx(pb + 2 * kLqBatch);
+            }
 #pragma unroll
           for (int k = 0; k < kLqBatch; ++k) {
-            const long long pt = pb + k;
-            if (pt >= p1) break;
+            if (pb + k >= p1) break;
+            const long long pt = cur[k].q;
             const int b = (int)(pt / a.N);
             const float* c = a.calibs + (size_t)b * 12;
             const float px = cur[k].x, py = cur[k].y, pz = cur[k].z;
@@ -242,6 +260,77 @@ __global__ void __launch_bounds__(256) local_query_bwd_kernel(const LocalQueryBw
     }
 }
 
+// ---- round 6: the points sorted by the pixel of their top-left corner ---------------------------------------------------------------------
+// Along a ray of ANOTHER view consecutive samples land on different pixels (measured: the pixel changes at every one of the 98,304 points
+// of the stage-2 step's reference-view gather, against 4 % for a view's own rays), so the run accumulation above never merges anything and
+// the launch is 1.57 M device-scope atomic instructions: 290 us, six times the query view's.  A counting sort by (image, corner pixel)
+// makes every pixel's ~6 points neighbours in `order`: a wave's run then flushes once per pixel.  Keys: (y0 + 1) (w + 1) + (x0 + 1) per
+// image, one more bin for points that touch no pixel (they sort to the end and are skipped).
+struct LqSortK { const float* pts; const float* calibs; int* keys; int* counts; int* starts; int* cursor; int* order; long long N; int B, h, w, nb; };
+
+__device__ __forceinline__ int lq_corner_key(const float* c, const float* p, float zsign, int b, int h, int w, int nb) {
+    // (the same arithmetic, in the same order, as local_query_bwd_kernel)
+    const float px = p[0], py = p[1], pz = p[2];
+    const float hx = c[3] + (c[0] * px + c[1] * py + c[2] * pz);
+    const float hy = c[7] + (c[4] * px + c[5] * py + c[6] * pz);
+    const float hz = c[11] + (c[8] * px + c[9] * py + c[10] * pz);
+    const float z = zsign * hz;
+    const float x = hx / z, y = -(hy / z);
+    const float fx = ((x + 1.0f) * (float)w - 1.0f) * 0.5f, fy = ((y + 1.0f) * (float)h - 1.0f) * 0.5f;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const bool finite = fx > -2.0f && fx < (float)w + 1.0f && fy > -2.0f && fy < (float)h + 1.0f;
+    const int x0 = finite ? (int)x0f : -5, y0 = finite ? (int)y0f : -5;
+    const bool vx = (x0 >= 0 && x0 < w) || (x0 + 1 >= 0 && x0 + 1 < w), vy = (y0 >= 0 && y0 < h) || (y0 + 1 >= 0 && y0 + 1 < h);
+    return (vx && vy) ? b * ((h + 1) * (w + 1)) + (y0 + 1) * (w + 1) + (x0 + 1) : nb - 1;
+}
+
+__global__ void __launch_bounds__(256) lq_zero_kernel(int* __restrict__ p, int n) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = 0;
+}
+
+__global__ void __launch_bounds__(256) lq_key_kernel(const LqSortK a) {
+    float zsign;
+    {
+        const float* c = a.calibs;
+        const float* p = a.pts;
+        const float hz = fmaf(c[8], p[0], fmaf(c[9], p[1], fmaf(c[10], p[2], c[11])));
+        zsign = hz < 0.0f ? -1.0f : 1.0f;
+    }
+    const long long total = (long long)a.B * a.N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / a.N);
+        const int key = lq_corner_key(a.calibs + (size_t)b * 12, a.pts + (size_t)i * 3, zsign, b, a.h, a.w, a.nb);
+        a.keys[i] = key;
+        atomicAdd(a.counts + key, 1);
+    }
+}
+
+// exclusive scan of the bin counts: one workgroup, a thread per chunk of consecutive bins
+__global__ void __launch_bounds__(1024) lq_scan_kernel(const LqSortK a) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, chunk = (a.nb + 1023) / 1024, b0 = tid * chunk, b1 = min(a.nb, b0 + chunk);
+    int sum = 0;
+    for (int i = b0; i < b1; ++i) sum += a.counts[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;
+    for (int i = b0; i < b1; ++i) { a.starts[i] = run; run += a.counts[i]; }
+}
+
+__global__ void __launch_bounds__(256) lq_scatter_kernel(const LqSortK a) {
+    const long long total = (long long)a.B * a.N;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int key = a.keys[i];
+        a.order[a.starts[key] + atomicAdd(a.cursor + key, 1)] = (int)i;
+    }
+}
+
 // out[m, col_off + ...] = [x(3), sin(f_0 x)(3), cos(f_0 x)(3), sin(f_1 x)(3), ...], f_k = 2^k
 __global__ void __launch_bounds__(256)
 pos_encoding_kernel(float* __restrict__ out, const float* __restrict__ pts, long long M, int n_freqs, int ld, int col_off) {
@@ -286,9 +375,49 @@ extern "C" int e3dge_local_query(float* out, int ld, int col_off, float* in_img,
     return check_launch("local_query");
 }
 
+static int local_query_bwd_launch(float* d_fmap_nhwc, float* d_pts, const float* d_out, int ld, int col_off, const float* pts,
+                                  const float* calibs, const float* fmap_nhwc, int batch, int64_t n_pts, int channels, int fh, int fw,
+                                  int* sort_ws, e3dge_stream_t stream);
+
 extern "C" int e3dge_local_query_bwd(float* d_fmap_nhwc, float* d_pts, const float* d_out, int ld, int col_off, const float* pts,
                                      const float* calibs, const float* fmap_nhwc, int batch, int64_t n_pts, int channels, int fh, int fw,
                                      e3dge_stream_t stream) {
+    return local_query_bwd_launch(d_fmap_nhwc, d_pts, d_out, ld, col_off, pts, calibs, fmap_nhwc, batch, n_pts, channels, fh, fw, nullptr, stream);
+}
+
+extern "C" int64_t e3dge_local_query_sort_ws_ints(int batch, int64_t n_pts, int fh, int fw) {
+    if (batch <= 0 || n_pts <= 0 || fh <= 0 || fw <= 0) return 0;
+    const int64_t nb = (int64_t)batch * (fh + 1) * (fw + 1) + 1;
+    return 2 * (int64_t)batch * n_pts + 3 * nb;                   // keys, order | counts, cursor, starts
+}
+
+extern "C" int e3dge_local_query_bwd_sorted(float* d_fmap_nhwc, float* d_pts, const float* d_out, int ld, int col_off, const float* pts,
+                                            const float* calibs, const float* fmap_nhwc, int batch, int64_t n_pts, int channels, int fh, int fw,
+                                            int* ws, int64_t ws_ints, e3dge_stream_t stream) {
+    E3DGE_REQUIRE(batch >= 0 && n_pts >= 0 && fh >= 1 && fw >= 1, "local_query_bwd_sorted: bad sizes");
+    if (batch == 0 || n_pts == 0 || (!d_fmap_nhwc && !d_pts)) return E3DGE_OK;
+    E3DGE_REQUIRE(ws && ws_ints >= e3dge_local_query_sort_ws_ints(batch, n_pts, fh, fw), "local_query_bwd_sorted: workspace too small");
+    E3DGE_REQUIRE((int64_t)batch * n_pts < ((int64_t)1 << 31) && (int64_t)batch * (fh + 1) * (fw + 1) < ((int64_t)1 << 30), "local_query_bwd_sorted: too many points / pixels for 32-bit keys");
+    E3DGE_REQUIRE(pts && calibs, "local_query_bwd_sorted: null pointer");
+    const int64_t total = (int64_t)batch * n_pts;
+    LqSortK k{};
+    k.pts = pts; k.calibs = calibs; k.N = n_pts; k.B = batch; k.h = fh; k.w = fw; k.nb = batch * (fh + 1) * (fw + 1) + 1;
+    k.keys = ws; k.order = ws + total; k.counts = ws + 2 * total; k.cursor = k.counts + k.nb; k.starts = k.cursor + k.nb;
+    hipStream_t st = as_stream(stream);
+    lq_zero_kernel<<<dim3((unsigned)((2 * k.nb + 255) / 256 > 1024 ? 1024 : (2 * k.nb + 255) / 256)), dim3(256), 0, st>>>(k.counts, 2 * k.nb);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    lq_key_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(k);
+    lq_scan_kernel<<<dim3(1), dim3(1024), 0, st>>>(k);
+    lq_scatter_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(k);
+    int rc = check_launch("local_query_bwd_sorted(sort)");
+    if (rc) return rc;
+    return local_query_bwd_launch(d_fmap_nhwc, d_pts, d_out, ld, col_off, pts, calibs, fmap_nhwc, batch, n_pts, channels, fh, fw, k.order, stream);
+}
+
+static int local_query_bwd_launch(float* d_fmap_nhwc, float* d_pts, const float* d_out, int ld, int col_off, const float* pts,
+                                  const float* calibs, const float* fmap_nhwc, int batch, int64_t n_pts, int channels, int fh, int fw,
+                                  int* sort_ws, e3dge_stream_t stream) {
     E3DGE_REQUIRE(batch >= 0 && n_pts >= 0, "local_query_bwd: bad sizes");
     if (batch == 0 || n_pts == 0 || (!d_fmap_nhwc && !d_pts)) return E3DGE_OK;
     E3DGE_REQUIRE(pts && calibs && d_out && fmap_nhwc, "local_query_bwd: null pointer");
@@ -297,7 +426,7 @@ extern "C" int e3dge_local_query_bwd(float* d_fmap_nhwc, float* d_pts, const flo
     E3DGE_REQUIRE((reinterpret_cast<uintptr_t>(fmap_nhwc) & 15) == 0 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0, "local_query_bwd: fmap / d_out must be 16-B aligned");
     LocalQueryBwdK k{};
     k.pts = pts; k.calibs = calibs; k.fmap = fmap_nhwc; k.d_out = d_out; k.d_fmap = d_fmap_nhwc; k.d_pts = d_pts; k.N = n_pts; k.B = batch;
-    k.C = channels; k.h = fh; k.w = fw; k.ld = ld; k.col_off = col_off;
+    k.C = channels; k.h = fh; k.w = fw; k.ld = ld; k.col_off = col_off; k.order = sort_ws;
     E3DGE_REQUIRE(channels <= 256, "local_query_bwd: at most 256 channels (four per lane)");
     int64_t blocks = (((int64_t)batch * n_pts + kLqRun - 1) / kLqRun + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;

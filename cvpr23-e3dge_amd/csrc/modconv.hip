@@ -477,8 +477,18 @@ modconv_demod_kernel(float* __restrict__ demod, float* __restrict__ s_amax, cons
 __global__ void __launch_bounds__(256) amax_kernel(float* __restrict__ out, const float* __restrict__ x, int64_t n) {
     __shared__ float part[4];
     float m = 0.0f;
-    const int64_t n4 = n >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // four independent 16-byte loads per trip (round 6: one load per trip streamed a 100-MB operand at 3.7 TB/s -- 25 us per launch, ten
+    // launches per stage-2 step -- where the element-wise kernels of this library reach 5-7)
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = reinterpret_cast<const f32x4*>(x)[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[k][0]), fabsf(v[k][1]))), fmaxf(fabsf(v[k][2]), fabsf(v[k][3])));
+    }
+    for (; i < n4; i += stride) {
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
@@ -626,7 +636,19 @@ __global__ void __launch_bounds__(256) amax_rows_kernel(float* __restrict__ out,
     __shared__ float part[4];
     float m = 0.0f;
     const int64_t n = n_rows * width;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 7 * stride < n; i += 8 * stride) {               // eight independent loads per trip
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t e = i + k * stride, r = e / width;
+            v[k] = x[r * ld + (e - r * width)];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m = fmaxf(m, fabsf(v[k]));
+    }
+    for (; i < n; i += stride) {
         const int64_t r = i / width;
         m = fmaxf(m, fabsf(x[r * ld + (i - r * width)]));
     }
@@ -641,8 +663,8 @@ __global__ void __launch_bounds__(256) amax_rows_kernel(float* __restrict__ out,
 extern "C" int e3dge_amax_rows(float* out, const float* x, int64_t n_rows, int width, int64_t ld, e3dge_stream_t stream) {
     E3DGE_REQUIRE(out && n_rows >= 0 && width >= 0 && ld >= width && (x || n_rows * width == 0), "amax_rows: bad arguments");
     if (n_rows * width == 0) return E3DGE_OK;
-    int64_t blocks = (n_rows * width + 1023) / 1024;
-    if (blocks > 2048) blocks = 2048;
+    int64_t blocks = (n_rows * width + 2047) / 2048;
+    if (blocks > 4096) blocks = 4096;
     amax_rows_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(out, x, n_rows, width, ld);
     return check_launch("amax_rows");
 }
@@ -651,8 +673,8 @@ extern "C" int e3dge_amax(float* out, const float* x, int64_t n, e3dge_stream_t 
     E3DGE_REQUIRE(out && (x || n == 0) && n >= 0, "amax: bad arguments");
     if (n == 0) return E3DGE_OK;
     E3DGE_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "amax: x must be 16-B aligned");
-    int64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
+    int64_t blocks = (n / 16 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     amax_kernel<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(out, x, n);
     return check_launch("amax");

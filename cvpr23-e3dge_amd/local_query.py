@@ -155,7 +155,12 @@ class _EncInFn(torch.autograd.Function):
         ld = g.shape[-1]
         p = pts.detach().contiguous()
         out = []
-        for need, fmap, calibs, off in ((ctx.needs_input_grad[4], que_map, que_calibs, 0), (ctx.needs_input_grad[5], ref_map, ref_calibs, ctx.n_enc)):
+        lib = _lib.load()
+        sort_ref = os.environ.get("E3DGE_GATHER_BWD_SORT", "1") != "0"
+        # (the points are samples along the QUERY view's rays: in that view's map a ray is one pixel and the kernel's run accumulation merges
+        # its samples; in the reference view's map every sample lands on its own pixel -- those are walked in pixel order instead)
+        for need, fmap, calibs, off, other_view in ((ctx.needs_input_grad[4], que_map, que_calibs, 0, False),
+                                                    (ctx.needs_input_grad[5], ref_map, ref_calibs, ctx.n_enc, True)):
             if not need:
                 out.append(None)
                 continue
@@ -164,8 +169,14 @@ class _EncInFn(torch.autograd.Function):
             d_fm = torch.zeros((B, h, w, C), device=g.device, dtype=torch.float32)
             c = calibs.detach()[:, :3, :4].contiguous()
             with torch.cuda.device(g.device):
-                rc = _lib.load().e3dge_local_query_bwd(_lib.ptr(d_fm), None, _lib.ptr(g), ld, off, _lib.ptr(p), _lib.ptr(c), _lib.ptr(fm),
-                                                       B, N, C, h, w, _lib.stream_of(g))
+                if other_view and sort_ref and B * N < 2 ** 31:
+                    n_ws = lib.e3dge_local_query_sort_ws_ints(B, N, h, w)
+                    ws = torch.empty(n_ws, device=g.device, dtype=torch.int32)
+                    rc = lib.e3dge_local_query_bwd_sorted(_lib.ptr(d_fm), None, _lib.ptr(g), ld, off, _lib.ptr(p), _lib.ptr(c), _lib.ptr(fm),
+                                                          B, N, C, h, w, _lib.ptr(ws), n_ws, _lib.stream_of(g))
+                else:
+                    rc = lib.e3dge_local_query_bwd(_lib.ptr(d_fm), None, _lib.ptr(g), ld, off, _lib.ptr(p), _lib.ptr(c), _lib.ptr(fm),
+                                                   B, N, C, h, w, _lib.stream_of(g))
             _lib.check(rc, "e3dge_local_query_bwd")
             out.append(d_fm.permute(0, 3, 1, 2))
         return None, None, None, None, out[0], out[1]

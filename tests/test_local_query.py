@@ -172,6 +172,32 @@ def test_gather_backward_against_float64_grid_sample(C, h, w, N):
     from conftest import record
     record("local_query_backward", C=C, h=h, w=w, N=N, **e)
     assert e['fwd'] <= 2e-5 and e['d_fmap'] <= 2e-5 and e['d_pts'] <= 1e-4, e
+    # round 6: the same scatter with the points walked in pixel order (e3dge_local_query_bwd_sorted: counting sort by corner pixel, then
+    # the same kernel on `order`) -- d map against float64 at the same bound, d points bit-identical (per-point arithmetic, order-free)
+    from e3dge_amd import _lib
+    lib = _lib.load()
+    gd = g_out.to(DEV).contiguous()
+    fm = fmap.to(DEV).permute(0, 2, 3, 1).contiguous()
+    pd, cd = pts.to(DEV).contiguous(), calib.to(DEV).contiguous()
+    res = {}
+    for name in ("plain", "sorted"):
+        d_fm = torch.zeros(B, h, w, C, device=DEV)
+        d_p = torch.empty(B, N, 3, device=DEV)
+        if name == "plain":
+            rc = lib.e3dge_local_query_bwd(_lib.ptr(d_fm), _lib.ptr(d_p), _lib.ptr(gd), C, 0, _lib.ptr(pd), _lib.ptr(cd), _lib.ptr(fm), B, N, C, h, w, None)
+        else:
+            n_ws = lib.e3dge_local_query_sort_ws_ints(B, N, h, w)
+            ws = torch.empty(n_ws, device=DEV, dtype=torch.int32)
+            rc = lib.e3dge_local_query_bwd_sorted(_lib.ptr(d_fm), _lib.ptr(d_p), _lib.ptr(gd), C, 0, _lib.ptr(pd), _lib.ptr(cd), _lib.ptr(fm), B, N, C, h, w,
+                                                  _lib.ptr(ws), n_ws, None)
+            order = ws[B * N:2 * B * N].long()
+            assert torch.equal(torch.sort(order).values, torch.arange(B * N, device=DEV)), "order is not a permutation"
+        assert rc == 0
+        torch.cuda.synchronize()
+        res[name] = (d_fm.permute(0, 3, 1, 2).cpu().double(), d_p.clone())
+    e2 = float((res["sorted"][0] - f64.grad).abs().max() / f64.grad.abs().max())
+    record("local_query_backward_sorted", C=C, h=h, w=w, N=N, d_fmap=e2)
+    assert e2 <= 2e-5 and torch.equal(res["sorted"][1], res["plain"][1]), e2
 
 
 @pytest.mark.gpu

@@ -41,7 +41,17 @@ def bwd(c, off):
                                          _lib.stream_of(g)), "bwd")
 
 
-out = {"que_view_ms": ms(lambda: bwd(cq, 0)), "ref_view_ms": ms(lambda: bwd(cr, 257)), "row_read_floor_ms_at_3p7TBps": round(N * 1024 / 3.7e9, 4)}
+n_ws = lib.e3dge_local_query_sort_ws_ints(1, N, 128, 128)
+ws = torch.empty(n_ws, device=dev, dtype=torch.int32)
+
+
+def bwd_sorted(c, off):
+    _lib.check(lib.e3dge_local_query_bwd_sorted(_lib.ptr(d_fm), None, _lib.ptr(g), 513, off, _lib.ptr(pts), _lib.ptr(c), _lib.ptr(fm), 1, N, 256, 128, 128,
+                                                _lib.ptr(ws), n_ws, _lib.stream_of(g)), "bwd_sorted")
+
+
+out = {"que_view_ms": ms(lambda: bwd(cq, 0)), "ref_view_ms": ms(lambda: bwd(cr, 257)),
+       "que_view_sorted_ms": ms(lambda: bwd_sorted(cq, 0)), "ref_view_sorted_ms": ms(lambda: bwd_sorted(cr, 257)), "row_read_floor_ms_at_3p7TBps": round(N * 1024 / 3.7e9, 4)}
 # how often the pixel changes along the 32-point runs
 with torch.no_grad():
     for name, c in (("que", cq), ("ref", cr)):
