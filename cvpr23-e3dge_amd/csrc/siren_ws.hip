@@ -92,27 +92,37 @@ __global__ void __launch_bounds__(kWsThreads) ws_linear_kernel(const WsLinK a) {
     // staging: this lane's 8 columns 32 wave + 8 q .. + 7 of the rows 16 t + n (t = 0..3) of a group
     // (two of the four row tiles at a time -- half = the LDS set they belong to: 16 staging registers live across a contraction)
     f32x4 sa[2], sb[2];
+    // Every load of this kernel is issued for ALL lanes from a clamped row (rows past the end re-read the last one and are zeroed by a
+    // select) and the loads of a phase go out back to back: a load inside `if (row < n_rows)` / `if (ok)` sits in a basic block of its own and
+    // the compiler's wait insertion drained the queue after each one -- 60 of the kernel's 80 vmcnt waits were vmcnt(0), every round trip to
+    // HBM exposed: 74-130 us per launch for 0.2-0.4 GB (round 6; the texture head's loads taught the same lesson in round 2).
+    const int64_t last_row = a.n_rows - 1;
     auto stage_load = [&](int64_t grp, int half) {
+        F4U u0[2], u1[2], m0[2], m1[2];
+        bool ok[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int64_t row = grp * kWlRows + 32 * half + 16 * t + n;
-            if (row < a.n_rows) {
-                const float* p = a.x + row * a.ld_x + a.off_x + 32 * wave + 8 * q;
-                const F4U u0 = *reinterpret_cast<const F4U*>(p), u1 = *reinterpret_cast<const F4U*>(p + 4);
-                sa[t] = f32x4{u0.v[0], u0.v[1], u0.v[2], u0.v[3]};
-                sb[t] = f32x4{u1.v[0], u1.v[1], u1.v[2], u1.v[3]};
-                if (a.xmul) {                                   // x <- x (.) xmul * x_scale  (d scale = w g (.) dec of the SFT fuse's backward)
-                    const float* m = a.xmul + row * a.ld_xmul + a.off_xmul + 32 * wave + 8 * q;
-                    const F4U m0 = *reinterpret_cast<const F4U*>(m), m1 = *reinterpret_cast<const F4U*>(m + 4);
+            ok[t] = row <= last_row;
+            const int64_t rc = ok[t] ? row : last_row;
+            const float* p = a.x + rc * a.ld_x + a.off_x + 32 * wave + 8 * q;
+            u0[t] = *reinterpret_cast<const F4U*>(p); u1[t] = *reinterpret_cast<const F4U*>(p + 4);
+        }
+        if (a.xmul) {                                       // x <- x (.) xmul * x_scale  (d scale = w g (.) dec of the SFT fuse's backward)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { sa[t][i] *= m0.v[i] * xs; sb[t][i] *= m1.v[i] * xs; }
-                } else if (xs != 1.0f) {
+            for (int t = 0; t < 2; ++t) {
+                const int64_t row = grp * kWlRows + 32 * half + 16 * t + n;
+                const float* m = a.xmul + (row <= last_row ? row : last_row) * a.ld_xmul + a.off_xmul + 32 * wave + 8 * q;
+                m0[t] = *reinterpret_cast<const F4U*>(m); m1[t] = *reinterpret_cast<const F4U*>(m + 4);
+            }
+        }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { sa[t][i] *= xs; sb[t][i] *= xs; }
-                }
-            } else {
-                sa[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                sb[t] = sa[t];
+        for (int t = 0; t < 2; ++t) {
+            const float z = ok[t] ? xs : 0.0f;               // (x_scale and the zeroing of rows past the end in one factor)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sa[t][i] = u0[t].v[i] * (a.xmul ? m0[t].v[i] * z : z);
+                sb[t][i] = u1[t].v[i] * (a.xmul ? m1[t].v[i] * z : z);
             }
         }
     };
@@ -215,32 +225,56 @@ __global__ void __launch_bounds__(kWsThreads) ws_linear_kernel(const WsLinK a) {
                         }
             }
             // ---- post: this lane's features 32 wave + 16 ft + 4 q .. + 3 of the rows 16 pt + n of the set ----
+            // (all residual loads of the set first, unconditional lanes on clamped rows -- see stage_load)
+            F4U d1[2][2], d2[2][2];
+            float mvs[2] = {0.0f, 0.0f};
+            bool okr[2];
+            int64_t rcl[2];
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
                 const int64_t row = grp * kWlRows + st * 32 + 16 * pt + n;
-                const bool ok = row < a.n_rows;
-                float mv = 0.0f;
-                if (a.m && ok) { mv = a.m[row * a.ld_m + a.off_m]; if (a.pre_relu) mv = fmaxf(mv, 0.0f); }
+                okr[pt] = row <= last_row;
+                rcl[pt] = okr[pt] ? row : last_row;
+            }
+            if (a.r1) {
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft) d1[pt][ft] = *reinterpret_cast<const F4U*>(a.r1 + rcl[pt] * a.ld_r1 + a.off_r1 + 32 * wave + 16 * ft + 4 * q);
+            }
+            if (a.r2) {
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+                    for (int ft = 0; ft < 2; ++ft) d2[pt][ft] = *reinterpret_cast<const F4U*>(a.r2 + rcl[pt] * a.ld_r2 + a.off_r2 + 32 * wave + 16 * ft + 4 * q);
+            }
+            if (a.m) {
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) { mvs[pt] = a.m[rcl[pt] * a.ld_m + a.off_m]; if (a.pre_relu) mvs[pt] = fmaxf(mvs[pt], 0.0f); }
+            }
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+                const int64_t row = rcl[pt];
+                const bool ok = okr[pt];
+                const float mv = mvs[pt];
 #pragma unroll
                 for (int ft = 0; ft < 2; ++ft) {
                     const int f0 = 32 * wave + 16 * ft + 4 * q;
                     const f32x4v b4 = *reinterpret_cast<const f32x4v*>(tab + f0), c4 = *reinterpret_cast<const f32x4v*>(tab + kWidth + f0);
-                    float v[4], d1[4] = {0.f, 0.f, 0.f, 0.f}, d2[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (a.r1 && ok) { const F4U u = *reinterpret_cast<const F4U*>(a.r1 + row * a.ld_r1 + a.off_r1 + f0); d1[0] = u.v[0]; d1[1] = u.v[1]; d1[2] = u.v[2]; d1[3] = u.v[3]; }
-                    if (a.r2 && ok) { const F4U u = *reinterpret_cast<const F4U*>(a.r2 + row * a.ld_r2 + a.off_r2 + f0); d2[0] = u.v[0]; d2[1] = u.v[1]; d2[2] = u.v[2]; d2[3] = u.v[3]; }
                     F4U out;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
+                        const float e1 = a.r1 ? d1[pt][ft].v[i] : 0.0f, e2 = a.r2 ? d2[pt][ft].v[i] : 0.0f;
                         float t = fmaf(acc.t[ft][pt][i], inv_row[pt], b4[i]);
                         t = fmaf(c4[i], mv, t);
                         if (a.post == 2) {
-                            t = fmaf(a.w_fuse, fmaf(d1[i], d2[i], t), d1[i]);                  // D + w (D S + shift)
+                            t = fmaf(a.w_fuse, fmaf(e1, e2, t), e1);                           // D + w (D S + shift)
                         } else if (a.post == 3) {
-                            t = fmaf(t, d1[i] > 0.0f ? 1.0f : a.slope, d2[i]);                  // act'(r1) * v + r2: the backward through lrelu / relu
+                            t = fmaf(t, e1 > 0.0f ? 1.0f : a.slope, e2);                        // act'(r1) * v + r2: the backward through lrelu / relu
                         } else if (a.post == 4) {
-                            t = fmaf(d1[i], fmaf(a.w_fuse, d2[i], 1.0f), t);                   // v + D (1 + w S): d dec of the SFT fuse
+                            t = fmaf(e1, fmaf(a.w_fuse, e2, 1.0f), t);                         // v + D (1 + w S): d dec of the SFT fuse
                         } else {
-                            t = (t + d1[i]) + d2[i];
+                            t = (t + e1) + e2;
                             if (a.post == 1) t = fmaxf(t, t * a.slope);                         // leaky relu, 0 <= slope <= 1
                         }
                         out.v[i] = t;
