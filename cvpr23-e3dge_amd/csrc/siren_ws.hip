@@ -252,6 +252,9 @@ __global__ void __launch_bounds__(kWsThreads) ws_linear_kernel(const WsLinK a) {
 #pragma unroll
                 for (int pt = 0; pt < 2; ++pt) { mvs[pt] = a.m[rcl[pt] * a.ld_m + a.off_m]; if (a.pre_relu) mvs[pt] = fmaxf(mvs[pt], 0.0f); }
             }
+            // (the next group's half is converted and written to LDS HERE, between the residual loads and their first use: ~150 VALU
+            // instructions under the loads' round trip instead of behind it)
+            if (has_next) stage_write(buf ^ 1, st);
 #pragma unroll
             for (int pt = 0; pt < 2; ++pt) {
                 const int64_t row = rcl[pt];
@@ -283,7 +286,6 @@ __global__ void __launch_bounds__(kWsThreads) ws_linear_kernel(const WsLinK a) {
                     if (ok) *reinterpret_cast<F4U*>(a.y + row * a.ld_y + a.off_y + f0) = out;
                 }
             }
-            if (has_next) stage_write(buf ^ 1, st);
         }
         __syncthreads();
     }
