@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(256) local_query_bwd_kernel(const LocalQueryBw
 // the launch is 1.57 M device-scope atomic instructions: 290 us, six times the query view's.  A counting sort by (image, corner pixel)
 // makes every pixel's ~6 points neighbours in `order`: a wave's run then flushes once per pixel.  Keys: (y0 + 1) (w + 1) + (x0 + 1) per
 // image, one more bin for points that touch no pixel (they sort to the end and are skipped).
-struct LqSortK { const float* pts; const float* calibs; int* keys; int* counts; int* starts; int* cursor; int* order; long long N; int B, h, w, nb; };
+struct LqSortK { const float* pts; const float* calibs; int* keys; int* counts; int* starts; int* cursor; int* order; long long N; int B, h, w, nb; };   // cursor: per-point ranks
 
 __device__ __forceinline__ int lq_corner_key(const float* c, const float* p, float zsign, int b, int h, int w, int nb) {
     // (the same arithmetic, in the same order, as local_query_bwd_kernel)
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256) lq_key_kernel(const LqSortK a) {
         const int b = (int)(i / a.N);
         const int key = lq_corner_key(a.calibs + (size_t)b * 12, a.pts + (size_t)i * 3, zsign, b, a.h, a.w, a.nb);
         a.keys[i] = key;
-        atomicAdd(a.counts + key, 1);
+        a.cursor[i] = atomicAdd(a.counts + key, 1);            // this point's rank inside its bin (the scatter then needs no atomics)
     }
 }
 
@@ -326,8 +326,7 @@ __global__ void __launch_bounds__(1024) lq_scan_kernel(const LqSortK a) {
 __global__ void __launch_bounds__(256) lq_scatter_kernel(const LqSortK a) {
     const long long total = (long long)a.B * a.N;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int key = a.keys[i];
-        a.order[a.starts[key] + atomicAdd(a.cursor + key, 1)] = (int)i;
+        a.order[a.starts[a.keys[i]] + a.cursor[i]] = (int)i;
     }
 }
 
@@ -388,7 +387,7 @@ extern "C" int e3dge_local_query_bwd(float* d_fmap_nhwc, float* d_pts, const flo
 extern "C" int64_t e3dge_local_query_sort_ws_ints(int batch, int64_t n_pts, int fh, int fw) {
     if (batch <= 0 || n_pts <= 0 || fh <= 0 || fw <= 0) return 0;
     const int64_t nb = (int64_t)batch * (fh + 1) * (fw + 1) + 1;
-    return 2 * (int64_t)batch * n_pts + 3 * nb;                   // keys, order | counts, cursor, starts
+    return 3 * (int64_t)batch * n_pts + 2 * nb;                   // keys, order, ranks | counts, starts
 }
 
 extern "C" int e3dge_local_query_bwd_sorted(float* d_fmap_nhwc, float* d_pts, const float* d_out, int ld, int col_off, const float* pts,
@@ -402,9 +401,9 @@ extern "C" int e3dge_local_query_bwd_sorted(float* d_fmap_nhwc, float* d_pts, co
     const int64_t total = (int64_t)batch * n_pts;
     LqSortK k{};
     k.pts = pts; k.calibs = calibs; k.N = n_pts; k.B = batch; k.h = fh; k.w = fw; k.nb = batch * (fh + 1) * (fw + 1) + 1;
-    k.keys = ws; k.order = ws + total; k.counts = ws + 2 * total; k.cursor = k.counts + k.nb; k.starts = k.cursor + k.nb;
+    k.keys = ws; k.order = ws + total; k.cursor = ws + 2 * total; k.counts = ws + 3 * total; k.starts = k.counts + k.nb;
     hipStream_t st = as_stream(stream);
-    lq_zero_kernel<<<dim3((unsigned)((2 * k.nb + 255) / 256 > 1024 ? 1024 : (2 * k.nb + 255) / 256)), dim3(256), 0, st>>>(k.counts, 2 * k.nb);
+    lq_zero_kernel<<<dim3((unsigned)((k.nb + 255) / 256 > 1024 ? 1024 : (k.nb + 255) / 256)), dim3(256), 0, st>>>(k.counts, k.nb);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     lq_key_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(k);

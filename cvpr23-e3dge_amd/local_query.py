@@ -139,7 +139,10 @@ class _EncInFn(torch.autograd.Function):
             _, in_img, _ = query_feature_map(pts.detach(), ref_calibs.detach(), ref_map.detach(), out=enc_in, col_off=n_enc)
             if vis is not None:
                 enc_in[..., C] = vis
-        ctx.save_for_backward(pts, que_calibs, ref_calibs, que_map, ref_map)
+        # (the backward never reads the maps' VALUES -- d map is a scatter of the incoming rows, and no gradient goes to the points here --
+        # so it needs neither the maps nor their channel-last copies: 25 us per 16-MB transposing copy, twice per step, gone)
+        ctx.map_shapes = (tuple(que_map.shape), tuple(ref_map.shape))
+        ctx.save_for_backward(pts, que_calibs, ref_calibs)
         ctx.n_enc = n_enc
         ctx.mark_non_differentiable(in_img)
         return enc_in, in_img
@@ -147,7 +150,7 @@ class _EncInFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_enc, _d_mask):
-        pts, que_calibs, ref_calibs, que_map, ref_map = ctx.saved_tensors
+        pts, que_calibs, ref_calibs = ctx.saved_tensors
         B, N, _ = pts.shape
         g = d_enc.float()
         if not g.is_contiguous():
@@ -159,14 +162,14 @@ class _EncInFn(torch.autograd.Function):
         sort_ref = os.environ.get("E3DGE_GATHER_BWD_SORT", "1") != "0"
         # (the points are samples along the QUERY view's rays: in that view's map a ray is one pixel and the kernel's run accumulation merges
         # its samples; in the reference view's map every sample lands on its own pixel -- those are walked in pixel order instead)
-        for need, fmap, calibs, off, other_view in ((ctx.needs_input_grad[4], que_map, que_calibs, 0, False),
-                                                    (ctx.needs_input_grad[5], ref_map, ref_calibs, ctx.n_enc, True)):
+        for need, shape, calibs, off, other_view in ((ctx.needs_input_grad[4], ctx.map_shapes[0], que_calibs, 0, False),
+                                                     (ctx.needs_input_grad[5], ctx.map_shapes[1], ref_calibs, ctx.n_enc, True)):
             if not need:
                 out.append(None)
                 continue
-            C, h, w = fmap.shape[1:]
-            fm = fmap.detach().permute(0, 2, 3, 1).contiguous()
+            C, h, w = shape[1:]
             d_fm = torch.zeros((B, h, w, C), device=g.device, dtype=torch.float32)
+            fm = d_fm                                            # (fmap_nhwc is only read for d pts, which this node does not produce; any valid pointer)
             c = calibs.detach()[:, :3, :4].contiguous()
             with torch.cuda.device(g.device):
                 if other_view and sort_ref and B * N < 2 ** 31:
@@ -245,7 +248,7 @@ class Fuse_sft_MLP(nn.Module):
             if out is None and fuse_autograd_backend() == "hip" and self._fusefn_ok(enc_in, dec_feat, w):
                 # training (round 4): the same nine launches as the forward of an autograd node; its backward is library GEMMs on
                 # the intermediates the launches left behind (the 3D-projected block of enc_in IS dec_feat, as on the inference path)
-                return _FuseFn.apply(self, enc_in, float(w), None, 0, *self._param_list())
+                return _FuseFn.apply(self, enc_in, float(w), None, 0, False, *self._param_list())
         e = self.encode_enc(enc_in)
         res = dec_feat + w * (dec_feat * self.scale(e) + self.shift(e))
         if out is None:
@@ -334,7 +337,7 @@ class Fuse_sft_MLP(nn.Module):
                      f0a_t=img_t(f0[:, :256]), f0b_t=img_t(f0[:, b_off:]))
         return I
 
-    def _fuse_bwd_native(self, g, x, net, s1, t1, scale, am_x, w, b_off, slope, need_x, ld_g=256):
+    def _fuse_bwd_native(self, g, x, net, s1, t1, scale, am_x, w, b_off, slope, need_x, ld_g=256, mask_col=True):
         """The data-gradient chain of sft.py:84-109 + resnetfc.py:49-58 as e3dge_ws_linear launches on the transposed images (round 5):
         dz1 = (w g . dec) Wsc2 . lrelu'(s1), dz2 = (w g) Wsh2 . lrelu'(t1), de = dz1 Wsc1 + dz2 Wsh1, dnet = de W1 . [net > 0],
         dx = de Ws + (dnet W0) . [x > 0], dx[dec block] += g (1 + w scale).  Returns (dz1, dz2, de, dnet, dx or None, the amax buffers of g / dz1 / dz2 / de / dnet).
@@ -377,7 +380,9 @@ class Fuse_sft_MLP(nn.Module):
                 lin(I['f0a_t'], dnet, am[4], dx, ld_y=ld, off_y=0, post=3, sl=0.0, r1=x, r1_ld=ld, r1_off=0, r2=dx, r2_ld=ld, r2_off=0)
                 lin(I['sb_t'], de, am[3], dx, ld_y=ld, off_y=b_off, post=4, r1=g, r1_ld=ld_g, r2=scale)
                 lin(I['f0b_t'], dnet, am[4], dx, ld_y=ld, off_y=b_off, post=3, sl=0.0, r1=x, r1_ld=ld, r1_off=b_off, r2=dx, r2_ld=ld, r2_off=b_off)
-            if need_x and I['has_col']:
+            if need_x and I['has_col'] and not mask_col:
+                dx[:, 256].zero_()
+            if need_x and I['has_col'] and mask_col:
                 # the visibility-mask column (one input column of fc_0 and of the shortcut): two row dot products in one launch
                 _lib.check(lib.e3dge_ws_rowdot2(_lib.ptr(dx), ld, 256, _lib.ptr(de), _lib.ptr(I['scol']), _lib.ptr(dnet), _lib.ptr(I['f0col']),
                                                 _lib.ptr(x), ld, 256, N, st), "e3dge_ws_rowdot2")
@@ -447,10 +452,12 @@ class _FuseFn(torch.autograd.Function):
     E3DGE_FUSE_BWD=torch keeps round 4's library GEMMs), the thirteen parameter gradients stay library GEMMs.  Not double-differentiable."""
 
     @staticmethod
-    def forward(ctx, mod, enc_in, w, pe_pts, n_freqs, *params):
+    def forward(ctx, mod, enc_in, w, pe_pts, n_freqs, mask_col_const, *params):
         """pe_pts (round 6): None, or the points (.., 3) whose positional encoding (PosEncoding.forward, misc_utils.py:148-185) fills the
         columns behind the 256 fused ones -- the node then returns the assembled (.., 256 + 3 (2 n_freqs + 1)) feature rows, written in place
-        (no torch.cat), and its backward reads the first 256 gradient columns in place (no .contiguous())."""
+        (no torch.cat), and its backward reads the first 256 gradient columns in place (no .contiguous()).
+        mask_col_const: the caller guarantees that nothing differentiates through column 256 of a 513-wide enc_in (the visibility mask written
+        by _EncInFn): its gradient is returned as zeros instead of the two row dot products of e3dge_ws_rowdot2 (50 us at 98,304 points)."""
         keep = {}
         with torch.no_grad():
             if pe_pts is None:
@@ -460,7 +467,7 @@ class _FuseFn(torch.autograd.Function):
                 out = torch.empty(enc_in.shape[:-1] + (256 + width,), device=enc_in.device, dtype=torch.float32)
                 mod._fuse_native(enc_in.detach(), w, out, 0, keep=keep)
                 pos_encoding(pe_pts.detach(), n_freqs, out=out.reshape(-1, 256 + width), col_off=256)
-        ctx.mod, ctx.w, ctx.in_shape = mod, w, enc_in.shape
+        ctx.mod, ctx.w, ctx.in_shape, ctx.mask_col_const = mod, w, enc_in.shape, bool(mask_col_const)
         ctx.b_off, ctx.slope, ctx.am_x, ctx.am_fwd = keep['b_off'], keep['slope'], keep['am_x'], keep['am']
         ctx.save_for_backward(keep['x'], keep['net'], keep['e'], keep['s1'], keep['t1'], keep['scale'], *params)
         return out
@@ -471,7 +478,7 @@ class _FuseFn(torch.autograd.Function):
         x, net, e, s1, t1, scale = ctx.saved_tensors[:6]
         W0, _, W1, _, Ws, Wsc1, _, Wsc2, _, Wsh1, _, Wsh2, _ = ctx.saved_tensors[6:]
         w, b_off, slope = ctx.w, ctx.b_off, ctx.slope
-        need = ctx.needs_input_grad[5:]
+        need = ctx.needs_input_grad[6:]
         need_x = ctx.needs_input_grad[1]
         g_rows = grad_out.reshape(-1, grad_out.shape[-1]).float()
         if g_rows.stride(-1) != 1 or (g_rows.shape[0] > 1 and g_rows.stride(0) < g_rows.shape[1]) or g_rows.data_ptr() % 4:
@@ -484,12 +491,14 @@ class _FuseFn(torch.autograd.Function):
         if os.environ.get("E3DGE_FUSE_BWD", "hip") == "hip":
             # round 5: the data-gradient chain as nine e3dge_ws_linear launches on the transposed weight images; the thirteen parameter
             # gradients (reductions over the points: library GEMMs with K = number of points) only when a parameter wants one
-            dz1, dz2, de, dnet, dx, am_b = ctx.mod._fuse_bwd_native(g, x, net, s1, t1, scale, ctx.am_x, w, b_off, slope, need_x, ld_g=ld_g)
+            dz1, dz2, de, dnet, dx, am_b = ctx.mod._fuse_bwd_native(g, x, net, s1, t1, scale, ctx.am_x, w, b_off, slope, need_x, ld_g=ld_g,
+                                                                    mask_col=not ctx.mask_col_const)
             if any(need):
                 # the seven weight gradients: e3dge_wgrad (split-f16 MFMA, split over the points, fixed-order fold; E3DGE_WGRAD=library = matmul),
                 # the relu of a layer's input folded into the operand load
                 from .wgrad import amax_of, wgrad
-                d_scale, d_shift = (w * g) * dec, w * g
+                d_shift = g if w == 1.0 else w * g                # (a view of the incoming gradient rows when w = 1: e3dge_wgrad takes any row pitch)
+                d_scale = d_shift * dec
                 # amax buffers the two chains already hold: the forward's (x, net, e, s1, t1), the backward's (g, dz1, dz2, de, dnet); d shift = w g
                 af = ctx.am_fwd
                 am = {id(x): af[0], id(net): af[1], id(e): af[2], id(s1): af[3], id(t1): af[4],
@@ -518,7 +527,7 @@ class _FuseFn(torch.autograd.Function):
                 wg(2, 3, de, net, True)
                 wg(4, None, de, x, gap_col=gap)
                 wg(0, 1, dnet, x, True, gap_col=gap)
-            return (None, dx.reshape(ctx.in_shape) if dx is not None else None, None, None, None, *gp)
+            return (None, dx.reshape(ctx.in_shape) if dx is not None else None, None, None, None, None, *gp)
         d_scale, d_shift = (w * g) * dec, w * g                   # out = dec + w (dec scale + shift)
         # scale = W2 lrelu(W1 e + b1) + b2 ; shift likewise
         dz1 = (d_scale @ Wsc2) * torch.where(s1 > 0, 1.0, slope)
@@ -544,7 +553,7 @@ class _FuseFn(torch.autograd.Function):
             dx = de @ Ws + (dnet @ W0) * (x > 0)
             dx[:, b_off:] += g * (1.0 + w * scale)
             dx = dx.reshape(ctx.in_shape)
-        return (None, dx, None, None, None, *gp)
+        return (None, dx, None, None, None, None, *gp)
 
 
 def local_features_from_maps(local_data_batch, n_freqs=7):
@@ -577,7 +586,7 @@ def local_features_from_maps(local_data_batch, n_freqs=7):
             # round 6: two nodes instead of eight -- the row buffers are written and read in place (E3DGE_LOCAL_FEATS_NODES=composed: as before)
             enc_in, in_img = _EncInFn.apply(pts, local_data_batch['que_calibs'], local_data_batch['ref_calibs'], vis_rows, maps['que'], maps['ref'])
             if fuse._native_ok(enc_in) and fuse._wants_grad(enc_in):
-                feats = _FuseFn.apply(fuse, enc_in, 1.0, pts, n_freqs, *fuse._param_list())
+                feats = _FuseFn.apply(fuse, enc_in, 1.0, pts, n_freqs, True, *fuse._param_list())
                 return feats.reshape(B, H, W, S, feats.shape[-1]), in_img.reshape(B, H, W, S, 1)
         a, _, _ = query_feature_map(pts, local_data_batch['que_calibs'], maps['que'])
         dec, in_img, _ = query_feature_map(pts, local_data_batch['ref_calibs'], maps['ref'])

@@ -615,7 +615,7 @@ int e3dge_local_query_bwd(float* d_fmap_nhwc, float* d_pts, const float* d_out, 
 /* ABI 14 (round 6): the same with the points walked in the order of a counting sort by (image, pixel of the top-left corner) -- for gathers
  * whose consecutive points do NOT share pixels (another view's rays: every sample of the reference-view gather lands on its own pixel, and the
  * scatter is then one device-scope atomic instruction per corner, channel group and point).  ws: e3dge_local_query_sort_ws_ints(...) ints of
- * scratch (keys, order, bin counters); five launches (zero, key + count, scan, scatter, the gather's backward on `order`).  Sums within a pixel
+ * scratch (keys, order, ranks, bin counters); five launches (zero, key + count + rank, scan, scatter, the gather's backward on `order`).  Sums within a pixel
  * arrive in an order that varies from run to run, like the atomics' of the unsorted form. */
 int64_t e3dge_local_query_sort_ws_ints(int batch, int64_t n_pts, int fh, int fw);
 int e3dge_local_query_bwd_sorted(float* d_fmap_nhwc, float* d_pts, const float* d_out, int ld, int col_off, const float* pts,

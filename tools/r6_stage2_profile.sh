@@ -14,7 +14,7 @@ for r in rows:
     a = agg[name]; a[0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); a[1] += 1
 tot = sum(v[0] for v in agg.values())
 out = [f"stage-2 step (tools/stage2_step.py): kernel time per step by kernel name, {steps} steps in the trace; total {tot / steps / 1e6:.3f} ms of kernels per step"]
-for name, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:28]:
+for name, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(__import__('os').environ.get('TOPN', '28'))]:
     out.append(f"{name:<70} {v[0] / steps / 1e3:>9.1f} us/step {v[1] / steps:>6.1f} launches/step {100 * v[0] / tot:>6.2f} %")
 open("gpurun_out/r6_stage2_step_by_kernel.txt", "w").write("\n".join(out) + "\n")
 print("\n".join(out))
