@@ -181,7 +181,7 @@ SIGNATURES = {
     "e3dge_resblock_bwd_packed_floats": (_i64, []),
     "e3dge_resblock_bwd_pack_weights": (_i32, [_vp] * 5 + [_i32, _vp]),
     "e3dge_tex_modulations_bwd_ws_floats": (_i64, [_i64]),
-    "e3dge_tex_modulations_bwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "e3dge_tex_modulations_bwd": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "e3dge_wgrad_ws_floats": (_i64, [_i32, _i32, _i64]),
     "e3dge_wgrad": (_i32, [_vp, _vp]),
     "e3dge_local_query": (_i32, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]),

@@ -694,7 +694,7 @@ extern "C" int e3dge_resblock_bwd_pack_weights(float* packed, const float* w0, c
 extern "C" int64_t e3dge_tex_modulations_bwd_ws_floats(int64_t n_pts) { return n_pts > 0 ? 2 * n_pts * (int64_t)kRbWsRow : 0; }
 
 extern "C" int e3dge_tex_modulations_bwd(const float* packed_bwd, const float* feats, int cin, int64_t n_pts, const float* d_alpha,
-                                         const float* d_beta, float* d_feats, float* ws, float* net_out, e3dge_stream_t stream) {
+                                         const float* d_beta, float* d_feats, float* ws, float* net_out, float* amax4, e3dge_stream_t stream) {
     E3DGE_REQUIRE(n_pts >= 0, "tex_modulations_bwd: bad size");
     if (n_pts == 0) return E3DGE_OK;
     E3DGE_REQUIRE(packed_bwd && feats && d_alpha && d_beta && d_feats && ws, "tex_modulations_bwd: null pointer");
@@ -702,7 +702,7 @@ extern "C" int e3dge_tex_modulations_bwd(const float* packed_bwd, const float* f
     E3DGE_REQUIRE(((reinterpret_cast<uintptr_t>(packed_bwd) | reinterpret_cast<uintptr_t>(d_alpha) | reinterpret_cast<uintptr_t>(d_beta) | reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(net_out)) & 15) == 0,
                   "tex_modulations_bwd: packed / d_alpha / d_beta / ws / net_out must be 16-B aligned");
     ResblockBwdK k{};
-    k.packed = packed_bwd; k.feats = feats; k.d_alpha = d_alpha; k.d_beta = d_beta; k.d_feats = d_feats; k.ws = ws; k.net_out = net_out;
+    k.packed = packed_bwd; k.feats = feats; k.d_alpha = d_alpha; k.d_beta = d_beta; k.d_feats = d_feats; k.ws = ws; k.net_out = net_out; k.amax4 = amax4;
     k.n_pts = n_pts; k.cin = cin;
     hipStream_t st = as_stream(stream);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kRbBLdsBytes);

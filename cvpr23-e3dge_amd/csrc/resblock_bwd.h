@@ -114,9 +114,18 @@ struct ResblockBwdK {
     float* d_feats;             // (n_pts, cin) out
     float* ws;                  // 2 x (n_pts, 320): d net (valid on return, rows padded to 320) | W_s^T d out
     float* net_out;             // null, or (n_pts, 320): net as recomputed by G1
+    float* amax4;               // null, or four amax buffers (zeroed by the caller): max |feats|, |d out|, |d net|, |net| -- the operand scales of e3dge_wgrad
     long long n_pts;
     int cin, subtiles_per_wg;
 };
+
+// the wave's largest value into an amax buffer (round 6: the kernel holds every operand of the head's parameter gradients anyway; four
+// e3dge_amax passes over 100-MB tensors -- 120 us per stage-2 step -- are not needed)
+__device__ __forceinline__ void rb_amax_publish(float* buf, float m, int lane, int slot) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+    if (lane == 0) atomic_max_nonneg(buf + (slot & (kAmaxSlots - 1)) * kAmaxStride, m);
+}
 
 // power-of-two block scale of a point whose largest magnitude is m: operand = value * sc in [1, 2), accumulator * inv = true sum (the
 // weight image carries kW16Scale = 128); the forward's rule (resblock_kernel, "x")
@@ -249,6 +258,7 @@ __global__ void __launch_bounds__(kThreads) resblock_bwd_kernel(const ResblockBw
                     msk[w * kThreads + tid] = word;
                 }
                 m = fmaxf(m, xhalf(m));
+                if (a.amax4) rb_amax_publish(a.amax4, m, lane, (int)blockIdx.x * 4 + wave);
                 float sc;
                 rb_block_scale(m, sc, inv_x);
 #pragma unroll
@@ -260,6 +270,7 @@ __global__ void __launch_bounds__(kThreads) resblock_bwd_kernel(const ResblockBw
             }
             // ---- 2. G1: net = W_0 relu(x) + b_0, signs only ----
             unsigned word = 0u;
+            float m_n = 0.0f;
 #pragma unroll 1
             for (int t = 0; t < kRbTilesIn; ++t) {
                 P0 = zero16(); P1 = zero16();
@@ -283,11 +294,13 @@ __global__ void __launch_bounds__(kThreads) resblock_bwd_kernel(const ResblockBw
                     for (int j = 0; j < 4; ++j) {
                         nv[j] = (P0[4 * q + j] + P1[4 * q + j]) * inv_x + b4[j];      // the forward's expression for net
                         rb_push_sign(word, nv[j]);
+                        m_n = fmaxf(m_n, fabsf(nv[j]));
                     }
                     if (a.net_out && valid) *reinterpret_cast<f32x4*>(a.net_out + (pt0 * kRbWsRow + row_off + 32u * t + 8 * q)) = nv;
                 }
                 if (t & 1) { msk[((kRbTilesIn / 2) + (t >> 1)) * kThreads + tid] = word; word = 0u; }
             }
+            if (a.amax4 && a.net_out) rb_amax_publish(a.amax4 + 3 * E3DGE_AMAX_FLOATS, m_n, lane, (int)blockIdx.x * 4 + wave);
         }
 
         // ---- 3. d out resident: register 4q + j of tile T = column 32 T + 8 q + 4 half + j of [d alpha | d beta] ----
@@ -307,6 +320,7 @@ __global__ void __launch_bounds__(kThreads) resblock_bwd_kernel(const ResblockBw
                 }
             }
             m = fmaxf(m, xhalf(m));
+            if (a.amax4) rb_amax_publish(a.amax4 + E3DGE_AMAX_FLOATS, m, lane, (int)blockIdx.x * 4 + wave);
             float sc_y;
             rb_block_scale(m, sc_y, inv_y);
 #pragma unroll
@@ -355,6 +369,7 @@ __global__ void __launch_bounds__(kThreads) resblock_bwd_kernel(const ResblockBw
                 if (valid) *reinterpret_cast<f32x4*>(dst + 8 * q) = o4;
             }
         }
+        if (a.amax4) rb_amax_publish(a.amax4 + 2 * E3DGE_AMAX_FLOATS, m_d, lane, (int)blockIdx.x * 4 + wave);
         // ---- 5. G4: W_s^T d out -> second workspace ----
 #pragma unroll 1
         for (int t = 0; t < kRbTilesIn; ++t) {

@@ -812,22 +812,27 @@ class _TexHead(torch.autograd.Function):
                     dw1 if need[4] else None, db1 if need[5] else None, dws if need[6] else None)
         from .wgrad import amax_of, wgrad
         d_alpha, d_beta = d_alpha.contiguous().float(), d_beta.contiguous().float()
-        dx, dnet_p, net_p = ctx.block._launch_bwd(x, d_alpha, d_beta, want_net=need[4])      # (n, 320) rows, columns >= cin zero
+        trainable = any(need[2:])
+        r_ = ctx.block._launch_bwd(x, d_alpha, d_beta, want_net=need[4], want_amax=trainable)      # (n, 320) rows, columns >= cin zero
+        dx, dnet_p, net_p = r_[:3]
         dw0 = db0 = dw1 = db1 = dws = None
         cin = x.shape[1]
         dnet = dnet_p[:, :cin]
-        am_x = amax_of(x) if (need[2] or need[6]) else None
-        am_a, am_b = (amax_of(d_alpha), amax_of(d_beta)) if (need[4] or need[6]) else (None, None)
+        # (round 6: the operand scales of the five weight gradients come out of the backward launch itself -- max |x|, max |[d alpha | d beta]|
+        # (one bound for both halves), max |d net|, max |net|: five e3dge_amax passes over 100-MB tensors less)
+        am4 = r_[3] if trainable else None
+        am_x = am4[0] if trainable else None
+        am_a = am_b = am4[1] if trainable else None
         # (round 6: the bias gradients -- column sums of d net / d out -- come from the weight gradient's pass over the same rows)
         if need[2]:
-            r = wgrad(dnet, x, relu_b=True, amax_a=amax_of(dnet_p), amax_b=am_x, colsum=need[3])     # d net^T relu(x)
+            r = wgrad(dnet, x, relu_b=True, amax_a=am4[2], amax_b=am_x, colsum=need[3])     # d net^T relu(x)
             dw0, db0 = r if need[3] else (r, None)
         elif need[3]:
             db0 = dnet_p.sum(0)[:cin]                                             # (the contiguous rows: a strided view reduces 25x slower)
         db1a = db1b = None
         if need[4]:                                                               # d out^T relu(net), net as the backward kernel recomputed it
             dw1 = torch.empty((512, cin), device=x.device, dtype=torch.float32)
-            am_n, net = amax_of(net_p), net_p[:, :cin]
+            am_n, net = am4[3], net_p[:, :cin]
             ra = wgrad(d_alpha, net, relu_b=True, amax_a=am_a, amax_b=am_n, out=dw1[:256], colsum=need[5])
             rb = wgrad(d_beta, net, relu_b=True, amax_a=am_b, amax_b=am_n, out=dw1[256:], colsum=need[5])
             if need[5]:
@@ -936,9 +941,9 @@ class ResnetBlockFC(nn.Module):
             st["event"] = None
             self._raise_if_out_of_range(float(st["host"][0]))
 
-    def _launch_bwd(self, x, d_alpha, d_beta, want_net=False):
+    def _launch_bwd(self, x, d_alpha, d_beta, want_net=False, want_amax=False):
         """x (n, size_in), d_alpha / d_beta (n, 256), contiguous fp32 on the GPU -> (d x (n, size_in), d net as (n, 320) rows of the workspace
-        (columns >= size_in are zero), net likewise or None)."""
+        (columns >= size_in are zero), net likewise or None[, amax buffers (4, AMAX_FLOATS) of x, d out, d net, net from the same launch])."""
         _lib.require_gpu(x, "feats")
         n = x.shape[0]
         lib = _lib.load()
@@ -947,10 +952,13 @@ class ResnetBlockFC(nn.Module):
         dx = torch.empty_like(x)
         ws = torch.empty(lib.e3dge_tex_modulations_bwd_ws_floats(n), device=x.device, dtype=torch.float32)
         net = torch.empty((n, 320), device=x.device, dtype=torch.float32) if want_net else None
+        am = torch.zeros((4, _lib.AMAX_FLOATS), device=x.device, dtype=torch.float32) if want_amax else None
         with _lib.on_device(x.device):
             rc = lib.e3dge_tex_modulations_bwd(_lib.ptr(packed), _lib.ptr(x), self.size_in, n, _lib.ptr(d_alpha), _lib.ptr(d_beta),
-                                               _lib.ptr(dx), _lib.ptr(ws), _lib.ptr(net) if want_net else None, _lib.stream_of(x))
+                                               _lib.ptr(dx), _lib.ptr(ws), _lib.ptr(net) if want_net else None, _lib.ptr(am), _lib.stream_of(x))
         _lib.check(rc, "e3dge_tex_modulations_bwd")
+        if want_amax:
+            return dx, ws[:n * 320].view(n, 320), net, am
         return dx, ws[:n * 320].view(n, 320), net
 
     def forward(self, x):

@@ -573,13 +573,15 @@ int e3dge_tex_modulations_fwd(const float* packed, const float* feats, int cin, 
  *   d_alpha, d_beta (n_pts, 256), 16-byte aligned     d_feats (n_pts, cin) out
  *   ws           e3dge_tex_modulations_bwd_ws_floats(n_pts) floats, 16-byte aligned; on return ws[0 .. n_pts * 320) holds d net = d L / d (fc_0
  *                output) as (n_pts, 320) rows (columns >= cin are zero) -- the operand of the parameter gradients (e3dge_wgrad)
- *   net_out      NULL, or (n_pts, 320) rows receiving net = fc_0(relu(x)) as recomputed (the input of fc_1's parameter gradient, before its relu) */
+ *   net_out      NULL, or (n_pts, 320) rows receiving net = fc_0(relu(x)) as recomputed (the input of fc_1's parameter gradient, before its relu)
+ *   amax4        (ABI 14) NULL, or 4 x E3DGE_AMAX_FLOATS floats, zeroed by the caller: amax buffers of feats, [d alpha | d beta], d net and net (the
+ *                last only with net_out) -- the operand scales e3dge_wgrad needs, from values this launch holds anyway */
 int64_t e3dge_resblock_bwd_packed_floats(void);
 int e3dge_resblock_bwd_pack_weights(float* packed_bwd, const float* w0, const float* b0, const float* w1, const float* ws, int cin,
                                     e3dge_stream_t stream);
 int64_t e3dge_tex_modulations_bwd_ws_floats(int64_t n_pts);
 int e3dge_tex_modulations_bwd(const float* packed_bwd, const float* feats, int cin, int64_t n_pts, const float* d_alpha, const float* d_beta,
-                              float* d_feats, float* ws, float* net_out, e3dge_stream_t stream);
+                              float* d_feats, float* ws, float* net_out, float* amax4, e3dge_stream_t stream);
 /* The head INSIDE the second render pass's data flow (ABI 11; SURVEY.md 8 f1 as specified: (alpha, beta) never materialise):
  * feats (batch, height, width, n_samples, cin) -> h' = (alpha + 1) h8 + beta, where h8 is the layer-7 output that render
  * pass #1 left in `backbone_in` (e3dge_siren_render_fwd backbone_out, e3dge_siren_backbone_bytes bytes) -- the FiLM step of

@@ -245,9 +245,9 @@ int main(void) {
     assert lib.e3dge_wgrad(ctypes.byref(G(xcol=one, ld_xcol=1, **ok)), None) == -1                      # xcol without ccol
     assert lib.e3dge_tex_modulations_bwd_ws_floats(1000) == 2 * 1000 * 320 and lib.e3dge_tex_modulations_bwd_ws_floats(0) == 0
     assert lib.e3dge_resblock_bwd_packed_floats() == 120 * 5120 + 320
-    assert lib.e3dge_tex_modulations_bwd(None, None, 301, 5, None, None, None, None, None, None) == -1
-    assert lib.e3dge_tex_modulations_bwd(one, one, 321, 5, one, one, one, one, None, None) == -1       # cin > 320
-    assert lib.e3dge_tex_modulations_bwd(None, None, 301, 0, None, None, None, None, None, None) == 0   # nothing to do
+    assert lib.e3dge_tex_modulations_bwd(None, None, 301, 5, None, None, None, None, None, None, None) == -1
+    assert lib.e3dge_tex_modulations_bwd(one, one, 321, 5, one, one, one, one, None, None, None) == -1       # cin > 320
+    assert lib.e3dge_tex_modulations_bwd(None, None, 301, 0, None, None, None, None, None, None, None) == 0   # nothing to do
     assert lib.e3dge_resblock_bwd_pack_weights(None, None, None, None, None, 301, None) == -1
 
 

@@ -514,3 +514,20 @@ def test_head_and_film_in_one_launch_is_bit_identical(res, S, B, monkeypatch):
     out = r(poses, focal, near, far, styles=wr, local_data_batch={'feats': f2})
     out['features'].square().mean().backward()
     assert f2.grad is not None and torch.isfinite(f2.grad).all() and float(f2.grad.abs().max()) > 0
+
+
+def test_backward_launch_reports_the_operand_maxima():
+    """Round 6: e3dge_tex_modulations_bwd writes the four amax buffers e3dge_wgrad needs (max |x|, |[d alpha | d beta]|, |d net|, |net|) from the
+    values it holds anyway -- they must equal the maxima of the tensors it read / left behind, exactly (3,000 points: a ragged last sub-tile)."""
+    h, _ = make_head(301)
+    rs = np.random.RandomState(21)
+    n = 3000
+    x = torch.from_numpy((3.0 * rs.standard_normal((n, 301))).astype(np.float32)).to(DEV)
+    ga = torch.from_numpy((1e-3 * rs.standard_normal((n, 256))).astype(np.float32)).to(DEV)
+    gb = torch.from_numpy((2e-3 * rs.standard_normal((n, 256))).astype(np.float32)).to(DEV)
+    dx, dnet, net, am = h._launch_bwd(x, ga, gb, want_net=True, want_amax=True)
+    torch.cuda.synchronize()
+    got = [float(am[k].max()) for k in range(4)]
+    want = [float(x.abs().max()), float(torch.maximum(ga.abs().max(), gb.abs().max())), float(dnet.abs().max()), float(net.abs().max())]
+    assert got == want, (got, want)
+    assert all(v > 0 for v in want)
