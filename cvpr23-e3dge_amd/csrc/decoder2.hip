@@ -2465,7 +2465,7 @@ extern "C" int e3dge_dec2_backward(const E3dgeDec2Plan* P, const E3dgeDec2BwdPla
         k.d_amax = am_d(n_up - 1); k.rgb_l1 = bd_rgb(n_up - 1); k.out_meta = mt_g2(n_up - 1); k.out_amax = am_g2(n_up - 1);
         k.act_scale = P->act_scale; k.slope = P->negative_slope; k.B = B; k.C = rgb_top.ci; k.R = top_res;
         E3DGE_REQUIRE(k.C % 8 == 0, "dec2_backward: top channel count %d", k.C);
-        pk_rgbt_mask_kernel<<<dim3((unsigned)(((int64_t)top_res * top_res + 255) / 256), (unsigned)(k.C / 8), (unsigned)B), dim3(256), 0, st>>>(k);
+        pk_rgbt_mask_kernel<<<dim3((unsigned)(((int64_t)top_res * top_res + 256 * kRgbtPix - 1) / (256 * kRgbtPix)), (unsigned)(k.C / 8), (unsigned)B), dim3(256), 0, st>>>(k);
         DEC2_STEP(check_launch("dec2 bwd rgbT+mask"));
     }
     auto bwd_args = [&](const E3dgeDec2Conv& c, const E3dgeDec2BwdConv& q, int res) {

@@ -101,6 +101,7 @@ struct PkRgbtK {
     const float* d_amax; const float* rgb_l1; int* out_meta; float* out_amax;
     float act_scale, slope; int B, C, R;
 };
+constexpr int kRgbtPix = 1;     // (2 and 4 pixels per thread with all loads first measured slower: 50 vs 44 us at 1024^2)
 __global__ void __launch_bounds__(256) pk_rgbt_mask_kernel(const PkRgbtK a) {
     __shared__ float red[4];
     const int lane = threadIdx.x & 63;
@@ -108,24 +109,36 @@ __global__ void __launch_bounds__(256) pk_rgbt_mask_kernel(const PkRgbtK a) {
     const unsigned eb = scale_exponent(bound);
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) a.out_meta[0] = (int)eb;
     const float gmul = a.act_scale * pow2_bits(268u - eb);
-    const int p = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y, b = blockIdx.z, G = a.C >> 3, R = a.R;
+    // kRgbtPix pixels per thread, every load of the thread first
+    const int g = blockIdx.y, b = blockIdx.z, G = a.C >> 3, R = a.R;
+    const int64_t hw = (int64_t)R * R, plane = (int64_t)(R + 2) * (R + 2);
     float m = 0.0f;
-    if (p < R * R) {
-        const int y = p / R, x = p - y * R;
-        const int64_t hw = (int64_t)R * R, plane = (int64_t)(R + 2) * (R + 2);
-        const int64_t e = ((int64_t)(b * G + g) * 2) * plane + (int64_t)(y + 1) * (R + 2) + x + 1;
-        const u32x4 ah = reinterpret_cast<const u32x4*>(a.act)[e];
-        float d[3];
+    u32x4 ah[kRgbtPix];
+    float d[kRgbtPix][3];
+    int64_t e[kRgbtPix];
+    bool in[kRgbtPix];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) d[c] = a.d_img[((int64_t)b * 3 + c) * hw + p];
-        const float* __restrict__ w = a.wm + (size_t)b * 3 * a.C + 8 * g;          // (block-uniform: scalar loads)
+    for (int u = 0; u < kRgbtPix; ++u) {
+        const int p = ((int)blockIdx.x * kRgbtPix + u) * 256 + threadIdx.x;
+        in[u] = p < R * R;
+        const int pc = in[u] ? p : 0;
+        const int y = pc / R, x = pc - y * R;
+        e[u] = ((int64_t)(b * G + g) * 2) * plane + (int64_t)(y + 1) * (R + 2) + x + 1;
+        ah[u] = reinterpret_cast<const u32x4*>(a.act)[e[u]];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d[u][c] = a.d_img[((int64_t)b * 3 + c) * hw + pc];
+    }
+    const float* __restrict__ w = a.wm + (size_t)b * 3 * a.C + 8 * g;              // (block-uniform: scalar loads)
+#pragma unroll
+    for (int u = 0; u < kRgbtPix; ++u) {
+        if (!in[u]) continue;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float t = w[j] * d[0];
-            t = fmaf(w[a.C + j], d[1], t);
-            t = fmaf(w[2 * a.C + j], d[2], t);
-            const unsigned hb = (ah[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+            float t = w[j] * d[u][0];
+            t = fmaf(w[a.C + j], d[u][1], t);
+            t = fmaf(w[2 * a.C + j], d[u][2], t);
+            const unsigned hb = (ah[u][j >> 1] >> (16 * (j & 1))) & 0xffffu;
             t = (hb - 1u < 0x7fffu) ? t : t * a.slope;
             v[j] = t * gmul;
             m = fmaxf(m, fabsf(v[j]));
@@ -133,8 +146,8 @@ __global__ void __launch_bounds__(256) pk_rgbt_mask_kernel(const PkRgbtK a) {
         u32x4 hi, lo;
 #pragma unroll
         for (int q = 0; q < 4; ++q) SPLIT2_TO(v[2 * q], v[2 * q + 1], hi[q], lo[q]);
-        reinterpret_cast<u32x4*>(a.y)[e] = hi;
-        reinterpret_cast<u32x4*>(a.y)[e + plane] = lo;
+        reinterpret_cast<u32x4*>(a.y)[e[u]] = hi;
+        reinterpret_cast<u32x4*>(a.y)[e[u] + plane] = lo;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
@@ -179,17 +192,31 @@ __global__ void __launch_bounds__(256) pk_dblur_kernel(const PkDblurK a) {
     {
         const int64_t plane = (int64_t)(R + 2) * (R + 2);
         const u32x4* __restrict__ gp = reinterpret_cast<const u32x4*>(a.g) + ((int64_t)(b * G + g) * 2) * plane;
-        for (int idx = tid; idx < kDbRows * kDbCols; idx += 256) {
+        // all of a thread's loads first, from clamped addresses (round 6: a load per trip of a loop that also unpacks and writes LDS kept
+        // ~24 KB per CU in flight -- the kernel streamed at 3.8 TB/s where the library's element-wise kernels reach 5-7)
+        constexpr int NIT = (kDbRows * kDbCols + 255) / 256;
+        u32x4 hi[NIT], lo[NIT];
+        bool in[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it;
             const int r = idx / kDbCols, cx = idx - r * kDbCols;
             const int Y = 2 * i0 - 2 + r, X = 2 * j0 - 2 + cx;
+            in[it] = idx < kDbRows * kDbCols && Y >= 0 && Y < R && X >= 0 && X < R;
+            const int64_t e = in[it] ? (int64_t)(Y + 1) * (R + 2) + X + 1 : 0;
+            hi[it] = gp[e]; lo[it] = gp[e + plane];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + 256 * it;
+            if (idx >= kDbRows * kDbCols) break;
+            const int r = idx / kDbCols, cx = idx - r * kDbCols;
             f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-            if (Y >= 0 && Y < R && X >= 0 && X < R) {
-                const int64_t e = (int64_t)(Y + 1) * (R + 2) + X + 1;
-                const u32x4 hi = gp[e], lo = gp[e + plane];
-                v0[0] = (f16lo(hi[0]) + f16lo(lo[0])) * inv_in; v0[1] = (f16hi(hi[0]) + f16hi(lo[0])) * inv_in;
-                v0[2] = (f16lo(hi[1]) + f16lo(lo[1])) * inv_in; v0[3] = (f16hi(hi[1]) + f16hi(lo[1])) * inv_in;
-                v1[0] = (f16lo(hi[2]) + f16lo(lo[2])) * inv_in; v1[1] = (f16hi(hi[2]) + f16hi(lo[2])) * inv_in;
-                v1[2] = (f16lo(hi[3]) + f16lo(lo[3])) * inv_in; v1[3] = (f16hi(hi[3]) + f16hi(lo[3])) * inv_in;
+            if (in[it]) {
+                v0[0] = (f16lo(hi[it][0]) + f16lo(lo[it][0])) * inv_in; v0[1] = (f16hi(hi[it][0]) + f16hi(lo[it][0])) * inv_in;
+                v0[2] = (f16lo(hi[it][1]) + f16lo(lo[it][1])) * inv_in; v0[3] = (f16hi(hi[it][1]) + f16hi(lo[it][1])) * inv_in;
+                v1[0] = (f16lo(hi[it][2]) + f16lo(lo[it][2])) * inv_in; v1[1] = (f16hi(hi[it][2]) + f16hi(lo[it][2])) * inv_in;
+                v1[2] = (f16lo(hi[it][3]) + f16lo(lo[it][3])) * inv_in; v1[3] = (f16hi(hi[it][3]) + f16hi(lo[it][3])) * inv_in;
             }
             sm[r][cx & 1][0][cx >> 1] = v0;
             sm[r][cx & 1][1][cx >> 1] = v1;
