@@ -949,6 +949,26 @@ __global__ void __launch_bounds__(kThreads) composite_bwd_kernel(const Composite
             // phase 1: recompute feat / rgb of every sample, four wave-wide dot products each.  The S argument rows of a ray are fetched six
             // at a time (round 6: one load in flight per wave made this kernel a chain of S cold-HBM round trips, 48-61 us for 4,096 rays)
             const long long arow0 = (long long)b * saved_rows_per_image(a.args_blocked != 0, a.rays_per_img * S) + (ray * S - (long long)b * a.rays_per_img * S);
+            // phase 0 (round 6, late): the per-sample scalars of d weight -- d xyz . point + d depth z (+ d weights) -- lanes over samples, into
+            // slot 0 of the sample's LDS row.  They used to be loaded by lane 0 inside the sample loop below: one exposed round trip per sample.
+            for (int s = lane; s < S; s += kWave) {
+                const long long gpt = ray * S + s;
+                const float tv = a.t_vals[s];
+                const float z = nearv * (1.0f - tv) + farv * tv;
+                const float* pp = a.points + gpt * 3;
+                float ex = dxyz[0] * pp[0] + dxyz[1] * pp[1] + dxyz[2] * pp[2] + ddepth * z;
+                if (a.d_weights) ex += a.d_weights[gpt];
+                ws[s * kCbStride + 0] = ex;
+                // (what used to be phase 2 -- alpha and d(alpha)/d(sdf) -- needs only sdf and dists: its loads travel with the ones above)
+                const float sg = sigmoid_f32(-a.sdf[gpt] * inv_beta);
+                const float sigma = sg * inv_beta;
+                const float delta = a.dists[gpt];
+                const float e = __expf(-sigma * delta);
+                ws[s * kCbStride + 1] = 1.0f - e;
+                // d alpha / d sdf = delta e * (-sg (1 - sg) / beta^2); delta = 1e10 |d| on the last sample: e == 0 there
+                ws[s * kCbStride + 3] = (e == 0.0f) ? 0.0f : delta * e * (-sg * (1.0f - sg) * inv_beta * inv_beta);
+            }
+            __builtin_amdgcn_wave_barrier();
             constexpr int kCbAhead = 6;
             for (int s0 = 0; s0 < S; s0 += kCbAhead) {
                 f32x4 a4s[kCbAhead];
@@ -979,11 +999,7 @@ __global__ void __launch_bounds__(kThreads) composite_bwd_kernel(const Composite
                         for (int i = 0; i < 4; ++i) v[i] += __shfl_xor(v[i], off, kWave);
                     }
                     if (lane == 0) {
-                        const float tv = a.t_vals[s];
-                        const float z = nearv * (1.0f - tv) + farv * tv;
-                        const float* pp = a.points + gpt * 3;
-                        float dw = v[0] + dxyz[0] * pp[0] + dxyz[1] * pp[1] + dxyz[2] * pp[2] + ddepth * z;
-                        if (a.d_weights) dw += a.d_weights[gpt];
+                        float dw = v[0] + ws[s * kCbStride + 0];
 #pragma unroll
                         for (int c = 0; c < 3; ++c) {
                             const float rc = v[1 + c] + bhead[1 + c];
@@ -993,17 +1009,6 @@ __global__ void __launch_bounds__(kThreads) composite_bwd_kernel(const Composite
                         ws[s * kCbStride + 0] = dw;
                     }
                 }
-            }
-            // phase 2: alpha and d(alpha)/d(sdf), lanes over samples
-            for (int s = lane; s < S; s += kWave) {
-                const long long gpt = ray * S + s;
-                const float sg = sigmoid_f32(-a.sdf[gpt] * inv_beta);
-                const float sigma = sg * inv_beta;
-                const float delta = a.dists[gpt];
-                const float e = __expf(-sigma * delta);
-                ws[s * kCbStride + 1] = 1.0f - e;
-                // d alpha / d sdf = delta e * (-sg (1 - sg) / beta^2); delta = 1e10 |d| on the last sample: e == 0 there
-                ws[s * kCbStride + 3] = (e == 0.0f) ? 0.0f : delta * e * (-sg * (1.0f - sg) * inv_beta * inv_beta);
             }
         }
         __syncthreads();
