@@ -1086,7 +1086,18 @@ bwd_reduce_fin_kernel(float* __restrict__ dfilm, const float* __restrict__ parti
     const int l = ln >> 8, n = ln & 255;
     const float* p = partials + (int64_t)b * n_slices * (9 * 2 * kWidth) + (l * 2) * kWidth + n;
     float sa = 0.0f, sb = 0.0f;
-    for (int s = g; s < n_slices; s += kFinGroups) {
+    int s = g;
+    for (; s + 3 * kFinGroups < n_slices; s += 4 * kFinGroups) {          // four slices' loads in flight, added in the same order as one by one
+        float va[4], vb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            va[k] = p[(int64_t)(s + k * kFinGroups) * (9 * 2 * kWidth)];
+            vb[k] = p[(int64_t)(s + k * kFinGroups) * (9 * 2 * kWidth) + kWidth];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sa += va[k]; sb += vb[k]; }
+    }
+    for (; s < n_slices; s += kFinGroups) {
         sa += p[(int64_t)s * (9 * 2 * kWidth)];
         sb += p[(int64_t)s * (9 * 2 * kWidth) + kWidth];
     }
